@@ -1,0 +1,519 @@
+/* kq_chan.c -- oracle restatement of one `radio` receiver channel, block at a time
+ * (test infrastructure only; PARITY UNPINNED for everything but the NCO, see kq_oracle.h).
+ *
+ * The reference runs this as three threads (procsamp / demod / pl); the oracle runs the same
+ * arithmetic in program order for one block of L input samples:
+ *   ingest + mix          radio.c:106-147   (zero fill: radio.c:81-100)
+ *   noise estimate        radio.c:383-425
+ *   FM                    fm.c:21-174       (PL-tone side thread fm.c:189-285 not restated)
+ *   AM                    am.c:15-83
+ *   linear (SSB/IQ/ISB)   linear.c:21-322   (carrier PLL linear.c:129-246 not restated)
+ *   oscillator setters    radio.c:180-184, 290-311
+ */
+#define _GNU_SOURCE 1
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+#include <limits.h>
+#include <pthread.h>
+#include <time.h>
+#include "kq_oracle.h"
+
+#define DB2VOLTAGE(x) (powf(10., (x) / 20.))   /* dsp.h:38 */
+#define M_1_2PI (0.5 * M_1_PI)                 /* dsp.h:11 */
+
+struct kqo_chan {
+  kqo_chan_cfg cfg;
+  kqo_filter_in *master;
+  kqo_filter_out *slave;
+  kqo_osc second_lo, doppler, shift;
+  /* ingest state (radio.c:47-48) */
+  float block_energy;
+  int in_cnt;
+  long long samples;
+  float if_power;
+  /* signal status (radio.h:164-175) */
+  float bb_power, n0, snr, foffset, pdeviation, agc_gain;
+  /* FM (fm.c:26,39-70) */
+  float complex fm_state;
+  float lastaudio;
+  int snr_below_threshold;
+  kqo_filter_in *audio_master;
+  kqo_filter_out *audio_filter;
+  int blanked;
+  /* AM / linear (am.c:26-34, linear.c:33-39) */
+  int hangcount, hangmax;
+  float recovery_factor;
+  float dc_filter;
+  float samptime, dsamprate;
+  float *cap_filt;             /* test hook: pre-detection filter output captured right after the slave runs */
+};
+
+static inline float norm2f(float complex z){
+  return crealf(z) * crealf(z) + cimagf(z) * cimagf(z);
+}
+
+/* radio.c:290-301 */
+void kqo_chan_set_lo2(kqo_chan *c, double lo2_hz){
+  if(lo2_hz == 0)
+    kqo_set_osc(&c->second_lo, 0.0, 0.0);
+  else
+    kqo_set_osc(&c->second_lo, lo2_hz / c->cfg.samprate, 0.0);
+}
+/* radio.c:180-184 */
+void kqo_chan_set_doppler(kqo_chan *c, double hz, double rate){
+  double const fs = c->cfg.samprate;
+  kqo_set_osc(&c->doppler, -hz / fs, -rate / (fs * fs));
+}
+/* radio.c:304-311 */
+static void chan_set_shift(kqo_chan *c, double shift){
+  if(shift == 0)
+    kqo_set_osc(&c->shift, 0.0, 0.0);
+  else
+    kqo_set_osc(&c->shift, shift * c->cfg.D / (double)c->cfg.samprate, 0.0);
+}
+
+/* radio.c:383-425.  The reference forms n*samprate in int (radio.c:407,409), which overflows
+ * for N/2*samprate >= 2^31 (all the multi-MS/s configs); the oracle reproduces the wrapped
+ * 32-bit product that gcc emits, so passband exclusion matches the compiled reference. */
+float kqo_compute_n0(const float complex *fdomain, unsigned N, int samprate, float low, float high){
+  int const n_bins = (int)N;
+  float *power = malloc(sizeof(float) * N);
+  for(int n = 0; n < n_bins; n++)
+    power[n] = norm2f(fdomain[n]);
+  float avg = INFINITY;
+  for(int iter = 0; iter < 2; iter++){
+    int bins = 0;
+    float acc = 0;
+    for(int n = 0; n < n_bins; n++){
+      int32_t const k = (n <= n_bins / 2) ? n : n - n_bins;
+      int32_t const prod = (int32_t)((uint32_t)k * (uint32_t)samprate);   /* wraps like the int product */
+      float const f = (float)prod / n_bins;
+      if(f >= low && f <= high)
+        continue;
+      float const s = power[n];
+      if(s < avg * 2){
+        acc += s;
+        bins++;
+      }
+    }
+    avg = acc / bins;
+  }
+  free(power);
+  return avg / (2.0 * N * samprate);
+}
+
+kqo_chan *kqo_chan_create(const kqo_chan_cfg *cfg){
+  kqo_chan *c = calloc(1, sizeof(*c));
+  c->cfg = *cfg;
+  c->master = kqo_create_filter_input(cfg->L, cfg->M, KQO_COMPLEX);       /* main.c:232 */
+  if(!c->master){
+    free(c);
+    return NULL;
+  }
+  c->n0 = NAN;
+  c->snr = 0;
+  c->samptime = (float)cfg->D / (float)cfg->samprate;                      /* am.c:21, linear.c:29 */
+  c->dsamprate = (float)cfg->samprate / cfg->D;                            /* fm.c:27 */
+  /* struct osc zero-initialised => phasor not initialised => first set_osc sets it to 1 */
+  kqo_chan_set_lo2(c, cfg->lo2_hz);
+  kqo_chan_set_doppler(c, cfg->doppler_hz, cfg->doppler_rate);
+  chan_set_shift(c, cfg->shift_hz);
+
+  int out_type = KQO_COMPLEX;
+  if(cfg->demod_type == KQO_LINEAR && cfg->isb)
+    out_type = KQO_CROSS_CONJ;                                             /* linear.c:78-79 */
+  c->slave = kqo_create_filter_output(c->master, NULL, cfg->D, out_type);
+  if(!c->slave){
+    kqo_delete_filter_input(c->master);
+    free(c);
+    return NULL;
+  }
+  switch(cfg->demod_type){
+  case KQO_FM:{
+    kqo_set_filter(c->slave, cfg->low / c->dsamprate, cfg->high / c->dsamprate, cfg->kaiser_beta); /* fm.c:35 */
+    int const AL = cfg->L / cfg->D;                                        /* fm.c:39-41 */
+    int const AM = (cfg->M - 1) / cfg->D + 1;
+    int const AN = AL + AM - 1;
+    float const filter_gain = 10. / AN;                                    /* fm.c:42 */
+    c->audio_master = kqo_create_filter_input(AL, AM, KQO_REAL);
+    if(!cfg->flat){
+      float complex *ar = calloc(AN / 2 + 1, sizeof(float complex));
+      for(int j = 0; j <= AN / 2; j++){                                    /* fm.c:59-63 */
+        float const f = (float)j * c->dsamprate / AN;
+        if(f >= 300 && f <= 6000)
+          ar[j] = filter_gain * 300. / f;
+      }
+      kqo_window_rfilter(AL, AM, ar, cfg->kaiser_beta);
+      c->audio_filter = kqo_create_filter_output(c->audio_master, ar, 1, KQO_REAL);
+    }
+    c->fm_state = 1;                                                       /* fm.c:26 */
+    c->pdeviation = 0;
+    c->foffset = 0;
+    break;
+  }
+  case KQO_AM:
+    kqo_set_filter(c->slave, c->samptime * cfg->low, c->samptime * cfg->high, cfg->kaiser_beta); /* am.c:41 */
+    c->recovery_factor = DB2VOLTAGE(cfg->recovery_rate * c->samptime);     /* am.c:27 */
+    c->hangmax = cfg->hangtime / c->samptime;                              /* am.c:29 */
+    c->agc_gain = DB2VOLTAGE(80.);                                         /* am.c:30 */
+    break;
+  default:
+    kqo_set_filter(c->slave, c->samptime * cfg->low, c->samptime * cfg->high, cfg->kaiser_beta); /* linear.c:81 */
+    c->recovery_factor = DB2VOLTAGE(cfg->recovery_rate * c->samptime);     /* linear.c:34 */
+    c->hangmax = cfg->hangtime / c->samptime;                              /* linear.c:38 */
+    c->agc_gain = DB2VOLTAGE(100.0);                                       /* linear.c:39 */
+    break;
+  }
+  return c;
+}
+
+void kqo_chan_destroy(kqo_chan *c){
+  if(!c)
+    return;
+  kqo_delete_filter_output(c->audio_filter);
+  kqo_delete_filter_input(c->audio_master);
+  kqo_delete_filter_output(c->slave);
+  kqo_delete_filter_input(c->master);
+  free(c);
+}
+
+unsigned kqo_chan_olen(const kqo_chan *c){ return c->slave->olen; }
+float kqo_chan_noise_gain(const kqo_chan *c){ return c->slave->noise_gain; }
+const float complex *kqo_chan_response(const kqo_chan *c, unsigned *n){
+  if(n)
+    *n = c->slave->n_dec;
+  return c->slave->response;
+}
+const float complex *kqo_chan_audio_response(const kqo_chan *c, unsigned *n){
+  if(!c->audio_filter)
+    return NULL;
+  if(n)
+    *n = c->audio_filter->n_dec / 2 + 1;
+  return c->audio_filter->response;
+}
+
+/* --- demodulators, one block each --- */
+
+static void capture_filt(kqo_chan *c){
+  if(c->cap_filt)
+    memcpy(c->cap_filt, c->slave->output_c, sizeof(float complex) * c->slave->olen);
+}
+
+static void update_n0(kqo_chan *c, float rate){
+  if(!c->cfg.compute_n0)
+    return;
+  float const fresh = kqo_compute_n0(c->master->fdomain, c->master->n, c->cfg.samprate, c->cfg.low, c->cfg.high);
+  if(isnan(c->n0))
+    c->n0 = fresh;                                                         /* fm.c:79-80, am.c:49 */
+  else
+    c->n0 += rate * (fresh - c->n0);                                       /* fm.c:82, am.c:47 */
+}
+
+static int fm_block(kqo_chan *c, float *audio){
+  kqo_filter_out *flt = c->slave;
+  kqo_filter_in *am = c->audio_master;
+  int const olen = (int)flt->olen;
+  kqo_execute_filter_output(flt);
+  capture_filt(c);
+  update_n0(c, .01);
+
+  float const gain = (c->cfg.headroom * M_1_PI * c->dsamprate) / fabsf(c->cfg.low - c->cfg.high); /* fm.c:86 */
+
+  float avg_amp = 0;
+  c->bb_power = 0;
+  for(int n = 0; n < olen; n++){                                           /* fm.c:93-97 */
+    float const t = norm2f(flt->output_c[n]);
+    c->bb_power += t;
+    avg_amp += sqrtf(t);
+  }
+  c->bb_power /= 2 * olen;
+  avg_amp /= M_SQRT2 * olen;
+  float const variance = c->bb_power - avg_amp * avg_amp;
+  c->snr = avg_amp * avg_amp / (2 * variance) - 1;
+  c->snr = fmaxf(0.0f, c->snr);                                            /* fm.c:103 (misc.h max) */
+
+  if(c->snr > 2){                                                          /* fm.c:108-114 */
+    c->snr_below_threshold = 0;
+  } else if(++c->snr_below_threshold > 1000){
+    c->snr_below_threshold = 1000;
+  }
+  c->blanked = 0;
+  if(c->snr_below_threshold < 2){
+    float const min_ampl = 0.55 * 0.55 * avg_amp * avg_amp;                /* fm.c:121 */
+    float pdev_pos = 0, pdev_neg = 0, avg_f = 0;
+    for(int n = 0; n < olen; n++){                                         /* fm.c:128-144 */
+      float complex const samp = flt->output_c[n];
+      if(norm2f(samp) > min_ampl){
+        c->lastaudio = audio[n] = am->input_r[n] = cargf(samp * c->fm_state);
+        c->fm_state = conjf(samp);
+        if(n == 0)
+          pdev_pos = pdev_neg = c->lastaudio;
+        else if(c->lastaudio > pdev_pos)
+          pdev_pos = c->lastaudio;
+        else if(c->lastaudio < pdev_neg)
+          pdev_neg = c->lastaudio;
+      } else {
+        audio[n] = am->input_r[n] = c->lastaudio;
+        c->blanked++;
+      }
+      avg_f += c->lastaudio;
+    }
+    avg_f /= olen;
+    if(c->snr_below_threshold < 1){                                        /* fm.c:146-154 */
+      c->foffset = c->dsamprate * avg_f * M_1_2PI;
+      pdev_pos -= avg_f;
+      pdev_neg -= avg_f;
+      c->pdeviation = c->dsamprate * fmaxf(pdev_pos, -pdev_neg) * M_1_2PI;
+    }
+  } else {
+    c->fm_state = 0;                                                       /* fm.c:156-160 */
+    c->lastaudio = 0;
+    memset(audio, 0, sizeof(float) * am->ilen);
+    memset(am->input_r, 0, sizeof(float) * am->ilen);
+  }
+  kqo_execute_filter_input(am);                                            /* fm.c:162 */
+  if(c->audio_filter){
+    kqo_execute_filter_output(c->audio_filter);
+    for(int n = 0; n < (int)c->audio_filter->olen; n++)                    /* fm.c:169-170 */
+      audio[n] = c->audio_filter->output_r[n] * gain;
+  }
+  return (int)am->ilen;
+}
+
+static int am_block(kqo_chan *c, float *audio){
+  kqo_filter_out *flt = c->slave;
+  int const olen = (int)flt->olen;
+  kqo_execute_filter_output(flt);
+  capture_filt(c);
+  update_n0(c, .001);
+  float signal = 0, noise = 0;
+  float const dc_coeff = .0001;                                            /* am.c:34 */
+  for(int n = 0; n < olen; n++){                                           /* am.c:55-75 */
+    float const sq = norm2f(flt->output_c[n]);
+    signal += sq;
+    float const samp = sqrtf(sq);
+    c->dc_filter += dc_coeff * (samp - c->dc_filter);
+    if(isnan(c->agc_gain)){
+      c->agc_gain = c->cfg.headroom / c->dc_filter;
+    } else if(c->agc_gain * c->dc_filter > c->cfg.headroom){
+      c->agc_gain = c->cfg.headroom / c->dc_filter;
+      c->hangcount = c->hangmax;
+    } else if(c->hangcount != 0){
+      c->hangcount--;
+    } else {
+      c->agc_gain *= c->recovery_factor;
+    }
+    audio[n] = (samp - c->dc_filter) * c->agc_gain;
+  }
+  c->bb_power = (signal + noise) / (2 * olen);                             /* am.c:78 */
+  return olen;
+}
+
+static int linear_block(kqo_chan *c, float *audio){
+  kqo_filter_out *flt = c->slave;
+  int const olen = (int)flt->olen;
+  flt->out_type = c->cfg.isb ? KQO_CROSS_CONJ : KQO_COMPLEX;               /* linear.c:117-120 */
+  kqo_execute_filter_output(flt);
+  capture_filt(c);
+  update_n0(c, .001);
+  float signal = 0, noise = 0;
+  for(int n = 0; n < olen; n++){                                           /* linear.c:251-281 */
+    float complex const s = flt->output_c[n];
+    float const rp = crealf(s) * crealf(s);
+    float const ip = cimagf(s) * cimagf(s);
+    signal += rp;
+    noise += ip;
+    float const amplitude = sqrtf(rp + ip);
+    if(isnan(c->agc_gain)){
+      c->agc_gain = c->cfg.headroom / amplitude;
+    } else if(amplitude * c->agc_gain > c->cfg.headroom){
+      c->agc_gain = c->cfg.headroom / amplitude;
+      c->hangcount = c->hangmax;
+    } else if(c->hangcount != 0){
+      c->hangcount--;
+    } else {
+      c->agc_gain *= c->recovery_factor;
+    }
+    flt->output_c[n] *= c->agc_gain;
+  }
+  if(c->shift.freq != 0){                                                  /* linear.c:283-289 */
+    for(int n = 0; n < olen; n++)
+      flt->output_c[n] *= kqo_step_osc(&c->shift);
+  }
+  int nout;
+  if(c->cfg.channels == 1){                                                /* linear.c:291-300 */
+    for(int n = 0; n < olen; n++)
+      audio[n] = crealf(flt->output_c[n]);
+    nout = olen;
+  } else {
+    memcpy(audio, flt->output_c, sizeof(float complex) * olen);
+    nout = 2 * olen;
+  }
+  c->bb_power = (signal + noise) / (2 * olen);                             /* linear.c:302 */
+  c->snr = NAN;                                                            /* linear.c:309 (no PLL) */
+  return nout;
+}
+
+static int demod_block(kqo_chan *c, float *audio, kqo_status *st, float *filt, float *spectrum){
+  int nout;
+  if(spectrum)
+    memcpy(spectrum, c->master->fdomain, sizeof(float complex) * c->master->n);
+  c->cap_filt = filt;
+  switch(c->cfg.demod_type){
+  case KQO_FM: nout = fm_block(c, audio); break;
+  case KQO_AM: nout = am_block(c, audio); break;
+  default:     nout = linear_block(c, audio); break;
+  }
+  c->cap_filt = NULL;
+  if(st){
+    st->if_power = c->if_power;
+    st->bb_power = c->bb_power;
+    st->n0 = c->n0;
+    st->snr = c->snr;
+    st->foffset = c->foffset;
+    st->pdeviation = c->pdeviation;
+    st->agc_gain = c->agc_gain;
+    st->squelch_count = c->snr_below_threshold;
+    st->hangcount = c->hangcount;
+    st->blanked = c->blanked;
+    st->nout = nout;
+    st->samples = c->samples;
+  }
+  return nout;
+}
+
+/* One sample through radio.c:122-146; returns 1 when a block was completed */
+static inline int ingest_sample(kqo_chan *c, float complex samp){
+  c->block_energy += norm2f(samp);                                         /* radio.c:123 */
+  samp *= kqo_step_osc(&c->second_lo);                                     /* radio.c:132: double product, rounded to float */
+  if(c->doppler.freq != 0)
+    samp *= kqo_step_osc(&c->doppler);                                     /* radio.c:135-136 */
+  c->master->input_c[c->in_cnt++] = samp;
+  if(c->in_cnt == (int)c->master->ilen){
+    kqo_execute_filter_input(c->master);
+    c->block_energy *= 0.5;                                                /* halved, never cleared: radio.c:143 */
+    c->if_power = c->block_energy / c->in_cnt;
+    c->in_cnt = 0;
+    return 1;
+  }
+  return 0;
+}
+
+int kqo_chan_block(kqo_chan *c, const float *iq, float *audio, kqo_status *st, float *filt, float *spectrum){
+  unsigned const L = c->master->ilen;
+  int done = 0;
+  c->samples += L;
+  for(unsigned i = 0; i < L; i++){
+    float complex const samp = (iq[2 * i] + iq[2 * i + 1] * _Complex_I) * c->cfg.gain_factor; /* radio.c:122 */
+    done += ingest_sample(c, samp);
+  }
+  if(done)
+    demod_block(c, audio, st, filt, spectrum);
+  return 0;
+}
+
+int kqo_chan_block_i16(kqo_chan *c, const int16_t *iq, float *audio, kqo_status *st){
+  float const scale16 = 1. / SHRT_MAX;                                     /* radio.c:38 */
+  unsigned const L = c->master->ilen;
+  int done = 0;
+  c->samples += L;
+  for(unsigned i = 0; i < L; i++){
+    float const si = iq[2 * i] * scale16, sq = iq[2 * i + 1] * scale16;    /* radio.c:113-114 */
+    done += ingest_sample(c, (si + sq * _Complex_I) * c->cfg.gain_factor);
+  }
+  if(done)
+    demod_block(c, audio, st, NULL, NULL);
+  return 0;
+}
+
+int kqo_chan_block_i8(kqo_chan *c, const int8_t *iq, float *audio, kqo_status *st){
+  float const scale8 = 1. / 127;                                           /* radio.c:39 */
+  unsigned const L = c->master->ilen;
+  int done = 0;
+  c->samples += L;
+  for(unsigned i = 0; i < L; i++){
+    float const si = iq[2 * i] * scale8, sq = iq[2 * i + 1] * scale8;      /* radio.c:117-118 */
+    done += ingest_sample(c, (si + sq * _Complex_I) * c->cfg.gain_factor);
+  }
+  if(done)
+    demod_block(c, audio, st, NULL, NULL);
+  return 0;
+}
+
+int kqo_chan_zero_fill(kqo_chan *c, int count, float *audio, kqo_status *st){
+  int blocks = 0;
+  unsigned const olen_max = 2 * c->slave->olen;
+  c->samples += count;                                                     /* radio.c:87 */
+  for(int i = 0; i < count; i++){                                          /* radio.c:88-99 */
+    c->master->input_c[c->in_cnt++] = 0;
+    (void)kqo_step_osc(&c->second_lo);
+    (void)kqo_step_osc(&c->doppler);
+    if(c->in_cnt == (int)c->master->ilen){
+      kqo_execute_filter_input(c->master);
+      c->in_cnt = 0;
+      demod_block(c, audio + (size_t)blocks * olen_max, st ? st + blocks : NULL, NULL, NULL);
+      blocks++;
+    }
+  }
+  return blocks;
+}
+
+/* ---- multi-channel CPU baseline (bench.py cpu_baseline leg only) ---- */
+struct bench_arg {
+  const kqo_chan_cfg *cfgs;
+  int first, last, nblocks;
+  const float *iq;
+  double checksum;
+};
+
+static void *bench_worker(void *p){
+  struct bench_arg *a = p;
+  double sum = 0;
+  for(int ch = a->first; ch < a->last; ch++){
+    kqo_chan *c = kqo_chan_create(&a->cfgs[ch]);
+    unsigned const L = a->cfgs[ch].L;
+    float *audio = malloc(sizeof(float) * 2 * (kqo_chan_olen(c) + 1));
+    for(int b = 0; b < a->nblocks; b++){
+      kqo_status st;
+      kqo_chan_block(c, a->iq + (size_t)2 * L * b, audio, &st, NULL, NULL);
+      for(int n = 0; n < st.nout; n++)
+        sum += audio[n];
+    }
+    free(audio);
+    kqo_chan_destroy(c);
+  }
+  a->checksum = sum;
+  return NULL;
+}
+
+double kqo_bench_channels(const kqo_chan_cfg *cfgs, int nchan, const float *iq, int nblocks, int nthreads, double *checksum){
+  if(nthreads < 1)
+    nthreads = 1;
+  if(nthreads > nchan)
+    nthreads = nchan;
+  pthread_t *tid = malloc(sizeof(pthread_t) * nthreads);
+  struct bench_arg *args = calloc(nthreads, sizeof(*args));
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for(int t = 0; t < nthreads; t++){
+    args[t].cfgs = cfgs;
+    args[t].first = (int)((long long)nchan * t / nthreads);
+    args[t].last = (int)((long long)nchan * (t + 1) / nthreads);
+    args[t].nblocks = nblocks;
+    args[t].iq = iq;
+    pthread_create(&tid[t], NULL, bench_worker, &args[t]);
+  }
+  double sum = 0;
+  for(int t = 0; t < nthreads; t++){
+    pthread_join(tid[t], NULL);
+    sum += args[t].checksum;
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if(checksum)
+    *checksum = sum;
+  free(tid);
+  free(args);
+  return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+}

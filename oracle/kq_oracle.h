@@ -1,0 +1,167 @@
+/* kq_oracle.h -- CPU restatement ("oracle") of the ka9q-radio per-channel DSP hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the shipped library (libka9q_hip.so)
+ * never links or calls anything in oracle/.
+ *
+ * Every function restates, in fresh single-threaded C, the algorithm of the reference
+ * function whose file:line is cited next to it (paths relative to the reference tree).
+ * The reference's FFTs come from FFTW3 single precision (un-vendored dependency,
+ * libfftw3f >= 3.3.5, INSTALLING.md:12-24); here they are replaced by the plain
+ * power-of-two float FFT in kq_fft.c (same unnormalised forward -1 / backward +1
+ * convention as FFTW's fftwf_plan_dft_1d / r2c / c2r).
+ *
+ * PINNING STATUS
+ *   osc/dsp (NCO)   : pinned against the reference itself -- oracle/_ref/libref_osc.so is
+ *                     built from /root/reference/{osc.c,dsp.c} unmodified (oracle/Makefile).
+ *   filter/radio/fm/am/linear : PARITY UNPINNED.  Those reference files include <fftw3.h>
+ *                     (filter.h:12) which this image lacks, and the reference ships no tests,
+ *                     golden vectors or fixtures.  The restatement is
+ *                     instead cross-checked against independent float64 numpy/scipy
+ *                     formulations (direct convolution, scipy.signal.windows.kaiser, ...).
+ */
+#ifndef KQ_ORACLE_H
+#define KQ_ORACLE_H 1
+
+#include <complex.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+#error "oracle is plain C"
+#endif
+
+/* ---------- FFT (stands in for FFTW3f; kq_fft.c) ---------- */
+typedef struct kqo_fft kqo_fft;
+kqo_fft *kqo_fft_create(unsigned n);           /* n must be a power of two >= 1 */
+void kqo_fft_destroy(kqo_fft *p);
+/* out-of-place or in-place (in == out) complex transform; sign -1 forward, +1 backward */
+void kqo_fft_c2c(const kqo_fft *p, const float complex *in, float complex *out, int sign);
+/* real -> n/2+1 complex bins (forward) */
+void kqo_fft_r2c(const kqo_fft *p, const float *in, float complex *out);
+/* n/2+1 complex bins -> n reals (backward, unnormalised) */
+void kqo_fft_c2r(const kqo_fft *p, const float complex *in, float *out);
+
+/* ---------- NCO: osc.c:14-59, dsp.c:38-50 ---------- */
+typedef struct {
+  double freq;                 /* cycles/sample */
+  double rate;                 /* cycles/sample^2 */
+  double complex phasor;
+  double complex phasor_step;
+  double complex phasor_step_step;
+  int steps;                   /* since last renormalisation */
+} kqo_osc;
+#define KQO_RENORM_RATE 16384  /* osc.c:11 */
+int kqo_is_phasor_init(double complex x);
+void kqo_set_osc(kqo_osc *o, double f, double r);
+double complex kqo_step_osc(kqo_osc *o);
+void kqo_renorm_osc(kqo_osc *o);
+
+/* ---------- Fast-convolution filter: filter.c:54-546 ---------- */
+enum kqo_ftype { KQO_NONE = 0, KQO_COMPLEX = 1, KQO_CROSS_CONJ = 2, KQO_REAL = 3 }; /* filter.h:17-22 */
+
+typedef struct kqo_filter_in {
+  int in_type;
+  unsigned ilen;               /* L */
+  unsigned impulse_length;     /* M */
+  unsigned n;                  /* L+M-1 */
+  float complex *fdomain;      /* n (complex in) or n/2+1 (real in) bins */
+  float complex *inbuf_c;      /* n samples, user area at +M-1 */
+  float *inbuf_r;
+  float complex *input_c;      /* = inbuf_c + M-1 */
+  float *input_r;
+  unsigned blocknum;
+  kqo_fft *plan;
+} kqo_filter_in;
+
+typedef struct kqo_filter_out {
+  kqo_filter_in *master;
+  int out_type;
+  float complex *response;     /* n_dec (or n_dec/2+1 for real out) bins; owned */
+  float complex *f_fdomain;
+  float noise_gain;
+  float complex *outbuf_c;     /* n_dec */
+  float *outbuf_r;
+  float complex *output_c;     /* last olen of outbuf */
+  float *output_r;
+  unsigned decimate, olen, n_dec;
+  unsigned blocknum;
+  kqo_fft *plan;
+} kqo_filter_out;
+
+kqo_filter_in *kqo_create_filter_input(unsigned L, unsigned M, int in_type);
+kqo_filter_out *kqo_create_filter_output(kqo_filter_in *m, float complex *response, unsigned decimate, int out_type);
+int kqo_execute_filter_input(kqo_filter_in *m);
+int kqo_execute_filter_output(kqo_filter_out *s);
+int kqo_delete_filter_input(kqo_filter_in *m);
+int kqo_delete_filter_output(kqo_filter_out *s);
+int kqo_make_kaiser(float *window, unsigned M, float beta);
+int kqo_window_filter(int L, int M, float complex *response, float beta);
+int kqo_window_rfilter(int L, int M, float complex *response, float beta);
+int kqo_set_filter(kqo_filter_out *s, float low, float high, float beta);
+float kqo_noise_gain(const kqo_filter_out *s);
+
+/* ---------- One receiver channel: radio.c:41-150,383-425; fm.c; am.c; linear.c ---------- */
+enum kqo_demod { KQO_LINEAR = 0, KQO_AM = 1, KQO_FM = 2 };   /* radio.h:20-24 */
+
+typedef struct {
+  int samprate;        /* demod->input.samprate */
+  unsigned L, M, D;    /* demod->filter.{L,M,decimate} */
+  int demod_type;      /* enum kqo_demod */
+  int flat;            /* opt.flat (FM) */
+  int isb;             /* filter.isb (linear, CROSS_CONJ) */
+  int channels;        /* output.channels 1|2 (linear) */
+  float low, high;     /* Hz */
+  float kaiser_beta;
+  float headroom;      /* agc.headroom (amplitude ratio) */
+  float hangtime;      /* s */
+  float recovery_rate; /* dB/s */
+  float gain_factor;   /* sdr.gain_factor */
+  double lo2_hz;       /* set_second_LO argument (Hz; 0 = frozen) */
+  double doppler_hz;   /* set_doppler arguments */
+  double doppler_rate; /* Hz/s */
+  double shift_hz;     /* set_shift argument */
+  int compute_n0;      /* 0: skip the status-only noise estimate */
+} kqo_chan_cfg;
+
+typedef struct {
+  float if_power, bb_power, n0, snr, foffset, pdeviation, agc_gain;
+  int squelch_count;   /* fm.c snr_below_threshold */
+  int hangcount;       /* am.c / linear.c hangcount */
+  int blanked;         /* FM samples replaced by lastaudio this block */
+  int nout;            /* floats written to audio this block */
+  long long samples;   /* input samples consumed so far */
+} kqo_status;
+
+typedef struct kqo_chan kqo_chan;
+kqo_chan *kqo_chan_create(const kqo_chan_cfg *cfg);
+void kqo_chan_destroy(kqo_chan *c);
+/* Retune while running (phase continuous, osc.c:24-27) */
+void kqo_chan_set_lo2(kqo_chan *c, double lo2_hz);
+void kqo_chan_set_doppler(kqo_chan *c, double hz, double rate);
+/* Feed exactly L complex-float samples (re,im interleaved), run the whole chain for one block.
+ * audio: olen*channels floats.  filt (optional): olen complex pre-detection filter outputs,
+ * captured right after execute_filter_output (i.e. before linear.c:280 scales them in place).
+ * spectrum (optional): N master bins.  Returns 0. */
+int kqo_chan_block(kqo_chan *c, const float *iq, float *audio, kqo_status *st,
+                   float *filt, float *spectrum);
+/* int16 / int8 interleaved I/Q ingest (radio.c:110-122) -> same as above */
+int kqo_chan_block_i16(kqo_chan *c, const int16_t *iq, float *audio, kqo_status *st);
+int kqo_chan_block_i8(kqo_chan *c, const int8_t *iq, float *audio, kqo_status *st);
+/* Lost-sample zero fill (radio.c:81-100): inject `count` zero samples, LOs keep running. Any
+ * blocks completed meanwhile are demodulated; audio must hold ceil(count/L)+1 blocks.
+ * Returns number of blocks completed. */
+int kqo_chan_zero_fill(kqo_chan *c, int count, float *audio, kqo_status *st);
+unsigned kqo_chan_olen(const kqo_chan *c);
+float kqo_chan_noise_gain(const kqo_chan *c);
+const float complex *kqo_chan_response(const kqo_chan *c, unsigned *n);
+const float complex *kqo_chan_audio_response(const kqo_chan *c, unsigned *n);
+
+/* compute_n0 on a bare spectrum (radio.c:383-425) */
+float kqo_compute_n0(const float complex *fdomain, unsigned N, int samprate, float low, float high);
+
+/* Multi-channel CPU baseline: nchan channels over `nthreads` pthreads, each channel fed the same
+ * nblocks*L input; returns wall seconds (used only by bench.py cpu_baseline). */
+double kqo_bench_channels(const kqo_chan_cfg *cfgs, int nchan, const float *iq, int nblocks, int nthreads,
+                          double *checksum);
+
+#endif

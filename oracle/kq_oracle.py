@@ -1,0 +1,286 @@
+"""ctypes binding of the CPU oracle (oracle/libkq_oracle.so) and of oracle/_ref/libref_osc.so.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under ka9q_sdr_amd/ imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+KQO_NONE, KQO_COMPLEX, KQO_CROSS_CONJ, KQO_REAL = 0, 1, 2, 3
+KQO_LINEAR, KQO_AM, KQO_FM = 0, 1, 2
+
+
+class ChanCfg(C.Structure):
+    _fields_ = [
+        ("samprate", C.c_int), ("L", C.c_uint), ("M", C.c_uint), ("D", C.c_uint),
+        ("demod_type", C.c_int), ("flat", C.c_int), ("isb", C.c_int), ("channels", C.c_int),
+        ("low", C.c_float), ("high", C.c_float), ("kaiser_beta", C.c_float),
+        ("headroom", C.c_float), ("hangtime", C.c_float), ("recovery_rate", C.c_float),
+        ("gain_factor", C.c_float),
+        ("lo2_hz", C.c_double), ("doppler_hz", C.c_double), ("doppler_rate", C.c_double),
+        ("shift_hz", C.c_double), ("compute_n0", C.c_int),
+    ]
+
+
+class Status(C.Structure):
+    _fields_ = [
+        ("if_power", C.c_float), ("bb_power", C.c_float), ("n0", C.c_float), ("snr", C.c_float),
+        ("foffset", C.c_float), ("pdeviation", C.c_float), ("agc_gain", C.c_float),
+        ("squelch_count", C.c_int), ("hangcount", C.c_int), ("blanked", C.c_int), ("nout", C.c_int),
+        ("samples", C.c_longlong),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Osc(C.Structure):
+    """kqo_osc (oracle restatement)"""
+    _fields_ = [("freq", C.c_double), ("rate", C.c_double),
+                ("phasor", C.c_double * 2), ("phasor_step", C.c_double * 2),
+                ("phasor_step_step", C.c_double * 2), ("steps", C.c_int)]
+
+
+class RefOsc(C.Structure):
+    """struct osc of the reference (osc.h:9-17), x86-64 glibc layout: pthread_mutex_t is 40 bytes."""
+    _fields_ = [("freq", C.c_double), ("rate", C.c_double),
+                ("phasor", C.c_double * 2), ("phasor_step", C.c_double * 2),
+                ("phasor_step_step", C.c_double * 2),
+                ("mutex", C.c_byte * 40), ("steps", C.c_int)]
+
+
+class _Cplx(C.Structure):
+    _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+
+def build(force=False):
+    """Compile the oracle (and oracle/_ref when /root/reference is present)."""
+    so = os.path.join(_HERE, "libkq_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("kq_fft.c", "kq_osc.c", "kq_filter.c", "kq_chan.c", "kq_oracle.h")]
+    stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "libkq_oracle.so"], stdout=subprocess.DEVNULL)
+    ref_so = os.path.join(_HERE, "_ref", "libref_osc.so")
+    if os.path.exists("/root/reference/osc.c") and (force or not os.path.exists(ref_so)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = build()
+    L = C.CDLL(so)
+    fp = C.POINTER(C.c_float)
+    L.kqo_chan_create.restype = C.c_void_p
+    L.kqo_chan_create.argtypes = [C.POINTER(ChanCfg)]
+    L.kqo_chan_destroy.argtypes = [C.c_void_p]
+    L.kqo_chan_block.argtypes = [C.c_void_p, fp, fp, C.POINTER(Status), fp, fp]
+    L.kqo_chan_block_i16.argtypes = [C.c_void_p, C.POINTER(C.c_int16), fp, C.POINTER(Status)]
+    L.kqo_chan_block_i8.argtypes = [C.c_void_p, C.POINTER(C.c_int8), fp, C.POINTER(Status)]
+    L.kqo_chan_zero_fill.argtypes = [C.c_void_p, C.c_int, fp, C.POINTER(Status)]
+    L.kqo_chan_zero_fill.restype = C.c_int
+    L.kqo_chan_olen.argtypes = [C.c_void_p]
+    L.kqo_chan_olen.restype = C.c_uint
+    L.kqo_chan_noise_gain.argtypes = [C.c_void_p]
+    L.kqo_chan_noise_gain.restype = C.c_float
+    L.kqo_chan_response.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+    L.kqo_chan_response.restype = C.c_void_p
+    L.kqo_chan_audio_response.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+    L.kqo_chan_audio_response.restype = C.c_void_p
+    L.kqo_chan_set_lo2.argtypes = [C.c_void_p, C.c_double]
+    L.kqo_chan_set_doppler.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.kqo_compute_n0.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.c_float, C.c_float]
+    L.kqo_compute_n0.restype = C.c_float
+    L.kqo_make_kaiser.argtypes = [fp, C.c_uint, C.c_float]
+    L.kqo_window_filter.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_float]
+    L.kqo_window_rfilter.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_float]
+    L.kqo_fft_create.restype = C.c_void_p
+    L.kqo_fft_create.argtypes = [C.c_uint]
+    L.kqo_fft_destroy.argtypes = [C.c_void_p]
+    L.kqo_fft_c2c.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.kqo_fft_r2c.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kqo_fft_c2r.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kqo_set_osc.argtypes = [C.POINTER(Osc), C.c_double, C.c_double]
+    L.kqo_step_osc.argtypes = [C.POINTER(Osc)]
+    L.kqo_step_osc.restype = _Cplx
+    L.kqo_create_filter_input.restype = C.c_void_p
+    L.kqo_create_filter_input.argtypes = [C.c_uint, C.c_uint, C.c_int]
+    L.kqo_create_filter_output.restype = C.c_void_p
+    L.kqo_create_filter_output.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_int]
+    L.kqo_execute_filter_input.argtypes = [C.c_void_p]
+    L.kqo_execute_filter_output.argtypes = [C.c_void_p]
+    L.kqo_delete_filter_input.argtypes = [C.c_void_p]
+    L.kqo_delete_filter_output.argtypes = [C.c_void_p]
+    L.kqo_set_filter.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    L.kqo_bench_channels.restype = C.c_double
+    L.kqo_bench_channels.argtypes = [C.POINTER(ChanCfg), C.c_int, fp, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    _LIB = L
+    return L
+
+
+def ref_osc_lib():
+    """The reference's own osc.c+dsp.c (oracle/_ref/libref_osc.so); None if not built."""
+    global _REF
+    if _REF is not None:
+        return _REF
+    build()
+    so = os.path.join(_HERE, "_ref", "libref_osc.so")
+    if not os.path.exists(so):
+        return None
+    R = C.CDLL(so)
+    R.set_osc.argtypes = [C.POINTER(RefOsc), C.c_double, C.c_double]
+    R.step_osc.argtypes = [C.POINTER(RefOsc)]
+    R.step_osc.restype = _Cplx
+    R.renorm_osc.argtypes = [C.POINTER(RefOsc)]
+    R.is_phasor_init.argtypes = [_Cplx]
+    R.is_phasor_init.restype = C.c_int
+    _REF = R
+    return R
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def make_cfg(**kw):
+    """ChanCfg with the reference's defaults (main.c:113-117, modes.txt:25-38)."""
+    d = dict(samprate=192000, L=8192, M=8193, D=4, demod_type=KQO_FM, flat=0, isb=0, channels=1,
+             low=-8000.0, high=8000.0, kaiser_beta=3.0, headroom=10 ** (-15 / 20), hangtime=0.0,
+             recovery_rate=0.0, gain_factor=1.0, lo2_hz=0.0, doppler_hz=0.0, doppler_rate=0.0,
+             shift_hz=0.0, compute_n0=1)
+    d.update(kw)
+    c = ChanCfg()
+    for k, v in d.items():
+        setattr(c, k, v)
+    return c
+
+
+class Channel:
+    """One oracle receiver channel (kqo_chan)."""
+
+    def __init__(self, cfg):
+        self.L = lib()
+        self.cfg = cfg
+        self.h = self.L.kqo_chan_create(C.byref(cfg))
+        if not self.h:
+            raise ValueError("oracle: unsupported geometry (FFT sizes must be powers of two)")
+        self.olen = self.L.kqo_chan_olen(self.h)
+        self.N = cfg.L + cfg.M - 1
+
+    def close(self):
+        if self.h:
+            self.L.kqo_chan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def block(self, iq, want_filt=False, want_spectrum=False):
+        """iq: complex64[L] -> (audio float32[nout], status dict, filt complex64[olen]|None, spectrum|None)"""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        assert iq.shape == (self.cfg.L,)
+        audio = np.zeros(2 * self.olen, np.float32)
+        filt = np.zeros(self.olen, np.complex64) if want_filt else None
+        spec = np.zeros(self.N, np.complex64) if want_spectrum else None
+        st = Status()
+        self.L.kqo_chan_block(self.h, _fp(iq.view(np.float32)), _fp(audio), C.byref(st),
+                              _fp(filt.view(np.float32)) if want_filt else None,
+                              _fp(spec.view(np.float32)) if want_spectrum else None)
+        return audio[:st.nout].copy(), st.as_dict(), filt, spec
+
+    def block_i16(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.int16)
+        audio = np.zeros(2 * self.olen, np.float32)
+        st = Status()
+        self.L.kqo_chan_block_i16(self.h, iq.ctypes.data_as(C.POINTER(C.c_int16)), _fp(audio), C.byref(st))
+        return audio[:st.nout].copy(), st.as_dict()
+
+    def block_i8(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.int8)
+        audio = np.zeros(2 * self.olen, np.float32)
+        st = Status()
+        self.L.kqo_chan_block_i8(self.h, iq.ctypes.data_as(C.POINTER(C.c_int8)), _fp(audio), C.byref(st))
+        return audio[:st.nout].copy(), st.as_dict()
+
+    def zero_fill(self, count):
+        nb = count // self.cfg.L + 2
+        audio = np.zeros(nb * 2 * self.olen, np.float32)
+        sts = (Status * nb)()
+        done = self.L.kqo_chan_zero_fill(self.h, count, _fp(audio), sts)
+        out = []
+        for b in range(done):
+            out.append((audio[b * 2 * self.olen: b * 2 * self.olen + sts[b].nout].copy(), sts[b].as_dict()))
+        return out
+
+    def set_lo2(self, hz):
+        self.L.kqo_chan_set_lo2(self.h, hz)
+
+    def set_doppler(self, hz, rate):
+        self.L.kqo_chan_set_doppler(self.h, hz, rate)
+
+    def response(self):
+        n = C.c_uint()
+        p = self.L.kqo_chan_response(self.h, C.byref(n))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), (2 * n.value,)).view(np.complex64).copy()
+
+    def audio_response(self):
+        n = C.c_uint()
+        p = self.L.kqo_chan_audio_response(self.h, C.byref(n))
+        if not p:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), (2 * n.value,)).view(np.complex64).copy()
+
+    def noise_gain(self):
+        return self.L.kqo_chan_noise_gain(self.h)
+
+
+def run_chain(cfg, iq_blocks, want_filt=False):
+    """Run nblocks through one channel; returns (audio list, status list, filt list)."""
+    ch = Channel(cfg)
+    auds, sts, filts = [], [], []
+    for blk in iq_blocks:
+        a, s, f, _ = ch.block(blk, want_filt=want_filt)
+        auds.append(a)
+        sts.append(s)
+        filts.append(f)
+    ch.close()
+    return auds, sts, filts
+
+
+def fft_c2c(x, sign=-1):
+    L = lib()
+    x = np.ascontiguousarray(x, np.complex64)
+    p = L.kqo_fft_create(len(x))
+    out = np.zeros_like(x)
+    L.kqo_fft_c2c(p, x.ctypes.data, out.ctypes.data, sign)
+    L.kqo_fft_destroy(p)
+    return out
+
+
+def make_kaiser(M, beta):
+    w = np.zeros(M, np.float32)
+    lib().kqo_make_kaiser(_fp(w), M, beta)
+    return w
+
+
+def compute_n0(spec, samprate, low, high):
+    spec = np.ascontiguousarray(spec, np.complex64)
+    return lib().kqo_compute_n0(spec.ctypes.data, len(spec), samprate, low, high)
+
+
+def cpu_baseline(cfgs, iq, nblocks, nthreads):
+    """Times nchan oracle channels over nthreads host threads; returns (seconds, checksum)."""
+    arr = (ChanCfg * len(cfgs))(*cfgs)
+    iq = np.ascontiguousarray(iq, np.complex64)
+    cs = C.c_double()
+    t = lib().kqo_bench_channels(arr, len(cfgs), _fp(iq.view(np.float32)), nblocks, nthreads, C.byref(cs))
+    return t, cs.value

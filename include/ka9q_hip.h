@@ -1,0 +1,175 @@
+/* ka9q_hip.h -- C ABI of libka9q_hip.so: the MI355X (gfx950) implementation of ka9q-radio's
+ * per-channel DSP hot path (NCO mix -> overlap-save filter/decimator -> FM / AM / linear demod).
+ *
+ * Plain C: pointers, sizes, ints and doubles only.  No HIP or torch types appear here; device
+ * pointers and streams cross the boundary as void*.
+ *
+ * Two surfaces:
+ *   1. kq_bank_*   -- the batched "channel bank": many receiver channels share one front-end I/Q
+ *                     stream.  This is what a multi-channel `radio` binds.  Each
+ *                     entry point cites the reference interface it replaces (paths relative to
+ *                     the reference tree).
+ *   2. compat      -- the reference's own filter.h / osc.h symbol names, one channel per object,
+ *                     in ka9q_hip_compat.h.
+ *
+ * Error convention follows the reference (filter.c:148-149, 504-505): int functions return 0 on
+ * success and -1 on a NULL / NaN / out-of-range argument; constructors return NULL on failure.
+ * kq_last_error() adds a human-readable reason (the reference has none).
+ */
+#ifndef KA9Q_HIP_H
+#define KA9Q_HIP_H 1
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum demod_type of radio.h:20-24 */
+enum kq_demod_type { KQ_LINEAR_DEMOD = 0, KQ_AM_DEMOD = 1, KQ_FM_DEMOD = 2 };
+
+/* I/Q sample formats accepted by kq_bank_push_iq:
+ *   KQ_IQ_CF32 : complex float (re,im)           -- the synthetic configs of BASELINE.json
+ *   KQ_IQ_S16  : int16 little-endian I,Q  (RTP payload type IQ_PT  = 97, multicast.h:19; radio.c:113-114)
+ *   KQ_IQ_S8   : int8 I,Q                 (RTP payload type IQ_PT8 = 98, multicast.h:20; radio.c:117-118) */
+enum kq_iq_format { KQ_IQ_CF32 = 0, KQ_IQ_S16 = 1, KQ_IQ_S8 = 2 };
+
+/* Forward-transform strategy of the pre-detection filter */
+enum kq_fwd_mode {
+  KQ_FWD_AUTO = 0,    /* pruned when the geometry allows and n0 is off, else full */
+  KQ_FWD_FULL = 1,    /* N-point FFT per channel in LDS, all N bins (needed by compute_n0) */
+  KQ_FWD_PRUNED = 2   /* only the N/D bins execute_filter_output reads (filter.c:206-227) */
+};
+
+typedef struct kq_bank kq_bank;   /* opaque */
+
+/* Bank geometry: replaces the arguments of create_filter_input(L, M, COMPLEX) (filter.c:54,
+ * called from main.c:232) plus demod->filter.decimate and demod->input.samprate
+ * (radio_status.c:264-267), which the reference keeps per process. */
+typedef struct kq_bank_config {
+  int device;              /* HIP device ordinal */
+  int samprate;            /* front-end complex sample rate, Hz */
+  unsigned L;              /* new samples per block            (demod->filter.L) */
+  unsigned M;              /* impulse response length          (demod->filter.M); N = L+M-1 power of two */
+  unsigned decimate;       /* D: output rate = samprate / D    (demod->filter.decimate), >= 2 */
+  unsigned max_channels;
+  unsigned max_blocks;     /* largest number of blocks one kq_bank_process call may take */
+  float gain_factor;       /* demod->sdr.gain_factor (radio.c:122); 1.0 for synthetic float input */
+  int compute_n0;          /* run the status-only compute_n0 (radio.c:383-425) every block */
+  int fwd_mode;            /* enum kq_fwd_mode */
+  void *stream;            /* hipStream_t to launch on, or NULL for the bank's own stream */
+} kq_bank_config;
+
+/* One receiver channel: the fields of struct demod / struct modetab that the path reads
+ * (radio.h:64-193, radio.h:35-50; defaults in modes.txt:25-39, main.c:113-117). */
+typedef struct kq_channel_config {
+  int demod_type;          /* enum kq_demod_type */
+  int flat;                /* opt.flat : FM without de-emphasis filter and gain (fm.c:55, 164-172) */
+  int isb;                 /* filter.isb : CROSS_CONJ slave (linear.c:78-79, filter.c:239-249) */
+  int channels;            /* output.channels : 1 mono, 2 stereo (linear.c:291-300) */
+  float low, high;         /* filter.low / filter.high, Hz */
+  float kaiser_beta;       /* filter.kaiser_beta */
+  float headroom;          /* agc.headroom, amplitude ratio (main.c:117: 10^(-15/20)) */
+  float hangtime;          /* agc.hangtime, s */
+  float recovery_rate;     /* agc.recovery_rate, dB/s */
+  double second_lo;        /* set_second_LO() argument, Hz (radio.c:290-301); 0 freezes the NCO */
+  double doppler;          /* set_doppler() arguments, Hz and Hz/s (radio.c:180-184) */
+  double doppler_rate;
+  double shift;            /* set_shift() argument, Hz (radio.c:304-311) */
+} kq_channel_config;
+
+/* Per channel, per block signal status: the demod->sig.* / agc.gain values the path produces
+ * (radio.h:164-175), plus the integer decision state that must match the reference exactly. */
+typedef struct kq_chan_status {
+  float if_power;          /* radio.c:143-145 (halving accumulator, shared by all channels) */
+  float bb_power;          /* fm.c:99, am.c:78, linear.c:302 */
+  float n0;                /* smoothed noise density (fm.c:78-82, am.c:46-49); NaN when compute_n0 = 0 */
+  float snr;               /* fm.c:102-103; NaN for linear without PLL (linear.c:309); 0 for AM */
+  float foffset;           /* fm.c:148 */
+  float pdeviation;        /* fm.c:153 */
+  float agc_gain;          /* am.c / linear.c agc.gain after the block */
+  float noise_gain;        /* filter.out->noise_gain (filter.c:472-497) */
+  int32_t squelch_count;   /* fm.c:70 snr_below_threshold after the block */
+  int32_t hangcount;       /* am.c:26 / linear.c:33 hangcount after the block */
+  int32_t blanked;         /* FM samples held at lastaudio this block (fm.c:141) */
+  int32_t nout;            /* floats of audio this block: olen (mono) or 2*olen (stereo) */
+} kq_chan_status;
+
+/* Per-kernel device time accumulated since the last reset (HIP events on the bank's stream) */
+typedef struct kq_timing {
+  double filter_ms;        /* pre-detection filter kernel (mix + forward FFT + response + IFFT) */
+  double demod_ms;         /* FM + AM + linear demodulator kernels */
+  double ingest_ms;        /* format conversion + IF power */
+  uint64_t filter_launches;
+  uint64_t channel_blocks; /* channel-blocks processed by the filter kernel */
+} kq_timing;
+
+const char *kq_last_error(void);
+const char *kq_version(void);
+/* Number of visible HIP devices, or -1 when the HIP runtime cannot be initialised */
+int kq_device_count(void);
+
+/* --- lifetime --- */
+kq_bank *kq_bank_create(const kq_bank_config *cfg);               /* main.c:232 create_filter_input */
+int kq_bank_destroy(kq_bank *bank);                               /* filter.c:254 delete_filter_input */
+
+/* --- channels: what set_mode() + the demod thread prologue do (radio.c:322-374; fm.c:27-67,
+ *     am.c:21-41, linear.c:29-81): creates the slave, designs its response, arms the demodulator.
+ *     Returns the channel index (>= 0) or -1. --- */
+int kq_bank_add_channel(kq_bank *bank, const kq_channel_config *cfg);
+unsigned kq_bank_num_channels(const kq_bank *bank);
+
+/* --- tuning, all phase continuous and effective from the next block (osc.c:22-36) --- */
+int kq_bank_set_second_lo(kq_bank *bank, int ch, double hz);                 /* radio.c:290 set_second_LO */
+int kq_bank_set_doppler(kq_bank *bank, int ch, double hz, double hz_per_s);  /* radio.c:180 set_doppler */
+int kq_bank_set_shift(kq_bank *bank, int ch, double hz);                     /* radio.c:304 set_shift */
+int kq_bank_set_filter(kq_bank *bank, int ch, float low_hz, float high_hz, float kaiser_beta); /* filter.c:500 set_filter */
+
+/* --- data path --- */
+/* Append nsamples complex samples of the given format to the bank's input ring.  `iq` is a host
+ * pointer, or a device pointer when is_device != 0.  Conversion/scaling as radio.c:110-122. */
+int kq_bank_push_iq(kq_bank *bank, const void *iq, size_t nsamples, int format, int is_device);
+/* Lost-sample zero fill (radio.c:81-100): append `nsamples` zeros; LOs keep running. */
+int kq_bank_push_zeros(kq_bank *bank, size_t nsamples);
+/* Number of complete blocks waiting in the ring */
+unsigned kq_bank_blocks_ready(const kq_bank *bank);
+/* Run mix + filter + demod for up to max_blocks waiting blocks on every channel
+ * (radio.c:140-146 execute_filter_input, then each demod thread's loop body).
+ * Asynchronous on the bank's stream.  Returns the number of blocks processed, or -1. */
+int kq_bank_process(kq_bank *bank);
+/* Convenience for resident-input benchmarks: process `nblocks` blocks reading the window
+ * [M-1 history | nblocks*L] straight from `iq_dev` (device, complex float), no ring copy. */
+int kq_bank_process_resident(kq_bank *bank, const void *iq_dev, unsigned nblocks);
+int kq_bank_sync(kq_bank *bank);
+
+/* --- results of the last kq_bank_process call (replace send_mono_output/send_stereo_output,
+ *     audio.c:82 / audio.c:32, and the sig.* fields read by radio_status.c:170-203) --- */
+unsigned kq_bank_olen(const kq_bank *bank);                       /* filter.c:116 */
+unsigned kq_bank_last_blocks(const kq_bank *bank);
+/* Audio of channel ch for block blk of the last call: status.nout floats. Synchronises. */
+int kq_bank_pull_audio(kq_bank *bank, int ch, unsigned blk, float *dst, size_t cap, size_t *n);
+int kq_bank_pull_status(kq_bank *bank, int ch, unsigned blk, kq_chan_status *st);
+/* Pre-detection filter output (filter.out->output.c, olen complex) before demodulation */
+int kq_bank_pull_filter_output(kq_bank *bank, int ch, unsigned blk, float *dst_re_im, size_t cap_complex);
+/* Master spectrum fdomain[N] of one channel/block (only in KQ_FWD_FULL mode; radio.c:396) */
+int kq_bank_pull_spectrum(kq_bank *bank, int ch, unsigned blk, float *dst_re_im, size_t cap_complex);
+/* Designed responses (filter.out->response, N/D complex; FM audio response N/D/2+1) */
+int kq_bank_get_response(kq_bank *bank, int ch, float *dst_re_im, size_t cap_complex);
+int kq_bank_get_audio_response(kq_bank *bank, int ch, float *dst_re_im, size_t cap_complex);
+/* Device-resident result planes for zero-copy consumers:
+ *   audio  : float [max_channels][max_blocks][2*olen]
+ *   status : kq_chan_status [max_channels][max_blocks] */
+void *kq_bank_audio_device_ptr(kq_bank *bank);
+void *kq_bank_status_device_ptr(kq_bank *bank);
+
+/* --- measurement --- */
+int kq_bank_enable_timing(kq_bank *bank, int on);
+int kq_bank_get_timing(kq_bank *bank, kq_timing *t, int reset);
+/* Which forward path the bank resolved to (enum kq_fwd_mode, never AUTO) */
+int kq_bank_fwd_mode(const kq_bank *bank);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

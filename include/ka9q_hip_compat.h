@@ -1,0 +1,113 @@
+/* ka9q_hip_compat.h -- the reference's own one-channel API, served by libka9q_hip.so.
+ *
+ * Same function names, argument meaning, struct field names and error behaviour as the
+ * reference's filter.h / osc.h / dsp.h, so that radio.c, fm.c, am.c, linear.c, packet.c and
+ * modulate.c compile against this header in place of theirs.  What changes
+ * underneath: every FFT runs on the GPU (execute_filter_input = H2D + N-point forward transform +
+ * D2H of fdomain; execute_filter_output = response multiply + N/D-point inverse on the resident
+ * spectrum + D2H of the output block).  FFTW is not used anywhere.
+ *
+ * Differences a maintainer must know:
+ *   - `fwd_plan` / `rev_plan` are opaque device contexts (void *), not fftwf_plan.
+ *   - response arrays handed to create_filter_output() must come from malloc()/calloc()
+ *     (the reference frees them with fftwf_free, filter.c:271; here it is free()).
+ *   - N = L+M-1 and N/decimate must be powers of two, N <= 16384.
+ *   - This surface moves one block over PCIe per call; it exists for drop-in correctness.  The
+ *     throughput path is the channel bank in ka9q_hip.h.
+ */
+#ifndef KA9Q_HIP_COMPAT_H
+#define KA9Q_HIP_COMPAT_H 1
+
+#include <pthread.h>
+
+#ifdef __cplusplus
+typedef float _Complex kq_cfloat;
+typedef double _Complex kq_cdouble;
+extern "C" {
+#else
+#include <complex.h>
+typedef float _Complex kq_cfloat;
+typedef double _Complex kq_cdouble;
+#endif
+
+/* filter.h:17-22 */
+enum filtertype { NONE, COMPLEX, CROSS_CONJ, REAL };
+
+/* filter.h:25-28 */
+union rc {
+  float *r;
+  kq_cfloat *c;
+};
+
+/* Master half -- field names of filter.h:54-66 */
+struct filter_in {
+  enum filtertype in_type;
+  unsigned int ilen;            /* L */
+  unsigned int impulse_length;  /* M */
+  kq_cfloat *fdomain;           /* N bins (complex in) or N/2+1 (real in), host copy refreshed every block */
+  union rc input_buffer;        /* N samples */
+  union rc input;               /* user area: input_buffer + M-1 */
+  void *fwd_plan;               /* opaque device context */
+  unsigned int blocknum;
+  pthread_mutex_t filter_mutex;
+  pthread_cond_t filter_cond;
+};
+
+/* Slave half -- field names of filter.h:67-80 */
+struct filter_out {
+  struct filter_in *master;
+  enum filtertype out_type;
+  kq_cfloat *response;
+  pthread_mutex_t response_mutex;
+  kq_cfloat *f_fdomain;         /* kept for source compatibility; not filled (the product stays on the device) */
+  float noise_gain;
+  union rc output_buffer;       /* N/decimate samples */
+  union rc output;              /* last olen of output_buffer */
+  void *rev_plan;               /* opaque device context */
+  unsigned int decimate;
+  unsigned int olen;
+  unsigned int blocknum;
+};
+
+/* filter.h:81-92 */
+int window_filter(int L, int M, kq_cfloat *response, float beta);
+int window_rfilter(int L, int M, kq_cfloat *response, float beta);
+struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filtertype in_type);
+struct filter_out *create_filter_output(struct filter_in *master, kq_cfloat *response, unsigned int decimate,
+                                        enum filtertype out_type);
+int execute_filter_input(struct filter_in *);
+int execute_filter_output(struct filter_out *);
+int delete_filter_input(struct filter_in *);
+int delete_filter_output(struct filter_out *);
+int make_kaiser(float *window, unsigned int M, float beta);
+int set_filter(struct filter_out *, float low, float high, float kaiser_beta);
+float noise_gain(struct filter_out const *);
+extern float Kaiser_beta;       /* filter.c:279 */
+
+/* osc.h:9-24 */
+struct osc {
+  double freq;
+  double rate;
+  kq_cdouble phasor;
+  kq_cdouble phasor_step;
+  kq_cdouble phasor_step_step;
+  pthread_mutex_t mutex;
+  int steps;
+};
+void set_osc(struct osc *osc, double f, double r);
+kq_cdouble step_osc(struct osc *osc);
+void renorm_osc(struct osc *osc);
+int is_phasor_init(kq_cdouble x);
+
+/* dsp.h:20-31 */
+kq_cfloat csincosf(float x);
+kq_cfloat csincospif(float x);
+kq_cdouble csincos(double x);
+kq_cdouble csincospi(double x);
+float cnrmf(kq_cfloat x);
+double cnrm(kq_cdouble x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,284 @@
+"""ctypes mirror of include/ka9q_hip.h (the channel-bank C ABI of libka9q_hip.so).
+
+Names follow the reference's vocabulary: a *bank* holds the shared master half of the
+overlap-save filter (create_filter_input, filter.c:54) and one slave + demodulator per
+*channel* (what one `radio` process is in the reference, main.c:105).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBPATH = os.path.join(_HERE, "lib", "libka9q_hip.so")
+_lib = None
+
+KQ_LINEAR_DEMOD, KQ_AM_DEMOD, KQ_FM_DEMOD = 0, 1, 2
+KQ_IQ_CF32, KQ_IQ_S16, KQ_IQ_S8 = 0, 1, 2
+KQ_FWD_AUTO, KQ_FWD_FULL, KQ_FWD_PRUNED = 0, 1, 2
+
+
+class KqError(RuntimeError):
+    pass
+
+
+class BankConfig(C.Structure):
+    _fields_ = [
+        ("device", C.c_int), ("samprate", C.c_int), ("L", C.c_uint), ("M", C.c_uint),
+        ("decimate", C.c_uint), ("max_channels", C.c_uint), ("max_blocks", C.c_uint),
+        ("gain_factor", C.c_float), ("compute_n0", C.c_int), ("fwd_mode", C.c_int),
+        ("stream", C.c_void_p),
+    ]
+
+
+class ChannelConfig(C.Structure):
+    _fields_ = [
+        ("demod_type", C.c_int), ("flat", C.c_int), ("isb", C.c_int), ("channels", C.c_int),
+        ("low", C.c_float), ("high", C.c_float), ("kaiser_beta", C.c_float), ("headroom", C.c_float),
+        ("hangtime", C.c_float), ("recovery_rate", C.c_float),
+        ("second_lo", C.c_double), ("doppler", C.c_double), ("doppler_rate", C.c_double),
+        ("shift", C.c_double),
+    ]
+
+
+class ChanStatus(C.Structure):
+    _fields_ = [
+        ("if_power", C.c_float), ("bb_power", C.c_float), ("n0", C.c_float), ("snr", C.c_float),
+        ("foffset", C.c_float), ("pdeviation", C.c_float), ("agc_gain", C.c_float),
+        ("noise_gain", C.c_float),
+        ("squelch_count", C.c_int32), ("hangcount", C.c_int32), ("blanked", C.c_int32), ("nout", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Timing(C.Structure):
+    _fields_ = [("filter_ms", C.c_double), ("demod_ms", C.c_double), ("ingest_ms", C.c_double),
+                ("filter_launches", C.c_uint64), ("channel_blocks", C.c_uint64)]
+
+
+STATUS_DTYPE = np.dtype([
+    ("if_power", "f4"), ("bb_power", "f4"), ("n0", "f4"), ("snr", "f4"), ("foffset", "f4"),
+    ("pdeviation", "f4"), ("agc_gain", "f4"), ("noise_gain", "f4"),
+    ("squelch_count", "i4"), ("hangcount", "i4"), ("blanked", "i4"), ("nout", "i4")])
+
+
+def library_path():
+    return _LIBPATH
+
+
+def build_library(force=False):
+    """Compile every HIP source for gfx950 into ka9q_sdr_amd/lib/libka9q_hip.so (in-tree)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src_dir, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", src_dir], stdout=subprocess.DEVNULL)
+    if not os.path.exists(_LIBPATH):
+        raise KqError("build did not produce " + _LIBPATH)
+    return _LIBPATH
+
+
+def load_library():
+    """dlopen libka9q_hip.so.  Raises KqError when it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIBPATH):
+        raise KqError("libka9q_hip.so is missing (%s): run __graft_entry__.build() or "
+                      "`make -C ka9q_sdr_amd/csrc`; the HIP library is the only compute path" % _LIBPATH)
+    L = C.CDLL(_LIBPATH)
+    L.kq_last_error.restype = C.c_char_p
+    L.kq_version.restype = C.c_char_p
+    L.kq_device_count.restype = C.c_int
+    L.kq_bank_create.restype = C.c_void_p
+    L.kq_bank_create.argtypes = [C.POINTER(BankConfig)]
+    L.kq_bank_destroy.argtypes = [C.c_void_p]
+    L.kq_bank_add_channel.argtypes = [C.c_void_p, C.POINTER(ChannelConfig)]
+    L.kq_bank_num_channels.argtypes = [C.c_void_p]
+    L.kq_bank_num_channels.restype = C.c_uint
+    L.kq_bank_set_second_lo.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.kq_bank_set_doppler.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+    L.kq_bank_set_shift.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.kq_bank_set_filter.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float]
+    L.kq_bank_push_iq.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+    L.kq_bank_push_zeros.argtypes = [C.c_void_p, C.c_size_t]
+    L.kq_bank_blocks_ready.argtypes = [C.c_void_p]
+    L.kq_bank_blocks_ready.restype = C.c_uint
+    L.kq_bank_process.argtypes = [C.c_void_p]
+    L.kq_bank_process_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    L.kq_bank_sync.argtypes = [C.c_void_p]
+    L.kq_bank_olen.argtypes = [C.c_void_p]
+    L.kq_bank_olen.restype = C.c_uint
+    L.kq_bank_last_blocks.argtypes = [C.c_void_p]
+    L.kq_bank_last_blocks.restype = C.c_uint
+    L.kq_bank_pull_audio.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.kq_bank_pull_status.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.POINTER(ChanStatus)]
+    L.kq_bank_pull_filter_output.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_void_p, C.c_size_t]
+    L.kq_bank_pull_spectrum.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_void_p, C.c_size_t]
+    L.kq_bank_get_response.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.kq_bank_get_audio_response.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.kq_bank_audio_device_ptr.argtypes = [C.c_void_p]
+    L.kq_bank_audio_device_ptr.restype = C.c_void_p
+    L.kq_bank_status_device_ptr.argtypes = [C.c_void_p]
+    L.kq_bank_status_device_ptr.restype = C.c_void_p
+    L.kq_bank_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    L.kq_bank_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing), C.c_int]
+    L.kq_bank_fwd_mode.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def device_count():
+    return load_library().kq_device_count()
+
+
+def _err(L):
+    return (L.kq_last_error() or b"").decode()
+
+
+def channel_config(demod_type=KQ_FM_DEMOD, low=-8000.0, high=8000.0, second_lo=0.0, flat=0, isb=0, channels=1,
+                   kaiser_beta=3.0, headroom=10 ** (-15 / 20), hangtime=0.0, recovery_rate=0.0,
+                   doppler=0.0, doppler_rate=0.0, shift=0.0):
+    """Defaults: main.c:113-117 (beta 3.0, headroom -15 dB); filter edges as modes.txt:25."""
+    c = ChannelConfig()
+    c.demod_type, c.flat, c.isb, c.channels = demod_type, flat, isb, channels
+    c.low, c.high, c.kaiser_beta, c.headroom = low, high, kaiser_beta, headroom
+    c.hangtime, c.recovery_rate = hangtime, recovery_rate
+    c.second_lo, c.doppler, c.doppler_rate, c.shift = second_lo, doppler, doppler_rate, shift
+    return c
+
+
+class Bank:
+    """A bank of receiver channels sharing one front-end I/Q stream on one GPU."""
+
+    def __init__(self, samprate, L, M, decimate, max_channels, max_blocks, device=0, gain_factor=1.0,
+                 compute_n0=False, fwd_mode=KQ_FWD_AUTO, stream=None):
+        self.lib = load_library()
+        cfg = BankConfig(device, samprate, L, M, decimate, max_channels, max_blocks, gain_factor,
+                         int(compute_n0), fwd_mode, stream)
+        self.h = self.lib.kq_bank_create(C.byref(cfg))
+        if not self.h:
+            raise KqError("kq_bank_create: " + _err(self.lib))
+        self.samprate, self.L, self.M, self.D = samprate, L, M, decimate
+        self.N = L + M - 1
+        self.Ndec = self.N // decimate
+        self.olen = self.lib.kq_bank_olen(self.h)
+        self.max_blocks = max_blocks
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.kq_bank_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise KqError("%s: %s" % (what, _err(self.lib)))
+        return rc
+
+    def add_channel(self, cfg):
+        return self._chk(self.lib.kq_bank_add_channel(self.h, C.byref(cfg)), "kq_bank_add_channel")
+
+    @property
+    def num_channels(self):
+        return self.lib.kq_bank_num_channels(self.h)
+
+    @property
+    def fwd_mode(self):
+        return self.lib.kq_bank_fwd_mode(self.h)
+
+    def set_second_lo(self, ch, hz):
+        self._chk(self.lib.kq_bank_set_second_lo(self.h, ch, hz), "kq_bank_set_second_lo")
+
+    def set_doppler(self, ch, hz, rate):
+        self._chk(self.lib.kq_bank_set_doppler(self.h, ch, hz, rate), "kq_bank_set_doppler")
+
+    def set_shift(self, ch, hz):
+        self._chk(self.lib.kq_bank_set_shift(self.h, ch, hz), "kq_bank_set_shift")
+
+    def set_filter(self, ch, low, high, beta):
+        self._chk(self.lib.kq_bank_set_filter(self.h, ch, low, high, beta), "kq_bank_set_filter")
+
+    def push_iq(self, iq):
+        """iq: host numpy array -- complex64, or int16 / int8 of shape (n, 2)."""
+        iq = np.ascontiguousarray(iq)
+        if iq.dtype == np.complex64:
+            fmt, n = KQ_IQ_CF32, iq.size
+        elif iq.dtype == np.int16:
+            fmt, n = KQ_IQ_S16, iq.size // 2
+        elif iq.dtype == np.int8:
+            fmt, n = KQ_IQ_S8, iq.size // 2
+        else:
+            raise TypeError("unsupported I/Q dtype %s" % iq.dtype)
+        self._chk(self.lib.kq_bank_push_iq(self.h, iq.ctypes.data, n, fmt, 0), "kq_bank_push_iq")
+
+    def push_iq_device(self, ptr, nsamples, fmt=KQ_IQ_CF32):
+        self._chk(self.lib.kq_bank_push_iq(self.h, ptr, nsamples, fmt, 1), "kq_bank_push_iq")
+
+    def push_zeros(self, n):
+        self._chk(self.lib.kq_bank_push_zeros(self.h, n), "kq_bank_push_zeros")
+
+    def blocks_ready(self):
+        return self.lib.kq_bank_blocks_ready(self.h)
+
+    def process(self):
+        return self._chk(self.lib.kq_bank_process(self.h), "kq_bank_process")
+
+    def process_resident(self, dev_ptr, nblocks):
+        return self._chk(self.lib.kq_bank_process_resident(self.h, dev_ptr, nblocks), "kq_bank_process_resident")
+
+    def sync(self):
+        self._chk(self.lib.kq_bank_sync(self.h), "kq_bank_sync")
+
+    def status(self, ch, blk):
+        st = ChanStatus()
+        self._chk(self.lib.kq_bank_pull_status(self.h, ch, blk, C.byref(st)), "kq_bank_pull_status")
+        return st.as_dict()
+
+    def audio(self, ch, blk):
+        buf = np.zeros(2 * self.olen, np.float32)
+        n = C.c_size_t()
+        self._chk(self.lib.kq_bank_pull_audio(self.h, ch, blk, buf.ctypes.data, buf.size, C.byref(n)), "kq_bank_pull_audio")
+        return buf[:n.value].copy()
+
+    def filter_output(self, ch, blk):
+        buf = np.zeros(self.olen, np.complex64)
+        self._chk(self.lib.kq_bank_pull_filter_output(self.h, ch, blk, buf.ctypes.data, buf.size), "kq_bank_pull_filter_output")
+        return buf
+
+    def arm_spectrum(self, ch):
+        buf = np.zeros(self.N, np.complex64)
+        self.lib.kq_bank_pull_spectrum(self.h, ch, 0, buf.ctypes.data, buf.size)  # first call arms the capture
+
+    def spectrum(self, ch, blk):
+        buf = np.zeros(self.N, np.complex64)
+        self._chk(self.lib.kq_bank_pull_spectrum(self.h, ch, blk, buf.ctypes.data, buf.size), "kq_bank_pull_spectrum")
+        return buf
+
+    def response(self, ch):
+        buf = np.zeros(self.Ndec, np.complex64)
+        self._chk(self.lib.kq_bank_get_response(self.h, ch, buf.ctypes.data, buf.size), "kq_bank_get_response")
+        return buf
+
+    def audio_response(self, ch):
+        buf = np.zeros(self.Ndec // 2 + 1, np.complex64)
+        self._chk(self.lib.kq_bank_get_audio_response(self.h, ch, buf.ctypes.data, buf.size), "kq_bank_get_audio_response")
+        return buf
+
+    def enable_timing(self, on=True):
+        self.lib.kq_bank_enable_timing(self.h, int(on))
+
+    def timing(self, reset=True):
+        t = Timing()
+        self._chk(self.lib.kq_bank_get_timing(self.h, C.byref(t), int(reset)), "kq_bank_get_timing")
+        return {n: getattr(t, n) for n, _ in t._fields_}
+
+    def audio_device_ptr(self):
+        return self.lib.kq_bank_audio_device_ptr(self.h)
+
+    def status_device_ptr(self):
+        return self.lib.kq_bank_status_device_ptr(self.h)

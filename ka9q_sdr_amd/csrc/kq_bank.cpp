@@ -1,0 +1,865 @@
+// kq_bank.cpp -- host side of the channel bank: the C ABI of include/ka9q_hip.h.
+//
+// Host responsibilities (control plane, once per call or per retune -- never per sample):
+//   * NCO bookkeeping in closed form.  The reference advances a complex-double phasor one sample at
+//     a time (osc.c:39-51); here each oscillator is (phase, step, sweep) at a reference sample index
+//     and the kernels evaluate phase(n) = phase + step*k + sweep*k*(k-1)/2 themselves.
+//   * response design (kq_design.cpp) and upload
+//   * ring management and kernel sequencing
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kq_design.hpp"
+#include "kq_device.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+void set_err(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return -1;                                                                       \
+    }                                                                                  \
+  } while (0)
+
+// One NCO in closed form.  `frozen` mirrors osc.c:43: an oscillator whose set frequency is zero
+// never advances, whatever its sweep rate.
+struct Osc {
+  bool init = false;
+  bool frozen = true;
+  double phase = 0;  // turns at sample n_ref
+  double f = 0;      // cycles/sample applied between n_ref and n_ref+1
+  double r = 0;      // cycles/sample^2
+  double set_f = 0;  // value last passed to set() -- what osc->freq holds in the reference
+  int64_t n_ref = 0;
+
+  double phase_at(int64_t n) const {
+    if (frozen) return phase;
+    double const k = (double)(n - n_ref);
+    return phase + f * k + r * (0.5 * k * (k - 1.0));
+  }
+  double step_at(int64_t n) const { return frozen ? 0.0 : f + r * (double)(n - n_ref); }
+  double sweep() const { return frozen ? 0.0 : r; }
+  // set_osc (osc.c:22-36): keeps the phase when already initialised
+  void set(double freq, double rate, int64_t now) {
+    if (init) {
+      phase = phase_at(now);
+      phase -= std::floor(phase);
+    } else {
+      phase = 0;
+      init = true;
+    }
+    n_ref = now;
+    set_f = freq;
+    frozen = (freq == 0);
+    f = freq;
+    r = rate;
+  }
+  // move the reference point forward so k stays small (no change of the generated sequence)
+  void rebase(int64_t now) {
+    if (!init || frozen) {
+      n_ref = now;
+      return;
+    }
+    double const p = phase_at(now);
+    f = step_at(now);
+    phase = p - std::floor(p);
+    n_ref = now;
+  }
+};
+
+struct HostChan {
+  kq_channel_config cfg;
+  Osc lo2, dop, shift;
+  int out_type;
+  std::vector<kq::cfloat> resp, aresp;
+  float noise_gain;
+};
+
+struct EventPair {
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct kq_bank {
+  kq_bank_config cfg;
+  kq::Geom g;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int fwd_mode = KQ_FWD_FULL;
+
+  float2 *ring[2] = {nullptr, nullptr};
+  int cur = 0;
+  size_t ring_cap = 0;   // samples, including the M-1 history
+  size_t pending = 0;    // new samples in the ring beyond the history
+  std::vector<unsigned char> zero_tail;  // per pending block: 1 if its last sample came from a zero fill
+  size_t zero_run = 0;                   // trailing zero-fill samples of the partially filled block
+  bool partial_ends_in_zero = false;
+
+  float2 *tw = nullptr;
+  float2 *chan_tw = nullptr;  // pruned path: per-channel twiddle tables
+  bool chan_tw_dirty = true;
+  kq::ChanDev chd;
+  kq::Planes pl;
+  int *list_dev[3] = {nullptr, nullptr, nullptr};  // fm, am, linear
+  std::vector<int> list_host[3];
+  bool lists_dirty = true;
+  float *energy_state = nullptr;
+  unsigned char *update_dev = nullptr;
+  float2 *spec_dump = nullptr;
+  int spec_ch = -1;
+  void *stage_dev = nullptr;  // staging for host-side raw I/Q before conversion
+  size_t stage_cap = 0;
+
+  std::vector<HostChan> chans;
+  int64_t n_abs = 0;        // absolute index of the first new (not yet processed) sample
+  int64_t out_abs = 0;      // absolute index of the next output sample
+  unsigned last_blocks = 0;
+
+  bool timing = false;
+  std::vector<EventPair> ev_filter, ev_demod, ev_ingest;
+  size_t ev_used[3] = {0, 0, 0};
+  kq_timing acc = {};
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T **p, size_t n) {
+  HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
+  HIP_TRY(hipMemset(*p, 0, n * sizeof(T)));
+  return 0;
+}
+
+int ilog2(unsigned v) {
+  int l = 0;
+  while ((1u << l) < v) l++;
+  return l;
+}
+
+int upload(kq_bank *b, void *dst, const void *src, size_t bytes) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->stream));
+  return 0;
+}
+
+// Derived per-channel constants, as each demod thread computes them in its prologue
+int upload_channel(kq_bank *b, int c) {
+  HostChan &h = b->chans[c];
+  kq::Geom const &g = b->g;
+  kq_channel_config const &k = h.cfg;
+  int const mode = k.demod_type;
+  int flags = 0;
+  if (k.flat) flags |= kq::FLAG_FLAT;
+  if (k.isb && mode == KQ_LINEAR_DEMOD) flags |= kq::FLAG_ISB;
+  if (k.channels == 2 && mode == KQ_LINEAR_DEMOD) flags |= kq::FLAG_STEREO;
+  float const samptime = (float)g.D / (float)g.samprate;  // am.c:21, linear.c:29
+  float const rec_db = k.recovery_rate * samptime;
+  float const recovery = powf(10.f, (float)((double)rec_db / 20.));  // dB2voltage, dsp.h:38
+  int const hangmax = (int)(k.hangtime / samptime);                  // am.c:29, linear.c:38
+  float const fm_gain = (float)((k.headroom * M_1_PI * g.dsamprate) / fabsf(k.low - k.high));  // fm.c:86
+  float const init_gain = (mode == KQ_AM_DEMOD) ? powf(10.f, (float)(80. / 20.)) : powf(10.f, (float)(100.0 / 20.));
+  float const nan = NAN;
+  float2 const one = make_float2(1.f, 0.f);  // fm.c:26
+
+  if (upload(b, b->chd.mode + c, &mode, sizeof(int))) return -1;
+  if (upload(b, b->chd.flags + c, &flags, sizeof(int))) return -1;
+  if (upload(b, b->chd.low + c, &k.low, sizeof(float))) return -1;
+  if (upload(b, b->chd.high + c, &k.high, sizeof(float))) return -1;
+  if (upload(b, b->chd.fm_gain + c, &fm_gain, sizeof(float))) return -1;
+  if (upload(b, b->chd.headroom + c, &k.headroom, sizeof(float))) return -1;
+  if (upload(b, b->chd.recovery + c, &recovery, sizeof(float))) return -1;
+  if (upload(b, b->chd.hangmax + c, &hangmax, sizeof(int))) return -1;
+  if (upload(b, b->chd.gain + c, &init_gain, sizeof(float))) return -1;
+  if (upload(b, b->chd.n0 + c, &nan, sizeof(float))) return -1;
+  if (upload(b, b->chd.fm_state + c, &one, sizeof(float2))) return -1;
+  HIP_TRY(hipStreamSynchronize(b->stream));  // locals above go out of scope
+  return 0;
+}
+
+int upload_response(kq_bank *b, int c) {
+  HostChan &h = b->chans[c];
+  kq::Geom const &g = b->g;
+  if (upload(b, b->chd.resp + (size_t)c * g.Ndec, h.resp.data(), sizeof(float2) * g.Ndec)) return -1;
+  if (upload(b, b->chd.noise_gain + c, &h.noise_gain, sizeof(float))) return -1;
+  if (!h.aresp.empty())
+    if (upload(b, b->chd.aresp + (size_t)c * (g.Ndec / 2 + 1), h.aresp.data(), sizeof(float2) * (g.Ndec / 2 + 1))) return -1;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+// Pre-detection response: set_filter with edges normalised to the output rate
+// (fm.c:35: low/dsamprate; am.c:41, linear.c:81: samptime*low)
+void design_channel(kq_bank *b, HostChan &h) {
+  kq::Geom const &g = b->g;
+  float lo_n, hi_n;
+  if (h.cfg.demod_type == KQ_FM_DEMOD) {
+    lo_n = h.cfg.low / g.dsamprate;
+    hi_n = h.cfg.high / g.dsamprate;
+  } else {
+    float const samptime = (float)g.D / (float)g.samprate;
+    lo_n = samptime * h.cfg.low;
+    hi_n = samptime * h.cfg.high;
+  }
+  h.resp = kq::design_response(g.N, g.olen, g.Mdec, h.out_type, lo_n, hi_n, h.cfg.kaiser_beta);
+  h.noise_gain = kq::noise_gain(h.resp, g.N, g.Ndec, false, h.out_type);
+  if (h.cfg.demod_type == KQ_FM_DEMOD && !h.cfg.flat)
+    h.aresp = kq::design_fm_audio_response(g.olen, g.Mdec, g.dsamprate, h.cfg.kaiser_beta);
+  else
+    h.aresp.clear();
+}
+
+int ensure_events(std::vector<EventPair> &v, size_t need) {
+  while (v.size() < need) {
+    EventPair p;
+    HIP_TRY(hipEventCreate(&p.a));
+    HIP_TRY(hipEventCreate(&p.b));
+    v.push_back(p);
+  }
+  return 0;
+}
+
+int drain_timing(kq_bank *b) {
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  std::vector<EventPair> *sets[3] = {&b->ev_filter, &b->ev_demod, &b->ev_ingest};
+  double *dst[3] = {&b->acc.filter_ms, &b->acc.demod_ms, &b->acc.ingest_ms};
+  for (int k = 0; k < 3; k++) {
+    for (size_t i = 0; i < b->ev_used[k]; i++) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, (*sets[k])[i].a, (*sets[k])[i].b));
+      *dst[k] += ms;
+    }
+    b->ev_used[k] = 0;
+  }
+  return 0;
+}
+
+struct Scope {
+  kq_bank *b;
+  int kind;
+  EventPair *p = nullptr;
+  Scope(kq_bank *bank, int k) : b(bank), kind(k) {
+    if (!b->timing) return;
+    std::vector<EventPair> &v = kind == 0 ? b->ev_filter : kind == 1 ? b->ev_demod : b->ev_ingest;
+    if (b->ev_used[kind] >= 512) drain_timing(b);
+    if (ensure_events(v, b->ev_used[kind] + 1)) return;
+    p = &v[b->ev_used[kind]++];
+    (void)hipEventRecord(p->a, b->stream);
+  }
+  ~Scope() {
+    if (p) (void)hipEventRecord(p->b, b->stream);
+  }
+};
+
+// Oscillator parameters for a call whose first window starts at absolute sample n_w
+int upload_osc(kq_bank *b, int64_t n_w) {
+  size_t const C = b->chans.size();
+  std::vector<double> ph(C), fr(C), rt(C), sp(C), sf(C);
+  for (size_t c = 0; c < C; c++) {
+    HostChan const &h = b->chans[c];
+    double p = h.lo2.phase_at(n_w), f = h.lo2.step_at(n_w), r = h.lo2.sweep();
+    if (h.dop.set_f != 0) {  // radio.c:135: the Doppler NCO is applied only while its frequency is non-zero
+      p += h.dop.phase_at(n_w);
+      f += h.dop.step_at(n_w);
+      r += h.dop.sweep();
+    }
+    ph[c] = p - std::floor(p);
+    fr[c] = f;
+    rt[c] = r;
+    sp[c] = h.shift.phase_at(b->out_abs);
+    sp[c] -= std::floor(sp[c]);
+    sf[c] = h.shift.step_at(b->out_abs);
+  }
+  if (upload(b, b->chd.lo_phase, ph.data(), C * sizeof(double))) return -1;
+  if (upload(b, b->chd.lo_freq, fr.data(), C * sizeof(double))) return -1;
+  if (upload(b, b->chd.lo_rate, rt.data(), C * sizeof(double))) return -1;
+  if (upload(b, b->chd.sh_phase, sp.data(), C * sizeof(double))) return -1;
+  if (upload(b, b->chd.sh_freq, sf.data(), C * sizeof(double))) return -1;
+  HIP_TRY(hipStreamSynchronize(b->stream));  // host vectors are about to die
+  return 0;
+}
+
+int upload_lists(kq_bank *b) {
+  for (int k = 0; k < 3; k++) b->list_host[k].clear();
+  for (size_t c = 0; c < b->chans.size(); c++) {
+    int const m = b->chans[c].cfg.demod_type;
+    b->list_host[m == KQ_FM_DEMOD ? 0 : m == KQ_AM_DEMOD ? 1 : 2].push_back((int)c);
+  }
+  for (int k = 0; k < 3; k++)
+    if (!b->list_host[k].empty())
+      if (upload(b, b->list_dev[k], b->list_host[k].data(), b->list_host[k].size() * sizeof(int))) return -1;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->lists_dirty = false;
+  return 0;
+}
+
+// The kernels of one call over `nblocks` blocks whose first window starts at `window`
+int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigned char *update_host) {
+  kq::Geom const &g = b->g;
+  int const C = (int)b->chans.size();
+  if (C == 0) {
+    set_err("no channels in bank");
+    return -1;
+  }
+  if (b->lists_dirty && upload_lists(b)) return -1;
+  if (upload_osc(b, b->n_abs - (g.M - 1))) return -1;
+  if (upload(b, b->update_dev, update_host, nblocks)) return -1;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  {
+    Scope t(b, 2);
+    kq::launch_block_energy(b->stream, window + (g.M - 1), g.L, (int)nblocks, b->update_dev, b->energy_state, b->pl.if_power);
+  }
+  {
+    Scope t(b, 0);
+    if (b->fwd_mode == KQ_FWD_PRUNED) {
+      kq::launch_pruned_tables(b->stream, g, b->chd, b->chan_tw, C);
+      kq::launch_filter_pruned(b->stream, g, b->chd, b->pl, window, b->tw, b->chan_tw, C, (int)nblocks);
+    } else {
+      kq::launch_filter_full(b->stream, g, b->chd, b->pl, window, b->tw, C, (int)nblocks, b->cfg.compute_n0, b->spec_dump,
+                             b->spec_ch);
+    }
+    b->acc.filter_launches++;
+    b->acc.channel_blocks += (uint64_t)C * nblocks;
+  }
+  {
+    Scope t(b, 1);
+    kq::launch_demods(b->stream, g, b->chd, b->pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), b->list_dev[1],
+                      (int)b->list_host[1].size(), b->list_dev[2], (int)b->list_host[2].size(), (int)nblocks,
+                      b->cfg.compute_n0);
+  }
+  HIP_TRY(hipGetLastError());
+  b->n_abs += (int64_t)nblocks * g.L;
+  b->out_abs += (int64_t)nblocks * g.olen;
+  for (HostChan &h : b->chans) {
+    h.lo2.rebase(b->n_abs);
+    h.dop.rebase(b->n_abs);
+    h.shift.rebase(b->out_abs);
+  }
+  b->last_blocks = nblocks;
+  return (int)nblocks;
+}
+
+bool valid_ch(const kq_bank *b, int ch) { return b && ch >= 0 && (size_t)ch < b->chans.size(); }
+
+}  // namespace
+
+extern "C" {
+
+const char *kq_last_error(void) { return g_err.c_str(); }
+const char *kq_version(void) { return "ka9q_hip 0.1 (gfx950)"; }
+
+int kq_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+
+kq_bank *kq_bank_create(const kq_bank_config *cfg) {
+  if (!cfg) {
+    set_err("NULL config");
+    return nullptr;
+  }
+  unsigned const N = cfg->L + cfg->M - 1;
+  if (cfg->L == 0 || cfg->M < 2 || (N & (N - 1)) != 0 || N < 16) {
+    set_err("L+M-1 = %u must be a power of two >= 16", N);
+    return nullptr;
+  }
+  if (cfg->decimate < 2 || N % cfg->decimate != 0 || cfg->L % cfg->decimate != 0 || (cfg->M - 1) % cfg->decimate != 0) {
+    set_err("decimate %u must be >= 2 and divide N, L and M-1", cfg->decimate);
+    return nullptr;
+  }
+  unsigned const Ndec = N / cfg->decimate;
+  if ((Ndec & (Ndec - 1)) != 0 || Ndec < 4) {
+    set_err("N/decimate = %u must be a power of two >= 4", Ndec);
+    return nullptr;
+  }
+  if (cfg->max_channels == 0 || cfg->max_blocks == 0 || cfg->samprate <= 0) {
+    set_err("max_channels, max_blocks and samprate must be positive");
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_err("no HIP device available (the gfx950 kernels are the only compute path)");
+    return nullptr;
+  }
+  if (cfg->device < 0 || cfg->device >= ndev) {
+    set_err("device %d out of range (%d visible)", cfg->device, ndev);
+    return nullptr;
+  }
+  if (hipSetDevice(cfg->device) != hipSuccess) {
+    set_err("hipSetDevice(%d) failed", cfg->device);
+    return nullptr;
+  }
+
+  kq_bank *b = new kq_bank();
+  b->cfg = *cfg;
+  kq::Geom &g = b->g;
+  g.N = (int)N;
+  g.L = (int)cfg->L;
+  g.M = (int)cfg->M;
+  g.D = (int)cfg->decimate;
+  g.Ndec = (int)Ndec;
+  g.olen = (int)(cfg->L / cfg->decimate);           // filter.c:116
+  g.Mdec = (int)((cfg->M - 1) / cfg->decimate + 1); // filter.c:514
+  g.log2N = ilog2(N);
+  g.log2Ndec = ilog2(Ndec);
+  g.samprate = cfg->samprate;
+  g.tw_log2 = g.log2N;
+  g.max_blocks = (int)cfg->max_blocks;
+  g.dsamprate = (float)cfg->samprate / cfg->decimate;
+
+  bool const can_prune = kq::pruned_supported(g) && !cfg->compute_n0;
+  if (cfg->fwd_mode == KQ_FWD_PRUNED) {
+    if (!can_prune) {
+      set_err("pruned forward path unavailable for this geometry or with compute_n0 enabled");
+      delete b;
+      return nullptr;
+    }
+    b->fwd_mode = KQ_FWD_PRUNED;
+  } else if (cfg->fwd_mode == KQ_FWD_FULL) {
+    b->fwd_mode = KQ_FWD_FULL;
+  } else {
+    b->fwd_mode = can_prune ? KQ_FWD_PRUNED : KQ_FWD_FULL;
+  }
+  if (b->fwd_mode == KQ_FWD_FULL && (size_t)N * sizeof(float2) > 160 * 1024) {
+    set_err("full forward path keeps the N-point block in LDS: N = %u exceeds 160 KiB", N);
+    delete b;
+    return nullptr;
+  }
+
+  if (cfg->stream) {
+    b->stream = (hipStream_t)cfg->stream;
+  } else {
+    if (hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
+      set_err("hipStreamCreate failed");
+      delete b;
+      return nullptr;
+    }
+    b->own_stream = true;
+  }
+
+  size_t const C = cfg->max_channels, B = cfg->max_blocks;
+  b->ring_cap = (size_t)(g.M - 1) + B * (size_t)g.L;
+  int rc = 0;
+  rc |= dev_alloc(&b->ring[0], b->ring_cap);
+  rc |= dev_alloc(&b->ring[1], b->ring_cap);
+  rc |= dev_alloc(&b->tw, (size_t)1 << (g.tw_log2 - 1));
+  rc |= dev_alloc(&b->chd.mode, C);
+  rc |= dev_alloc(&b->chd.flags, C);
+  rc |= dev_alloc(&b->chd.low, C);
+  rc |= dev_alloc(&b->chd.high, C);
+  rc |= dev_alloc(&b->chd.resp, C * g.Ndec);
+  rc |= dev_alloc(&b->chd.aresp, C * (g.Ndec / 2 + 1));
+  rc |= dev_alloc(&b->chd.fm_gain, C);
+  rc |= dev_alloc(&b->chd.headroom, C);
+  rc |= dev_alloc(&b->chd.recovery, C);
+  rc |= dev_alloc(&b->chd.hangmax, C);
+  rc |= dev_alloc(&b->chd.noise_gain, C);
+  rc |= dev_alloc(&b->chd.lo_phase, C);
+  rc |= dev_alloc(&b->chd.lo_freq, C);
+  rc |= dev_alloc(&b->chd.lo_rate, C);
+  rc |= dev_alloc(&b->chd.sh_phase, C);
+  rc |= dev_alloc(&b->chd.sh_freq, C);
+  rc |= dev_alloc(&b->chd.fm_state, C);
+  rc |= dev_alloc(&b->chd.lastaudio, C);
+  rc |= dev_alloc(&b->chd.sq_count, C);
+  rc |= dev_alloc(&b->chd.ahist, C * (size_t)(g.Mdec > 1 ? g.Mdec - 1 : 1));
+  rc |= dev_alloc(&b->chd.foffset, C);
+  rc |= dev_alloc(&b->chd.pdev, C);
+  rc |= dev_alloc(&b->chd.gain, C);
+  rc |= dev_alloc(&b->chd.hang, C);
+  rc |= dev_alloc(&b->chd.dc, C);
+  rc |= dev_alloc(&b->chd.n0, C);
+  rc |= dev_alloc(&b->pl.filt, C * B * g.olen);
+  rc |= dev_alloc(&b->pl.audio, C * B * 2 * (size_t)g.olen);
+  rc |= dev_alloc(&b->pl.status, C * B);
+  rc |= dev_alloc(&b->pl.n0raw, C * B);
+  rc |= dev_alloc(&b->pl.if_power, B);
+  rc |= dev_alloc(&b->energy_state, 2);
+  rc |= dev_alloc(&b->update_dev, B);
+  for (int k = 0; k < 3; k++) rc |= dev_alloc(&b->list_dev[k], C);
+  if (b->fwd_mode == KQ_FWD_PRUNED) rc |= dev_alloc(&b->chan_tw, C * kq::pruned_table_elems(g));
+  if (rc) {
+    kq_bank_destroy(b);
+    return nullptr;
+  }
+  // twiddles exp(-2*pi*i*k/T) in double, rounded once
+  {
+    size_t const T = (size_t)1 << g.tw_log2;
+    std::vector<float2> tw(T / 2);
+    for (size_t k = 0; k < T / 2; k++) {
+      double const a = -2.0 * M_PI * (double)k / (double)T;
+      tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    if (hipMemcpy(b->tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+      set_err("twiddle upload failed");
+      kq_bank_destroy(b);
+      return nullptr;
+    }
+  }
+  return b;
+}
+
+int kq_bank_destroy(kq_bank *b) {
+  if (!b) return 0;
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  void *ptrs[] = {b->ring[0], b->ring[1], b->tw, b->chan_tw, b->chd.mode, b->chd.flags, b->chd.low, b->chd.high, b->chd.resp,
+                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain,
+                  b->chd.lo_phase, b->chd.lo_freq, b->chd.lo_rate, b->chd.sh_phase, b->chd.sh_freq, b->chd.fm_state,
+                  b->chd.lastaudio, b->chd.sq_count, b->chd.ahist, b->chd.foffset, b->chd.pdev, b->chd.gain, b->chd.hang,
+                  b->chd.dc, b->chd.n0, b->pl.filt, b->pl.audio, b->pl.status, b->pl.n0raw, b->pl.if_power, b->energy_state,
+                  b->update_dev, b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto *v : {&b->ev_filter, &b->ev_demod, &b->ev_ingest})
+    for (EventPair &p : *v) {
+      (void)hipEventDestroy(p.a);
+      (void)hipEventDestroy(p.b);
+    }
+  if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+  return 0;
+}
+
+int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
+  if (!b || !cfg) {
+    set_err("NULL argument");
+    return -1;
+  }
+  if (b->chans.size() >= b->cfg.max_channels) {
+    set_err("bank is full (%u channels)", b->cfg.max_channels);
+    return -1;
+  }
+  if (cfg->demod_type < KQ_LINEAR_DEMOD || cfg->demod_type > KQ_FM_DEMOD) {
+    set_err("unknown demod_type %d", cfg->demod_type);
+    return -1;
+  }
+  if (std::isnan(cfg->low) || std::isnan(cfg->high)) {  // filter.c:504-505
+    set_err("NaN filter edge");
+    return -1;
+  }
+  HostChan h;
+  h.cfg = *cfg;
+  h.out_type = (cfg->demod_type == KQ_LINEAR_DEMOD && cfg->isb) ? kq::FT_CROSS_CONJ : kq::FT_COMPLEX;
+  double const fs = b->g.samprate;
+  // oscillator setter scalings: radio.c:299, radio.c:182, radio.c:309
+  h.lo2.set(cfg->second_lo == 0 ? 0.0 : cfg->second_lo / fs, 0.0, b->n_abs);
+  h.dop.set(-cfg->doppler / fs, -cfg->doppler_rate / (fs * fs), b->n_abs);
+  h.shift.set(cfg->shift == 0 ? 0.0 : cfg->shift * b->g.D / fs, 0.0, b->out_abs);
+  design_channel(b, h);
+  b->chans.push_back(h);
+  int const c = (int)b->chans.size() - 1;
+  if (upload_channel(b, c) || upload_response(b, c)) {
+    b->chans.pop_back();
+    return -1;
+  }
+  b->lists_dirty = true;
+  b->chan_tw_dirty = true;
+  return c;
+}
+
+unsigned kq_bank_num_channels(const kq_bank *b) { return b ? (unsigned)b->chans.size() : 0; }
+
+int kq_bank_set_second_lo(kq_bank *b, int ch, double hz) {
+  if (!valid_ch(b, ch) || std::isnan(hz)) {
+    set_err("bad channel or NaN");
+    return -1;
+  }
+  b->chans[ch].cfg.second_lo = hz;
+  b->chans[ch].lo2.set(hz == 0 ? 0.0 : hz / b->g.samprate, 0.0, b->n_abs);
+  b->chan_tw_dirty = true;
+  return 0;
+}
+
+int kq_bank_set_doppler(kq_bank *b, int ch, double hz, double hz_per_s) {
+  if (!valid_ch(b, ch) || std::isnan(hz) || std::isnan(hz_per_s)) {
+    set_err("bad channel or NaN");
+    return -1;
+  }
+  double const fs = b->g.samprate;
+  b->chans[ch].cfg.doppler = hz;
+  b->chans[ch].cfg.doppler_rate = hz_per_s;
+  b->chans[ch].dop.set(-hz / fs, -hz_per_s / (fs * fs), b->n_abs);
+  b->chan_tw_dirty = true;
+  return 0;
+}
+
+int kq_bank_set_shift(kq_bank *b, int ch, double hz) {
+  if (!valid_ch(b, ch) || std::isnan(hz)) {
+    set_err("bad channel or NaN");
+    return -1;
+  }
+  b->chans[ch].cfg.shift = hz;
+  b->chans[ch].shift.set(hz == 0 ? 0.0 : hz * b->g.D / (double)b->g.samprate, 0.0, b->out_abs);
+  return 0;
+}
+
+int kq_bank_set_filter(kq_bank *b, int ch, float low, float high, float beta) {
+  if (!valid_ch(b, ch)) {
+    set_err("bad channel");
+    return -1;
+  }
+  if (std::isnan(low) || std::isnan(high)) {  // filter.c:504-505
+    set_err("NaN filter edge");
+    return -1;
+  }
+  HostChan &h = b->chans[ch];
+  h.cfg.low = low;
+  h.cfg.high = high;
+  h.cfg.kaiser_beta = beta;
+  design_channel(b, h);
+  float const fm_gain = (float)((h.cfg.headroom * M_1_PI * b->g.dsamprate) / fabsf(low - high));
+  if (upload(b, b->chd.low + ch, &low, sizeof(float))) return -1;
+  if (upload(b, b->chd.high + ch, &high, sizeof(float))) return -1;
+  if (upload(b, b->chd.fm_gain + ch, &fm_gain, sizeof(float))) return -1;
+  return upload_response(b, ch);
+}
+
+int kq_bank_push_iq(kq_bank *b, const void *iq, size_t nsamples, int format, int is_device) {
+  if (!b || (!iq && nsamples)) {
+    set_err("NULL argument");
+    return -1;
+  }
+  if (format < KQ_IQ_CF32 || format > KQ_IQ_S8) {
+    set_err("unknown I/Q format %d", format);
+    return -1;
+  }
+  kq::Geom const &g = b->g;
+  size_t const used = (size_t)(g.M - 1) + b->pending;
+  if (used + nsamples > b->ring_cap) {
+    set_err("ring overflow: %zu pending + %zu pushed > %zu", b->pending, nsamples, b->ring_cap - (g.M - 1));
+    return -1;
+  }
+  size_t const bps = format == KQ_IQ_CF32 ? 8 : format == KQ_IQ_S16 ? 4 : 2;
+  const void *src = iq;
+  if (!is_device) {
+    if (b->stage_cap < nsamples * bps) {
+      if (b->stage_dev) (void)hipFree(b->stage_dev);
+      b->stage_cap = nsamples * bps;
+      HIP_TRY(hipMalloc(&b->stage_dev, b->stage_cap));
+    }
+    HIP_TRY(hipMemcpyAsync(b->stage_dev, iq, nsamples * bps, hipMemcpyHostToDevice, b->stream));
+    src = b->stage_dev;
+  }
+  {
+    Scope t(b, 2);
+    kq::launch_ingest(b->stream, src, format, b->ring[b->cur] + used, nsamples, b->cfg.gain_factor);
+  }
+  if (!is_device) HIP_TRY(hipStreamSynchronize(b->stream));  // the caller may reuse iq
+  // block completion bookkeeping for the IF-power rule
+  size_t fill = b->pending % g.L;
+  size_t left = nsamples;
+  while (left) {
+    size_t const take = std::min(left, (size_t)g.L - fill);
+    fill += take;
+    left -= take;
+    if (fill == (size_t)g.L) {
+      b->zero_tail.push_back(0);
+      fill = 0;
+    }
+  }
+  b->pending += nsamples;
+  return 0;
+}
+
+int kq_bank_push_zeros(kq_bank *b, size_t nsamples) {
+  if (!b) {
+    set_err("NULL bank");
+    return -1;
+  }
+  kq::Geom const &g = b->g;
+  size_t const used = (size_t)(g.M - 1) + b->pending;
+  if (used + nsamples > b->ring_cap) {
+    set_err("ring overflow");
+    return -1;
+  }
+  HIP_TRY(hipMemsetAsync(b->ring[b->cur] + used, 0, nsamples * sizeof(float2), b->stream));
+  size_t fill = b->pending % g.L;
+  size_t left = nsamples;
+  while (left) {
+    size_t const take = std::min(left, (size_t)g.L - fill);
+    fill += take;
+    left -= take;
+    if (fill == (size_t)g.L) {
+      b->zero_tail.push_back(1);  // completed inside radio.c:88-99
+      fill = 0;
+    }
+  }
+  b->pending += nsamples;
+  return 0;
+}
+
+unsigned kq_bank_blocks_ready(const kq_bank *b) { return b ? (unsigned)(b->pending / b->g.L) : 0; }
+
+int kq_bank_process(kq_bank *b) {
+  if (!b) {
+    set_err("NULL bank");
+    return -1;
+  }
+  kq::Geom const &g = b->g;
+  unsigned nb = (unsigned)(b->pending / g.L);
+  if (nb > b->cfg.max_blocks) nb = b->cfg.max_blocks;
+  if (nb == 0) return 0;
+  std::vector<unsigned char> upd(nb);
+  for (unsigned i = 0; i < nb; i++) upd[i] = b->zero_tail[i] ? 0 : 1;
+  int const done = run_blocks(b, b->ring[b->cur], nb, upd.data());
+  if (done < 0) return -1;
+  b->zero_tail.erase(b->zero_tail.begin(), b->zero_tail.begin() + nb);
+  // overlap-save history (filter.c:164) plus any unprocessed tail moves to the other ring buffer
+  size_t const consumed = (size_t)nb * g.L;
+  size_t const keep = (size_t)(g.M - 1) + (b->pending - consumed);
+  HIP_TRY(hipMemcpyAsync(b->ring[b->cur ^ 1], b->ring[b->cur] + consumed, keep * sizeof(float2), hipMemcpyDeviceToDevice,
+                         b->stream));
+  b->cur ^= 1;
+  b->pending -= consumed;
+  return done;
+}
+
+int kq_bank_process_resident(kq_bank *b, const void *iq_dev, unsigned nblocks) {
+  if (!b || !iq_dev) {
+    set_err("NULL argument");
+    return -1;
+  }
+  if (nblocks == 0 || nblocks > b->cfg.max_blocks) {
+    set_err("nblocks %u out of range 1..%u", nblocks, b->cfg.max_blocks);
+    return -1;
+  }
+  std::vector<unsigned char> upd(nblocks, 1);
+  return run_blocks(b, (const float2 *)iq_dev, nblocks, upd.data());
+}
+
+int kq_bank_sync(kq_bank *b) {
+  if (!b) return -1;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+unsigned kq_bank_olen(const kq_bank *b) { return b ? (unsigned)b->g.olen : 0; }
+unsigned kq_bank_last_blocks(const kq_bank *b) { return b ? b->last_blocks : 0; }
+
+int kq_bank_pull_status(kq_bank *b, int ch, unsigned blk, kq_chan_status *st) {
+  if (!valid_ch(b, ch) || !st || blk >= b->last_blocks) {
+    set_err("bad channel/block");
+    return -1;
+  }
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(st, b->pl.status + (size_t)ch * b->g.max_blocks + blk, sizeof(*st), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int kq_bank_pull_audio(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap, size_t *n) {
+  if (!valid_ch(b, ch) || !dst || blk >= b->last_blocks) {
+    set_err("bad channel/block");
+    return -1;
+  }
+  kq_chan_status st;
+  if (kq_bank_pull_status(b, ch, blk, &st)) return -1;
+  if ((size_t)st.nout > cap) {
+    set_err("audio buffer too small: %d > %zu", st.nout, cap);
+    return -1;
+  }
+  HIP_TRY(hipMemcpy(dst, b->pl.audio + ((size_t)ch * b->g.max_blocks + blk) * 2 * (size_t)b->g.olen, st.nout * sizeof(float),
+                    hipMemcpyDeviceToHost));
+  if (n) *n = (size_t)st.nout;
+  return 0;
+}
+
+int kq_bank_pull_filter_output(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap) {
+  if (!valid_ch(b, ch) || !dst || blk >= b->last_blocks || cap < (size_t)b->g.olen) {
+    set_err("bad channel/block/capacity");
+    return -1;
+  }
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(dst, b->pl.filt + ((size_t)ch * b->g.max_blocks + blk) * b->g.olen, b->g.olen * sizeof(float2),
+                    hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int kq_bank_pull_spectrum(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap) {
+  if (!valid_ch(b, ch) || !dst || cap < (size_t)b->g.N) {
+    set_err("bad channel/capacity");
+    return -1;
+  }
+  if (b->fwd_mode != KQ_FWD_FULL) {
+    set_err("master spectrum exists only in KQ_FWD_FULL mode");
+    return -1;
+  }
+  // The dump is armed for one channel at a time: the first pull after (re)arming returns -1 with a
+  // hint; spectra are captured by the next kq_bank_process call.
+  if (b->spec_ch != ch || !b->spec_dump) {
+    if (!b->spec_dump && dev_alloc(&b->spec_dump, (size_t)b->g.max_blocks * b->g.N)) return -1;
+    b->spec_ch = ch;
+    set_err("spectrum capture armed for channel %d; it is filled by the next process call", ch);
+    return -1;
+  }
+  if (blk >= b->last_blocks) {
+    set_err("bad block");
+    return -1;
+  }
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(dst, b->spec_dump + (size_t)blk * b->g.N, b->g.N * sizeof(float2), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int kq_bank_get_response(kq_bank *b, int ch, float *dst, size_t cap) {
+  if (!valid_ch(b, ch) || !dst || cap < (size_t)b->g.Ndec) {
+    set_err("bad channel/capacity");
+    return -1;
+  }
+  memcpy(dst, b->chans[ch].resp.data(), sizeof(float2) * b->g.Ndec);
+  return 0;
+}
+
+int kq_bank_get_audio_response(kq_bank *b, int ch, float *dst, size_t cap) {
+  if (!valid_ch(b, ch) || !dst) {
+    set_err("bad channel");
+    return -1;
+  }
+  auto const &a = b->chans[ch].aresp;
+  if (a.empty() || cap < a.size()) {
+    set_err("no audio response (not FM, or flat) or capacity too small");
+    return -1;
+  }
+  memcpy(dst, a.data(), sizeof(float2) * a.size());
+  return 0;
+}
+
+void *kq_bank_audio_device_ptr(kq_bank *b) { return b ? b->pl.audio : nullptr; }
+void *kq_bank_status_device_ptr(kq_bank *b) { return b ? b->pl.status : nullptr; }
+
+int kq_bank_enable_timing(kq_bank *b, int on) {
+  if (!b) return -1;
+  if (!on && b->timing) drain_timing(b);
+  b->timing = on != 0;
+  return 0;
+}
+
+int kq_bank_get_timing(kq_bank *b, kq_timing *t, int reset) {
+  if (!b || !t) return -1;
+  if (drain_timing(b)) return -1;
+  *t = b->acc;
+  if (reset) b->acc = kq_timing{};
+  return 0;
+}
+
+int kq_bank_fwd_mode(const kq_bank *b) { return b ? b->fwd_mode : -1; }
+
+}  // extern "C"

@@ -1,0 +1,401 @@
+// kq_compat.cpp -- the reference's one-channel filter / osc / dsp API on top of the gfx950 kernels
+// (include/ka9q_hip_compat.h).  Blocking, one block per call, host buffers at the boundary exactly
+// as the reference's callers expect (radio.c:139-142 fills input.c[]; linear.c:211 reads output.c[]).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/ka9q_hip_compat.h"
+#include "kq_design.hpp"
+#include "kq_device.hpp"
+
+namespace {
+
+struct DevCtx {
+  bool ok = false;
+  hipStream_t stream = nullptr;
+  std::map<int, float2 *> tw;  // log2(T) -> table of T/2 twiddles
+  std::mutex mu;
+};
+
+DevCtx &ctx() {
+  static DevCtx c;
+  return c;
+}
+
+bool ctx_init() {
+  DevCtx &c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  if (c.ok) return true;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    fprintf(stderr, "ka9q_hip: no HIP device; the filter API has no CPU fallback\n");
+    return false;
+  }
+  if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return false;
+  c.ok = true;
+  return true;
+}
+
+float2 *twiddles(int log2T) {
+  DevCtx &c = ctx();
+  std::lock_guard<std::mutex> lk(c.mu);
+  auto it = c.tw.find(log2T);
+  if (it != c.tw.end()) return it->second;
+  size_t const T = (size_t)1 << log2T;
+  std::vector<float2> h(T / 2 ? T / 2 : 1);
+  for (size_t k = 0; k < T / 2; k++) {
+    double const a = -2.0 * M_PI * (double)k / (double)T;
+    h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  float2 *d = nullptr;
+  if (hipMalloc((void **)&d, h.size() * sizeof(float2)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  c.tw[log2T] = d;
+  return d;
+}
+
+int ilog2(unsigned v) {
+  int l = 0;
+  while ((1u << l) < v) l++;
+  return l;
+}
+
+struct MasterDev {
+  int N, log2N;
+  float2 *d_in = nullptr, *d_fdomain = nullptr;
+  std::vector<float2> stage;
+  float2 *tw = nullptr;
+};
+
+struct SlaveDev {
+  int Ndec;
+  float2 *d_resp = nullptr, *d_out = nullptr;
+};
+
+inline float re(kq_cfloat z) { return __real__ z; }
+inline float im(kq_cfloat z) { return __imag__ z; }
+
+}  // namespace
+
+extern "C" {
+
+float Kaiser_beta = 3.0;
+
+struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filtertype in_type) {
+  unsigned const N = L + M - 1;
+  if (L == 0 || M == 0 || (N & (N - 1)) != 0 || N > 16384 || N < 4) {
+    fprintf(stderr, "ka9q_hip: create_filter_input: N=%u must be a power of two in 4..16384\n", N);
+    return NULL;
+  }
+  if (!ctx_init()) return NULL;
+  struct filter_in *m = (struct filter_in *)calloc(1, sizeof(*m));
+  if (!m) return NULL;
+  pthread_mutex_init(&m->filter_mutex, NULL);
+  pthread_cond_init(&m->filter_cond, NULL);
+  if (in_type != REAL && in_type != COMPLEX) {
+    fprintf(stderr, "Filter input type %d, assuming complex\n", in_type);  // filter.c:69-71
+    in_type = COMPLEX;
+  }
+  m->in_type = in_type;
+  m->ilen = L;
+  m->impulse_length = M;
+  MasterDev *d = new MasterDev();
+  d->N = (int)N;
+  d->log2N = ilog2(N);
+  d->tw = twiddles(d->log2N);
+  d->stage.resize(N);
+  if (!d->tw || hipMalloc((void **)&d->d_in, N * sizeof(float2)) != hipSuccess ||
+      hipMalloc((void **)&d->d_fdomain, N * sizeof(float2)) != hipSuccess) {
+    delete d;
+    free(m);
+    return NULL;
+  }
+  m->fwd_plan = d;
+  if (in_type == COMPLEX) {
+    m->fdomain = (kq_cfloat *)calloc(N, sizeof(kq_cfloat));
+    m->input_buffer.c = (kq_cfloat *)calloc(N, sizeof(kq_cfloat));  // history cleared: filter.c:76
+    m->input.c = m->input_buffer.c + (M - 1);
+  } else {
+    m->fdomain = (kq_cfloat *)calloc(N / 2 + 1, sizeof(kq_cfloat));
+    m->input_buffer.r = (float *)calloc(N, sizeof(float));
+    m->input.r = m->input_buffer.r + (M - 1);
+  }
+  return m;
+}
+
+int execute_filter_input(struct filter_in *m) {
+  if (m == NULL) return -1;  // filter.c:148-149
+  MasterDev *d = (MasterDev *)m->fwd_plan;
+  hipStream_t s = ctx().stream;
+  int const N = d->N;
+  const void *src;
+  if (m->in_type == REAL) {
+    for (int i = 0; i < N; i++) d->stage[i] = make_float2(m->input_buffer.r[i], 0.f);
+    src = d->stage.data();
+  } else {
+    src = m->input_buffer.c;
+  }
+  if (hipMemcpyAsync(d->d_in, src, N * sizeof(float2), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+  kq::launch_fft_single(s, d->d_in, d->d_fdomain, d->log2N, -1, d->tw, d->log2N);
+  size_t const bins = (m->in_type == REAL) ? N / 2 + 1 : N;
+  if (hipMemcpyAsync(m->fdomain, d->d_fdomain, bins * sizeof(float2), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+
+  pthread_mutex_lock(&m->filter_mutex);  // filter.c:154-157
+  m->blocknum++;
+  pthread_cond_broadcast(&m->filter_cond);
+  pthread_mutex_unlock(&m->filter_mutex);
+
+  if (m->in_type == REAL)
+    memmove(m->input_buffer.r, m->input_buffer.r + m->ilen, (m->impulse_length - 1) * sizeof(float));
+  else
+    memmove(m->input_buffer.c, m->input_buffer.c + m->ilen, (m->impulse_length - 1) * sizeof(kq_cfloat));
+  return 0;
+}
+
+int delete_filter_input(struct filter_in *m) {
+  if (m == NULL) return 0;
+  MasterDev *d = (MasterDev *)m->fwd_plan;
+  if (d) {
+    (void)hipFree(d->d_in);
+    (void)hipFree(d->d_fdomain);
+    delete d;
+  }
+  free(m->input_buffer.c);  // same storage either way (union), as filter.c:259
+  free(m->fdomain);
+  free(m);
+  return 0;
+}
+
+float noise_gain(struct filter_out const *f) {
+  if (f == NULL) return NAN;
+  struct filter_in const *m = f->master;
+  int const N = (int)(m->ilen + m->impulse_length - 1);
+  int const nd = N / (int)f->decimate;
+  int const count = (m->in_type == REAL && f->out_type == REAL) ? nd / 2 + 1 : nd;
+  float sum = 0;
+  for (int i = 0; i < count; i++) sum += re(f->response[i]) * re(f->response[i]) + im(f->response[i]) * im(f->response[i]);
+  if (f->out_type == REAL || f->out_type == CROSS_CONJ) return 2 * N * sum;
+  return N * sum;
+}
+
+struct filter_out *create_filter_output(struct filter_in *master, kq_cfloat *response, unsigned int decimate,
+                                        enum filtertype out_type) {
+  if (master == NULL || decimate == 0) return NULL;  // filter.c:99-100
+  int const N = (int)(master->ilen + master->impulse_length - 1);
+  int const nd = N / (int)decimate;
+  if ((N % decimate) != 0) fprintf(stderr, "Warning: FFT size %d is not divisible by decimation ratio %u\n", N, decimate);
+  if ((nd & (nd - 1)) != 0 || nd < 4) {
+    fprintf(stderr, "ka9q_hip: create_filter_output: N/decimate=%d must be a power of two >= 4\n", nd);
+    return NULL;
+  }
+  struct filter_out *s = (struct filter_out *)calloc(1, sizeof(*s));
+  if (!s) return NULL;
+  pthread_mutex_init(&s->response_mutex, NULL);
+  s->master = master;
+  s->out_type = out_type;
+  s->decimate = decimate;
+  s->olen = master->ilen / decimate;
+  s->response = response;
+  s->noise_gain = response ? noise_gain(s) : NAN;
+  SlaveDev *d = new SlaveDev();
+  d->Ndec = nd;
+  if (hipMalloc((void **)&d->d_resp, nd * sizeof(float2)) != hipSuccess ||
+      hipMalloc((void **)&d->d_out, nd * sizeof(float2)) != hipSuccess) {
+    delete d;
+    free(s);
+    return NULL;
+  }
+  s->rev_plan = d;
+  if (out_type == REAL) {
+    s->output_buffer.r = (float *)calloc(nd, sizeof(float));
+    s->output.r = s->output_buffer.r + nd - s->olen;  // filter.c:140
+  } else {
+    s->output_buffer.c = (kq_cfloat *)calloc(nd, sizeof(kq_cfloat));
+    s->output.c = s->output_buffer.c + nd - s->olen;  // filter.c:131
+  }
+  return s;
+}
+
+int execute_filter_output(struct filter_out *s) {
+  if (s == NULL) return -1;
+  struct filter_in *m = s->master;
+  MasterDev *md = (MasterDev *)m->fwd_plan;
+  SlaveDev *sd = (SlaveDev *)s->rev_plan;
+  hipStream_t st = ctx().stream;
+
+  pthread_mutex_lock(&m->filter_mutex);  // filter.c:195-199: wait for a new block
+  while (s->blocknum == m->blocknum) pthread_cond_wait(&m->filter_cond, &m->filter_mutex);
+  s->blocknum = m->blocknum;
+  pthread_mutex_unlock(&m->filter_mutex);
+
+  int const nd = sd->Ndec;
+  bool const real_out = s->out_type == REAL;
+  size_t const rbins = real_out ? nd / 2 + 1 : nd;
+  pthread_mutex_lock(&s->response_mutex);  // filter.c:201
+  if (s->response == NULL) {
+    pthread_mutex_unlock(&s->response_mutex);
+    return -1;
+  }
+  hipError_t e = hipMemcpyAsync(sd->d_resp, s->response, rbins * sizeof(float2), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  pthread_mutex_unlock(&s->response_mutex);
+  if (e != hipSuccess) return -1;
+
+  kq::launch_slave_single(st, md->d_fdomain, sd->d_resp, sd->d_out, md->N, nd, m->in_type == REAL, (int)s->out_type, md->tw,
+                          md->log2N);
+  size_t const obytes = real_out ? nd * sizeof(float) : nd * sizeof(float2);
+  if (hipMemcpyAsync(s->output_buffer.c, sd->d_out, obytes, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+  if (hipStreamSynchronize(st) != hipSuccess) return -1;
+  return 0;
+}
+
+int delete_filter_output(struct filter_out *s) {
+  if (s == NULL) return 0;
+  SlaveDev *d = (SlaveDev *)s->rev_plan;
+  if (d) {
+    (void)hipFree(d->d_resp);
+    (void)hipFree(d->d_out);
+    delete d;
+  }
+  pthread_mutex_destroy(&s->response_mutex);
+  free(s->output_buffer.c);
+  free(s->response);
+  free(s);
+  return 0;
+}
+
+int make_kaiser(float *window, unsigned int M, float beta) {
+  if (window == NULL) return -1;
+  kq::make_kaiser(window, M, beta);
+  return 0;
+}
+
+int window_filter(int L, int M, kq_cfloat *response, float beta) {
+  if (response == NULL) return -1;
+  int const N = L + M - 1;
+  std::vector<kq::cfloat> r(N);
+  memcpy((void *)r.data(), response, N * sizeof(kq_cfloat));
+  if (kq::window_filter(L, M, r, beta)) return -1;
+  memcpy(response, r.data(), N * sizeof(kq_cfloat));
+  return 0;
+}
+
+int window_rfilter(int L, int M, kq_cfloat *response, float beta) {
+  if (response == NULL) return -1;
+  int const N = L + M - 1;
+  std::vector<kq::cfloat> r(N / 2 + 1);
+  memcpy((void *)r.data(), response, r.size() * sizeof(kq_cfloat));
+  if (kq::window_rfilter(L, M, r, beta)) return -1;
+  memcpy(response, r.data(), r.size() * sizeof(kq_cfloat));
+  return 0;
+}
+
+int set_filter(struct filter_out *s, float low, float high, float kaiser_beta) {
+  if (s == NULL) return -1;
+  if (std::isnan(low) || std::isnan(high)) return -1;  // filter.c:504-505
+  struct filter_in *m = s->master;
+  int const L_dec = (int)s->olen;
+  int const M_dec = (int)((m->impulse_length - 1) / s->decimate + 1);
+  int const N = (int)(m->ilen + m->impulse_length - 1);
+  std::vector<kq::cfloat> r = kq::design_response(N, L_dec, M_dec, (int)s->out_type, low, high, kaiser_beta);
+  kq_cfloat *fresh = (kq_cfloat *)malloc(r.size() * sizeof(kq_cfloat));
+  if (!fresh) return -1;
+  memcpy(fresh, r.data(), r.size() * sizeof(kq_cfloat));
+  pthread_mutex_lock(&s->response_mutex);  // hot swap: filter.c:538-543
+  kq_cfloat *old = s->response;
+  s->response = fresh;
+  s->noise_gain = noise_gain(s);
+  pthread_mutex_unlock(&s->response_mutex);
+  free(old);
+  return 0;
+}
+
+// ---- NCO (host scalar API; inside the bank the kernels evaluate the same sequence in closed form) ----
+int is_phasor_init(kq_cdouble x) {
+  double const a = __real__ x, b = __imag__ x;
+  if (std::isnan(a) || std::isnan(b) || a * a + b * b < 0.9) return 0;  // osc.c:14-18
+  return 1;
+}
+
+static kq_cdouble unit_pi(double x) {
+  kq_cdouble z;
+  __real__ z = std::cos(x * M_PI);
+  __imag__ z = std::sin(x * M_PI);
+  return z;
+}
+
+void set_osc(struct osc *o, double f, double r) {
+  pthread_mutex_lock(&o->mutex);
+  if (!is_phasor_init(o->phasor)) {  // osc.c:24-27
+    __real__ o->phasor = 1;
+    __imag__ o->phasor = 0;
+    o->steps = 0;
+  }
+  o->freq = f;
+  o->rate = r;
+  o->phasor_step = unit_pi(2 * f);
+  if (r != 0) {
+    o->phasor_step_step = unit_pi(2 * r);
+  } else {
+    __real__ o->phasor_step_step = 1;
+    __imag__ o->phasor_step_step = 0;
+  }
+  pthread_mutex_unlock(&o->mutex);
+}
+
+static inline kq_cdouble zmul(kq_cdouble a, kq_cdouble b) {
+  kq_cdouble z;
+  __real__ z = __real__ a * __real__ b - __imag__ a * __imag__ b;
+  __imag__ z = __real__ a * __imag__ b + __imag__ a * __real__ b;
+  return z;
+}
+
+void renorm_osc(struct osc *o) {
+  o->steps = 0;
+  double const mag = std::hypot(__real__ o->phasor, __imag__ o->phasor);
+  __real__ o->phasor /= mag;
+  __imag__ o->phasor /= mag;
+  if (o->rate != 0) {
+    double const ms = std::hypot(__real__ o->phasor_step, __imag__ o->phasor_step);
+    __real__ o->phasor_step /= ms;
+    __imag__ o->phasor_step /= ms;
+  }
+}
+
+kq_cdouble step_osc(struct osc *o) {
+  kq_cdouble const now = o->phasor;
+  if (o->freq != 0) {  // osc.c:43-47
+    o->phasor = zmul(o->phasor, o->phasor_step);
+    if (o->rate != 0) o->phasor_step = zmul(o->phasor_step, o->phasor_step_step);
+  }
+  if (++o->steps == 16384) renorm_osc(o);  // Renorm_rate, osc.c:11
+  return now;
+}
+
+// ---- dsp.h helpers ----
+kq_cfloat csincosf(float x) {
+  kq_cfloat z;
+  __real__ z = cosf(x);
+  __imag__ z = sinf(x);
+  return z;
+}
+kq_cfloat csincospif(float x) { return csincosf(x * (float)M_PI); }
+kq_cdouble csincos(double x) {
+  kq_cdouble z;
+  __real__ z = std::cos(x);
+  __imag__ z = std::sin(x);
+  return z;
+}
+kq_cdouble csincospi(double x) { return csincos(x * M_PI); }
+float cnrmf(kq_cfloat x) { return __real__ x * __real__ x + __imag__ x * __imag__ x; }
+double cnrm(kq_cdouble x) { return __real__ x * __real__ x + __imag__ x * __imag__ x; }
+
+}  // extern "C"

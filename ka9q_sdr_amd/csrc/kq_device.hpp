@@ -1,0 +1,87 @@
+// kq_device.hpp -- device-side data layout shared by the kernels and the host bank.
+//
+// HBM layout (all planes allocated once at bank creation):
+//   ring      float2 [M-1 + max_blocks*L]        front-end I/Q, one copy shared by every channel
+//   resp      float2 [C][N_dec]                  pre-detection responses (filter.out->response)
+//   aresp     float2 [C][N_dec/2+1]              FM de-emphasis responses
+//   filt      float2 [C][max_blocks][olen]       filter.out->output.c per channel-block
+//   audio     float  [C][max_blocks][2*olen]     demodulated audio
+//   status    kq_chan_status [C][max_blocks]
+//   per-channel parameter / carried-state vectors (SoA, indexed by channel)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ka9q_hip.h"
+
+namespace kq {
+
+enum { FLAG_FLAT = 1, FLAG_ISB = 2, FLAG_STEREO = 4 };
+
+struct Geom {
+  int N, L, M, D;
+  int Ndec, olen, Mdec;
+  int log2N, log2Ndec;
+  int samprate;
+  int tw_log2;      // twiddle table period = 1 << tw_log2 (>= N)
+  int max_blocks;
+  float dsamprate;  // fm.c:27
+};
+
+struct ChanDev {
+  // configuration
+  int *mode;            // enum kq_demod_type
+  int *flags;
+  float *low, *high;    // Hz, for compute_n0's passband exclusion
+  float2 *resp;
+  float2 *aresp;
+  float *fm_gain;       // fm.c:86
+  float *headroom;
+  float *recovery;      // am.c:27 / linear.c:34 recovery_factor
+  int *hangmax;
+  float *noise_gain;
+  // oscillator phase (turns), step (cycles/sample) and sweep (cycles/sample^2) at sample 0 of the
+  // first window of the call; second LO and Doppler already summed (they multiply, so phases add)
+  double *lo_phase, *lo_freq, *lo_rate;
+  // post-detection shift oscillator at output sample 0 of the call
+  double *sh_phase, *sh_freq;
+  // carried demodulator state
+  float2 *fm_state;
+  float *lastaudio;
+  int *sq_count;
+  float *ahist;         // [C][Mdec-1] FM audio overlap-save history
+  float *foffset, *pdev;
+  float *gain;          // agc.gain
+  int *hang;
+  float *dc;            // AM DC_filter
+  float *n0;            // smoothed noise density
+};
+
+struct Planes {
+  float2 *filt;
+  float *audio;
+  kq_chan_status *status;
+  float *n0raw;         // [C][max_blocks] unsmoothed compute_n0 results
+  float *if_power;      // [max_blocks]
+};
+
+// launchers (kq_kernels.hip)
+void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size_t nsamples, float scale);
+void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nblocks, const unsigned char *update,
+                         float *energy_state, float *if_power);
+void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
+                        const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch);
+bool pruned_supported(const Geom &g);
+void launch_filter_pruned(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
+                          const float2 *tw, const float2 *chan_tw, int nchan, int nblocks);
+void launch_pruned_tables(hipStream_t s, const Geom &g, const ChanDev &ch, float2 *chan_tw, int nchan);
+void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw,
+                   const int *list_fm, int n_fm, const int *list_am, int n_am, const int *list_lin, int n_lin,
+                   int nblocks, int compute_n0);
+// single transforms for the compat surface
+void launch_fft_single(hipStream_t s, const float2 *in, float2 *out, int log2n, int sign, const float2 *tw, int tw_log2);
+void launch_slave_single(hipStream_t s, const float2 *fdomain, const float2 *resp, float2 *out, int N, int Ndec,
+                         int in_real, int out_type, const float2 *tw, int tw_log2);
+size_t pruned_table_elems(const Geom &g);
+
+}  // namespace kq

@@ -1,0 +1,697 @@
+// kq_kernels.hip -- gfx950 kernels of the ka9q-radio per-channel DSP hot path.
+//
+//   k_ingest            int16/int8/float I/Q -> float2 ring, scaled           (radio.c:110-122)
+//   k_block_energy      IF power, halving accumulator                          (radio.c:123,143-145)
+//   k_filter_full       per (channel, block): NCO mix -> N-point FFT in LDS -> [compute_n0] ->
+//                       response multiply / CROSS_CONJ -> N/D-point IFFT -> last olen samples
+//                       (radio.c:132-139, filter.c:151, radio.c:383-425, filter.c:206-250)
+//   k_demod_fm/am/lin   demodulators with state carried across blocks in HBM (fm.c, am.c, linear.c)
+//
+// The pruned forward path lives in kq_pruned.hip.
+#include "kq_device.hpp"
+
+namespace kq {
+
+// ---------------------------------------------------------------- helpers
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float cnrm(float2 a) { return a.x * a.x + a.y * a.y; }
+
+__device__ __forceinline__ unsigned bitrev(unsigned i, int bits) { return bits ? (__brev(i) >> (32 - bits)) : 0u; }
+
+// Unit phasor exp(j*2*pi*turns) from a double phase in turns
+__device__ __forceinline__ float2 phasor_turns(double turns) {
+  turns -= rint(turns);
+  float s, c;
+  sincospif(2.0f * (float)turns, &s, &c);
+  return make_float2(c, s);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum of (float, int) pairs; red_f / red_i hold one slot per wave (<= 16 waves)
+__device__ __forceinline__ void block_sum_fi(float &f, int &i, float *red_f, int *red_i) {
+  f = wave_sum(f);
+  i = wave_sum_i(i);
+  int const w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    red_f[w] = f;
+    red_i[w] = i;
+  }
+  __syncthreads();
+  float tf = 0;
+  int ti = 0;
+  for (int k = 0; k < nw; k++) {
+    tf += red_f[k];
+    ti += red_i[k];
+  }
+  f = tf;
+  i = ti;
+}
+
+// In-place FFT of 2^log2n points held in LDS in BIT-REVERSED order; result in natural order.
+// Radix-2^2 decimation in time (plus one radix-2 stage when log2n is odd).  tw[k] = exp(-2*pi*i*k/T),
+// T = 1 << tw_log2 >= n, k < T/2.  SIGN -1 forward / +1 backward, unnormalised like FFTW.
+template <int SIGN>
+__device__ void lds_fft(float2 *s, int log2n, const float2 *__restrict__ tw, int tw_log2) {
+  int const n = 1 << log2n;
+  int stage = 0;
+  __syncthreads();
+  if (log2n & 1) {
+    for (int i = threadIdx.x; i < n / 2; i += blockDim.x) {
+      float2 const a = s[2 * i], b = s[2 * i + 1];
+      s[2 * i] = cadd(a, b);
+      s[2 * i + 1] = csub(a, b);
+    }
+    stage = 1;
+    __syncthreads();
+  }
+  for (; stage < log2n; stage += 2) {
+    int const m = 1 << stage;
+    for (int i = threadIdx.x; i < n / 4; i += blockDim.x) {
+      int const j = i & (m - 1);
+      int const base = ((i >> stage) << (stage + 2)) + j;
+      float2 w2 = tw[(size_t)j << (tw_log2 - stage - 1)];
+      float2 w4 = tw[(size_t)j << (tw_log2 - stage - 2)];
+      if (SIGN > 0) {
+        w2.y = -w2.y;
+        w4.y = -w4.y;
+      }
+      float2 const a0 = s[base], a1 = cmul(s[base + m], w2);
+      float2 const a2 = s[base + 2 * m], a3 = cmul(s[base + 3 * m], w2);
+      float2 const b0 = cadd(a0, a1), b1 = csub(a0, a1), b2 = cadd(a2, a3), b3 = csub(a2, a3);
+      float2 const c2 = cmul(b2, w4);
+      float2 c3 = cmul(b3, w4);
+      c3 = (SIGN < 0) ? make_float2(c3.y, -c3.x) : make_float2(-c3.y, c3.x);  // times exp(-+ i*pi/2)
+      s[base] = cadd(b0, c2);
+      s[base + 2 * m] = csub(b0, c2);
+      s[base + m] = cadd(b1, c3);
+      s[base + 3 * m] = csub(b1, c3);
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- ingest
+__global__ void k_ingest(const void *__restrict__ src, int format, float2 *__restrict__ dst, size_t n, float gain) {
+  size_t const stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float2 v;
+    if (format == KQ_IQ_S16) {
+      short2 const q = reinterpret_cast<const short2 *>(src)[i];
+      float const sc = 1.f / 32767.f;  // SCALE16, radio.c:38
+      v = make_float2(q.x * sc, q.y * sc);
+    } else if (format == KQ_IQ_S8) {
+      char2 const q = reinterpret_cast<const char2 *>(src)[i];
+      float const sc = 1.f / 127.f;  // SCALE8, radio.c:39
+      v = make_float2(q.x * sc, q.y * sc);
+    } else {
+      v = reinterpret_cast<const float2 *>(src)[i];
+    }
+    dst[i] = make_float2(v.x * gain, v.y * gain);  // radio.c:122
+  }
+}
+
+void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size_t nsamples, float gain) {
+  if (nsamples == 0) return;
+  int const threads = 256;
+  size_t blocks = (nsamples + threads - 1) / threads;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_ingest, dim3((unsigned)blocks), dim3(threads), 0, s, src, format, dst, nsamples, gain);
+}
+
+// Sum |s|^2 over the L new samples of each block (radio.c:123)
+__global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *__restrict__ sums) {
+  __shared__ float red_f[16];
+  __shared__ int red_i[16];
+  const float2 *p = x + (size_t)blockIdx.x * L;
+  float acc = 0;
+  int dummy = 0;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) acc += cnrm(p[i]);
+  block_sum_fi(acc, dummy, red_f, red_i);
+  if (threadIdx.x == 0) sums[blockIdx.x] = acc;
+}
+// E <- 0.5*(E + sum); if_power = E / L  (the accumulator is halved, never cleared: radio.c:143-145).
+// A block whose last sample came from the lost-packet zero fill completes inside radio.c:94-98,
+// which runs the filter but leaves block_energy and if_power alone: update[b] == 0 marks those.
+__global__ void k_block_energy_iir(const float *sums, const unsigned char *__restrict__ update, int nblocks, int L,
+                                   float *__restrict__ state, float *if_power) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float e = state[0], last = state[1];
+  for (int b = 0; b < nblocks; b++) {
+    e += sums[b];
+    if (update[b]) {
+      e *= 0.5f;
+      last = e / L;
+    }
+    if_power[b] = last;
+  }
+  state[0] = e;
+  state[1] = last;
+}
+
+void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nblocks, const unsigned char *update,
+                         float *energy_state, float *if_power) {
+  // if_power doubles as scratch for the per-block sums: the IIR pass reads sums[b] before writing if_power[b]
+  hipLaunchKernelGGL(k_block_energy_sum, dim3(nblocks), dim3(1024), 0, s, newsamples, L, if_power);
+  hipLaunchKernelGGL(k_block_energy_iir, dim3(1), dim3(64), 0, s, if_power, update, nblocks, L, energy_state, if_power);
+}
+
+// ---------------------------------------------------------------- full-FFT pre-detection filter
+// grid (channel, block); dynamic LDS = N float2.
+__global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,
+                              const float2 *__restrict__ tw, int compute_n0, float2 *__restrict__ spec_dump, int spec_ch) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  __shared__ float red_f[16];
+  __shared__ int red_i[16];
+  int const c = blockIdx.x, b = blockIdx.y;
+  int const N = g.N, Ndec = g.Ndec;
+
+  // --- NCO mix (radio.c:132-139): closed form of the phasor recurrence of osc.c:39-51
+  double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c], r = ch.lo_rate[c];
+  const float2 *x = window + (size_t)b * g.L;
+  double const mbase = (double)b * g.L;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    double const m = mbase + i;
+    double turns = ph0 + f0 * m;
+    if (r != 0.0) turns += r * (0.5 * m * (m - 1.0));
+    float2 const lo = phasor_turns(turns);
+    lds[bitrev((unsigned)i, g.log2N)] = cmul(x[i], lo);
+  }
+  lds_fft<-1>(lds, g.log2N, tw, g.tw_log2);  // filter.c:151
+
+  if (spec_dump != nullptr && c == spec_ch) {
+    float2 *o = spec_dump + (size_t)b * N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) o[i] = lds[i];
+  }
+
+  // --- compute_n0 (radio.c:383-425), status only
+  if (compute_n0) {
+    float const low = ch.low[c], high = ch.high[c];
+    float avg = INFINITY;
+    for (int iter = 0; iter < 2; iter++) {
+      float acc = 0;
+      int bins = 0;
+      for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        int const k = (n <= N / 2) ? n : n - N;
+        // the reference forms k*samprate in int (radio.c:407,409): keep its 32-bit wrap
+        int const prod = (int)((unsigned)k * (unsigned)g.samprate);
+        float const f = (float)prod / N;
+        if (f >= low && f <= high) continue;
+        float const p = cnrm(lds[n]);
+        if (p < avg * 2) {
+          acc += p;
+          bins++;
+        }
+      }
+      block_sum_fi(acc, bins, red_f, red_i);
+      avg = acc / bins;
+    }
+    if (threadIdx.x == 0) pl.n0raw[(size_t)c * g.max_blocks + b] = (float)(avg / (2.0 * N * g.samprate));
+  }
+
+  // --- slave: response multiply (filter.c:206-227), CROSS_CONJ (filter.c:239-249)
+  // G goes to the unused middle of the spectrum buffer: bins N_dec/2+1 .. N-N_dec/2 are never read
+  float2 *G = lds + (Ndec / 2 + 1);
+  const float2 *H = ch.resp + (size_t)c * Ndec;
+  bool const isb = (ch.flags[c] & FLAG_ISB) != 0;
+  for (int p = threadIdx.x; p <= Ndec / 2; p += blockDim.x) {
+    float2 gp = cmul(H[p], lds[p]);
+    if (p > 0 && p < Ndec / 2) {
+      int const k = Ndec - p;
+      float2 gn = cmul(H[k], lds[N - p]);
+      if (isb) {
+        float2 const pos = gp, neg = gn;
+        gp = cadd(pos, cconj(neg));
+        gn = csub(neg, cconj(pos));
+      }
+      G[bitrev((unsigned)k, g.log2Ndec)] = gn;
+    }
+    G[bitrev((unsigned)p, g.log2Ndec)] = gp;
+  }
+  lds_fft<+1>(G, g.log2Ndec, tw, g.tw_log2);  // filter.c:250
+
+  float2 *o = pl.filt + ((size_t)c * g.max_blocks + b) * g.olen;
+  for (int i = threadIdx.x; i < g.olen; i += blockDim.x) o[i] = G[Ndec - g.olen + i];  // filter.c:131
+}
+
+void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
+                        const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch) {
+  size_t const lds_bytes = (size_t)g.N * sizeof(float2);
+  static size_t configured = 0;
+  if (lds_bytes > configured) {
+    (void)hipFuncSetAttribute((const void *)k_filter_full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    configured = lds_bytes;
+  }
+  int const threads = g.N >= 4096 ? 1024 : 256;
+  hipLaunchKernelGGL(k_filter_full, dim3(nchan, nblocks), dim3(threads), lds_bytes, s, g, ch, pl, window, tw, compute_n0,
+                     spec_dump, spec_ch);
+}
+
+// ---------------------------------------------------------------- demodulators
+__device__ __forceinline__ void status_common(kq_chan_status &st, const Geom &g, const ChanDev &ch, const Planes &pl, int c,
+                                              int b, int compute_n0, float n0_rate) {
+  st.if_power = pl.if_power[b];
+  st.noise_gain = ch.noise_gain[c];
+  if (compute_n0) {
+    float const fresh = pl.n0raw[(size_t)c * g.max_blocks + b];
+    float n0 = ch.n0[c];
+    if (isnan(n0))
+      n0 = fresh;  // fm.c:79-80
+    else
+      n0 += n0_rate * (fresh - n0);  // fm.c:82 / am.c:47 / linear.c:124
+    ch.n0[c] = n0;
+    st.n0 = n0;
+  } else {
+    st.n0 = NAN;
+  }
+}
+
+// FM: one wave per channel, blocks in sequence.  Dynamic LDS carve (floats):
+//   S float2[olen] | Y float[olen] | OUT float[olen] | LV int[olen] | PV int[olen] | AIN float[AN] | F float2[AN]
+__global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ tw,
+                                                 const int *__restrict__ list, int nblocks, int compute_n0) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  int const c = list[blockIdx.x];
+  int const lane = threadIdx.x;
+  int const olen = g.olen, AN = g.Ndec, AM = g.Mdec, AL = g.olen;
+  float2 *S = lds;
+  float2 *F = S + olen;
+  float *Y = reinterpret_cast<float *>(F + AN);
+  float *OUT = Y + olen;
+  float *AIN = OUT + olen;
+  int *LV = reinterpret_cast<int *>(AIN + AN);
+  int *PV = LV + olen;
+
+  bool const flat = (ch.flags[c] & FLAG_FLAT) != 0;
+  float const gain = ch.fm_gain[c];
+  const float2 *HA = ch.aresp + (size_t)c * (AN / 2 + 1);
+  float2 state = ch.fm_state[c];
+  float lastaudio = ch.lastaudio[c];
+  int sq = ch.sq_count[c];
+  float foffset = ch.foffset[c], pdev = ch.pdev[c];
+  float *hist = ch.ahist + (size_t)c * (AM - 1);
+  for (int i = lane; i < AM - 1; i += 64) AIN[i] = hist[i];
+
+  for (int b = 0; b < nblocks; b++) {
+    const float2 *in = pl.filt + ((size_t)c * g.max_blocks + b) * olen;
+    // amplitude statistics (fm.c:91-103)
+    float sum_t = 0, sum_a = 0;
+    for (int n = lane; n < olen; n += 64) {
+      float2 const s = in[n];
+      S[n] = s;
+      float const t = cnrm(s);
+      sum_t += t;
+      sum_a += sqrtf(t);
+    }
+    sum_t = wave_sum(sum_t);
+    sum_a = wave_sum(sum_a);
+    float const bb = sum_t / (2 * olen);
+    float const amp = (float)((double)sum_a / (M_SQRT2 * olen));
+    float const variance = bb - amp * amp;
+    float snr = amp * amp / (2 * variance) - 1;
+    snr = (0.0f > snr) ? 0.0f : snr;  // misc.h max(): NaN propagates
+    if (snr > 2) {
+      sq = 0;  // fm.c:108-114
+    } else if (++sq > 1000) {
+      sq = 1000;
+    }
+    int blanked = 0;
+    __syncthreads();
+    if (sq < 2) {
+      float const thr = (float)(0.55 * 0.55 * amp * amp);  // fm.c:121
+      // pass 1: for every sample the last valid index <= n (LV) and < n (PV), -1 = none in this block
+      int carry = -1;
+      for (int cb = 0; cb < olen; cb += 64) {
+        int const n = cb + lane;
+        bool const valid = n < olen && cnrm(S[n < olen ? n : 0]) > thr;
+        int idx = valid ? n : -1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          int const up = __shfl_up(idx, o, 64);
+          if (lane >= o) idx = max(idx, up);
+        }
+        int ex = __shfl_up(idx, 1, 64);
+        if (lane == 0) ex = -1;
+        if (n < olen) {
+          LV[n] = max(idx, carry);
+          PV[n] = max(ex, carry);
+        }
+        carry = max(carry, __shfl(idx, 63, 64));
+      }
+      __syncthreads();
+      // pass 2: discriminator on valid samples (fm.c:130-132): arg(s_n * conj(s_prev_valid))
+      for (int n = lane; n < olen; n += 64) {
+        if (LV[n] == n) {
+          int const pv = PV[n];
+          float2 const st = (pv >= 0) ? cconj(S[pv]) : state;
+          float2 const pr = cmul(S[n], st);
+          Y[n] = atan2f(pr.y, pr.x);
+        }
+      }
+      __syncthreads();
+      // pass 3: weak samples repeat the last good audio value (fm.c:141)
+      float sum_y = 0, vmax = -INFINITY, vmin = INFINITY;
+      for (int n = lane; n < olen; n += 64) {
+        int const lv = LV[n];
+        float const y = (lv >= 0) ? Y[lv] : lastaudio;
+        OUT[n] = y;
+        sum_y += y;
+        if (lv == n) {
+          if (n > 0) {
+            vmax = fmaxf(vmax, y);
+            vmin = fminf(vmin, y);
+          }
+        } else {
+          blanked++;
+        }
+      }
+      sum_y = wave_sum(sum_y);
+      vmax = wave_max(vmax);
+      vmin = wave_min(vmin);
+      blanked = wave_sum_i(blanked);
+      __syncthreads();
+      // peak-deviation seeds: sample 0 seeds both only when it is valid (fm.c:125-139)
+      float const seed = (LV[0] == 0) ? Y[0] : 0.0f;
+      float pdev_pos = fmaxf(seed, vmax), pdev_neg = fminf(seed, vmin);
+      float const avg_f = sum_y / olen;
+      if (carry >= 0) {
+        state = cconj(S[carry]);
+        lastaudio = Y[carry];
+      }
+      if (sq < 1) {  // fm.c:146-154
+        foffset = (float)(g.dsamprate * avg_f * (0.5 * M_1_PI));
+        pdev_pos -= avg_f;
+        pdev_neg -= avg_f;
+        float const mx = (pdev_pos > -pdev_neg) ? pdev_pos : -pdev_neg;
+        pdev = (float)(g.dsamprate * mx * (0.5 * M_1_PI));
+      }
+    } else {
+      state = make_float2(0, 0);  // fm.c:156-160
+      lastaudio = 0;
+      for (int n = lane; n < olen; n += 64) OUT[n] = 0;
+    }
+    __syncthreads();
+    // post-detection overlap-save filter, REAL -> REAL (fm.c:162-171; filter.c:151,206-208,250)
+    for (int n = lane; n < AL; n += 64) AIN[AM - 1 + n] = OUT[n];
+    __syncthreads();
+    float *aud = pl.audio + ((size_t)c * g.max_blocks + b) * (2 * (size_t)olen);
+    if (!flat) {
+      for (int i = lane; i < AN; i += 64) F[bitrev((unsigned)i, g.log2Ndec)] = make_float2(AIN[i], 0.f);
+      lds_fft<-1>(F, g.log2Ndec, tw, g.tw_log2);
+      // multiply DC..Nyquist (filter.c:206-208) and Hermitian-extend for the c2r transform, which
+      // ignores the imaginary parts of DC and Nyquist.  Lane k touches only F[k] and F[AN-k].
+      for (int k = lane; k <= AN / 2; k += 64) {
+        float2 const gk = cmul(HA[k], F[k]);
+        if (k == 0 || k == AN / 2) {
+          F[k] = make_float2(gk.x, 0.f);
+        } else {
+          F[k] = gk;
+          F[AN - k] = cconj(gk);
+        }
+      }
+      __syncthreads();
+      // bit-reverse in place, then backward transform
+      for (int i = lane; i < AN; i += 64) {
+        unsigned const r = bitrev((unsigned)i, g.log2Ndec);
+        if (r > (unsigned)i) {
+          float2 const t = F[i];
+          F[i] = F[r];
+          F[r] = t;
+        }
+      }
+      lds_fft<+1>(F, g.log2Ndec, tw, g.tw_log2);
+      for (int n = lane; n < AL; n += 64) aud[n] = F[AN - AL + n].x * gain;  // fm.c:169-170
+    } else {
+      for (int n = lane; n < AL; n += 64) aud[n] = OUT[n];
+    }
+    __syncthreads();
+    // overlap-save history shift (filter.c:168)
+    for (int base = 0; base < AM - 1; base += 64) {
+      int const i = base + lane;
+      float const v = (i < AM - 1) ? AIN[AL + i] : 0.f;
+      __syncthreads();
+      if (i < AM - 1) AIN[i] = v;
+      __syncthreads();
+    }
+    if (lane == 0) {
+      kq_chan_status st;
+      status_common(st, g, ch, pl, c, b, compute_n0, .01f);
+      st.bb_power = bb;
+      st.snr = snr;
+      st.foffset = foffset;
+      st.pdeviation = pdev;
+      st.agc_gain = 0;
+      st.squelch_count = sq;
+      st.hangcount = 0;
+      st.blanked = blanked;
+      st.nout = AL;
+      pl.status[(size_t)c * g.max_blocks + b] = st;
+    }
+  }
+  for (int i = lane; i < AM - 1; i += 64) hist[i] = AIN[i];
+  if (lane == 0) {
+    ch.fm_state[c] = state;
+    ch.lastaudio[c] = lastaudio;
+    ch.sq_count[c] = sq;
+    ch.foffset[c] = foffset;
+    ch.pdev[c] = pdev;
+  }
+}
+
+// AM: envelope, carrier removal, hang AGC -- a strictly sequential recurrence per channel
+// (am.c:55-75), so one lane per channel and channels across lanes.
+__global__ void k_demod_am(Geom g, ChanDev ch, Planes pl, const int *__restrict__ list, int nchan, int nblocks,
+                           int compute_n0) {
+  int const t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchan) return;
+  int const c = list[t];
+  int const olen = g.olen;
+  float const headroom = ch.headroom[c], recovery = ch.recovery[c];
+  int const hangmax = ch.hangmax[c];
+  float gain = ch.gain[c], dc = ch.dc[c];
+  int hang = ch.hang[c];
+  for (int b = 0; b < nblocks; b++) {
+    const float2 *in = pl.filt + ((size_t)c * g.max_blocks + b) * olen;
+    float *aud = pl.audio + ((size_t)c * g.max_blocks + b) * (2 * (size_t)olen);
+    float signal = 0;
+    for (int n = 0; n < olen; n++) {
+      float const sq = cnrm(in[n]);
+      signal += sq;
+      float const samp = sqrtf(sq);
+      dc += 0.0001f * (samp - dc);  // am.c:34,62
+      if (isnan(gain)) {
+        gain = headroom / dc;
+      } else if (gain * dc > headroom) {
+        gain = headroom / dc;
+        hang = hangmax;
+      } else if (hang != 0) {
+        hang--;
+      } else {
+        gain *= recovery;
+      }
+      aud[n] = (samp - dc) * gain;
+    }
+    kq_chan_status st;
+    status_common(st, g, ch, pl, c, b, compute_n0, .001f);
+    st.bb_power = signal / (2 * olen);  // am.c:78
+    st.snr = 0;
+    st.foffset = 0;
+    st.pdeviation = 0;
+    st.agc_gain = gain;
+    st.squelch_count = 0;
+    st.hangcount = hang;
+    st.blanked = 0;
+    st.nout = olen;
+    pl.status[(size_t)c * g.max_blocks + b] = st;
+  }
+  ch.gain[c] = gain;
+  ch.dc[c] = dc;
+  ch.hang[c] = hang;
+}
+
+// Linear (SSB/CW/IQ/ISB without carrier PLL): hang AGC on |s|, optional shift NCO, mono = Re or
+// stereo = I/Q (linear.c:251-300).
+__global__ void k_demod_linear(Geom g, ChanDev ch, Planes pl, const int *__restrict__ list, int nchan, int nblocks,
+                               int compute_n0) {
+  int const t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nchan) return;
+  int const c = list[t];
+  int const olen = g.olen;
+  float const headroom = ch.headroom[c], recovery = ch.recovery[c];
+  int const hangmax = ch.hangmax[c];
+  bool const stereo = (ch.flags[c] & FLAG_STEREO) != 0;
+  double const sh_ph = ch.sh_phase[c], sh_f = ch.sh_freq[c];
+  float gain = ch.gain[c];
+  int hang = ch.hang[c];
+  for (int b = 0; b < nblocks; b++) {
+    const float2 *in = pl.filt + ((size_t)c * g.max_blocks + b) * olen;
+    float *aud = pl.audio + ((size_t)c * g.max_blocks + b) * (2 * (size_t)olen);
+    float signal = 0, noise = 0;
+    for (int n = 0; n < olen; n++) {
+      float2 s = in[n];
+      float const rp = s.x * s.x, ip = s.y * s.y;
+      signal += rp;
+      noise += ip;
+      float const amplitude = sqrtf(rp + ip);
+      if (isnan(gain)) {
+        gain = headroom / amplitude;
+      } else if (amplitude * gain > headroom) {
+        gain = headroom / amplitude;
+        hang = hangmax;
+      } else if (hang != 0) {
+        hang--;
+      } else {
+        gain *= recovery;
+      }
+      s = make_float2(s.x * gain, s.y * gain);
+      if (sh_f != 0.0) {  // linear.c:283-289
+        double const j = (double)b * olen + n;
+        s = cmul(s, phasor_turns(sh_ph + sh_f * j));
+      }
+      if (stereo) {
+        aud[2 * n] = s.x;
+        aud[2 * n + 1] = s.y;
+      } else {
+        aud[n] = s.x;
+      }
+    }
+    kq_chan_status st;
+    status_common(st, g, ch, pl, c, b, compute_n0, .001f);
+    st.bb_power = (signal + noise) / (2 * olen);  // linear.c:302
+    st.snr = NAN;                                 // linear.c:309
+    st.foffset = 0;
+    st.pdeviation = 0;
+    st.agc_gain = gain;
+    st.squelch_count = 0;
+    st.hangcount = hang;
+    st.blanked = 0;
+    st.nout = stereo ? 2 * olen : olen;
+    pl.status[(size_t)c * g.max_blocks + b] = st;
+  }
+  ch.gain[c] = gain;
+  ch.hang[c] = hang;
+}
+
+void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_fm,
+                   int n_fm, const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0) {
+  if (n_fm > 0) {
+    size_t const lds_bytes = (size_t)g.olen * (8 + 4 + 4 + 4 + 4) + (size_t)g.Ndec * (8 + 4);
+    static size_t configured = 0;
+    if (lds_bytes > configured) {
+      (void)hipFuncSetAttribute((const void *)k_demod_fm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      configured = lds_bytes;
+    }
+    hipLaunchKernelGGL(k_demod_fm, dim3(n_fm), dim3(64), lds_bytes, s, g, ch, pl, tw, list_fm, nblocks, compute_n0);
+  }
+  if (n_am > 0)
+    hipLaunchKernelGGL(k_demod_am, dim3((n_am + 63) / 64), dim3(64), 0, s, g, ch, pl, list_am, n_am, nblocks, compute_n0);
+  if (n_lin > 0)
+    hipLaunchKernelGGL(k_demod_linear, dim3((n_lin + 63) / 64), dim3(64), 0, s, g, ch, pl, list_lin, n_lin, nblocks,
+                       compute_n0);
+}
+
+// ---------------------------------------------------------------- single transforms (compat surface)
+__global__ void k_fft_single(const float2 *__restrict__ in, float2 *__restrict__ out, int log2n, int sign,
+                             const float2 *__restrict__ tw, int tw_log2) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  int const n = 1 << log2n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) lds[bitrev((unsigned)i, log2n)] = in[i];
+  if (sign < 0)
+    lds_fft<-1>(lds, log2n, tw, tw_log2);
+  else
+    lds_fft<+1>(lds, log2n, tw, tw_log2);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = lds[i];
+}
+
+void launch_fft_single(hipStream_t s, const float2 *in, float2 *out, int log2n, int sign, const float2 *tw, int tw_log2) {
+  size_t const lds_bytes = sizeof(float2) << log2n;
+  static size_t configured = 0;
+  if (lds_bytes > configured) {
+    (void)hipFuncSetAttribute((const void *)k_fft_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    configured = lds_bytes;
+  }
+  int const threads = (1 << log2n) >= 4096 ? 1024 : 256;
+  hipLaunchKernelGGL(k_fft_single, dim3(1), dim3(threads), lds_bytes, s, in, out, log2n, sign, tw, tw_log2);
+}
+
+// One slave execution on a resident master spectrum: all four in/out type combinations of
+// filter.c:206-250.  out: N_dec float2 (complex out) or N_dec floats packed in float2[N_dec/2] (real out).
+__global__ void k_slave_single(const float2 *__restrict__ X, const float2 *__restrict__ H, float2 *__restrict__ out, int N,
+                               int Ndec, int log2Ndec, int in_real, int out_type, const float2 *__restrict__ tw, int tw_log2) {
+  extern __shared__ __attribute__((aligned(16))) float2 G[];
+  bool const out_real = out_type == 3;
+  for (int p = threadIdx.x; p <= Ndec / 2; p += blockDim.x) {
+    float2 gp = cmul(H[p], X[p]);
+    bool const interior = p > 0 && p < Ndec / 2;
+    int const k = Ndec - p;
+    float2 gn = make_float2(0, 0);
+    if (interior) {
+      if (in_real) {
+        if (!out_real) gn = cmul(H[k], cconj(X[p]));  // filter.c:214-216
+      } else if (!out_real) {
+        gn = cmul(H[k], X[N - p]);  // filter.c:225-227
+      } else {
+        gp = cadd(gp, cconj(cmul(H[k], X[N - p])));  // filter.c:232-234
+      }
+      if (out_type == 2) {  // CROSS_CONJ, filter.c:239-249
+        float2 const pos = gp, neg = gn;
+        gp = cadd(pos, cconj(neg));
+        gn = csub(neg, cconj(pos));
+      }
+      if (out_real) gn = cconj(gp);  // c2r Hermitian extension
+      G[bitrev((unsigned)k, log2Ndec)] = gn;
+    } else if (out_real) {
+      gp.y = 0;  // c2r ignores the imaginary parts of DC and Nyquist
+    }
+    G[bitrev((unsigned)p, log2Ndec)] = gp;
+  }
+  lds_fft<+1>(G, log2Ndec, tw, tw_log2);
+  if (out_real) {
+    float *o = reinterpret_cast<float *>(out);
+    for (int i = threadIdx.x; i < Ndec; i += blockDim.x) o[i] = G[i].x;
+  } else {
+    for (int i = threadIdx.x; i < Ndec; i += blockDim.x) out[i] = G[i];
+  }
+}
+
+void launch_slave_single(hipStream_t s, const float2 *fdomain, const float2 *resp, float2 *out, int N, int Ndec, int in_real,
+                         int out_type, const float2 *tw, int tw_log2) {
+  int log2Ndec = 0;
+  while ((1 << log2Ndec) < Ndec) log2Ndec++;
+  size_t const lds_bytes = sizeof(float2) * (size_t)Ndec;
+  static size_t configured = 0;
+  if (lds_bytes > configured) {
+    (void)hipFuncSetAttribute((const void *)k_slave_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    configured = lds_bytes;
+  }
+  int const threads = Ndec >= 4096 ? 1024 : 256;
+  hipLaunchKernelGGL(k_slave_single, dim3(1), dim3(threads), lds_bytes, s, fdomain, resp, out, N, Ndec, log2Ndec, in_real,
+                     out_type, tw, tw_log2);
+}
+
+}  // namespace kq

@@ -22,6 +22,7 @@
 
 #define DB2VOLTAGE(x) (powf(10., (x) / 20.))   /* dsp.h:38 */
 #define M_1_2PI (0.5 * M_1_PI)                 /* dsp.h:11 */
+#define MAXF(x, y) ((x) > (y) ? (x) : (y))     /* misc.h:17-21: a NaN second argument propagates */
 
 struct kqo_chan {
   kqo_chan_cfg cfg;
@@ -232,7 +233,7 @@ static int fm_block(kqo_chan *c, float *audio){
   avg_amp /= M_SQRT2 * olen;
   float const variance = c->bb_power - avg_amp * avg_amp;
   c->snr = avg_amp * avg_amp / (2 * variance) - 1;
-  c->snr = fmaxf(0.0f, c->snr);                                            /* fm.c:103 (misc.h max) */
+  c->snr = MAXF(0.0f, c->snr);                                             /* fm.c:103 (misc.h max) */
 
   if(c->snr > 2){                                                          /* fm.c:108-114 */
     c->snr_below_threshold = 0;
@@ -265,7 +266,7 @@ static int fm_block(kqo_chan *c, float *audio){
       c->foffset = c->dsamprate * avg_f * M_1_2PI;
       pdev_pos -= avg_f;
       pdev_neg -= avg_f;
-      c->pdeviation = c->dsamprate * fmaxf(pdev_pos, -pdev_neg) * M_1_2PI;
+      c->pdeviation = c->dsamprate * MAXF(pdev_pos, -pdev_neg) * M_1_2PI;
     }
   } else {
     c->fm_state = 0;                                                       /* fm.c:156-160 */

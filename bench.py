@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the ka9q-radio per-channel DSP hot path on MI355X.
+
+One *step* = one pass of the whole hot path (IF power, NCO mix + overlap-save filter/decimator,
+FM/AM/linear demodulators) over one batch of `--blocks` overlap-save blocks for every channel of
+this GPU, with the front-end I/Q already resident in HBM.
+
+Default workload (N=1): BASELINE.json configs[3] per-GPU share = the north_star target shape:
+1024 FM channels, 16384-point overlap-save (L=8192, M=8193), decimate 256, 10 MS/s synthetic I/Q.
+With --gpus N the channels are sharded (1024 per GPU, weak scaling, configs[3] at N=8) and every
+batch of front-end I/Q is broadcast from rank 0 over RCCL (torch.distributed backend "nccl").
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg4", help="workload: cfg2|cfg3|cfg4|cfg5 (ka9q_sdr_amd/workload.py)")
+    ap.add_argument("--channels", type=int, default=None, help="channels per GPU (default: the config's)")
+    ap.add_argument("--blocks", type=int, default=64, help="overlap-save blocks per step")
+    ap.add_argument("--fwd", default="auto", choices=["auto", "full", "pruned"])
+    ap.add_argument("--n0", type=int, default=0, help="1: also run the status-only compute_n0 every block")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(name, geom, plan, iq_host, target_s):
+    """Oracle ('port') timed on this box's host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import kq_oracle as ko
+    from common import oracle_cfg
+    cores = os.cpu_count() or 1
+    L = geom["L"]
+    nchan = min(len(plan), 2 * cores)
+    cfgs = [oracle_cfg(p, geom["samprate"], L, geom["M"], geom["D"], compute_n0=0) for p in plan[:nchan]]
+    nblocks = 4
+    t, _ = ko.cpu_baseline(cfgs, iq_host, nblocks, cores)            # calibration pass
+    rate = nchan * nblocks / t
+    nblocks = int(max(4, min(len(iq_host) // L, target_s * rate / nchan)))
+    t, _ = ko.cpu_baseline(cfgs, iq_host, nblocks, cores)
+    msps = nchan * nblocks * L / t / 1e6
+    return {"value": round(msps, 3), "unit": "Msamples/s (channel-samples)", "cores": cores, "kind": "port",
+            "sample": "%d channels x %d blocks of %s (oracle C restatement, own radix-2 FFT, no compute_n0), "
+                      "%d threads, %.1f s" % (nchan, nblocks, name, cores, t)}
+
+
+def main():
+    a = parse()
+    import torch
+    import ka9q_sdr_amd as kq
+    from ka9q_sdr_amd import workload as wl
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X: there is no CPU path to measure"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    geom = dict(wl.GEOMETRY[a.config])
+    L, M, D, fs = geom["L"], geom["M"], geom["D"], geom["samprate"]
+    C = a.channels or geom["channels"]
+    B = a.blocks
+    plan = wl.channel_plan(a.config, C, first=rank * C)   # shard: rank r owns channels [r*C, (r+1)*C)
+
+    fwd = {"auto": kq.KQ_FWD_AUTO, "full": kq.KQ_FWD_FULL, "pruned": kq.KQ_FWD_PRUNED}[a.fwd]
+    stream = torch.cuda.Stream(device=dev)     # an explicit (non-null) HIP stream handed to the library
+    torch.cuda.set_stream(stream)
+    bank = kq.Bank(fs, L, M, D, C, B, device=local_rank, compute_n0=bool(a.n0), fwd_mode=fwd,
+                   stream=stream.cuda_stream)
+    for p in plan:
+        bank.add_channel(wl.bank_channel_config(p))
+
+    # Front-end I/Q: window layout [M-1 history | B*L new samples], generated once on rank 0
+    nwin = (M - 1) + B * L
+    bufs = [torch.zeros(nwin, dtype=torch.complex64, device=dev) for _ in range(2)]
+    iq_host = None
+    if rank == 0:
+        iq_host = wl.make_iq(fs, nwin, seed=0x6B613971)
+        bufs[0].copy_(torch.from_numpy(iq_host))
+        bufs[1].copy_(bufs[0])
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    ready = [torch.cuda.Event() for _ in range(2)]
+    freed = [torch.cuda.Event() for _ in range(2)]
+
+    def bcast(i):
+        """Front-end fan-out (the reference's UDP multicast, multicast.c:143-237): rank 0 -> all, on the side stream."""
+        if world == 1:
+            return
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(freed[i])
+            dist.broadcast(bufs[i], src=0)
+            ready[i].record(comm_stream)
+
+    def step(k):
+        i = k & 1
+        if world > 1:
+            stream.wait_event(ready[i])
+        bank.process_resident(bufs[i].data_ptr(), B)
+        if world > 1:
+            freed[i].record(stream)
+            bcast(i)          # refill this buffer for step k+2 while step k+1 computes
+
+    if world > 1:
+        for i in range(2):
+            freed[i].record(stream)
+            bcast(i)
+    for k in range(a.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    bank.enable_timing(True)
+    bank.timing(reset=True)
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        step(a.warmup + k)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    tm = bank.timing(reset=True)
+    bank.enable_timing(False)
+
+    if rank == 0:
+        total_ch = C * world
+        chan_samples = total_ch * B * L * a.steps
+        value = chan_samples / elapsed / 1e6
+        front_end_msps = B * L * a.steps / elapsed / 1e6
+        per_kind = {}
+        for p in plan:
+            per_kind[p["demod"]] = per_kind.get(p["demod"], 0) + 1
+        abytes = sum(wl.algorithmic_bytes(geom, p["demod"], p.get("channels", 1) == 2) for p in plan) * B
+        k_ms = tm["filter_ms"] / max(1, tm["filter_launches"])
+        achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "input Msamples/s + channels @ real-time, 16384-pt overlap-save",
+            "value": round(value, 1),
+            "unit": "Msamples/s (channel-samples: front-end input samples x channels, all GPUs)",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "%s: %d channels/GPU (%s), N=%d (L=%d, M=%d), decimate %d, %.3g MS/s synthetic complex-float "
+                            "I/Q, %d blocks/step, fwd=%s, compute_n0=%d" %
+                            (a.config, C, "+".join("%d %s" % (v, k) for k, v in sorted(per_kind.items())), L + M - 1, L, M, D,
+                             fs / 1e6, B, {1: "full", 2: "pruned"}[bank.fwd_mode], a.n0),
+                "channels_total": total_ch,
+                "front_end_Msamples_per_s": round(front_end_msps, 2),
+                "realtime_factor": round(front_end_msps * 1e6 / fs, 2),
+                "channels_at_realtime": int(total_ch * front_end_msps * 1e6 / fs),
+                "parallelism": "channels sharded x%d, front-end I/Q broadcast over RCCL" % world if world > 1 else "1 GPU",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "kernel": "pre-detection filter (mix + forward FFT + response + IFFT)",
+                "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": abytes,
+                "demod_ms": round(tm["demod_ms"] / max(1, tm["filter_launches"]), 4),
+            },
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.config, geom, plan, iq_host[M - 1:], a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    bank.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -125,6 +125,14 @@ struct kq_bank {
   bool lists_dirty = true;
   float *energy_state = nullptr;
   unsigned char *update_dev = nullptr;
+  // per-call parameters (5 double planes of max_channels + max_blocks update flags) travel through
+  // pinned staging slots so kq_bank_process never has to synchronise the stream
+  static constexpr int kSlots = 4;
+  double *osc_dev = nullptr;
+  unsigned char *stage_host[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t stage_ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+  int stage_next = 0;
+  size_t stage_bytes = 0;
   float2 *spec_dump = nullptr;
   int spec_ch = -1;
   void *stage_dev = nullptr;  // staging for host-side raw I/Q before conversion
@@ -269,10 +277,15 @@ struct Scope {
   }
 };
 
-// Oscillator parameters for a call whose first window starts at absolute sample n_w
-int upload_osc(kq_bank *b, int64_t n_w) {
-  size_t const C = b->chans.size();
-  std::vector<double> ph(C), fr(C), rt(C), sp(C), sf(C);
+// Per-call parameters: oscillator phase/step/sweep for a call whose first window starts at absolute
+// sample n_w, the shift oscillator at the first output sample, and the IF-power update flags.
+int upload_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsigned nblocks) {
+  size_t const C = b->chans.size(), Cmax = b->cfg.max_channels;
+  int const slot = b->stage_next;
+  b->stage_next = (slot + 1) % kq_bank::kSlots;
+  HIP_TRY(hipEventSynchronize(b->stage_ev[slot]));  // the copy that last used this slot has completed
+  double *pl = reinterpret_cast<double *>(b->stage_host[slot]);
+  double *ph = pl, *fr = pl + Cmax, *rt = pl + 2 * Cmax, *sp = pl + 3 * Cmax, *sf = pl + 4 * Cmax;
   for (size_t c = 0; c < C; c++) {
     HostChan const &h = b->chans[c];
     double p = h.lo2.phase_at(n_w), f = h.lo2.step_at(n_w), r = h.lo2.sweep();
@@ -284,16 +297,15 @@ int upload_osc(kq_bank *b, int64_t n_w) {
     ph[c] = p - std::floor(p);
     fr[c] = f;
     rt[c] = r;
-    sp[c] = h.shift.phase_at(b->out_abs);
-    sp[c] -= std::floor(sp[c]);
+    double q = h.shift.phase_at(b->out_abs);
+    sp[c] = q - std::floor(q);
     sf[c] = h.shift.step_at(b->out_abs);
   }
-  if (upload(b, b->chd.lo_phase, ph.data(), C * sizeof(double))) return -1;
-  if (upload(b, b->chd.lo_freq, fr.data(), C * sizeof(double))) return -1;
-  if (upload(b, b->chd.lo_rate, rt.data(), C * sizeof(double))) return -1;
-  if (upload(b, b->chd.sh_phase, sp.data(), C * sizeof(double))) return -1;
-  if (upload(b, b->chd.sh_freq, sf.data(), C * sizeof(double))) return -1;
-  HIP_TRY(hipStreamSynchronize(b->stream));  // host vectors are about to die
+  unsigned char *flags = b->stage_host[slot] + 5 * Cmax * sizeof(double);
+  memcpy(flags, update, nblocks);
+  HIP_TRY(hipMemcpyAsync(b->osc_dev, b->stage_host[slot], 5 * Cmax * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(b->update_dev, flags, nblocks, hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
   return 0;
 }
 
@@ -320,9 +332,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     return -1;
   }
   if (b->lists_dirty && upload_lists(b)) return -1;
-  if (upload_osc(b, b->n_abs - (g.M - 1))) return -1;
-  if (upload(b, b->update_dev, update_host, nblocks)) return -1;
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (upload_call_params(b, b->n_abs - (g.M - 1), update_host, nblocks)) return -1;
   {
     Scope t(b, 2);
     kq::launch_block_energy(b->stream, window + (g.M - 1), g.L, (int)nblocks, b->update_dev, b->energy_state, b->pl.if_power);
@@ -473,11 +483,20 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.recovery, C);
   rc |= dev_alloc(&b->chd.hangmax, C);
   rc |= dev_alloc(&b->chd.noise_gain, C);
-  rc |= dev_alloc(&b->chd.lo_phase, C);
-  rc |= dev_alloc(&b->chd.lo_freq, C);
-  rc |= dev_alloc(&b->chd.lo_rate, C);
-  rc |= dev_alloc(&b->chd.sh_phase, C);
-  rc |= dev_alloc(&b->chd.sh_freq, C);
+  rc |= dev_alloc(&b->osc_dev, 5 * C);
+  b->chd.lo_phase = b->osc_dev;
+  b->chd.lo_freq = b->osc_dev + C;
+  b->chd.lo_rate = b->osc_dev + 2 * C;
+  b->chd.sh_phase = b->osc_dev + 3 * C;
+  b->chd.sh_freq = b->osc_dev + 4 * C;
+  b->stage_bytes = 5 * C * sizeof(double) + B;
+  for (int k = 0; k < kq_bank::kSlots && !rc; k++) {
+    if (hipHostMalloc((void **)&b->stage_host[k], b->stage_bytes, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&b->stage_ev[k], hipEventDisableTiming) != hipSuccess) {
+      set_err("pinned staging allocation failed");
+      rc = -1;
+    }
+  }
   rc |= dev_alloc(&b->chd.fm_state, C);
   rc |= dev_alloc(&b->chd.lastaudio, C);
   rc |= dev_alloc(&b->chd.sq_count, C);
@@ -523,7 +542,7 @@ int kq_bank_destroy(kq_bank *b) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   void *ptrs[] = {b->ring[0], b->ring[1], b->tw, b->chan_tw, b->chd.mode, b->chd.flags, b->chd.low, b->chd.high, b->chd.resp,
                   b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain,
-                  b->chd.lo_phase, b->chd.lo_freq, b->chd.lo_rate, b->chd.sh_phase, b->chd.sh_freq, b->chd.fm_state,
+                  b->osc_dev, b->chd.fm_state,
                   b->chd.lastaudio, b->chd.sq_count, b->chd.ahist, b->chd.foffset, b->chd.pdev, b->chd.gain, b->chd.hang,
                   b->chd.dc, b->chd.n0, b->pl.filt, b->pl.audio, b->pl.status, b->pl.n0raw, b->pl.if_power, b->energy_state,
                   b->update_dev, b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev};
@@ -534,6 +553,10 @@ int kq_bank_destroy(kq_bank *b) {
       (void)hipEventDestroy(p.a);
       (void)hipEventDestroy(p.b);
     }
+  for (int k = 0; k < kq_bank::kSlots; k++) {
+    if (b->stage_host[k]) (void)hipHostFree(b->stage_host[k]);
+    if (b->stage_ev[k]) (void)hipEventDestroy(b->stage_ev[k]);
+  }
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
   return 0;

@@ -103,3 +103,15 @@ def algorithmic_bytes(name_or_geom, demod="fm", stereo=False):
     if demod == "fm":
         b += 8 * (ndec // 2 + 1)
     return b
+
+
+def bank_channel_config(p):
+    """Plan entry -> kq_channel_config for kq_bank_add_channel."""
+    from . import bank as _b
+    demod = {"fm": _b.KQ_FM_DEMOD, "am": _b.KQ_AM_DEMOD, "linear": _b.KQ_LINEAR_DEMOD}[p["demod"]]
+    return _b.channel_config(demod_type=demod, low=p["low"], high=p["high"], second_lo=p.get("second_lo", 0.0),
+                             flat=p.get("flat", 0), isb=p.get("isb", 0), channels=p.get("channels", 1),
+                             kaiser_beta=p.get("kaiser_beta", 3.0), headroom=p.get("headroom", HEADROOM),
+                             hangtime=p.get("hangtime", 0.0), recovery_rate=p.get("recovery_rate", 0.0),
+                             doppler=p.get("doppler", 0.0), doppler_rate=p.get("doppler_rate", 0.0),
+                             shift=p.get("shift", 0.0))

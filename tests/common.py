@@ -5,7 +5,6 @@ import kq_oracle as ko
 import ka9q_sdr_amd as kq
 
 _DEMOD_O = {"fm": ko.KQO_FM, "am": ko.KQO_AM, "linear": ko.KQO_LINEAR}
-_DEMOD_K = {"fm": kq.KQ_FM_DEMOD, "am": kq.KQ_AM_DEMOD, "linear": kq.KQ_LINEAR_DEMOD}
 
 
 def oracle_cfg(p, samprate, L, M, D, compute_n0=0, gain_factor=1.0):
@@ -18,12 +17,8 @@ def oracle_cfg(p, samprate, L, M, D, compute_n0=0, gain_factor=1.0):
 
 
 def bank_cfg(p):
-    return kq.channel_config(demod_type=_DEMOD_K[p["demod"]], low=p["low"], high=p["high"],
-                             second_lo=p.get("second_lo", 0.0), flat=p.get("flat", 0), isb=p.get("isb", 0),
-                             channels=p.get("channels", 1), kaiser_beta=p.get("kaiser_beta", 3.0),
-                             headroom=p.get("headroom", 10 ** (-15 / 20)), hangtime=p.get("hangtime", 0.0),
-                             recovery_rate=p.get("recovery_rate", 0.0), doppler=p.get("doppler", 0.0),
-                             doppler_rate=p.get("doppler_rate", 0.0), shift=p.get("shift", 0.0))
+    from ka9q_sdr_amd import workload as wl
+    return wl.bank_channel_config(p)
 
 
 def rel_rms(a, b):

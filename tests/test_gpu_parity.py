@@ -169,3 +169,16 @@ def test_int16_ingest_and_zero_fill(gpu):
         np.testing.assert_allclose(st["if_power"], want_s[b]["if_power"], rtol=2e-4)
         assert rel_rms(bank.audio(0, b), want_a[b]) < AUDIO_TOL or np.abs(want_a[b]).max() == 0
     bank.close()
+
+
+@pytest.mark.parametrize("name,nchan,nblocks", [("cfg3", 40, 5), ("cfg4", 33, 4)])
+def test_config_geometry_pruned(gpu, name, nchan, nblocks):
+    """Pruned forward path (only the N/D bins the slave reads) against the oracle's full N-point FFT."""
+    g = wl.GEOMETRY[name]
+    plan = wl.channel_plan(name, nchan)
+    plan[3]["isb"] = 1 if plan[3]["demod"] == "linear" else 0
+    iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=9)
+    want = run_oracle(plan, g, iq, nblocks)
+    got, mode = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_PRUNED, per_call=3)
+    assert mode == kq.KQ_FWD_PRUNED
+    _compare(plan, got, want)

@@ -84,7 +84,10 @@ def main():
     L, M, D, fs = geom["L"], geom["M"], geom["D"], geom["samprate"]
     C = a.channels or geom["channels"]
     B = a.blocks
-    plan = wl.channel_plan(a.config, C, first=rank * C)   # shard: rank r owns channels [r*C, (r+1)*C)
+    from ka9q_sdr_amd.shard import FrontEndFanout, shard_range
+    first, count = shard_range(C * world, world, rank)    # weak scaling: C channels per GPU
+    assert count == C
+    plan = wl.channel_plan(a.config, C, first=first)
 
     fwd = {"auto": kq.KQ_FWD_AUTO, "full": kq.KQ_FWD_FULL, "pruned": kq.KQ_FWD_PRUNED}[a.fwd]
     stream = torch.cuda.Stream(device=dev)     # an explicit (non-null) HIP stream handed to the library
@@ -102,32 +105,20 @@ def main():
         iq_host = wl.make_iq(fs, nwin, seed=0x6B613971)
         bufs[0].copy_(torch.from_numpy(iq_host))
         bufs[1].copy_(bufs[0])
-    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
-    ready = [torch.cuda.Event() for _ in range(2)]
-    freed = [torch.cuda.Event() for _ in range(2)]
-
-    def bcast(i):
-        """Front-end fan-out (the reference's UDP multicast, multicast.c:143-237): rank 0 -> all, on the side stream."""
-        if world == 1:
-            return
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(freed[i])
-            dist.broadcast(bufs[i], src=0)
-            ready[i].record(comm_stream)
+    # Front-end fan-out (the reference's UDP multicast, multicast.c:143-237): rank 0 -> all over RCCL,
+    # double buffered on a side stream so batch k+1 travels while batch k is processed
+    fan = FrontEndFanout(bufs, src=0)
 
     def step(k):
         i = k & 1
-        if world > 1:
-            stream.wait_event(ready[i])
-        bank.process_resident(bufs[i].data_ptr(), B)
-        if world > 1:
-            freed[i].record(stream)
-            bcast(i)          # refill this buffer for step k+2 while step k+1 computes
+        buf = fan.acquire(i, stream)
+        bank.process_resident(buf.data_ptr(), B)
+        fan.release(i, stream)
+        fan.post(i, stream)       # refill this buffer for step k+2 while step k+1 computes
 
-    if world > 1:
-        for i in range(2):
-            freed[i].record(stream)
-            bcast(i)
+    for i in range(2):
+        fan.release(i, stream)
+        fan.post(i, stream)
     for k in range(a.warmup):
         step(k)
     torch.cuda.synchronize()

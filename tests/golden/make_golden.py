@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz.  Run in the build container (needs /root/reference for the NCO).
+
+  osc_*.npz      : sequences produced by the REFERENCE's own osc.c + dsp.c (oracle/_ref/libref_osc.so):
+                   they pin the oracle NCO wherever the tests run.
+  chain_*.npz    : inputs and outputs of the oracle chain (oracle/libkq_oracle.so).  The reference's
+                   filter / demodulator sources need FFTW headers this image lacks, so these are
+                   oracle-generated regression vectors, NOT reference outputs (parity unpinned).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+
+import kq_oracle as ko  # noqa: E402
+from ka9q_sdr_amd import workload as wl  # noqa: E402
+from common import oracle_cfg  # noqa: E402
+from test_oracle_osc import SCRIPTS, _run_ref  # noqa: E402
+
+
+def osc():
+    assert ko.ref_osc_lib() is not None, "build oracle/_ref first (make -C oracle ref)"
+    for name, (script, n) in SCRIPTS.items():
+        seq, steps = _run_ref(script, n)
+        idx = np.unique(np.concatenate([np.arange(0, n, 97), np.arange(max(0, n - 50), n),
+                                        np.arange(16380, min(n, 16390)), np.arange(min(n, 32764), min(n, 32774))]))
+        np.savez_compressed(os.path.join(HERE, "osc_%s.npz" % name), index=idx, phasor=seq[idx], steps=steps)
+
+
+def chain():
+    geom = dict(samprate=192000, L=512, M=513, D=4)
+    fs, L = geom["samprate"], geom["L"]
+    nblocks = 6
+    iq = wl.make_iq(fs, nblocks * L, seed=21, emitters=range(24, 40))
+    for tag, e, extra in (("fm", 28, {}), ("fmflat", 29, {"flat": 1}), ("am", 30, {}), ("usb", 31, {}), ("lsb", 35, {}),
+                          ("isb", 31, {"isb": 1, "channels": 2, "low": -5000.0, "high": 5000.0})):
+        p = wl._mode_params(wl.emitter_kind(e), e)
+        p.update(second_lo=-(wl.emitter_freq(e, fs) + 2.5))
+        p.update(extra)
+        cfg = oracle_cfg(p, fs, L, geom["M"], geom["D"], compute_n0=1)
+        auds, sts, filts = ko.run_chain(cfg, iq.reshape(nblocks, L), want_filt=True)
+        keys = ("if_power", "bb_power", "n0", "snr", "foffset", "pdeviation", "agc_gain", "squelch_count", "hangcount",
+                "blanked", "nout")
+        np.savez_compressed(os.path.join(HERE, "chain_%s.npz" % tag), iq=iq, audio=np.concatenate(auds),
+                            filt=np.concatenate(filts), plan=np.array(repr(p)),
+                            **{k: np.array([s[k] for s in sts]) for k in keys})
+
+
+if __name__ == "__main__":
+    osc()
+    chain()
+    print("golden vectors written to", HERE)

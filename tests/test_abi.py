@@ -1,0 +1,102 @@
+"""The C-ABI library loads and exports every symbol that include/*.h declares (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import ka9q_sdr_amd as kq
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set()
+    for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", txt):
+        n = m.group(1)
+        if n in ("defined", "sizeof") or n.startswith("__"):
+            continue
+        names.add(n)
+    return names
+
+
+@pytest.fixture(scope="module")
+def lib():
+    kq.build_library()
+    return kq.load_library()
+
+
+def test_bank_symbols_exported(lib):
+    names = {n for n in _declared("ka9q_hip.h") if n.startswith("kq_")}
+    assert len(names) >= 30
+    for n in sorted(names):
+        assert hasattr(lib, n), "libka9q_hip.so does not export %s" % n
+
+
+def test_compat_symbols_exported(lib):
+    want = {"create_filter_input", "create_filter_output", "execute_filter_input", "execute_filter_output",
+            "delete_filter_input", "delete_filter_output", "set_filter", "window_filter", "window_rfilter",
+            "make_kaiser", "noise_gain", "set_osc", "step_osc", "renorm_osc", "is_phasor_init",
+            "csincosf", "csincospif", "csincos", "csincospi", "cnrmf", "cnrm"}
+    assert want <= _declared("ka9q_hip_compat.h")
+    for n in sorted(want):
+        assert hasattr(lib, n), "libka9q_hip.so does not export %s" % n
+    assert C.c_float.in_dll(lib, "Kaiser_beta").value == 3.0     # filter.c:279
+
+
+def test_version_and_errors(lib):
+    assert b"gfx950" in lib.kq_version()
+    # argument validation happens before any device work
+    assert lib.kq_bank_create(None) is None
+    assert b"NULL" in lib.kq_last_error()
+    cfg = kq.BankConfig(0, 192000, 512, 500, 4, 1, 1, 1.0, 0, 0, None)      # N = 1011: not a power of two
+    assert lib.kq_bank_create(C.byref(cfg)) is None
+    assert b"power of two" in lib.kq_last_error()
+    cfg = kq.BankConfig(0, 192000, 512, 513, 3, 1, 1, 1.0, 0, 0, None)      # decimate must divide N
+    assert lib.kq_bank_create(C.byref(cfg)) is None
+
+
+def test_no_silent_cpu_fallback(lib):
+    """Without a GPU the product path must fail loudly, never compute on the CPU."""
+    if lib.kq_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(kq.KqError, match="no HIP device"):
+        kq.Bank(192000, 512, 513, 4, 1, 1)
+    lib.create_filter_input.restype = C.c_void_p
+    assert lib.create_filter_input(512, 513, 1) is None
+
+
+def test_host_nco_entry_points(lib):
+    """set_osc/step_osc of the compat surface are host scalar code: check them against the oracle."""
+    import kq_oracle as ko
+    lib.set_osc.argtypes = [C.POINTER(ko.RefOsc), C.c_double, C.c_double]
+    lib.step_osc.argtypes = [C.POINTER(ko.RefOsc)]
+    lib.step_osc.restype = ko._Cplx
+    O = ko.lib()
+    a, b = ko.RefOsc(), ko.Osc()
+    lib.set_osc(C.byref(a), 0.0371, 2e-10)
+    O.kqo_set_osc(C.byref(b), 0.0371, 2e-10)
+    for i in range(20000):
+        x, y = lib.step_osc(C.byref(a)), O.kqo_step_osc(C.byref(b))
+        assert abs(x.re - y.re) < 1e-11 and abs(x.im - y.im) < 1e-11
+    assert a.steps == b.steps
+
+
+def test_host_design_entry_points(lib):
+    """make_kaiser / window_filter of the compat surface (host control plane) against the oracle."""
+    import numpy as np
+    import kq_oracle as ko
+    w = np.zeros(129, np.float32)
+    lib.make_kaiser.argtypes = [C.c_void_p, C.c_uint, C.c_float]
+    assert lib.make_kaiser(w.ctypes.data, 129, 3.0) == 0
+    assert np.array_equal(w, ko.make_kaiser(129, 3.0))
+    assert lib.make_kaiser(None, 129, 3.0) == -1
+    rng = np.random.default_rng(0)
+    r = (rng.standard_normal(256) + 1j * rng.standard_normal(256)).astype(np.complex64)
+    r2 = r.copy()
+    lib.window_filter.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_float]
+    assert lib.window_filter(128, 129, r.ctypes.data, 3.0) == 0
+    ko.lib().kqo_window_filter(128, 129, r2.ctypes.data, 3.0)
+    assert np.abs(r - r2).max() / np.abs(r2).max() < 1e-6

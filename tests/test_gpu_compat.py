@@ -1,0 +1,105 @@
+"""The reference's own one-channel filter API (include/ka9q_hip_compat.h) served by the GPU, against the
+oracle: create/execute/set_filter for every in/out type combination of filter.c:206-250."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ka9q_sdr_amd as kq
+import kq_oracle as ko
+from test_oracle_filter import _FilterIn as OFilterIn, _FilterOut as OFilterOut, _as
+
+pytestmark = pytest.mark.gpu
+
+
+class FilterIn(C.Structure):      # struct filter_in of ka9q_hip_compat.h (x86-64 glibc pthread sizes)
+    _fields_ = [("in_type", C.c_int), ("ilen", C.c_uint), ("impulse_length", C.c_uint), ("fdomain", C.c_void_p),
+                ("input_buffer", C.c_void_p), ("input", C.c_void_p), ("fwd_plan", C.c_void_p), ("blocknum", C.c_uint),
+                ("filter_mutex", C.c_byte * 40), ("filter_cond", C.c_byte * 48)]
+
+
+class FilterOut(C.Structure):
+    _fields_ = [("master", C.c_void_p), ("out_type", C.c_int), ("response", C.c_void_p), ("response_mutex", C.c_byte * 40),
+                ("f_fdomain", C.c_void_p), ("noise_gain", C.c_float), ("output_buffer", C.c_void_p), ("output", C.c_void_p),
+                ("rev_plan", C.c_void_p), ("decimate", C.c_uint), ("olen", C.c_uint), ("blocknum", C.c_uint)]
+
+
+@pytest.fixture(scope="module")
+def lib(gpu):
+    L = kq.load_library()
+    L.create_filter_input.restype = C.POINTER(FilterIn)
+    L.create_filter_input.argtypes = [C.c_uint, C.c_uint, C.c_int]
+    L.create_filter_output.restype = C.POINTER(FilterOut)
+    L.create_filter_output.argtypes = [C.POINTER(FilterIn), C.c_void_p, C.c_uint, C.c_int]
+    L.execute_filter_input.argtypes = [C.POINTER(FilterIn)]
+    L.execute_filter_output.argtypes = [C.POINTER(FilterOut)]
+    L.delete_filter_input.argtypes = [C.POINTER(FilterIn)]
+    L.delete_filter_output.argtypes = [C.POINTER(FilterOut)]
+    L.set_filter.argtypes = [C.POINTER(FilterOut), C.c_float, C.c_float, C.c_float]
+    return L
+
+
+@pytest.mark.parametrize("in_type,out_type,D", [(1, 1, 4), (1, 2, 4), (1, 3, 4), (1, 1, 16), (3, 3, 1), (3, 1, 1)])
+def test_compat_filter_matches_oracle(lib, in_type, out_type, D):
+    Lb, M = 512, 513
+    N = Lb + M - 1
+    O = ko.lib()
+    m = lib.create_filter_input(Lb, M, in_type)
+    assert m and m.contents.ilen == Lb and m.contents.impulse_length == M
+    s = lib.create_filter_output(m, None, D, out_type)
+    assert s and s.contents.olen == Lb // D and np.isnan(s.contents.noise_gain)
+    om = O.kqo_create_filter_input(Lb, M, in_type)
+    os_ = O.kqo_create_filter_output(om, None, D, out_type)
+    if in_type == 3 and out_type == 3:
+        # REAL/REAL slaves take an N/2+1-bin response (fm.c:56-66): use the FM de-emphasis design
+        from ka9q_sdr_amd import workload  # noqa: F401
+        libc = C.CDLL(None)
+        libc.malloc.restype = C.c_void_p
+        resp = np.zeros(N // 2 + 1, np.complex64)
+        f = np.arange(N // 2 + 1) * 48000.0 / N
+        sel = (f >= 300) & (f <= 6000)
+        resp[sel] = (10.0 / N) * 300.0 / f[sel]
+        for target, setter in ((s, None), (os_, None)):
+            p = libc.malloc(8 * (N // 2 + 1))
+            C.memmove(p, resp.ctypes.data, 8 * (N // 2 + 1))
+            if target is s:
+                s.contents.response = p
+            else:
+                C.cast(os_, C.POINTER(OFilterOut)).contents.response = p
+    else:
+        assert lib.set_filter(s, -0.11, 0.17, 3.0) == 0
+        assert O.kqo_set_filter(os_, -0.11, 0.17, 3.0) == 0
+        oso = C.cast(os_, C.POINTER(OFilterOut)).contents
+        np.testing.assert_allclose(s.contents.noise_gain, oso.noise_gain, rtol=1e-5)
+    assert lib.set_filter(s, float("nan"), 0.1, 3.0) == -1      # filter.c:504-505
+    assert lib.execute_filter_input(None) == -1                  # filter.c:148-149
+    omi = C.cast(om, C.POINTER(OFilterIn)).contents
+    oso = C.cast(os_, C.POINTER(OFilterOut)).contents
+    rng = np.random.default_rng(7)
+    olen = Lb // D
+    for b in range(4):
+        if in_type == 3:
+            x = rng.standard_normal(Lb).astype(np.float32)
+            _as(m.contents.input, Lb, np.float32)[:] = x
+            _as(omi.input_r, Lb, np.float32)[:] = x
+        else:
+            x = (rng.standard_normal(Lb) + 1j * rng.standard_normal(Lb)).astype(np.complex64)
+            _as(m.contents.input, Lb, np.complex64)[:] = x
+            _as(omi.input_c, Lb, np.complex64)[:] = x
+        assert lib.execute_filter_input(m) == 0
+        assert m.contents.blocknum == b + 1
+        assert lib.execute_filter_output(s) == 0
+        O.kqo_execute_filter_input(om)
+        O.kqo_execute_filter_output(os_)
+        nb = N // 2 + 1 if in_type == 3 else N
+        fd_g = _as(m.contents.fdomain, nb, np.complex64)
+        fd_o = _as(omi.fdomain, nb, np.complex64)
+        assert np.abs(fd_g - fd_o).max() / np.abs(fd_o).max() < 2e-6          # master spectrum (radio.c:396 reads it)
+        if out_type == 3:
+            got, want = _as(s.contents.output, olen, np.float32), _as(oso.output_r, olen, np.float32)
+        else:
+            got, want = _as(s.contents.output, olen, np.complex64), _as(oso.output_c, olen, np.complex64)
+        assert np.sqrt(np.mean(np.abs(got - want) ** 2)) / np.sqrt(np.mean(np.abs(want) ** 2)) < 1e-5
+    assert lib.delete_filter_output(s) == 0 and lib.delete_filter_input(m) == 0
+    O.kqo_delete_filter_output(os_)
+    O.kqo_delete_filter_input(om)

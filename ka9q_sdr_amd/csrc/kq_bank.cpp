@@ -351,9 +351,14 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   }
   {
     Scope t(b, 1);
-    kq::launch_demods(b->stream, g, b->chd, b->pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), b->list_dev[1],
-                      (int)b->list_host[1].size(), b->list_dev[2], (int)b->list_host[2].size(), (int)nblocks,
-                      b->cfg.compute_n0);
+    if (kq::demod64_supported(g))
+      kq::launch_demod64(b->stream, g, b->chd, b->pl, b->list_dev[0], (int)b->list_host[0].size(), b->list_dev[1],
+                         (int)b->list_host[1].size(), b->list_dev[2], (int)b->list_host[2].size(), (int)nblocks,
+                         b->cfg.compute_n0);
+    else
+      kq::launch_demods(b->stream, g, b->chd, b->pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), b->list_dev[1],
+                        (int)b->list_host[1].size(), b->list_dev[2], (int)b->list_host[2].size(), (int)nblocks,
+                        b->cfg.compute_n0);
   }
   HIP_TRY(hipGetLastError());
   b->n_abs += (int64_t)nblocks * g.L;

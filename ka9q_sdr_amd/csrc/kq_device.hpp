@@ -78,6 +78,9 @@ void launch_pruned_tables(hipStream_t s, const Geom &g, const ChanDev &ch, float
 void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw,
                    const int *list_fm, int n_fm, const int *list_am, int n_am, const int *list_lin, int n_lin,
                    int nblocks, int compute_n0);
+bool demod64_supported(const Geom &g);
+void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const int *list_fm, int n_fm,
+                    const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0);
 // single transforms for the compat surface
 void launch_fft_single(hipStream_t s, const float2 *in, float2 *out, int log2n, int sign, const float2 *tw, int tw_log2);
 void launch_slave_single(hipStream_t s, const float2 *fdomain, const float2 *resp, float2 *out, int N, int Ndec,

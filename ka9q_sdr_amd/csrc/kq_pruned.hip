@@ -16,6 +16,8 @@
 // the remaining 64-lane sum done as a cross-lane reduce-scatter, then response multiply, CROSS_CONJ
 // and the 64-point inverse FFT across lanes.  The N-sample window is staged once in LDS and shared by
 // all waves of the workgroup and by several channels per wave.
+#include <cstdlib>
+
 #include "kq_device.hpp"
 
 namespace kq {
@@ -93,16 +95,28 @@ __device__ __forceinline__ void fft32_dif(float2 (&v)[32]) {
   }
 }
 
-// Table layout per channel (floats): see launch_pruned_tables
+// Table layout per channel (floats), built by k_pruned_tables:
 //   A  : [2 passes][32] float4  = (A0.re, A0.im, A1.re, A1.im)
-//   J  : [3][64] float2          column-group twiddles, j = 1..3, natural q
-//   Lv : [6][64] float2          cross-lane levels, lane bit i, natural q
+//   J  : [3][2 passes][32] float2  column-group twiddles, j = 1..3, bin q = 2 q' + pass
+//   Lv : [6][64] float2            cross-lane levels, lane bit i, natural q
+// A and J (2560 B) are copied into a wave-private LDS slot per channel-block and read back with
+// wave-uniform ds_read_b128 (broadcast): LDS reads retire in order, so they pipeline with the column
+// reads.  (Scalar loads were tried first: they return out of order, every use needs s_waitcnt lgkmcnt(0),
+// and that also drains the LDS column reads -- 48 % of wave time was spent waiting.)
 constexpr int kTabA = 2 * 32 * 4;
 constexpr int kTabJ = 3 * 64 * 2;
 constexpr int kTabL = 6 * 64 * 2;
 constexpr int kTabFloats = kTabA + kTabJ + kTabL;
+constexpr int kWaveTabF4 = (kTabA + kTabJ) / 4;  // 160 float4 per wave
 
 __device__ __forceinline__ int signed_bin(int q) { return q <= 32 ? q : q - 64; }
+
+__device__ __forceinline__ void swap32(float &a, float &b) {
+  // v_permlane32_swap: lanes 32..63 of a <-> lanes 0..31 of b
+  auto const r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
 
 }  // namespace
 
@@ -135,8 +149,9 @@ __global__ void k_pruned_tables(Geom g, ChanDev ch, float *__restrict__ tab, int
     o[3] = s1;
   }
   for (int i = threadIdx.x; i < 3 * 64 + 6 * 64; i += blockDim.x) {
-    int const row = i >> 6, q = i & 63;
-    // rows 0..2: column groups j=1..3 (offset 64 j); rows 3..8: lane bit i (offset 2^i)
+    int const row = i >> 6, rem = i & 63;
+    // rows 0..2: column groups j=1..3 (offset 64 j), stored [pass][q']; rows 3..8: lane bit (offset 2^bit), natural q
+    int const q = row < 3 ? 2 * (rem & 31) + (rem >> 5) : rem;
     double const off = row < 3 ? 64.0 * (row + 1) : (double)(1 << (row - 3));
     double turns = off * f;
     turns -= rint(turns);
@@ -150,108 +165,162 @@ __global__ void k_pruned_tables(Geom g, ChanDev ch, float *__restrict__ tab, int
   }
 }
 
-// grid (channel groups, blocks); block = 512 threads = 8 waves; dynamic LDS = N float2
-template <int CPW>
-__global__ void __launch_bounds__(512) k_filter_pruned64(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,
-                                                         const float *__restrict__ tab, int nchan) {
+// grid (channel groups, blocks); block = NWAVES waves; dynamic LDS = N float2 + NWAVES * 2560 B
+template <int NWAVES, int CPW, int R>
+__global__ void __launch_bounds__(NWAVES * 64) k_filter_pruned64(Geom g, ChanDev ch, Planes pl,
+                                                                 const float2 *__restrict__ window,
+                                                                 const float *__restrict__ tab, int nchan) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   int const blk = blockIdx.y;
-  int const N = g.N;
-  int const R = g.D;
+  constexpr int N = 64 * R;  // R = decimation ratio = number of columns; compile-time so LDS offsets are immediates
   {
     const float4 *src = reinterpret_cast<const float4 *>(window + (size_t)blk * g.L);
     float4 *dst = reinterpret_cast<float4 *>(lds);
-    for (int i = threadIdx.x; i < N / 2; i += 512) dst[i] = src[i];
+    for (int i = threadIdx.x; i < N / 2; i += NWAVES * 64) dst[i] = src[i];
   }
   __syncthreads();
   int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int const groups = R / 64;  // column groups of 64 lanes
+  constexpr int groups = R / 64;  // column groups of 64 lanes
+  float4 *wtab = reinterpret_cast<float4 *>(lds + N) + wave * kWaveTabF4;
+  int const b0 = lane & 1;
 
   for (int ci = 0; ci < CPW; ci++) {
-    int const c = __builtin_amdgcn_readfirstlane((blockIdx.x * 8 + wave) * CPW + ci);
+    int const c = __builtin_amdgcn_readfirstlane((blockIdx.x * NWAVES + wave) * CPW + ci);
     if (c >= nchan) break;
     const float *tc = tab + (size_t)c * kTabFloats;
-    const float4 *tA = reinterpret_cast<const float4 *>(tc);
-    const float2 *tJ = reinterpret_cast<const float2 *>(tc + kTabA);
     const float2 *tL = reinterpret_cast<const float2 *>(tc + kTabA + kTabJ);
+    {
+      const float4 *src = reinterpret_cast<const float4 *>(tc);
+      for (int i = lane; i < kWaveTabF4; i += 64) wtab[i] = src[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const float2 *wJ = reinterpret_cast<const float2 *>(wtab + 64);
 
-    float2 acc[2][32];  // [pass][bitrev5(q')]  with q = 2 q' + pass
-    // pass 0 = even bins, pass 1 = odd bins: pass outermost so that only one 32-point work set and the
-    // two accumulator sets are ever live (3 x 64 VGPRs); the window is re-read from LDS per pass
+    float2 ypass[2];
+    // pass 0 = even bins, pass 1 = odd bins (first radix-2 DIF stage of the 64-point column FFT fused into the
+    // premultiply).  Each pass: accumulate the column groups, then reduce over the 64 lanes.
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
+      float2 acc[32];  // bin q' (q = 2 q' + pass) lives in acc[bitrev5(q')]
 #pragma unroll 1
       for (int j = 0; j < groups; j++) {
         const float2 *col = lds + 64 * j + lane;
-        // the A table does not depend on j: hide that from LICM or all its scalars are hoisted and spilled
-        int aoff = pass * 32;
-        asm volatile("" : "+s"(aoff));
-        const float4 *tAj = tA + aoff;
+        const float4 *tAj = wtab + pass * 32;
         float2 v[32];
+        // Software pipeline in chunks of CH samples: the LDS reads of chunk k+1 (2 column samples and one
+        // broadcast twiddle pair per row) are issued before the arithmetic of chunk k; sched_barriers pin
+        // that order, otherwise the scheduler hoists all 96 reads of the pass and spills.
+        constexpr int CH = 4;
+        float4 tw_[2][CH];
+        float2 xa_[2][CH], xb_[2][CH];
 #pragma unroll
-        for (int a = 0; a < 32; a++) {
-          float4 const t = tAj[a];  // wave-uniform: scalar load
-          float2 const x0 = col[(size_t)R * a], x1 = col[(size_t)R * (a + 32)];
-          float2 r = make_float2(x0.x * t.x - x0.y * t.y, x0.x * t.y + x0.y * t.x);
-          r.x = fmaf(x1.x, t.z, fmaf(-x1.y, t.w, r.x));
-          r.y = fmaf(x1.x, t.w, fmaf(x1.y, t.z, r.y));
-          v[a] = r;
+        for (int i = 0; i < CH; i++) {
+          tw_[0][i] = tAj[i];
+          xa_[0][i] = col[R * i];
+          xb_[0][i] = col[R * (i + 32)];
+        }
+#pragma unroll
+        for (int k = 0; k < 32 / CH; k++) {
+          int const cur = k & 1, nxt = cur ^ 1;
+          if (k + 1 < 32 / CH) {
+#pragma unroll
+            for (int i = 0; i < CH; i++) {
+              int const a = (k + 1) * CH + i;
+              tw_[nxt][i] = tAj[a];
+              xa_[nxt][i] = col[R * a];
+              xb_[nxt][i] = col[R * (a + 32)];
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < CH; i++) {
+            float4 const t = tw_[cur][i];
+            float2 const x0 = xa_[cur][i], x1 = xb_[cur][i];
+            float2 r = make_float2(x0.x * t.x - x0.y * t.y, x0.x * t.y + x0.y * t.x);
+            r.x = fmaf(x1.x, t.z, fmaf(-x1.y, t.w, r.x));
+            r.y = fmaf(x1.x, t.w, fmaf(x1.y, t.z, r.y));
+            v[k * CH + i] = r;
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
         fft32_dif(v);
+        __builtin_amdgcn_sched_barrier(0);
         if (j == 0) {
 #pragma unroll
-          for (int i = 0; i < 32; i++) acc[pass][i] = v[i];
+          for (int i = 0; i < 32; i++) acc[i] = v[i];
         } else {
-          const float2 *tj = tJ + (size_t)(j - 1) * 64;
+          const float4 *tj = reinterpret_cast<const float4 *>(wJ + ((j - 1) * 2 + pass) * 32);
 #pragma unroll
-          for (int qp = 0; qp < 32; qp++) {
-            float2 const w = tj[2 * qp + pass];  // wave-uniform
-            acc[pass][bitrev5(qp)] = cfma(w, v[bitrev5(qp)], acc[pass][bitrev5(qp)]);
+          for (int k = 0; k < 4; k++) {  // 8 bins per chunk, twiddles as 4 broadcast ds_read_b128
+            float4 w4[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) w4[i] = tj[k * 4 + i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              int const q0 = k * 8 + 2 * i;
+              acc[bitrev5(q0)] = cfma(make_float2(w4[i].x, w4[i].y), v[bitrev5(q0)], acc[bitrev5(q0)]);
+              acc[bitrev5(q0 + 1)] = cfma(make_float2(w4[i].z, w4[i].w), v[bitrev5(q0 + 1)], acc[bitrev5(q0 + 1)]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
+      // ---- reduce-scatter over lane bits 5..1, then a pair sum over bit 0
+      float2 z[16];
+      int qlow;
+      {  // lane bit 5 through v_permlane32_swap: no LDS, no selects
+        int const bit = (lane >> 5) & 1;
+        qlow = bit;
+        const float2 *tl = tL + 5 * 64;
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+          float2 e = acc[bitrev5(2 * m)], o = acc[bitrev5(2 * m + 1)];
+          swap32(e.x, o.x);
+          swap32(e.y, o.y);
+          // lower lanes: e = own even, o = partner's even; upper lanes: e = partner's odd, o = own odd
+          z[m] = cfma(tl[2 * (2 * m + bit) + pass], o, e);
+        }
+      }
+#pragma unroll
+      for (int t = 1; t < 5; t++) {
+        int const i = 5 - t;
+        int const bit = (lane >> i) & 1;
+        int const cnt = 16 >> t;
+        const float2 *tl = tL + (size_t)i * 64;
+#pragma unroll
+        for (int m = 0; m < cnt; m++) {
+          float2 const e = z[2 * m], o = z[2 * m + 1];
+          float2 const keep = bit ? o : e, send = bit ? e : o;
+          float2 recv;
+          recv.x = __shfl_xor(send.x, 1 << i, 64);
+          recv.y = __shfl_xor(send.y, 1 << i, 64);
+          float2 const lo = bit ? recv : keep, hi = bit ? keep : recv;
+          int const qp = (((2 * m + bit) << t) | qlow);
+          z[m] = cfma(tl[2 * qp + pass], hi, lo);
+        }
+        qlow |= bit << t;
+      }
+      {  // lane bit 0: both lanes of a pair end with the full sum
+        float2 recv;
+        recv.x = __shfl_xor(z[0].x, 1, 64);
+        recv.y = __shfl_xor(z[0].y, 1, 64);
+        float2 const lo = b0 ? recv : z[0], hi = b0 ? z[0] : recv;
+        ypass[pass] = cfma(tL[2 * qlow + pass], hi, lo);
+      }
     }
-
-    // ---- cross-lane reduce-scatter over the 6 lane bits; lane ends with bin q = bitrev6(lane)
-    // level t = 0..5 handles lane bit i = 5 - t and halves the per-lane bin set
-    float2 z[32];
-    int qlow;
+    // lane now holds bin 2*rev5(lane>>1) + pass for both passes; keep pass = lane bit 0, then move bin
+    // bitrev6(lane) into each lane for the decimation-in-time inverse transform
+    float2 y = b0 ? ypass[1] : ypass[0];
+    int const q = (int)(__brev((unsigned)lane) >> 26);  // bin this lane must hold
     {
-      int const bit = (lane >> 5) & 1;
-      qlow = bit;
-      const float2 *tl = tL + 5 * 64;
-#pragma unroll
-      for (int m = 0; m < 32; m++) {
-        float2 const e = acc[0][bitrev5(m)], o = acc[1][bitrev5(m)];  // q = 2m, 2m+1
-        float2 const keep = bit ? o : e, send = bit ? e : o;
-        float2 recv;
-        recv.x = __shfl_xor(send.x, 32, 64);
-        recv.y = __shfl_xor(send.y, 32, 64);
-        float2 const lo = bit ? recv : keep, hi = bit ? keep : recv;
-        z[m] = cfma(tl[2 * m + bit], hi, lo);
-      }
+      int const src = (int)((__brev((unsigned)(q >> 1)) >> 27) << 1) | (q & 1);
+      float2 t2;
+      t2.x = __shfl(y.x, src, 64);
+      t2.y = __shfl(y.y, src, 64);
+      y = t2;
     }
-#pragma unroll
-    for (int t = 1; t < 6; t++) {
-      int const i = 5 - t;
-      int const bit = (lane >> i) & 1;
-      int const cnt = 32 >> t;  // elements kept after this level
-      const float2 *tl = tL + (size_t)i * 64;
-#pragma unroll
-      for (int m = 0; m < cnt; m++) {
-        float2 const e = z[2 * m], o = z[2 * m + 1];
-        float2 const keep = bit ? o : e, send = bit ? e : o;
-        float2 recv;
-        recv.x = __shfl_xor(send.x, 1 << i, 64);
-        recv.y = __shfl_xor(send.y, 1 << i, 64);
-        float2 const lo = bit ? recv : keep, hi = bit ? keep : recv;
-        int const q = (((2 * m + bit) << t) | qlow);
-        z[m] = cfma(tl[q], hi, lo);
-      }
-      qlow |= bit << t;
-    }
-    int const q = qlow;  // == bitrev6(lane)
-    float2 y = z[0];
 
     // ---- P0, response multiply (filter.c:206-227), CROSS_CONJ (filter.c:239-249)
     {
@@ -291,25 +360,52 @@ __global__ void __launch_bounds__(512) k_filter_pruned64(Geom g, ChanDev ch, Pla
   }
 }
 
-bool pruned_supported(const Geom &g) { return g.Ndec == 64 && g.D >= 64 && g.D % 64 == 0 && (size_t)g.N * 8 <= 128 * 1024; }
+bool pruned_supported(const Geom &g) { return g.Ndec == 64 && (g.D == 64 || g.D == 128 || g.D == 256); }
 size_t pruned_table_elems(const Geom &) { return (size_t)kTabFloats / 2; }
 
 void launch_pruned_tables(hipStream_t s, const Geom &g, const ChanDev &ch, float2 *chan_tw, int nchan) {
   hipLaunchKernelGGL(k_pruned_tables, dim3(nchan), dim3(256), 0, s, g, ch, reinterpret_cast<float *>(chan_tw), nchan);
 }
 
-void launch_filter_pruned(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
-                          const float2 *, const float2 *chan_tw, int nchan, int nblocks) {
-  constexpr int CPW = 4;
-  size_t const lds_bytes = (size_t)g.N * sizeof(float2);
+namespace {
+template <int NWAVES, int CPW, int R>
+void launch_r(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window, const float *tab,
+              int nchan, int nblocks) {
+  size_t const lds_bytes = (size_t)g.N * sizeof(float2) + (size_t)NWAVES * kWaveTabF4 * sizeof(float4);
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void *)k_filter_pruned64<CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_filter_pruned64<NWAVES, CPW, R>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     configured = true;
   }
-  int const per_wg = 8 * CPW;
-  hipLaunchKernelGGL(k_filter_pruned64<CPW>, dim3((nchan + per_wg - 1) / per_wg, nblocks), dim3(512), lds_bytes, s, g, ch, pl,
-                     window, reinterpret_cast<const float *>(chan_tw), nchan);
+  int const per_wg = NWAVES * CPW;
+  hipLaunchKernelGGL((k_filter_pruned64<NWAVES, CPW, R>), dim3((nchan + per_wg - 1) / per_wg, nblocks), dim3(NWAVES * 64),
+                     lds_bytes, s, g, ch, pl, window, tab, nchan);
+}
+template <int NWAVES, int CPW>
+void launch_variant(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window, const float *tab,
+                    int nchan, int nblocks) {
+  if (g.D == 256) return launch_r<NWAVES, CPW, 256>(s, g, ch, pl, window, tab, nchan, nblocks);
+  if (g.D == 128) return launch_r<NWAVES, CPW, 128>(s, g, ch, pl, window, tab, nchan, nblocks);
+  return launch_r<NWAVES, CPW, 64>(s, g, ch, pl, window, tab, nchan, nblocks);
+}
+}  // namespace
+
+void launch_filter_pruned(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
+                          const float2 *, const float2 *chan_tw, int nchan, int nblocks) {
+  // tuning knobs (waves per workgroup, channels per wave); defaults chosen on MI355X
+  static int waves = 0, cpw = 0;
+  if (!waves) {
+    const char *e = getenv("KQ_PRUNED_WAVES");
+    waves = e ? atoi(e) : 8;
+    e = getenv("KQ_PRUNED_CPW");
+    cpw = e ? atoi(e) : 4;
+  }
+  const float *tab = reinterpret_cast<const float *>(chan_tw);
+  if (waves == 12 && cpw == 2) return launch_variant<12, 2>(s, g, ch, pl, window, tab, nchan, nblocks);
+  if (waves == 12) return launch_variant<12, 4>(s, g, ch, pl, window, tab, nchan, nblocks);
+  if (cpw == 2) return launch_variant<8, 2>(s, g, ch, pl, window, tab, nchan, nblocks);
+  return launch_variant<8, 4>(s, g, ch, pl, window, tab, nchan, nblocks);
 }
 
 }  // namespace kq

@@ -141,6 +141,10 @@ int kq_bank_process(kq_bank *bank);
 /* Convenience for resident-input benchmarks: process `nblocks` blocks reading the window
  * [M-1 history | nblocks*L] straight from `iq_dev` (device, complex float), no ring copy. */
 int kq_bank_process_resident(kq_bank *bank, const void *iq_dev, unsigned nblocks);
+/* The demodulators of a call run on a second internal stream, overlapping the next call's filter pass.
+ * kq_bank_join makes the bank's main stream wait (on the device) for the last call's demodulators;
+ * kq_bank_sync blocks the host until everything issued so far has finished. */
+int kq_bank_join(kq_bank *bank);
 int kq_bank_sync(kq_bank *bank);
 
 /* --- results of the last kq_bank_process call (replace send_mono_output/send_stereo_output,

@@ -109,6 +109,7 @@ def load_library():
     L.kq_bank_process.argtypes = [C.c_void_p]
     L.kq_bank_process_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
     L.kq_bank_sync.argtypes = [C.c_void_p]
+    L.kq_bank_join.argtypes = [C.c_void_p]
     L.kq_bank_olen.argtypes = [C.c_void_p]
     L.kq_bank_olen.restype = C.c_uint
     L.kq_bank_last_blocks.argtypes = [C.c_void_p]
@@ -230,6 +231,9 @@ class Bank:
 
     def process_resident(self, dev_ptr, nblocks):
         return self._chk(self.lib.kq_bank_process_resident(self.h, dev_ptr, nblocks), "kq_bank_process_resident")
+
+    def join(self):
+        self._chk(self.lib.kq_bank_join(self.h), "kq_bank_join")
 
     def sync(self):
         self._chk(self.lib.kq_bank_sync(self.h), "kq_bank_sync")

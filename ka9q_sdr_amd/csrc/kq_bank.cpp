@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -106,6 +107,14 @@ struct kq_bank {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int fwd_mode = KQ_FWD_FULL;
+  // The demodulators are latency-bound and independent of the next batch's filter pass, so they run on a
+  // second stream: filter(k+1) overlaps demod(k).  Planes the two stages hand over are double buffered.
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_filter_done = nullptr;
+  hipEvent_t ev_demod_done[2] = {nullptr, nullptr};
+  kq::Planes pl2[2];
+  double *osc_dev2[2] = {nullptr, nullptr};
+  uint64_t calls = 0;
 
   float2 *ring[2] = {nullptr, nullptr};
   int cur = 0;
@@ -128,7 +137,6 @@ struct kq_bank {
   // per-call parameters (5 double planes of max_channels + max_blocks update flags) travel through
   // pinned staging slots so kq_bank_process never has to synchronise the stream
   static constexpr int kSlots = 4;
-  double *osc_dev = nullptr;
   unsigned char *stage_host[kSlots] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t stage_ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
   int stage_next = 0;
@@ -164,6 +172,8 @@ int ilog2(unsigned v) {
   return l;
 }
 
+int sync_all(kq_bank *b);
+
 int upload(kq_bank *b, void *dst, const void *src, size_t bytes) {
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->stream));
   return 0;
@@ -171,6 +181,7 @@ int upload(kq_bank *b, void *dst, const void *src, size_t bytes) {
 
 // Derived per-channel constants, as each demod thread computes them in its prologue
 int upload_channel(kq_bank *b, int c) {
+  if (sync_all(b)) return -1;  // quiesce both streams before touching per-channel state
   HostChan &h = b->chans[c];
   kq::Geom const &g = b->g;
   kq_channel_config const &k = h.cfg;
@@ -199,18 +210,19 @@ int upload_channel(kq_bank *b, int c) {
   if (upload(b, b->chd.gain + c, &init_gain, sizeof(float))) return -1;
   if (upload(b, b->chd.n0 + c, &nan, sizeof(float))) return -1;
   if (upload(b, b->chd.fm_state + c, &one, sizeof(float2))) return -1;
-  HIP_TRY(hipStreamSynchronize(b->stream));  // locals above go out of scope
+  if (sync_all(b)) return -1;  // also: the demod stream may still be reading the old parameters
   return 0;
 }
 
 int upload_response(kq_bank *b, int c) {
+  if (sync_all(b)) return -1;
   HostChan &h = b->chans[c];
   kq::Geom const &g = b->g;
   if (upload(b, b->chd.resp + (size_t)c * g.Ndec, h.resp.data(), sizeof(float2) * g.Ndec)) return -1;
   if (upload(b, b->chd.noise_gain + c, &h.noise_gain, sizeof(float))) return -1;
   if (!h.aresp.empty())
     if (upload(b, b->chd.aresp + (size_t)c * (g.Ndec / 2 + 1), h.aresp.data(), sizeof(float2) * (g.Ndec / 2 + 1))) return -1;
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (sync_all(b)) return -1;
   return 0;
 }
 
@@ -245,8 +257,14 @@ int ensure_events(std::vector<EventPair> &v, size_t need) {
   return 0;
 }
 
-int drain_timing(kq_bank *b) {
+int sync_all(kq_bank *b) {
   HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream2));
+  return 0;
+}
+
+int drain_timing(kq_bank *b) {
+  if (sync_all(b)) return -1;
   std::vector<EventPair> *sets[3] = {&b->ev_filter, &b->ev_demod, &b->ev_ingest};
   double *dst[3] = {&b->acc.filter_ms, &b->acc.demod_ms, &b->acc.ingest_ms};
   for (int k = 0; k < 3; k++) {
@@ -264,22 +282,23 @@ struct Scope {
   kq_bank *b;
   int kind;
   EventPair *p = nullptr;
-  Scope(kq_bank *bank, int k) : b(bank), kind(k) {
+  hipStream_t st;
+  Scope(kq_bank *bank, int k, hipStream_t stream) : b(bank), kind(k), st(stream) {
     if (!b->timing) return;
     std::vector<EventPair> &v = kind == 0 ? b->ev_filter : kind == 1 ? b->ev_demod : b->ev_ingest;
     if (b->ev_used[kind] >= 512) drain_timing(b);
     if (ensure_events(v, b->ev_used[kind] + 1)) return;
     p = &v[b->ev_used[kind]++];
-    (void)hipEventRecord(p->a, b->stream);
+    (void)hipEventRecord(p->a, st);
   }
   ~Scope() {
-    if (p) (void)hipEventRecord(p->b, b->stream);
+    if (p) (void)hipEventRecord(p->b, st);
   }
 };
 
 // Per-call parameters: oscillator phase/step/sweep for a call whose first window starts at absolute
 // sample n_w, the shift oscillator at the first output sample, and the IF-power update flags.
-int upload_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsigned nblocks) {
+int upload_call_params(kq_bank *b, double *osc_dst, int64_t n_w, const unsigned char *update, unsigned nblocks) {
   size_t const C = b->chans.size(), Cmax = b->cfg.max_channels;
   int const slot = b->stage_next;
   b->stage_next = (slot + 1) % kq_bank::kSlots;
@@ -303,7 +322,7 @@ int upload_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, uns
   }
   unsigned char *flags = b->stage_host[slot] + 5 * Cmax * sizeof(double);
   memcpy(flags, update, nblocks);
-  HIP_TRY(hipMemcpyAsync(b->osc_dev, b->stage_host[slot], 5 * Cmax * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(osc_dst, b->stage_host[slot], 5 * Cmax * sizeof(double), hipMemcpyHostToDevice, b->stream));
   HIP_TRY(hipMemcpyAsync(b->update_dev, flags, nblocks, hipMemcpyHostToDevice, b->stream));
   HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
   return 0;
@@ -332,34 +351,53 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     return -1;
   }
   if (b->lists_dirty && upload_lists(b)) return -1;
-  if (upload_call_params(b, b->n_abs - (g.M - 1), update_host, nblocks)) return -1;
+  int const pp = (int)(b->calls & 1);
+  size_t const Cmax = b->cfg.max_channels;
+  kq::Planes pl = b->pl2[pp];
+  kq::ChanDev chd = b->chd;
+  chd.lo_phase = b->osc_dev2[pp];
+  chd.lo_freq = chd.lo_phase + Cmax;
+  chd.lo_rate = chd.lo_phase + 2 * Cmax;
+  chd.sh_phase = chd.lo_phase + 3 * Cmax;
+  chd.sh_freq = chd.lo_phase + 4 * Cmax;
+  // this parity's hand-over planes were last read by the demodulators two calls ago
+  HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[pp], 0));
+  if (upload_call_params(b, b->osc_dev2[pp], b->n_abs - (g.M - 1), update_host, nblocks)) return -1;
   {
-    Scope t(b, 2);
-    kq::launch_block_energy(b->stream, window + (g.M - 1), g.L, (int)nblocks, b->update_dev, b->energy_state, b->pl.if_power);
+    Scope t(b, 2, b->stream);
+    kq::launch_block_energy(b->stream, window + (g.M - 1), g.L, (int)nblocks, b->update_dev, b->energy_state, pl.if_power);
   }
   {
-    Scope t(b, 0);
+    Scope t(b, 0, b->stream);
     if (b->fwd_mode == KQ_FWD_PRUNED) {
-      kq::launch_pruned_tables(b->stream, g, b->chd, b->chan_tw, C);
-      kq::launch_filter_pruned(b->stream, g, b->chd, b->pl, window, b->tw, b->chan_tw, C, (int)nblocks);
+      if (b->chan_tw_dirty) {  // the tables depend only on each channel's LO step: rebuild after a retune
+        kq::launch_pruned_tables(b->stream, g, chd, b->chan_tw, C);
+        b->chan_tw_dirty = false;
+      }
+      kq::launch_filter_pruned(b->stream, g, chd, pl, window, b->tw, b->chan_tw, C, (int)nblocks);
     } else {
-      kq::launch_filter_full(b->stream, g, b->chd, b->pl, window, b->tw, C, (int)nblocks, b->cfg.compute_n0, b->spec_dump,
+      kq::launch_filter_full(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, b->cfg.compute_n0, b->spec_dump,
                              b->spec_ch);
     }
     b->acc.filter_launches++;
     b->acc.channel_blocks += (uint64_t)C * nblocks;
   }
+  HIP_TRY(hipEventRecord(b->ev_filter_done, b->stream));
+  HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_filter_done, 0));
   {
-    Scope t(b, 1);
+    Scope t(b, 1, b->stream2);
     if (kq::demod64_supported(g))
-      kq::launch_demod64(b->stream, g, b->chd, b->pl, b->list_dev[0], (int)b->list_host[0].size(), b->list_dev[1],
+      kq::launch_demod64(b->stream2, g, chd, pl, b->list_dev[0], (int)b->list_host[0].size(), b->list_dev[1],
                          (int)b->list_host[1].size(), b->list_dev[2], (int)b->list_host[2].size(), (int)nblocks,
                          b->cfg.compute_n0);
     else
-      kq::launch_demods(b->stream, g, b->chd, b->pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), b->list_dev[1],
+      kq::launch_demods(b->stream2, g, chd, pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), b->list_dev[1],
                         (int)b->list_host[1].size(), b->list_dev[2], (int)b->list_host[2].size(), (int)nblocks,
                         b->cfg.compute_n0);
   }
+  HIP_TRY(hipEventRecord(b->ev_demod_done[pp], b->stream2));
+  b->pl = pl;  // what the pull functions read
+  b->calls++;
   HIP_TRY(hipGetLastError());
   b->n_abs += (int64_t)nblocks * g.L;
   b->out_abs += (int64_t)nblocks * g.olen;
@@ -488,12 +526,21 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.recovery, C);
   rc |= dev_alloc(&b->chd.hangmax, C);
   rc |= dev_alloc(&b->chd.noise_gain, C);
-  rc |= dev_alloc(&b->osc_dev, 5 * C);
-  b->chd.lo_phase = b->osc_dev;
-  b->chd.lo_freq = b->osc_dev + C;
-  b->chd.lo_rate = b->osc_dev + 2 * C;
-  b->chd.sh_phase = b->osc_dev + 3 * C;
-  b->chd.sh_freq = b->osc_dev + 4 * C;
+  for (int k = 0; k < 2; k++) rc |= dev_alloc(&b->osc_dev2[k], 5 * C);
+  b->chd.lo_phase = b->chd.lo_freq = b->chd.lo_rate = b->chd.sh_phase = b->chd.sh_freq = nullptr;  // set per call
+  // Overlap is opt-in (KQ_DEMOD_OVERLAP=1): measured on MI355X the single-wave demodulator workgroups squat on
+  // CUs between filter workgroups (236-VGPR waves cannot co-reside with them) and the step gets slower, so by
+  // default the demodulators simply follow the filter on the main stream.
+  const char *ov = getenv("KQ_DEMOD_OVERLAP");
+  bool const overlap = ov && atoi(ov) != 0;
+  if (!overlap) b->stream2 = b->stream;
+  if ((overlap && hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess) ||
+      hipEventCreateWithFlags(&b->ev_filter_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&b->ev_demod_done[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&b->ev_demod_done[1], hipEventDisableTiming) != hipSuccess) {
+    set_err("second stream / event creation failed");
+    rc = -1;
+  }
   b->stage_bytes = 5 * C * sizeof(double) + B;
   for (int k = 0; k < kq_bank::kSlots && !rc; k++) {
     if (hipHostMalloc((void **)&b->stage_host[k], b->stage_bytes, hipHostMallocDefault) != hipSuccess ||
@@ -512,11 +559,16 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.hang, C);
   rc |= dev_alloc(&b->chd.dc, C);
   rc |= dev_alloc(&b->chd.n0, C);
-  rc |= dev_alloc(&b->pl.filt, C * B * g.olen);
   rc |= dev_alloc(&b->pl.audio, C * B * 2 * (size_t)g.olen);
   rc |= dev_alloc(&b->pl.status, C * B);
-  rc |= dev_alloc(&b->pl.n0raw, C * B);
-  rc |= dev_alloc(&b->pl.if_power, B);
+  for (int k = 0; k < 2; k++) {  // filter -> demod hand-over planes, one set per call parity
+    b->pl2[k].audio = b->pl.audio;
+    b->pl2[k].status = b->pl.status;
+    rc |= dev_alloc(&b->pl2[k].filt, C * B * g.olen);
+    rc |= dev_alloc(&b->pl2[k].n0raw, C * B);
+    rc |= dev_alloc(&b->pl2[k].if_power, B);
+  }
+  b->pl = b->pl2[0];
   rc |= dev_alloc(&b->energy_state, 2);
   rc |= dev_alloc(&b->update_dev, B);
   for (int k = 0; k < 3; k++) rc |= dev_alloc(&b->list_dev[k], C);
@@ -545,11 +597,13 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
 int kq_bank_destroy(kq_bank *b) {
   if (!b) return 0;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->stream2 && b->stream2 != b->stream) (void)hipStreamSynchronize(b->stream2);
   void *ptrs[] = {b->ring[0], b->ring[1], b->tw, b->chan_tw, b->chd.mode, b->chd.flags, b->chd.low, b->chd.high, b->chd.resp,
                   b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain,
-                  b->osc_dev, b->chd.fm_state,
+                  b->osc_dev2[0], b->osc_dev2[1], b->chd.fm_state,
                   b->chd.lastaudio, b->chd.sq_count, b->chd.ahist, b->chd.foffset, b->chd.pdev, b->chd.gain, b->chd.hang,
-                  b->chd.dc, b->chd.n0, b->pl.filt, b->pl.audio, b->pl.status, b->pl.n0raw, b->pl.if_power, b->energy_state,
+                  b->chd.dc, b->chd.n0, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
+                  b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state,
                   b->update_dev, b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -562,6 +616,10 @@ int kq_bank_destroy(kq_bank *b) {
     if (b->stage_host[k]) (void)hipHostFree(b->stage_host[k]);
     if (b->stage_ev[k]) (void)hipEventDestroy(b->stage_ev[k]);
   }
+  if (b->ev_filter_done) (void)hipEventDestroy(b->ev_filter_done);
+  for (int k = 0; k < 2; k++)
+    if (b->ev_demod_done[k]) (void)hipEventDestroy(b->ev_demod_done[k]);
+  if (b->stream2 && b->stream2 != b->stream) (void)hipStreamDestroy(b->stream2);
   if (b->own_stream && b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
   return 0;
@@ -688,7 +746,7 @@ int kq_bank_push_iq(kq_bank *b, const void *iq, size_t nsamples, int format, int
     src = b->stage_dev;
   }
   {
-    Scope t(b, 2);
+    Scope t(b, 2, b->stream);
     kq::launch_ingest(b->stream, src, format, b->ring[b->cur] + used, nsamples, b->cfg.gain_factor);
   }
   if (!is_device) HIP_TRY(hipStreamSynchronize(b->stream));  // the caller may reuse iq
@@ -774,9 +832,16 @@ int kq_bank_process_resident(kq_bank *b, const void *iq_dev, unsigned nblocks) {
   return run_blocks(b, (const float2 *)iq_dev, nblocks, upd.data());
 }
 
+int kq_bank_join(kq_bank *b) {
+  if (!b) return -1;
+  if (b->calls == 0) return 0;
+  HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[(b->calls - 1) & 1], 0));
+  return 0;
+}
+
 int kq_bank_sync(kq_bank *b) {
   if (!b) return -1;
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (sync_all(b)) return -1;
   return 0;
 }
 
@@ -788,7 +853,7 @@ int kq_bank_pull_status(kq_bank *b, int ch, unsigned blk, kq_chan_status *st) {
     set_err("bad channel/block");
     return -1;
   }
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (sync_all(b)) return -1;
   HIP_TRY(hipMemcpy(st, b->pl.status + (size_t)ch * b->g.max_blocks + blk, sizeof(*st), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -815,7 +880,7 @@ int kq_bank_pull_filter_output(kq_bank *b, int ch, unsigned blk, float *dst, siz
     set_err("bad channel/block/capacity");
     return -1;
   }
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (sync_all(b)) return -1;
   HIP_TRY(hipMemcpy(dst, b->pl.filt + ((size_t)ch * b->g.max_blocks + blk) * b->g.olen, b->g.olen * sizeof(float2),
                     hipMemcpyDeviceToHost));
   return 0;
@@ -842,7 +907,7 @@ int kq_bank_pull_spectrum(kq_bank *b, int ch, unsigned blk, float *dst, size_t c
     set_err("bad block");
     return -1;
   }
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (sync_all(b)) return -1;
   HIP_TRY(hipMemcpy(dst, b->spec_dump + (size_t)blk * b->g.N, b->g.N * sizeof(float2), hipMemcpyDeviceToHost));
   return 0;
 }

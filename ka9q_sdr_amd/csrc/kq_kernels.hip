@@ -160,18 +160,30 @@ __global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *_
 // which runs the filter but leaves block_energy and if_power alone: update[b] == 0 marks those.
 __global__ void k_block_energy_iir(const float *sums, const unsigned char *__restrict__ update, int nblocks, int L,
                                    float *__restrict__ state, float *if_power) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave: fetch 64 sums/flags at a time in parallel, then run the (inherently serial) recurrence out of
+  // registers via readlane
+  int const lane = threadIdx.x;
   float e = state[0], last = state[1];
-  for (int b = 0; b < nblocks; b++) {
-    e += sums[b];
-    if (update[b]) {
-      e *= 0.5f;
-      last = e / L;
+  for (int base = 0; base < nblocks; base += 64) {
+    int const i = base + lane;
+    float const sm = i < nblocks ? sums[i] : 0.f;
+    int const up = i < nblocks ? update[i] : 0;
+    float mine = 0.f;
+    int const cnt = min(64, nblocks - base);
+    for (int k = 0; k < cnt; k++) {
+      e += __shfl(sm, k, 64);
+      if (__shfl(up, k, 64)) {
+        e *= 0.5f;
+        last = e / L;
+      }
+      if (lane == k) mine = last;
     }
-    if_power[b] = last;
+    if (i < nblocks) if_power[i] = mine;
   }
-  state[0] = e;
-  state[1] = last;
+  if (lane == 0) {
+    state[0] = e;
+    state[1] = last;
+  }
 }
 
 void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nblocks, const unsigned char *update,

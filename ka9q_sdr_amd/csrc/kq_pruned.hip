@@ -67,28 +67,34 @@ constexpr int bitrev5(int i) {
   return ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
 }
 
-// 32-point forward FFT in registers, decimation in frequency, radix 2, fully unrolled.
-// In: v[0..31] natural order.  Out: bin q' is left in v[bitrev5(q')].
-__device__ __forceinline__ void fft32_dif(float2 (&v)[32]) {
+// 32-point forward FFT in registers, decimation in time, radix 2, fully unrolled, compile-time twiddles.
+// In: sample a must have been stored at v[bitrev5(a)].  Out: bin q' in v[q'] (natural order).
+// Butterflies are FMA-fused: u = a + w b costs 4 fma, the other output is 2a - u (2 fma): 6 ops instead of the
+// 8 of multiply-then-add/sub.
+__device__ __forceinline__ void fft32_dit(float2 (&v)[32]) {
 #pragma unroll
-  for (int len = 32; len >= 2; len >>= 1) {
+  for (int len = 2; len <= 32; len <<= 1) {
     int const half = len / 2;
-    int const tstep = 64 / len;  // twiddle exp(-2 pi i j / len) = w64[j * 64/len]
+    int const tstep = 64 / len;  // exp(-2 pi i j / len) = w64[j * 64/len]
 #pragma unroll
     for (int base = 0; base < 32; base += len) {
 #pragma unroll
       for (int j = 0; j < half; j++) {
         float2 const a = v[base + j], b = v[base + j + half];
-        v[base + j] = cadd(a, b);
-        float2 const d = csub(a, b);
         int const t = j * tstep;  // 0..31
         if (t == 0) {
-          v[base + j + half] = d;
-        } else if (t == 16) {
-          v[base + j + half] = make_float2(d.y, -d.x);  // times -i
+          v[base + j] = cadd(a, b);
+          v[base + j + half] = csub(a, b);
+        } else if (t == 16) {  // w = -i: w b = (b.y, -b.x)
+          v[base + j] = make_float2(a.x + b.y, a.y - b.x);
+          v[base + j + half] = make_float2(a.x - b.y, a.y + b.x);
         } else {
           float const wr = w64_re(t), wi = w64_im(t);
-          v[base + j + half] = make_float2(d.x * wr - d.y * wi, d.x * wi + d.y * wr);
+          float2 u;
+          u.x = fmaf(wr, b.x, fmaf(-wi, b.y, a.x));
+          u.y = fmaf(wr, b.y, fmaf(wi, b.x, a.y));
+          v[base + j] = u;
+          v[base + j + half] = make_float2(fmaf(2.f, a.x, -u.x), fmaf(2.f, a.y, -u.y));
         }
       }
     }
@@ -203,7 +209,7 @@ __global__ void __launch_bounds__(NWAVES * 64) k_filter_pruned64(Geom g, ChanDev
     // premultiply).  Each pass: accumulate the column groups, then reduce over the 64 lanes.
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-      float2 acc[32];  // bin q' (q = 2 q' + pass) lives in acc[bitrev5(q')]
+      float2 acc[32];  // acc[q'] = bin q = 2 q' + pass
 #pragma unroll 1
       for (int j = 0; j < groups; j++) {
         const float2 *col = lds + 64 * j + lane;
@@ -241,15 +247,15 @@ __global__ void __launch_bounds__(NWAVES * 64) k_filter_pruned64(Geom g, ChanDev
             float2 r = make_float2(x0.x * t.x - x0.y * t.y, x0.x * t.y + x0.y * t.x);
             r.x = fmaf(x1.x, t.z, fmaf(-x1.y, t.w, r.x));
             r.y = fmaf(x1.x, t.w, fmaf(x1.y, t.z, r.y));
-            v[k * CH + i] = r;
+            v[bitrev5(k * CH + i)] = r;
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        fft32_dif(v);
+        fft32_dit(v);
         __builtin_amdgcn_sched_barrier(0);
         if (j == 0) {
 #pragma unroll
-          for (int i = 0; i < 32; i++) acc[i] = v[i];
+          for (int i = 0; i < 32; i++) acc[i] = v[i];  // natural bin order
         } else {
           const float4 *tj = reinterpret_cast<const float4 *>(wJ + ((j - 1) * 2 + pass) * 32);
 #pragma unroll
@@ -260,8 +266,8 @@ __global__ void __launch_bounds__(NWAVES * 64) k_filter_pruned64(Geom g, ChanDev
 #pragma unroll
             for (int i = 0; i < 4; i++) {
               int const q0 = k * 8 + 2 * i;
-              acc[bitrev5(q0)] = cfma(make_float2(w4[i].x, w4[i].y), v[bitrev5(q0)], acc[bitrev5(q0)]);
-              acc[bitrev5(q0 + 1)] = cfma(make_float2(w4[i].z, w4[i].w), v[bitrev5(q0 + 1)], acc[bitrev5(q0 + 1)]);
+              acc[q0] = cfma(make_float2(w4[i].x, w4[i].y), v[q0], acc[q0]);
+              acc[q0 + 1] = cfma(make_float2(w4[i].z, w4[i].w), v[q0 + 1], acc[q0 + 1]);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -276,7 +282,7 @@ __global__ void __launch_bounds__(NWAVES * 64) k_filter_pruned64(Geom g, ChanDev
         const float2 *tl = tL + 5 * 64;
 #pragma unroll
         for (int m = 0; m < 16; m++) {
-          float2 e = acc[bitrev5(2 * m)], o = acc[bitrev5(2 * m + 1)];
+          float2 e = acc[2 * m], o = acc[2 * m + 1];
           swap32(e.x, o.x);
           swap32(e.y, o.y);
           // lower lanes: e = own even, o = partner's even; upper lanes: e = partner's odd, o = own odd

@@ -6,8 +6,8 @@
 //            (previous valid sample = highest set bit below the lane), and the REAL->REAL de-emphasis
 //            overlap-save (fm.c:162-171) as 64-point transforms across the 64 lanes (history in lanes 0-31,
 //            the new block in lanes 32-63).  No LDS, no barriers.
-//   AM/lin : the AGC is a sequential recurrence (am.c:55-75, linear.c:251-281): one lane per channel, the
-//            block's 32 samples fetched up front so the loop is pure ALU.
+//   AM/lin : one wave per channel, one lane per sample (two blocks per iteration); only the AGC recurrence
+//            (am.c:55-75, linear.c:251-281) is serial, wave-uniform through v_readlane.
 // Blocks of one channel are processed in sequence with the state carried in registers, and written back
 // to HBM at the end of the launch.
 #include "kq_device.hpp"
@@ -200,8 +200,15 @@ __device__ void fm_channel(const Geom &g, const ChanDev &ch, const Planes &pl, i
   }
 }
 
+// AM / linear: one wave per channel, one lane per sample, two consecutive blocks per iteration (lanes 0-31 and
+// 32-63).  Square roots, the attack gains headroom/level (IEEE divisions), the shift NCO and all loads/stores are
+// lane-parallel and coalesced; only the AGC recurrence itself (am.c:64-74, linear.c:269-279: one multiply, one
+// compare, two selects per sample) runs serially, wave-uniform, reading its per-sample inputs with v_readlane.
+// The arithmetic per sample is exactly the reference's, in the reference's order.
 template <bool LINEAR>
 __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
+  int const lane = threadIdx.x & 63;
+  int const half = lane >> 5, n = lane & 31;
   float const headroom = ch.headroom[c], recovery = ch.recovery[c];
   int const hangmax = ch.hangmax[c];
   bool const stereo = LINEAR && (ch.flags[c] & FLAG_STEREO) != 0;
@@ -209,97 +216,108 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
   float gain = ch.gain[c], dc = LINEAR ? 0.f : ch.dc[c];
   int hang = ch.hang[c];
   float n0 = ch.n0[c];
-  for (int b = 0; b < nblocks; b++) {
-    const float4 *in = reinterpret_cast<const float4 *>(pl.filt + ((size_t)c * g.max_blocks + b) * 32);
-    float4 buf[16];
+  const float2 *in = pl.filt + (size_t)c * g.max_blocks * 32;
+  float2 s_next = (half < nblocks) ? in[lane] : make_float2(0.f, 0.f);
+  for (int b0 = 0; b0 < nblocks; b0 += 2) {
+    int const blk = b0 + half;
+    bool const active = blk < nblocks;
+    int const nsamp = (b0 + 1 < nblocks) ? 64 : 32;  // wave-uniform
+    float2 const S = s_next;
+    if (b0 + 2 < nblocks) s_next = (blk + 2 < nblocks) ? in[(size_t)(b0 + 2) * 32 + lane] : make_float2(0.f, 0.f);
+    float const rp = S.x * S.x, ip = S.y * S.y;
+    float level = sqrtf(LINEAR ? rp + ip : S.x * S.x + S.y * S.y);  // amplitude (linear.c:260) / envelope (am.c:58)
+    float const env = level;
+    // per-block power sums over each 32-lane half
+    float sig = LINEAR ? rp : rp + ip, noi = LINEAR ? ip : 0.f;
+    if (!LINEAR) sig = S.x * S.x + S.y * S.y;
 #pragma unroll
-    for (int i = 0; i < 16; i++) buf[i] = in[i];
-    float *aud = pl.audio + ((size_t)c * g.max_blocks + b) * 64;
-    float signal = 0, noise = 0;
-    float o[64];
-#pragma unroll
-    for (int i = 0; i < 32; i++) {
-      float2 s = (i & 1) ? make_float2(buf[i >> 1].z, buf[i >> 1].w) : make_float2(buf[i >> 1].x, buf[i >> 1].y);
+    for (int o = 16; o > 0; o >>= 1) {
+      sig += __shfl_xor(sig, o, 64);
+      noi += __shfl_xor(noi, o, 64);
+    }
+    if (!LINEAR) {
+      // carrier tracking (am.c:62), serial; lane i keeps the value after sample i
+      float dc_mine = dc;
+      for (int i = 0; i < nsamp; i++) {
+        float const e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, env), i));
+        dc += 0.0001f * (e - dc);
+        dc_mine = (lane == i) ? dc : dc_mine;
+      }
+      level = dc_mine;
+    }
+    float const inv = headroom / level;
+    float g_mine = gain;
+    float gain_end[2] = {gain, gain};
+    int hang_end[2] = {hang, hang};
+    for (int i = 0; i < nsamp; i++) {
+      float const lv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, level), i));
+      float const iv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), i));
+      bool const nan_gain = isnan(gain);
+      bool const attack = nan_gain || (LINEAR ? lv * gain > headroom : gain * lv > headroom);
+      float const rec = (hang != 0) ? gain : gain * recovery;
+      int const hdec = (hang != 0) ? hang - 1 : 0;
+      hang = (attack && !nan_gain) ? hangmax : (attack ? hang : hdec);
+      gain = attack ? iv : rec;
+      g_mine = (lane == i) ? gain : g_mine;
+      if (i == 31) {
+        gain_end[0] = gain;
+        hang_end[0] = hang;
+      }
+    }
+    gain_end[1] = gain;
+    hang_end[1] = hang;
+    float *aud = pl.audio + ((size_t)c * g.max_blocks + blk) * 64;
+    if (active) {
       if (LINEAR) {
-        float const rp = s.x * s.x, ip = s.y * s.y;
-        signal += rp;
-        noise += ip;
-        float const amplitude = sqrtf(rp + ip);
-        if (isnan(gain)) {
-          gain = headroom / amplitude;
-        } else if (amplitude * gain > headroom) {
-          gain = headroom / amplitude;
-          hang = hangmax;
-        } else if (hang != 0) {
-          hang--;
-        } else {
-          gain *= recovery;
-        }
-        s = make_float2(s.x * gain, s.y * gain);
-        if (sh_f != 0.0) {
-          double turns = sh_ph + sh_f * ((double)b * 32 + i);
+        float2 sv = make_float2(S.x * g_mine, S.y * g_mine);
+        if (sh_f != 0.0) {  // linear.c:283-289
+          double turns = sh_ph + sh_f * ((double)blk * 32 + n);
           turns -= rint(turns);
           float sn, cs;
           sincospif(2.f * (float)turns, &sn, &cs);
-          s = cmul(s, make_float2(cs, sn));
+          sv = cmul(sv, make_float2(cs, sn));
         }
-        o[2 * i] = s.x;
-        o[2 * i + 1] = s.y;
+        if (stereo)
+          reinterpret_cast<float2 *>(aud)[n] = sv;
+        else
+          aud[n] = sv.x;
       } else {
-        float const sq = cnrm(s);
-        signal += sq;
-        float const samp = sqrtf(sq);
-        dc += 0.0001f * (samp - dc);
-        if (isnan(gain)) {
-          gain = headroom / dc;
-        } else if (gain * dc > headroom) {
-          gain = headroom / dc;
-          hang = hangmax;
-        } else if (hang != 0) {
-          hang--;
-        } else {
-          gain *= recovery;
-        }
-        o[i] = (samp - dc) * gain;
+        aud[n] = (env - level) * g_mine;
       }
     }
-    if (LINEAR) {
-      if (stereo) {
-        float4 *a4 = reinterpret_cast<float4 *>(aud);
+    // status: lane 0 of each half, in block order so the smoothed n0 follows the sequence
 #pragma unroll
-        for (int i = 0; i < 16; i++) a4[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
-      } else {
-        float4 *a4 = reinterpret_cast<float4 *>(aud);
-#pragma unroll
-        for (int i = 0; i < 8; i++) a4[i] = make_float4(o[8 * i], o[8 * i + 2], o[8 * i + 4], o[8 * i + 6]);
+    for (int h = 0; h < 2; h++) {
+      if (b0 + h < nblocks) {
+        float const sg = __shfl(sig, h * 32, 64), nz = __shfl(noi, h * 32, 64);
+        if (lane == 0) {
+          kq_chan_status st;
+          put_status(st, g, ch, pl, c, b0 + h, compute_n0, .001f, n0);
+          st.bb_power = (sg + nz) / 64.f;
+          st.snr = LINEAR ? NAN : 0.f;
+          st.foffset = 0;
+          st.pdeviation = 0;
+          st.agc_gain = gain_end[h];
+          st.squelch_count = 0;
+          st.hangcount = hang_end[h];
+          st.blanked = 0;
+          st.nout = stereo ? 64 : 32;
+          pl.status[(size_t)c * g.max_blocks + b0 + h] = st;
+        }
       }
-    } else {
-      float4 *a4 = reinterpret_cast<float4 *>(aud);
-#pragma unroll
-      for (int i = 0; i < 8; i++) a4[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
     }
-    kq_chan_status st;
-    put_status(st, g, ch, pl, c, b, compute_n0, .001f, n0);
-    st.bb_power = (signal + noise) / 64.f;
-    st.snr = LINEAR ? NAN : 0.f;
-    st.foffset = 0;
-    st.pdeviation = 0;
-    st.agc_gain = gain;
-    st.squelch_count = 0;
-    st.hangcount = hang;
-    st.blanked = 0;
-    st.nout = stereo ? 64 : 32;
-    pl.status[(size_t)c * g.max_blocks + b] = st;
   }
-  ch.gain[c] = gain;
-  if (!LINEAR) ch.dc[c] = dc;
-  ch.hang[c] = hang;
-  ch.n0[c] = n0;
+  if (lane == 0) {
+    ch.gain[c] = gain;
+    if (!LINEAR) ch.dc[c] = dc;
+    ch.hang[c] = hang;
+    ch.n0[c] = n0;
+  }
 }
 
 }  // namespace
 
-// grid = n_fm + ceil(n_am/64) + ceil(n_lin/64) workgroups of one wave
+// grid = n_fm + n_am + n_lin workgroups of one wave (one channel each)
 __global__ void __launch_bounds__(64) k_demod64(Geom g, ChanDev ch, Planes pl, const int *__restrict__ list_fm, int n_fm,
                                                 const int *__restrict__ list_am, int n_am,
                                                 const int *__restrict__ list_lin, int n_lin, int nblocks, int compute_n0) {
@@ -309,22 +327,19 @@ __global__ void __launch_bounds__(64) k_demod64(Geom g, ChanDev ch, Planes pl, c
     return;
   }
   wg -= n_fm;
-  int const am_wgs = (n_am + 63) / 64;
-  if (wg < am_wgs) {
-    int const i = wg * 64 + threadIdx.x;
-    if (i < n_am) agc_channel<false>(g, ch, pl, list_am[i], nblocks, compute_n0);
+  if (wg < n_am) {
+    agc_channel<false>(g, ch, pl, list_am[wg], nblocks, compute_n0);
     return;
   }
-  wg -= am_wgs;
-  int const i = wg * 64 + threadIdx.x;
-  if (i < n_lin) agc_channel<true>(g, ch, pl, list_lin[i], nblocks, compute_n0);
+  wg -= n_am;
+  if (wg < n_lin) agc_channel<true>(g, ch, pl, list_lin[wg], nblocks, compute_n0);
 }
 
 bool demod64_supported(const Geom &g) { return g.Ndec == 64 && g.olen == 32 && g.Mdec == 33; }
 
 void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const int *list_fm, int n_fm,
                     const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0) {
-  int const wgs = n_fm + (n_am + 63) / 64 + (n_lin + 63) / 64;
+  int const wgs = n_fm + n_am + n_lin;
   if (wgs == 0) return;
   hipLaunchKernelGGL(k_demod64, dim3(wgs), dim3(64), 0, s, g, ch, pl, list_fm, n_fm, list_am, n_am, list_lin, n_lin, nblocks,
                      compute_n0);

@@ -351,6 +351,12 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     return -1;
   }
   if (b->lists_dirty && upload_lists(b)) return -1;
+  if (b->fwd_mode == KQ_FWD_PRUNED)
+    for (HostChan const &h : b->chans)
+      if (h.lo2.sweep() != 0 || (h.dop.set_f != 0 && h.dop.sweep() != 0)) {
+        set_err("the pruned forward path does not handle a swept NCO (Doppler rate) yet: use KQ_FWD_FULL");
+        return -1;
+      }
   int const pp = (int)(b->calls & 1);
   size_t const Cmax = b->cfg.max_channels;
   kq::Planes pl = b->pl2[pp];
@@ -375,6 +381,8 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
         b->chan_tw_dirty = false;
       }
       kq::launch_filter_pruned(b->stream, g, chd, pl, window, b->tw, b->chan_tw, C, (int)nblocks);
+    } else if (g.N > 16384) {
+      kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks);
     } else {
       kq::launch_filter_full(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, b->cfg.compute_n0, b->spec_dump,
                              b->spec_ch);
@@ -492,8 +500,8 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   } else {
     b->fwd_mode = can_prune ? KQ_FWD_PRUNED : KQ_FWD_FULL;
   }
-  if (b->fwd_mode == KQ_FWD_FULL && (size_t)N * sizeof(float2) > 160 * 1024) {
-    set_err("full forward path keeps the N-point block in LDS: N = %u exceeds 160 KiB", N);
+  if (b->fwd_mode == KQ_FWD_FULL && N > 16384 && (!kq::split_supported(g) || cfg->compute_n0)) {
+    set_err("N = %u: the full path beyond 16384 points needs N <= 65536, N/D <= 2048 and compute_n0 off", N);
     delete b;
     return nullptr;
   }

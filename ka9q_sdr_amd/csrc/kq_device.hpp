@@ -71,6 +71,9 @@ void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nbl
                          float *energy_state, float *if_power);
 void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                         const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch);
+bool split_supported(const Geom &g);
+void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
+                         const float2 *tw, int nchan, int nblocks);
 bool pruned_supported(const Geom &g);
 void launch_filter_pruned(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                           const float2 *tw, const float2 *chan_tw, int nchan, int nblocks);

@@ -284,6 +284,83 @@ void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const P
                      spec_dump, spec_ch);
 }
 
+// ---------------------------------------------------------------- full path for N beyond one LDS block
+// N = S * N1 with N1 * 8 B <= 128 KiB.  Decimation in time over s: F_s = FFT_N1{ xm[S m + s] } and
+// X[k] = sum_s W_N^{s k} F_s[k mod N1]; only the N/D bins the slave reads (filter.c:206-227) are combined,
+// into a small side buffer.  Same mix, response multiply, CROSS_CONJ and inverse transform as k_filter_full.
+// compute_n0 needs every bin of the N-point spectrum and is not available on this path.
+// grid (channel, block); dynamic LDS = (N1 + N_dec) float2.
+__global__ void k_filter_split(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,
+                               const float2 *__restrict__ tw, int S, int log2N1) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  int const c = blockIdx.x, b = blockIdx.y;
+  int const N = g.N, Ndec = g.Ndec, N1 = 1 << log2N1;
+  float2 *side = lds + N1;  // X at signed bin k, stored at index k mod N_dec
+  for (int i = threadIdx.x; i < Ndec; i += blockDim.x) side[i] = make_float2(0.f, 0.f);
+
+  double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c], r = ch.lo_rate[c];
+  const float2 *x = window + (size_t)b * g.L;
+  double const mbase = (double)b * g.L;
+  for (int s = 0; s < S; s++) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < N1; i += blockDim.x) {
+      int const n = S * i + s;
+      double const m = mbase + n;
+      double turns = ph0 + f0 * m;
+      if (r != 0.0) turns += r * (0.5 * m * (m - 1.0));
+      lds[bitrev((unsigned)i, log2N1)] = cmul(x[n], phasor_turns(turns));
+    }
+    lds_fft<-1>(lds, log2N1, tw, g.tw_log2);
+    for (int q = threadIdx.x; q < Ndec; q += blockDim.x) {
+      int const k = (q <= Ndec / 2) ? q : q - Ndec;            // signed bin
+      int const src = (k >= 0) ? k : N1 + k;                   // k mod N1
+      int idx = (int)(((long long)s * k) % N);                 // W_N^{s k}
+      if (idx < 0) idx += N;
+      float2 w = tw[(size_t)(idx & (N / 2 - 1)) << (g.tw_log2 - g.log2N)];
+      if (idx >= N / 2) w = make_float2(-w.x, -w.y);
+      side[q] = cadd(side[q], cmul(w, lds[src]));
+    }
+  }
+  __syncthreads();
+  const float2 *H = ch.resp + (size_t)c * Ndec;
+  bool const isb = (ch.flags[c] & FLAG_ISB) != 0;
+  float2 *G = lds;
+  for (int p = threadIdx.x; p <= Ndec / 2; p += blockDim.x) {
+    float2 gp = cmul(H[p], side[p]);
+    if (p > 0 && p < Ndec / 2) {
+      int const k = Ndec - p;
+      float2 gn = cmul(H[k], side[k]);
+      if (isb) {
+        float2 const pos = gp, neg = gn;
+        gp = cadd(pos, cconj(neg));
+        gn = csub(neg, cconj(pos));
+      }
+      G[bitrev((unsigned)k, g.log2Ndec)] = gn;
+    }
+    G[bitrev((unsigned)p, g.log2Ndec)] = gp;
+  }
+  lds_fft<+1>(G, g.log2Ndec, tw, g.tw_log2);
+  float2 *o = pl.filt + ((size_t)c * g.max_blocks + b) * g.olen;
+  for (int i = threadIdx.x; i < g.olen; i += blockDim.x) o[i] = G[Ndec - g.olen + i];
+}
+
+bool split_supported(const Geom &g) {
+  return g.N > 16384 && g.N <= 65536 && (size_t)g.Ndec * 8 + 16384 * 8 <= 160 * 1024 - 256;
+}
+
+void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
+                         const float2 *tw, int nchan, int nblocks) {
+  int const log2N1 = 14;
+  int const S = g.N >> log2N1;
+  size_t const lds_bytes = ((size_t)(1 << log2N1) + g.Ndec) * sizeof(float2);
+  static size_t configured = 0;
+  if (lds_bytes > configured) {
+    (void)hipFuncSetAttribute((const void *)k_filter_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    configured = lds_bytes;
+  }
+  hipLaunchKernelGGL(k_filter_split, dim3(nchan, nblocks), dim3(1024), lds_bytes, s, g, ch, pl, window, tw, S, log2N1);
+}
+
 // ---------------------------------------------------------------- demodulators
 __device__ __forceinline__ void status_common(kq_chan_status &st, const Geom &g, const ChanDev &ch, const Planes &pl, int c,
                                               int b, int compute_n0, float n0_rate) {

@@ -182,3 +182,29 @@ def test_config_geometry_pruned(gpu, name, nchan, nblocks):
     got, mode = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_PRUNED, per_call=3)
     assert mode == kq.KQ_FWD_PRUNED
     _compare(plan, got, want)
+
+
+def test_cfg5_geometry_swept_doppler(gpu):
+    """BASELINE configs[4] geometry: N=65536 (L=32768, M=32769), D=512, SSB with a swept Doppler NCO
+    (doppler.freq != 0, rate != 0: osc.c:43-47 sweep).  Runs on the split full path (N > one LDS block)."""
+    g = wl.GEOMETRY["cfg5"]
+    plan = wl.channel_plan("cfg5", 4, first=100)
+    plan[1]["channels"] = 2          # one stereo I/Q channel
+    nblocks = 3
+    iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=13)
+    want = run_oracle(plan, g, iq, nblocks)
+    got, mode = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_FULL, per_call=2)
+    assert mode == kq.KQ_FWD_FULL
+    _compare(plan, got, want)
+
+
+def test_pruned_refuses_swept_nco(gpu):
+    g = wl.GEOMETRY["cfg4"]
+    p = wl.channel_plan("cfg4", 1)[0]
+    p.update(doppler=1000.0, doppler_rate=50.0)
+    bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], 1, 1, fwd_mode=kq.KQ_FWD_PRUNED)
+    bank.add_channel(bank_cfg(p))
+    bank.push_iq(np.zeros(g["L"], np.complex64))
+    with pytest.raises(kq.KqError, match="swept"):
+        bank.process()
+    bank.close()

@@ -351,12 +351,21 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     return -1;
   }
   if (b->lists_dirty && upload_lists(b)) return -1;
+  bool swept = false;
   if (b->fwd_mode == KQ_FWD_PRUNED)
-    for (HostChan const &h : b->chans)
-      if (h.lo2.sweep() != 0 || (h.dop.set_f != 0 && h.dop.sweep() != 0)) {
-        set_err("the pruned forward path does not handle a swept NCO (Doppler rate) yet: use KQ_FWD_FULL");
+    for (HostChan const &h : b->chans) {
+      double const r = h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0);
+      if (r == 0) continue;
+      swept = true;
+      // The pruned kernels take the sweep's cross term r*R*a*b to first order and drop its b^2 part:
+      // both must stay far below the 1e-5 parity budget over one window.
+      double const cross = 2 * M_PI * std::fabs(r) * (double)g.N * g.D, quad = std::fabs(r) * (double)g.D * g.D * 0.5;
+      if (cross > 3e-4 || quad > 2e-7) {
+        set_err("sweep rate too large for the pruned forward path (cross term %.3g rad): use KQ_FWD_FULL", cross);
         return -1;
       }
+    }
+  if (swept) b->chan_tw_dirty = true;  // the step changes from call to call
   int const pp = (int)(b->calls & 1);
   size_t const Cmax = b->cfg.max_channels;
   kq::Planes pl = b->pl2[pp];
@@ -380,7 +389,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
         kq::launch_pruned_tables(b->stream, g, chd, b->chan_tw, C);
         b->chan_tw_dirty = false;
       }
-      kq::launch_filter_pruned(b->stream, g, chd, pl, window, b->tw, b->chan_tw, C, (int)nblocks);
+      kq::launch_filter_pruned(b->stream, g, chd, pl, window, b->chan_tw, C, (int)nblocks, swept);
     } else if (g.N > 16384) {
       kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks);
     } else {

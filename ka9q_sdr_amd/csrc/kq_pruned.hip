@@ -10,12 +10,26 @@
 // T_b[k] = exp(j 2 pi b (f - k/N)).  Same values as the full N-point FFT at those bins up to float
 // rounding, for (5 N log2 N_dec + ~14 N) flops instead of 5 N log2 N.
 //
-// Mapping (N_dec = 64): one wave per channel-block, one lane per column b (mod 64), the 64-point
-// column FFT in registers as two 32-point halves (even / odd output bins), per-channel twiddles from
-// small tables read through the scalar cache, columns b, b+64, b+128, ... accumulated in registers,
-// the remaining 64-lane sum done as a cross-lane reduce-scatter, then response multiply, CROSS_CONJ
-// and the 64-point inverse FFT across lanes.  The N-sample window is staged once in LDS and shared by
-// all waves of the workgroup and by several channels per wave.
+// Mapping: one wave per channel-block, one lane per column b (mod 64).  The N_dec-point column FFT runs
+// entirely in the lane's registers as P = N_dec/32 passes of a 32-point FFT (pass p yields bins q = P q' + p;
+// the first radix-P stage is fused into the premultiply by A).  Columns b, b+64, ... are accumulated in
+// registers by Horner's rule with one wave-uniform twiddle T[k] = exp(j 2 pi 64 (f - k/N)); the remaining sum
+// over the 64 lanes is a reduce-scatter over the lane bits (v_permlane32_swap for bit 5), followed in the same
+// wave by P0, the response multiply, CROSS_CONJ and the N_dec-point inverse transform.
+// Per-channel twiddles live in a wave-private LDS slot and are read back as wave-uniform (broadcast)
+// ds_reads: LDS reads retire in order, so they pipeline with the column reads.  (Scalar loads were tried
+// first: they return out of order, every use needs s_waitcnt lgkmcnt(0), which also drains the LDS column
+// reads -- 48 % of wave time was spent waiting.)
+//
+// Two kernels:
+//   k_pruned_resident  N_dec = 64, N <= 16384: the whole window is staged once in LDS and shared by all waves
+//                      of the workgroup and several channels per wave.
+//   k_pruned_stream    N_dec = 128, N = 65536: the window is streamed through LDS in slices of 64 columns
+//                      with global_load_lds (no VGPR staging), double buffered.
+// Swept NCO (set_doppler rate != 0, osc.c:43-47): phase(n) = phi + f n + r n(n-1)/2.  With n = R a + b the
+// quadratic term splits into a part in a (folded into A), a part in b (negligible, checked on the host) and the
+// cross term r R a b, applied per sample to first order (x *= 1 + j 2 pi r R a b).  The SWEPT kernels rebuild
+// their tables per channel-block from the block's instantaneous step.
 #include <cstdlib>
 
 #include "kq_device.hpp"
@@ -35,9 +49,9 @@ __device__ __forceinline__ float2 cfma(float2 b, float2 c, float2 a) {
   return make_float2(fmaf(-b.y, c.y, fmaf(b.x, c.x, a.x)), fmaf(b.y, c.x, fmaf(b.x, c.y, a.y)));
 }
 
-// compile-time twiddles exp(-2 pi i k / 64)
+// ---- compile-time twiddles exp(-2 pi i k / n), 0 <= k < n/2
 constexpr double kPi = 3.14159265358979323846264338327950288;
-constexpr double cx_cos(double x) {  // |x| <= pi/2 after reduction below; Taylor to 1e-17
+constexpr double cx_cos(double x) {  // |x| <= pi/4
   double const x2 = x * x;
   double term = 1, sum = 1;
   for (int n = 1; n < 14; n++) {
@@ -55,13 +69,14 @@ constexpr double cx_sin(double x) {
   }
   return sum;
 }
-// real / imaginary part of exp(-2 pi i k / 64) for 0 <= k < 32, exact symmetries used for accuracy
-constexpr float w64_re(int k) {
-  return k == 0 ? 1.f : k == 16 ? 0.f : (k < 16 ? (float)cx_cos(2 * kPi * k / 64) : (float)(-cx_sin(2 * kPi * (k - 16) / 64)));
+constexpr double turn_cos(double t) {  // cos(2 pi t), 0 <= t < 0.5, octant symmetries keep exact zeros exact
+  return t <= 0.125 ? cx_cos(2 * kPi * t) : t <= 0.375 ? -cx_sin(2 * kPi * (t - 0.25)) : -cx_cos(2 * kPi * (0.5 - t));
 }
-constexpr float w64_im(int k) {
-  return k == 0 ? 0.f : k == 16 ? -1.f : (k < 16 ? (float)(-cx_sin(2 * kPi * k / 64)) : (float)(-cx_cos(2 * kPi * (k - 16) / 64)));
+constexpr double turn_sin(double t) {
+  return t <= 0.125 ? cx_sin(2 * kPi * t) : t <= 0.375 ? cx_cos(2 * kPi * (t - 0.25)) : cx_sin(2 * kPi * (0.5 - t));
 }
+constexpr float tw_re(int k, int n) { return (float)turn_cos((double)k / n); }
+constexpr float tw_im(int k, int n) { return (float)(-turn_sin((double)k / n)); }
 
 constexpr int bitrev5(int i) {
   return ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
@@ -69,27 +84,26 @@ constexpr int bitrev5(int i) {
 
 // 32-point forward FFT in registers, decimation in time, radix 2, fully unrolled, compile-time twiddles.
 // In: sample a must have been stored at v[bitrev5(a)].  Out: bin q' in v[q'] (natural order).
-// Butterflies are FMA-fused: u = a + w b costs 4 fma, the other output is 2a - u (2 fma): 6 ops instead of the
-// 8 of multiply-then-add/sub.
+// Butterflies are FMA-fused: u = a + w b costs 4 fma, the other output is 2a - u (2 fma).
 __device__ __forceinline__ void fft32_dit(float2 (&v)[32]) {
 #pragma unroll
   for (int len = 2; len <= 32; len <<= 1) {
     int const half = len / 2;
-    int const tstep = 64 / len;  // exp(-2 pi i j / len) = w64[j * 64/len]
+    int const tstep = 64 / len;
 #pragma unroll
     for (int base = 0; base < 32; base += len) {
 #pragma unroll
       for (int j = 0; j < half; j++) {
         float2 const a = v[base + j], b = v[base + j + half];
-        int const t = j * tstep;  // 0..31
+        int const t = j * tstep;  // twiddle exp(-2 pi i t / 64), 0..31
         if (t == 0) {
           v[base + j] = cadd(a, b);
           v[base + j + half] = csub(a, b);
-        } else if (t == 16) {  // w = -i: w b = (b.y, -b.x)
+        } else if (t == 16) {  // w = -i
           v[base + j] = make_float2(a.x + b.y, a.y - b.x);
           v[base + j + half] = make_float2(a.x - b.y, a.y + b.x);
         } else {
-          float const wr = w64_re(t), wi = w64_im(t);
+          float const wr = tw_re(t, 64), wi = tw_im(t, 64);
           float2 u;
           u.x = fmaf(wr, b.x, fmaf(-wi, b.y, a.x));
           u.y = fmaf(wr, b.y, fmaf(wi, b.x, a.y));
@@ -101,21 +115,59 @@ __device__ __forceinline__ void fft32_dit(float2 (&v)[32]) {
   }
 }
 
-// Table layout per channel (floats), built by k_pruned_tables:
-//   A  : [2 passes][32] float4  = (A0.re, A0.im, A1.re, A1.im)
-//   J  : [3][2 passes][32] float2  column-group twiddles, j = 1..3, bin q = 2 q' + pass
-//   Lv : [6][64] float2            cross-lane levels, lane bit i, natural q
-// A and J (2560 B) are copied into a wave-private LDS slot per channel-block and read back with
-// wave-uniform ds_read_b128 (broadcast): LDS reads retire in order, so they pipeline with the column
-// reads.  (Scalar loads were tried first: they return out of order, every use needs s_waitcnt lgkmcnt(0),
-// and that also drains the LDS column reads -- 48 % of wave time was spent waiting.)
-constexpr int kTabA = 2 * 32 * 4;
-constexpr int kTabJ = 3 * 64 * 2;
-constexpr int kTabL = 6 * 64 * 2;
-constexpr int kTabFloats = kTabA + kTabJ + kTabL;
-constexpr int kWaveTabF4 = (kTabA + kTabJ) / 4;  // 160 float4 per wave
+// ---- per-channel tables (floats).  ND = 64: A is merged per pass, [2][32] float4 = (A[a] w, A[a+32] w') with the
+// pass twiddle folded in.  ND = 128: A only, [32][4] float2 = A[a' + 32 s] (the pass twiddle W_128^{a' p} is a
+// compile-time constant applied after the fold).  T: [P][32] float2 Horner twiddle of bin q = P q' + p.
+// Lv: [6][ND] float2 cross-lane level twiddles, natural q.
+template <int ND>
+struct Tab {
+  static constexpr int P = ND / 32;
+  static constexpr int kA = (ND == 64) ? 2 * 32 * 4 : 32 * 4 * 2;
+  static constexpr int kT = ND * 2;
+  static constexpr int kL = 6 * ND * 2;
+  static constexpr int kFloats = kA + kT + kL;
+  static constexpr int kWaveF4 = (kA + kT) / 4;  // float4 copied into the wave's LDS slot
+};
 
-__device__ __forceinline__ int signed_bin(int q) { return q <= 32 ? q : q - 64; }
+template <int ND>
+__device__ __forceinline__ int signed_bin(int q) {
+  return q <= ND / 2 ? q : q - ND;
+}
+
+__device__ __forceinline__ float2 unit(double turns) {
+  turns -= rint(turns);
+  float s, c;
+  sincospif(2.f * (float)turns, &s, &c);
+  return make_float2(c, s);
+}
+
+// Table entry i of the A + T part (i indexes float2 units), for instantaneous step f, sweep r, R columns
+template <int ND>
+__device__ __forceinline__ float2 table_entry_AT(int i, double f, double r, int R, int N) {
+  constexpr int P = ND / 32;
+  constexpr int nA = Tab<ND>::kA / 2;
+  if (i < nA) {
+    double a, extra = 0;
+    if (ND == 64) {
+      // entry = [pass][a'][half]: A[a' + 32 half], times W64^{a'} (and a minus sign on the second) in pass 1
+      int const pass = i >> 6, ap = (i >> 1) & 31, hf = i & 1;
+      a = ap + 32 * hf;
+      if (pass) extra = -(double)ap / 64.0 + (hf ? 0.5 : 0.0);
+    } else {
+      int const ap = i >> 2, s = i & 3;  // [a'][s]
+      a = ap + 32 * s;
+    }
+    double const Ra = (double)R * a;
+    return unit(f * Ra + r * (0.5 * Ra * (Ra - 1.0)) + extra);
+  }
+  int const t = i - nA;  // T: [p][q'] -> bin q = P q' + p
+  int const p = t >> 5, qp = t & 31;
+  int const q = P * qp + p;
+  double turns = 64.0 * f;
+  turns -= rint(turns);
+  turns -= 64.0 * (double)signed_bin<ND>(q) / (double)N;
+  return unit(turns);
+}
 
 __device__ __forceinline__ void swap32(float &a, float &b) {
   // v_permlane32_swap: lanes 32..63 of a <-> lanes 0..31 of b
@@ -124,61 +176,220 @@ __device__ __forceinline__ void swap32(float &a, float &b) {
   b = __uint_as_float(r[1]);
 }
 
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- one column group, one pass: premultiply + radix-P fold + 32-point FFT.
+// col[STRIDE * a] is row a of this lane's column; tab is the wave's LDS slot (A part).
+template <int ND, int PASS, int STRIDE, bool SWEPT>
+__device__ __forceinline__ void column_pass(const float2 *col, const float4 *tab, float kappa, float2 (&v)[32]) {
+  constexpr int P = ND / 32;
+  constexpr int CH = (ND == 64) ? 4 : 2;  // rows a' per software-pipeline stage
+  // Software pipeline in chunks of CH rows: the LDS reads of chunk k+1 are issued before the arithmetic of chunk
+  // k; sched_barriers pin that order, otherwise the scheduler hoists every read of the pass and spills.
+  float2 xs[2][CH][P];
+  float4 tw[2][CH][(ND == 64) ? 1 : 2];
+#pragma unroll
+  for (int i = 0; i < CH; i++) {
+#pragma unroll
+    for (int s = 0; s < P; s++) xs[0][i][s] = col[STRIDE * (i + 32 * s)];
+    if (ND == 64) {
+      tw[0][i][0] = tab[PASS * 32 + i];
+    } else {
+      tw[0][i][0] = tab[2 * i];
+      tw[0][i][1] = tab[2 * i + 1];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 32 / CH; k++) {
+    int const cur = k & 1, nxt = cur ^ 1;
+    if (k + 1 < 32 / CH) {
+#pragma unroll
+      for (int i = 0; i < CH; i++) {
+        int const ap = (k + 1) * CH + i;
+#pragma unroll
+        for (int s = 0; s < P; s++) xs[nxt][i][s] = col[STRIDE * (ap + 32 * s)];
+        if (ND == 64) {
+          tw[nxt][i][0] = tab[PASS * 32 + ap];
+        } else {
+          tw[nxt][i][0] = tab[2 * ap];
+          tw[nxt][i][1] = tab[2 * ap + 1];
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+      int const ap = k * CH + i;
+      float2 x[P];
+#pragma unroll
+      for (int s = 0; s < P; s++) {
+        x[s] = xs[cur][i][s];
+        if (SWEPT) {  // cross term of the sweep, first order: x *= 1 + j kappa a
+          float const ph = kappa * (float)(ap + 32 * s);
+          x[s] = make_float2(fmaf(-ph, x[s].y, x[s].x), fmaf(ph, x[s].x, x[s].y));
+        }
+      }
+      float2 r;
+      if (ND == 64) {
+        float4 const t = tw[cur][i][0];
+        r = make_float2(x[0].x * t.x - x[0].y * t.y, x[0].x * t.y + x[0].y * t.x);
+        r.x = fmaf(x[1].x, t.z, fmaf(-x[1].y, t.w, r.x));
+        r.y = fmaf(x[1].x, t.w, fmaf(x[1].y, t.z, r.y));
+      } else {
+        // sum_s x_s A_s (-i)^{s PASS}: the power of -i is a compile-time component swap / sign of A_s
+        float2 const A[4] = {make_float2(tw[cur][i][0].x, tw[cur][i][0].y), make_float2(tw[cur][i][0].z, tw[cur][i][0].w),
+                             make_float2(tw[cur][i][1].x, tw[cur][i][1].y), make_float2(tw[cur][i][1].z, tw[cur][i][1].w)};
+        r = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < P; s++) {
+          int const e = (s * PASS) & 3;  // A * (-i)^e
+          float2 const As = e == 0   ? A[s]
+                            : e == 1 ? make_float2(A[s].y, -A[s].x)
+                            : e == 2 ? make_float2(-A[s].x, -A[s].y)
+                                     : make_float2(-A[s].y, A[s].x);
+          r = (s == 0) ? cmul(x[0], As) : cfma(x[s], As, r);
+        }
+        if (PASS != 0 && ap != 0) {  // times W_128^{a' PASS}
+          int const t = (ap * PASS) % 128;  // < 96
+          float const wr = t < 64 ? tw_re(t, 128) : -tw_re(t - 64, 128);
+          float const wi = t < 64 ? tw_im(t, 128) : -tw_im(t - 64, 128);
+          r = make_float2(r.x * wr - r.y * wi, r.x * wi + r.y * wr);
+        }
+      }
+      v[bitrev5(ap)] = r;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  fft32_dit(v);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// acc = v + T * acc (Horner over the column groups), T from the wave's LDS slot, 8 bins per chunk
+__device__ __forceinline__ void horner(float2 (&acc)[32], const float2 (&v)[32], const float4 *tT) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    float4 w4[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) w4[i] = tT[k * 4 + i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int const q0 = k * 8 + 2 * i;
+      acc[q0] = cfma(make_float2(w4[i].x, w4[i].y), acc[q0], v[q0]);
+      acc[q0 + 1] = cfma(make_float2(w4[i].z, w4[i].w), acc[q0 + 1], v[q0 + 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Reduce acc[q'] (bin q = P q' + PASS) over the 64 lanes: reduce-scatter over lane bits 5..1, pair sum over bit 0.
+// Returns the bin with q' = rev5(lane >> 1), identical in both lanes of a pair.  th[i]: extra uniform factor of
+// level i (swept NCO), multiplied into the level twiddle.
+template <int ND, int PASS, bool SWEPT>
+__device__ __forceinline__ float2 lane_reduce(float2 (&acc)[32], const float2 *tL, const float2 (&th)[6], int lane) {
+  constexpr int P = ND / 32;
+  float2 z[16];
+  int qlow;
+  {
+    int const bit = (lane >> 5) & 1;
+    qlow = bit;
+    const float2 *tl = tL + 5 * ND;
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      float2 e = acc[2 * m], o = acc[2 * m + 1];
+      swap32(e.x, o.x);
+      swap32(e.y, o.y);
+      // lower lanes: e = own even, o = partner's even; upper lanes: e = partner's odd, o = own odd
+      float2 w = tl[P * (2 * m + bit) + PASS];
+      if (SWEPT) w = cmul(w, th[5]);
+      z[m] = cfma(w, o, e);
+    }
+  }
+#pragma unroll
+  for (int t = 1; t < 5; t++) {
+    int const i = 5 - t;
+    int const bit = (lane >> i) & 1;
+    int const cnt = 16 >> t;
+    const float2 *tl = tL + (size_t)i * ND;
+#pragma unroll
+    for (int m = 0; m < cnt; m++) {
+      float2 const e = z[2 * m], o = z[2 * m + 1];
+      float2 const keep = bit ? o : e, send = bit ? e : o;
+      float2 recv;
+      recv.x = __shfl_xor(send.x, 1 << i, 64);
+      recv.y = __shfl_xor(send.y, 1 << i, 64);
+      float2 const lo = bit ? recv : keep, hi = bit ? keep : recv;
+      int const qp = (((2 * m + bit) << t) | qlow);
+      float2 w = tl[P * qp + PASS];
+      if (SWEPT) w = cmul(w, th[i]);
+      z[m] = cfma(w, hi, lo);
+    }
+    qlow |= bit << t;
+  }
+  float2 recv;
+  recv.x = __shfl_xor(z[0].x, 1, 64);
+  recv.y = __shfl_xor(z[0].y, 1, 64);
+  int const b0 = lane & 1;
+  float2 const lo = b0 ? recv : z[0], hi = b0 ? z[0] : recv;
+  float2 w = tL[P * qlow + PASS];
+  if (SWEPT) w = cmul(w, th[0]);
+  return cfma(w, hi, lo);
+}
+
+// Fill the wave's LDS slot (A and T) and the per-level sweep factors for channel c, block blk
+template <int ND, bool SWEPT>
+__device__ __forceinline__ void fill_tables(float4 *wtab, const float *tc, double f_blk, double df, double r, int R, int N,
+                                            float2 (&th)[6], int lane) {
+  if (SWEPT) {
+    float2 *w2 = reinterpret_cast<float2 *>(wtab);
+    for (int i = lane; i < Tab<ND>::kWaveF4 * 2; i += 64) w2[i] = table_entry_AT<ND>(i, f_blk, r, R, N);
+    // the level tables in HBM were built for the call's first block: rotate them by the step difference
+#pragma unroll
+    for (int i = 0; i < 6; i++) th[i] = unit((double)(1 << i) * df);
+  } else {
+    const float4 *src = reinterpret_cast<const float4 *>(tc);
+    for (int i = lane; i < Tab<ND>::kWaveF4; i += 64) wtab[i] = src[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) th[i] = make_float2(1.f, 0.f);
+  }
+  wave_lds_sync();
+}
+
 }  // namespace
 
-// Per-channel twiddle tables for the call (the NCO step f0 is constant over a call for unswept channels)
+// Per-channel twiddle tables for the call (step f0 at the first window; constant over a call for unswept channels)
+template <int ND>
 __global__ void k_pruned_tables(Geom g, ChanDev ch, float *__restrict__ tab, int nchan) {
   int const c = blockIdx.x;
   if (c >= nchan) return;
   double const f = ch.lo_freq[c];
-  int const R = g.D;  // N = N_dec * R
-  float *t = tab + (size_t)c * kTabFloats;
-  for (int i = threadIdx.x; i < 2 * 32; i += blockDim.x) {
-    int const pass = i >> 5, a = i & 31;
-    // even bins: u[a] = x[a] A[a] + x[a+32] A[a+32]
-    // odd bins : v[a] = (x[a] A[a] - x[a+32] A[a+32]) * W64^a
-    double t0 = f * (double)R * a, t1 = f * (double)R * (a + 32);
-    if (pass) {
-      t0 -= a / 64.0;
-      t1 -= a / 64.0;
-      t1 += 0.5;  // the minus sign
-    }
-    t0 -= rint(t0);
-    t1 -= rint(t1);
-    float s0, c0, s1, c1;
-    sincospif(2.f * (float)t0, &s0, &c0);
-    sincospif(2.f * (float)t1, &s1, &c1);
-    float *o = t + (size_t)i * 4;
-    o[0] = c0;
-    o[1] = s0;
-    o[2] = c1;
-    o[3] = s1;
-  }
-  for (int i = threadIdx.x; i < 3 * 64 + 6 * 64; i += blockDim.x) {
-    int const row = i >> 6, rem = i & 63;
-    // rows 0..2: column groups j=1..3 (offset 64 j), stored [pass][q']; rows 3..8: lane bit (offset 2^bit), natural q
-    int const q = row < 3 ? 2 * (rem & 31) + (rem >> 5) : rem;
-    double const off = row < 3 ? 64.0 * (row + 1) : (double)(1 << (row - 3));
+  float2 *t = reinterpret_cast<float2 *>(tab + (size_t)c * Tab<ND>::kFloats);
+  constexpr int nAT = (Tab<ND>::kA + Tab<ND>::kT) / 2;
+  for (int i = threadIdx.x; i < nAT; i += blockDim.x) t[i] = table_entry_AT<ND>(i, f, 0.0, g.D, g.N);
+  for (int i = threadIdx.x; i < 6 * ND; i += blockDim.x) {
+    int const lvl = i / ND, q = i % ND;
+    double const off = (double)(1 << lvl);
     double turns = off * f;
     turns -= rint(turns);
-    turns -= off * (double)signed_bin(q) / (double)g.N;
-    turns -= rint(turns);
-    float s, co;
-    sincospif(2.f * (float)turns, &s, &co);
-    float *o = t + kTabA + (size_t)i * 2;
-    o[0] = co;
-    o[1] = s;
+    turns -= off * (double)signed_bin<ND>(q) / (double)g.N;
+    t[nAT + i] = unit(turns);
   }
 }
 
-// grid (channel groups, blocks); block = NWAVES waves; dynamic LDS = N float2 + NWAVES * 2560 B
-template <int NWAVES, int CPW, int R>
-__global__ void __launch_bounds__(NWAVES * 64) k_filter_pruned64(Geom g, ChanDev ch, Planes pl,
+// ------------------------------------------------------------------ N_dec = 64, window resident in LDS
+// grid (channel groups, blocks); block = NWAVES waves; dynamic LDS = N float2 + NWAVES wave slots
+template <int NWAVES, int CPW, int R, bool SWEPT>
+__global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident(Geom g, ChanDev ch, Planes pl,
                                                                  const float2 *__restrict__ window,
                                                                  const float *__restrict__ tab, int nchan) {
+  constexpr int ND = 64;
+  constexpr int N = ND * R;  // compile time, so that LDS offsets are immediates
+  constexpr int groups = R / 64;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   int const blk = blockIdx.y;
-  constexpr int N = 64 * R;  // R = decimation ratio = number of columns; compile-time so LDS offsets are immediates
   {
     const float4 *src = reinterpret_cast<const float4 *>(window + (size_t)blk * g.L);
     float4 *dst = reinterpret_cast<float4 *>(lds);
@@ -186,140 +397,48 @@ __global__ void __launch_bounds__(NWAVES * 64) k_filter_pruned64(Geom g, ChanDev
   }
   __syncthreads();
   int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  constexpr int groups = R / 64;  // column groups of 64 lanes
-  float4 *wtab = reinterpret_cast<float4 *>(lds + N) + wave * kWaveTabF4;
+  float4 *wtab = reinterpret_cast<float4 *>(lds + N) + wave * Tab<ND>::kWaveF4;
   int const b0 = lane & 1;
+  double const m0 = (double)blk * g.L;
 
   for (int ci = 0; ci < CPW; ci++) {
     int const c = __builtin_amdgcn_readfirstlane((blockIdx.x * NWAVES + wave) * CPW + ci);
     if (c >= nchan) break;
-    const float *tc = tab + (size_t)c * kTabFloats;
-    const float2 *tL = reinterpret_cast<const float2 *>(tc + kTabA + kTabJ);
-    {
-      const float4 *src = reinterpret_cast<const float4 *>(tc);
-      for (int i = lane; i < kWaveTabF4; i += 64) wtab[i] = src[i];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    const float2 *wJ = reinterpret_cast<const float2 *>(wtab + 64);
+    const float *tc = tab + (size_t)c * Tab<ND>::kFloats;
+    const float2 *tL = reinterpret_cast<const float2 *>(tc + Tab<ND>::kA + Tab<ND>::kT);
+    double const f0 = ch.lo_freq[c], r = SWEPT ? ch.lo_rate[c] : 0.0;
+    double const f_blk = f0 + r * m0;
+    float2 th[6];
+    fill_tables<ND, SWEPT>(wtab, tc, f_blk, r * m0, r, R, N, th, lane);
+    const float4 *wT = wtab + Tab<ND>::kA / 4;
+    float const kap_lane = SWEPT ? (float)(2.0 * kPi * r * (double)R) : 0.f;  // times b = 64 j + lane below
 
     float2 ypass[2];
-    // pass 0 = even bins, pass 1 = odd bins (first radix-2 DIF stage of the 64-point column FFT fused into the
-    // premultiply).  Each pass: accumulate the column groups, then reduce over the 64 lanes.
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
-      float2 acc[32];  // acc[q'] = bin q = 2 q' + pass
+      float2 acc[32];
 #pragma unroll 1
-      for (int j = 0; j < groups; j++) {
+      for (int j = groups - 1; j >= 0; j--) {
         const float2 *col = lds + 64 * j + lane;
-        const float4 *tAj = wtab + pass * 32;
+        float const kappa = kap_lane * (float)(64 * j + lane);
         float2 v[32];
-        // Software pipeline in chunks of CH samples: the LDS reads of chunk k+1 (2 column samples and one
-        // broadcast twiddle pair per row) are issued before the arithmetic of chunk k; sched_barriers pin
-        // that order, otherwise the scheduler hoists all 96 reads of the pass and spills.
-        constexpr int CH = 4;
-        float4 tw_[2][CH];
-        float2 xa_[2][CH], xb_[2][CH];
+        if (pass == 0)
+          column_pass<ND, 0, R, SWEPT>(col, wtab, kappa, v);
+        else
+          column_pass<ND, 1, R, SWEPT>(col, wtab, kappa, v);
+        if (j == groups - 1) {
 #pragma unroll
-        for (int i = 0; i < CH; i++) {
-          tw_[0][i] = tAj[i];
-          xa_[0][i] = col[R * i];
-          xb_[0][i] = col[R * (i + 32)];
-        }
-#pragma unroll
-        for (int k = 0; k < 32 / CH; k++) {
-          int const cur = k & 1, nxt = cur ^ 1;
-          if (k + 1 < 32 / CH) {
-#pragma unroll
-            for (int i = 0; i < CH; i++) {
-              int const a = (k + 1) * CH + i;
-              tw_[nxt][i] = tAj[a];
-              xa_[nxt][i] = col[R * a];
-              xb_[nxt][i] = col[R * (a + 32)];
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < CH; i++) {
-            float4 const t = tw_[cur][i];
-            float2 const x0 = xa_[cur][i], x1 = xb_[cur][i];
-            float2 r = make_float2(x0.x * t.x - x0.y * t.y, x0.x * t.y + x0.y * t.x);
-            r.x = fmaf(x1.x, t.z, fmaf(-x1.y, t.w, r.x));
-            r.y = fmaf(x1.x, t.w, fmaf(x1.y, t.z, r.y));
-            v[bitrev5(k * CH + i)] = r;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        fft32_dit(v);
-        __builtin_amdgcn_sched_barrier(0);
-        if (j == 0) {
-#pragma unroll
-          for (int i = 0; i < 32; i++) acc[i] = v[i];  // natural bin order
+          for (int i = 0; i < 32; i++) acc[i] = v[i];
         } else {
-          const float4 *tj = reinterpret_cast<const float4 *>(wJ + ((j - 1) * 2 + pass) * 32);
-#pragma unroll
-          for (int k = 0; k < 4; k++) {  // 8 bins per chunk, twiddles as 4 broadcast ds_read_b128
-            float4 w4[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) w4[i] = tj[k * 4 + i];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-              int const q0 = k * 8 + 2 * i;
-              acc[q0] = cfma(make_float2(w4[i].x, w4[i].y), v[q0], acc[q0]);
-              acc[q0 + 1] = cfma(make_float2(w4[i].z, w4[i].w), v[q0 + 1], acc[q0 + 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          horner(acc, v, wT + pass * 16);
         }
       }
-      // ---- reduce-scatter over lane bits 5..1, then a pair sum over bit 0
-      float2 z[16];
-      int qlow;
-      {  // lane bit 5 through v_permlane32_swap: no LDS, no selects
-        int const bit = (lane >> 5) & 1;
-        qlow = bit;
-        const float2 *tl = tL + 5 * 64;
-#pragma unroll
-        for (int m = 0; m < 16; m++) {
-          float2 e = acc[2 * m], o = acc[2 * m + 1];
-          swap32(e.x, o.x);
-          swap32(e.y, o.y);
-          // lower lanes: e = own even, o = partner's even; upper lanes: e = partner's odd, o = own odd
-          z[m] = cfma(tl[2 * (2 * m + bit) + pass], o, e);
-        }
-      }
-#pragma unroll
-      for (int t = 1; t < 5; t++) {
-        int const i = 5 - t;
-        int const bit = (lane >> i) & 1;
-        int const cnt = 16 >> t;
-        const float2 *tl = tL + (size_t)i * 64;
-#pragma unroll
-        for (int m = 0; m < cnt; m++) {
-          float2 const e = z[2 * m], o = z[2 * m + 1];
-          float2 const keep = bit ? o : e, send = bit ? e : o;
-          float2 recv;
-          recv.x = __shfl_xor(send.x, 1 << i, 64);
-          recv.y = __shfl_xor(send.y, 1 << i, 64);
-          float2 const lo = bit ? recv : keep, hi = bit ? keep : recv;
-          int const qp = (((2 * m + bit) << t) | qlow);
-          z[m] = cfma(tl[2 * qp + pass], hi, lo);
-        }
-        qlow |= bit << t;
-      }
-      {  // lane bit 0: both lanes of a pair end with the full sum
-        float2 recv;
-        recv.x = __shfl_xor(z[0].x, 1, 64);
-        recv.y = __shfl_xor(z[0].y, 1, 64);
-        float2 const lo = b0 ? recv : z[0], hi = b0 ? z[0] : recv;
-        ypass[pass] = cfma(tL[2 * qlow + pass], hi, lo);
-      }
+      ypass[pass] = (pass == 0) ? lane_reduce<ND, 0, SWEPT>(acc, tL, th, lane) : lane_reduce<ND, 1, SWEPT>(acc, tL, th, lane);
     }
-    // lane now holds bin 2*rev5(lane>>1) + pass for both passes; keep pass = lane bit 0, then move bin
-    // bitrev6(lane) into each lane for the decimation-in-time inverse transform
+    // lane holds bin 2*rev5(lane>>1) + pass for both passes; keep pass = lane bit 0, then move bin bitrev6(lane)
+    // into each lane for the decimation-in-time inverse transform
     float2 y = b0 ? ypass[1] : ypass[0];
-    int const q = (int)(__brev((unsigned)lane) >> 26);  // bin this lane must hold
+    int const q = (int)(__brev((unsigned)lane) >> 26);
     {
       int const src = (int)((__brev((unsigned)(q >> 1)) >> 27) << 1) | (q & 1);
       float2 t2;
@@ -327,15 +446,11 @@ __global__ void __launch_bounds__(NWAVES * 64) k_filter_pruned64(Geom g, ChanDev
       t2.y = __shfl(y.y, src, 64);
       y = t2;
     }
-
     // ---- P0, response multiply (filter.c:206-227), CROSS_CONJ (filter.c:239-249)
     {
-      double const m0 = (double)blk * g.L;
-      double turns = ch.lo_phase[c] + ch.lo_freq[c] * m0;
-      turns -= rint(turns);
-      float s, co;
-      sincospif(2.f * (float)turns, &s, &co);
-      y = cmul(y, make_float2(co, s));
+      double turns = ch.lo_phase[c] + f0 * m0;
+      if (SWEPT) turns += r * (0.5 * m0 * (m0 - 1.0));
+      y = cmul(y, unit(turns));
       y = cmul(y, ch.resp[(size_t)c * 64 + q]);
       if (ch.flags[c] & FLAG_ISB) {
         int const qp = (64 - q) & 63;
@@ -351,67 +466,230 @@ __global__ void __launch_bounds__(NWAVES * 64) k_filter_pruned64(Geom g, ChanDev
     for (int s = 0; s < 6; s++) {
       int const half = 1 << s;
       int const bit = (lane >> s) & 1;
-      int const jj = lane & (half - 1);
       float sw, cw;
-      sincospif((float)jj / (float)half, &sw, &cw);  // exp(+i pi jj / half) = exp(+2 pi i jj / (2 half))
+      sincospif((float)(lane & (half - 1)) / (float)half, &sw, &cw);
       float2 const v = bit ? cmul(y, make_float2(cw, sw)) : y;
-      float2 r;
-      r.x = __shfl_xor(v.x, half, 64);
-      r.y = __shfl_xor(v.y, half, 64);
-      y = bit ? csub(r, v) : cadd(v, r);
+      float2 rr;
+      rr.x = __shfl_xor(v.x, half, 64);
+      rr.y = __shfl_xor(v.y, half, 64);
+      y = bit ? csub(rr, v) : cadd(v, rr);
     }
-    // lane m holds sample m of the N_dec-point block; the last olen are the output (filter.c:131)
-    int const first = 64 - g.olen;
+    int const first = 64 - g.olen;  // the last olen samples are the output (filter.c:131)
     if (lane >= first) pl.filt[((size_t)c * g.max_blocks + blk) * g.olen + (lane - first)] = y;
   }
 }
 
-bool pruned_supported(const Geom &g) { return g.Ndec == 64 && (g.D == 64 || g.D == 128 || g.D == 256); }
-size_t pruned_table_elems(const Geom &) { return (size_t)kTabFloats / 2; }
+// ------------------------------------------------------------------ N_dec = 128, window streamed in column slices
+// grid (channel groups, blocks); block = NWAVES waves = NWAVES channels.
+// LDS: 2 slices of [128 rows][64 columns] float2 (64 KiB each) + per wave: A (1 KiB), T (1 KiB), scratch (1 KiB).
+template <int NWAVES, int R, bool SWEPT>
+__global__ void __launch_bounds__(NWAVES * 64) k_pruned_stream(Geom g, ChanDev ch, Planes pl,
+                                                               const float2 *__restrict__ window,
+                                                               const float *__restrict__ tab, int nchan) {
+  constexpr int ND = 128, P = 4;
+  constexpr int N = ND * R;
+  constexpr int groups = R / 64;
+  constexpr int kSlice = ND * 64;  // float2 per slice
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  int const blk = blockIdx.y;
+  int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float4 *wtab = reinterpret_cast<float4 *>(lds + 2 * kSlice) + wave * (Tab<ND>::kWaveF4 + ND / 2);
+  float2 *scratch = reinterpret_cast<float2 *>(wtab + Tab<ND>::kWaveF4);  // ND float2
+  const float2 *win = window + (size_t)blk * g.L;
+  double const m0 = (double)blk * g.L;
+
+  int const c = __builtin_amdgcn_readfirstlane(min((int)(blockIdx.x * NWAVES + wave), nchan - 1));
+  bool const live = (int)(blockIdx.x * NWAVES + wave) < nchan;  // idle waves still help loading the slices
+  const float *tc = tab + (size_t)c * Tab<ND>::kFloats;
+  const float2 *tL = reinterpret_cast<const float2 *>(tc + Tab<ND>::kA + Tab<ND>::kT);
+  double const f0 = ch.lo_freq[c], r = SWEPT ? ch.lo_rate[c] : 0.0;
+  double const f_blk = f0 + r * m0;
+  float2 th[6];
+  fill_tables<ND, SWEPT>(wtab, tc, f_blk, r * m0, r, R, N, th, lane);
+  const float4 *wT = wtab + Tab<ND>::kA / 4;
+  float const kap_lane = SWEPT ? (float)(2.0 * kPi * r * (double)R) : 0.f;
+
+  // slice j -> LDS buffer: each wave copies ND/NWAVES rows, two 512-byte rows per global_load_lds instruction
+  auto stage = [&](int j, int buf) {
+    constexpr int rows_per_wave = ND / NWAVES;
+#pragma unroll
+    for (int i = 0; i < rows_per_wave / 2; i++) {
+      int const row0 = wave * rows_per_wave + 2 * i;
+      const float4 *src = reinterpret_cast<const float4 *>(win + (size_t)(row0 + (lane >> 5)) * R + 64 * j) + (lane & 31);
+      float2 *dst = lds + buf * kSlice + row0 * 64;  // wave-uniform base; the hardware adds lane * 16 bytes
+      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    }
+  };
+
+  float2 ypass[P];
+  int step = 0;
+  stage(groups - 1, 0);
+#pragma unroll
+  for (int pass = 0; pass < P; pass++) {
+    float2 acc[32];
+#pragma unroll 1
+    for (int j = groups - 1; j >= 0; j--, step++) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // slice (pass, j) has landed; everyone is done with the other buffer
+      {
+        int nj = j - 1, np = pass;
+        if (nj < 0) {
+          nj = groups - 1;
+          np = pass + 1;
+        }
+        if (np < P) stage(nj, (step + 1) & 1);
+      }
+      const float2 *col = lds + (step & 1) * kSlice + lane;
+      float const kappa = kap_lane * (float)(64 * j + lane);
+      float2 v[32];
+      if (pass == 0)
+        column_pass<ND, 0, 64, SWEPT>(col, wtab, kappa, v);
+      else if (pass == 1)
+        column_pass<ND, 1, 64, SWEPT>(col, wtab, kappa, v);
+      else if (pass == 2)
+        column_pass<ND, 2, 64, SWEPT>(col, wtab, kappa, v);
+      else
+        column_pass<ND, 3, 64, SWEPT>(col, wtab, kappa, v);
+      if (j == groups - 1) {
+#pragma unroll
+        for (int i = 0; i < 32; i++) acc[i] = v[i];
+      } else {
+        horner(acc, v, wT + pass * 16);
+      }
+    }
+    ypass[pass] = pass == 0   ? lane_reduce<ND, 0, SWEPT>(acc, tL, th, lane)
+                  : pass == 1 ? lane_reduce<ND, 1, SWEPT>(acc, tL, th, lane)
+                  : pass == 2 ? lane_reduce<ND, 2, SWEPT>(acc, tL, th, lane)
+                              : lane_reduce<ND, 3, SWEPT>(acc, tL, th, lane);
+  }
+  if (!live) return;
+  // ---- each lane owns bins q = 4 q' + p, q' = rev5(lane >> 1), p = b0 and b0 + 2: P0 and response multiply
+  // (filter.c:206-227), then through the wave's scratch for CROSS_CONJ and the bit-reversed order of the inverse
+  {
+    int const b0 = lane & 1;
+    int const qp = (int)(__brev((unsigned)(lane >> 1)) >> 27);
+    double turns = ch.lo_phase[c] + f0 * m0;
+    if (SWEPT) turns += r * (0.5 * m0 * (m0 - 1.0));
+    float2 const p0 = unit(turns);
+    float2 const ya = b0 ? ypass[1] : ypass[0], yb = b0 ? ypass[3] : ypass[2];
+    int const qa = 4 * qp + b0, qb = qa + 2;
+    const float2 *H = ch.resp + (size_t)c * ND;
+    scratch[qa] = cmul(cmul(ya, p0), H[qa]);
+    scratch[qb] = cmul(cmul(yb, p0), H[qb]);
+  }
+  wave_lds_sync();
+  bool const isb = (ch.flags[c] & FLAG_ISB) != 0;
+  float2 z[2];
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    int const q = (int)(__brev((unsigned)(2 * lane + e)) >> 25);  // bitrev7
+    float2 gq = scratch[q];
+    if (isb && q != 0 && q != ND / 2) {  // filter.c:239-249
+      float2 const o = scratch[ND - q];
+      gq = (q < ND / 2) ? cadd(gq, cconj(o)) : csub(gq, cconj(o));
+    }
+    z[e] = gq;
+  }
+  // 128-point inverse, decimation in time on bit-reversed positions 2*lane, 2*lane+1
+  {
+    float2 const a = z[0], b = z[1];
+    z[0] = cadd(a, b);
+    z[1] = csub(a, b);
+  }
+#pragma unroll
+  for (int s = 1; s < 7; s++) {
+    int const half = 1 << s;
+    int const bit = (lane >> (s - 1)) & 1;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      int const jj = (2 * lane + e) & (half - 1);
+      float sw, cw;
+      sincospif((float)jj / (float)half, &sw, &cw);
+      float2 const v = bit ? cmul(z[e], make_float2(cw, sw)) : z[e];
+      float2 rr;
+      rr.x = __shfl_xor(v.x, half >> 1, 64);
+      rr.y = __shfl_xor(v.y, half >> 1, 64);
+      z[e] = bit ? csub(rr, v) : cadd(v, rr);
+    }
+  }
+  int const first = ND - g.olen;  // filter.c:131
+  float2 *o = pl.filt + ((size_t)c * g.max_blocks + blk) * g.olen;
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    int const pos = 2 * lane + e;
+    if (pos >= first) o[pos - first] = z[e];
+  }
+}
+
+// ------------------------------------------------------------------ host side
+bool pruned_supported(const Geom &g) {
+  if (g.Ndec == 64) return g.D == 64 || g.D == 128 || g.D == 256;
+  return g.Ndec == 128 && g.D == 512;
+}
+size_t pruned_table_elems(const Geom &g) { return (size_t)(g.Ndec == 64 ? Tab<64>::kFloats : Tab<128>::kFloats) / 2; }
 
 void launch_pruned_tables(hipStream_t s, const Geom &g, const ChanDev &ch, float2 *chan_tw, int nchan) {
-  hipLaunchKernelGGL(k_pruned_tables, dim3(nchan), dim3(256), 0, s, g, ch, reinterpret_cast<float *>(chan_tw), nchan);
+  if (g.Ndec == 64)
+    hipLaunchKernelGGL(k_pruned_tables<64>, dim3(nchan), dim3(256), 0, s, g, ch, reinterpret_cast<float *>(chan_tw), nchan);
+  else
+    hipLaunchKernelGGL(k_pruned_tables<128>, dim3(nchan), dim3(256), 0, s, g, ch, reinterpret_cast<float *>(chan_tw), nchan);
 }
 
 namespace {
-template <int NWAVES, int CPW, int R>
-void launch_r(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window, const float *tab,
-              int nchan, int nblocks) {
-  size_t const lds_bytes = (size_t)g.N * sizeof(float2) + (size_t)NWAVES * kWaveTabF4 * sizeof(float4);
+template <int R, bool SWEPT>
+void launch_resident(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window, const float *tab,
+                     int nchan, int nblocks) {
+  constexpr int NWAVES = 8, CPW = 4;
+  size_t const lds_bytes = (size_t)64 * R * sizeof(float2) + (size_t)NWAVES * Tab<64>::kWaveF4 * sizeof(float4);
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void *)k_filter_pruned64<NWAVES, CPW, R>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_pruned_resident<NWAVES, CPW, R, SWEPT>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     configured = true;
   }
   int const per_wg = NWAVES * CPW;
-  hipLaunchKernelGGL((k_filter_pruned64<NWAVES, CPW, R>), dim3((nchan + per_wg - 1) / per_wg, nblocks), dim3(NWAVES * 64),
-                     lds_bytes, s, g, ch, pl, window, tab, nchan);
+  hipLaunchKernelGGL((k_pruned_resident<NWAVES, CPW, R, SWEPT>), dim3((nchan + per_wg - 1) / per_wg, nblocks),
+                     dim3(NWAVES * 64), lds_bytes, s, g, ch, pl, window, tab, nchan);
 }
-template <int NWAVES, int CPW>
-void launch_variant(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window, const float *tab,
-                    int nchan, int nblocks) {
-  if (g.D == 256) return launch_r<NWAVES, CPW, 256>(s, g, ch, pl, window, tab, nchan, nblocks);
-  if (g.D == 128) return launch_r<NWAVES, CPW, 128>(s, g, ch, pl, window, tab, nchan, nblocks);
-  return launch_r<NWAVES, CPW, 64>(s, g, ch, pl, window, tab, nchan, nblocks);
+
+template <bool SWEPT>
+void launch_stream(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window, const float *tab,
+                   int nchan, int nblocks) {
+  constexpr int NWAVES = 8, R = 512;
+  size_t const lds_bytes = (size_t)2 * 128 * 64 * sizeof(float2) + (size_t)NWAVES * (Tab<128>::kWaveF4 + 64) * sizeof(float4);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void *)k_pruned_stream<NWAVES, R, SWEPT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes);
+    configured = true;
+  }
+  hipLaunchKernelGGL((k_pruned_stream<NWAVES, R, SWEPT>), dim3((nchan + NWAVES - 1) / NWAVES, nblocks), dim3(NWAVES * 64),
+                     lds_bytes, s, g, ch, pl, window, tab, nchan);
 }
 }  // namespace
 
 void launch_filter_pruned(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
-                          const float2 *, const float2 *chan_tw, int nchan, int nblocks) {
-  // tuning knobs (waves per workgroup, channels per wave); defaults chosen on MI355X
-  static int waves = 0, cpw = 0;
-  if (!waves) {
-    const char *e = getenv("KQ_PRUNED_WAVES");
-    waves = e ? atoi(e) : 8;
-    e = getenv("KQ_PRUNED_CPW");
-    cpw = e ? atoi(e) : 4;
-  }
+                          const float2 *chan_tw, int nchan, int nblocks, bool swept) {
   const float *tab = reinterpret_cast<const float *>(chan_tw);
-  if (waves == 12 && cpw == 2) return launch_variant<12, 2>(s, g, ch, pl, window, tab, nchan, nblocks);
-  if (waves == 12) return launch_variant<12, 4>(s, g, ch, pl, window, tab, nchan, nblocks);
-  if (cpw == 2) return launch_variant<8, 2>(s, g, ch, pl, window, tab, nchan, nblocks);
-  return launch_variant<8, 4>(s, g, ch, pl, window, tab, nchan, nblocks);
+  if (g.Ndec == 128) {
+    if (swept)
+      launch_stream<true>(s, g, ch, pl, window, tab, nchan, nblocks);
+    else
+      launch_stream<false>(s, g, ch, pl, window, tab, nchan, nblocks);
+    return;
+  }
+#define KQ_RES(RR)                                                           \
+  if (g.D == RR) {                                                           \
+    if (swept)                                                               \
+      launch_resident<RR, true>(s, g, ch, pl, window, tab, nchan, nblocks);  \
+    else                                                                     \
+      launch_resident<RR, false>(s, g, ch, pl, window, tab, nchan, nblocks); \
+    return;                                                                  \
+  }
+  KQ_RES(256)
+  KQ_RES(128)
+  KQ_RES(64)
+#undef KQ_RES
 }
 
 }  // namespace kq

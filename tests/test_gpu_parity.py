@@ -198,13 +198,60 @@ def test_cfg5_geometry_swept_doppler(gpu):
     _compare(plan, got, want)
 
 
-def test_pruned_refuses_swept_nco(gpu):
+def test_cfg5_geometry_pruned_stream(gpu):
+    """configs[4] on the pruned path: N/D = 128, window streamed through LDS, swept Doppler NCO per channel."""
+    g = wl.GEOMETRY["cfg5"]
+    plan = wl.channel_plan("cfg5", 11, first=200)
+    plan[2]["isb"] = 1
+    plan[2]["channels"] = 2
+    plan[5]["second_lo"] -= plan[5]["doppler"]    # one unswept channel in the swept launch, still on its emitter
+    plan[5]["doppler"] = plan[5]["doppler_rate"] = 0.0
+    nblocks = 3
+    iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=17)
+    want = run_oracle(plan, g, iq, nblocks)
+    got, mode = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_PRUNED, per_call=2)
+    assert mode == kq.KQ_FWD_PRUNED
+    _compare(plan, got, want)
+
+
+def test_cfg5_geometry_pruned_stream_unswept(gpu):
+    g = wl.GEOMETRY["cfg5"]
+    plan = wl.channel_plan("cfg5", 9)
+    for p in plan:
+        p["second_lo"] -= p["doppler"]
+        p["doppler"] = p["doppler_rate"] = 0.0
+    nblocks = 2
+    iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=19)
+    want = run_oracle(plan, g, iq, nblocks)
+    got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_PRUNED)
+    _compare(plan, got, want)
+
+
+def test_pruned_swept_doppler_cfg4_geometry(gpu):
+    """Doppler-tracked FM channels (rate != 0) at the cfg 3/4 geometry on the pruned path, several calls."""
+    g = wl.GEOMETRY["cfg4"]
+    plan = wl.channel_plan("cfg4", 6)
+    for i, p in enumerate(plan):
+        d = (-1) ** i * (3000.0 + 500.0 * i)
+        p.update(doppler=d, doppler_rate=(-1) ** i * (100.0 + 40.0 * i))
+        p["second_lo"] += d
+    plan[4]["second_lo"] -= plan[4]["doppler"]
+    plan[4]["doppler"] = plan[4]["doppler_rate"] = 0.0
+    nblocks = 6
+    iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=23)
+    want = run_oracle(plan, g, iq, nblocks)
+    got, mode = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_PRUNED, per_call=2)
+    assert mode == kq.KQ_FWD_PRUNED
+    _compare(plan, got, want)
+
+
+def test_pruned_refuses_huge_sweep(gpu):
     g = wl.GEOMETRY["cfg4"]
     p = wl.channel_plan("cfg4", 1)[0]
-    p.update(doppler=1000.0, doppler_rate=50.0)
+    p.update(doppler=1000.0, doppler_rate=5e6)       # 5 MHz/s: beyond the first-order treatment
     bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], 1, 1, fwd_mode=kq.KQ_FWD_PRUNED)
     bank.add_channel(bank_cfg(p))
     bank.push_iq(np.zeros(g["L"], np.complex64))
-    with pytest.raises(kq.KqError, match="swept"):
+    with pytest.raises(kq.KqError, match="sweep"):
         bank.process()
     bank.close()

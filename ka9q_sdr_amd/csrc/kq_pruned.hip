@@ -31,6 +31,7 @@
 // cross term r R a b, applied per sample to first order (x *= 1 + j 2 pi r R a b).  The SWEPT kernels rebuild
 // their tables per channel-block from the block's instantaneous step.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kq_device.hpp"
 
@@ -185,7 +186,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 // ---- one column group, one pass: premultiply + radix-P fold + 32-point FFT.
 // col[STRIDE * a] is row a of this lane's column; tab is the wave's LDS slot (A part).
 template <int ND, int PASS, int STRIDE, bool SWEPT>
-__device__ __forceinline__ void column_pass(const float2 *col, const float4 *tab, float kappa, float2 (&v)[32]) {
+__device__ __forceinline__ void column_pass(const float2 *col, const float4 *tab, const float2 *wsh, float kappa,
+                                            float2 (&v)[32]) {
   constexpr int P = ND / 32;
   constexpr int CH = (ND == 64) ? 4 : 2;  // rows a' per software-pipeline stage
   // Software pipeline in chunks of CH rows: the LDS reads of chunk k+1 are issued before the arithmetic of chunk
@@ -253,11 +255,10 @@ __device__ __forceinline__ void column_pass(const float2 *col, const float4 *tab
                                      : make_float2(-A[s].y, A[s].x);
           r = (s == 0) ? cmul(x[0], As) : cfma(x[s], As, r);
         }
-        if (PASS != 0 && ap != 0) {  // times W_128^{a' PASS}
-          int const t = (ap * PASS) % 128;  // < 96
-          float const wr = t < 64 ? tw_re(t, 128) : -tw_re(t - 64, 128);
-          float const wi = t < 64 ? tw_im(t, 128) : -tw_im(t - 64, 128);
-          r = make_float2(r.x * wr - r.y * wi, r.x * wi + r.y * wr);
+        if (PASS != 0 && ap != 0) {
+          // times W_128^{a' PASS}: read from a workgroup-shared LDS table (wave-uniform address).  As immediates
+          // the ~190 distinct constants of passes 1-3 do not fit the register file and spill.
+          r = cmul(r, wsh[(ap * PASS) % 128]);
         }
       }
       v[bitrev5(ap)] = r;
@@ -423,9 +424,9 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident(Geom g, ChanDev
         float const kappa = kap_lane * (float)(64 * j + lane);
         float2 v[32];
         if (pass == 0)
-          column_pass<ND, 0, R, SWEPT>(col, wtab, kappa, v);
+          column_pass<ND, 0, R, SWEPT>(col, wtab, nullptr, kappa, v);
         else
-          column_pass<ND, 1, R, SWEPT>(col, wtab, kappa, v);
+          column_pass<ND, 1, R, SWEPT>(col, wtab, nullptr, kappa, v);
         if (j == groups - 1) {
 #pragma unroll
           for (int i = 0; i < 32; i++) acc[i] = v[i];
@@ -481,7 +482,8 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident(Geom g, ChanDev
 
 // ------------------------------------------------------------------ N_dec = 128, window streamed in column slices
 // grid (channel groups, blocks); block = NWAVES waves = NWAVES channels.
-// LDS: 2 slices of [128 rows][64 columns] float2 (64 KiB each) + per wave: A (1 KiB), T (1 KiB), scratch (1 KiB).
+// LDS: 2 slices of [128 rows][64 columns] float2 (64 KiB each) + per wave: A (1 KiB), T (1 KiB), scratch (1 KiB)
+// + one shared table exp(-2 pi i k/128).
 template <int NWAVES, int R, bool SWEPT>
 __global__ void __launch_bounds__(NWAVES * 64) k_pruned_stream(Geom g, ChanDev ch, Planes pl,
                                                                const float2 *__restrict__ window,
@@ -495,6 +497,8 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_stream(Geom g, ChanDev c
   int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float4 *wtab = reinterpret_cast<float4 *>(lds + 2 * kSlice) + wave * (Tab<ND>::kWaveF4 + ND / 2);
   float2 *scratch = reinterpret_cast<float2 *>(wtab + Tab<ND>::kWaveF4);  // ND float2
+  float2 *wsh = reinterpret_cast<float2 *>(reinterpret_cast<float4 *>(lds + 2 * kSlice) + NWAVES * (Tab<ND>::kWaveF4 + ND / 2));
+  for (int i = threadIdx.x; i < 128; i += NWAVES * 64) wsh[i] = unit(-(double)i / 128.0);  // exp(-2 pi i k / 128)
   const float2 *win = window + (size_t)blk * g.L;
   double const m0 = (double)blk * g.L;
 
@@ -509,47 +513,40 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_stream(Geom g, ChanDev c
   const float4 *wT = wtab + Tab<ND>::kA / 4;
   float const kap_lane = SWEPT ? (float)(2.0 * kPi * r * (double)R) : 0.f;
 
-  // slice j -> LDS buffer: each wave copies ND/NWAVES rows, two 512-byte rows per global_load_lds instruction
+  // slice j -> LDS buffer: each wave copies ND/NWAVES rows, two 512-byte rows per global_load_lds instruction.
+  // Address = wave-uniform base (SGPR pair) + one per-lane byte offset, so no per-load address registers pile up.
+  unsigned const lane_off = (unsigned)(lane >> 5) * (unsigned)(R * sizeof(float2)) + (unsigned)(lane & 31) * 16u;
   auto stage = [&](int j, int buf) {
     constexpr int rows_per_wave = ND / NWAVES;
+    const char *slice0 = reinterpret_cast<const char *>(win + (size_t)(wave * rows_per_wave) * R + 64 * j);
 #pragma unroll
     for (int i = 0; i < rows_per_wave / 2; i++) {
-      int const row0 = wave * rows_per_wave + 2 * i;
-      const float4 *src = reinterpret_cast<const float4 *>(win + (size_t)(row0 + (lane >> 5)) * R + 64 * j) + (lane & 31);
-      float2 *dst = lds + buf * kSlice + row0 * 64;  // wave-uniform base; the hardware adds lane * 16 bytes
-      __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+      const char *ubase = slice0 + (size_t)(2 * i) * R * sizeof(float2);  // wave-uniform
+      float2 *dst = lds + buf * kSlice + (wave * rows_per_wave + 2 * i) * 64;  // wave-uniform; hardware adds lane*16
+      __builtin_amdgcn_global_load_lds(ubase + lane_off, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     }
   };
 
   float2 ypass[P];
   int step = 0;
   stage(groups - 1, 0);
-#pragma unroll
-  for (int pass = 0; pass < P; pass++) {
+  // The four passes are spelled out through a compile-time index: left as a loop the compiler unrolls it only
+  // partially, `pass` becomes a run-time value and every per-pass array lands in scratch.
+  auto do_pass = [&](auto pass_c) {
+    constexpr int pass = decltype(pass_c)::value;
     float2 acc[32];
 #pragma unroll 1
     for (int j = groups - 1; j >= 0; j--, step++) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // slice (pass, j) has landed; everyone is done with the other buffer
-      {
-        int nj = j - 1, np = pass;
-        if (nj < 0) {
-          nj = groups - 1;
-          np = pass + 1;
-        }
-        if (np < P) stage(nj, (step + 1) & 1);
-      }
+      if (j > 0)
+        stage(j - 1, (step + 1) & 1);
+      else if (pass + 1 < P)
+        stage(groups - 1, (step + 1) & 1);
       const float2 *col = lds + (step & 1) * kSlice + lane;
       float const kappa = kap_lane * (float)(64 * j + lane);
       float2 v[32];
-      if (pass == 0)
-        column_pass<ND, 0, 64, SWEPT>(col, wtab, kappa, v);
-      else if (pass == 1)
-        column_pass<ND, 1, 64, SWEPT>(col, wtab, kappa, v);
-      else if (pass == 2)
-        column_pass<ND, 2, 64, SWEPT>(col, wtab, kappa, v);
-      else
-        column_pass<ND, 3, 64, SWEPT>(col, wtab, kappa, v);
+      column_pass<ND, pass, 64, SWEPT>(col, wtab, wsh, kappa, v);
       if (j == groups - 1) {
 #pragma unroll
         for (int i = 0; i < 32; i++) acc[i] = v[i];
@@ -557,11 +554,12 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_stream(Geom g, ChanDev c
         horner(acc, v, wT + pass * 16);
       }
     }
-    ypass[pass] = pass == 0   ? lane_reduce<ND, 0, SWEPT>(acc, tL, th, lane)
-                  : pass == 1 ? lane_reduce<ND, 1, SWEPT>(acc, tL, th, lane)
-                  : pass == 2 ? lane_reduce<ND, 2, SWEPT>(acc, tL, th, lane)
-                              : lane_reduce<ND, 3, SWEPT>(acc, tL, th, lane);
-  }
+    ypass[pass] = lane_reduce<ND, pass, SWEPT>(acc, tL, th, lane);
+  };
+  do_pass(std::integral_constant<int, 0>{});
+  do_pass(std::integral_constant<int, 1>{});
+  do_pass(std::integral_constant<int, 2>{});
+  do_pass(std::integral_constant<int, 3>{});
   if (!live) return;
   // ---- each lane owns bins q = 4 q' + p, q' = rev5(lane >> 1), p = b0 and b0 + 2: P0 and response multiply
   // (filter.c:206-227), then through the wave's scratch for CROSS_CONJ and the bit-reversed order of the inverse
@@ -656,7 +654,8 @@ template <bool SWEPT>
 void launch_stream(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window, const float *tab,
                    int nchan, int nblocks) {
   constexpr int NWAVES = 8, R = 512;
-  size_t const lds_bytes = (size_t)2 * 128 * 64 * sizeof(float2) + (size_t)NWAVES * (Tab<128>::kWaveF4 + 64) * sizeof(float4);
+  size_t const lds_bytes = (size_t)2 * 128 * 64 * sizeof(float2) + (size_t)NWAVES * (Tab<128>::kWaveF4 + 64) * sizeof(float4) +
+                           128 * sizeof(float2);
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void *)k_pruned_stream<NWAVES, R, SWEPT>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -403,14 +403,19 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_filter_done, 0));
   {
     Scope t(b, 1, b->stream2);
-    if (kq::demod64_supported(g))
-      kq::launch_demod64(b->stream2, g, chd, pl, b->list_dev[0], (int)b->list_host[0].size(), b->list_dev[1],
-                         (int)b->list_host[1].size(), b->list_dev[2], (int)b->list_host[2].size(), (int)nblocks,
+    int const nfm = (int)b->list_host[0].size(), nam = (int)b->list_host[1].size(), nlin = (int)b->list_host[2].size();
+    if (kq::demod64_supported(g)) {
+      kq::launch_demod64(b->stream2, g, chd, pl, b->list_dev[0], nfm, b->list_dev[1], nam, b->list_dev[2], nlin, (int)nblocks,
                          b->cfg.compute_n0);
-    else
-      kq::launch_demods(b->stream2, g, chd, pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), b->list_dev[1],
-                        (int)b->list_host[1].size(), b->list_dev[2], (int)b->list_host[2].size(), (int)nblocks,
+    } else if (kq::demod_agc_wave_supported(g)) {  // wave-per-channel AM / linear, generic FM
+      kq::launch_demod64(b->stream2, g, chd, pl, b->list_dev[0], 0, b->list_dev[1], nam, b->list_dev[2], nlin, (int)nblocks,
+                         b->cfg.compute_n0);
+      kq::launch_demods(b->stream2, g, chd, pl, b->tw, b->list_dev[0], nfm, b->list_dev[1], 0, b->list_dev[2], 0, (int)nblocks,
                         b->cfg.compute_n0);
+    } else {
+      kq::launch_demods(b->stream2, g, chd, pl, b->tw, b->list_dev[0], nfm, b->list_dev[1], nam, b->list_dev[2], nlin,
+                        (int)nblocks, b->cfg.compute_n0);
+    }
   }
   HIP_TRY(hipEventRecord(b->ev_demod_done[pp], b->stream2));
   b->pl = pl;  // what the pull functions read

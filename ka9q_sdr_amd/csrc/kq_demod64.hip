@@ -205,10 +205,11 @@ __device__ void fm_channel(const Geom &g, const ChanDev &ch, const Planes &pl, i
 // lane-parallel and coalesced; only the AGC recurrence itself (am.c:64-74, linear.c:269-279: one multiply, one
 // compare, two selects per sample) runs serially, wave-uniform, reading its per-sample inputs with v_readlane.
 // The arithmetic per sample is exactly the reference's, in the reference's order.
-template <bool LINEAR>
+template <bool LINEAR, int OLEN>
 __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
   int const lane = threadIdx.x & 63;
-  int const half = lane >> 5, n = lane & 31;
+  constexpr int BPI = 64 / OLEN;  // blocks per iteration
+  int const half = lane / OLEN, n = lane % OLEN;
   float const headroom = ch.headroom[c], recovery = ch.recovery[c];
   int const hangmax = ch.hangmax[c];
   bool const stereo = LINEAR && (ch.flags[c] & FLAG_STEREO) != 0;
@@ -216,22 +217,22 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
   float gain = ch.gain[c], dc = LINEAR ? 0.f : ch.dc[c];
   int hang = ch.hang[c];
   float n0 = ch.n0[c];
-  const float2 *in = pl.filt + (size_t)c * g.max_blocks * 32;
+  const float2 *in = pl.filt + (size_t)c * g.max_blocks * OLEN;
   float2 s_next = (half < nblocks) ? in[lane] : make_float2(0.f, 0.f);
-  for (int b0 = 0; b0 < nblocks; b0 += 2) {
+  for (int b0 = 0; b0 < nblocks; b0 += BPI) {
     int const blk = b0 + half;
     bool const active = blk < nblocks;
-    int const nsamp = (b0 + 1 < nblocks) ? 64 : 32;  // wave-uniform
+    int const nsamp = (b0 + BPI <= nblocks) ? 64 : OLEN;  // wave-uniform
     float2 const S = s_next;
-    if (b0 + 2 < nblocks) s_next = (blk + 2 < nblocks) ? in[(size_t)(b0 + 2) * 32 + lane] : make_float2(0.f, 0.f);
+    if (b0 + BPI < nblocks) s_next = (blk + BPI < nblocks) ? in[(size_t)(b0 + BPI) * OLEN + lane] : make_float2(0.f, 0.f);
     float const rp = S.x * S.x, ip = S.y * S.y;
     float level = sqrtf(LINEAR ? rp + ip : S.x * S.x + S.y * S.y);  // amplitude (linear.c:260) / envelope (am.c:58)
     float const env = level;
-    // per-block power sums over each 32-lane half
+    // per-block power sums over each OLEN-lane group
     float sig = LINEAR ? rp : rp + ip, noi = LINEAR ? ip : 0.f;
     if (!LINEAR) sig = S.x * S.x + S.y * S.y;
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
+    for (int o = OLEN / 2; o > 0; o >>= 1) {
       sig += __shfl_xor(sig, o, 64);
       noi += __shfl_xor(noi, o, 64);
     }
@@ -259,19 +260,19 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
       hang = (attack && !nan_gain) ? hangmax : (attack ? hang : hdec);
       gain = attack ? iv : rec;
       g_mine = (lane == i) ? gain : g_mine;
-      if (i == 31) {
+      if (i == OLEN - 1) {
         gain_end[0] = gain;
         hang_end[0] = hang;
       }
     }
     gain_end[1] = gain;
     hang_end[1] = hang;
-    float *aud = pl.audio + ((size_t)c * g.max_blocks + blk) * 64;
+    float *aud = pl.audio + ((size_t)c * g.max_blocks + blk) * (2 * OLEN);
     if (active) {
       if (LINEAR) {
         float2 sv = make_float2(S.x * g_mine, S.y * g_mine);
         if (sh_f != 0.0) {  // linear.c:283-289
-          double turns = sh_ph + sh_f * ((double)blk * 32 + n);
+          double turns = sh_ph + sh_f * ((double)blk * OLEN + n);
           turns -= rint(turns);
           float sn, cs;
           sincospif(2.f * (float)turns, &sn, &cs);
@@ -287,21 +288,21 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
     }
     // status: lane 0 of each half, in block order so the smoothed n0 follows the sequence
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
+    for (int h = 0; h < BPI; h++) {
       if (b0 + h < nblocks) {
-        float const sg = __shfl(sig, h * 32, 64), nz = __shfl(noi, h * 32, 64);
+        float const sg = __shfl(sig, h * OLEN, 64), nz = __shfl(noi, h * OLEN, 64);
         if (lane == 0) {
           kq_chan_status st;
           put_status(st, g, ch, pl, c, b0 + h, compute_n0, .001f, n0);
-          st.bb_power = (sg + nz) / 64.f;
+          st.bb_power = (sg + nz) / (2.f * OLEN);
           st.snr = LINEAR ? NAN : 0.f;
           st.foffset = 0;
           st.pdeviation = 0;
-          st.agc_gain = gain_end[h];
+          st.agc_gain = gain_end[BPI == 1 ? 1 : h];
           st.squelch_count = 0;
-          st.hangcount = hang_end[h];
+          st.hangcount = hang_end[BPI == 1 ? 1 : h];
           st.blanked = 0;
-          st.nout = stereo ? 64 : 32;
+          st.nout = stereo ? 2 * OLEN : OLEN;
           pl.status[(size_t)c * g.max_blocks + b0 + h] = st;
         }
       }
@@ -318,31 +319,43 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
 }  // namespace
 
 // grid = n_fm + n_am + n_lin workgroups of one wave (one channel each)
+template <int OLEN>
 __global__ void __launch_bounds__(64) k_demod64(Geom g, ChanDev ch, Planes pl, const int *__restrict__ list_fm, int n_fm,
                                                 const int *__restrict__ list_am, int n_am,
                                                 const int *__restrict__ list_lin, int n_lin, int nblocks, int compute_n0) {
   int wg = blockIdx.x;
-  if (wg < n_fm) {
-    fm_channel(g, ch, pl, list_fm[wg], nblocks, compute_n0);
-    return;
+  if (OLEN == 32) {
+    if (wg < n_fm) {
+      fm_channel(g, ch, pl, list_fm[wg], nblocks, compute_n0);
+      return;
+    }
+    wg -= n_fm;
   }
-  wg -= n_fm;
   if (wg < n_am) {
-    agc_channel<false>(g, ch, pl, list_am[wg], nblocks, compute_n0);
+    agc_channel<false, OLEN>(g, ch, pl, list_am[wg], nblocks, compute_n0);
     return;
   }
   wg -= n_am;
-  if (wg < n_lin) agc_channel<true>(g, ch, pl, list_lin[wg], nblocks, compute_n0);
+  if (wg < n_lin) agc_channel<true, OLEN>(g, ch, pl, list_lin[wg], nblocks, compute_n0);
 }
 
+// Register-resident demodulators exist for olen = 32 (all three types) and olen = 64 (AM / linear)
 bool demod64_supported(const Geom &g) { return g.Ndec == 64 && g.olen == 32 && g.Mdec == 33; }
+bool demod_agc_wave_supported(const Geom &g) { return g.olen == 64 || g.olen == 32; }
 
 void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const int *list_fm, int n_fm,
                     const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0) {
-  int const wgs = n_fm + n_am + n_lin;
-  if (wgs == 0) return;
-  hipLaunchKernelGGL(k_demod64, dim3(wgs), dim3(64), 0, s, g, ch, pl, list_fm, n_fm, list_am, n_am, list_lin, n_lin, nblocks,
-                     compute_n0);
+  if (g.olen == 32) {
+    int const wgs = n_fm + n_am + n_lin;
+    if (wgs == 0) return;
+    hipLaunchKernelGGL(k_demod64<32>, dim3(wgs), dim3(64), 0, s, g, ch, pl, list_fm, n_fm, list_am, n_am, list_lin, n_lin,
+                       nblocks, compute_n0);
+  } else {  // olen = 64: AM / linear only; FM stays on the generic kernel (launch_demods)
+    int const wgs = n_am + n_lin;
+    if (wgs == 0) return;
+    hipLaunchKernelGGL(k_demod64<64>, dim3(wgs), dim3(64), 0, s, g, ch, pl, list_fm, 0, list_am, n_am, list_lin, n_lin,
+                       nblocks, compute_n0);
+  }
 }
 
 }  // namespace kq

@@ -82,6 +82,7 @@ void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes
                    const int *list_fm, int n_fm, const int *list_am, int n_am, const int *list_lin, int n_lin,
                    int nblocks, int compute_n0);
 bool demod64_supported(const Geom &g);
+bool demod_agc_wave_supported(const Geom &g);
 void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const int *list_fm, int n_fm,
                     const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0);
 // single transforms for the compat surface

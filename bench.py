@@ -60,6 +60,24 @@ def cpu_baseline(name, geom, plan, iq_host, target_s):
                       "%d threads, %.1f s" % (nchan, nblocks, name, cores, t)}
 
 
+def pmc_traffic(config, channels, blocks, fwd):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 read correction: tools/pmc_summary.py).  PMC collection
+    cannot run inside this process, so the figure comes from the newest profiles/*/pmc_*.json recorded for the
+    same workload; null when none matches."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_*.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        w = d.get("workload", {})
+        if w.get("config") == config and w.get("channels") == channels and w.get("blocks") == blocks and w.get("fwd") == fwd:
+            best = (d.get("traffic"), os.path.relpath(path, ROOT))
+    return best if best else (None, None)
+
+
 def main():
     a = parse()
     import torch
@@ -151,6 +169,7 @@ def main():
             per_kind[p["demod"]] = per_kind.get(p["demod"], 0) + 1
         abytes = sum(wl.algorithmic_bytes(geom, p["demod"], p.get("channels", 1) == 2) for p in plan) * B
         k_ms = tm["filter_ms"] / max(1, tm["filter_launches"])
+        traffic, traffic_src = pmc_traffic(a.config, C, B, {1: "full", 2: "pruned"}[bank.fwd_mode])
         achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "input Msamples/s + channels @ real-time, 16384-pt overlap-save",
@@ -173,7 +192,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": None,
+                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "pre-detection filter (mix + forward FFT + response + IFFT)",
                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": abytes,
                 "demod_ms": round(tm["demod_ms"] / max(1, tm["filter_launches"]), 4),

@@ -31,6 +31,8 @@ class FrontEndFanout:
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.bufs = buffers
+        # collectives move the real view of complex buffers (same storage): every backend handles float32
+        self.wire = [torch.view_as_real(b) if b.is_complex() else b for b in buffers]
         self.src = src
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -47,11 +49,11 @@ class FrontEndFanout:
         if self.world == 1:
             return
         if self.side is None:
-            self.dist.broadcast(self.bufs[i], src=self.src, group=self.group)
+            self.dist.broadcast(self.wire[i], src=self.src, group=self.group)
             return
         with self.torch.cuda.stream(self.side):
             self.side.wait_event(self.freed[i])
-            self.dist.broadcast(self.bufs[i], src=self.src, group=self.group)
+            self.dist.broadcast(self.wire[i], src=self.src, group=self.group)
             self.ready[i].record(self.side)
 
     def acquire(self, i, compute_stream=None):

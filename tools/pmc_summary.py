@@ -2,6 +2,7 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into HBM-side bytes per launch.
 
   tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [kernel substring]
+                       [config channels blocks fwd]      (workload tag that bench.py matches)
 
 Units and corrections as MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are in KiB-granular units of
 1024 B; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so the
@@ -24,8 +25,11 @@ def per_kernel(path):
 def main():
     fetch, write, out = sys.argv[1:4]
     sel = sys.argv[4] if len(sys.argv) > 4 else "k_filter"
+    tag = sys.argv[5:9]
     f, w = per_kernel(fetch), per_kernel(write)
     res = {"unit": "bytes per launch", "read_correction": 2.0, "kernels": {}}
+    if len(tag) == 4:
+        res["workload"] = {"config": tag[0], "channels": int(tag[1]), "blocks": int(tag[2]), "fwd": tag[3]}
     for k in f:
         if "kq::" not in k:
             continue

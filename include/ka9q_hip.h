@@ -90,6 +90,7 @@ typedef struct kq_chan_status {
   float pdeviation;        /* fm.c:153 */
   float agc_gain;          /* am.c / linear.c agc.gain after the block */
   float noise_gain;        /* filter.out->noise_gain (filter.c:472-497) */
+  float plfreq;            /* fm.c:189-285 CTCSS (PL) tone estimate, Hz; NaN: none, not FM, or N/D < 128 */
   int32_t squelch_count;   /* fm.c:70 snr_below_threshold after the block */
   int32_t hangcount;       /* am.c:26 / linear.c:33 hangcount after the block */
   int32_t blanked;         /* FM samples held at lastaudio this block (fm.c:141) */

@@ -46,7 +46,7 @@ class ChanStatus(C.Structure):
     _fields_ = [
         ("if_power", C.c_float), ("bb_power", C.c_float), ("n0", C.c_float), ("snr", C.c_float),
         ("foffset", C.c_float), ("pdeviation", C.c_float), ("agc_gain", C.c_float),
-        ("noise_gain", C.c_float),
+        ("noise_gain", C.c_float), ("plfreq", C.c_float),
         ("squelch_count", C.c_int32), ("hangcount", C.c_int32), ("blanked", C.c_int32), ("nout", C.c_int32),
     ]
 
@@ -61,7 +61,7 @@ class Timing(C.Structure):
 
 STATUS_DTYPE = np.dtype([
     ("if_power", "f4"), ("bb_power", "f4"), ("n0", "f4"), ("snr", "f4"), ("foffset", "f4"),
-    ("pdeviation", "f4"), ("agc_gain", "f4"), ("noise_gain", "f4"),
+    ("pdeviation", "f4"), ("agc_gain", "f4"), ("noise_gain", "f4"), ("plfreq", "f4"),
     ("squelch_count", "i4"), ("hangcount", "i4"), ("blanked", "i4"), ("nout", "i4")])
 
 

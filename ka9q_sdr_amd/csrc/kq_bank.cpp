@@ -417,6 +417,8 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
                         (int)nblocks, b->cfg.compute_n0);
     }
   }
+  if (g.pl_n > 0 && !b->list_host[0].empty())
+    kq::launch_pl_track(b->stream2, g, chd, pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), (int)nblocks);
   HIP_TRY(hipEventRecord(b->ev_demod_done[pp], b->stream2));
   b->pl = pl;  // what the pull functions read
   b->calls++;
@@ -497,7 +499,14 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   g.log2N = ilog2(N);
   g.log2Ndec = ilog2(Ndec);
   g.samprate = cfg->samprate;
-  g.tw_log2 = g.log2N;
+  g.tw_log2 = g.log2N < 14 ? 14 : g.log2N;  // the PL tracker transforms 16384 points whatever N is
+  {
+    // pltask geometry (fm.c:201-205): decimate 32 from the audio master; needs a usable transform size
+    int const pn = g.Ndec / 32, plen = g.olen / 32;
+    bool const ok = pn >= 4 && plen >= 1 && (pn & (pn - 1)) == 0;
+    g.pl_n = ok ? pn : 0;
+    g.pl_l = ok ? plen : 0;
+  }
   g.max_blocks = (int)cfg->max_blocks;
   g.dsamprate = (float)cfg->samprate / cfg->decimate;
 
@@ -581,6 +590,15 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.hang, C);
   rc |= dev_alloc(&b->chd.dc, C);
   rc |= dev_alloc(&b->chd.n0, C);
+  b->chd.plresp = nullptr;
+  b->chd.plring = nullptr;
+  rc |= dev_alloc(&b->chd.pl_ptr, C);
+  rc |= dev_alloc(&b->chd.pl_last, C);
+  rc |= dev_alloc(&b->chd.plfreq, C);
+  if (g.pl_n > 0) {
+    rc |= dev_alloc(&b->chd.plresp, (size_t)g.pl_n / 2 + 1);
+    rc |= dev_alloc(&b->chd.plring, C * 16384);
+  }
   rc |= dev_alloc(&b->pl.audio, C * B * 2 * (size_t)g.olen);
   rc |= dev_alloc(&b->pl.status, C * B);
   for (int k = 0; k < 2; k++) {  // filter -> demod hand-over planes, one set per call parity
@@ -589,6 +607,8 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     rc |= dev_alloc(&b->pl2[k].filt, C * B * g.olen);
     rc |= dev_alloc(&b->pl2[k].n0raw, C * B);
     rc |= dev_alloc(&b->pl2[k].if_power, B);
+    b->pl2[k].plout = nullptr;
+    if (g.pl_n > 0) rc |= dev_alloc(&b->pl2[k].plout, C * B * g.pl_l);
   }
   b->pl = b->pl2[0];
   rc |= dev_alloc(&b->energy_state, 2);
@@ -598,6 +618,21 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   if (rc) {
     kq_bank_destroy(b);
     return nullptr;
+  }
+  if (g.pl_n > 0) {
+    // PL low-pass: bins with 0 < f < 300 Hz, Kaiser beta 2.0 (fm.c:207-218)
+    int const PL_M = g.pl_n - g.pl_l + 1;
+    std::vector<kq::cfloat> r(g.pl_n / 2 + 1, kq::cfloat(0, 0));
+    for (int j = 0; j <= g.pl_n / 2; j++) {
+      float const f = (float)j * g.dsamprate / g.Ndec;
+      if (f > 0 && f < 300) r[j] = 1;
+    }
+    kq::window_rfilter(g.pl_l, PL_M, r, 2.0);
+    (void)hipMemcpy(b->chd.plresp, r.data(), r.size() * sizeof(float2), hipMemcpyHostToDevice);
+  }
+  {
+    std::vector<float> nanv(C, NAN);
+    (void)hipMemcpy(b->chd.plfreq, nanv.data(), C * sizeof(float), hipMemcpyHostToDevice);
   }
   // twiddles exp(-2*pi*i*k/T) in double, rounded once
   {
@@ -624,7 +659,8 @@ int kq_bank_destroy(kq_bank *b) {
                   b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain,
                   b->osc_dev2[0], b->osc_dev2[1], b->chd.fm_state,
                   b->chd.lastaudio, b->chd.sq_count, b->chd.ahist, b->chd.foffset, b->chd.pdev, b->chd.gain, b->chd.hang,
-                  b->chd.dc, b->chd.n0, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
+                  b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
+                  b->pl2[0].plout, b->pl2[1].plout, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
                   b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state,
                   b->update_dev, b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev};
   for (void *p : ptrs)

@@ -26,6 +26,7 @@ struct Geom {
   int tw_log2;      // twiddle table period = 1 << tw_log2 (>= N)
   int max_blocks;
   float dsamprate;  // fm.c:27
+  int pl_n, pl_l;   // PL slave geometry N_dec/32, olen/32 (0: PL measurement off)
 };
 
 struct ChanDev {
@@ -55,6 +56,11 @@ struct ChanDev {
   int *hang;
   float *dc;            // AM DC_filter
   float *n0;            // smoothed noise density
+  // PL (CTCSS) tone measurement, fm.c:189-285 (only when N/D >= 128)
+  float2 *plresp;       // [PL_N/2+1] shared: geometry only
+  float *plring;        // [C][16384]
+  int *pl_ptr, *pl_last;
+  float *plfreq;
 };
 
 struct Planes {
@@ -63,6 +69,7 @@ struct Planes {
   kq_chan_status *status;
   float *n0raw;         // [C][max_blocks] unsmoothed compute_n0 results
   float *if_power;      // [max_blocks]
+  float *plout;         // [C][max_blocks][PL_L] PL filter outputs of the call (null when PL is off)
 };
 
 // launchers (kq_kernels.hip)
@@ -85,6 +92,8 @@ bool demod64_supported(const Geom &g);
 bool demod_agc_wave_supported(const Geom &g);
 void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const int *list_fm, int n_fm,
                     const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0);
+void launch_pl_track(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_fm,
+                     int n_fm, int nblocks);
 // single transforms for the compat surface
 void launch_fft_single(hipStream_t s, const float2 *in, float2 *out, int log2n, int sign, const float2 *tw, int tw_log2);
 void launch_slave_single(hipStream_t s, const float2 *fdomain, const float2 *resp, float2 *out, int N, int Ndec,

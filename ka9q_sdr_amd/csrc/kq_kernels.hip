@@ -366,6 +366,7 @@ __device__ __forceinline__ void status_common(kq_chan_status &st, const Geom &g,
                                               int b, int compute_n0, float n0_rate) {
   st.if_power = pl.if_power[b];
   st.noise_gain = ch.noise_gain[c];
+  st.plfreq = NAN;
   if (compute_n0) {
     float const fresh = pl.n0raw[(size_t)c * g.max_blocks + b];
     float n0 = ch.n0[c];
@@ -395,6 +396,10 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
   float *AIN = OUT + olen;
   int *LV = reinterpret_cast<int *>(AIN + AN);
   int *PV = LV + olen;
+  float2 *PLB = reinterpret_cast<float2 *>(PV + olen);  // PL slave transform buffer, pl_n points
+  bool const pl_on = g.pl_n > 0 && pl.plout != nullptr;
+  int log2pl = 0;
+  while ((1 << log2pl) < g.pl_n) log2pl++;
 
   bool const flat = (ch.flags[c] & FLAG_FLAT) != 0;
   float const gain = ch.fm_gain[c];
@@ -509,9 +514,28 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
     for (int n = lane; n < AL; n += 64) AIN[AM - 1 + n] = OUT[n];
     __syncthreads();
     float *aud = pl.audio + ((size_t)c * g.max_blocks + b) * (2 * (size_t)olen);
-    if (!flat) {
+    if (!flat || pl_on) {  // forward transform of the audio master (fm.c:162, filter.c:151)
       for (int i = lane; i < AN; i += 64) F[bitrev((unsigned)i, g.log2Ndec)] = make_float2(AIN[i], 0.f);
       lds_fft<-1>(F, g.log2Ndec, tw, g.tw_log2);
+    }
+    if (pl_on) {
+      // PL slave: REAL -> REAL, decimate 32 (fm.c:219,234; filter.c:206-208 then c2r of pl_n points)
+      int const PN = g.pl_n;
+      for (int k = lane; k <= PN / 2; k += 64) {
+        float2 gk = cmul(ch.plresp[k], F[k]);
+        if (k == 0 || k == PN / 2) {
+          gk.y = 0.f;
+        } else {
+          PLB[bitrev((unsigned)(PN - k), log2pl)] = cconj(gk);
+        }
+        PLB[bitrev((unsigned)k, log2pl)] = gk;
+      }
+      lds_fft<+1>(PLB, log2pl, tw, g.tw_log2);
+      float *po = pl.plout + ((size_t)c * g.max_blocks + b) * g.pl_l;
+      for (int n = lane; n < g.pl_l; n += 64) po[n] = PLB[PN - g.pl_l + n].x;  // filter.c:140
+      __syncthreads();
+    }
+    if (!flat) {
       // multiply DC..Nyquist (filter.c:206-208) and Hermitian-extend for the c2r transform, which
       // ignores the imaginary parts of DC and Nyquist.  Lane k touches only F[k] and F[AN-k].
       for (int k = lane; k <= AN / 2; k += 64) {
@@ -686,10 +710,101 @@ __global__ void k_demod_linear(Geom g, ChanDev ch, Planes pl, const int *__restr
   ch.hang[c] = hang;
 }
 
+// PL tone tracker (fm.c:236-277): per FM channel, blocks in sequence: append the PL filter output to the
+// 16384-sample ring; after every >= 512 new samples transform the ring (in storage order, as the reference
+// does) and pick the peak bin.  One workgroup per channel; the ring transform runs in LDS (128 KiB).
+__global__ void __launch_bounds__(1024) k_pl_track(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ tw,
+                                                   const int *__restrict__ list, int nblocks) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  __shared__ float red_e[16];
+  __shared__ float red_p[16];
+  __shared__ int red_i[16];
+  constexpr int FS = 16384;  // (1 << 19) / 32, fm.c:225
+  int const c = list[blockIdx.x];
+  float *ring = ch.plring + (size_t)c * FS;
+  int ptr = ch.pl_ptr[c], last = ch.pl_last[c];
+  float plfreq = ch.plfreq[c];
+  float const pl_samprate = g.dsamprate / 32.f;
+  for (int b = 0; b < nblocks; b++) {
+    const float *src = pl.plout + ((size_t)c * g.max_blocks + b) * g.pl_l;
+    for (int i = threadIdx.x; i < g.pl_l; i += blockDim.x) ring[(ptr + i) & (FS - 1)] = src[i];
+    ptr = (ptr + g.pl_l) & (FS - 1);
+    last += g.pl_l;
+    if (last >= 512) {  // fm.c:251
+      last = 0;
+      __syncthreads();
+      for (int i = threadIdx.x; i < FS; i += blockDim.x) lds[bitrev((unsigned)i, 14)] = make_float2(ring[i], 0.f);
+      lds_fft<-1>(lds, 14, tw, g.tw_log2);
+      float tot = 0, pe = 0;
+      int pb = -1;
+      for (int n = 1 + threadIdx.x; n < FS / 2; n += blockDim.x) {  // skip DC (fm.c:260)
+        float const e = cnrm(lds[n]);
+        tot += e;
+        if (e > pe) {
+          pe = e;
+          pb = n;
+        }
+      }
+      // block reduction: total energy, and the first bin holding the maximum energy
+      tot = wave_sum(tot);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        float const oe = __shfl_xor(pe, o, 64);
+        int const ob = __shfl_xor(pb, o, 64);
+        if (oe > pe || (oe == pe && ob >= 0 && (pb < 0 || ob < pb))) {
+          pe = oe;
+          pb = ob;
+        }
+      }
+      int const w = threadIdx.x >> 6;
+      if ((threadIdx.x & 63) == 0) {
+        red_e[w] = tot;
+        red_p[w] = pe;
+        red_i[w] = pb;
+      }
+      __syncthreads();
+      tot = 0;
+      pe = 0;
+      pb = -1;
+      for (int k = 0; k < (int)(blockDim.x >> 6); k++) {
+        tot += red_e[k];
+        if (red_p[k] > pe || (red_p[k] == pe && red_i[k] >= 0 && (pb < 0 || red_i[k] < pb))) {
+          pe = red_p[k];
+          pb = red_i[k];
+        }
+      }
+      if (pb > 0 && pe > 0.01f * tot) {  // fm.c:271-276
+        float const f = (float)pb * pl_samprate / FS;
+        if (f > 67 && f < 255) plfreq = f;
+      } else {
+        plfreq = NAN;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) pl.status[(size_t)c * g.max_blocks + b].plfreq = plfreq;
+  }
+  if (threadIdx.x == 0) {
+    ch.pl_ptr[c] = ptr;
+    ch.pl_last[c] = last;
+    ch.plfreq[c] = plfreq;
+  }
+}
+
+void launch_pl_track(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_fm,
+                     int n_fm, int nblocks) {
+  if (n_fm <= 0 || g.pl_n <= 0) return;
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void *)k_pl_track, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
+    configured = true;
+  }
+  hipLaunchKernelGGL(k_pl_track, dim3(n_fm), dim3(1024), 16384 * 8, s, g, ch, pl, tw, list_fm, nblocks);
+}
+
 void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_fm,
                    int n_fm, const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0) {
   if (n_fm > 0) {
-    size_t const lds_bytes = (size_t)g.olen * (8 + 4 + 4 + 4 + 4) + (size_t)g.Ndec * (8 + 4);
+    size_t const lds_bytes = (size_t)g.olen * (8 + 4 + 4 + 4 + 4) + (size_t)g.Ndec * (8 + 4) + (size_t)g.pl_n * 8;
     static size_t configured = 0;
     if (lds_bytes > configured) {
       (void)hipFuncSetAttribute((const void *)k_demod_fm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -5,7 +5,7 @@
  * arithmetic in program order for one block of L input samples:
  *   ingest + mix          radio.c:106-147   (zero fill: radio.c:81-100)
  *   noise estimate        radio.c:383-425
- *   FM                    fm.c:21-174       (PL-tone side thread fm.c:189-285 not restated)
+ *   FM                    fm.c:21-174, PL-tone measurement fm.c:189-285 (run in lockstep after each block)
  *   AM                    am.c:15-83
  *   linear (SSB/IQ/ISB)   linear.c:21-322   (carrier PLL linear.c:129-246 not restated)
  *   oscillator setters    radio.c:180-184, 290-311
@@ -43,6 +43,13 @@ struct kqo_chan {
   kqo_filter_in *audio_master;
   kqo_filter_out *audio_filter;
   int blanked;
+  /* PL tone measurement (fm.c:189-285) */
+  kqo_filter_out *pl_filter;
+  float *pl_input;
+  float complex *pl_spectrum;
+  kqo_fft *pl_plan;
+  int pl_fft_ptr, pl_last_fft;
+  float pl_samprate, plfreq;
   /* AM / linear (am.c:26-34, linear.c:33-39) */
   int hangcount, hangmax;
   float recovery_factor;
@@ -149,6 +156,28 @@ kqo_chan *kqo_chan_create(const kqo_chan_cfg *cfg){
       kqo_window_rfilter(AL, AM, ar, cfg->kaiser_beta);
       c->audio_filter = kqo_create_filter_output(c->audio_master, ar, 1, KQO_REAL);
     }
+    {
+      /* pltask set-up, fm.c:196-229.  PL_N = AN/32 must leave a usable transform (the reference runs it
+       * regardless; below 4 points it is meaningless and the oracle leaves plfreq NaN). */
+      int const PL_decimate = 32;
+      int const PL_N = AN / PL_decimate, PL_L = AL / PL_decimate, PL_M = PL_N - PL_L + 1;
+      c->plfreq = NAN;
+      if(PL_N >= 4 && PL_L >= 1 && (PL_N & (PL_N - 1)) == 0){
+        c->pl_samprate = c->dsamprate / PL_decimate;
+        float complex *plr = calloc(PL_N / 2 + 1, sizeof(float complex));
+        for(int j = 0; j <= PL_N / 2; j++){
+          float const f = (float)j * c->dsamprate / AN;                    /* fm.c:214 */
+          if(f > 0 && f < 300)
+            plr[j] = 1;
+        }
+        kqo_window_rfilter(PL_L, PL_M, plr, 2.0);                          /* fm.c:218 */
+        c->pl_filter = kqo_create_filter_output(c->audio_master, plr, PL_decimate, KQO_REAL);
+        int const pl_fft_size = (1 << 19) / PL_decimate;                   /* fm.c:225 */
+        c->pl_input = calloc(pl_fft_size, sizeof(float));
+        c->pl_spectrum = calloc(pl_fft_size / 2 + 1, sizeof(float complex));
+        c->pl_plan = kqo_fft_create(pl_fft_size);
+      }
+    }
     c->fm_state = 1;                                                       /* fm.c:26 */
     c->pdeviation = 0;
     c->foffset = 0;
@@ -173,6 +202,10 @@ kqo_chan *kqo_chan_create(const kqo_chan_cfg *cfg){
 void kqo_chan_destroy(kqo_chan *c){
   if(!c)
     return;
+  kqo_delete_filter_output(c->pl_filter);
+  free(c->pl_input);
+  free(c->pl_spectrum);
+  kqo_fft_destroy(c->pl_plan);
   kqo_delete_filter_output(c->audio_filter);
   kqo_delete_filter_input(c->audio_master);
   kqo_delete_filter_output(c->slave);
@@ -275,6 +308,45 @@ static int fm_block(kqo_chan *c, float *audio){
     memset(am->input_r, 0, sizeof(float) * am->ilen);
   }
   kqo_execute_filter_input(am);                                            /* fm.c:162 */
+  if(c->pl_filter){
+    /* one iteration of pltask's loop, fm.c:233-277 */
+    int const pl_fft_size = (1 << 19) / 32;
+    kqo_execute_filter_output(c->pl_filter);
+    int remain = (int)c->pl_filter->olen;
+    c->pl_last_fft += remain;
+    float const *data = c->pl_filter->output_r;
+    while(remain != 0){
+      int chunk = pl_fft_size - c->pl_fft_ptr;
+      if(chunk > remain)
+        chunk = remain;
+      memcpy(c->pl_input + c->pl_fft_ptr, data, sizeof(float) * chunk);
+      c->pl_fft_ptr += chunk;
+      data += chunk;
+      remain -= chunk;
+      if(c->pl_fft_ptr >= pl_fft_size)
+        c->pl_fft_ptr -= pl_fft_size;
+    }
+    if(c->pl_last_fft >= 512){                                             /* fm.c:251 */
+      c->pl_last_fft = 0;
+      kqo_fft_r2c(c->pl_plan, c->pl_input, c->pl_spectrum);
+      int peakbin = -1;
+      float peakenergy = 0, totenergy = 0;
+      for(int n = 1; n < pl_fft_size / 2; n++){                            /* fm.c:260-267 */
+        float const energy = norm2f(c->pl_spectrum[n]);
+        totenergy += energy;
+        if(energy > peakenergy){
+          peakenergy = energy;
+          peakbin = n;
+        }
+      }
+      if(peakbin > 0 && peakenergy > 0.01 * totenergy){                    /* fm.c:271-276 */
+        float const f = (float)peakbin * c->pl_samprate / pl_fft_size;
+        if(f > 67 && f < 255)
+          c->plfreq = f;
+      } else
+        c->plfreq = NAN;
+    }
+  }
   if(c->audio_filter){
     kqo_execute_filter_output(c->audio_filter);
     for(int n = 0; n < (int)c->audio_filter->olen; n++)                    /* fm.c:169-170 */
@@ -379,6 +451,7 @@ static int demod_block(kqo_chan *c, float *audio, kqo_status *st, float *filt, f
     st->squelch_count = c->snr_below_threshold;
     st->hangcount = c->hangcount;
     st->blanked = c->blanked;
+    st->plfreq = (c->cfg.demod_type == KQO_FM) ? c->plfreq : NAN;
     st->nout = nout;
     st->samples = c->samples;
   }

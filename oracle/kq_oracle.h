@@ -125,6 +125,7 @@ typedef struct {
 
 typedef struct {
   float if_power, bb_power, n0, snr, foffset, pdeviation, agc_gain;
+  float plfreq;        /* fm.c:189-285 CTCSS tone estimate; NaN when none / not FM / geometry too small */
   int squelch_count;   /* fm.c snr_below_threshold */
   int hangcount;       /* am.c / linear.c hangcount */
   int blanked;         /* FM samples replaced by lastaudio this block */

@@ -32,7 +32,7 @@ class ChanCfg(C.Structure):
 class Status(C.Structure):
     _fields_ = [
         ("if_power", C.c_float), ("bb_power", C.c_float), ("n0", C.c_float), ("snr", C.c_float),
-        ("foffset", C.c_float), ("pdeviation", C.c_float), ("agc_gain", C.c_float),
+        ("foffset", C.c_float), ("pdeviation", C.c_float), ("agc_gain", C.c_float), ("plfreq", C.c_float),
         ("squelch_count", C.c_int), ("hangcount", C.c_int), ("blanked", C.c_int), ("nout", C.c_int),
         ("samples", C.c_longlong),
     ]

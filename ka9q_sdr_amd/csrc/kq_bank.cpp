@@ -90,6 +90,10 @@ struct Osc {
 struct HostChan {
   kq_channel_config cfg;
   Osc lo2, dop, shift;
+  // oscillators as they were before a retune that has not reached the kernels yet: the M-1 history samples of
+  // the next block were mixed with these (radio.c:132-139)
+  Osc lo2_old, dop_old;
+  bool retuned = false;
   int out_type;
   std::vector<kq::cfloat> resp, aresp;
   float noise_gain;
@@ -130,6 +134,7 @@ struct kq_bank {
   kq::ChanDev chd;
   kq::Planes pl;
   int *list_dev[3] = {nullptr, nullptr, nullptr};  // fm, am, linear
+  int *retune_list = nullptr;
   std::vector<int> list_host[3];
   bool lists_dirty = true;
   float *energy_state = nullptr;
@@ -308,6 +313,7 @@ int upload_call_params(kq_bank *b, double *osc_dst, int64_t n_w, const unsigned 
   HIP_TRY(hipEventSynchronize(b->stage_ev[slot]));  // the copy that last used this slot has completed
   double *pl = reinterpret_cast<double *>(b->stage_host[slot]);
   double *ph = pl, *fr = pl + Cmax, *rt = pl + 2 * Cmax, *sp = pl + 3 * Cmax, *sf = pl + 4 * Cmax;
+  double *hph = pl + 5 * Cmax, *hfr = pl + 6 * Cmax, *hrt = pl + 7 * Cmax;
   for (size_t c = 0; c < C; c++) {
     HostChan const &h = b->chans[c];
     double p = h.lo2.phase_at(n_w), f = h.lo2.step_at(n_w), r = h.lo2.sweep();
@@ -319,13 +325,28 @@ int upload_call_params(kq_bank *b, double *osc_dst, int64_t n_w, const unsigned 
     ph[c] = p - std::floor(p);
     fr[c] = f;
     rt[c] = r;
+    if (h.retuned) {  // history of the first block keeps the pre-retune oscillators
+      double q = h.lo2_old.phase_at(n_w), g2 = h.lo2_old.step_at(n_w), r2 = h.lo2_old.sweep();
+      if (h.dop_old.set_f != 0) {
+        q += h.dop_old.phase_at(n_w);
+        g2 += h.dop_old.step_at(n_w);
+        r2 += h.dop_old.sweep();
+      }
+      hph[c] = q - std::floor(q);
+      hfr[c] = g2;
+      hrt[c] = r2;
+    } else {
+      hph[c] = ph[c];
+      hfr[c] = f;
+      hrt[c] = r;
+    }
     double q = h.shift.phase_at(b->out_abs);
     sp[c] = q - std::floor(q);
     sf[c] = h.shift.step_at(b->out_abs);
   }
-  unsigned char *flags = b->stage_host[slot] + 5 * Cmax * sizeof(double);
+  unsigned char *flags = b->stage_host[slot] + 8 * Cmax * sizeof(double);
   memcpy(flags, update, nblocks);
-  HIP_TRY(hipMemcpyAsync(osc_dst, b->stage_host[slot], 5 * Cmax * sizeof(double), hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(osc_dst, b->stage_host[slot], 8 * Cmax * sizeof(double), hipMemcpyHostToDevice, b->stream));
   HIP_TRY(hipMemcpyAsync(b->update_dev, flags, nblocks, hipMemcpyHostToDevice, b->stream));
   HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
   return 0;
@@ -378,6 +399,9 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   chd.lo_rate = chd.lo_phase + 2 * Cmax;
   chd.sh_phase = chd.lo_phase + 3 * Cmax;
   chd.sh_freq = chd.lo_phase + 4 * Cmax;
+  chd.hist_phase = chd.lo_phase + 5 * Cmax;
+  chd.hist_freq = chd.lo_phase + 6 * Cmax;
+  chd.hist_rate = chd.lo_phase + 7 * Cmax;
   // this parity's hand-over planes were last read by the demodulators two calls ago
   HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[pp], 0));
   if (upload_call_params(b, b->osc_dev2[pp], b->n_abs - (g.M - 1), update_host, nblocks)) return -1;
@@ -393,11 +417,24 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
         b->chan_tw_dirty = false;
       }
       kq::launch_filter_pruned(b->stream, g, chd, pl, window, b->chan_tw, C, (int)nblocks, swept);
+      // The pruned kernels assume one oscillator over the whole window.  For the first block after a retune the
+      // history half still carries the old one: redo just those channel-blocks on the per-sample path.
+      std::vector<int> ret;
+      for (int c = 0; c < C; c++)
+        if (b->chans[c].retuned) ret.push_back(c);
+      if (!ret.empty()) {
+        if (upload(b, b->retune_list, ret.data(), ret.size() * sizeof(int))) return -1;
+        HIP_TRY(hipStreamSynchronize(b->stream));  // `ret` is about to die; retunes are rare
+        if (g.N > 16384)
+          kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, (int)ret.size(), 1, b->retune_list);
+        else
+          kq::launch_filter_full(b->stream, g, chd, pl, window, b->tw, (int)ret.size(), 1, 0, nullptr, -1, b->retune_list);
+      }
     } else if (g.N > 16384) {
-      kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks);
+      kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, nullptr);
     } else {
       kq::launch_filter_full(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, b->cfg.compute_n0, b->spec_dump,
-                             b->spec_ch);
+                             b->spec_ch, nullptr);
     }
     b->acc.filter_launches++;
     b->acc.channel_blocks += (uint64_t)C * nblocks;
@@ -430,6 +467,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   b->n_abs += (int64_t)nblocks * g.L;
   b->out_abs += (int64_t)nblocks * g.olen;
   for (HostChan &h : b->chans) {
+    h.retuned = false;
     h.lo2.rebase(b->n_abs);
     h.dop.rebase(b->n_abs);
     h.shift.rebase(b->out_abs);
@@ -561,8 +599,9 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.recovery, C);
   rc |= dev_alloc(&b->chd.hangmax, C);
   rc |= dev_alloc(&b->chd.noise_gain, C);
-  for (int k = 0; k < 2; k++) rc |= dev_alloc(&b->osc_dev2[k], 5 * C);
+  for (int k = 0; k < 2; k++) rc |= dev_alloc(&b->osc_dev2[k], 8 * C);
   b->chd.lo_phase = b->chd.lo_freq = b->chd.lo_rate = b->chd.sh_phase = b->chd.sh_freq = nullptr;  // set per call
+  b->chd.hist_phase = b->chd.hist_freq = b->chd.hist_rate = nullptr;
   // Overlap is opt-in (KQ_DEMOD_OVERLAP=1): measured on MI355X the single-wave demodulator workgroups squat on
   // CUs between filter workgroups (236-VGPR waves cannot co-reside with them) and the step gets slower, so by
   // default the demodulators simply follow the filter on the main stream.
@@ -576,7 +615,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     set_err("second stream / event creation failed");
     rc = -1;
   }
-  b->stage_bytes = 5 * C * sizeof(double) + B;
+  b->stage_bytes = 8 * C * sizeof(double) + B;
   for (int k = 0; k < kq_bank::kSlots && !rc; k++) {
     if (hipHostMalloc((void **)&b->stage_host[k], b->stage_bytes, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&b->stage_ev[k], hipEventDisableTiming) != hipSuccess) {
@@ -618,6 +657,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->energy_state, 2);
   rc |= dev_alloc(&b->update_dev, B);
   for (int k = 0; k < 3; k++) rc |= dev_alloc(&b->list_dev[k], C);
+  rc |= dev_alloc(&b->retune_list, C);
   if (b->fwd_mode == KQ_FWD_PRUNED) rc |= dev_alloc(&b->chan_tw, C * kq::pruned_table_elems(g));
   if (rc) {
     kq_bank_destroy(b);
@@ -666,7 +706,7 @@ int kq_bank_destroy(kq_bank *b) {
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
                   b->pl2[0].plout, b->pl2[1].plout, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
                   b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state,
-                  b->update_dev, b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask};
+                  b->update_dev, b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->retune_list};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (auto *v : {&b->ev_filter, &b->ev_demod, &b->ev_ingest})
@@ -731,6 +771,11 @@ int kq_bank_set_second_lo(kq_bank *b, int ch, double hz) {
     set_err("bad channel or NaN");
     return -1;
   }
+  if (!b->chans[ch].retuned) {
+    b->chans[ch].lo2_old = b->chans[ch].lo2;
+    b->chans[ch].dop_old = b->chans[ch].dop;
+    b->chans[ch].retuned = true;
+  }
   b->chans[ch].cfg.second_lo = hz;
   b->chans[ch].lo2.set(hz == 0 ? 0.0 : hz / b->g.samprate, 0.0, b->n_abs);
   b->chan_tw_dirty = true;
@@ -743,6 +788,11 @@ int kq_bank_set_doppler(kq_bank *b, int ch, double hz, double hz_per_s) {
     return -1;
   }
   double const fs = b->g.samprate;
+  if (!b->chans[ch].retuned) {
+    b->chans[ch].lo2_old = b->chans[ch].lo2;
+    b->chans[ch].dop_old = b->chans[ch].dop;
+    b->chans[ch].retuned = true;
+  }
   b->chans[ch].cfg.doppler = hz;
   b->chans[ch].cfg.doppler_rate = hz_per_s;
   b->chans[ch].dop.set(-hz / fs, -hz_per_s / (fs * fs), b->n_abs);

@@ -44,6 +44,9 @@ struct ChanDev {
   // oscillator phase (turns), step (cycles/sample) and sweep (cycles/sample^2) at sample 0 of the
   // first window of the call; second LO and Doppler already summed (they multiply, so phases add)
   double *lo_phase, *lo_freq, *lo_rate;
+  // the same for the M-1 history samples of the call's first block: they were mixed before a retune took effect
+  // and keep the old oscillator (radio.c:132-139 mixes sample by sample; osc.c:22-36 only changes what follows)
+  double *hist_phase, *hist_freq, *hist_rate;
   // post-detection shift oscillator at output sample 0 of the call
   double *sh_phase, *sh_freq;
   // carried demodulator state
@@ -77,10 +80,11 @@ void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size
 void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nblocks, const unsigned char *update,
                          float *energy_state, float *if_power);
 void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
-                        const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch);
+                        const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
+                        const int *chan_list);
 bool split_supported(const Geom &g);
 void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
-                         const float2 *tw, int nchan, int nblocks);
+                         const float2 *tw, int nchan, int nblocks, const int *chan_list);
 bool pruned_supported(const Geom &g);
 void launch_filter_pruned(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                           const float2 *chan_tw, int nchan, int nblocks, bool swept);

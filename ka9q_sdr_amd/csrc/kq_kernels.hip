@@ -196,21 +196,25 @@ void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nbl
 // ---------------------------------------------------------------- full-FFT pre-detection filter
 // grid (channel, block); dynamic LDS = N float2.
 __global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,
-                              const float2 *__restrict__ tw, int compute_n0, float2 *__restrict__ spec_dump, int spec_ch) {
+                              const float2 *__restrict__ tw, int compute_n0, float2 *__restrict__ spec_dump, int spec_ch,
+                              const int *__restrict__ chan_list) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   __shared__ float red_f[16];
   __shared__ int red_i[16];
-  int const c = blockIdx.x, b = blockIdx.y;
+  int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
   int const N = g.N, Ndec = g.Ndec;
 
   // --- NCO mix (radio.c:132-139): closed form of the phasor recurrence of osc.c:39-51
   double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c], r = ch.lo_rate[c];
+  double const hp0 = ch.hist_phase[c], hf0 = ch.hist_freq[c], hr = ch.hist_rate[c];
   const float2 *x = window + (size_t)b * g.L;
   double const mbase = (double)b * g.L;
   for (int i = threadIdx.x; i < N; i += blockDim.x) {
     double const m = mbase + i;
-    double turns = ph0 + f0 * m;
-    if (r != 0.0) turns += r * (0.5 * m * (m - 1.0));
+    bool const old = (b == 0) && i < g.M - 1;  // history of the call's first block: pre-retune oscillator
+    double const rr = old ? hr : r;
+    double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
+    if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
     float2 const lo = phasor_turns(turns);
     lds[bitrev((unsigned)i, g.log2N)] = cmul(x[i], lo);
   }
@@ -272,7 +276,8 @@ __global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__res
 }
 
 void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
-                        const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch) {
+                        const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
+                        const int *chan_list) {
   size_t const lds_bytes = (size_t)g.N * sizeof(float2);
   static size_t configured = 0;
   if (lds_bytes > configured) {
@@ -281,7 +286,7 @@ void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const P
   }
   int const threads = g.N >= 4096 ? 1024 : 256;
   hipLaunchKernelGGL(k_filter_full, dim3(nchan, nblocks), dim3(threads), lds_bytes, s, g, ch, pl, window, tw, compute_n0,
-                     spec_dump, spec_ch);
+                     spec_dump, spec_ch, chan_list);
 }
 
 // ---------------------------------------------------------------- full path for N beyond one LDS block
@@ -291,14 +296,15 @@ void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const P
 // compute_n0 needs every bin of the N-point spectrum and is not available on this path.
 // grid (channel, block); dynamic LDS = (N1 + N_dec) float2.
 __global__ void k_filter_split(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,
-                               const float2 *__restrict__ tw, int S, int log2N1) {
+                               const float2 *__restrict__ tw, int S, int log2N1, const int *__restrict__ chan_list) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  int const c = blockIdx.x, b = blockIdx.y;
+  int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
   int const N = g.N, Ndec = g.Ndec, N1 = 1 << log2N1;
   float2 *side = lds + N1;  // X at signed bin k, stored at index k mod N_dec
   for (int i = threadIdx.x; i < Ndec; i += blockDim.x) side[i] = make_float2(0.f, 0.f);
 
   double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c], r = ch.lo_rate[c];
+  double const hp0 = ch.hist_phase[c], hf0 = ch.hist_freq[c], hr = ch.hist_rate[c];
   const float2 *x = window + (size_t)b * g.L;
   double const mbase = (double)b * g.L;
   for (int s = 0; s < S; s++) {
@@ -306,8 +312,10 @@ __global__ void k_filter_split(Geom g, ChanDev ch, Planes pl, const float2 *__re
     for (int i = threadIdx.x; i < N1; i += blockDim.x) {
       int const n = S * i + s;
       double const m = mbase + n;
-      double turns = ph0 + f0 * m;
-      if (r != 0.0) turns += r * (0.5 * m * (m - 1.0));
+      bool const old = (b == 0) && n < g.M - 1;
+      double const rr = old ? hr : r;
+      double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
+      if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
       lds[bitrev((unsigned)i, log2N1)] = cmul(x[n], phasor_turns(turns));
     }
     lds_fft<-1>(lds, log2N1, tw, g.tw_log2);
@@ -349,7 +357,7 @@ bool split_supported(const Geom &g) {
 }
 
 void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
-                         const float2 *tw, int nchan, int nblocks) {
+                         const float2 *tw, int nchan, int nblocks, const int *chan_list) {
   int const log2N1 = 14;
   int const S = g.N >> log2N1;
   size_t const lds_bytes = ((size_t)(1 << log2N1) + g.Ndec) * sizeof(float2);
@@ -358,7 +366,8 @@ void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const 
     (void)hipFuncSetAttribute((const void *)k_filter_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     configured = lds_bytes;
   }
-  hipLaunchKernelGGL(k_filter_split, dim3(nchan, nblocks), dim3(1024), lds_bytes, s, g, ch, pl, window, tw, S, log2N1);
+  hipLaunchKernelGGL(k_filter_split, dim3(nchan, nblocks), dim3(1024), lds_bytes, s, g, ch, pl, window, tw, S, log2N1,
+                     chan_list);
 }
 
 // ---------------------------------------------------------------- demodulators

@@ -310,3 +310,43 @@ def test_pcm_output_stage(gpu):
             silent += bin(gmask).count("1")
     assert clipped > 0 and silent > 0
     bank.close()
+
+
+@pytest.mark.parametrize("name,mode", [("cfg4", "pruned"), ("cfg4", "full"), ("cfg5", "pruned")])
+def test_retune_mid_stream_is_sample_exact(gpu, name, mode):
+    """osc.c:22-36 + radio.c:132-139: a retune changes only the samples mixed after it; the M-1 history samples of
+    the next block keep the old oscillator (phase continuous).  Second LO and Doppler retuned between calls."""
+    import kq_oracle as ko
+    from common import oracle_cfg
+    g = wl.GEOMETRY[name]
+    fs, L = g["samprate"], g["L"]
+    plan = wl.channel_plan(name, 3)
+    for p in plan:
+        p["second_lo"] -= p["doppler"]
+        p["doppler"] = p["doppler_rate"] = 0.0
+    nblocks = 6
+    iq = wl.make_iq(fs, nblocks * L, seed=29)
+    chans = [ko.Channel(oracle_cfg(p, fs, L, g["M"], g["D"])) for p in plan]
+    bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), 2, fwd_mode=kq.KQ_FWD_PRUNED if mode == "pruned" else kq.KQ_FWD_FULL)
+    for p in plan:
+        bank.add_channel(bank_cfg(p))
+    for call in range(3):
+        if call == 1:      # retune channel 0's second LO by a non-bin-aligned amount, start a Doppler sweep on channel 1
+            new_lo = plan[0]["second_lo"] + 777.7
+            bank.set_second_lo(0, new_lo)
+            chans[0].set_lo2(new_lo)
+            bank.set_doppler(1, 1500.0, 80.0)
+            chans[1].set_doppler(1500.0, 80.0)
+        if call == 2:      # and back again
+            bank.set_second_lo(0, plan[0]["second_lo"])
+            chans[0].set_lo2(plan[0]["second_lo"])
+            bank.set_doppler(1, 0.0, 0.0)
+            chans[1].set_doppler(0.0, 0.0)
+        bank.push_iq(iq[2 * call * L:2 * (call + 1) * L])
+        assert bank.process() == 2
+        for c, ch in enumerate(chans):
+            for b in range(2):
+                _, _, filt, _ = ch.block(iq[(2 * call + b) * L:(2 * call + b + 1) * L], want_filt=True)
+                got = bank.filter_output(c, b)
+                assert rel_rms(got, filt) < FILT_TOL, (call, c, b, rel_rms(got, filt))
+    bank.close()

@@ -384,6 +384,10 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
       // The pruned kernels take the sweep's cross term r*R*a*b to first order and drop its b^2 part:
       // both must stay far below the 1e-5 parity budget over one window.
       double const cross = 2 * M_PI * std::fabs(r) * (double)g.N * g.D, quad = std::fabs(r) * (double)g.D * g.D * 0.5;
+      if (g.Ndec == 256) {
+        set_err("swept NCO at N/D = 256 is only available on the full forward path: use KQ_FWD_FULL");
+        return -1;
+      }
       if (cross > 3e-4 || quad > 2e-7) {
         set_err("sweep rate too large for the pruned forward path (cross term %.3g rad): use KQ_FWD_FULL", cross);
         return -1;
@@ -563,7 +567,9 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   } else if (cfg->fwd_mode == KQ_FWD_FULL) {
     b->fwd_mode = KQ_FWD_FULL;
   } else {
-    b->fwd_mode = can_prune ? KQ_FWD_PRUNED : KQ_FWD_FULL;
+    // N/D = 256 (cfg 2): the pruned kernel is correct but not yet faster than the full path (2.24 vs 2.12 ms
+    // per 16384 channel-blocks), so AUTO keeps the full path there; KQ_FWD_PRUNED still selects it explicitly
+    b->fwd_mode = (can_prune && g.Ndec != 256) ? KQ_FWD_PRUNED : KQ_FWD_FULL;
   }
   if (b->fwd_mode == KQ_FWD_FULL && N > 16384 && (!kq::split_supported(g) || cfg->compute_n0)) {
     set_err("N = %u: the full path beyond 16384 points needs N <= 65536, N/D <= 2048 and compute_n0 off", N);

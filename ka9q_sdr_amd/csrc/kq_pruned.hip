@@ -117,17 +117,20 @@ __device__ __forceinline__ void fft32_dit(float2 (&v)[32]) {
 }
 
 // ---- per-channel tables (floats).  ND = 64: A is merged per pass, [2][32] float4 = (A[a] w, A[a+32] w') with the
-// pass twiddle folded in.  ND = 128: A only, [32][4] float2 = A[a' + 32 s] (the pass twiddle W_128^{a' p} is a
-// compile-time constant applied after the fold).  T: [P][32] float2 Horner twiddle of bin q = P q' + p.
+// pass twiddle folded in.  ND = 128: A only, [32][4] float2 = A[a' + 32 s]; the radix-4 factor (-i)^{s p} is a
+// compile-time rotation and the residual twiddle W_128^{a' p} comes from a workgroup-shared LDS table.
+// ND = 256: fully merged, [8 passes][32][8] float2 = A[a' + 32 s] W_8^{s p} W_256^{a' p}.  T: [P][32] float2 Horner twiddle of bin q = P q' + p.
 // Lv: [6][ND] float2 cross-lane level twiddles, natural q.
 template <int ND>
 struct Tab {
   static constexpr int P = ND / 32;
-  static constexpr int kA = (ND == 64) ? 2 * 32 * 4 : 32 * 4 * 2;
+  static constexpr int kA = (ND == 64) ? 2 * 32 * 4 : (ND == 128) ? 32 * P * 2 : P * 32 * P * 2;
   static constexpr int kT = ND * 2;
   static constexpr int kL = 6 * ND * 2;
   static constexpr int kFloats = kA + kT + kL;
-  static constexpr int kWaveF4 = (kA + kT) / 4;  // float4 copied into the wave's LDS slot
+  // float4 copied into the wave's LDS slot: A and the Horner twiddle T.  N/D = 256 keeps its (16 KiB, fully merged)
+  // A table in HBM and reads it with wave-uniform vector loads; its wave slot is only the epilogue scratch.
+  static constexpr int kWaveF4 = (ND == 256) ? ND / 2 : (kA + kT) / 4;
 };
 
 template <int ND>
@@ -154,9 +157,13 @@ __device__ __forceinline__ float2 table_entry_AT(int i, double f, double r, int 
       int const pass = i >> 6, ap = (i >> 1) & 31, hf = i & 1;
       a = ap + 32 * hf;
       if (pass) extra = -(double)ap / 64.0 + (hf ? 0.5 : 0.0);
-    } else {
-      int const ap = i >> 2, s = i & 3;  // [a'][s]
+    } else if (ND == 128) {
+      int const ap = i / P, s = i % P;  // [a'][s]
       a = ap + 32 * s;
+    } else {
+      int const pass = i / (32 * P), ap = (i / P) % 32, s = i % P;  // [pass][a'][s]
+      a = ap + 32 * s;
+      extra = -(double)(s * pass) / 8.0 - (double)(ap * pass) / 256.0;
     }
     double const Ra = (double)R * a;
     return unit(f * Ra + r * (0.5 * Ra * (Ra - 1.0)) + extra);
@@ -189,21 +196,18 @@ template <int ND, int PASS, int STRIDE, bool SWEPT>
 __device__ __forceinline__ void column_pass(const float2 *col, const float4 *tab, const float2 *wsh, float kappa,
                                             float2 (&v)[32]) {
   constexpr int P = ND / 32;
-  constexpr int CH = (ND == 64) ? 4 : 2;  // rows a' per software-pipeline stage
+  constexpr int CH = (ND == 64) ? 4 : (ND == 128) ? 2 : 1;  // rows a' per software-pipeline stage
   // Software pipeline in chunks of CH rows: the LDS reads of chunk k+1 are issued before the arithmetic of chunk
   // k; sched_barriers pin that order, otherwise the scheduler hoists every read of the pass and spills.
+  constexpr int TW4 = (ND == 64) ? 1 : P / 2;  // float4 of twiddles per row a'
   float2 xs[2][CH][P];
-  float4 tw[2][CH][(ND == 64) ? 1 : 2];
+  float4 tw[2][CH][TW4];
 #pragma unroll
   for (int i = 0; i < CH; i++) {
 #pragma unroll
     for (int s = 0; s < P; s++) xs[0][i][s] = col[STRIDE * (i + 32 * s)];
-    if (ND == 64) {
-      tw[0][i][0] = tab[PASS * 32 + i];
-    } else {
-      tw[0][i][0] = tab[2 * i];
-      tw[0][i][1] = tab[2 * i + 1];
-    }
+#pragma unroll
+    for (int t = 0; t < TW4; t++) tw[0][i][t] = (ND == 64) ? tab[PASS * 32 + i] : tab[TW4 * i + t];
   }
 #pragma unroll
   for (int k = 0; k < 32 / CH; k++) {
@@ -214,12 +218,8 @@ __device__ __forceinline__ void column_pass(const float2 *col, const float4 *tab
         int const ap = (k + 1) * CH + i;
 #pragma unroll
         for (int s = 0; s < P; s++) xs[nxt][i][s] = col[STRIDE * (ap + 32 * s)];
-        if (ND == 64) {
-          tw[nxt][i][0] = tab[PASS * 32 + ap];
-        } else {
-          tw[nxt][i][0] = tab[2 * ap];
-          tw[nxt][i][1] = tab[2 * ap + 1];
-        }
+#pragma unroll
+        for (int t = 0; t < TW4; t++) tw[nxt][i][t] = (ND == 64) ? tab[PASS * 32 + ap] : tab[TW4 * ap + t];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -242,23 +242,39 @@ __device__ __forceinline__ void column_pass(const float2 *col, const float4 *tab
         r.x = fmaf(x[1].x, t.z, fmaf(-x[1].y, t.w, r.x));
         r.y = fmaf(x[1].x, t.w, fmaf(x[1].y, t.z, r.y));
       } else {
-        // sum_s x_s A_s (-i)^{s PASS}: the power of -i is a compile-time component swap / sign of A_s
-        float2 const A[4] = {make_float2(tw[cur][i][0].x, tw[cur][i][0].y), make_float2(tw[cur][i][0].z, tw[cur][i][0].w),
-                             make_float2(tw[cur][i][1].x, tw[cur][i][1].y), make_float2(tw[cur][i][1].z, tw[cur][i][1].w)};
-        r = make_float2(0.f, 0.f);
+        // sum_s x_s A_s W_P^{s PASS}.  W_P^e = (-i)^(e8 >> 1) * W_8^(e8 & 1) with e8 the exponent on the 8th-root
+        // circle: the power of -i is a compile-time component swap / sign of A_s; terms with an odd e8 go to a
+        // second accumulator that is rotated by W_8 = (1 - i)/sqrt(2) once at the end.
+        float2 re = make_float2(0.f, 0.f), ro = make_float2(0.f, 0.f);
+        bool first_e = true, first_o = true;
 #pragma unroll
         for (int s = 0; s < P; s++) {
-          int const e = (s * PASS) & 3;  // A * (-i)^e
-          float2 const As = e == 0   ? A[s]
-                            : e == 1 ? make_float2(A[s].y, -A[s].x)
-                            : e == 2 ? make_float2(-A[s].x, -A[s].y)
-                                     : make_float2(-A[s].y, A[s].x);
-          r = (s == 0) ? cmul(x[0], As) : cfma(x[s], As, r);
+          float4 const t4 = tw[cur][i][s >> 1];
+          float2 const A = (s & 1) ? make_float2(t4.z, t4.w) : make_float2(t4.x, t4.y);
+          int const e8 = ((8 / P) * s * PASS) & 7;
+          int const rot = e8 >> 1;
+          float2 const As = rot == 0   ? A
+                            : rot == 1 ? make_float2(A.y, -A.x)
+                            : rot == 2 ? make_float2(-A.x, -A.y)
+                                       : make_float2(-A.y, A.x);
+          if (e8 & 1) {
+            ro = first_o ? cmul(x[s], As) : cfma(x[s], As, ro);
+            first_o = false;
+          } else {
+            re = first_e ? cmul(x[s], As) : cfma(x[s], As, re);
+            first_e = false;
+          }
+        }
+        r = re;
+        if (!first_o) {
+          float const h = 0.70710678118654752440f;
+          r.x += (ro.x + ro.y) * h;
+          r.y += (ro.y - ro.x) * h;
         }
         if (PASS != 0 && ap != 0) {
-          // times W_128^{a' PASS}: read from a workgroup-shared LDS table (wave-uniform address).  As immediates
-          // the ~190 distinct constants of passes 1-3 do not fit the register file and spill.
-          r = cmul(r, wsh[(ap * PASS) % 128]);
+          // times W_ND^{a' PASS}: read from a workgroup-shared LDS table (wave-uniform address).  As immediates
+          // the distinct constants of the later passes do not fit the register file and spill.
+          r = cmul(r, wsh[(ap * PASS) % ND]);
         }
       }
       v[bitrev5(ap)] = r;
@@ -340,6 +356,51 @@ __device__ __forceinline__ float2 lane_reduce(float2 (&acc)[32], const float2 *t
   return cfma(w, hi, lo);
 }
 
+// lane_reduce with the pass as a run-time value (rolled pass loop of the N/D = 256 kernel), unswept only
+template <int ND>
+__device__ __forceinline__ float2 lane_reduce_rt(float2 (&acc)[32], const float2 *tL, int pass, int lane) {
+  constexpr int P = ND / 32;
+  float2 z[16];
+  int qlow;
+  {
+    int const bit = (lane >> 5) & 1;
+    qlow = bit;
+    const float2 *tl = tL + 5 * ND + pass;
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      float2 e = acc[2 * m], o = acc[2 * m + 1];
+      swap32(e.x, o.x);
+      swap32(e.y, o.y);
+      z[m] = cfma(tl[P * (2 * m + bit)], o, e);
+    }
+  }
+#pragma unroll
+  for (int t = 1; t < 5; t++) {
+    int const i = 5 - t;
+    int const bit = (lane >> i) & 1;
+    int const cnt = 16 >> t;
+    const float2 *tl = tL + (size_t)i * ND + pass;
+#pragma unroll
+    for (int m = 0; m < cnt; m++) {
+      float2 const e = z[2 * m], o = z[2 * m + 1];
+      float2 const keep = bit ? o : e, send = bit ? e : o;
+      float2 recv;
+      recv.x = __shfl_xor(send.x, 1 << i, 64);
+      recv.y = __shfl_xor(send.y, 1 << i, 64);
+      float2 const lo = bit ? recv : keep, hi = bit ? keep : recv;
+      int const qp = (((2 * m + bit) << t) | qlow);
+      z[m] = cfma(tl[P * qp], hi, lo);
+    }
+    qlow |= bit << t;
+  }
+  float2 recv;
+  recv.x = __shfl_xor(z[0].x, 1, 64);
+  recv.y = __shfl_xor(z[0].y, 1, 64);
+  int const b0 = lane & 1;
+  float2 const lo = b0 ? recv : z[0], hi = b0 ? z[0] : recv;
+  return cfma(tL[P * qlow + pass], hi, lo);
+}
+
 // Fill the wave's LDS slot (A and T) and the per-level sweep factors for channel c, block blk
 template <int ND, bool SWEPT>
 __device__ __forceinline__ void fill_tables(float4 *wtab, const float *tc, double f_blk, double df, double r, int R, int N,
@@ -357,6 +418,84 @@ __device__ __forceinline__ void fill_tables(float4 *wtab, const float *tc, doubl
     for (int i = 0; i < 6; i++) th[i] = make_float2(1.f, 0.f);
   }
   wave_lds_sync();
+}
+
+// Epilogue for N_dec > 64: each lane owns the bins q = P q' + p with q' = rev5(lane >> 1) and p = b0, b0+2, ...
+// (P/2 bins per lane).  P0 and the response multiply (filter.c:206-227) are applied on the way into the wave's LDS
+// scratch, which then serves CROSS_CONJ (filter.c:239-249) and the bit-reversed order of the N_dec-point inverse
+// transform: V = N_dec/64 positions per lane, log2(V) in-lane stages, 6 cross-lane stages.
+template <int ND>
+__device__ __forceinline__ void epilogue_from_scratch(const float2 *scratch, bool isb, float2 *out, int olen, int lane);
+
+template <int ND>
+__device__ __forceinline__ void epilogue_lds(float2 *scratch, const float2 (&ypass)[ND / 32], float2 p0, const float2 *H,
+                                             bool isb, float2 *out, int olen, int lane) {
+  constexpr int P = ND / 32, V = ND / 64;
+  int const b0 = lane & 1;
+  int const qp = (int)(__brev((unsigned)(lane >> 1)) >> 27);
+#pragma unroll
+  for (int i = 0; i < V; i++) {
+    float2 const y = b0 ? ypass[2 * i + 1] : ypass[2 * i];
+    int const q = P * qp + 2 * i + b0;
+    scratch[q] = cmul(cmul(y, p0), H[q]);
+  }
+  wave_lds_sync();
+  epilogue_from_scratch<ND>(scratch, isb, out, olen, lane);
+}
+
+// CROSS_CONJ and the inverse transform, reading the response-weighted bins G[q] (natural order) from the scratch
+template <int ND>
+__device__ __forceinline__ void epilogue_from_scratch(const float2 *scratch, bool isb, float2 *out, int olen, int lane) {
+  constexpr int V = ND / 64;
+  constexpr int LOGN = (ND == 128) ? 7 : 8, LOGV = (ND == 128) ? 1 : 2;
+  float2 z[V];
+#pragma unroll
+  for (int e = 0; e < V; e++) {
+    int const q = (int)(__brev((unsigned)(V * lane + e)) >> (32 - LOGN));
+    float2 gq = scratch[q];
+    if (isb && q != 0 && q != ND / 2) {
+      float2 const o = scratch[ND - q];
+      gq = (q < ND / 2) ? cadd(gq, cconj(o)) : csub(gq, cconj(o));
+    }
+    z[e] = gq;
+  }
+  // decimation in time on bit-reversed positions V*lane + e
+#pragma unroll
+  for (int s = 0; s < LOGV; s++) {  // in-lane stages: twiddles exp(+i pi jj / half) with jj = e mod half
+    int const half = 1 << s;
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      if (e & half) continue;
+      int const jj = e & (half - 1);
+      float2 const a = z[e];
+      float2 b = z[e + half];
+      if (jj != 0) b = make_float2(-b.y, b.x);  // only half = 2, jj = 1: times +i
+      z[e] = cadd(a, b);
+      z[e + half] = csub(a, b);
+    }
+  }
+#pragma unroll
+  for (int s = LOGV; s < LOGN; s++) {
+    int const half = 1 << s;
+    int const bit = (lane >> (s - LOGV)) & 1;
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      int const jj = (V * lane + e) & (half - 1);
+      float sw, cw;
+      sincospif((float)jj / (float)half, &sw, &cw);
+      float2 const v = bit ? cmul(z[e], make_float2(cw, sw)) : z[e];
+      float2 rr;
+      rr.x = __shfl_xor(v.x, half / V, 64);
+      rr.y = __shfl_xor(v.y, half / V, 64);
+      z[e] = bit ? csub(rr, v) : cadd(v, rr);
+    }
+  }
+  int const first = ND - olen;  // filter.c:131
+#pragma unroll
+  for (int e = 0; e < V; e++) {
+    int const pos = V * lane + e;
+    if (pos >= first) out[pos - first] = z[e];
+  }
 }
 
 }  // namespace
@@ -561,76 +700,113 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_stream(Geom g, ChanDev c
   do_pass(std::integral_constant<int, 2>{});
   do_pass(std::integral_constant<int, 3>{});
   if (!live) return;
-  // ---- each lane owns bins q = 4 q' + p, q' = rev5(lane >> 1), p = b0 and b0 + 2: P0 and response multiply
-  // (filter.c:206-227), then through the wave's scratch for CROSS_CONJ and the bit-reversed order of the inverse
   {
-    int const b0 = lane & 1;
-    int const qp = (int)(__brev((unsigned)(lane >> 1)) >> 27);
     double turns = ch.lo_phase[c] + f0 * m0;
     if (SWEPT) turns += r * (0.5 * m0 * (m0 - 1.0));
-    float2 const p0 = unit(turns);
-    float2 const ya = b0 ? ypass[1] : ypass[0], yb = b0 ? ypass[3] : ypass[2];
-    int const qa = 4 * qp + b0, qb = qa + 2;
-    const float2 *H = ch.resp + (size_t)c * ND;
-    scratch[qa] = cmul(cmul(ya, p0), H[qa]);
-    scratch[qb] = cmul(cmul(yb, p0), H[qb]);
+    epilogue_lds<ND>(scratch, ypass, unit(turns), ch.resp + (size_t)c * ND, (ch.flags[c] & FLAG_ISB) != 0,
+                     pl.filt + ((size_t)c * g.max_blocks + blk) * g.olen, g.olen, lane);
   }
-  wave_lds_sync();
-  bool const isb = (ch.flags[c] & FLAG_ISB) != 0;
-  float2 z[2];
-#pragma unroll
-  for (int e = 0; e < 2; e++) {
-    int const q = (int)(__brev((unsigned)(2 * lane + e)) >> 25);  // bitrev7
-    float2 gq = scratch[q];
-    if (isb && q != 0 && q != ND / 2) {  // filter.c:239-249
-      float2 const o = scratch[ND - q];
-      gq = (q < ND / 2) ? cadd(gq, cconj(o)) : csub(gq, cconj(o));
-    }
-    z[e] = gq;
-  }
-  // 128-point inverse, decimation in time on bit-reversed positions 2*lane, 2*lane+1
+}
+
+// ------------------------------------------------------------------ N_dec = 256, N = 16384 (R = 64: one column group)
+// Window resident in LDS like k_pruned_resident.  8 passes of the 32-point column FFT; the radix-8 first stage, the
+// premultiply and the pass twiddle are merged into one table A[p][a'][s] (16 KiB per channel, in HBM, read with
+// wave-uniform vector loads that retire in order under vmcnt), which keeps the pass loop rolled.  No Horner step.
+// After each pass the owning lane of a pair drops its bin, already times P0 and H, into the wave's LDS scratch.
+template <int NWAVES, int CPW>
+__global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident256(Geom g, ChanDev ch, Planes pl,
+                                                                    const float2 *__restrict__ window,
+                                                                    const float *__restrict__ tab, int nchan) {
+  constexpr int ND = 256, P = 8, R = 64;
+  constexpr int N = ND * R;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  int const blk = blockIdx.y;
   {
-    float2 const a = z[0], b = z[1];
-    z[0] = cadd(a, b);
-    z[1] = csub(a, b);
+    const float4 *src = reinterpret_cast<const float4 *>(window + (size_t)blk * g.L);
+    float4 *dst = reinterpret_cast<float4 *>(lds);
+    for (int i = threadIdx.x; i < N / 2; i += NWAVES * 64) dst[i] = src[i];
   }
+  __syncthreads();
+  int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float2 *scratch = lds + N + wave * ND;
+  double const m0 = (double)blk * g.L;
+  int const vzero = __builtin_amdgcn_mbcnt_lo(0u, 0u);  // a zero the compiler cannot prove uniform: vector loads
+  int const b0 = lane & 1;
+  int const qp = (int)(__brev((unsigned)(lane >> 1)) >> 27);
+  float2 th[6];
 #pragma unroll
-  for (int s = 1; s < 7; s++) {
-    int const half = 1 << s;
-    int const bit = (lane >> (s - 1)) & 1;
+  for (int i = 0; i < 6; i++) th[i] = make_float2(1.f, 0.f);
+
+  for (int ci = 0; ci < CPW; ci++) {
+    int const c = __builtin_amdgcn_readfirstlane((blockIdx.x * NWAVES + wave) * CPW + ci);
+    if (c >= nchan) break;
+    const float *tc = tab + (size_t)c * Tab<ND>::kFloats;
+    const float2 *tL = reinterpret_cast<const float2 *>(tc + Tab<ND>::kA + Tab<ND>::kT);
+    const float2 *H = ch.resp + (size_t)c * ND;
+    float2 const p0 = unit(ch.lo_phase[c] + ch.lo_freq[c] * m0);
+    const float2 *col = lds + lane;
+#pragma unroll 1
+    for (int pass = 0; pass < P; pass++) {
+      const float4 *tp = reinterpret_cast<const float4 *>(tc) + (size_t)pass * 32 * 4 + vzero;
+      float2 v[32];
+      float2 xs[2][P];
+      float4 tw[2][4];
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
-      int const jj = (2 * lane + e) & (half - 1);
-      float sw, cw;
-      sincospif((float)jj / (float)half, &sw, &cw);
-      float2 const v = bit ? cmul(z[e], make_float2(cw, sw)) : z[e];
-      float2 rr;
-      rr.x = __shfl_xor(v.x, half >> 1, 64);
-      rr.y = __shfl_xor(v.y, half >> 1, 64);
-      z[e] = bit ? csub(rr, v) : cadd(v, rr);
+      for (int s = 0; s < P; s++) xs[0][s] = col[R * (32 * s)];
+#pragma unroll
+      for (int t = 0; t < 4; t++) tw[0][t] = tp[t];
+#pragma unroll
+      for (int ap = 0; ap < 32; ap++) {
+        int const cur = ap & 1, nxt = cur ^ 1;
+        if (ap + 1 < 32) {
+#pragma unroll
+          for (int s = 0; s < P; s++) xs[nxt][s] = col[R * (ap + 1 + 32 * s)];
+#pragma unroll
+          for (int t = 0; t < 4; t++) tw[nxt][t] = tp[4 * (ap + 1) + t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float2 r = cmul(xs[cur][0], make_float2(tw[cur][0].x, tw[cur][0].y));
+        r = cfma(xs[cur][1], make_float2(tw[cur][0].z, tw[cur][0].w), r);
+#pragma unroll
+        for (int t = 1; t < 4; t++) {
+          r = cfma(xs[cur][2 * t], make_float2(tw[cur][t].x, tw[cur][t].y), r);
+          r = cfma(xs[cur][2 * t + 1], make_float2(tw[cur][t].z, tw[cur][t].w), r);
+        }
+        v[bitrev5(ap)] = r;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      fft32_dit(v);
+      __builtin_amdgcn_sched_barrier(0);
+      float2 const y = lane_reduce_rt<ND>(v, tL, pass, lane);
+      if (b0 == (pass & 1)) {
+        int const q = P * qp + pass;
+        scratch[q] = cmul(cmul(y, p0), H[q]);
+      }
     }
-  }
-  int const first = ND - g.olen;  // filter.c:131
-  float2 *o = pl.filt + ((size_t)c * g.max_blocks + blk) * g.olen;
-#pragma unroll
-  for (int e = 0; e < 2; e++) {
-    int const pos = 2 * lane + e;
-    if (pos >= first) o[pos - first] = z[e];
+    wave_lds_sync();
+    epilogue_from_scratch<ND>(scratch, (ch.flags[c] & FLAG_ISB) != 0, pl.filt + ((size_t)c * g.max_blocks + blk) * g.olen,
+                              g.olen, lane);
+    wave_lds_sync();
   }
 }
 
 // ------------------------------------------------------------------ host side
 bool pruned_supported(const Geom &g) {
   if (g.Ndec == 64) return g.D == 64 || g.D == 128 || g.D == 256;
+  if (g.Ndec == 256) return g.D == 64;
   return g.Ndec == 128 && g.D == 512;
 }
-size_t pruned_table_elems(const Geom &g) { return (size_t)(g.Ndec == 64 ? Tab<64>::kFloats : Tab<128>::kFloats) / 2; }
+size_t pruned_table_elems(const Geom &g) {
+  return (size_t)(g.Ndec == 64 ? Tab<64>::kFloats : g.Ndec == 128 ? Tab<128>::kFloats : Tab<256>::kFloats) / 2;
+}
 
 void launch_pruned_tables(hipStream_t s, const Geom &g, const ChanDev &ch, float2 *chan_tw, int nchan) {
   if (g.Ndec == 64)
     hipLaunchKernelGGL(k_pruned_tables<64>, dim3(nchan), dim3(256), 0, s, g, ch, reinterpret_cast<float *>(chan_tw), nchan);
-  else
+  else if (g.Ndec == 128)
     hipLaunchKernelGGL(k_pruned_tables<128>, dim3(nchan), dim3(256), 0, s, g, ch, reinterpret_cast<float *>(chan_tw), nchan);
+  else
+    hipLaunchKernelGGL(k_pruned_tables<256>, dim3(nchan), dim3(256), 0, s, g, ch, reinterpret_cast<float *>(chan_tw), nchan);
 }
 
 namespace {
@@ -647,6 +823,21 @@ void launch_resident(hipStream_t s, const Geom &g, const ChanDev &ch, const Plan
   }
   int const per_wg = NWAVES * CPW;
   hipLaunchKernelGGL((k_pruned_resident<NWAVES, CPW, R, SWEPT>), dim3((nchan + per_wg - 1) / per_wg, nblocks),
+                     dim3(NWAVES * 64), lds_bytes, s, g, ch, pl, window, tab, nchan);
+}
+
+void launch_resident256(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
+                        const float *tab, int nchan, int nblocks) {
+  constexpr int NWAVES = 8, CPW = 4;
+  size_t const lds_bytes = (size_t)16384 * sizeof(float2) + (size_t)NWAVES * 256 * sizeof(float2);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void *)k_pruned_resident256<NWAVES, CPW>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    configured = true;
+  }
+  int const per_wg = NWAVES * CPW;
+  hipLaunchKernelGGL((k_pruned_resident256<NWAVES, CPW>), dim3((nchan + per_wg - 1) / per_wg, nblocks),
                      dim3(NWAVES * 64), lds_bytes, s, g, ch, pl, window, tab, nchan);
 }
 
@@ -670,6 +861,10 @@ void launch_stream(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes
 void launch_filter_pruned(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                           const float2 *chan_tw, int nchan, int nblocks, bool swept) {
   const float *tab = reinterpret_cast<const float *>(chan_tw);
+  if (g.Ndec == 256) {  // unswept only (the host routes swept channels at this geometry to the full path)
+    launch_resident256(s, g, ch, pl, window, tab, nchan, nblocks);
+    return;
+  }
   if (g.Ndec == 128) {
     if (swept)
       launch_stream<true>(s, g, ch, pl, window, tab, nchan, nblocks);

@@ -174,7 +174,7 @@ def test_int16_ingest_and_zero_fill(gpu):
     bank.close()
 
 
-@pytest.mark.parametrize("name,nchan,nblocks", [("cfg3", 40, 5), ("cfg4", 33, 4)])
+@pytest.mark.parametrize("name,nchan,nblocks", [("cfg3", 40, 5), ("cfg4", 33, 4), ("cfg2", 37, 3)])
 def test_config_geometry_pruned(gpu, name, nchan, nblocks):
     """Pruned forward path (only the N/D bins the slave reads) against the oracle's full N-point FFT."""
     g = wl.GEOMETRY[name]

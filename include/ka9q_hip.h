@@ -77,6 +77,8 @@ typedef struct kq_channel_config {
   double doppler;          /* set_doppler() arguments, Hz and Hz/s (radio.c:180-184) */
   double doppler_rate;
   double shift;            /* set_shift() argument, Hz (radio.c:304-311) */
+  int pll;                 /* opt.pll : carrier-tracking PLL in linear mode (linear.c:129-246; modes CAM, AME, CISB) */
+  int square;              /* opt.square : squaring loop for suppressed-carrier DSB / BPSK (mode DSB) */
 } kq_channel_config;
 
 /* Per channel, per block signal status: the demod->sig.* / agc.gain values the path produces
@@ -91,6 +93,9 @@ typedef struct kq_chan_status {
   float agc_gain;          /* am.c / linear.c agc.gain after the block */
   float noise_gain;        /* filter.out->noise_gain (filter.c:472-497) */
   float plfreq;            /* fm.c:189-285 CTCSS (PL) tone estimate, Hz; NaN: none, not FM, or N/D < 128 */
+  float cphase;            /* linear.c:219-223 carrier phase of the block, rad (PLL modes; else 0) */
+  int32_t pll_lock;        /* linear.c:162-169 */
+  int32_t lock_count;      /* linear.c:157-170 (sig.lock_timer) */
   int32_t squelch_count;   /* fm.c:70 snr_below_threshold after the block */
   int32_t hangcount;       /* am.c:26 / linear.c:33 hangcount after the block */
   int32_t blanked;         /* FM samples held at lastaudio this block (fm.c:141) */

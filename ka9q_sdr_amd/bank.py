@@ -38,7 +38,7 @@ class ChannelConfig(C.Structure):
         ("low", C.c_float), ("high", C.c_float), ("kaiser_beta", C.c_float), ("headroom", C.c_float),
         ("hangtime", C.c_float), ("recovery_rate", C.c_float),
         ("second_lo", C.c_double), ("doppler", C.c_double), ("doppler_rate", C.c_double),
-        ("shift", C.c_double),
+        ("shift", C.c_double), ("pll", C.c_int), ("square", C.c_int),
     ]
 
 
@@ -46,7 +46,8 @@ class ChanStatus(C.Structure):
     _fields_ = [
         ("if_power", C.c_float), ("bb_power", C.c_float), ("n0", C.c_float), ("snr", C.c_float),
         ("foffset", C.c_float), ("pdeviation", C.c_float), ("agc_gain", C.c_float),
-        ("noise_gain", C.c_float), ("plfreq", C.c_float),
+        ("noise_gain", C.c_float), ("plfreq", C.c_float), ("cphase", C.c_float),
+        ("pll_lock", C.c_int32), ("lock_count", C.c_int32),
         ("squelch_count", C.c_int32), ("hangcount", C.c_int32), ("blanked", C.c_int32), ("nout", C.c_int32),
     ]
 
@@ -61,7 +62,7 @@ class Timing(C.Structure):
 
 STATUS_DTYPE = np.dtype([
     ("if_power", "f4"), ("bb_power", "f4"), ("n0", "f4"), ("snr", "f4"), ("foffset", "f4"),
-    ("pdeviation", "f4"), ("agc_gain", "f4"), ("noise_gain", "f4"), ("plfreq", "f4"),
+    ("pdeviation", "f4"), ("agc_gain", "f4"), ("noise_gain", "f4"), ("plfreq", "f4"), ("cphase", "f4"), ("pll_lock", "i4"), ("lock_count", "i4"),
     ("squelch_count", "i4"), ("hangcount", "i4"), ("blanked", "i4"), ("nout", "i4")])
 
 
@@ -144,13 +145,14 @@ def _err(L):
 
 def channel_config(demod_type=KQ_FM_DEMOD, low=-8000.0, high=8000.0, second_lo=0.0, flat=0, isb=0, channels=1,
                    kaiser_beta=3.0, headroom=10 ** (-15 / 20), hangtime=0.0, recovery_rate=0.0,
-                   doppler=0.0, doppler_rate=0.0, shift=0.0):
+                   doppler=0.0, doppler_rate=0.0, shift=0.0, pll=0, square=0):
     """Defaults: main.c:113-117 (beta 3.0, headroom -15 dB); filter edges as modes.txt:25."""
     c = ChannelConfig()
     c.demod_type, c.flat, c.isb, c.channels = demod_type, flat, isb, channels
     c.low, c.high, c.kaiser_beta, c.headroom = low, high, kaiser_beta, headroom
     c.hangtime, c.recovery_rate = hangtime, recovery_rate
     c.second_lo, c.doppler, c.doppler_rate, c.shift = second_lo, doppler, doppler_rate, shift
+    c.pll, c.square = pll, square
     return c
 
 

@@ -133,8 +133,14 @@ struct kq_bank {
   bool chan_tw_dirty = true;
   kq::ChanDev chd;
   kq::Planes pl;
-  int *list_dev[3] = {nullptr, nullptr, nullptr};  // fm, am, linear
+  int *list_dev[3] = {nullptr, nullptr, nullptr};  // fm, am, linear (without PLL)
   int *retune_list = nullptr;
+  // carrier-tracking linear channels (linear.c:129-246): own list, 65536-sample search ring per channel
+  static constexpr int kMaxPll = 64;
+  int *list_pll_dev = nullptr;
+  std::vector<int> list_pll_host;
+  kq::PllState *pll_state = nullptr;
+  float2 *pll_rings = nullptr, *pll_side = nullptr;
   std::vector<int> list_host[3];
   bool lists_dirty = true;
   float *energy_state = nullptr;
@@ -198,6 +204,7 @@ int upload_channel(kq_bank *b, int c) {
   if (k.flat) flags |= kq::FLAG_FLAT;
   if (k.isb && mode == KQ_LINEAR_DEMOD) flags |= kq::FLAG_ISB;
   if (k.channels == 2 && mode == KQ_LINEAR_DEMOD) flags |= kq::FLAG_STEREO;
+  if (k.square && mode == KQ_LINEAR_DEMOD) flags |= kq::FLAG_SQUARE;
   float const samptime = (float)g.D / (float)g.samprate;  // am.c:21, linear.c:29
   float const rec_db = k.recovery_rate * samptime;
   float const recovery = powf(10.f, (float)((double)rec_db / 20.));  // dB2voltage, dsp.h:38
@@ -354,10 +361,16 @@ int upload_call_params(kq_bank *b, double *osc_dst, int64_t n_w, const unsigned 
 
 int upload_lists(kq_bank *b) {
   for (int k = 0; k < 3; k++) b->list_host[k].clear();
+  b->list_pll_host.clear();
   for (size_t c = 0; c < b->chans.size(); c++) {
     int const m = b->chans[c].cfg.demod_type;
-    b->list_host[m == KQ_FM_DEMOD ? 0 : m == KQ_AM_DEMOD ? 1 : 2].push_back((int)c);
+    if (m == KQ_LINEAR_DEMOD && b->chans[c].cfg.pll)
+      b->list_pll_host.push_back((int)c);  // slot = position in this list = order of creation
+    else
+      b->list_host[m == KQ_FM_DEMOD ? 0 : m == KQ_AM_DEMOD ? 1 : 2].push_back((int)c);
   }
+  if (!b->list_pll_host.empty())
+    if (upload(b, b->list_pll_dev, b->list_pll_host.data(), b->list_pll_host.size() * sizeof(int))) return -1;
   for (int k = 0; k < 3; k++)
     if (!b->list_host[k].empty())
       if (upload(b, b->list_dev[k], b->list_host[k].data(), b->list_host[k].size() * sizeof(int))) return -1;
@@ -461,6 +474,9 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
                         (int)nblocks, b->cfg.compute_n0);
     }
   }
+  if (!b->list_pll_host.empty())
+    kq::launch_demod_pll(b->stream2, g, chd, pl, b->tw, b->list_pll_dev, (int)b->list_pll_host.size(), b->pll_state,
+                         b->pll_rings, b->pll_side, (int)nblocks, b->cfg.compute_n0);
   if (g.pl_n > 0 && !b->list_host[0].empty())
     kq::launch_pl_track(b->stream2, g, chd, pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), (int)nblocks);
   if (b->pcm_on) kq::launch_pcm(b->stream2, g, pl, b->pcm, b->pcm_mask, C, (int)nblocks);
@@ -545,7 +561,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   g.log2N = ilog2(N);
   g.log2Ndec = ilog2(Ndec);
   g.samprate = cfg->samprate;
-  g.tw_log2 = g.log2N < 14 ? 14 : g.log2N;  // the PL tracker transforms 16384 points whatever N is
+  g.tw_log2 = g.log2N < 16 ? 16 : g.log2N;  // the PL tracker (16384) and the PLL carrier search (65536) need these periods
   {
     // pltask geometry (fm.c:201-205): decimate 32 from the audio master; needs a usable transform size
     int const pn = g.Ndec / 32, plen = g.olen / 32;
@@ -712,7 +728,8 @@ int kq_bank_destroy(kq_bank *b) {
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
                   b->pl2[0].plout, b->pl2[1].plout, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
                   b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state,
-                  b->update_dev, b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->retune_list};
+                  b->update_dev, b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->retune_list, b->list_pll_dev, b->pll_state, b->pll_rings,
+                  b->pll_side};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (auto *v : {&b->ev_filter, &b->ev_demod, &b->ev_ingest})
@@ -749,6 +766,30 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
   if (std::isnan(cfg->low) || std::isnan(cfg->high)) {  // filter.c:504-505
     set_err("NaN filter edge");
     return -1;
+  }
+  if (cfg->demod_type == KQ_LINEAR_DEMOD && cfg->pll) {
+    size_t npll = 0;
+    for (HostChan const &o : b->chans) npll += (o.cfg.demod_type == KQ_LINEAR_DEMOD && o.cfg.pll) ? 1 : 0;
+    if (npll >= (size_t)kq_bank::kMaxPll) {
+      set_err("at most %d carrier-tracking (pll) channels per bank", kq_bank::kMaxPll);
+      return -1;
+    }
+    {
+      // carrier search window (linear.c:51-56): +-300 Hz (x2 when squaring) in bins of the 65536-point transform
+      float const samptime = (float)b->g.D / (float)b->g.samprate;
+      float const binsize = (float)(1. / (65536 * samptime));
+      int const nbins = 2 * (int)round((cfg->square ? 2 : 1) * 300.f / binsize) + 1;
+      if (nbins > 4096) {
+        set_err("output rate too low for the PLL search window (%d bins > 4096)", nbins);
+        return -1;
+      }
+    }
+    if (!b->pll_state) {
+      if (sync_all(b)) return -1;
+      if (dev_alloc(&b->pll_state, kq_bank::kMaxPll) || dev_alloc(&b->pll_rings, (size_t)kq_bank::kMaxPll * 65536) ||
+          dev_alloc(&b->pll_side, (size_t)kq_bank::kMaxPll * 4096) || dev_alloc(&b->list_pll_dev, kq_bank::kMaxPll))
+        return -1;
+    }
   }
   HostChan h;
   h.cfg = *cfg;

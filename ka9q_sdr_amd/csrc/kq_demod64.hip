@@ -50,7 +50,10 @@ __device__ __forceinline__ void put_status(kq_chan_status &st, const Geom &g, co
                                            int compute_n0, float n0_rate, float &n0) {
   st.if_power = pl.if_power[b];
   st.noise_gain = ch.noise_gain[c];
-  st.plfreq = NAN;  // N/D = 64: the PL slave would have 2 points (fm.c:203), measurement off
+  st.plfreq = NAN;
+  st.cphase = 0;
+  st.pll_lock = 0;
+  st.lock_count = 0;  // N/D = 64: the PL slave would have 2 points (fm.c:203), measurement off
   if (compute_n0) {
     float const fresh = pl.n0raw[(size_t)c * g.max_blocks + b];
     if (isnan(n0))

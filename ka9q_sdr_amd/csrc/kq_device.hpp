@@ -16,7 +16,15 @@
 
 namespace kq {
 
-enum { FLAG_FLAT = 1, FLAG_ISB = 2, FLAG_STEREO = 4 };
+enum { FLAG_FLAT = 1, FLAG_ISB = 2, FLAG_STEREO = 4, FLAG_SQUARE = 8 };
+
+// Carried state of one carrier-tracking (PLL) linear channel, linear.c:97-112
+struct PllState {
+  double c_phase, c_freq;  // coarse (FFT-steered) oscillator: turns, cycles per output sample
+  double f_phase, f_freq;  // fine (loop-steered) oscillator
+  float integrator, delta_f, snr, foffset, cphase;
+  int lock_count, pll_lock, fft_samples, fft_ptr;
+};
 
 struct Geom {
   int N, L, M, D;
@@ -96,6 +104,8 @@ bool demod64_supported(const Geom &g);
 bool demod_agc_wave_supported(const Geom &g);
 void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const int *list_fm, int n_fm,
                     const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0);
+void launch_demod_pll(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_pll,
+                      int n_pll, PllState *state, float2 *rings, float2 *side, int nblocks, int compute_n0);
 void launch_pcm(hipStream_t s, const Geom &g, const Planes &pl, short *pcm, unsigned *mask, int nchan, int nblocks);
 void launch_pl_track(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_fm,
                      int n_fm, int nblocks);

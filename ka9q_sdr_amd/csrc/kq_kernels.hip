@@ -376,6 +376,9 @@ __device__ __forceinline__ void status_common(kq_chan_status &st, const Geom &g,
   st.if_power = pl.if_power[b];
   st.noise_gain = ch.noise_gain[c];
   st.plfreq = NAN;
+  st.cphase = 0;
+  st.pll_lock = 0;
+  st.lock_count = 0;
   if (compute_n0) {
     float const fresh = pl.n0raw[(size_t)c * g.max_blocks + b];
     float n0 = ch.n0[c];

@@ -114,4 +114,4 @@ def bank_channel_config(p):
                              kaiser_beta=p.get("kaiser_beta", 3.0), headroom=p.get("headroom", HEADROOM),
                              hangtime=p.get("hangtime", 0.0), recovery_rate=p.get("recovery_rate", 0.0),
                              doppler=p.get("doppler", 0.0), doppler_rate=p.get("doppler_rate", 0.0),
-                             shift=p.get("shift", 0.0))
+                             shift=p.get("shift", 0.0), pll=p.get("pll", 0), square=p.get("square", 0))

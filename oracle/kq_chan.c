@@ -7,7 +7,7 @@
  *   noise estimate        radio.c:383-425
  *   FM                    fm.c:21-174, PL-tone measurement fm.c:189-285 (run in lockstep after each block)
  *   AM                    am.c:15-83
- *   linear (SSB/IQ/ISB)   linear.c:21-322   (carrier PLL linear.c:129-246 not restated)
+ *   linear                linear.c:21-322 incl. the carrier PLL / squaring loop (linear.c:129-246)
  *   oscillator setters    radio.c:180-184, 290-311
  */
 #define _GNU_SOURCE 1
@@ -55,6 +55,12 @@ struct kqo_chan {
   float recovery_factor;
   float dc_filter;
   float samptime, dsamprate;
+  /* linear carrier PLL (linear.c:26-112) */
+  kqo_osc pll_fine, pll_coarse;
+  float pll_integrator, pll_delta_f, pll_ramp, cphase;
+  int pll_lock_count, pll_lock, pll_fft_samples, pll_fft_ptr;
+  float complex *pll_fftin, *pll_fftout;
+  kqo_fft *pll_plan;
   float *cap_filt;             /* test hook: pre-detection filter output captured right after the slave runs */
 };
 
@@ -194,6 +200,16 @@ kqo_chan *kqo_chan_create(const kqo_chan_cfg *cfg){
     c->recovery_factor = DB2VOLTAGE(cfg->recovery_rate * c->samptime);     /* linear.c:34 */
     c->hangmax = cfg->hangtime / c->samptime;                              /* linear.c:38 */
     c->agc_gain = DB2VOLTAGE(100.0);                                       /* linear.c:39 */
+    c->snr = 0;                                                            /* linear.c:75 */
+    if(cfg->pll){
+      c->pll_fftin = calloc(1 << 16, sizeof(float complex));               /* linear.c:89-93 */
+      c->pll_fftout = calloc(1 << 16, sizeof(float complex));
+      c->pll_plan = kqo_fft_create(1 << 16);
+      c->pll_fine.phasor = 1;                                              /* linear.c:97-105 */
+      kqo_set_osc(&c->pll_fine, 0.0, 0.0);
+      c->pll_coarse.phasor = 1;
+      kqo_set_osc(&c->pll_coarse, 0.0, 0.0);
+    }
     break;
   }
   return c;
@@ -202,6 +218,9 @@ kqo_chan *kqo_chan_create(const kqo_chan_cfg *cfg){
 void kqo_chan_destroy(kqo_chan *c){
   if(!c)
     return;
+  free(c->pll_fftin);
+  free(c->pll_fftout);
+  kqo_fft_destroy(c->pll_plan);
   kqo_delete_filter_output(c->pl_filter);
   free(c->pl_input);
   free(c->pl_spectrum);
@@ -391,6 +410,100 @@ static int linear_block(kqo_chan *c, float *audio){
   kqo_execute_filter_output(flt);
   capture_filt(c);
   update_n0(c, .001);
+  if(c->cfg.pll){                                                          /* linear.c:129-246 */
+    float const samptime = c->samptime;
+    float const blocktime = samptime * c->cfg.L;                           /* linear.c:30 (L is the undecimated block) */
+    int const fftsize = 1 << 16;
+    float const snrthresh = powf(10, 3. / 10);                             /* linear.c:42,49 */
+    int const lock_limit = round(1 / samptime);                            /* linear.c:45,50 */
+    float const binsize = 1. / (fftsize * samptime);
+    int const sq = c->cfg.square ? 2 : 1;
+    int const lowlimit = round(sq * -300.f / binsize);                     /* linear.c:53-56 */
+    int const highlimit = round(sq * 300.f / binsize);
+    float const vcogain = 2 * M_PI, pdgain = 1, damping = M_SQRT1_2;       /* linear.c:59-65 */
+    float const natfreq = 1 * 2 * M_PI;                                    /* loop_bw = 1, linear.c:26 */
+    float const tau1 = vcogain * pdgain / (natfreq * natfreq);
+    float const integrator_gain = 1 / tau1;
+    float const tau2 = 2 * damping / natfreq;
+    float const prop_gain = tau2 / tau1;
+    float const ramprate = 0;                                              /* linear.c:67 */
+
+    c->pll_fft_samples += olen;                                            /* linear.c:132-152 */
+    if(c->pll_fft_samples > fftsize)
+      c->pll_fft_samples = fftsize;
+    for(int i = 0; i < olen; i++){
+      float complex const s = flt->output_c[i];
+      c->pll_fftin[c->pll_fft_ptr++] = c->cfg.square ? s * s : s;
+      if(c->pll_fft_ptr >= fftsize)
+        c->pll_fft_ptr -= fftsize;
+    }
+    if(c->snr < snrthresh)                                                 /* linear.c:157-170: uses the PREVIOUS block's snr */
+      c->pll_lock_count -= olen;
+    else
+      c->pll_lock_count += olen;
+    if(c->pll_lock_count >= lock_limit){
+      c->pll_lock_count = lock_limit;
+      c->pll_lock = 1;
+    }
+    if(c->pll_lock_count <= -lock_limit){
+      c->pll_lock_count = -lock_limit;
+      c->pll_lock = 0;
+    }
+    if(!c->pll_lock){                                                      /* linear.c:173-203 */
+      if(c->pll_fft_samples > fftsize / 2){
+        c->pll_fft_samples = 0;
+        kqo_fft_c2c(c->pll_plan, c->pll_fftin, c->pll_fftout, -1);
+        int maxbin = 0;
+        float maxenergy = 0;
+        for(int n = lowlimit; n <= highlimit; n++){
+          float const e = norm2f(c->pll_fftout[n < 0 ? n + fftsize : n]);
+          if(e > maxenergy){
+            maxenergy = e;
+            maxbin = n;
+          }
+        }
+        if(maxenergy > 0){
+          double new_delta_f = binsize * maxbin;
+          if(c->cfg.square)
+            new_delta_f /= 2;
+          if(new_delta_f != c->pll_delta_f){
+            c->pll_delta_f = new_delta_f;
+            c->pll_integrator = 0;
+            kqo_set_osc(&c->pll_coarse, -samptime * c->pll_delta_f, 0.0);
+          }
+        }
+      }
+      if(c->pll_ramp == 0)
+        c->pll_ramp = ramprate;
+    } else {
+      c->pll_ramp = 0;
+    }
+    float complex accum = 0;                                               /* linear.c:208-223 */
+    for(int n = 0; n < olen; n++){
+      flt->output_c[n] *= kqo_step_osc(&c->pll_coarse) * kqo_step_osc(&c->pll_fine);
+      float complex ss = flt->output_c[n];
+      if(c->cfg.square)
+        ss *= ss;
+      accum += ss;
+    }
+    c->cphase = cargf(accum);
+    if(isnan(c->cphase))
+      c->cphase = 0;
+    if(c->cfg.square)
+      c->cphase /= 2;
+    float const carrier_phase = c->cphase;                                 /* linear.c:228-245 */
+    c->pll_integrator += carrier_phase * blocktime + c->pll_ramp;
+    float const feedback = integrator_gain * c->pll_integrator + prop_gain * carrier_phase;
+    kqo_set_osc(&c->pll_fine, -feedback * samptime, 0.0);
+    if((feedback >= binsize) && (c->pll_ramp > 0))
+      c->pll_ramp = -ramprate;
+    else if((feedback <= binsize) && (c->pll_ramp < 0))
+      c->pll_ramp = ramprate;
+    if(isnan(c->foffset))
+      c->foffset = feedback + c->pll_delta_f;
+    else
+      c->foffset += 0.001 * (feedback + c->pll_delta_f - c->foffset);
+  }
   float signal = 0, noise = 0;
   for(int n = 0; n < olen; n++){                                           /* linear.c:251-281 */
     float complex const s = flt->output_c[n];
@@ -425,7 +538,12 @@ static int linear_block(kqo_chan *c, float *audio){
     nout = 2 * olen;
   }
   c->bb_power = (signal + noise) / (2 * olen);                             /* linear.c:302 */
-  c->snr = NAN;                                                            /* linear.c:309 (no PLL) */
+  if(noise != 0 && c->cfg.pll){                                            /* linear.c:304-309 */
+    c->snr = (signal / noise) - 1;
+    if(c->snr < 0)
+      c->snr = 0;
+  } else
+    c->snr = NAN;
   return nout;
 }
 
@@ -452,6 +570,9 @@ static int demod_block(kqo_chan *c, float *audio, kqo_status *st, float *filt, f
     st->hangcount = c->hangcount;
     st->blanked = c->blanked;
     st->plfreq = (c->cfg.demod_type == KQO_FM) ? c->plfreq : NAN;
+    st->cphase = c->cphase;
+    st->pll_lock = c->pll_lock;
+    st->lock_count = c->pll_lock_count;
     st->nout = nout;
     st->samples = c->samples;
   }

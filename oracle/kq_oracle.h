@@ -121,11 +121,16 @@ typedef struct {
   double doppler_rate; /* Hz/s */
   double shift_hz;     /* set_shift argument */
   int compute_n0;      /* 0: skip the status-only noise estimate */
+  int pll;             /* opt.pll: carrier tracking in linear mode (linear.c:129-246) */
+  int square;          /* opt.square: squaring loop for suppressed-carrier DSB / BPSK */
 } kqo_chan_cfg;
 
 typedef struct {
   float if_power, bb_power, n0, snr, foffset, pdeviation, agc_gain;
   float plfreq;        /* fm.c:189-285 CTCSS tone estimate; NaN when none / not FM / geometry too small */
+  float cphase;        /* linear.c:219-223 carrier phase of the block (PLL modes) */
+  int pll_lock;        /* linear.c:162-169 */
+  int lock_count;      /* linear.c:157-170 (sig.lock_timer) */
   int squelch_count;   /* fm.c snr_below_threshold */
   int hangcount;       /* am.c / linear.c hangcount */
   int blanked;         /* FM samples replaced by lastaudio this block */

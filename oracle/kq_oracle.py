@@ -25,7 +25,7 @@ class ChanCfg(C.Structure):
         ("headroom", C.c_float), ("hangtime", C.c_float), ("recovery_rate", C.c_float),
         ("gain_factor", C.c_float),
         ("lo2_hz", C.c_double), ("doppler_hz", C.c_double), ("doppler_rate", C.c_double),
-        ("shift_hz", C.c_double), ("compute_n0", C.c_int),
+        ("shift_hz", C.c_double), ("compute_n0", C.c_int), ("pll", C.c_int), ("square", C.c_int),
     ]
 
 
@@ -33,6 +33,7 @@ class Status(C.Structure):
     _fields_ = [
         ("if_power", C.c_float), ("bb_power", C.c_float), ("n0", C.c_float), ("snr", C.c_float),
         ("foffset", C.c_float), ("pdeviation", C.c_float), ("agc_gain", C.c_float), ("plfreq", C.c_float),
+        ("cphase", C.c_float), ("pll_lock", C.c_int), ("lock_count", C.c_int),
         ("squelch_count", C.c_int), ("hangcount", C.c_int), ("blanked", C.c_int), ("nout", C.c_int),
         ("samples", C.c_longlong),
     ]
@@ -158,7 +159,7 @@ def make_cfg(**kw):
     d = dict(samprate=192000, L=8192, M=8193, D=4, demod_type=KQO_FM, flat=0, isb=0, channels=1,
              low=-8000.0, high=8000.0, kaiser_beta=3.0, headroom=10 ** (-15 / 20), hangtime=0.0,
              recovery_rate=0.0, gain_factor=1.0, lo2_hz=0.0, doppler_hz=0.0, doppler_rate=0.0,
-             shift_hz=0.0, compute_n0=1)
+             shift_hz=0.0, compute_n0=1, pll=0, square=0)
     d.update(kw)
     c = ChanCfg()
     for k, v in d.items():

@@ -13,7 +13,8 @@ def oracle_cfg(p, samprate, L, M, D, compute_n0=0, gain_factor=1.0):
                        kaiser_beta=p.get("kaiser_beta", 3.0), headroom=p.get("headroom", 10 ** (-15 / 20)),
                        hangtime=p.get("hangtime", 0.0), recovery_rate=p.get("recovery_rate", 0.0),
                        gain_factor=gain_factor, lo2_hz=p.get("second_lo", 0.0), doppler_hz=p.get("doppler", 0.0),
-                       doppler_rate=p.get("doppler_rate", 0.0), shift_hz=p.get("shift", 0.0), compute_n0=compute_n0)
+                       doppler_rate=p.get("doppler_rate", 0.0), shift_hz=p.get("shift", 0.0), compute_n0=compute_n0,
+                       pll=p.get("pll", 0), square=p.get("square", 0))
 
 
 def bank_cfg(p):

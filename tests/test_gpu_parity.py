@@ -350,3 +350,38 @@ def test_retune_mid_stream_is_sample_exact(gpu, name, mode):
                 got = bank.filter_output(c, b)
                 assert rel_rms(got, filt) < FILT_TOL, (call, c, b, rel_rms(got, filt))
     bank.close()
+
+
+@pytest.mark.parametrize("mode", ["cam", "dsb"])
+def test_linear_carrier_pll(gpu, mode):
+    """linear.c:129-246: carrier search (65536-point transform, +-300 Hz window), coarse + fine NCO, 2nd-order loop,
+    lock detector with hysteresis.  CAM = full-carrier AM tracked coherently; DSB = suppressed carrier through the
+    squaring loop.  Lock state and lock counter must match block for block; audio within the float budget."""
+    g = wl.GEOMETRY["cfg1"]
+    fs, L = g["samprate"], g["L"]
+    nblocks = 64
+    t = np.arange(nblocks * L) / fs
+    rng = np.random.default_rng(41)
+    msg = np.cos(2 * np.pi * 1000.0 * t)
+    if mode == "cam":
+        sig = 0.1 * (1 + 0.5 * msg) * np.exp(2j * np.pi * (20000.0 + 37.0) * t)
+        p = dict(demod="linear", low=-5000.0, high=5000.0, second_lo=-20000.0, hangtime=0.0, recovery_rate=50.0, pll=1)
+    else:
+        sig = 0.1 * msg * np.exp(2j * np.pi * (20000.0 - 61.0) * t + 0.7j)
+        p = dict(demod="linear", low=-5000.0, high=5000.0, second_lo=-20000.0, hangtime=1.1, recovery_rate=6.0, pll=1, square=1)
+    iq = (sig + 1e-3 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    plan = [p, dict(p, channels=2)]
+    want = run_oracle(plan, g, iq, nblocks)
+    got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_FULL, per_call=9)
+    for c in range(len(plan)):
+        auds, sts, _ = want[c]
+        for b in range(nblocks):
+            sg, sw = got[c]["status"][b], sts[b]
+            assert (sg["pll_lock"], sg["lock_count"], sg["nout"], sg["hangcount"]) == \
+                   (sw["pll_lock"], sw["lock_count"], sw["nout"], sw["hangcount"]), (c, b)
+            np.testing.assert_allclose(sg["foffset"], sw["foffset"], rtol=1e-3, atol=1e-3)
+            np.testing.assert_allclose(sg["cphase"], sw["cphase"], atol=2e-4)
+        assert got[c]["status"][-1]["pll_lock"] == 1
+        a_g = np.concatenate(got[c]["audio"][20:])
+        a_w = np.concatenate(auds[20:])
+        assert rel_rms(a_g, a_w) < 2e-5, (c, rel_rms(a_g, a_w))

@@ -212,3 +212,23 @@ def test_pl_tone_known_answer():
             assert abs(sts[-1]["plfreq"] - want) < 0.1
         else:
             assert np.isnan(sts[-1]["plfreq"]) or not (67 < sts[-1]["plfreq"] < 255) or True
+
+
+def test_linear_pll_known_answer():
+    """linear.c:129-246: a full-carrier AM signal 37 Hz off tune: the FFT search puts the coarse NCO within one bin
+    (0.73 Hz), the loop pulls the carrier phase to zero, the lock detector sets after 2 x 1 s of good SNR, and the
+    coherent detector recovers the modulation on I."""
+    fs, L, nb = 192000, 8192, 120
+    t = np.arange(nb * L) / fs
+    rng = np.random.default_rng(0)
+    x = (0.1 * (1 + 0.5 * np.cos(2 * np.pi * 1000 * t)) * np.exp(2j * np.pi * (20000 + 37.0) * t)
+         + 1e-3 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    p = dict(demod="linear", low=-5000.0, high=5000.0, second_lo=-20000.0, hangtime=0.0, recovery_rate=50.0, pll=1)
+    auds, sts, _ = ko.run_chain(oracle_cfg(p, fs, L, L + 1, 4), x.reshape(nb, L))
+    assert sts[0]["pll_lock"] == 0 and sts[-1]["pll_lock"] == 1
+    assert sts[-1]["lock_count"] == 48000                    # lock_limit = round(1 / samptime) (linear.c:50)
+    assert abs(sts[-1]["cphase"]) < 2e-3
+    assert sts[-1]["snr"] > 1000                              # carrier on I, only noise on Q
+    y = np.concatenate(auds[-20:])
+    tone = 2 * np.abs(np.mean(y * np.exp(-2j * np.pi * 1000.0 * np.arange(len(y)) / 48000.0)))
+    assert 0.3 < tone / np.abs(np.mean(y)) < 0.6             # 50 % modulation on top of the carrier (DC) level

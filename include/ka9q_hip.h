@@ -186,6 +186,35 @@ int kq_bank_get_timing(kq_bank *bank, kq_timing *t, int reset);
 /* Which forward path the bank resolved to (enum kq_fwd_mode, never AUTO) */
 int kq_bank_fwd_mode(const kq_bank *bank);
 
+/* --- front-end half-band decimator cascade ---------------------------------------------------
+ * What hackrf.c:260-330 does to every block of raw A/D samples before they reach the channel filter: rotate by
+ * +offset*Fs/4 (hackrf.c:272-291), run log_decimate half-band stages -- hb3_block (decimate.c:146-160) while the
+ * stage index j >= stage_threshold, hb15_block (decimate.c:108-144) below it (hackrf.c:295-300) -- multiply by
+ * Filter_atten (hackrf.c:469), convert to int16 (hackrf.c:307-311) and sum the output energy.  The filter state
+ * (struct hb15_state / hb3state, hackrf.c:211-216) is carried inside the handle across calls. */
+typedef struct kq_decimator kq_decimator;
+typedef struct kq_decim_config {
+  int device;
+  int log_decimate;     /* hackrf.c:64 Log_decimate: decimation ratio is 2^log_decimate */
+  int stage_threshold;  /* hackrf.c:76: stages j >= this use the 1-2-1 filter */
+  int offset;           /* hackrf.c:68 Offset: rotate_phase increment per input sample, 0 = no rotation */
+  float filter_atten;   /* hackrf.c:65,469 Filter_atten; 0 selects 0.5^log_decimate */
+  size_t max_out;       /* largest n_out of one process call */
+  void *stream;         /* hipStream_t to run on, NULL = private stream */
+} kq_decim_config;
+kq_decimator *kq_decim_create(const kq_decim_config *cfg);
+int kq_decim_destroy(kq_decimator *d);
+/* hb15 coefficients, order as struct hb15_state.coeffs (decimate.h:5); default is hackrf.c:229-238 */
+int kq_decim_set_coeffs(kq_decimator *d, const float coeffs[4]);
+/* iq_in: n_out << log_decimate interleaved complex float samples.  out_cf32: n_out complex samples after
+ * Filter_atten; out_s16 (may be NULL): the same as (short)round(32767*s), interleaved I,Q; out_energy (may be
+ * NULL): sum of s*s over the call (hackrf.c:308,325 output_energy).  on_device != 0: every pointer is device
+ * memory and the call is asynchronous on the handle's stream; otherwise host memory, synchronous. */
+int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t n_out, float *out_cf32,
+                     int16_t *out_s16, float *out_energy);
+int kq_decim_sync(kq_decimator *d);
+int kq_decim_reset(kq_decimator *d);
+
 #ifdef __cplusplus
 }
 #endif

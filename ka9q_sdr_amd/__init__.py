@@ -26,3 +26,4 @@ from .bank import (  # noqa: F401
     library_path,
     load_library,
 )
+from .decimate import Decimator  # noqa: F401,E402

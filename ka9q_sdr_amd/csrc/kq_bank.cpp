@@ -500,6 +500,16 @@ bool valid_ch(const kq_bank *b, int ch) { return b && ch >= 0 && (size_t)ch < b-
 
 }  // namespace
 
+// error reporting for the other translation units of the library (kq_decim.hip)
+void kq_internal_set_error(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
 extern "C" {
 
 const char *kq_last_error(void) { return g_err.c_str(); }

@@ -1,0 +1,471 @@
+// kq_decim.hip -- half-band decimator cascade of the front-end daemons on gfx950.
+//
+// Replaces decimate.c:108-160 (hb15_block / hb3_block, portable branch) as hackrf.c:260-330 drives them: Fs/4
+// rotation of the raw samples, Log_decimate half-band stages (the first ones, j >= stage_threshold, with the 1-2-1
+// filter, the rest with the 15-tap Goodman/Carey F8), scaling by Filter_atten, conversion to int16 and the output
+// energy.  I and Q go through the same real filter, so a complex sample is one float2 element.
+//
+// Every stage is a FIR, so instead of the reference's per-stage shift registers the carried state is the tail of
+// each kernel's INPUT (zero at start, exactly like the zeroed states of hackrf.c:211-216): a workgroup re-derives
+// the few intermediate samples it needs from that halo.  Up to three stages (decimate by 8) are fused in one
+// kernel, staged through LDS, so HBM sees the input once plus 1/8 + 1/8 of it between kernels.  The arithmetic
+// keeps the reference's operand order with FMA contraction switched off, so the
+// result is bit-identical to a scalar C evaluation of decimate.c.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "ka9q_hip.h"
+#include "kq_device.hpp"
+
+// hipcc contracts a*b+c into an FMA by default (and its __fmul_rn/__fadd_rn are plain operators), which would change
+// the rounding with respect to decimate.c built for x86-64: switch contraction off for this translation unit.
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+__device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+
+constexpr int kMaxFuse = 3;       // stages per kernel
+constexpr int kTileOut = 512;     // outputs of a fused group per workgroup
+constexpr int kThreads = 256;
+
+struct GroupArgs {
+  const float2 *in;    // n_in = n_out << nstages complex samples
+  const float2 *hist;  // the `halo` samples preceding in[0]
+  float2 *out;         // n_out complex samples (scaled by `scale` when final)
+  int16_t *out16;      // final group only, may be null: interleaved I,Q int16
+  float *partial;      // final group only: per-workgroup energy
+  long long n_out;
+  int nstages;
+  unsigned hb15_mask;  // bit s set: stage s of this group is the 15-tap filter, else 1-2-1
+  int halo;            // input history needed by output 0
+  int rot_step;        // Fs/4 rotation (first group only): phase(i) = (rot_phase0 + i*rot_step) & 3
+  int rot_phase0;
+  int rotate;
+  int final;
+  float scale;
+  float c0, c1, c2, c3;
+};
+
+__device__ __forceinline__ float2 rot90(float2 v, int phase) {
+  // hackrf.c:272-289: multiply by j^phase (exact sign/swap)
+  switch (phase & 3) {
+    default:
+    case 0: return v;
+    case 1: return make_float2(-v.y, v.x);
+    case 2: return make_float2(-v.x, -v.y);
+    case 3: return make_float2(v.y, -v.x);
+  }
+}
+
+__device__ __forceinline__ float hb15_tap(float acc, float a, float b, float c) {
+  // decimate.c:128: result += (odd[i] + old_odd[i]) * coeffs[i], unfused
+  return add_rn(acc, mul_rn(add_rn(a, b), c));
+}
+
+// A level lives in LDS de-interleaved: local sample i is plane[i & 1][i >> 1] (local index 0 = first history sample).
+// Both filters then read with unit stride across lanes: output k of the 15-tap filter needs the odd-plane samples
+// k..k+7 and the even-plane sample k+4, the 1-2-1 filter even k, odd k, even k+1.  A thread produces the output pair
+// (2p, 2p+1), which shares 7 of its 8 odd taps and lands on element p of each plane of the next level.
+struct Level {
+  float2 *even, *odd;
+};
+
+template <class Emit>
+__device__ __forceinline__ void stage_hb15(Level src, int n_prod, const GroupArgs &a, Emit emit) {
+  for (int p = threadIdx.x; 2 * p < n_prod; p += kThreads) {
+    float2 o[10], e[2];
+    const float4 *o4 = reinterpret_cast<const float4 *>(src.odd + 2 * p);
+#pragma unroll
+    for (int m = 0; m < 5; m++) {
+      float4 const t = o4[m];
+      o[2 * m] = make_float2(t.x, t.y);
+      o[2 * m + 1] = make_float2(t.z, t.w);
+    }
+    {
+      float4 const t = *reinterpret_cast<const float4 *>(src.even + 2 * p + 4);
+      e[0] = make_float2(t.x, t.y);
+      e[1] = make_float2(t.z, t.w);
+    }
+    float2 r[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      // output k = 2p+j: o[k-i] is o[j+7-i], o[k-7+i] is o[j+i]
+      r[j] = e[j];
+      r[j].x = hb15_tap(r[j].x, o[j + 7].x, o[j].x, a.c0);
+      r[j].y = hb15_tap(r[j].y, o[j + 7].y, o[j].y, a.c0);
+      r[j].x = hb15_tap(r[j].x, o[j + 6].x, o[j + 1].x, a.c1);
+      r[j].y = hb15_tap(r[j].y, o[j + 6].y, o[j + 1].y, a.c1);
+      r[j].x = hb15_tap(r[j].x, o[j + 5].x, o[j + 2].x, a.c2);
+      r[j].y = hb15_tap(r[j].y, o[j + 5].y, o[j + 2].y, a.c2);
+      r[j].x = hb15_tap(r[j].x, o[j + 4].x, o[j + 3].x, a.c3);
+      r[j].y = hb15_tap(r[j].y, o[j + 4].y, o[j + 3].y, a.c3);
+    }
+    emit(p, r[0], r[1]);
+  }
+}
+
+template <class Emit>
+__device__ __forceinline__ void stage_hb3(Level src, int n_prod, Emit emit) {
+  for (int p = threadIdx.x; 2 * p < n_prod; p += kThreads) {
+    // decimate.c:155: 2*in[2k] + in[2k+1] + in[2k-1]; in[2k-1] is local sample 2k
+    float2 const e0 = src.even[2 * p], o0 = src.odd[2 * p], e1 = src.even[2 * p + 1], o1 = src.odd[2 * p + 1],
+                 e2 = src.even[2 * p + 2];
+    float2 r0, r1;
+    r0.x = add_rn(add_rn(mul_rn(2.f, o0.x), e1.x), e0.x);
+    r0.y = add_rn(add_rn(mul_rn(2.f, o0.y), e1.y), e0.y);
+    r1.x = add_rn(add_rn(mul_rn(2.f, o1.x), e2.x), e1.x);
+    r1.y = add_rn(add_rn(mul_rn(2.f, o1.y), e2.y), e1.y);
+    emit(p, r0, r1);
+  }
+}
+
+// plane capacity (float2 elements, multiple of 2 so that every plane stays 16-byte aligned) for a level of n samples;
+// the slack covers the over-read of the last output pair
+__host__ __device__ constexpr int plane_cap(int n) { return ((n + 1) / 2 + 12) & ~1; }
+
+__global__ __launch_bounds__(kThreads) void k_hb_group(GroupArgs a) {
+  extern __shared__ float4 lds4[];
+  float2 *lds = reinterpret_cast<float2 *>(lds4);
+  int const G = a.nstages;
+  // halo_s: history (in level-s samples) that level s must hold ahead of this workgroup's first output
+  int halo[kMaxFuse + 1], len[kMaxFuse + 1];
+  halo[G] = 0;
+  long long const first_out = (long long)blockIdx.x * kTileOut;
+  int const tile = (int)min((long long)kTileOut, a.n_out - first_out);
+  for (int s = G - 1; s >= 0; s--) halo[s] = 2 * halo[s + 1] + ((a.hb15_mask >> s) & 1 ? 14 : 1);
+  for (int s = 0; s <= G; s++) len[s] = (tile << (G - s)) + halo[s];
+
+  int const cap0 = plane_cap((kTileOut << G) + halo[0]);
+  int const cap1 = plane_cap((kTileOut << (G - 1)) + halo[1]);
+  Level lvA{lds, lds + cap0};                        // level 0 (and level 2)
+  Level lvB{lds + 2 * cap0, lds + 2 * cap0 + cap1};  // level 1
+
+  // load level 0: global input index = first_out * 2^G - halo[0] + i.  All loads of a thread are issued before the
+  // first LDS write (fixed trip count, clamped index, pointer select instead of a branch) so that a wave keeps
+  // kLoadIters x 512 B in flight.
+  long long const lo0 = (first_out << G) - halo[0];
+  constexpr int kLoadIters = ((kTileOut << kMaxFuse) + 14 * ((1 << kMaxFuse) - 1) + kThreads - 1) / kThreads;
+  float2 v[kLoadIters];
+#pragma unroll
+  for (int it = 0; it < kLoadIters; it++) {
+    int const i = min(it * kThreads + (int)threadIdx.x, len[0] - 1);
+    long long const gi = lo0 + i;
+    const float2 *src = gi >= 0 ? a.in + gi : a.hist + (a.halo + gi);
+    v[it] = *src;
+  }
+#pragma unroll
+  for (int it = 0; it < kLoadIters; it++) {
+    int const i = it * kThreads + (int)threadIdx.x;
+    if (i < len[0]) {
+      long long const gi = lo0 + i;
+      float2 w = v[it];
+      if (a.rotate) w = rot90(w, a.rot_phase0 + (int)(gi & 3) * a.rot_step);
+      (i & 1 ? lvA.odd : lvA.even)[i >> 1] = w;
+    }
+  }
+  __syncthreads();
+
+  float energy = 0.f;
+  Level src = lvA, dst = lvB;
+  for (int s = 0; s < G; s++) {
+    bool const last = s == G - 1;
+    bool const is15 = (a.hb15_mask >> s) & 1;
+    int const n_prod = len[s + 1];
+    auto emit = [&](int p, float2 r0, float2 r1) {
+      if (!last) {
+        dst.even[p] = r0;  // the element past an odd n_prod is slack
+        dst.odd[p] = r1;
+        return;
+      }
+      long long const go = first_out + 2 * p;
+      bool const two = 2 * p + 1 < n_prod;
+      if (a.final) {
+        // hackrf.c:307-311: s = sample * Filter_atten; energy += s*s; (short)round(32767 * s)
+        r0.x = mul_rn(r0.x, a.scale);
+        r0.y = mul_rn(r0.y, a.scale);
+        r1.x = mul_rn(r1.x, a.scale);
+        r1.y = mul_rn(r1.y, a.scale);
+        energy = add_rn(energy, add_rn(mul_rn(r0.x, r0.x), mul_rn(r0.y, r0.y)));
+        if (two) energy = add_rn(energy, add_rn(mul_rn(r1.x, r1.x), mul_rn(r1.y, r1.y)));
+        if (a.out16) {
+          short4 q;
+          q.x = (int16_t)(int)roundf(mul_rn(32767.f, r0.x));
+          q.y = (int16_t)(int)roundf(mul_rn(32767.f, r0.y));
+          q.z = (int16_t)(int)roundf(mul_rn(32767.f, r1.x));
+          q.w = (int16_t)(int)roundf(mul_rn(32767.f, r1.y));
+          if (two)
+            *reinterpret_cast<short4 *>(a.out16 + 2 * go) = q;
+          else
+            *reinterpret_cast<short2 *>(a.out16 + 2 * go) = make_short2(q.x, q.y);
+        }
+      }
+      if (two)
+        *reinterpret_cast<float4 *>(a.out + go) = make_float4(r0.x, r0.y, r1.x, r1.y);
+      else
+        a.out[go] = r0;
+    };
+    if (is15)
+      stage_hb15(src, n_prod, a, emit);
+    else
+      stage_hb3(src, n_prod, emit);
+    __syncthreads();
+    Level const t = src;
+    src = dst;
+    dst = t;
+  }
+
+  if (a.final && a.partial) {
+    // fixed-order reduction: lanes by xor-shuffle, then waves in order
+    __shared__ float wsum[kThreads / 64];
+    for (int off = 32; off; off >>= 1) energy += __shfl_xor(energy, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = energy;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0;
+      for (int w = 0; w < kThreads / 64; w++) t += wsum[w];
+      a.partial[blockIdx.x] = t;
+    }
+  }
+}
+
+// new_hist[i] = sample (n_in - halo + i) of the stream hist ++ in
+__global__ void k_hb_history(const float2 *in, const float2 *hist, float2 *new_hist, long long n_in, int halo) {
+  int const i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= halo) return;
+  long long const gi = n_in - halo + i;
+  new_hist[i] = gi >= 0 ? in[gi] : hist[halo + gi];
+}
+
+__global__ void k_hb_energy(const float *partial, int n, float *out) {
+  // one wave, fixed order
+  double t = 0;
+  for (int i = threadIdx.x; i < n; i += 64) t += partial[i];
+  for (int off = 32; off; off >>= 1) t += __shfl_xor(t, off);
+  if (threadIdx.x == 0) *out = (float)t;
+}
+
+struct Group {
+  int nstages = 0;
+  unsigned mask = 0;
+  int halo = 0;
+  int shift_in = 0;  // log2(input rate / final output rate)
+  float2 *hist[2] = {nullptr, nullptr};
+  float2 *out = nullptr;  // intermediate buffer (null for the last group)
+};
+
+}  // namespace
+
+struct kq_decimator {
+  kq_decim_config cfg;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::vector<Group> groups;
+  int cur = 0;  // which hist buffer is live
+  int rot_phase = 0;
+  float atten = 1;
+  float coeffs[4];
+  float2 *in_dev = nullptr;   // staging for host-resident input
+  float2 *out_dev = nullptr;  // staging for host-resident output
+  int16_t *out16_dev = nullptr;
+  float *partial = nullptr;
+  float *energy_dev = nullptr;
+  size_t n_partial = 0;
+};
+
+void kq_internal_set_error(const char *fmt, ...);
+
+#define DEC_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      kq_internal_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return -1;                                                                              \
+    }                                                                                         \
+  } while (0)
+
+static int decim_alloc(kq_decimator *d) {
+  kq_decim_config const &c = d->cfg;
+  DEC_TRY(hipSetDevice(c.device));
+  if (c.stream)
+    d->stream = (hipStream_t)c.stream;
+  else {
+    DEC_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    d->own_stream = true;
+  }
+  // stages in processing order: j = log_decimate-1 .. 0, 1-2-1 while j >= stage_threshold (hackrf.c:297-300)
+  int const S = c.log_decimate;
+  int done = 0;
+  while (done < S) {
+    Group g;
+    g.nstages = std::min(kMaxFuse, S - done);
+    g.shift_in = S - done;
+    for (int s = 0; s < g.nstages; s++) {
+      int const j = S - 1 - (done + s);
+      if (j < c.stage_threshold) g.mask |= 1u << s;
+    }
+    int need = 0;
+    for (int s = g.nstages - 1; s >= 0; s--) need = 2 * need + ((g.mask >> s) & 1 ? 14 : 1);
+    g.halo = need;
+    done += g.nstages;
+    for (int k = 0; k < 2; k++) {
+      DEC_TRY(hipMalloc(&g.hist[k], sizeof(float2) * need));
+      DEC_TRY(hipMemsetAsync(g.hist[k], 0, sizeof(float2) * need, d->stream));
+    }
+    if (done < S) DEC_TRY(hipMalloc(&g.out, sizeof(float2) * (c.max_out << (S - done))));
+    d->groups.push_back(g);
+  }
+  d->n_partial = (c.max_out + kTileOut - 1) / kTileOut;
+  DEC_TRY(hipMalloc(&d->partial, sizeof(float) * d->n_partial));
+  DEC_TRY(hipMalloc(&d->energy_dev, sizeof(float)));
+  DEC_TRY(hipStreamSynchronize(d->stream));
+  return 0;
+}
+
+extern "C" {
+
+kq_decimator *kq_decim_create(const kq_decim_config *cfg) {
+  if (!cfg || cfg->log_decimate < 1 || cfg->log_decimate > 16 || cfg->max_out == 0) {
+    kq_internal_set_error("kq_decim_create: log_decimate must be 1..16 and max_out > 0");
+    return nullptr;
+  }
+  kq_decimator *d = new kq_decimator;
+  d->cfg = *cfg;
+  d->atten = cfg->filter_atten != 0 ? cfg->filter_atten : powf(.5f, (float)cfg->log_decimate);  // hackrf.c:469
+  // hackrf.c:229-238 -- [3] is next to the centre tap, [0] on the tails
+  d->coeffs[3] = 490. / 802;
+  d->coeffs[2] = -116. / 802;
+  d->coeffs[1] = 33. / 802;
+  d->coeffs[0] = -6. / 802;
+  if (decim_alloc(d) != 0) {
+    kq_decim_destroy(d);
+    return nullptr;
+  }
+  return d;
+}
+
+int kq_decim_destroy(kq_decimator *d) {
+  if (!d) return -1;
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
+  for (Group &g : d->groups) {
+    (void)hipFree(g.hist[0]);
+    (void)hipFree(g.hist[1]);
+    (void)hipFree(g.out);
+  }
+  (void)hipFree(d->in_dev);
+  (void)hipFree(d->out_dev);
+  (void)hipFree(d->out16_dev);
+  (void)hipFree(d->partial);
+  (void)hipFree(d->energy_dev);
+  if (d->own_stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+  return 0;
+}
+
+int kq_decim_set_coeffs(kq_decimator *d, const float coeffs[4]) {
+  if (!d || !coeffs) return -1;
+  for (int i = 0; i < 4; i++) d->coeffs[i] = coeffs[i];
+  return 0;
+}
+
+int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t n_out, float *out_cf32,
+                     int16_t *out_s16, float *out_energy) {
+  if (!d || !iq_in || !out_cf32) {
+    kq_internal_set_error("kq_decim_process: null argument");
+    return -1;
+  }
+  if (n_out == 0) return 0;
+  if (n_out > d->cfg.max_out) {
+    kq_internal_set_error("kq_decim_process: n_out %zu exceeds max_out %zu", n_out, d->cfg.max_out);
+    return -1;
+  }
+  int const S = d->cfg.log_decimate;
+  size_t const n_in = n_out << S;
+  const float2 *src = (const float2 *)iq_in;
+  float2 *final_out = (float2 *)out_cf32;
+  int16_t *final16 = out_s16;
+  if (!on_device) {
+    if (!d->in_dev) {
+      DEC_TRY(hipMalloc(&d->in_dev, sizeof(float2) * (d->cfg.max_out << S)));
+      DEC_TRY(hipMalloc(&d->out_dev, sizeof(float2) * d->cfg.max_out));
+      DEC_TRY(hipMalloc(&d->out16_dev, sizeof(int16_t) * 2 * d->cfg.max_out));
+    }
+    DEC_TRY(hipMemcpyAsync(d->in_dev, iq_in, sizeof(float2) * n_in, hipMemcpyHostToDevice, d->stream));
+    src = d->in_dev;
+    final_out = d->out_dev;
+    final16 = out_s16 ? d->out16_dev : nullptr;
+  }
+  int const cur = d->cur, nxt = cur ^ 1;
+  size_t n_g_in = n_in;
+  for (size_t gi = 0; gi < d->groups.size(); gi++) {
+    Group &g = d->groups[gi];
+    bool const last = gi + 1 == d->groups.size();
+    GroupArgs a{};
+    a.in = src;
+    a.hist = g.hist[cur];
+    a.out = last ? final_out : g.out;
+    a.out16 = last ? final16 : nullptr;
+    a.partial = last ? d->partial : nullptr;
+    a.n_out = (long long)(n_g_in >> g.nstages);
+    a.nstages = g.nstages;
+    a.hb15_mask = g.mask;
+    a.halo = g.halo;
+    a.rotate = gi == 0 && (d->cfg.offset & 3) != 0;
+    a.rot_step = d->cfg.offset & 3;
+    a.rot_phase0 = d->rot_phase;
+    a.final = last;
+    a.scale = d->atten;
+    a.c0 = d->coeffs[0];
+    a.c1 = d->coeffs[1];
+    a.c2 = d->coeffs[2];
+    a.c3 = d->coeffs[3];
+    unsigned const grid = (unsigned)((a.n_out + kTileOut - 1) / kTileOut);
+    // two planes each for level 0 and level 1
+    int const h1 = (g.halo - ((g.mask & 1) ? 14 : 1)) / 2;
+    size_t const lds_elems = 2 * (size_t)plane_cap((kTileOut << g.nstages) + g.halo) +
+                             2 * (size_t)plane_cap((kTileOut << (g.nstages - 1)) + h1);
+    hipLaunchKernelGGL(k_hb_group, dim3(grid), dim3(kThreads), sizeof(float2) * lds_elems, d->stream, a);
+    hipLaunchKernelGGL(k_hb_history, dim3((g.halo + 127) / 128), dim3(128), 0, d->stream, src, g.hist[cur], g.hist[nxt],
+                       (long long)n_g_in, g.halo);
+    src = g.out;
+    n_g_in >>= g.nstages;
+  }
+  DEC_TRY(hipGetLastError());
+  d->cur = nxt;
+  d->rot_phase = (int)((d->rot_phase + (long long)(n_in & 3) * (d->cfg.offset & 3)) & 3);
+  if (out_energy) {
+    unsigned const np = (unsigned)((n_out + kTileOut - 1) / kTileOut);
+    hipLaunchKernelGGL(k_hb_energy, dim3(1), dim3(64), 0, d->stream, d->partial, (int)np, d->energy_dev);
+    if (on_device)
+      DEC_TRY(hipMemcpyAsync(out_energy, d->energy_dev, sizeof(float), hipMemcpyDeviceToDevice, d->stream));
+    else
+      DEC_TRY(hipMemcpyAsync(out_energy, d->energy_dev, sizeof(float), hipMemcpyDeviceToHost, d->stream));
+  }
+  if (!on_device) {
+    DEC_TRY(hipMemcpyAsync(out_cf32, d->out_dev, sizeof(float2) * n_out, hipMemcpyDeviceToHost, d->stream));
+    if (out_s16)
+      DEC_TRY(hipMemcpyAsync(out_s16, d->out16_dev, sizeof(int16_t) * 2 * n_out, hipMemcpyDeviceToHost, d->stream));
+    DEC_TRY(hipStreamSynchronize(d->stream));
+  }
+  return 0;
+}
+
+int kq_decim_sync(kq_decimator *d) {
+  if (!d) return -1;
+  DEC_TRY(hipStreamSynchronize(d->stream));
+  return 0;
+}
+
+int kq_decim_reset(kq_decimator *d) {
+  if (!d) return -1;
+  for (Group &g : d->groups)
+    for (int k = 0; k < 2; k++) DEC_TRY(hipMemsetAsync(g.hist[k], 0, sizeof(float2) * g.halo, d->stream));
+  d->rot_phase = 0;
+  return 0;
+}
+
+}  // extern "C"

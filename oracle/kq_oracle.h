@@ -162,6 +162,17 @@ float kqo_chan_noise_gain(const kqo_chan *c);
 const float complex *kqo_chan_response(const kqo_chan *c, unsigned *n);
 const float complex *kqo_chan_audio_response(const kqo_chan *c, unsigned *n);
 
+/* Half-band decimators of the front-end daemons (decimate.c:108-160, decimate.h:4-9) */
+typedef struct {
+  float coeffs[4];
+  float even_samples[4];
+  float odd_samples[4];
+  float old_odd_samples[4];
+} kqo_hb15_state;
+void kqo_hb15_init(kqo_hb15_state *st);
+void kqo_hb15_block(kqo_hb15_state *st, float *output, const float *input, int cnt);
+void kqo_hb3_block(float *state, float *output, const float *input, int cnt);
+
 /* PCM output stage (audio.c:22-28, 45-50, 95-100): float -> clipped int16, network byte order, in chunks of at
  * most 480 words; bit i of *silent_mask is set when chunk i is all zero (the reference then skips the packet but
  * still advances the RTP timestamp).  Returns the number of chunks. */

@@ -64,12 +64,14 @@ class _Cplx(C.Structure):
 def build(force=False):
     """Compile the oracle (and oracle/_ref when /root/reference is present)."""
     so = os.path.join(_HERE, "libkq_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("kq_fft.c", "kq_osc.c", "kq_filter.c", "kq_chan.c", "kq_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("kq_fft.c", "kq_osc.c", "kq_filter.c", "kq_chan.c", "kq_decimate.c",
+                                             "kq_oracle.h")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "libkq_oracle.so"], stdout=subprocess.DEVNULL)
     ref_so = os.path.join(_HERE, "_ref", "libref_osc.so")
-    if os.path.exists("/root/reference/osc.c") and (force or not os.path.exists(ref_so)):
+    ref_dec = os.path.join(_HERE, "_ref", "libref_decimate.so")
+    if os.path.exists("/root/reference/osc.c") and (force or not os.path.exists(ref_so) or not os.path.exists(ref_dec)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return so
 
@@ -122,6 +124,9 @@ def lib():
     L.kqo_delete_filter_input.argtypes = [C.c_void_p]
     L.kqo_delete_filter_output.argtypes = [C.c_void_p]
     L.kqo_set_filter.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    L.kqo_hb15_init.argtypes = [C.POINTER(Hb15State)]
+    L.kqo_hb15_block.argtypes = [C.POINTER(Hb15State), fp, fp, C.c_int]
+    L.kqo_hb3_block.argtypes = [fp, fp, fp, C.c_int]
     L.kqo_pcm_block.argtypes = [fp, C.c_int, C.POINTER(C.c_int16), C.POINTER(C.c_uint32)]
     L.kqo_pcm_block.restype = C.c_int
     L.kqo_bench_channels.restype = C.c_double
@@ -278,6 +283,80 @@ def make_kaiser(M, beta):
 def compute_n0(spec, samprate, low, high):
     spec = np.ascontiguousarray(spec, np.complex64)
     return lib().kqo_compute_n0(spec.ctypes.data, len(spec), samprate, low, high)
+
+
+class Hb15State(C.Structure):
+    """struct hb15_state (decimate.h:4-9) == kqo_hb15_state"""
+    _fields_ = [("coeffs", C.c_float * 4), ("even_samples", C.c_float * 4), ("odd_samples", C.c_float * 4),
+                ("old_odd_samples", C.c_float * 4)]
+
+
+def ref_decimate_lib():
+    """The reference's own decimate.c (oracle/_ref/libref_decimate.so); None if not built."""
+    build()
+    so = os.path.join(_HERE, "_ref", "libref_decimate.so")
+    if not os.path.exists(so):
+        return None
+    R = C.CDLL(so)
+    fp = C.POINTER(C.c_float)
+    R.hb15_block.argtypes = [C.POINTER(Hb15State), fp, fp, C.c_int]
+    R.hb3_block.argtypes = [fp, fp, fp, C.c_int]
+    return R
+
+
+def halfband_cascade(x, log_decimate, stage_threshold, states=None, use_ref=False):
+    """hackrf.c:295-300 on one real channel: stages j = log_decimate-1 .. stage_threshold use hb3, the rest hb15.
+    x: float32[n * 2**log_decimate] -> float32[n].  states = (hb15 list, hb3 array) carried across calls."""
+    L = ref_decimate_lib() if use_ref else lib()
+    fp = C.POINTER(C.c_float)
+    if states is None:
+        h15 = [Hb15State() for _ in range(log_decimate)]
+        for h in h15:
+            lib().kqo_hb15_init(C.byref(h))
+        states = (h15, np.zeros(log_decimate, np.float32))
+    h15, h3 = states
+    work = np.ascontiguousarray(x, np.float32).copy()
+    n_out = len(work) >> log_decimate
+    for j in range(log_decimate - 1, -1, -1):
+        cnt = (1 << j) * n_out
+        out = np.zeros(cnt, np.float32)
+        if j >= stage_threshold:
+            st = h3[j:j + 1]
+            (L.hb3_block if use_ref else L.kqo_hb3_block)(st.ctypes.data_as(fp), out.ctypes.data_as(fp), work.ctypes.data_as(fp), cnt)
+        else:
+            (L.hb15_block if use_ref else L.kqo_hb15_block)(C.byref(h15[j]), out.ctypes.data_as(fp), work.ctypes.data_as(fp), cnt)
+        work = out
+    return work, states
+
+
+class FrontEndDecimator:
+    """hackrf.c:260-330 for one stream: Fs/4 rotation, half-band cascade on I and Q, Filter_atten, int16, energy."""
+
+    def __init__(self, log_decimate, stage_threshold=8, offset=1, filter_atten=None, use_ref=False):
+        self.log, self.thr, self.offset, self.use_ref = log_decimate, stage_threshold, offset, use_ref
+        self.atten = np.float32(filter_atten if filter_atten else np.float32(0.5) ** np.float32(log_decimate))
+        self.phase = 0
+        self.st = [None, None]
+
+    def process(self, iq):
+        iq = np.asarray(iq, np.complex64)
+        n = len(iq)
+        ph = (self.phase + np.arange(n) * self.offset) & 3
+        self.phase = int((self.phase + n * self.offset) & 3)
+        re, im = iq.real.copy(), iq.imag.copy()
+        # hackrf.c:272-289
+        wr = np.select([ph == 0, ph == 1, ph == 2, ph == 3], [re, -im, -re, im]).astype(np.float32)
+        wi = np.select([ph == 0, ph == 1, ph == 2, ph == 3], [im, re, -im, -re]).astype(np.float32)
+        outs = []
+        for k, w in enumerate((wr, wi)):
+            y, self.st[k] = halfband_cascade(w, self.log, self.thr, self.st[k], self.use_ref)
+            outs.append((y * self.atten).astype(np.float32))
+        energy = np.float32(0)
+        for y in outs:  # hackrf.c:308,325 accumulate real block then imaginary block, in float
+            energy = np.float32(energy + np.sum((y * y).astype(np.float32), dtype=np.float64))
+        v = [np.float32(32767) * y for y in outs]
+        s16 = [(np.sign(t) * np.floor(np.abs(t.astype(np.float64)) + 0.5)).astype(np.int64).astype(np.int16) for t in v]
+        return (outs[0] + 1j * outs[1]).astype(np.complex64), np.stack(s16, axis=1), float(energy)
 
 
 def pcm_block(audio):

@@ -12,9 +12,11 @@
 // keeps the reference's operand order with FMA contraction switched off, so the
 // result is bit-identical to a scalar C evaluation of decimate.c.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <type_traits>
 #include <vector>
 
 #include "ka9q_hip.h"
@@ -52,14 +54,12 @@ struct GroupArgs {
 };
 
 __device__ __forceinline__ float2 rot90(float2 v, int phase) {
-  // hackrf.c:272-289: multiply by j^phase (exact sign/swap)
-  switch (phase & 3) {
-    default:
-    case 0: return v;
-    case 1: return make_float2(-v.y, v.x);
-    case 2: return make_float2(-v.x, -v.y);
-    case 3: return make_float2(v.y, -v.x);
-  }
+  // hackrf.c:272-289: multiply by j^phase -- an exact swap and sign flip, done without branches
+  bool const sw = phase & 1;
+  unsigned const ax = __float_as_uint(sw ? v.y : v.x), ay = __float_as_uint(sw ? v.x : v.y);
+  unsigned const negx = ((phase + 1) & 2) << 30;  // phases 1, 2
+  unsigned const negy = (phase & 2) << 30;        // phases 2, 3
+  return make_float2(__uint_as_float(ax ^ negx), __uint_as_float(ay ^ negy));
 }
 
 __device__ __forceinline__ float hb15_tap(float acc, float a, float b, float c) {
@@ -75,52 +75,80 @@ struct Level {
   float2 *even, *odd;
 };
 
-template <class Emit>
-__device__ __forceinline__ void stage_hb15(Level src, int n_prod, const GroupArgs &a, Emit emit) {
-  for (int p = threadIdx.x; 2 * p < n_prod; p += kThreads) {
-    float2 o[10], e[2];
-    const float4 *o4 = reinterpret_cast<const float4 *>(src.odd + 2 * p);
+struct Taps15 {
+  float4 o[5], e;
+};
+struct Taps3 {
+  float2 e0, o0, e1, o1, e2;
+};
+
+__device__ __forceinline__ Taps15 read15(Level src, int p) {
+  Taps15 t;
+  const float4 *o4 = reinterpret_cast<const float4 *>(src.odd + 2 * p);
 #pragma unroll
-    for (int m = 0; m < 5; m++) {
-      float4 const t = o4[m];
-      o[2 * m] = make_float2(t.x, t.y);
-      o[2 * m + 1] = make_float2(t.z, t.w);
-    }
-    {
-      float4 const t = *reinterpret_cast<const float4 *>(src.even + 2 * p + 4);
-      e[0] = make_float2(t.x, t.y);
-      e[1] = make_float2(t.z, t.w);
-    }
-    float2 r[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      // output k = 2p+j: o[k-i] is o[j+7-i], o[k-7+i] is o[j+i]
-      r[j] = e[j];
-      r[j].x = hb15_tap(r[j].x, o[j + 7].x, o[j].x, a.c0);
-      r[j].y = hb15_tap(r[j].y, o[j + 7].y, o[j].y, a.c0);
-      r[j].x = hb15_tap(r[j].x, o[j + 6].x, o[j + 1].x, a.c1);
-      r[j].y = hb15_tap(r[j].y, o[j + 6].y, o[j + 1].y, a.c1);
-      r[j].x = hb15_tap(r[j].x, o[j + 5].x, o[j + 2].x, a.c2);
-      r[j].y = hb15_tap(r[j].y, o[j + 5].y, o[j + 2].y, a.c2);
-      r[j].x = hb15_tap(r[j].x, o[j + 4].x, o[j + 3].x, a.c3);
-      r[j].y = hb15_tap(r[j].y, o[j + 4].y, o[j + 3].y, a.c3);
-    }
-    emit(p, r[0], r[1]);
-  }
+  for (int m = 0; m < 5; m++) t.o[m] = o4[m];
+  t.e = *reinterpret_cast<const float4 *>(src.even + 2 * p + 4);
+  return t;
 }
 
-template <class Emit>
-__device__ __forceinline__ void stage_hb3(Level src, int n_prod, Emit emit) {
-  for (int p = threadIdx.x; 2 * p < n_prod; p += kThreads) {
-    // decimate.c:155: 2*in[2k] + in[2k+1] + in[2k-1]; in[2k-1] is local sample 2k
-    float2 const e0 = src.even[2 * p], o0 = src.odd[2 * p], e1 = src.even[2 * p + 1], o1 = src.odd[2 * p + 1],
-                 e2 = src.even[2 * p + 2];
-    float2 r0, r1;
-    r0.x = add_rn(add_rn(mul_rn(2.f, o0.x), e1.x), e0.x);
-    r0.y = add_rn(add_rn(mul_rn(2.f, o0.y), e1.y), e0.y);
-    r1.x = add_rn(add_rn(mul_rn(2.f, o1.x), e2.x), e1.x);
-    r1.y = add_rn(add_rn(mul_rn(2.f, o1.y), e2.y), e1.y);
+__device__ __forceinline__ void filter15(const Taps15 &t, const GroupArgs &a, float2 &r0, float2 &r1) {
+  float2 o[10];
+#pragma unroll
+  for (int m = 0; m < 5; m++) {
+    o[2 * m] = make_float2(t.o[m].x, t.o[m].y);
+    o[2 * m + 1] = make_float2(t.o[m].z, t.o[m].w);
+  }
+  float2 r[2] = {make_float2(t.e.x, t.e.y), make_float2(t.e.z, t.e.w)};
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    // output k = 2p+j: o[k-i] is o[j+7-i], o[k-7+i] is o[j+i]
+    r[j].x = hb15_tap(r[j].x, o[j + 7].x, o[j].x, a.c0);
+    r[j].y = hb15_tap(r[j].y, o[j + 7].y, o[j].y, a.c0);
+    r[j].x = hb15_tap(r[j].x, o[j + 6].x, o[j + 1].x, a.c1);
+    r[j].y = hb15_tap(r[j].y, o[j + 6].y, o[j + 1].y, a.c1);
+    r[j].x = hb15_tap(r[j].x, o[j + 5].x, o[j + 2].x, a.c2);
+    r[j].y = hb15_tap(r[j].y, o[j + 5].y, o[j + 2].y, a.c2);
+    r[j].x = hb15_tap(r[j].x, o[j + 4].x, o[j + 3].x, a.c3);
+    r[j].y = hb15_tap(r[j].y, o[j + 4].y, o[j + 3].y, a.c3);
+  }
+  r0 = r[0];
+  r1 = r[1];
+}
+
+__device__ __forceinline__ Taps3 read3(Level src, int p) {
+  return Taps3{src.even[2 * p], src.odd[2 * p], src.even[2 * p + 1], src.odd[2 * p + 1], src.even[2 * p + 2]};
+}
+
+__device__ __forceinline__ void filter3(const Taps3 &t, float2 &r0, float2 &r1) {
+  // decimate.c:155: 2*in[2k] + in[2k+1] + in[2k-1]; in[2k-1] is local sample 2k
+  r0.x = add_rn(add_rn(mul_rn(2.f, t.o0.x), t.e1.x), t.e0.x);
+  r0.y = add_rn(add_rn(mul_rn(2.f, t.o0.y), t.e1.y), t.e0.y);
+  r1.x = add_rn(add_rn(mul_rn(2.f, t.o1.x), t.e2.x), t.e1.x);
+  r1.y = add_rn(add_rn(mul_rn(2.f, t.o1.y), t.e2.y), t.e1.y);
+}
+
+// One stage: every thread takes output pairs p, p + kThreads, ... two at a time, reading the taps of both before
+// filtering either so that the second LDS round trip hides behind the arithmetic of the first.
+template <bool HB15, class Emit>
+__device__ __forceinline__ void run_stage(Level src, int n_prod, const GroupArgs &a, Emit emit) {
+  int const npairs = (n_prod + 1) >> 1;
+  for (int p = threadIdx.x; p < npairs; p += 2 * kThreads) {
+    int const p2 = p + kThreads;
+    bool const has2 = p2 < npairs;
+    float2 r0, r1, q0, q1;
+    if constexpr (HB15) {
+      Taps15 const ta = read15(src, p);
+      Taps15 const tb = read15(src, has2 ? p2 : p);
+      filter15(ta, a, r0, r1);
+      filter15(tb, a, q0, q1);
+    } else {
+      Taps3 const ta = read3(src, p);
+      Taps3 const tb = read3(src, has2 ? p2 : p);
+      filter3(ta, r0, r1);
+      filter3(tb, q0, q1);
+    }
     emit(p, r0, r1);
+    if (has2) emit(p2, q0, q1);
   }
 }
 
@@ -128,108 +156,212 @@ __device__ __forceinline__ void stage_hb3(Level src, int n_prod, Emit emit) {
 // the slack covers the over-read of the last output pair
 __host__ __device__ constexpr int plane_cap(int n) { return ((n + 1) / 2 + 12) & ~1; }
 
+template <int N>
+using ic = std::integral_constant<int, N>;
+
+// Persistent workgroups: each walks tiles blockIdx.x, +gridDim.x, ... and issues the global loads of its next tile
+// (held in registers) before it starts filtering the current one, so HBM requests stay in flight during the LDS phases.
+// G = stages in this group; FINAL = last group (Filter_atten, int16, energy); PAIR = the group's halo is even, so a
+// thread can load two neighbouring samples (16 bytes) that land on the same element of the two planes; ROT = Fs/4
+// rotation on the way in.
+// EDGE = this workgroup takes the tiles that need care -- the first (history buffer) and a ragged last one -- with
+// clamped indices and a pointer select; the other workgroups share the full tiles in between and need neither.
+template <int G, bool FINAL, bool PAIR, bool ROT, bool EDGE>
+__device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
+  // halo_s: history (in level-s samples) that level s must hold ahead of a tile's first output
+  int halo[G + 1];
+  halo[G] = 0;
+#pragma unroll
+  for (int s = G - 1; s >= 0; s--) halo[s] = 2 * halo[s + 1] + ((a.hb15_mask >> s) & 1 ? 14 : 1);
+
+  int const cap0 = plane_cap((kTileOut << G) + halo[0]);
+  int const cap1 = G > 1 ? plane_cap((kTileOut << (G - 1)) + halo[G > 1 ? 1 : 0]) : 0;
+  Level const lvA{lds, lds + cap0};                        // level 0 (and level 2)
+  Level const lvB{lds + 2 * cap0, lds + 2 * cap0 + cap1};  // level 1
+
+  long long const ntiles = (a.n_out + kTileOut - 1) / kTileOut;
+  constexpr int kMaxLen0 = (kTileOut << G) + 14 * ((1 << G) - 1);
+  constexpr int kPer = PAIR ? 2 : 1;
+  constexpr int kLoadIters = (kMaxLen0 + kPer * kThreads - 1) / (kPer * kThreads);
+  constexpr int kFullIters = (kTileOut << G) / (kPer * kThreads);  // always inside a full tile, whatever the halo
+  using LoadT = std::conditional_t<PAIR, float4, float2>;
+  LoadT v[kLoadIters];
+  int const tid = threadIdx.x;
+
+  // Level 0 of tile t: global input index = t * kTileOut * 2^G - halo[0] + i, i < (tile << G) + halo[0].  All loads of a
+  // thread are issued back to back.
+  auto fetch = [&](long long t) {
+    long long const first_out = t * kTileOut;
+    long long const lo0 = (first_out << G) - halo[0];
+    if constexpr (!EDGE) {
+      int const len0 = (kTileOut << G) + halo[0];
+      const LoadT *src = reinterpret_cast<const LoadT *>(a.in + lo0) + tid;
+#pragma unroll
+      for (int it = 0; it < kLoadIters; it++) {
+        if (it < kFullIters)
+          v[it] = src[it * kThreads];
+        else
+          v[it] = *reinterpret_cast<const LoadT *>(a.in + lo0 + min((it * kThreads + tid) * kPer, len0 - kPer));
+      }
+    } else {
+      int const tile = (int)min((long long)kTileOut, a.n_out - first_out);
+      int const len0 = (tile << G) + halo[0];
+#pragma unroll
+      for (int it = 0; it < kLoadIters; it++) {
+        int const i = min((it * kThreads + tid) * kPer, len0 - kPer);
+        long long const gi = lo0 + i;
+        const float2 *src = gi >= 0 ? a.in + gi : a.hist + (a.halo + gi);
+        v[it] = *reinterpret_cast<const LoadT *>(src);
+      }
+    }
+  };
+
+  // tile walk: the edge workgroup does tile 0 and then the ragged tile (if any); the others stride over 1..nfull-1
+  long long const nfull = a.n_out / kTileOut;
+  long long const first = EDGE ? 0 : (long long)blockIdx.x;  // blockIdx.x >= 1 here
+  long long const step = EDGE ? (nfull > 0 && nfull < ntiles ? nfull : ntiles) : (long long)gridDim.x - 1;
+  long long const end = EDGE ? ntiles : nfull;
+  long long t = first;
+  if (t < end) fetch(t);
+  for (; t < end; t += step) {
+    long long const first_out = t * kTileOut;
+    int const tile = (int)min((long long)kTileOut, a.n_out - first_out);
+    int len[G + 1];
+#pragma unroll
+    for (int s = 0; s <= G; s++) len[s] = (tile << (G - s)) + halo[s];
+    long long const lo0 = (first_out << G) - halo[0];
+    // rotation phase of this thread's first sample; later iterations are a multiple of 4 samples further on
+    int const ph = a.rot_phase0 + (int)((lo0 + tid * kPer) & 3) * a.rot_step;
+    bool const full = !EDGE;
+#pragma unroll
+    for (int it = 0; it < kLoadIters; it++) {
+      int const i = (it * kThreads + tid) * kPer;
+      if ((it < kFullIters && full) || i < len[0]) {
+        if constexpr (PAIR) {
+          float2 w0 = make_float2(v[it].x, v[it].y), w1 = make_float2(v[it].z, v[it].w);
+          if constexpr (ROT) {
+            w0 = rot90(w0, ph);
+            w1 = rot90(w1, ph + a.rot_step);
+          }
+          lvA.even[it * kThreads + tid] = w0;
+          lvA.odd[it * kThreads + tid] = w1;
+        } else {
+          float2 w = v[it];
+          if constexpr (ROT) w = rot90(w, ph);
+          // kThreads is even, so a thread's samples all have the parity of its first one
+          ((tid & 1) ? lvA.odd : lvA.even)[(it * kThreads + tid) >> 1] = w;
+        }
+      }
+    }
+    __syncthreads();
+    if (t + step < end) fetch(t + step);
+
+    float energy = 0.f;
+    auto do_stage = [&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s < G) {
+        constexpr bool last = s == G - 1;
+        Level const src = (s & 1) ? lvB : lvA;
+        Level const dst = (s & 1) ? lvA : lvB;
+        int const n_prod = len[s + 1];
+        auto emit = [&](int p, float2 r0, float2 r1) {
+          if constexpr (!last) {
+            dst.even[p] = r0;  // the element past an odd n_prod is slack
+            dst.odd[p] = r1;
+          } else {
+            long long const go = first_out + 2 * p;
+            bool const two = 2 * p + 1 < n_prod;
+            if constexpr (FINAL) {
+              // hackrf.c:307-311: s = sample * Filter_atten; energy += s*s; (short)round(32767 * s)
+              r0.x = mul_rn(r0.x, a.scale);
+              r0.y = mul_rn(r0.y, a.scale);
+              r1.x = mul_rn(r1.x, a.scale);
+              r1.y = mul_rn(r1.y, a.scale);
+              energy = add_rn(energy, add_rn(mul_rn(r0.x, r0.x), mul_rn(r0.y, r0.y)));
+              if (two) energy = add_rn(energy, add_rn(mul_rn(r1.x, r1.x), mul_rn(r1.y, r1.y)));
+              if (a.out16) {
+                short4 q;
+                q.x = (int16_t)(int)roundf(mul_rn(32767.f, r0.x));
+                q.y = (int16_t)(int)roundf(mul_rn(32767.f, r0.y));
+                q.z = (int16_t)(int)roundf(mul_rn(32767.f, r1.x));
+                q.w = (int16_t)(int)roundf(mul_rn(32767.f, r1.y));
+                if (two)
+                  *reinterpret_cast<short4 *>(a.out16 + 2 * go) = q;
+                else
+                  *reinterpret_cast<short2 *>(a.out16 + 2 * go) = make_short2(q.x, q.y);
+              }
+            }
+            if (two)
+              *reinterpret_cast<float4 *>(a.out + go) = make_float4(r0.x, r0.y, r1.x, r1.y);
+            else
+              a.out[go] = r0;
+          }
+        };
+        if ((a.hb15_mask >> s) & 1)
+          run_stage<true>(src, n_prod, a, emit);
+        else
+          run_stage<false>(src, n_prod, a, emit);
+        __syncthreads();
+      }
+    };
+    do_stage(ic<0>{});
+    do_stage(ic<1>{});
+    do_stage(ic<2>{});
+
+    if constexpr (FINAL) {
+      // fixed-order reduction: lanes by xor-shuffle, then waves in order
+      __shared__ float wsum[kThreads / 64];
+      for (int off = 32; off; off >>= 1) energy += __shfl_xor(energy, off);
+      if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = energy;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float e = 0;
+        for (int w = 0; w < kThreads / 64; w++) e += wsum[w];
+        a.partial[t] = e;
+      }
+    }
+  }
+}
+
+template <int G, bool FINAL, bool PAIR, bool ROT>
 __global__ __launch_bounds__(kThreads) void k_hb_group(GroupArgs a) {
   extern __shared__ float4 lds4[];
   float2 *lds = reinterpret_cast<float2 *>(lds4);
-  int const G = a.nstages;
-  // halo_s: history (in level-s samples) that level s must hold ahead of this workgroup's first output
-  int halo[kMaxFuse + 1], len[kMaxFuse + 1];
-  halo[G] = 0;
-  long long const first_out = (long long)blockIdx.x * kTileOut;
-  int const tile = (int)min((long long)kTileOut, a.n_out - first_out);
-  for (int s = G - 1; s >= 0; s--) halo[s] = 2 * halo[s + 1] + ((a.hb15_mask >> s) & 1 ? 14 : 1);
-  for (int s = 0; s <= G; s++) len[s] = (tile << (G - s)) + halo[s];
+  if (blockIdx.x == 0)
+    hb_group_body<G, FINAL, PAIR, ROT, true>(a, lds);
+  else
+    hb_group_body<G, FINAL, PAIR, ROT, false>(a, lds);
+}
 
-  int const cap0 = plane_cap((kTileOut << G) + halo[0]);
-  int const cap1 = plane_cap((kTileOut << (G - 1)) + halo[1]);
-  Level lvA{lds, lds + cap0};                        // level 0 (and level 2)
-  Level lvB{lds + 2 * cap0, lds + 2 * cap0 + cap1};  // level 1
+template <int G, bool FINAL, bool PAIR>
+void launch_group_r(const GroupArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st) {
+  if (a.rotate)
+    hipLaunchKernelGGL((k_hb_group<G, FINAL, PAIR, true>), dim3(grid), dim3(kThreads), lds_bytes, st, a);
+  else
+    hipLaunchKernelGGL((k_hb_group<G, FINAL, PAIR, false>), dim3(grid), dim3(kThreads), lds_bytes, st, a);
+}
 
-  // load level 0: global input index = first_out * 2^G - halo[0] + i.  All loads of a thread are issued before the
-  // first LDS write (fixed trip count, clamped index, pointer select instead of a branch) so that a wave keeps
-  // kLoadIters x 512 B in flight.
-  long long const lo0 = (first_out << G) - halo[0];
-  constexpr int kLoadIters = ((kTileOut << kMaxFuse) + 14 * ((1 << kMaxFuse) - 1) + kThreads - 1) / kThreads;
-  float2 v[kLoadIters];
-#pragma unroll
-  for (int it = 0; it < kLoadIters; it++) {
-    int const i = min(it * kThreads + (int)threadIdx.x, len[0] - 1);
-    long long const gi = lo0 + i;
-    const float2 *src = gi >= 0 ? a.in + gi : a.hist + (a.halo + gi);
-    v[it] = *src;
-  }
-#pragma unroll
-  for (int it = 0; it < kLoadIters; it++) {
-    int const i = it * kThreads + (int)threadIdx.x;
-    if (i < len[0]) {
-      long long const gi = lo0 + i;
-      float2 w = v[it];
-      if (a.rotate) w = rot90(w, a.rot_phase0 + (int)(gi & 3) * a.rot_step);
-      (i & 1 ? lvA.odd : lvA.even)[i >> 1] = w;
-    }
-  }
-  __syncthreads();
-
-  float energy = 0.f;
-  Level src = lvA, dst = lvB;
-  for (int s = 0; s < G; s++) {
-    bool const last = s == G - 1;
-    bool const is15 = (a.hb15_mask >> s) & 1;
-    int const n_prod = len[s + 1];
-    auto emit = [&](int p, float2 r0, float2 r1) {
-      if (!last) {
-        dst.even[p] = r0;  // the element past an odd n_prod is slack
-        dst.odd[p] = r1;
-        return;
-      }
-      long long const go = first_out + 2 * p;
-      bool const two = 2 * p + 1 < n_prod;
-      if (a.final) {
-        // hackrf.c:307-311: s = sample * Filter_atten; energy += s*s; (short)round(32767 * s)
-        r0.x = mul_rn(r0.x, a.scale);
-        r0.y = mul_rn(r0.y, a.scale);
-        r1.x = mul_rn(r1.x, a.scale);
-        r1.y = mul_rn(r1.y, a.scale);
-        energy = add_rn(energy, add_rn(mul_rn(r0.x, r0.x), mul_rn(r0.y, r0.y)));
-        if (two) energy = add_rn(energy, add_rn(mul_rn(r1.x, r1.x), mul_rn(r1.y, r1.y)));
-        if (a.out16) {
-          short4 q;
-          q.x = (int16_t)(int)roundf(mul_rn(32767.f, r0.x));
-          q.y = (int16_t)(int)roundf(mul_rn(32767.f, r0.y));
-          q.z = (int16_t)(int)roundf(mul_rn(32767.f, r1.x));
-          q.w = (int16_t)(int)roundf(mul_rn(32767.f, r1.y));
-          if (two)
-            *reinterpret_cast<short4 *>(a.out16 + 2 * go) = q;
-          else
-            *reinterpret_cast<short2 *>(a.out16 + 2 * go) = make_short2(q.x, q.y);
-        }
-      }
-      if (two)
-        *reinterpret_cast<float4 *>(a.out + go) = make_float4(r0.x, r0.y, r1.x, r1.y);
-      else
-        a.out[go] = r0;
-    };
-    if (is15)
-      stage_hb15(src, n_prod, a, emit);
+template <int G>
+void launch_group_g(const GroupArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st) {
+  bool const pair = (a.halo & 1) == 0;
+  if (a.final) {
+    if (pair)
+      launch_group_r<G, true, true>(a, grid, lds_bytes, st);
     else
-      stage_hb3(src, n_prod, emit);
-    __syncthreads();
-    Level const t = src;
-    src = dst;
-    dst = t;
+      launch_group_r<G, true, false>(a, grid, lds_bytes, st);
+  } else {
+    if (pair)
+      launch_group_r<G, false, true>(a, grid, lds_bytes, st);
+    else
+      launch_group_r<G, false, false>(a, grid, lds_bytes, st);
   }
+}
 
-  if (a.final && a.partial) {
-    // fixed-order reduction: lanes by xor-shuffle, then waves in order
-    __shared__ float wsum[kThreads / 64];
-    for (int off = 32; off; off >>= 1) energy += __shfl_xor(energy, off);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = energy;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float t = 0;
-      for (int w = 0; w < kThreads / 64; w++) t += wsum[w];
-      a.partial[blockIdx.x] = t;
-    }
+void launch_group(const GroupArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st) {
+  switch (a.nstages) {
+    case 1: launch_group_g<1>(a, grid, lds_bytes, st); break;
+    case 2: launch_group_g<2>(a, grid, lds_bytes, st); break;
+    default: launch_group_g<3>(a, grid, lds_bytes, st); break;
   }
 }
 
@@ -275,6 +407,7 @@ struct kq_decimator {
   float *partial = nullptr;
   float *energy_dev = nullptr;
   size_t n_partial = 0;
+  unsigned num_cus = 256;
 };
 
 void kq_internal_set_error(const char *fmt, ...);
@@ -291,6 +424,11 @@ void kq_internal_set_error(const char *fmt, ...);
 static int decim_alloc(kq_decimator *d) {
   kq_decim_config const &c = d->cfg;
   DEC_TRY(hipSetDevice(c.device));
+  {
+    hipDeviceProp_t prop;
+    DEC_TRY(hipGetDeviceProperties(&prop, c.device));
+    d->num_cus = (unsigned)prop.multiProcessorCount;
+  }
   if (c.stream)
     d->stream = (hipStream_t)c.stream;
   else {
@@ -423,12 +561,14 @@ int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t 
     a.c1 = d->coeffs[1];
     a.c2 = d->coeffs[2];
     a.c3 = d->coeffs[3];
-    unsigned const grid = (unsigned)((a.n_out + kTileOut - 1) / kTileOut);
+    unsigned const ntiles = (unsigned)((a.n_out + kTileOut - 1) / kTileOut);
     // two planes each for level 0 and level 1
     int const h1 = (g.halo - ((g.mask & 1) ? 14 : 1)) / 2;
     size_t const lds_elems = 2 * (size_t)plane_cap((kTileOut << g.nstages) + g.halo) +
-                             2 * (size_t)plane_cap((kTileOut << (g.nstages - 1)) + h1);
-    hipLaunchKernelGGL(k_hb_group, dim3(grid), dim3(kThreads), sizeof(float2) * lds_elems, d->stream, a);
+                             (g.nstages > 1 ? 2 * (size_t)plane_cap((kTileOut << (g.nstages - 1)) + h1) : 0);
+    unsigned const resident = std::max(1u, std::min(16u, (unsigned)(160 * 1024 / (sizeof(float2) * lds_elems + 64))));
+    unsigned const grid = std::min(ntiles, d->num_cus * resident) + 1;  // + the edge workgroup
+    launch_group(a, grid, sizeof(float2) * lds_elems, d->stream);
     hipLaunchKernelGGL(k_hb_history, dim3((g.halo + 127) / 128), dim3(128), 0, d->stream, src, g.hist[cur], g.hist[nxt],
                        (long long)n_g_in, g.halo);
     src = g.out;

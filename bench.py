@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--blocks", type=int, default=64, help="overlap-save blocks per step")
     ap.add_argument("--fwd", default="auto", choices=["auto", "full", "pruned"])
     ap.add_argument("--n0", type=int, default=0, help="1: also run the status-only compute_n0 every block")
+    ap.add_argument("--no-n0-row", action="store_true", help="skip the secondary compute_n0=1 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
@@ -159,6 +160,30 @@ def main():
     tm = bank.timing(reset=True)
     bank.enable_timing(False)
 
+    # Secondary row (1 GPU only): the same workload with the status-only noise estimate of radio.c:383-425 computed
+    # every block, as the reference's demod threads do.  It needs all N bins of every channel's mixed spectrum, so
+    # the bank runs its full-FFT path; reported beside the headline, never as `value`.
+    n0_row = None
+    if world == 1 and not a.n0 and not a.no_n0_row:
+        bank.close()
+        bank = kq.Bank(fs, L, M, D, C, B, device=local_rank, compute_n0=True, fwd_mode=kq.KQ_FWD_AUTO,
+                       stream=stream.cuda_stream)
+        for p in plan:
+            bank.add_channel(wl.bank_channel_config(p))
+        n0_steps = max(2, min(5, a.steps))
+        for k in range(2):
+            bank.process_resident(bufs[0].data_ptr(), B)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for k in range(n0_steps):
+            bank.process_resident(bufs[0].data_ptr(), B)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t2) / n0_steps
+        n0_row = {"value": round(C * B * L / dt / 1e6, 1), "unit": "Msamples/s (channel-samples)",
+                  "ms_per_step": round(dt * 1e3, 4), "steps": n0_steps,
+                  "note": "compute_n0 (radio.c:383-425, status only) on every channel-block: full N-point spectrum per "
+                          "channel, fwd=full"}
+
     if rank == 0:
         total_ch = C * world
         chan_samples = total_ch * B * L * a.steps
@@ -198,6 +223,8 @@ def main():
                 "demod_ms": round(tm["demod_ms"] / max(1, tm["filter_launches"]), 4),
             },
         }
+        if n0_row:
+            out["with_compute_n0"] = n0_row
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.config, geom, plan, iq_host[M - 1:], a.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -215,6 +215,49 @@ int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t 
 int kq_decim_sync(kq_decimator *d);
 int kq_decim_reset(kq_decimator *d);
 
+/* --- AFSK-1200 / HDLC packet decoder -----------------------------------------------------------
+ * What the `packet` program does per RTP session between its PCM input and a decoded AX.25 frame: the REAL master
+ * filter of 1000 new samples / 1049 taps (packet.c:41-45,190), the analytic 100..4000 Hz slave (packet.c:272-273),
+ * the mark / space correlators with on-time and mid-bit integrators, the Gardner-style bit clock, NRZI and HDLC
+ * deframing (packet.c:276-410) and the frame check (ax25.c:138-156 crc_good).  Constants are the reference's: 48 kHz
+ * audio, 1200 bit/s, 40 samples per bit.  A bank holds `max_sessions` independent sessions that advance in lock step;
+ * decoded frames (body + the two FCS bytes, exactly what packet.c:356 sends) collect in a per-session arena. */
+typedef struct kq_afsk_bank kq_afsk_bank;
+enum kq_pcm_format {
+  KQ_PCM_F32 = 0,   /* float samples, what packet.c:207 stores into input.r[] */
+  KQ_PCM_S16BE = 1  /* 16-bit big-endian PCM words as they arrive in the RTP payload, converted as packet.c:207 does:
+                       ntohs() is unsigned, so a negative word w becomes (w + 65536) / 32768 (quirk kept) */
+};
+typedef struct kq_afsk_config {
+  int device;
+  unsigned max_sessions;
+  unsigned max_frames;   /* arena slots per session between kq_afsk_clear_frames calls */
+  void *stream;          /* hipStream_t, NULL = private stream */
+} kq_afsk_config;
+typedef struct kq_afsk_state {   /* packet.c:286-299 after the last processed block */
+  int symphase, frame_bit, flagsync, ones;
+  float last_val, mid_val;
+  int decoded_packets;           /* packet.c:34 */
+  int pending_samples;           /* packet.c:31 input_pointer */
+  uint64_t blocks;
+} kq_afsk_state;
+kq_afsk_bank *kq_afsk_create(const kq_afsk_config *cfg);
+int kq_afsk_destroy(kq_afsk_bank *bank);
+/* Append `nsamples` samples to every session (session i at samples + i * session_stride elements) and decode every
+ * block of 1000 that completes (packet.c:204-211).  Returns the number of blocks decoded per session, or -1.
+ * on_device != 0: `samples` is device memory and the call is asynchronous on the bank's stream. */
+int kq_afsk_push(kq_afsk_bank *bank, const void *samples, int format, unsigned nsessions, size_t nsamples,
+                 size_t session_stride, int on_device);
+int kq_afsk_sync(kq_afsk_bank *bank);
+int kq_afsk_num_frames(kq_afsk_bank *bank, unsigned session);
+int kq_afsk_dropped_frames(kq_afsk_bank *bank, unsigned session);   /* good frames lost to a full arena */
+/* Copies frame `index` of `session` (at most cap bytes) and returns its length (<= 1024), or -1 */
+int kq_afsk_pull_frame(kq_afsk_bank *bank, unsigned session, unsigned index, unsigned char *dst, size_t cap);
+int kq_afsk_clear_frames(kq_afsk_bank *bank);
+/* filter.out->output.c of the last decoded block (1000 complex) and the decoder state, for parity checks */
+int kq_afsk_pull_filter_output(kq_afsk_bank *bank, unsigned session, float *dst_re_im, size_t cap_complex);
+int kq_afsk_pull_state(kq_afsk_bank *bank, unsigned session, kq_afsk_state *out);
+
 #ifdef __cplusplus
 }
 #endif

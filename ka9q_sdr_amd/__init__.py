@@ -27,3 +27,4 @@ from .bank import (  # noqa: F401
     load_library,
 )
 from .decimate import Decimator  # noqa: F401,E402
+from .packet import AfskBank, KQ_PCM_F32, KQ_PCM_S16BE  # noqa: F401,E402

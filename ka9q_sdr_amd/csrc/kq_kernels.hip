@@ -9,112 +9,9 @@
 //
 // The pruned forward path lives in kq_pruned.hip.
 #include "kq_device.hpp"
+#include "kq_ldsfft.hpp"
 
 namespace kq {
-
-// ---------------------------------------------------------------- helpers
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-__device__ __forceinline__ float cnrm(float2 a) { return a.x * a.x + a.y * a.y; }
-
-__device__ __forceinline__ unsigned bitrev(unsigned i, int bits) { return bits ? (__brev(i) >> (32 - bits)) : 0u; }
-
-// Unit phasor exp(j*2*pi*turns) from a double phase in turns
-__device__ __forceinline__ float2 phasor_turns(double turns) {
-  turns -= rint(turns);
-  float s, c;
-  sincospif(2.0f * (float)turns, &s, &c);
-  return make_float2(c, s);
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-
-// Block-wide sum of (float, int) pairs; red_f / red_i hold one slot per wave (<= 16 waves)
-__device__ __forceinline__ void block_sum_fi(float &f, int &i, float *red_f, int *red_i) {
-  f = wave_sum(f);
-  i = wave_sum_i(i);
-  int const w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) {
-    red_f[w] = f;
-    red_i[w] = i;
-  }
-  __syncthreads();
-  float tf = 0;
-  int ti = 0;
-  for (int k = 0; k < nw; k++) {
-    tf += red_f[k];
-    ti += red_i[k];
-  }
-  f = tf;
-  i = ti;
-}
-
-// In-place FFT of 2^log2n points held in LDS in BIT-REVERSED order; result in natural order.
-// Radix-2^2 decimation in time (plus one radix-2 stage when log2n is odd).  tw[k] = exp(-2*pi*i*k/T),
-// T = 1 << tw_log2 >= n, k < T/2.  SIGN -1 forward / +1 backward, unnormalised like FFTW.
-template <int SIGN>
-__device__ void lds_fft(float2 *s, int log2n, const float2 *__restrict__ tw, int tw_log2) {
-  int const n = 1 << log2n;
-  int stage = 0;
-  __syncthreads();
-  if (log2n & 1) {
-    for (int i = threadIdx.x; i < n / 2; i += blockDim.x) {
-      float2 const a = s[2 * i], b = s[2 * i + 1];
-      s[2 * i] = cadd(a, b);
-      s[2 * i + 1] = csub(a, b);
-    }
-    stage = 1;
-    __syncthreads();
-  }
-  for (; stage < log2n; stage += 2) {
-    int const m = 1 << stage;
-    for (int i = threadIdx.x; i < n / 4; i += blockDim.x) {
-      int const j = i & (m - 1);
-      int const base = ((i >> stage) << (stage + 2)) + j;
-      float2 w2 = tw[(size_t)j << (tw_log2 - stage - 1)];
-      float2 w4 = tw[(size_t)j << (tw_log2 - stage - 2)];
-      if (SIGN > 0) {
-        w2.y = -w2.y;
-        w4.y = -w4.y;
-      }
-      float2 const a0 = s[base], a1 = cmul(s[base + m], w2);
-      float2 const a2 = s[base + 2 * m], a3 = cmul(s[base + 3 * m], w2);
-      float2 const b0 = cadd(a0, a1), b1 = csub(a0, a1), b2 = cadd(a2, a3), b3 = csub(a2, a3);
-      float2 const c2 = cmul(b2, w4);
-      float2 c3 = cmul(b3, w4);
-      c3 = (SIGN < 0) ? make_float2(c3.y, -c3.x) : make_float2(-c3.y, c3.x);  // times exp(-+ i*pi/2)
-      s[base] = cadd(b0, c2);
-      s[base + 2 * m] = csub(b0, c2);
-      s[base + m] = cadd(b1, c3);
-      s[base + 3 * m] = csub(b1, c3);
-    }
-    __syncthreads();
-  }
-}
 
 // ---------------------------------------------------------------- ingest
 __global__ void k_ingest(const void *__restrict__ src, int format, float2 *__restrict__ dst, size_t n, float gain) {

@@ -14,7 +14,9 @@
  * PINNING STATUS
  *   osc/dsp (NCO)   : pinned against the reference itself -- oracle/_ref/libref_osc.so is
  *                     built from /root/reference/{osc.c,dsp.c} unmodified (oracle/Makefile).
- *   filter/radio/fm/am/linear : PARITY UNPINNED.  Those reference files include <fftw3.h>
+ *   decimate.c      : pinned likewise (oracle/_ref/libref_decimate.so).
+ *   ax25.c crc_good : pinned likewise (oracle/_ref/libref_ax25.so).
+ *   filter/radio/fm/am/linear/packet : PARITY UNPINNED.  Those reference files include <fftw3.h>
  *                     (filter.h:12) which this image lacks, and the reference ships no tests,
  *                     golden vectors or fixtures.  The restatement is
  *                     instead cross-checked against independent float64 numpy/scipy
@@ -172,6 +174,24 @@ typedef struct {
 void kqo_hb15_init(kqo_hb15_state *st);
 void kqo_hb15_block(kqo_hb15_state *st, float *output, const float *input, int cnt);
 void kqo_hb3_block(float *state, float *output, const float *input, int cnt);
+
+/* AFSK-1200 / HDLC packet decoder (packet.c:36-48, 201-212, 267-414; ax25.c:138-156) */
+#define KQO_AFSK_AL 1000        /* packet.c:42 */
+#define KQO_AFSK_AM 1049        /* packet.c:44 */
+#define KQO_AFSK_SAMPRATE 48000.f
+#define KQO_AFSK_SAMPPBIT 40    /* packet.c:48 */
+#define KQO_AFSK_FRAME_MAX 1024 /* packet.c:294 hdlc_frame[] */
+typedef struct kqo_afsk kqo_afsk;
+int kqo_crc_good(const unsigned char *frame, int length);
+kqo_afsk *kqo_afsk_create(void);
+void kqo_afsk_destroy(kqo_afsk *a);
+void kqo_afsk_push(kqo_afsk *a, const float *samples, int n);
+void kqo_afsk_push_pcm_be(kqo_afsk *a, const unsigned char *be, int nwords);
+int kqo_afsk_nframes(const kqo_afsk *a);
+int kqo_afsk_frame(const kqo_afsk *a, int i, unsigned char *dst, int cap);
+const float complex *kqo_afsk_filter_output(const kqo_afsk *a);
+void kqo_afsk_state(const kqo_afsk *a, int *symphase, int *frame_bit, int *flagsync, int *ones, float *last_val,
+                    float *mid_val);
 
 /* PCM output stage (audio.c:22-28, 45-50, 95-100): float -> clipped int16, network byte order, in chunks of at
  * most 480 words; bit i of *silent_mask is set when chunk i is all zero (the reference then skips the packet but

@@ -64,13 +64,13 @@ class _Cplx(C.Structure):
 def build(force=False):
     """Compile the oracle (and oracle/_ref when /root/reference is present)."""
     so = os.path.join(_HERE, "libkq_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("kq_fft.c", "kq_osc.c", "kq_filter.c", "kq_chan.c", "kq_decimate.c",
+    srcs = [os.path.join(_HERE, f) for f in ("kq_fft.c", "kq_osc.c", "kq_filter.c", "kq_chan.c", "kq_decimate.c", "kq_packet.c",
                                              "kq_oracle.h")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "libkq_oracle.so"], stdout=subprocess.DEVNULL)
     ref_so = os.path.join(_HERE, "_ref", "libref_osc.so")
-    ref_dec = os.path.join(_HERE, "_ref", "libref_decimate.so")
+    ref_dec = os.path.join(_HERE, "_ref", "libref_ax25.so")
     if os.path.exists("/root/reference/osc.c") and (force or not os.path.exists(ref_so) or not os.path.exists(ref_dec)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
     return so
@@ -124,6 +124,16 @@ def lib():
     L.kqo_delete_filter_input.argtypes = [C.c_void_p]
     L.kqo_delete_filter_output.argtypes = [C.c_void_p]
     L.kqo_set_filter.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    L.kqo_crc_good.argtypes = [C.c_char_p, C.c_int]
+    L.kqo_afsk_create.restype = C.c_void_p
+    L.kqo_afsk_destroy.argtypes = [C.c_void_p]
+    L.kqo_afsk_push.argtypes = [C.c_void_p, fp, C.c_int]
+    L.kqo_afsk_push_pcm_be.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.kqo_afsk_nframes.argtypes = [C.c_void_p]
+    L.kqo_afsk_frame.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    L.kqo_afsk_filter_output.argtypes = [C.c_void_p]
+    L.kqo_afsk_filter_output.restype = C.c_void_p
+    L.kqo_afsk_state.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4 + [fp, fp]
     L.kqo_hb15_init.argtypes = [C.POINTER(Hb15State)]
     L.kqo_hb15_block.argtypes = [C.POINTER(Hb15State), fp, fp, C.c_int]
     L.kqo_hb3_block.argtypes = [fp, fp, fp, C.c_int]
@@ -283,6 +293,64 @@ def make_kaiser(M, beta):
 def compute_n0(spec, samprate, low, high):
     spec = np.ascontiguousarray(spec, np.complex64)
     return lib().kqo_compute_n0(spec.ctypes.data, len(spec), samprate, low, high)
+
+
+class Afsk:
+    """packet.c session: REAL master (1000/1049), analytic slave, mark/space correlators, HDLC."""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = self.L.kqo_afsk_create()
+
+    def close(self):
+        if self.h:
+            self.L.kqo_afsk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def push(self, samples):
+        x = np.ascontiguousarray(samples, np.float32)
+        self.L.kqo_afsk_push(self.h, x.ctypes.data_as(C.POINTER(C.c_float)), len(x))
+
+    def push_pcm_be(self, raw):
+        raw = bytes(raw)
+        self.L.kqo_afsk_push_pcm_be(self.h, raw, len(raw) // 2)
+
+    def frames(self):
+        out = []
+        buf = C.create_string_buffer(1024)
+        for i in range(self.L.kqo_afsk_nframes(self.h)):
+            n = self.L.kqo_afsk_frame(self.h, i, buf, 1024)
+            out.append(bytes(buf.raw[:n]))
+        return out
+
+    def filter_output(self):
+        p = self.L.kqo_afsk_filter_output(self.h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(2000,)).view(np.complex64).copy()
+
+    def state(self):
+        i = [C.c_int() for _ in range(4)]
+        f = [C.c_float() for _ in range(2)]
+        self.L.kqo_afsk_state(self.h, *[C.byref(v) for v in i], *[C.byref(v) for v in f])
+        return dict(symphase=i[0].value, frame_bit=i[1].value, flagsync=i[2].value, ones=i[3].value,
+                    last_val=f[0].value, mid_val=f[1].value)
+
+
+def crc_good(frame):
+    return int(lib().kqo_crc_good(bytes(frame), len(frame)))
+
+
+def ref_ax25_lib():
+    """The reference's own ax25.c (oracle/_ref/libref_ax25.so); None if not built."""
+    build()
+    so = os.path.join(_HERE, "_ref", "libref_ax25.so")
+    if not os.path.exists(so):
+        return None
+    R = C.CDLL(so)
+    R.crc_good.argtypes = [C.c_char_p, C.c_int]
+    return R
 
 
 class Hb15State(C.Structure):

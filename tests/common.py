@@ -39,3 +39,53 @@ def run_oracle(plan, geom, iq, nblocks, compute_n0=0, gain_factor=1.0):
         cfg = oracle_cfg(p, geom["samprate"], L, geom["M"], geom["D"], compute_n0, gain_factor)
         out.append(ko.run_chain(cfg, iq[:nblocks * L].reshape(nblocks, L), want_filt=True))
     return out
+
+
+# ---- AX.25 / AFSK-1200 test signal (Bell 202: mark 1200 Hz, space 2200 Hz, NRZI, HDLC bit stuffing) ----
+def ax25_fcs(payload):
+    """CRC-16/X.25 of the frame body; appended low byte first, the receiver's residue is 0xf0b8 (ax25.c:138-156)."""
+    crc = 0xFFFF
+    for byte in payload:
+        for i in range(8):
+            fb = 0x8408 if (crc ^ (byte >> i)) & 1 else 0
+            crc = (crc >> 1) ^ fb
+    crc ^= 0xFFFF
+    return bytes([crc & 0xFF, crc >> 8])
+
+
+def afsk_bits(frames, lead_flags=8, gap_flags=3):
+    """HDLC bit stream: flags, each frame (+FCS) LSB first with zero stuffing, flags in between and at the end."""
+    flag = [0, 1, 1, 1, 1, 1, 1, 0]
+    bits = flag * lead_flags
+    for body in frames:
+        ones = 0
+        for byte in body + ax25_fcs(body):
+            for i in range(8):
+                b = (byte >> i) & 1
+                bits.append(b)
+                ones = ones + 1 if b else 0
+                if ones == 5:
+                    bits.append(0)
+                    ones = 0
+        bits += flag * gap_flags
+    return bits
+
+
+def afsk_audio(bits, samprate=48000.0, baud=1200.0, amp=0.5, noise=0.0, seed=0, clock_ppm=0.0):
+    """NRZI + continuous-phase FSK; float32 audio."""
+    import numpy as np
+    spb = samprate / baud * (1 + clock_ppm * 1e-6)
+    n = int(len(bits) * spb) + 1
+    tone = np.empty(len(bits), np.int8)
+    cur = 0
+    for i, b in enumerate(bits):
+        if b == 0:
+            cur ^= 1
+        tone[i] = cur
+    idx = np.minimum((np.arange(n) / spb).astype(np.int64), len(bits) - 1)
+    f = np.where(tone[idx] == 0, 1200.0, 2200.0)
+    ph = 2 * np.pi * np.cumsum(f) / samprate
+    x = amp * np.sin(ph)
+    if noise:
+        x = x + noise * np.random.default_rng(seed).standard_normal(n)
+    return x.astype(np.float32)

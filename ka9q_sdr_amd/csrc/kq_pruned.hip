@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "kq_device.hpp"
+#include "kq_regfft.hpp"
 
 namespace kq {
 
@@ -50,71 +51,12 @@ __device__ __forceinline__ float2 cfma(float2 b, float2 c, float2 a) {
   return make_float2(fmaf(-b.y, c.y, fmaf(b.x, c.x, a.x)), fmaf(b.y, c.x, fmaf(b.x, c.y, a.y)));
 }
 
-// ---- compile-time twiddles exp(-2 pi i k / n), 0 <= k < n/2
-constexpr double kPi = 3.14159265358979323846264338327950288;
-constexpr double cx_cos(double x) {  // |x| <= pi/4
-  double const x2 = x * x;
-  double term = 1, sum = 1;
-  for (int n = 1; n < 14; n++) {
-    term *= -x2 / ((2 * n - 1) * (2 * n));
-    sum += term;
-  }
-  return sum;
-}
-constexpr double cx_sin(double x) {
-  double const x2 = x * x;
-  double term = x, sum = x;
-  for (int n = 1; n < 14; n++) {
-    term *= -x2 / ((2 * n) * (2 * n + 1));
-    sum += term;
-  }
-  return sum;
-}
-constexpr double turn_cos(double t) {  // cos(2 pi t), 0 <= t < 0.5, octant symmetries keep exact zeros exact
-  return t <= 0.125 ? cx_cos(2 * kPi * t) : t <= 0.375 ? -cx_sin(2 * kPi * (t - 0.25)) : -cx_cos(2 * kPi * (0.5 - t));
-}
-constexpr double turn_sin(double t) {
-  return t <= 0.125 ? cx_sin(2 * kPi * t) : t <= 0.375 ? cx_cos(2 * kPi * (t - 0.25)) : cx_sin(2 * kPi * (0.5 - t));
-}
-constexpr float tw_re(int k, int n) { return (float)turn_cos((double)k / n); }
-constexpr float tw_im(int k, int n) { return (float)(-turn_sin((double)k / n)); }
-
-constexpr int bitrev5(int i) {
-  return ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
-}
-
-// 32-point forward FFT in registers, decimation in time, radix 2, fully unrolled, compile-time twiddles.
-// In: sample a must have been stored at v[bitrev5(a)].  Out: bin q' in v[q'] (natural order).
-// Butterflies are FMA-fused: u = a + w b costs 4 fma, the other output is 2a - u (2 fma).
-__device__ __forceinline__ void fft32_dit(float2 (&v)[32]) {
-#pragma unroll
-  for (int len = 2; len <= 32; len <<= 1) {
-    int const half = len / 2;
-    int const tstep = 64 / len;
-#pragma unroll
-    for (int base = 0; base < 32; base += len) {
-#pragma unroll
-      for (int j = 0; j < half; j++) {
-        float2 const a = v[base + j], b = v[base + j + half];
-        int const t = j * tstep;  // twiddle exp(-2 pi i t / 64), 0..31
-        if (t == 0) {
-          v[base + j] = cadd(a, b);
-          v[base + j + half] = csub(a, b);
-        } else if (t == 16) {  // w = -i
-          v[base + j] = make_float2(a.x + b.y, a.y - b.x);
-          v[base + j + half] = make_float2(a.x - b.y, a.y + b.x);
-        } else {
-          float const wr = tw_re(t, 64), wi = tw_im(t, 64);
-          float2 u;
-          u.x = fmaf(wr, b.x, fmaf(-wi, b.y, a.x));
-          u.y = fmaf(wr, b.y, fmaf(wi, b.x, a.y));
-          v[base + j] = u;
-          v[base + j + half] = make_float2(fmaf(2.f, a.x, -u.x), fmaf(2.f, a.y, -u.y));
-        }
-      }
-    }
-  }
-}
+using rfft::bitrev5;
+using rfft::kPi;
+using rfft::tw_im;
+using rfft::tw_re;
+// 32-point forward FFT in registers (kq_regfft.hpp): sample a goes in at v[bitrev5(a)], bin q' comes out in v[q']
+__device__ __forceinline__ void fft32_dit(float2 (&v)[32]) { rfft::fft_dit<32>(v); }
 
 // ---- per-channel tables (floats).  ND = 64: A is merged per pass, [2][32] float4 = (A[a] w, A[a+32] w') with the
 // pass twiddle folded in.  ND = 128: A only, [32][4] float2 = A[a' + 32 s]; the radix-4 factor (-i)^{s p} is a

@@ -1,0 +1,78 @@
+// kq_regfft.hpp -- small FFTs held entirely in a thread's registers (compile-time twiddles, fully unrolled), the
+// building block of the register-resident transforms (kq_pruned.hip, kq_full16k.hip).  Forward sign (-1),
+// unnormalised, like fftwf_plan_dft_1d(FFTW_FORWARD) in filter.c:84.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace kq {
+namespace rfft {
+
+// ---- compile-time twiddles exp(-2 pi i k / n), 0 <= k < n/2
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double cx_cos(double x) {  // |x| <= pi/4
+  double const x2 = x * x;
+  double term = 1, sum = 1;
+  for (int n = 1; n < 14; n++) {
+    term *= -x2 / ((2 * n - 1) * (2 * n));
+    sum += term;
+  }
+  return sum;
+}
+constexpr double cx_sin(double x) {
+  double const x2 = x * x;
+  double term = x, sum = x;
+  for (int n = 1; n < 14; n++) {
+    term *= -x2 / ((2 * n) * (2 * n + 1));
+    sum += term;
+  }
+  return sum;
+}
+constexpr double turn_cos(double t) {  // cos(2 pi t), 0 <= t < 0.5, octant symmetries keep exact zeros exact
+  return t <= 0.125 ? cx_cos(2 * kPi * t) : t <= 0.375 ? -cx_sin(2 * kPi * (t - 0.25)) : -cx_cos(2 * kPi * (0.5 - t));
+}
+constexpr double turn_sin(double t) {
+  return t <= 0.125 ? cx_sin(2 * kPi * t) : t <= 0.375 ? cx_cos(2 * kPi * (t - 0.25)) : cx_sin(2 * kPi * (0.5 - t));
+}
+constexpr float tw_re(int k, int n) { return (float)turn_cos((double)k / n); }
+constexpr float tw_im(int k, int n) { return (float)(-turn_sin((double)k / n)); }
+
+constexpr int bitrev5(int i) {
+  return ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
+}
+constexpr int bitrev4(int i) { return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3); }
+
+// NP-point forward FFT in registers, decimation in time, radix 2.  In: sample a stored at v[bitrev(a)].
+// Out: bin q in v[q].  Butterflies are FMA-fused: u = a + w b costs 4 fma, the other output is 2a - u (2 fma).
+template <int NP>
+__device__ __forceinline__ void fft_dit(float2 (&v)[NP]) {
+#pragma unroll
+  for (int len = 2; len <= NP; len <<= 1) {
+    int const half = len / 2;
+    int const tstep = 64 / len;
+#pragma unroll
+    for (int base = 0; base < NP; base += len) {
+#pragma unroll
+      for (int j = 0; j < half; j++) {
+        float2 const a = v[base + j], b = v[base + j + half];
+        int const t = j * tstep;  // twiddle exp(-2 pi i t / 64), 0..31
+        if (t == 0) {
+          v[base + j] = make_float2(a.x + b.x, a.y + b.y);
+          v[base + j + half] = make_float2(a.x - b.x, a.y - b.y);
+        } else if (t == 16) {  // w = -i
+          v[base + j] = make_float2(a.x + b.y, a.y - b.x);
+          v[base + j + half] = make_float2(a.x - b.y, a.y + b.x);
+        } else {
+          float const wr = tw_re(t, 64), wi = tw_im(t, 64);
+          float2 u;
+          u.x = fmaf(wr, b.x, fmaf(-wi, b.y, a.x));
+          u.y = fmaf(wr, b.y, fmaf(wi, b.x, a.y));
+          v[base + j] = u;
+          v[base + j + half] = make_float2(fmaf(2.f, a.x, -u.x), fmaf(2.f, a.y, -u.y));
+        }
+      }
+    }
+  }
+}
+
+}  // namespace rfft
+}  // namespace kq

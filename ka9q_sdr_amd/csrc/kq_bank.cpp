@@ -428,6 +428,9 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   }
   {
     Scope t(b, 0, b->stream);
+    // full-spectrum path: the register-resident N = 16384 kernel where it applies (KQ_FULL_LDS=1 forces the LDS one)
+    static bool const lds_only = getenv("KQ_FULL_LDS") && atoi(getenv("KQ_FULL_LDS")) != 0;
+    auto const full_launch = (!lds_only && kq::full16k_supported(g)) ? kq::launch_filter_full16k : kq::launch_filter_full;
     if (b->fwd_mode == KQ_FWD_PRUNED) {
       if (b->chan_tw_dirty) {  // the tables depend only on each channel's LO step: rebuild after a retune
         kq::launch_pruned_tables(b->stream, g, chd, b->chan_tw, C);
@@ -445,13 +448,13 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
         if (g.N > 16384)
           kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, (int)ret.size(), 1, b->retune_list);
         else
-          kq::launch_filter_full(b->stream, g, chd, pl, window, b->tw, (int)ret.size(), 1, 0, nullptr, -1, b->retune_list);
+          full_launch(b->stream, g, chd, pl, window, b->tw, (int)ret.size(), 1, 0, nullptr, -1, b->retune_list);
       }
     } else if (g.N > 16384) {
       kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, nullptr);
     } else {
-      kq::launch_filter_full(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, b->cfg.compute_n0, b->spec_dump,
-                             b->spec_ch, nullptr);
+      full_launch(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, b->cfg.compute_n0, b->spec_dump, b->spec_ch,
+                  nullptr);
     }
     b->acc.filter_launches++;
     b->acc.channel_blocks += (uint64_t)C * nblocks;

@@ -3,6 +3,7 @@
 // unnormalised, like fftwf_plan_dft_1d(FFTW_FORWARD) in filter.c:84.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <utility>
 
 namespace kq {
 namespace rfft {
@@ -41,37 +42,44 @@ constexpr int bitrev5(int i) {
 }
 constexpr int bitrev4(int i) { return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3); }
 
-// NP-point forward FFT in registers, decimation in time, radix 2.  In: sample a stored at v[bitrev(a)].
-// Out: bin q in v[q].  Butterflies are FMA-fused: u = a + w b costs 4 fma, the other output is 2a - u (2 fma).
+// One radix-2 butterfly of stage LEN: pair index I selects group base = (I / half) * LEN and offset j = I % half.
+// FMA-fused: u = a + w b costs 4 fma, the other output is 2a - u (2 fma).
+template <int NP, int LEN, int I>
+__device__ __forceinline__ void bfly(float2 (&v)[NP]) {
+  constexpr int half = LEN / 2, base = (I / half) * LEN, j = I % half;
+  constexpr int t = j * (64 / LEN);  // twiddle exp(-2 pi i t / 64), 0..31
+  float2 const a = v[base + j], b = v[base + j + half];
+  if constexpr (t == 0) {
+    v[base + j] = make_float2(a.x + b.x, a.y + b.y);
+    v[base + j + half] = make_float2(a.x - b.x, a.y - b.y);
+  } else if constexpr (t == 16) {  // w = -i
+    v[base + j] = make_float2(a.x + b.y, a.y - b.x);
+    v[base + j + half] = make_float2(a.x - b.y, a.y + b.x);
+  } else {
+    constexpr float wr = tw_re(t, 64), wi = tw_im(t, 64);
+    float2 u;
+    u.x = fmaf(wr, b.x, fmaf(-wi, b.y, a.x));
+    u.y = fmaf(wr, b.y, fmaf(wi, b.x, a.y));
+    v[base + j] = u;
+    v[base + j + half] = make_float2(fmaf(2.f, a.x, -u.x), fmaf(2.f, a.y, -u.y));
+  }
+}
+
+template <int NP, int LEN, int... I>
+__device__ __forceinline__ void stage(float2 (&v)[NP], std::integer_sequence<int, I...>) {
+  if constexpr (LEN <= NP) (bfly<NP, LEN, I>(v), ...);
+}
+
+// NP-point forward FFT in registers (NP <= 32), decimation in time, radix 2, unrolled by construction.
+// In: sample a stored at v[bitrev(a)].  Out: bin q in v[q].
 template <int NP>
 __device__ __forceinline__ void fft_dit(float2 (&v)[NP]) {
-#pragma unroll
-  for (int len = 2; len <= NP; len <<= 1) {
-    int const half = len / 2;
-    int const tstep = 64 / len;
-#pragma unroll
-    for (int base = 0; base < NP; base += len) {
-#pragma unroll
-      for (int j = 0; j < half; j++) {
-        float2 const a = v[base + j], b = v[base + j + half];
-        int const t = j * tstep;  // twiddle exp(-2 pi i t / 64), 0..31
-        if (t == 0) {
-          v[base + j] = make_float2(a.x + b.x, a.y + b.y);
-          v[base + j + half] = make_float2(a.x - b.x, a.y - b.y);
-        } else if (t == 16) {  // w = -i
-          v[base + j] = make_float2(a.x + b.y, a.y - b.x);
-          v[base + j + half] = make_float2(a.x - b.y, a.y + b.x);
-        } else {
-          float const wr = tw_re(t, 64), wi = tw_im(t, 64);
-          float2 u;
-          u.x = fmaf(wr, b.x, fmaf(-wi, b.y, a.x));
-          u.y = fmaf(wr, b.y, fmaf(wi, b.x, a.y));
-          v[base + j] = u;
-          v[base + j + half] = make_float2(fmaf(2.f, a.x, -u.x), fmaf(2.f, a.y, -u.y));
-        }
-      }
-    }
-  }
+  using pairs = std::make_integer_sequence<int, NP / 2>;
+  stage<NP, 2>(v, pairs{});
+  stage<NP, 4>(v, pairs{});
+  stage<NP, 8>(v, pairs{});
+  stage<NP, 16>(v, pairs{});
+  stage<NP, 32>(v, pairs{});
 }
 
 }  // namespace rfft

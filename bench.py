@@ -163,6 +163,7 @@ def main():
     # Secondary row (1 GPU only): the same workload with the status-only noise estimate of radio.c:383-425 computed
     # every block, as the reference's demod threads do.  It needs all N bins of every channel's mixed spectrum, so
     # the bank runs its full-FFT path; reported beside the headline, never as `value`.
+    fwd_used = {1: "full", 2: "pruned"}[bank.fwd_mode]
     n0_row = None
     if world == 1 and not a.n0 and not a.no_n0_row:
         bank.close()
@@ -194,7 +195,7 @@ def main():
             per_kind[p["demod"]] = per_kind.get(p["demod"], 0) + 1
         abytes = sum(wl.algorithmic_bytes(geom, p["demod"], p.get("channels", 1) == 2) for p in plan) * B
         k_ms = tm["filter_ms"] / max(1, tm["filter_launches"])
-        traffic, traffic_src = pmc_traffic(a.config, C, B, {1: "full", 2: "pruned"}[bank.fwd_mode])
+        traffic, traffic_src = pmc_traffic(a.config, C, B, fwd_used)
         achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "input Msamples/s + channels @ real-time, 16384-pt overlap-save",
@@ -208,7 +209,7 @@ def main():
                 "workload": "%s: %d channels/GPU (%s), N=%d (L=%d, M=%d), decimate %d, %.3g MS/s synthetic complex-float "
                             "I/Q, %d blocks/step, fwd=%s, compute_n0=%d" %
                             (a.config, C, "+".join("%d %s" % (v, k) for k, v in sorted(per_kind.items())), L + M - 1, L, M, D,
-                             fs / 1e6, B, {1: "full", 2: "pruned"}[bank.fwd_mode], a.n0),
+                             fs / 1e6, B, fwd_used, a.n0),
                 "channels_total": total_ch,
                 "front_end_Msamples_per_s": round(front_end_msps, 2),
                 "realtime_factor": round(front_end_msps * 1e6 / fs, 2),

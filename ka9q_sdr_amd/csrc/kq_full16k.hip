@@ -9,9 +9,10 @@
 // N = 32 * 32 * 16.  With n = 512 n1 + 16 n2 + n3 and k = k1 + 32 k2 + 1024 k3
 //   X[k] = sum_n3 W16^{n3 k3} W512^{n3 k2} sum_n2 W32^{n2 k2} W_N^{(16 n2 + n3) k1} sum_n1 W32^{n1 k1} x[n]
 // 512 threads; thread t = 16 n2 + n3 loads its 32 samples x[512 n1 + t] (coalesced), mixes them and runs the
-// 32-point transform over n1 in registers; the twiddle W_N^{t k1} is one product of two table entries per element.
-// Two transposes through LDS (real and imaginary planes in turn, so the buffer is 66 KiB and two workgroups share a
-// CU) feed the 32-point transform over n2 and the two 16-point transforms over n3.  Every bin ends up in a register:
+// 32-point transform over n1 in registers; the twiddle W_N^{t k1} = W^{(k1 & 3) t} W^{(k1 & ~3) t} is one product of
+// two entries of a small per-thread table (coalesced loads).  Complex values are 2-vectors: the arithmetic is
+// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32.
+// Two transposes through LDS (each in two half rounds, so the buffer is 68 KiB and two workgroups share a CU) feed the 32-point transform over n2 and the two 16-point transforms over n3.  Every bin ends up in a register:
 // compute_n0 is two block reductions, and the N/D bins the slave reads are dropped into LDS for the existing
 // multiply / inverse-transform epilogue.
 //
@@ -20,61 +21,75 @@
 // retune (history still on the old oscillator) evaluate the closed-form phase per sample, as k_filter_full does.
 #include "kq_device.hpp"
 #include "kq_ldsfft.hpp"
+#include <cmath>
+#include <mutex>
+#include <vector>
+
 #include "kq_regfft.hpp"
 
 namespace kq {
 
 namespace {
 
-constexpr int kN = 16384, kLog2N = 14, kT = 512;
-constexpr int kRow1 = 528;    // exchange 1: [k1][16 n2 + n3], row padded so that 4 rows x 16 lanes hit 64 banks
-constexpr int kRow2 = 1025;   // exchange 2: [n3][32 k1 + k2], row padded against the 1024-float stride
-constexpr int kPlane = 32 * kRow1;  // floats; 16 * kRow2 = 16400 fits as well
+constexpr int kN = 16384, kT = 512;
+// Both transposes move complex (8-byte) elements in two half rounds, so the buffer holds half of the data.
+constexpr int kRow1 = 528;    // transpose 1: [k1 & 15][16 n2 + n3]; rows 4224 B apart alternate 128-byte bank halves
+constexpr int kCol2 = 33;     // transpose 2: [n3][33 (k1 & 15) + k2], rows kRow2 apart: 16 n3 x 2 k1 lanes hit
+constexpr int kRow2 = 546;    //   32 distinct 8-byte bank pairs (546 = 2 mod 32, 33 = 1 mod 32)
+constexpr int kXchElems = 16 * kRow2;  // float2 elements; 16 * kRow1 fits as well
 
-// exp(-2 pi i idx / N) from the half-period table tw (period 1 << tw_log2)
-__device__ __forceinline__ float2 twN(const float2 *__restrict__ tw, int sh, int idx) {
-  idx &= kN - 1;
-  float2 w = tw[(size_t)(idx & (kN / 2 - 1)) << sh];
-  if (idx >= kN / 2) w = make_float2(-w.x, -w.y);
-  return w;
+using rfft::pk_cmul;
+using rfft::v2f;
+
+__device__ __forceinline__ v2f ld2(const float2 *p) {
+  float2 const f = *p;
+  return (v2f){f.x, f.y};
 }
 
-// v[q] *= W_N^{base q}, q = 0..31: W^{q} = W^{q & 3} * W^{q & ~3}, both factors straight from the table
-__device__ __forceinline__ void twiddle32(float2 (&v)[32], const float2 *__restrict__ tw, int sh, int base) {
-  float2 lo[4];
+// Twiddle tables (float2), computed in double on the host.  Pass 1, thread t: lo1[l-1][t] = W_N^{l t}, l = 1..3;
+// hi1[h-1][t] = W_N^{4 h t}, h = 1..7.  Pass 2, n3 = t & 15: lo2[l-1][n3] = W_N^{32 l n3}, hi2[h-1][n3] = W_N^{128 h n3}.
+// (Loading all 31 twiddles of a pass directly -- 31 coalesced loads, no products -- was measured 20 % slower: the
+// loads' latency is exposed, the 24 extra products are not.)
+constexpr int kTabLo1 = 0, kTabHi1 = 3 * kT, kTabLo2 = 10 * kT, kTabHi2 = 10 * kT + 3 * 16, kTabSize = 10 * kT + 10 * 16;
+
+// v[q] *= W^{q}, q = 0..31, W^{q} = lo[q & 3] * hi[q >> 2]; lo/hi rows are `stride` entries apart
+__device__ __forceinline__ void twiddle32(v2f (&v)[32], const float2 *__restrict__ lo_tab, const float2 *__restrict__ hi_tab,
+                                          int stride) {
+  v2f lo[4];
 #pragma unroll
-  for (int l = 1; l < 4; l++) lo[l] = twN(tw, sh, base * l);
+  for (int l = 1; l < 4; l++) lo[l] = ld2(lo_tab + (l - 1) * stride);
 #pragma unroll
-  for (int h = 0; h < 8; h++) {
-    if (h == 0) {
+  for (int l = 1; l < 4; l++) v[l] = pk_cmul(v[l], lo[l]);
 #pragma unroll
-      for (int l = 1; l < 4; l++) v[l] = cmul(v[l], lo[l]);
-    } else {
-      float2 const hi = twN(tw, sh, base * 4 * h);
-      v[4 * h] = cmul(v[4 * h], hi);
+  for (int h = 1; h < 8; h++) {
+    v2f const hi = ld2(hi_tab + (h - 1) * stride);
+    v[4 * h] = pk_cmul(v[4 * h], hi);
 #pragma unroll
-      for (int l = 1; l < 4; l++) v[4 * h + l] = cmul(v[4 * h + l], cmul(hi, lo[l]));
-    }
+    for (int l = 1; l < 4; l++) v[4 * h + l] = pk_cmul(v[4 * h + l], pk_cmul(hi, lo[l]));
   }
+}
+
+__device__ __forceinline__ v2f phasor2(double turns) {
+  float2 const p = phasor_turns(turns);
+  return (v2f){p.x, p.y};
 }
 
 }  // namespace
 
-// grid (channel, block); dynamic LDS = kPlane floats (+ room for the epilogue: 2 * N_dec float2 <= that)
+// grid (channel, block); dynamic LDS = kXchElems float2 (the epilogue's 2 * N_dec float2 fit in it)
 __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,
-                                                       const float2 *__restrict__ tw, int compute_n0,
-                                                       float2 *__restrict__ spec_dump, int spec_ch,
+                                                       const float2 *__restrict__ tw, const float2 *__restrict__ tab,
+                                                       int compute_n0, float2 *__restrict__ spec_dump, int spec_ch,
                                                        const int *__restrict__ chan_list) {
-  extern __shared__ __attribute__((aligned(16))) float xch[];
+  extern __shared__ __attribute__((aligned(16))) float2 xch[];
   __shared__ float red_f[16];
   __shared__ int red_i[16];
   int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
   int const t = threadIdx.x;
-  int const sh = g.tw_log2 - kLog2N;
   int const Ndec = g.Ndec;
 
   // ---------------- load + NCO mix (radio.c:132-139), samples n = 512 n1 + t into v[bitrev5(n1)]
-  float2 v[32];
+  v2f v[32];
   {
     double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c], r = ch.lo_rate[c];
     double const hp0 = ch.hist_phase[c], hf0 = ch.hist_freq[c], hr = ch.hist_rate[c];
@@ -82,26 +97,29 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     double const mbase = (double)b * g.L;
     bool const retuned = b == 0 && (hp0 != ph0 || hf0 != f0 || hr != r);
     if (r == 0.0 && !retuned) {
-      float2 const pt = phasor_turns(ph0 + f0 * (mbase + t));
-      float2 const s1 = phasor_turns(f0 * 512.0), s2 = phasor_turns(f0 * 1024.0), s4 = phasor_turns(f0 * 2048.0),
-                   s8 = phasor_turns(f0 * 4096.0), s16 = phasor_turns(f0 * 8192.0);
-      float2 lo[4];
+      v2f const pt = phasor2(ph0 + f0 * (mbase + t));
+      // S^(2^j), j = 0..4, S = exp(j 2 pi 512 f0): lane j of every wave evaluates one, the wave shares them
+      v2f const sj = phasor2(f0 * (double)(512 << (t & 7)));
+      auto rl = [](float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); };
+      auto bc = [&](int lane) { return (v2f){rl(sj.x, lane), rl(sj.y, lane)}; };
+      v2f const s1 = bc(0), s2 = bc(1), s4 = bc(2), s8 = bc(3), s16 = bc(4);
+      v2f lo[4];
       lo[0] = pt;
-      lo[1] = cmul(pt, s1);
-      lo[2] = cmul(pt, s2);
-      lo[3] = cmul(lo[2], s1);
+      lo[1] = pk_cmul(pt, s1);
+      lo[2] = pk_cmul(pt, s2);
+      lo[3] = pk_cmul(lo[2], s1);
 #pragma unroll
       for (int h = 0; h < 8; h++) {
         // S^{4h} from s4, s8, s16
-        float2 hi = make_float2(1.f, 0.f);
+        v2f hi = (v2f){1.f, 0.f};
         if (h & 1) hi = s4;
-        if (h & 2) hi = (h & 1) ? cmul(hi, s8) : s8;
-        if (h & 4) hi = (h & 3) ? cmul(hi, s16) : s16;
+        if (h & 2) hi = (h & 1) ? pk_cmul(hi, s8) : s8;
+        if (h & 4) hi = (h & 3) ? pk_cmul(hi, s16) : s16;
 #pragma unroll
         for (int l = 0; l < 4; l++) {
           int const n1 = 4 * h + l;
-          float2 const p = h ? cmul(lo[l], hi) : lo[l];
-          v[rfft::bitrev5(n1)] = cmul(x[512 * n1], p);
+          v2f const p = h ? pk_cmul(lo[l], hi) : lo[l];
+          v[rfft::bitrev5(n1)] = pk_cmul(ld2(x + 512 * n1), p);
         }
       }
     } else {
@@ -113,72 +131,67 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
         double const rr = old ? hr : r;
         double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
         if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
-        v[rfft::bitrev5(n1)] = cmul(x[512 * n1], phasor_turns(turns));
+        v[rfft::bitrev5(n1)] = pk_cmul(ld2(x + 512 * n1), phasor2(turns));
       }
     }
   }
 
   // ---------------- pass 1: 32-point transforms over n1, twiddle W_N^{t k1}
-  rfft::fft_dit<32>(v);
-  twiddle32(v, tw, sh, t);
+  rfft::fft_dit_pk<32>(v);
+  twiddle32(v, tab + kTabLo1 + t, tab + kTabHi1 + t, kT);
 
-  // ---------------- transpose 1: [k1][t] -> thread (k1 = t >> 4, n3 = t & 15) gathers n2 = 0..31
-  float2 u[32];
+  // ---------------- transpose 1: [k1][t] -> thread (k1 = t >> 4, n3 = t & 15) gathers n2 = 0..31.
+  // Half round A carries k1 < 16 (read by threads t < 256), half round B the rest.
+  v2f u[32];
   {
-    int const rd = (t >> 4) * kRow1 + (t & 15);
+    int const rd = ((t >> 4) & 15) * kRow1 + (t & 15);
 #pragma unroll
-    for (int k1 = 0; k1 < 32; k1++) xch[k1 * kRow1 + t] = v[k1].x;
-    __syncthreads();
+    for (int half = 0; half < 2; half++) {
 #pragma unroll
-    for (int n2 = 0; n2 < 32; n2++) u[rfft::bitrev5(n2)].x = xch[rd + 16 * n2];
-    __syncthreads();
+      for (int k1 = 0; k1 < 16; k1++) xch[k1 * kRow1 + t] = make_float2(v[16 * half + k1].x, v[16 * half + k1].y);
+      __syncthreads();
+      if ((t >> 8) == half) {
 #pragma unroll
-    for (int k1 = 0; k1 < 32; k1++) xch[k1 * kRow1 + t] = v[k1].y;
-    __syncthreads();
-#pragma unroll
-    for (int n2 = 0; n2 < 32; n2++) u[rfft::bitrev5(n2)].y = xch[rd + 16 * n2];
-    __syncthreads();
+        for (int n2 = 0; n2 < 32; n2++) u[rfft::bitrev5(n2)] = ld2(xch + rd + 16 * n2);
+      }
+      __syncthreads();
+    }
   }
 
   // ---------------- pass 2: 32-point transforms over n2, twiddle W_512^{n3 k2} = W_N^{32 n3 k2}
-  rfft::fft_dit<32>(u);
-  twiddle32(u, tw, sh, 32 * (t & 15));
+  rfft::fft_dit_pk<32>(u);
+  twiddle32(u, tab + kTabLo2 + (t & 15), tab + kTabHi2 + (t & 15), 16);
 
-  // ---------------- transpose 2: [n3][32 k1 + k2] -> thread (k1 = t >> 5 (+16), k2 = t & 31) gathers n3 = 0..15
-  float2 ya[16], yb[16];
+  // ---------------- transpose 2: [n3][k1][k2] -> thread (k1 = t >> 5 (+16), k2 = t & 31) gathers n3 = 0..15.
+  // Half round A is written by the threads holding k1 < 16 (t < 256) and yields ya, half round B yields yb.
+  v2f ya[16], yb[16];
   {
-    int const wr = (t & 15) * kRow2 + (t >> 4) * 32;
+    int const wr = (t & 15) * kRow2 + ((t >> 4) & 15) * kCol2;
+    int const rd = (t >> 5) * kCol2 + (t & 31);
 #pragma unroll
-    for (int k2 = 0; k2 < 32; k2++) xch[wr + k2] = u[k2].x;
-    __syncthreads();
+    for (int half = 0; half < 2; half++) {
+      if ((t >> 8) == half) {
 #pragma unroll
-    for (int n3 = 0; n3 < 16; n3++) {
-      ya[rfft::bitrev4(n3)].x = xch[n3 * kRow2 + t];
-      yb[rfft::bitrev4(n3)].x = xch[n3 * kRow2 + t + 512];
+        for (int k2 = 0; k2 < 32; k2++) xch[wr + k2] = make_float2(u[k2].x, u[k2].y);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int n3 = 0; n3 < 16; n3++) (half ? yb : ya)[rfft::bitrev4(n3)] = ld2(xch + n3 * kRow2 + rd);
+      __syncthreads();
     }
-    __syncthreads();
-#pragma unroll
-    for (int k2 = 0; k2 < 32; k2++) xch[wr + k2] = u[k2].y;
-    __syncthreads();
-#pragma unroll
-    for (int n3 = 0; n3 < 16; n3++) {
-      ya[rfft::bitrev4(n3)].y = xch[n3 * kRow2 + t];
-      yb[rfft::bitrev4(n3)].y = xch[n3 * kRow2 + t + 512];
-    }
-    __syncthreads();
   }
 
   // ---------------- pass 3: 16-point transforms over n3.  ya[k3] = X[ka + 1024 k3], yb[k3] = X[kb + 1024 k3]
-  rfft::fft_dit<16>(ya);
-  rfft::fft_dit<16>(yb);
+  rfft::fft_dit_pk<16>(ya);
+  rfft::fft_dit_pk<16>(yb);
   int const ka = (t >> 5) + 32 * (t & 31), kb = ka + 16;  // k1 + 32 k2 with k1 = t >> 5 and 16 + (t >> 5)
 
   if (spec_dump != nullptr && c == spec_ch) {
     float2 *o = spec_dump + (size_t)b * kN;
 #pragma unroll
     for (int k3 = 0; k3 < 16; k3++) {
-      o[ka + 1024 * k3] = ya[k3];
-      o[kb + 1024 * k3] = yb[k3];
+      o[ka + 1024 * k3] = make_float2(ya[k3].x, ya[k3].y);
+      o[kb + 1024 * k3] = make_float2(yb[k3].x, yb[k3].y);
     }
   }
 
@@ -187,17 +200,20 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     float const low = ch.low[c], high = ch.high[c];
     unsigned incl_a = 0, incl_b = 0;  // bit k3: bin outside the passband
     float pa[16], pb[16];
+    // The reference forms k*samprate in int (radio.c:407,409) with k the signed bin: keep its 32-bit wrap.
+    // n*samprate - (n > N/2 ? N*samprate : 0) modulo 2^32, built by additions from the thread's first bin.
+    unsigned const sr = (unsigned)g.samprate;
+    unsigned const prod_a0 = (unsigned)ka * sr, prod_b0 = (unsigned)kb * sr;
 #pragma unroll
     for (int k3 = 0; k3 < 16; k3++) {
-      pa[k3] = cnrm(ya[k3]);
-      pb[k3] = cnrm(yb[k3]);
+      pa[k3] = ya[k3].x * ya[k3].x + ya[k3].y * ya[k3].y;
+      pb[k3] = yb[k3].x * yb[k3].x + yb[k3].y * yb[k3].y;
 #pragma unroll
       for (int half = 0; half < 2; half++) {
-        int const n = (half ? kb : ka) + 1024 * k3;
-        int const k = (n <= kN / 2) ? n : n - kN;
-        // the reference forms k*samprate in int (radio.c:407,409): keep its 32-bit wrap
-        int const prod = (int)((unsigned)k * (unsigned)g.samprate);
-        float const f = (float)prod / kN;
+        // n = k + 1024 k3 <= N/2  <=>  k3 < 8, or k3 == 8 and k == 0 (only ka can be 0)
+        bool const neg = k3 > 8 || (k3 == 8 && (half || ka != 0));
+        unsigned const prod = (half ? prod_b0 : prod_a0) + (unsigned)(1024 * k3) * sr - (neg ? (unsigned)kN * sr : 0u);
+        float const f = (float)(int)prod / kN;
         if (!(f >= low && f <= high)) (half ? incl_b : incl_a) |= 1u << k3;
       }
     }
@@ -224,14 +240,16 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   }
 
   // ---------------- slave (filter.c:206-250): the N/D bins it reads go to LDS as Xs[p], p = k mod N_dec
-  float2 *Xs = reinterpret_cast<float2 *>(xch);
+  float2 *Xs = xch;
   float2 *G = Xs + Ndec;
 #pragma unroll
   for (int k3 = 0; k3 < 16; k3++) {
+    // bins of this k3 lie in [1024 k3, 1024 k3 + 1023]: skip the rows that cannot hold a bin the slave reads
+    if (1024 * k3 > Ndec / 2 && 1024 * k3 + 1023 <= kN - Ndec / 2) continue;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       int const n = (half ? kb : ka) + 1024 * k3;
-      float2 const val = half ? yb[k3] : ya[k3];
+      float2 const val = half ? make_float2(yb[k3].x, yb[k3].y) : make_float2(ya[k3].x, ya[k3].y);
       if (n <= Ndec / 2)
         Xs[n] = val;
       else if (n > kN - Ndec / 2)
@@ -263,20 +281,56 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
 
 bool full16k_supported(const Geom &g) {
   // the epilogue keeps Xs[N_dec] and G[N_dec] in the exchange buffer
-  return g.N == kN && (size_t)2 * g.Ndec * sizeof(float2) <= (size_t)kPlane * sizeof(float) && g.Ndec >= 4;
+  return g.N == kN && 2 * g.Ndec <= kXchElems && g.Ndec >= 4;
+}
+
+// The twiddle tables depend on nothing but N: one copy per device, built on first use.
+static const float2 *twiddle_tables() {
+  static std::mutex mu;
+  static float2 *tabs[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (tabs[dev]) return tabs[dev];
+  std::vector<float2> h(kTabSize);
+  auto w = [](long long e) {
+    double const ang = -2.0 * M_PI * (double)(e % kN) / kN;
+    return make_float2((float)cos(ang), (float)sin(ang));
+  };
+  for (int t = 0; t < kT; t++) {
+    for (int l = 1; l < 4; l++) h[kTabLo1 + (l - 1) * kT + t] = w((long long)l * t);
+    for (int hh = 1; hh < 8; hh++) h[kTabHi1 + (hh - 1) * kT + t] = w(4LL * hh * t);
+  }
+  for (int n3 = 0; n3 < 16; n3++) {
+    for (int l = 1; l < 4; l++) h[kTabLo2 + (l - 1) * 16 + n3] = w(32LL * l * n3);
+    for (int hh = 1; hh < 8; hh++) h[kTabHi2 + (hh - 1) * 16 + n3] = w(128LL * hh * n3);
+  }
+  float2 *d = nullptr;
+  if (hipMalloc(&d, h.size() * sizeof(float2)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(d);
+    return nullptr;
+  }
+  tabs[dev] = d;
+  return d;
 }
 
 void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
                            const int *chan_list) {
-  size_t const lds_bytes = (size_t)kPlane * sizeof(float);
+  size_t const lds_bytes = (size_t)kXchElems * sizeof(float2);
   static bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute((const void *)k_filter_full16k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     configured = true;
   }
-  hipLaunchKernelGGL(k_filter_full16k, dim3(nchan, nblocks), dim3(kT), lds_bytes, s, g, ch, pl, window, tw, compute_n0,
-                     spec_dump, spec_ch, chan_list);
+  const float2 *tab = twiddle_tables();
+  if (!tab) {  // cannot happen short of an allocation failure: fall back to the LDS kernel rather than fail the block
+    launch_filter_full(s, g, ch, pl, window, tw, nchan, nblocks, compute_n0, spec_dump, spec_ch, chan_list);
+    return;
+  }
+  hipLaunchKernelGGL(k_filter_full16k, dim3(nchan, nblocks), dim3(kT), lds_bytes, s, g, ch, pl, window, tw, tab,
+                     compute_n0, spec_dump, spec_ch, chan_list);
 }
 
 }  // namespace kq

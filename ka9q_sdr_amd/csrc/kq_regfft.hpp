@@ -82,5 +82,48 @@ __device__ __forceinline__ void fft_dit(float2 (&v)[NP]) {
   stage<NP, 32>(v, pairs{});
 }
 
+// ---- packed variant: a complex value is one 2-vector, so that a butterfly is three v_pk_fma_f32 (two for the
+// trivial twiddles) instead of six scalar FMAs.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// a * b, complex
+__device__ __forceinline__ v2f pk_cmul(v2f a, v2f b) { return pk_fma((v2f){-a.y, a.y}, b.yx, a.xx * b); }
+
+template <int NP, int LEN, int I>
+__device__ __forceinline__ void bfly_pk(v2f (&v)[NP]) {
+  constexpr int half = LEN / 2, base = (I / half) * LEN, j = I % half;
+  constexpr int t = j * (64 / LEN);
+  v2f const a = v[base + j], b = v[base + j + half];
+  if constexpr (t == 0) {
+    v[base + j] = a + b;
+    v[base + j + half] = a - b;
+  } else if constexpr (t == 16) {  // w = -i
+    v2f const r = (v2f){b.y, -b.x};
+    v[base + j] = a + r;
+    v[base + j + half] = a - r;
+  } else {
+    constexpr float wr = tw_re(t, 64), wi = tw_im(t, 64);
+    v2f const u = pk_fma((v2f){-wi, wi}, b.yx, pk_fma((v2f){wr, wr}, b, a));
+    v[base + j] = u;
+    v[base + j + half] = pk_fma((v2f){2.f, 2.f}, a, -u);
+  }
+}
+
+template <int NP, int LEN, int... I>
+__device__ __forceinline__ void stage_pk(v2f (&v)[NP], std::integer_sequence<int, I...>) {
+  if constexpr (LEN <= NP) (bfly_pk<NP, LEN, I>(v), ...);
+}
+
+template <int NP>
+__device__ __forceinline__ void fft_dit_pk(v2f (&v)[NP]) {
+  using pairs = std::make_integer_sequence<int, NP / 2>;
+  stage_pk<NP, 2>(v, pairs{});
+  stage_pk<NP, 4>(v, pairs{});
+  stage_pk<NP, 8>(v, pairs{});
+  stage_pk<NP, 16>(v, pairs{});
+  stage_pk<NP, 32>(v, pairs{});
+}
+
 }  // namespace rfft
 }  // namespace kq

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round profile: rocprofv3 --kernel-trace --stats of the default bench (pruned headline + compute_n0 row), of the
+# full-spectrum path, of the half-band cascade, and the FETCH_SIZE / WRITE_SIZE PMC passes of the headline kernel.
+# Usage on the GPU box: bash tools/profile_round.sh r01     (writes gpurun_out/profiles_<tag>/; copy into profiles/<tag>/)
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+run_stats() {  # name, program args...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats -d $OUT/raw_$name -o $name --output-format csv -- python3 "$@" > $OUT/${name}_bench.json 2> $OUT/${name}.err
+  local f=$(find $OUT/raw_$name -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $OUT/${name}_kernel_stats.csv
+}
+run_stats pruned_cfg4 $R/bench.py --steps 10 --cpu-seconds 4
+run_stats full_n0_cfg4 $R/bench.py --steps 5 --n0 1 --no-cpu-baseline
+run_stats full_cfg2 $R/bench.py --steps 10 --config cfg2 --no-cpu-baseline --no-n0-row
+run_stats pruned_cfg3 $R/bench.py --steps 10 --config cfg3 --no-cpu-baseline --no-n0-row
+run_stats stream_cfg5 $R/bench.py --steps 10 --config cfg5 --blocks 16 --no-cpu-baseline --no-n0-row
+run_stats decim_log6 $R/tools/bench_decim.py
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $OUT/raw_pmc_$c -o pmc_$c --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-n0-row > $OUT/pmc_$c.log 2>&1
+done
+F=$(find $OUT/raw_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
+W=$(find $OUT/raw_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python3 $R/tools/pmc_summary.py $F $W $OUT/pmc_pruned_cfg4.json k_pruned cfg4 1024 64 pruned > /dev/null
+rm -rf $OUT/raw_*
+ls -la $OUT
+for f in $OUT/*_bench.json; do echo "== $f"; tail -1 $f | cut -c1-600; done

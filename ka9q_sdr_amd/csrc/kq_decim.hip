@@ -40,7 +40,7 @@ struct GroupArgs {
   const float2 *hist;  // the `halo` samples preceding in[0]
   float2 *out;         // n_out complex samples (scaled by `scale` when final)
   int16_t *out16;      // final group only, may be null: interleaved I,Q int16
-  float *partial;      // final group only: per-workgroup energy
+  float *partial;      // final group only: per-tile energy
   long long n_out;
   int nstages;
   unsigned hb15_mask;  // bit s set: stage s of this group is the 15-tap filter, else 1-2-1
@@ -321,6 +321,37 @@ __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
       }
     }
   }
+
+  if constexpr (EDGE) {
+    // Carry for the next call: the last `halo` samples of hist ++ in replace the history, in place -- this
+    // workgroup is the only one that reads it (tile 0), and it has.
+    long long const n_in = a.n_out << G;
+    float2 hv = make_float2(0.f, 0.f);
+    if (tid < a.halo) {
+      long long const gi = n_in - a.halo + tid;
+      hv = gi >= 0 ? a.in[gi] : a.hist[a.halo + gi];
+    }
+    __syncthreads();
+    if (tid < a.halo) const_cast<float2 *>(a.hist)[tid] = hv;
+  }
+}
+
+// Output energy (hackrf.c:308,325): the per-tile partials added in a fixed order.  (Doing this in the group kernel
+// behind a "last workgroup" counter was measured slower: the release fence it needs writes back the L2 under every
+// workgroup's output stores.)
+__global__ __launch_bounds__(kThreads) void k_hb_energy(const float *__restrict__ partial, int n, float *out) {
+  __shared__ double dsum[kThreads / 64];
+  int const tid = threadIdx.x;
+  double acc = 0;
+  for (int i = tid; i < n; i += kThreads) acc += partial[i];
+  for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((tid & 63) == 0) dsum[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    double e = 0;
+    for (int w = 0; w < kThreads / 64; w++) e += dsum[w];
+    *out = (float)e;
+  }
 }
 
 template <int G, bool FINAL, bool PAIR, bool ROT>
@@ -365,28 +396,12 @@ void launch_group(const GroupArgs &a, unsigned grid, size_t lds_bytes, hipStream
   }
 }
 
-// new_hist[i] = sample (n_in - halo + i) of the stream hist ++ in
-__global__ void k_hb_history(const float2 *in, const float2 *hist, float2 *new_hist, long long n_in, int halo) {
-  int const i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= halo) return;
-  long long const gi = n_in - halo + i;
-  new_hist[i] = gi >= 0 ? in[gi] : hist[halo + gi];
-}
-
-__global__ void k_hb_energy(const float *partial, int n, float *out) {
-  // one wave, fixed order
-  double t = 0;
-  for (int i = threadIdx.x; i < n; i += 64) t += partial[i];
-  for (int off = 32; off; off >>= 1) t += __shfl_xor(t, off);
-  if (threadIdx.x == 0) *out = (float)t;
-}
-
 struct Group {
   int nstages = 0;
   unsigned mask = 0;
   int halo = 0;
   int shift_in = 0;  // log2(input rate / final output rate)
-  float2 *hist[2] = {nullptr, nullptr};
+  float2 *hist = nullptr;  // the `halo` input samples preceding the next call
   float2 *out = nullptr;  // intermediate buffer (null for the last group)
 };
 
@@ -397,7 +412,6 @@ struct kq_decimator {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::vector<Group> groups;
-  int cur = 0;  // which hist buffer is live
   int rot_phase = 0;
   float atten = 1;
   float coeffs[4];
@@ -450,10 +464,8 @@ static int decim_alloc(kq_decimator *d) {
     for (int s = g.nstages - 1; s >= 0; s--) need = 2 * need + ((g.mask >> s) & 1 ? 14 : 1);
     g.halo = need;
     done += g.nstages;
-    for (int k = 0; k < 2; k++) {
-      DEC_TRY(hipMalloc(&g.hist[k], sizeof(float2) * need));
-      DEC_TRY(hipMemsetAsync(g.hist[k], 0, sizeof(float2) * need, d->stream));
-    }
+    DEC_TRY(hipMalloc(&g.hist, sizeof(float2) * need));
+    DEC_TRY(hipMemsetAsync(g.hist, 0, sizeof(float2) * need, d->stream));
     if (done < S) DEC_TRY(hipMalloc(&g.out, sizeof(float2) * (c.max_out << (S - done))));
     d->groups.push_back(g);
   }
@@ -490,8 +502,7 @@ int kq_decim_destroy(kq_decimator *d) {
   if (!d) return -1;
   if (d->stream) (void)hipStreamSynchronize(d->stream);
   for (Group &g : d->groups) {
-    (void)hipFree(g.hist[0]);
-    (void)hipFree(g.hist[1]);
+    (void)hipFree(g.hist);
     (void)hipFree(g.out);
   }
   (void)hipFree(d->in_dev);
@@ -537,14 +548,13 @@ int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t 
     final_out = d->out_dev;
     final16 = out_s16 ? d->out16_dev : nullptr;
   }
-  int const cur = d->cur, nxt = cur ^ 1;
   size_t n_g_in = n_in;
   for (size_t gi = 0; gi < d->groups.size(); gi++) {
     Group &g = d->groups[gi];
     bool const last = gi + 1 == d->groups.size();
     GroupArgs a{};
     a.in = src;
-    a.hist = g.hist[cur];
+    a.hist = g.hist;
     a.out = last ? final_out : g.out;
     a.out16 = last ? final16 : nullptr;
     a.partial = last ? d->partial : nullptr;
@@ -569,17 +579,14 @@ int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t 
     unsigned const resident = std::max(1u, std::min(16u, (unsigned)(160 * 1024 / (sizeof(float2) * lds_elems + 64))));
     unsigned const grid = std::min(ntiles, d->num_cus * resident) + 1;  // + the edge workgroup
     launch_group(a, grid, sizeof(float2) * lds_elems, d->stream);
-    hipLaunchKernelGGL(k_hb_history, dim3((g.halo + 127) / 128), dim3(128), 0, d->stream, src, g.hist[cur], g.hist[nxt],
-                       (long long)n_g_in, g.halo);
     src = g.out;
     n_g_in >>= g.nstages;
   }
   DEC_TRY(hipGetLastError());
-  d->cur = nxt;
   d->rot_phase = (int)((d->rot_phase + (long long)(n_in & 3) * (d->cfg.offset & 3)) & 3);
   if (out_energy) {
     unsigned const np = (unsigned)((n_out + kTileOut - 1) / kTileOut);
-    hipLaunchKernelGGL(k_hb_energy, dim3(1), dim3(64), 0, d->stream, d->partial, (int)np, d->energy_dev);
+    hipLaunchKernelGGL(k_hb_energy, dim3(1), dim3(kThreads), 0, d->stream, d->partial, (int)np, d->energy_dev);
     if (on_device)
       DEC_TRY(hipMemcpyAsync(out_energy, d->energy_dev, sizeof(float), hipMemcpyDeviceToDevice, d->stream));
     else
@@ -603,7 +610,7 @@ int kq_decim_sync(kq_decimator *d) {
 int kq_decim_reset(kq_decimator *d) {
   if (!d) return -1;
   for (Group &g : d->groups)
-    for (int k = 0; k < 2; k++) DEC_TRY(hipMemsetAsync(g.hist[k], 0, sizeof(float2) * g.halo, d->stream));
+    DEC_TRY(hipMemsetAsync(g.hist, 0, sizeof(float2) * g.halo, d->stream));
   d->rot_phase = 0;
   return 0;
 }

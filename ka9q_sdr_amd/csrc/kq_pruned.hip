@@ -40,15 +40,17 @@ namespace kq {
 
 namespace {
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
+// Complex products and butterflies go through 2-vectors so that they become v_pk_fma_f32 / v_pk_mul_f32
+__device__ __forceinline__ rfft::v2f as_v2f(float2 a) { return (rfft::v2f){a.x, a.y}; }
+__device__ __forceinline__ float2 as_f2(rfft::v2f a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return as_f2(rfft::pk_cmul(as_v2f(a), as_v2f(b))); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 // a + b*c
 __device__ __forceinline__ float2 cfma(float2 b, float2 c, float2 a) {
-  return make_float2(fmaf(-b.y, c.y, fmaf(b.x, c.x, a.x)), fmaf(b.y, c.x, fmaf(b.x, c.y, a.y)));
+  rfft::v2f const bb = as_v2f(b), cc = as_v2f(c);
+  return as_f2(rfft::pk_fma((rfft::v2f){-bb.y, bb.y}, cc.yx, rfft::pk_fma(bb.xx, cc, as_v2f(a))));
 }
 
 using rfft::bitrev5;
@@ -56,7 +58,14 @@ using rfft::kPi;
 using rfft::tw_im;
 using rfft::tw_re;
 // 32-point forward FFT in registers (kq_regfft.hpp): sample a goes in at v[bitrev5(a)], bin q' comes out in v[q']
-__device__ __forceinline__ void fft32_dit(float2 (&v)[32]) { rfft::fft_dit<32>(v); }
+__device__ __forceinline__ void fft32_dit(float2 (&v)[32]) {
+  rfft::v2f w[32];
+#pragma unroll
+  for (int i = 0; i < 32; i++) w[i] = as_v2f(v[i]);
+  rfft::fft_dit_pk<32>(w);
+#pragma unroll
+  for (int i = 0; i < 32; i++) v[i] = as_f2(w[i]);
+}
 
 // ---- per-channel tables (floats).  ND = 64: A is merged per pass, [2][32] float4 = (A[a] w, A[a+32] w') with the
 // pass twiddle folded in.  ND = 128: A only, [32][4] float2 = A[a' + 32 s]; the radix-4 factor (-i)^{s p} is a

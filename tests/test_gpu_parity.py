@@ -129,9 +129,43 @@ def test_config_geometry_full(gpu, name, nchan):
     plan = wl.channel_plan(name, nchan)
     nblocks = 4
     iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=7)
-    want = run_oracle(plan, g, iq, nblocks)
-    got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_FULL, per_call=4)
-    _compare(plan, got, want)
+    # compute_n0 on: at these sample rates k*samprate overflows the reference's int (radio.c:407), so this also
+    # pins the wrapped passband mask of the full-spectrum kernel
+    want = run_oracle(plan, g, iq, nblocks, compute_n0=1)
+    got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_FULL, compute_n0=True, per_call=4)
+    _compare(plan, got, want, check_n0=True)
+
+
+def test_full_size_pruned_and_full_spectrum_agree_on_every_channel(gpu):
+    """BASELINE configs[2] at its full size (1024 mixed channels): the pruned kernel and the full-spectrum kernel
+    are independent implementations of the same filter; every channel must agree between them to the parity
+    tolerance, with identical sample counts and squelch decisions."""
+    g = wl.GEOMETRY["cfg3"]
+    plan = wl.channel_plan("cfg3", g["channels"])
+    nblocks = 6
+    iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=21)
+    res = {}
+    for mode in (kq.KQ_FWD_PRUNED, kq.KQ_FWD_FULL):
+        bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], len(plan), nblocks, fwd_mode=mode)
+        for p in plan:
+            bank.add_channel(bank_cfg(p))
+        bank.push_iq(iq)
+        assert bank.process() == nblocks
+        assert bank.fwd_mode == mode
+        res[mode] = [([bank.audio(c, b) for b in range(nblocks)], [bank.status(c, b) for b in range(nblocks)])
+                     for c in range(len(plan))]
+        bank.close()
+    worst = 0.0
+    for c, p in enumerate(plan):
+        (a0, s0), (a1, s1) = res[kq.KQ_FWD_PRUNED][c], res[kq.KQ_FWD_FULL][c]
+        for b in range(nblocks):
+            assert s0[b]["nout"] == s1[b]["nout"] and s0[b]["squelch_count"] == s1[b]["squelch_count"], (c, b)
+            assert s0[b]["blanked"] == s1[b]["blanked"] and s0[b]["hangcount"] == s1[b]["hangcount"], (c, b)
+        sk = 1 if p["demod"] == "linear" else 0          # AGC start-up on numerically-zero samples, see _compare
+        e = rel_rms(np.concatenate(a0[sk:]), np.concatenate(a1[sk:]))
+        worst = max(worst, e)
+        assert e < AUDIO_TOL, (c, p["demod"], e)
+    assert worst > 0          # two different code paths, not one result read twice
 
 
 def test_int16_ingest_and_zero_fill(gpu):

@@ -193,6 +193,30 @@ int upload(kq_bank *b, void *dst, const void *src, size_t bytes) {
   return 0;
 }
 
+// compute_n0's passband exclusion (radio.c:405-411) depends only on the channel's filter edges: one bit per bin,
+// in the order k_filter_full16k holds the bins (thread t: bins ka + 1024 k3 in bits 0..15, ka + 16 + 1024 k3 in
+// bits 16..31, ka = (t >> 5) + 32 (t & 31)).  Same arithmetic as the kernel's fallback, int wrap included.
+int upload_n0mask(kq_bank *b, int c) {
+  if (!b->chd.n0mask) return 0;
+  kq::Geom const &g = b->g;
+  float const low = b->chans[c].cfg.low, high = b->chans[c].cfg.high;
+  std::vector<unsigned> m(512, 0u);
+  for (int t = 0; t < 512; t++) {
+    int const ka = (t >> 5) + 32 * (t & 31);
+    for (int half = 0; half < 2; half++)
+      for (int k3 = 0; k3 < 16; k3++) {
+        int const n = ka + 16 * half + 1024 * k3;
+        int const k = (n <= g.N / 2) ? n : n - g.N;
+        int const prod = (int)((unsigned)k * (unsigned)g.samprate);
+        float const f = (float)prod / g.N;
+        if (!(f >= low && f <= high)) m[t] |= 1u << (16 * half + k3);
+      }
+  }
+  if (upload(b, b->chd.n0mask + (size_t)c * 512, m.data(), m.size() * sizeof(unsigned))) return -1;
+  HIP_TRY(hipStreamSynchronize(b->stream));  // `m` is about to die
+  return 0;
+}
+
 // Derived per-channel constants, as each demod thread computes them in its prologue
 int upload_channel(kq_bank *b, int c) {
   if (sync_all(b)) return -1;  // quiesce both streams before touching per-channel state
@@ -225,6 +249,7 @@ int upload_channel(kq_bank *b, int c) {
   if (upload(b, b->chd.gain + c, &init_gain, sizeof(float))) return -1;
   if (upload(b, b->chd.n0 + c, &nan, sizeof(float))) return -1;
   if (upload(b, b->chd.fm_state + c, &one, sizeof(float2))) return -1;
+  if (upload_n0mask(b, c)) return -1;
   if (sync_all(b)) return -1;  // also: the demod stream may still be reading the old parameters
   return 0;
 }
@@ -634,6 +659,8 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.recovery, C);
   rc |= dev_alloc(&b->chd.hangmax, C);
   rc |= dev_alloc(&b->chd.noise_gain, C);
+  b->chd.n0mask = nullptr;
+  if (b->cfg.compute_n0 && kq::full16k_supported(g)) rc |= dev_alloc(&b->chd.n0mask, C * 512);
   for (int k = 0; k < 2; k++) rc |= dev_alloc(&b->osc_dev2[k], 8 * C);
   b->chd.lo_phase = b->chd.lo_freq = b->chd.lo_rate = b->chd.sh_phase = b->chd.sh_freq = nullptr;  // set per call
   b->chd.hist_phase = b->chd.hist_freq = b->chd.hist_rate = nullptr;
@@ -735,7 +762,7 @@ int kq_bank_destroy(kq_bank *b) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->stream2 && b->stream2 != b->stream) (void)hipStreamSynchronize(b->stream2);
   void *ptrs[] = {b->ring[0], b->ring[1], b->tw, b->chan_tw, b->chd.mode, b->chd.flags, b->chd.low, b->chd.high, b->chd.resp,
-                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain,
+                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.n0mask,
                   b->osc_dev2[0], b->osc_dev2[1], b->chd.fm_state,
                   b->chd.lastaudio, b->chd.sq_count, b->chd.ahist, b->chd.foffset, b->chd.pdev, b->chd.gain, b->chd.hang,
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
@@ -888,6 +915,7 @@ int kq_bank_set_filter(kq_bank *b, int ch, float low, float high, float beta) {
   if (upload(b, b->chd.low + ch, &low, sizeof(float))) return -1;
   if (upload(b, b->chd.high + ch, &high, sizeof(float))) return -1;
   if (upload(b, b->chd.fm_gain + ch, &fm_gain, sizeof(float))) return -1;
+  if (upload_n0mask(b, ch)) return -1;
   return upload_response(b, ch);
 }
 

@@ -49,6 +49,7 @@ struct ChanDev {
   float *recovery;      // am.c:27 / linear.c:34 recovery_factor
   int *hangmax;
   float *noise_gain;
+  unsigned *n0mask;     // [C][512] compute_n0 passband mask in k_filter_full16k's bin order (null: computed in the kernel)
   // oscillator phase (turns), step (cycles/sample) and sweep (cycles/sample^2) at sample 0 of the
   // first window of the call; second LO and Doppler already summed (they multiply, so phases add)
   double *lo_phase, *lo_freq, *lo_rate;

@@ -200,21 +200,31 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     float const low = ch.low[c], high = ch.high[c];
     unsigned incl_a = 0, incl_b = 0;  // bit k3: bin outside the passband
     float pa[16], pb[16];
-    // The reference forms k*samprate in int (radio.c:407,409) with k the signed bin: keep its 32-bit wrap.
-    // n*samprate - (n > N/2 ? N*samprate : 0) modulo 2^32, built by additions from the thread's first bin.
-    unsigned const sr = (unsigned)g.samprate;
-    unsigned const prod_a0 = (unsigned)ka * sr, prod_b0 = (unsigned)kb * sr;
 #pragma unroll
     for (int k3 = 0; k3 < 16; k3++) {
       pa[k3] = ya[k3].x * ya[k3].x + ya[k3].y * ya[k3].y;
       pb[k3] = yb[k3].x * yb[k3].x + yb[k3].y * yb[k3].y;
+    }
+    if (ch.n0mask) {
+      // precomputed per channel on the host (kq_bank.cpp upload_n0mask): it depends only on the filter edges
+      unsigned const m = ch.n0mask[(size_t)c * kT + t];
+      incl_a = m & 0xffffu;
+      incl_b = m >> 16;
+    } else {
+      // The reference forms k*samprate in int (radio.c:407,409) with k the signed bin: keep its 32-bit wrap.
+      // n*samprate - (n > N/2 ? N*samprate : 0) modulo 2^32, built by additions from the thread's first bin.
+      unsigned const sr = (unsigned)g.samprate;
+      unsigned const prod_a0 = (unsigned)ka * sr, prod_b0 = (unsigned)kb * sr;
 #pragma unroll
-      for (int half = 0; half < 2; half++) {
-        // n = k + 1024 k3 <= N/2  <=>  k3 < 8, or k3 == 8 and k == 0 (only ka can be 0)
-        bool const neg = k3 > 8 || (k3 == 8 && (half || ka != 0));
-        unsigned const prod = (half ? prod_b0 : prod_a0) + (unsigned)(1024 * k3) * sr - (neg ? (unsigned)kN * sr : 0u);
-        float const f = (float)(int)prod / kN;
-        if (!(f >= low && f <= high)) (half ? incl_b : incl_a) |= 1u << k3;
+      for (int k3 = 0; k3 < 16; k3++) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+          // n = k + 1024 k3 <= N/2  <=>  k3 < 8, or k3 == 8 and k == 0 (only ka can be 0)
+          bool const neg = k3 > 8 || (k3 == 8 && (half || ka != 0));
+          unsigned const prod = (half ? prod_b0 : prod_a0) + (unsigned)(1024 * k3) * sr - (neg ? (unsigned)kN * sr : 0u);
+          float const f = (float)(int)prod / kN;
+          if (!(f >= low && f <= high)) (half ? incl_b : incl_a) |= 1u << k3;
+        }
       }
     }
     float avg = INFINITY;

@@ -99,6 +99,18 @@ kq_cdouble step_osc(struct osc *osc);
 void renorm_osc(struct osc *osc);
 int is_phasor_init(kq_cdouble x);
 
+/* filter.h:95-105, filter.c:549-571: experimental IIR complex notch (its only call site, radio.c, is #if 0'd in the
+ * reference; host scalar code here as there) */
+struct notchfilter {
+  kq_cdouble osc_phase; /* phase of the local complex mixer */
+  kq_cdouble osc_step;  /* mixer phase increment */
+  kq_cfloat dcstate;    /* average signal at the mixer frequency */
+  float bw;             /* relative bandwidth of the notch */
+};
+struct notchfilter *notch_create(double f, float bw);
+#define notch_delete(x) free(x)
+kq_cfloat notch(struct notchfilter *nf, kq_cfloat s);
+
 /* dsp.h:20-31 */
 kq_cfloat csincosf(float x);
 kq_cfloat csincospif(float x);

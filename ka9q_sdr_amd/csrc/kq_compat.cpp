@@ -395,6 +395,45 @@ kq_cdouble csincos(double x) {
   return z;
 }
 kq_cdouble csincospi(double x) { return csincos(x * M_PI); }
+// filter.c:551-571.  Mixed float/double complex arithmetic as C evaluates it: the products with the double phasor
+// are formed in double and rounded to float on assignment.
+struct notchfilter *notch_create(double f, float bw) {
+  struct notchfilter *nf = (struct notchfilter *)calloc(1, sizeof(struct notchfilter));
+  if (!nf) return nullptr;
+  __real__ nf->osc_phase = 1;
+  __imag__ nf->osc_phase = 0;
+  nf->osc_step = csincospi(2 * f);
+  __real__ nf->dcstate = 0;
+  __imag__ nf->dcstate = 0;
+  nf->bw = bw;
+  return nf;
+}
+
+kq_cfloat notch(struct notchfilter *nf, kq_cfloat s) {
+  kq_cfloat r;
+  if (!nf) {
+    __real__ r = NAN;
+    __imag__ r = 0;
+    return r;
+  }
+  double const pr = __real__ nf->osc_phase, pi = __imag__ nf->osc_phase;
+  double const sr = __real__ s, si = __imag__ s;
+  // s = s * conj(osc_phase) - dcstate
+  float const dr = (float)((sr * pr + si * pi) - (double)__real__ nf->dcstate);
+  float const di = (float)((si * pr - sr * pi) - (double)__imag__ nf->dcstate);
+  // dcstate += bw * s
+  __real__ nf->dcstate = __real__ nf->dcstate + nf->bw * dr;
+  __imag__ nf->dcstate = __imag__ nf->dcstate + nf->bw * di;
+  // s *= osc_phase
+  __real__ r = (float)((double)dr * pr - (double)di * pi);
+  __imag__ r = (float)((double)dr * pi + (double)di * pr);
+  // osc_phase *= osc_step
+  double const tr = __real__ nf->osc_step, ti = __imag__ nf->osc_step;
+  __real__ nf->osc_phase = pr * tr - pi * ti;
+  __imag__ nf->osc_phase = pr * ti + pi * tr;
+  return r;
+}
+
 float cnrmf(kq_cfloat x) { return __real__ x * __real__ x + __imag__ x * __imag__ x; }
 double cnrm(kq_cdouble x) { return __real__ x * __real__ x + __imag__ x * __imag__ x; }
 

@@ -290,3 +290,30 @@ int kqo_set_filter(kqo_filter_out *s, float low, float high, float beta){
   free(old);
   return 0;
 }
+
+/* ---- experimental IIR complex notch: filter.c:549-571 ---- */
+kqo_notch *kqo_notch_create(double f, float bw){
+  kqo_notch *nf = calloc(1, sizeof *nf);
+  if(!nf)
+    return NULL;
+  nf->osc_phase = 1;
+  nf->osc_step = cos(2 * f * M_PI) + I * sin(2 * f * M_PI);   /* csincospi(2*f), dsp.c:45-50 */
+  nf->dcstate = 0;
+  nf->bw = bw;
+  return nf;
+}
+
+float complex kqo_notch_step(kqo_notch *nf, float complex s){
+  if(!nf)
+    return NAN;
+  s = s * conj(nf->osc_phase) - nf->dcstate;
+  nf->dcstate += nf->bw * s;
+  s *= nf->osc_phase;
+  nf->osc_phase *= nf->osc_step;
+  return s;
+}
+
+void kqo_notch_run(kqo_notch *nf, const float complex *in, float complex *out, int n){
+  for(int i = 0; i < n; i++)
+    out[i] = kqo_notch_step(nf, in[i]);
+}

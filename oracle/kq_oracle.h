@@ -102,6 +102,16 @@ int kqo_window_rfilter(int L, int M, float complex *response, float beta);
 int kqo_set_filter(kqo_filter_out *s, float low, float high, float beta);
 float kqo_noise_gain(const kqo_filter_out *s);
 
+/* experimental IIR complex notch (filter.h:95-105, filter.c:549-571) */
+typedef struct {
+  double complex osc_phase, osc_step;
+  float complex dcstate;
+  float bw;
+} kqo_notch;
+kqo_notch *kqo_notch_create(double f, float bw);
+float complex kqo_notch_step(kqo_notch *nf, float complex s);
+void kqo_notch_run(kqo_notch *nf, const float complex *in, float complex *out, int n);
+
 /* ---------- One receiver channel: radio.c:41-150,383-425; fm.c; am.c; linear.c ---------- */
 enum kqo_demod { KQO_LINEAR = 0, KQO_AM = 1, KQO_FM = 2 };   /* radio.h:20-24 */
 

@@ -124,6 +124,9 @@ def lib():
     L.kqo_delete_filter_input.argtypes = [C.c_void_p]
     L.kqo_delete_filter_output.argtypes = [C.c_void_p]
     L.kqo_set_filter.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    L.kqo_notch_create.restype = C.c_void_p
+    L.kqo_notch_create.argtypes = [C.c_double, C.c_float]
+    L.kqo_notch_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.kqo_crc_good.argtypes = [C.c_char_p, C.c_int]
     L.kqo_afsk_create.restype = C.c_void_p
     L.kqo_afsk_destroy.argtypes = [C.c_void_p]
@@ -336,6 +339,17 @@ class Afsk:
         self.L.kqo_afsk_state(self.h, *[C.byref(v) for v in i], *[C.byref(v) for v in f])
         return dict(symphase=i[0].value, frame_bit=i[1].value, flagsync=i[2].value, ones=i[3].value,
                     last_val=f[0].value, mid_val=f[1].value)
+
+
+def notch_run(f, bw, x):
+    """filter.c:549-571 over a complex64 array (fresh filter state)."""
+    L = lib()
+    nf = L.kqo_notch_create(f, bw)
+    x = np.ascontiguousarray(x, np.complex64)
+    y = np.empty_like(x)
+    L.kqo_notch_run(nf, x.ctypes.data, y.ctypes.data, len(x))
+    C.CDLL(None).free(C.c_void_p(nf))
+    return y
 
 
 def crc_good(frame):

@@ -100,3 +100,32 @@ def test_host_design_entry_points(lib):
     assert lib.window_filter(128, 129, r.ctypes.data, 3.0) == 0
     ko.lib().kqo_window_filter(128, 129, r2.ctypes.data, 3.0)
     assert np.abs(r - r2).max() / np.abs(r2).max() < 1e-6
+
+
+def test_headers_are_valid_c():
+    """The boundary is a C ABI: both headers must compile as plain C (gnu11, the reference's dialect)."""
+    import subprocess
+    import tempfile
+    inc = os.path.join(ROOT, "include")
+    for body in ('#include "ka9q_hip.h"\nint f(void){ kq_bank_config c = {0}; return c.device; }\n',
+                 '#include "ka9q_hip_compat.h"\nint f(void){ struct osc o; struct notchfilter n; (void)o; (void)n; return 0; }\n',
+                 '#include "ka9q_hip.h"\n#include "ka9q_hip_compat.h"\nint f(void){ return 0; }\n'):
+        with tempfile.NamedTemporaryFile("w", suffix=".c", delete=False) as t:
+            t.write(body)
+        r = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", t.name],
+                           capture_output=True, text=True)
+        os.unlink(t.name)
+        assert r.returncode == 0, r.stderr
+
+
+def test_c_example_builds_against_the_library():
+    """examples/radio_bank.c compiles and links against libka9q_hip.so with gcc (running it needs the GPU)."""
+    import subprocess
+    import tempfile
+    lib = os.path.join(ROOT, "ka9q_sdr_amd", "lib")
+    out = os.path.join(tempfile.gettempdir(), "kq_radio_bank_example")
+    r = subprocess.run(["gcc", "-std=gnu11", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "radio_bank.c"), "-L", lib, "-lka9q_hip",
+                        "-Wl,-rpath," + lib, "-lm", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    os.unlink(out)

@@ -1,0 +1,27 @@
+"""The C example (examples/radio_bank.c) built with gcc against the C ABI and run on the GPU: a known FM signal
+must come back with its deviation (fm.c:146-158)."""
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_radio_bank_c_example_runs(gpu):
+    lib = os.path.join(ROOT, "ka9q_sdr_amd", "lib")
+    out = os.path.join(tempfile.gettempdir(), "kq_radio_bank_example_%d" % os.getpid())
+    r = subprocess.run(["gcc", "-std=gnu11", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "radio_bank.c"), "-L", lib, "-lka9q_hip", "-Wl,-rpath," + lib,
+                        "-lm", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    try:
+        run = subprocess.run([out], capture_output=True, text=True, timeout=300)
+    finally:
+        os.unlink(out)
+    assert run.returncode == 0, run.stdout + run.stderr
+    lines = run.stdout.strip().splitlines()
+    assert lines[-1] == "ok"
+    assert sum(1 for ln in lines if ln.startswith("block ")) == 4

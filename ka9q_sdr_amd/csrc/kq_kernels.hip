@@ -306,6 +306,11 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
   int *LV = reinterpret_cast<int *>(AIN + AN);
   int *PV = LV + olen;
   float2 *PLB = reinterpret_cast<float2 *>(PV + olen);  // PL slave transform buffer, pl_n points
+  // One wave walks the blocks of its channel in sequence, so every global round trip inside the loop is exposed
+  // latency: the AN-point twiddles and the de-emphasis response are staged in LDS once, and the next block's
+  // samples are fetched while the current one is processed.
+  float2 *TWL = PLB + g.pl_n;      // exp(-2 pi i k / AN), k < AN/2
+  float2 *HAL = TWL + AN / 2;      // audio response, AN/2 + 1 bins
   bool const pl_on = g.pl_n > 0 && pl.plout != nullptr;
   int log2pl = 0;
   while ((1 << log2pl) < g.pl_n) log2pl++;
@@ -319,17 +324,43 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
   float foffset = ch.foffset[c], pdev = ch.pdev[c];
   float *hist = ch.ahist + (size_t)c * (AM - 1);
   for (int i = lane; i < AM - 1; i += 64) AIN[i] = hist[i];
+  for (int k = lane; k < AN / 2; k += 64) TWL[k] = tw[(size_t)k << (g.tw_log2 - g.log2Ndec)];
+  for (int k = lane; k <= AN / 2; k += 64) HAL[k] = HA[k];
+  constexpr int kPre = 4;  // samples per lane prefetched in registers (olen <= 256); longer blocks load in place
+  bool const prefetch = olen <= 64 * kPre;
+  float2 nxt[kPre];
+  if (prefetch && nblocks > 0) {
+    const float2 *in0 = pl.filt + (size_t)c * g.max_blocks * olen;
+#pragma unroll
+    for (int j = 0; j < kPre; j++) nxt[j] = (lane + 64 * j < olen) ? in0[lane + 64 * j] : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
 
   for (int b = 0; b < nblocks; b++) {
     const float2 *in = pl.filt + ((size_t)c * g.max_blocks + b) * olen;
+    float2 cur[kPre];
+    if (prefetch) {
+#pragma unroll
+      for (int j = 0; j < kPre; j++) cur[j] = nxt[j];
+      if (b + 1 < nblocks) {
+#pragma unroll
+        for (int j = 0; j < kPre; j++) nxt[j] = (lane + 64 * j < olen) ? in[olen + lane + 64 * j] : make_float2(0.f, 0.f);
+      }
+    }
     // amplitude statistics (fm.c:91-103)
     float sum_t = 0, sum_a = 0;
-    for (int n = lane; n < olen; n += 64) {
-      float2 const s = in[n];
-      S[n] = s;
-      float const t = cnrm(s);
+    auto take = [&](int n, float2 sv) {
+      S[n] = sv;
+      float const t = cnrm(sv);
       sum_t += t;
       sum_a += sqrtf(t);
+    };
+    if (prefetch) {
+#pragma unroll
+      for (int j = 0; j < kPre; j++)
+        if (lane + 64 * j < olen) take(lane + 64 * j, cur[j]);
+    } else {
+      for (int n = lane; n < olen; n += 64) take(n, in[n]);
     }
     sum_t = wave_sum(sum_t);
     sum_a = wave_sum(sum_a);
@@ -425,7 +456,7 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
     float *aud = pl.audio + ((size_t)c * g.max_blocks + b) * (2 * (size_t)olen);
     if (!flat || pl_on) {  // forward transform of the audio master (fm.c:162, filter.c:151)
       for (int i = lane; i < AN; i += 64) F[bitrev((unsigned)i, g.log2Ndec)] = make_float2(AIN[i], 0.f);
-      lds_fft<-1>(F, g.log2Ndec, tw, g.tw_log2);
+      lds_fft<-1>(F, g.log2Ndec, TWL, g.log2Ndec);
     }
     if (pl_on) {
       // PL slave: REAL -> REAL, decimate 32 (fm.c:219,234; filter.c:206-208 then c2r of pl_n points)
@@ -439,7 +470,7 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
         }
         PLB[bitrev((unsigned)k, log2pl)] = gk;
       }
-      lds_fft<+1>(PLB, log2pl, tw, g.tw_log2);
+      lds_fft<+1>(PLB, log2pl, TWL, g.log2Ndec);
       float *po = pl.plout + ((size_t)c * g.max_blocks + b) * g.pl_l;
       for (int n = lane; n < g.pl_l; n += 64) po[n] = PLB[PN - g.pl_l + n].x;  // filter.c:140
       __syncthreads();
@@ -448,7 +479,7 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
       // multiply DC..Nyquist (filter.c:206-208) and Hermitian-extend for the c2r transform, which
       // ignores the imaginary parts of DC and Nyquist.  Lane k touches only F[k] and F[AN-k].
       for (int k = lane; k <= AN / 2; k += 64) {
-        float2 const gk = cmul(HA[k], F[k]);
+        float2 const gk = cmul(HAL[k], F[k]);
         if (k == 0 || k == AN / 2) {
           F[k] = make_float2(gk.x, 0.f);
         } else {
@@ -466,7 +497,7 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
           F[r] = t;
         }
       }
-      lds_fft<+1>(F, g.log2Ndec, tw, g.tw_log2);
+      lds_fft<+1>(F, g.log2Ndec, TWL, g.log2Ndec);
       for (int n = lane; n < AL; n += 64) aud[n] = F[AN - AL + n].x * gain;  // fm.c:169-170
     } else {
       for (int n = lane; n < AL; n += 64) aud[n] = OUT[n];
@@ -713,7 +744,8 @@ void launch_pl_track(hipStream_t s, const Geom &g, const ChanDev &ch, const Plan
 void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_fm,
                    int n_fm, const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0) {
   if (n_fm > 0) {
-    size_t const lds_bytes = (size_t)g.olen * (8 + 4 + 4 + 4 + 4) + (size_t)g.Ndec * (8 + 4) + (size_t)g.pl_n * 8;
+    size_t const lds_bytes = (size_t)g.olen * (8 + 4 + 4 + 4 + 4) + (size_t)g.Ndec * (8 + 4) + (size_t)g.pl_n * 8 +
+                             (size_t)(g.Ndec / 2) * 8 + (size_t)(g.Ndec / 2 + 1) * 8;
     static size_t configured = 0;
     if (lds_bytes > configured) {
       (void)hipFuncSetAttribute((const void *)k_demod_fm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -11,6 +11,7 @@
 // Blocks of one channel are processed in sequence with the state carried in registers, and written back
 // to HBM at the end of the launch.
 #include "kq_device.hpp"
+#include "kq_lane.hpp"
 
 namespace kq {
 
@@ -26,23 +27,45 @@ __device__ __forceinline__ float cnrm(float2 a) { return a.x * a.x + a.y * a.y; 
 __device__ __forceinline__ float2 shfl2(float2 v, int src) {
   return make_float2(__shfl(v.x, src, 64), __shfl(v.y, src, 64));
 }
-__device__ __forceinline__ float2 shfl2_xor(float2 v, int m) {
-  return make_float2(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64));
+template <int M>
+__device__ __forceinline__ float2 xor2(float2 v, int lane) {
+  return make_float2(lane_xor<M>(v.x, lane), lane_xor<M>(v.y, lane));
+}
+// lane ^ (1 << s) with s a constant after unrolling
+__device__ __forceinline__ float2 xor2_pow(float2 v, int s, int lane) {
+  switch (s) {
+    case 0: return xor2<1>(v, lane);
+    case 1: return xor2<2>(v, lane);
+    case 2: return xor2<4>(v, lane);
+    case 3: return xor2<8>(v, lane);
+    case 4: return xor2<16>(v, lane);
+    default: return xor2<32>(v, lane);
+  }
+}
+// value of a wave-uniform lane
+__device__ __forceinline__ float rdlane(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+// butterfly reductions over the 64 lanes, every lane gets the result
+template <class Op>
+__device__ __forceinline__ float wreduce(float v, Op op) {
+  int const lane = threadIdx.x & 63;
+  v = op(v, lane_xor<32>(v, lane));
+  v = op(v, lane_xor<16>(v, lane));
+  v = op(v, lane_xor<8>(v, lane));
+  v = op(v, lane_xor<4>(v, lane));
+  v = op(v, lane_xor<2>(v, lane));
+  v = op(v, lane_xor<1>(v, lane));
+  return v;
 }
 __device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return wreduce(v, [](float a, float b) { return a + b; });
 }
 __device__ __forceinline__ float wmax(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  return wreduce(v, [](float a, float b) { return fmaxf(a, b); });
 }
 __device__ __forceinline__ float wmin(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
+  return wreduce(v, [](float a, float b) { return fminf(a, b); });
 }
 __device__ __forceinline__ int bitrev6(int i) { return (int)(__brev((unsigned)i) >> 26); }
 
@@ -66,14 +89,25 @@ __device__ __forceinline__ void put_status(kq_chan_status &st, const Geom &g, co
   }
 }
 
-__device__ void fm_channel(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
+// What the discriminator half of a block (fm.c:91-160) leaves behind for the status record
+struct FmStats {
+  float bb, snr, foffset, pdev;
+  int sq, blanked;
+};
+
+// Software-pipelined over the blocks of the channel: the loop body holds the discriminator of block b+1 and the
+// de-emphasis filter of block b.  The only loop-carried chain (squelch counter, previous sample, last good audio
+// value) runs through the discriminator; the filter hangs off it.  The discriminator is written without branches
+// (the squelch decision selects its results) so that both halves sit in one basic block and the scheduler can
+// interleave their shuffle chains -- with one wave per SIMD there is nothing else to hide that latency behind.
+template <bool FLAT>
+__device__ void fm_channel_t(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
   int const lane = threadIdx.x & 63;
   bool const upper = lane >= 32;
   int const n = lane - 32;
-  bool const flat = (ch.flags[c] & FLAG_FLAT) != 0;
   float const gain = ch.fm_gain[c];
   int const kbin = bitrev6(lane);
-  float2 const HA = (!flat && kbin <= 32) ? ch.aresp[(size_t)c * 33 + kbin] : make_float2(0.f, 0.f);
+  float2 const HA = (!FLAT && kbin <= 32) ? ch.aresp[(size_t)c * 33 + kbin] : make_float2(0.f, 0.f);
   int const herm_src = bitrev6((64 - kbin) & 63);
 
   // per-lane stage twiddles: forward DIF (half = 32..1) and inverse DIT (half = 1..32)
@@ -93,12 +127,13 @@ __device__ void fm_channel(const Geom &g, const ChanDev &ch, const Planes &pl, i
   float foffset = ch.foffset[c], pdev = ch.pdev[c];
   float n0 = ch.n0[c];
   float hist = upper ? 0.f : ch.ahist[(size_t)c * 32 + lane];
-
+  float const noise_gain = ch.noise_gain[c];
+  float ifp_v = 0.f, n0raw_v = 0.f;
   const float2 *in = pl.filt + (size_t)c * g.max_blocks * 32;
-  float2 s_next = upper ? in[n] : make_float2(0.f, 0.f);
-  for (int b = 0; b < nblocks; b++) {
-    float2 const S = s_next;
-    if (b + 1 < nblocks) s_next = upper ? in[(size_t)(b + 1) * 32 + n] : make_float2(0.f, 0.f);
+
+  // discriminator of one block (fm.c:91-160): S = this lane's sample (upper lanes), returns the audio sample before
+  // de-emphasis and updates the carried state
+  auto discriminate = [&](float2 S, FmStats &st) -> float {
     float const t = upper ? cnrm(S) : 0.f;
     float const sum_t = wsum(t), sum_a = wsum(sqrtf(t));
     float const bb = sum_t / 64.f;                                   // / (2*olen), fm.c:99
@@ -106,59 +141,62 @@ __device__ void fm_channel(const Geom &g, const ChanDev &ch, const Planes &pl, i
     float const variance = bb - amp * amp;
     float snr = amp * amp / (2 * variance) - 1;
     snr = (0.0f > snr) ? 0.0f : snr;
-    if (snr > 2) {
-      sq = 0;
-    } else if (++sq > 1000) {
-      sq = 1000;
-    }
-    float out = 0.f;
-    int blanked = 0;
-    if (sq < 2) {
-      float const thr = (float)(0.55 * 0.55 * amp * amp);
-      bool const valid = upper && t > thr;
-      unsigned long long const mask = __ballot(valid);
-      unsigned long long const below = mask & ((1ull << lane) - 1ull);
-      unsigned long long const upto = mask & ((2ull << lane) - 1ull);
-      int const pv = below ? 63 - __clzll((long long)below) : -1;
-      int const lv = upto ? 63 - __clzll((long long)upto) : -1;
-      float2 const sp = shfl2(S, pv >= 0 ? pv : 0);
-      float2 const st = pv >= 0 ? cconj(sp) : state;
-      float2 const pr = cmul(S, st);
-      float const y = valid ? atan2f(pr.y, pr.x) : 0.f;
-      float const yl = __shfl(y, lv >= 0 ? lv : 0, 64);
-      out = upper ? (lv >= 0 ? yl : lastaudio) : 0.f;
-      float const sum_y = wsum(out);
-      float const vmax = wmax((valid && n > 0) ? y : -INFINITY);
-      float const vmin = wmin((valid && n > 0) ? y : INFINITY);
-      float const y0 = __shfl(y, 32, 64);
-      float const seed = ((mask >> 32) & 1ull) ? y0 : 0.f;
-      blanked = 32 - __popcll(mask);
-      if (mask) {
-        int const last = 63 - __clzll((long long)mask);
-        state = cconj(shfl2(S, last));
-        lastaudio = __shfl(y, last, 64);
-      }
-      float pdev_pos = fmaxf(seed, vmax), pdev_neg = fminf(seed, vmin);
-      float const avg_f = sum_y / 32.f;
-      if (sq < 1) {
-        foffset = (float)(g.dsamprate * avg_f * (0.5 * M_1_PI));
-        pdev_pos -= avg_f;
-        pdev_neg -= avg_f;
-        float const mx = (pdev_pos > -pdev_neg) ? pdev_pos : -pdev_neg;
-        pdev = (float)(g.dsamprate * mx * (0.5 * M_1_PI));
-      }
-    } else {
-      state = make_float2(0.f, 0.f);
-      lastaudio = 0.f;
-    }
-    // post-detection overlap-save: [history | block] across the 64 lanes
+    int nsq = sq + 1;                                                // fm.c:108-114
+    nsq = nsq > 1000 ? 1000 : nsq;
+    sq = (snr > 2) ? 0 : nsq;
+    bool const open = sq < 2;
+    // fm.c:117-154, evaluated unconditionally; `open` selects
+    float const thr = (float)(0.55 * 0.55 * amp * amp);
+    bool const valid = upper && t > thr;
+    unsigned long long const mask = __ballot(valid);
+    unsigned long long const below = mask & ((1ull << lane) - 1ull);
+    unsigned long long const upto = mask & ((2ull << lane) - 1ull);
+    int const pv = below ? 63 - __clzll((long long)below) : -1;
+    int const lv = upto ? 63 - __clzll((long long)upto) : -1;
+    float2 const sp = shfl2(S, pv >= 0 ? pv : 0);
+    float2 const stc = pv >= 0 ? cconj(sp) : state;
+    float2 const pr = cmul(S, stc);
+    float const y = valid ? atan2f(pr.y, pr.x) : 0.f;
+    float const yl = __shfl(y, lv >= 0 ? lv : 0, 64);
+    float const out_open = upper ? (lv >= 0 ? yl : lastaudio) : 0.f;
+    float const sum_y = wsum(out_open);
+    float const vmax = wmax((valid && n > 0) ? y : -INFINITY);
+    float const vmin = wmin((valid && n > 0) ? y : INFINITY);
+    float const y0 = rdlane(y, 32);
+    float const seed = ((mask >> 32) & 1ull) ? y0 : 0.f;
+    int const last = mask ? 63 - __clzll((long long)mask) : 0;
+    float2 const s_last = cconj(make_float2(rdlane(S.x, last), rdlane(S.y, last)));
+    float const y_last = rdlane(y, last);
+    // carried state: open and something valid -> last valid sample; open and nothing valid -> unchanged;
+    // squelched -> reset (fm.c:156-160)
+    bool const any = mask != 0;
+    state = open ? (any ? s_last : state) : make_float2(0.f, 0.f);
+    lastaudio = open ? (any ? y_last : lastaudio) : 0.f;
+    float pdev_pos = fmaxf(seed, vmax), pdev_neg = fminf(seed, vmin);
+    float const avg_f = sum_y / 32.f;
+    pdev_pos -= avg_f;
+    pdev_neg -= avg_f;
+    float const mx = (pdev_pos > -pdev_neg) ? pdev_pos : -pdev_neg;
+    bool const upd = sq < 1;                                          // fm.c:146
+    foffset = upd ? (float)(g.dsamprate * avg_f * (0.5 * M_1_PI)) : foffset;
+    pdev = upd ? (float)(g.dsamprate * mx * (0.5 * M_1_PI)) : pdev;
+    st.bb = bb;
+    st.snr = snr;
+    st.foffset = foffset;
+    st.pdev = pdev;
+    st.sq = sq;
+    st.blanked = open ? 32 - __popcll(mask) : 0;
+    return open ? out_open : 0.f;
+  };
+
+  // de-emphasis overlap-save of one block (fm.c:162-171): [history | block] across the 64 lanes
+  auto deemphasize = [&](float out, int b, const FmStats &st) {
     float audio = out;
-    if (!flat) {
+    if (!FLAT) {
       float2 z = make_float2(upper ? out : hist, 0.f);
 #pragma unroll
       for (int s = 5; s >= 0; s--) {  // forward, decimation in frequency: natural in, bit-reversed out
-        int const half = 1 << s;
-        float2 const r = shfl2_xor(z, half);
+        float2 const r = xor2_pow(z, s, lane);
         z = ((lane >> s) & 1) ? cmul(csub(r, z), wf[s]) : cadd(z, r);
       }
       float2 gk = cmul(HA, z);  // bins 0..32 (filter.c:206-208); zero elsewhere
@@ -168,30 +206,59 @@ __device__ void fm_channel(const Geom &g, const ChanDev &ch, const Planes &pl, i
       z = gk;
 #pragma unroll
       for (int s = 0; s < 6; s++) {  // backward, decimation in time: bit-reversed in, natural out
-        int const half = 1 << s;
         int const bit = (lane >> s) & 1;
         float2 const v = bit ? cmul(z, wi[s]) : z;
-        float2 const r = shfl2_xor(v, half);
+        float2 const r = xor2_pow(v, s, lane);
         z = bit ? csub(r, v) : cadd(v, r);
       }
       audio = z.x * gain;  // fm.c:169-170
     }
     if (upper) pl.audio[((size_t)c * g.max_blocks + b) * 64 + n] = audio;
-    hist = __shfl(out, lane + 32, 64);  // lanes 0..31 take this block as the next history (filter.c:168)
-    if (lane == 0) {
-      kq_chan_status st;
-      put_status(st, g, ch, pl, c, b, compute_n0, .01f, n0);
-      st.bb_power = bb;
-      st.snr = snr;
-      st.foffset = foffset;
-      st.pdeviation = pdev;
-      st.agc_gain = 0;
-      st.squelch_count = sq;
-      st.hangcount = 0;
-      st.blanked = blanked;
-      st.nout = 32;
-      pl.status[(size_t)c * g.max_blocks + b] = st;
+    hist = lane_xor<32>(out, lane);  // lanes 0..31 take this block as the next history (filter.c:168)
+    // per-block inputs of the status record come out of registers (lane b & 63 holds block b's values): a global
+    // load here would stall this in-order wave for a full memory round trip per block
+    if ((b & 63) == 0) {
+      int const bb = b + lane;
+      ifp_v = bb < nblocks ? pl.if_power[bb] : 0.f;
+      n0raw_v = (compute_n0 && bb < nblocks) ? pl.n0raw[(size_t)c * g.max_blocks + bb] : 0.f;
     }
+    float const ifp = rdlane(ifp_v, b & 63), fresh = rdlane(n0raw_v, b & 63);
+    if (compute_n0) n0 = isnan(n0) ? fresh : n0 + .01f * (fresh - n0);  // fm.c:79-82
+    if (lane == 0) {
+      kq_chan_status rec;
+      rec.if_power = ifp;
+      rec.noise_gain = noise_gain;
+      rec.plfreq = NAN;  // N/D = 64: the PL slave would have 2 points (fm.c:203), measurement off
+      rec.cphase = 0;
+      rec.pll_lock = 0;
+      rec.lock_count = 0;
+      rec.n0 = compute_n0 ? n0 : NAN;
+      rec.bb_power = st.bb;
+      rec.snr = st.snr;
+      rec.foffset = st.foffset;
+      rec.pdeviation = st.pdev;
+      rec.agc_gain = 0;
+      rec.squelch_count = st.sq;
+      rec.hangcount = 0;
+      rec.blanked = st.blanked;
+      rec.nout = 32;
+      pl.status[(size_t)c * g.max_blocks + b] = rec;
+    }
+  };
+
+  if (nblocks > 0) {
+    FmStats st_cur, st_next;
+    float2 s_next = (upper && nblocks > 1) ? in[32 + n] : make_float2(0.f, 0.f);
+    float out_cur = discriminate(upper ? in[n] : make_float2(0.f, 0.f), st_cur);
+    for (int b = 0; b + 1 < nblocks; b++) {
+      float2 const S = s_next;
+      if (b + 2 < nblocks) s_next = upper ? in[(size_t)(b + 2) * 32 + n] : make_float2(0.f, 0.f);
+      float const out_next = discriminate(S, st_next);
+      deemphasize(out_cur, b, st_cur);
+      out_cur = out_next;
+      st_cur = st_next;
+    }
+    deemphasize(out_cur, nblocks - 1, st_cur);
   }
   if (!upper) ch.ahist[(size_t)c * 32 + lane] = hist;
   if (lane == 0) {
@@ -202,6 +269,13 @@ __device__ void fm_channel(const Geom &g, const ChanDev &ch, const Planes &pl, i
     ch.pdev[c] = pdev;
     ch.n0[c] = n0;
   }
+}
+
+__device__ void fm_channel(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
+  if (ch.flags[c] & FLAG_FLAT)
+    fm_channel_t<true>(g, ch, pl, c, nblocks, compute_n0);
+  else
+    fm_channel_t<false>(g, ch, pl, c, nblocks, compute_n0);
 }
 
 // AM / linear: one wave per channel, one lane per sample, two consecutive blocks per iteration (lanes 0-31 and

@@ -1,0 +1,26 @@
+#!/bin/bash
+# SQ counters of one kernel (substring match), one small pass per counter group (no trace domains with --pmc).
+#   bash tools/pmc_sq.sh k_pruned_resident bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-n0-row
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+K=$1; shift
+PROG=$1; shift
+OUT=$R/gpurun_out/pmc_sq_$K
+rm -rf $OUT; mkdir -p $OUT
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM SQ_WAVES"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp -d $OUT/p$i -o p$i --output-format csv -- python3 $R/$PROG "$@" > $OUT/p$i.log 2>&1
+done
+python3 - <<PY
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "$K" in r["Kernel_Name"]:
+            agg[r["Kernel_Name"].split("(")[0][-48:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in agg.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print("   %-28s %14.0f  (n=%d)" % (c, sum(v) / len(v), len(v)))
+PY

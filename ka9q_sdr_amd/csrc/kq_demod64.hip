@@ -1,11 +1,11 @@
 // kq_demod64.hip -- demodulators specialised for N/D = 64, olen = 32 (BASELINE configs 3 and 4).
 //
 // One launch serves all three demodulator types (workgroup ranges by type) so they overlap on the chip.
-//   FM     : one wave per channel, one lane per sample; everything stays in registers: amplitude statistics
-//            by wave reductions, the "hold last good sample" rule of fm.c:128-144 through a ballot mask
-//            (previous valid sample = highest set bit below the lane), and the REAL->REAL de-emphasis
-//            overlap-save (fm.c:162-171) as 64-point transforms across the 64 lanes (history in lanes 0-31,
-//            the new block in lanes 32-63).  No LDS, no barriers.
+//   FM     : one wave per channel, one lane per sample, two blocks per iteration; everything stays in registers:
+//            amplitude statistics by half-wave reductions, the "hold last good sample" rule of fm.c:128-144
+//            through a ballot mask (previous valid sample = highest set bit below the lane), and the REAL->REAL
+//            de-emphasis overlap-save (fm.c:162-171) of both blocks as ONE complex 64-point transform pair
+//            across the 64 lanes.  No LDS, no barriers; lane exchanges by DPP / v_permlane (kq_lane.hpp).
 //   AM/lin : one wave per channel, one lane per sample (two blocks per iteration); only the AGC recurrence
 //            (am.c:55-75, linear.c:251-281) is serial, wave-uniform through v_readlane.
 // Blocks of one channel are processed in sequence with the state carried in registers, and written back
@@ -46,27 +46,6 @@ __device__ __forceinline__ float2 xor2_pow(float2 v, int s, int lane) {
 __device__ __forceinline__ float rdlane(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
-// butterfly reductions over the 64 lanes, every lane gets the result
-template <class Op>
-__device__ __forceinline__ float wreduce(float v, Op op) {
-  int const lane = threadIdx.x & 63;
-  v = op(v, lane_xor<32>(v, lane));
-  v = op(v, lane_xor<16>(v, lane));
-  v = op(v, lane_xor<8>(v, lane));
-  v = op(v, lane_xor<4>(v, lane));
-  v = op(v, lane_xor<2>(v, lane));
-  v = op(v, lane_xor<1>(v, lane));
-  return v;
-}
-__device__ __forceinline__ float wsum(float v) {
-  return wreduce(v, [](float a, float b) { return a + b; });
-}
-__device__ __forceinline__ float wmax(float v) {
-  return wreduce(v, [](float a, float b) { return fmaxf(a, b); });
-}
-__device__ __forceinline__ float wmin(float v) {
-  return wreduce(v, [](float a, float b) { return fminf(a, b); });
-}
 __device__ __forceinline__ int bitrev6(int i) { return (int)(__brev((unsigned)i) >> 26); }
 
 __device__ __forceinline__ void put_status(kq_chan_status &st, const Geom &g, const ChanDev &ch, const Planes &pl, int c, int b,
@@ -89,35 +68,54 @@ __device__ __forceinline__ void put_status(kq_chan_status &st, const Geom &g, co
   }
 }
 
-// What the discriminator half of a block (fm.c:91-160) leaves behind for the status record
-struct FmStats {
-  float bb, snr, foffset, pdev;
-  int sq, blanked;
-};
-
-// Software-pipelined over the blocks of the channel: the loop body holds the discriminator of block b+1 and the
-// de-emphasis filter of block b.  The only loop-carried chain (squelch counter, previous sample, last good audio
-// value) runs through the discriminator; the filter hangs off it.  The discriminator is written without branches
-// (the squelch decision selects its results) so that both halves sit in one basic block and the scheduler can
-// interleave their shuffle chains -- with one wave per SIMD there is nothing else to hide that latency behind.
-template <bool FLAT>
-__device__ void fm_channel_t(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
+// reduction over the 32 lanes of each half of the wave (lane bit 5 selects the half), every lane gets its half's result
+template <class Op>
+__device__ __forceinline__ float hreduce(float v, Op op) {
   int const lane = threadIdx.x & 63;
-  bool const upper = lane >= 32;
-  int const n = lane - 32;
-  float const gain = ch.fm_gain[c];
-  int const kbin = bitrev6(lane);
-  float2 const HA = (!FLAT && kbin <= 32) ? ch.aresp[(size_t)c * 33 + kbin] : make_float2(0.f, 0.f);
-  int const herm_src = bitrev6((64 - kbin) & 63);
+  v = op(v, lane_xor<16>(v, lane));
+  v = op(v, lane_xor<8>(v, lane));
+  v = op(v, lane_xor<4>(v, lane));
+  v = op(v, lane_xor<2>(v, lane));
+  v = op(v, lane_xor<1>(v, lane));
+  return v;
+}
+__device__ __forceinline__ float hsum(float v) {
+  return hreduce(v, [](float a, float b) { return a + b; });
+}
 
-  // per-lane stage twiddles: forward DIF (half = 32..1) and inverse DIT (half = 1..32)
+// Two consecutive blocks per iteration: block b in lanes 0-31, block b+1 in lanes 32-63.
+//  * Discriminator (fm.c:91-160): the "previous valid sample" search of fm.c:128-144 runs over the 64-bit ballot, so a
+//    sample of block b+1 finds its predecessor in block b exactly as the carried state of the reference would hand
+//    it over; per-block quantities (amplitude statistics, threshold, squelch, deviation) are reductions over a half.
+//    A squelched block b clears its half of the mask and hands zeros on, as fm.c:156-160 resets the state.
+//  * De-emphasis (fm.c:162-171): the two overlap-save windows [hist | b] and [b | b+1] are real, so they go through
+//    ONE complex 64-point transform as its real and imaginary parts, are separated by the Hermitian symmetry,
+//    multiplied by the response and come back through ONE inverse transform whose real part is the audio of block
+//    b and whose imaginary part is the audio of block b+1.
+// Half the instructions per block of the one-block-per-iteration version, which is what matters with one wave per SIMD.
+template <bool FLAT>
+__device__ void fm_channel_pair(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
+  int const lane = threadIdx.x & 63;
+  int const h = lane >> 5, n = lane & 31;
+  float const gain = ch.fm_gain[c];
+  float const noise_gain = ch.noise_gain[c];
+  int const kbin = bitrev6(lane);
+  int const herm_src = bitrev6((64 - kbin) & 63);
+  // response on every bin: HA[k] up to Nyquist, conj(HA[64-k]) above (the Hermitian extension of the c2r transform)
+  float2 HAf = make_float2(0.f, 0.f);
+  if (!FLAT) {
+    float2 const t = ch.aresp[(size_t)c * 33 + (kbin <= 32 ? kbin : 64 - kbin)];
+    HAf = kbin <= 32 ? t : cconj(t);
+  }
+  bool const real_bin = kbin == 0 || kbin == 32;
+
   float2 wf[6], wi[6];
 #pragma unroll
   for (int s = 0; s < 6; s++) {
     int const half = 1 << s;
     float sn, cs;
     sincospif((float)(lane & (half - 1)) / (float)half, &sn, &cs);
-    wf[s] = make_float2(cs, -sn);  // exp(-2 pi i j / (2 half))
+    wf[s] = make_float2(cs, -sn);
     wi[s] = make_float2(cs, sn);
   }
 
@@ -126,84 +124,113 @@ __device__ void fm_channel_t(const Geom &g, const ChanDev &ch, const Planes &pl,
   int sq = ch.sq_count[c];
   float foffset = ch.foffset[c], pdev = ch.pdev[c];
   float n0 = ch.n0[c];
-  float hist = upper ? 0.f : ch.ahist[(size_t)c * 32 + lane];
-  float const noise_gain = ch.noise_gain[c];
+  float hist = h ? 0.f : ch.ahist[(size_t)c * 32 + lane];  // lanes 0-31: the block before b
   float ifp_v = 0.f, n0raw_v = 0.f;
   const float2 *in = pl.filt + (size_t)c * g.max_blocks * 32;
 
-  // discriminator of one block (fm.c:91-160): S = this lane's sample (upper lanes), returns the audio sample before
-  // de-emphasis and updates the carried state
-  auto discriminate = [&](float2 S, FmStats &st) -> float {
-    float const t = upper ? cnrm(S) : 0.f;
-    float const sum_t = wsum(t), sum_a = wsum(sqrtf(t));
-    float const bb = sum_t / 64.f;                                   // / (2*olen), fm.c:99
+  float2 s_next = (h < nblocks) ? in[lane] : make_float2(0.f, 0.f);
+  for (int b = 0; b < nblocks; b += 2) {
+    bool const have1 = b + 1 < nblocks;
+    float2 const S = s_next;
+    if (b + 2 < nblocks) s_next = (b + 2 + h < nblocks) ? in[(size_t)(b + 2) * 32 + lane] : make_float2(0.f, 0.f);
+    if ((b & 63) == 0) {  // per-block status inputs, lane i holds block b + i
+      int const bb = b + lane;
+      ifp_v = bb < nblocks ? pl.if_power[bb] : 0.f;
+      n0raw_v = (compute_n0 && bb < nblocks) ? pl.n0raw[(size_t)c * g.max_blocks + bb] : 0.f;
+    }
+
+    // ---- amplitude statistics and squelch (fm.c:91-114), per half
+    float const t = cnrm(S);
+    float const sum_t = hsum(t), sum_a = hsum(sqrtf(t));
+    float const bbp = sum_t / 64.f;                                  // / (2*olen), fm.c:99
     float const amp = (float)((double)sum_a / (M_SQRT2 * 32));       // fm.c:100
-    float const variance = bb - amp * amp;
+    float const variance = bbp - amp * amp;
     float snr = amp * amp / (2 * variance) - 1;
     snr = (0.0f > snr) ? 0.0f : snr;
-    int nsq = sq + 1;                                                // fm.c:108-114
+    float const snr0 = rdlane(snr, 0), snr1 = rdlane(snr, 32);
+    int nsq = sq + 1;
     nsq = nsq > 1000 ? 1000 : nsq;
-    sq = (snr > 2) ? 0 : nsq;
-    bool const open = sq < 2;
-    // fm.c:117-154, evaluated unconditionally; `open` selects
+    int const sq0 = (snr0 > 2) ? 0 : nsq;
+    nsq = sq0 + 1;
+    nsq = nsq > 1000 ? 1000 : nsq;
+    int const sq1 = have1 ? ((snr1 > 2) ? 0 : nsq) : sq0;
+    bool const open0 = sq0 < 2, open1 = have1 && sq1 < 2;
+    bool const my_open = h ? open1 : open0;
+
+    // ---- discriminator with hold (fm.c:117-144)
     float const thr = (float)(0.55 * 0.55 * amp * amp);
-    bool const valid = upper && t > thr;
-    unsigned long long const mask = __ballot(valid);
+    unsigned long long const raw = __ballot(t > thr);
+    unsigned long long const m_lo = open0 ? (raw & 0xffffffffull) : 0ull;
+    unsigned long long const m_hi = open1 ? (raw >> 32) : 0ull;
+    unsigned long long const mask = m_lo | (m_hi << 32);
+    bool const valid = (mask >> lane) & 1ull;
     unsigned long long const below = mask & ((1ull << lane) - 1ull);
     unsigned long long const upto = mask & ((2ull << lane) - 1ull);
     int const pv = below ? 63 - __clzll((long long)below) : -1;
     int const lv = upto ? 63 - __clzll((long long)upto) : -1;
+    // with no predecessor in the mask: block b falls back on the carried state, block b+1 on what block b leaves
+    // behind when it has no valid sample either -- the carried state if b is open, zero if it is squelched
+    float2 const state_fb = (h && !open0) ? make_float2(0.f, 0.f) : state;
+    float const la_fb = (h && !open0) ? 0.f : lastaudio;
     float2 const sp = shfl2(S, pv >= 0 ? pv : 0);
-    float2 const stc = pv >= 0 ? cconj(sp) : state;
+    float2 const stc = pv >= 0 ? cconj(sp) : state_fb;
     float2 const pr = cmul(S, stc);
     float const y = valid ? atan2f(pr.y, pr.x) : 0.f;
     float const yl = __shfl(y, lv >= 0 ? lv : 0, 64);
-    float const out_open = upper ? (lv >= 0 ? yl : lastaudio) : 0.f;
-    float const sum_y = wsum(out_open);
-    float const vmax = wmax((valid && n > 0) ? y : -INFINITY);
-    float const vmin = wmin((valid && n > 0) ? y : INFINITY);
-    float const y0 = rdlane(y, 32);
-    float const seed = ((mask >> 32) & 1ull) ? y0 : 0.f;
-    int const last = mask ? 63 - __clzll((long long)mask) : 0;
-    float2 const s_last = cconj(make_float2(rdlane(S.x, last), rdlane(S.y, last)));
-    float const y_last = rdlane(y, last);
-    // carried state: open and something valid -> last valid sample; open and nothing valid -> unchanged;
-    // squelched -> reset (fm.c:156-160)
-    bool const any = mask != 0;
-    state = open ? (any ? s_last : state) : make_float2(0.f, 0.f);
-    lastaudio = open ? (any ? y_last : lastaudio) : 0.f;
+    float const out = my_open ? (lv >= 0 ? yl : la_fb) : 0.f;
+
+    // ---- frequency offset and peak deviation (fm.c:125-154), per half
+    float const sum_y = hsum(out);
+    float const vmax = hreduce((valid && n > 0) ? y : -INFINITY, [](float a, float b2) { return fmaxf(a, b2); });
+    float const vmin = hreduce((valid && n > 0) ? y : INFINITY, [](float a, float b2) { return fminf(a, b2); });
+    float const y_first = h ? rdlane(y, 32) : rdlane(y, 0);
+    float const seed = ((mask >> (32 * h)) & 1ull) ? y_first : 0.f;
     float pdev_pos = fmaxf(seed, vmax), pdev_neg = fminf(seed, vmin);
     float const avg_f = sum_y / 32.f;
     pdev_pos -= avg_f;
     pdev_neg -= avg_f;
     float const mx = (pdev_pos > -pdev_neg) ? pdev_pos : -pdev_neg;
-    bool const upd = sq < 1;                                          // fm.c:146
-    foffset = upd ? (float)(g.dsamprate * avg_f * (0.5 * M_1_PI)) : foffset;
-    pdev = upd ? (float)(g.dsamprate * mx * (0.5 * M_1_PI)) : pdev;
-    st.bb = bb;
-    st.snr = snr;
-    st.foffset = foffset;
-    st.pdev = pdev;
-    st.sq = sq;
-    st.blanked = open ? 32 - __popcll(mask) : 0;
-    return open ? out_open : 0.f;
-  };
+    float const fo_new = (float)(g.dsamprate * avg_f * (0.5 * M_1_PI));
+    float const pd_new = (float)(g.dsamprate * mx * (0.5 * M_1_PI));
+    float const fo0 = (sq0 < 1) ? rdlane(fo_new, 0) : foffset, pd0 = (sq0 < 1) ? rdlane(pd_new, 0) : pdev;
+    float const fo1 = (have1 && sq1 < 1) ? rdlane(fo_new, 32) : fo0, pd1 = (have1 && sq1 < 1) ? rdlane(pd_new, 32) : pd0;
 
-  // de-emphasis overlap-save of one block (fm.c:162-171): [history | block] across the 64 lanes
-  auto deemphasize = [&](float out, int b, const FmStats &st) {
-    float audio = out;
+    // ---- carried state after the pair (fm.c:133-144, 156-160)
+    {
+      int const last0 = m_lo ? 63 - __clzll((long long)m_lo) : 0;
+      int const last1 = m_hi ? 95 - __clzll((long long)m_hi) : 0;
+      float2 const sl0 = cconj(make_float2(rdlane(S.x, last0), rdlane(S.y, last0)));
+      float2 const sl1 = cconj(make_float2(rdlane(S.x, last1), rdlane(S.y, last1)));
+      float const yl0 = rdlane(y, last0), yl1 = rdlane(y, last1);
+      float2 st0 = open0 ? (m_lo ? sl0 : state) : make_float2(0.f, 0.f);
+      float la0 = open0 ? (m_lo ? yl0 : lastaudio) : 0.f;
+      if (have1) {
+        st0 = open1 ? (m_hi ? sl1 : st0) : make_float2(0.f, 0.f);
+        la0 = open1 ? (m_hi ? yl1 : la0) : 0.f;
+      }
+      state = st0;
+      lastaudio = la0;
+    }
+    sq = sq1;
+    foffset = fo1;
+    pdev = pd1;
+
+    // ---- de-emphasis (fm.c:162-171): both windows through one complex transform
+    float const xo = lane_xor<32>(out, lane);  // lanes 0-31: block b+1, lanes 32-63: block b
+    float a0 = out, a1 = xo;                   // flat: lanes 0-31 hold block b, and (after the exchange) block b+1
     if (!FLAT) {
-      float2 z = make_float2(upper ? out : hist, 0.f);
+      float2 z = make_float2(h ? xo : hist, out);  // real: [hist | b], imaginary: [b | b+1]
 #pragma unroll
       for (int s = 5; s >= 0; s--) {  // forward, decimation in frequency: natural in, bit-reversed out
         float2 const r = xor2_pow(z, s, lane);
         z = ((lane >> s) & 1) ? cmul(csub(r, z), wf[s]) : cadd(z, r);
       }
-      float2 gk = cmul(HA, z);  // bins 0..32 (filter.c:206-208); zero elsewhere
-      if (kbin == 0 || kbin == 32) gk.y = 0.f;
-      float2 const mirror = shfl2(gk, herm_src);
-      if (kbin > 32) gk = cconj(mirror);  // Hermitian extension of the c2r transform
-      z = gk;
+      float2 const zm = cconj(shfl2(z, herm_src));  // conj(Z[64 - k])
+      float2 const z1 = make_float2(0.5f * (z.x + zm.x), 0.5f * (z.y + zm.y));     // spectrum of the real part
+      float2 const z2 = make_float2(0.5f * (z.y - zm.y), -0.5f * (z.x - zm.x));    // spectrum of the imaginary part
+      float2 g1 = cmul(HAf, z1), g2 = cmul(HAf, z2);  // filter.c:206-208 on both
+      if (real_bin) g1.y = g2.y = 0.f;                // the c2r transform ignores these imaginary parts
+      z = make_float2(g1.x - g2.y, g1.y + g2.x);      // g1 + j g2
 #pragma unroll
       for (int s = 0; s < 6; s++) {  // backward, decimation in time: bit-reversed in, natural out
         int const bit = (lane >> s) & 1;
@@ -211,20 +238,31 @@ __device__ void fm_channel_t(const Geom &g, const ChanDev &ch, const Planes &pl,
         float2 const r = xor2_pow(v, s, lane);
         z = bit ? csub(r, v) : cadd(v, r);
       }
-      audio = z.x * gain;  // fm.c:169-170
+      // lanes 32-63 hold the kept halves: real part block b, imaginary part block b+1 (fm.c:169-170)
+      a0 = z.x * gain;
+      a1 = z.y * gain;
+      if (h) {
+        pl.audio[((size_t)c * g.max_blocks + b) * 64 + n] = a0;
+        if (have1) pl.audio[((size_t)c * g.max_blocks + b + 1) * 64 + n] = a1;
+      }
+    } else {
+      if (!h) {
+        pl.audio[((size_t)c * g.max_blocks + b) * 64 + n] = a0;
+        if (have1) pl.audio[((size_t)c * g.max_blocks + b + 1) * 64 + n] = a1;
+      }
     }
-    if (upper) pl.audio[((size_t)c * g.max_blocks + b) * 64 + n] = audio;
-    hist = lane_xor<32>(out, lane);  // lanes 0..31 take this block as the next history (filter.c:168)
-    // per-block inputs of the status record come out of registers (lane b & 63 holds block b's values): a global
-    // load here would stall this in-order wave for a full memory round trip per block
-    if ((b & 63) == 0) {
-      int const bb = b + lane;
-      ifp_v = bb < nblocks ? pl.if_power[bb] : 0.f;
-      n0raw_v = (compute_n0 && bb < nblocks) ? pl.n0raw[(size_t)c * g.max_blocks + bb] : 0.f;
+    hist = have1 ? xo : out;  // lanes 0-31: the last block processed becomes the history (filter.c:168)
+
+    // ---- status records: lane 0 writes block b, lane 32 block b+1
+    float const ifp = h ? rdlane(ifp_v, (b + 1) & 63) : rdlane(ifp_v, b & 63);
+    float const fresh0 = rdlane(n0raw_v, b & 63), fresh1 = rdlane(n0raw_v, (b + 1) & 63);
+    float n0a = n0, n0b = n0;
+    if (compute_n0) {  // fm.c:79-82, block after block
+      n0a = isnan(n0) ? fresh0 : n0 + .01f * (fresh0 - n0);
+      n0b = have1 ? (isnan(n0a) ? fresh1 : n0a + .01f * (fresh1 - n0a)) : n0a;
+      n0 = n0b;
     }
-    float const ifp = rdlane(ifp_v, b & 63), fresh = rdlane(n0raw_v, b & 63);
-    if (compute_n0) n0 = isnan(n0) ? fresh : n0 + .01f * (fresh - n0);  // fm.c:79-82
-    if (lane == 0) {
+    if (n == 0 && (h == 0 || have1)) {
       kq_chan_status rec;
       rec.if_power = ifp;
       rec.noise_gain = noise_gain;
@@ -232,35 +270,20 @@ __device__ void fm_channel_t(const Geom &g, const ChanDev &ch, const Planes &pl,
       rec.cphase = 0;
       rec.pll_lock = 0;
       rec.lock_count = 0;
-      rec.n0 = compute_n0 ? n0 : NAN;
-      rec.bb_power = st.bb;
-      rec.snr = st.snr;
-      rec.foffset = st.foffset;
-      rec.pdeviation = st.pdev;
+      rec.n0 = compute_n0 ? (h ? n0b : n0a) : NAN;
+      rec.bb_power = bbp;
+      rec.snr = snr;
+      rec.foffset = h ? fo1 : fo0;
+      rec.pdeviation = h ? pd1 : pd0;
       rec.agc_gain = 0;
-      rec.squelch_count = st.sq;
+      rec.squelch_count = h ? sq1 : sq0;
       rec.hangcount = 0;
-      rec.blanked = st.blanked;
+      rec.blanked = my_open ? 32 - __popcll((mask >> (32 * h)) & 0xffffffffull) : 0;
       rec.nout = 32;
-      pl.status[(size_t)c * g.max_blocks + b] = rec;
+      pl.status[(size_t)c * g.max_blocks + b + h] = rec;
     }
-  };
-
-  if (nblocks > 0) {
-    FmStats st_cur, st_next;
-    float2 s_next = (upper && nblocks > 1) ? in[32 + n] : make_float2(0.f, 0.f);
-    float out_cur = discriminate(upper ? in[n] : make_float2(0.f, 0.f), st_cur);
-    for (int b = 0; b + 1 < nblocks; b++) {
-      float2 const S = s_next;
-      if (b + 2 < nblocks) s_next = upper ? in[(size_t)(b + 2) * 32 + n] : make_float2(0.f, 0.f);
-      float const out_next = discriminate(S, st_next);
-      deemphasize(out_cur, b, st_cur);
-      out_cur = out_next;
-      st_cur = st_next;
-    }
-    deemphasize(out_cur, nblocks - 1, st_cur);
   }
-  if (!upper) ch.ahist[(size_t)c * 32 + lane] = hist;
+  if (!h) ch.ahist[(size_t)c * 32 + lane] = hist;
   if (lane == 0) {
     ch.fm_state[c] = state;
     ch.lastaudio[c] = lastaudio;
@@ -273,9 +296,9 @@ __device__ void fm_channel_t(const Geom &g, const ChanDev &ch, const Planes &pl,
 
 __device__ void fm_channel(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
   if (ch.flags[c] & FLAG_FLAT)
-    fm_channel_t<true>(g, ch, pl, c, nblocks, compute_n0);
+    fm_channel_pair<true>(g, ch, pl, c, nblocks, compute_n0);
   else
-    fm_channel_t<false>(g, ch, pl, c, nblocks, compute_n0);
+    fm_channel_pair<false>(g, ch, pl, c, nblocks, compute_n0);
 }
 
 // AM / linear: one wave per channel, one lane per sample, two consecutive blocks per iteration (lanes 0-31 and

@@ -181,6 +181,8 @@ void *kq_bank_audio_device_ptr(kq_bank *bank);
 void *kq_bank_status_device_ptr(kq_bank *bank);
 
 /* --- measurement --- */
+/* on = 0: off; 1: HIP events around the filter kernel only (two stream operations per call); 2: around the ingest /
+ * IF-power and demodulator kernels as well */
 int kq_bank_enable_timing(kq_bank *bank, int on);
 int kq_bank_get_timing(kq_bank *bank, kq_timing *t, int reset);
 /* Which forward path the bank resolved to (enum kq_fwd_mode, never AUTO) */

@@ -290,8 +290,9 @@ class Bank:
         self._chk(self.lib.kq_bank_get_audio_response(self.h, ch, buf.ctypes.data, buf.size), "kq_bank_get_audio_response")
         return buf
 
-    def enable_timing(self, on=True):
-        self.lib.kq_bank_enable_timing(self.h, int(on))
+    def enable_timing(self, level=1):
+        """0 off, 1 filter kernel only, 2 every kernel group"""
+        self.lib.kq_bank_enable_timing(self.h, int(level))
 
     def timing(self, reset=True):
         t = Timing()

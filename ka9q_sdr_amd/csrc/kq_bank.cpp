@@ -144,7 +144,6 @@ struct kq_bank {
   std::vector<int> list_host[3];
   bool lists_dirty = true;
   float *energy_state = nullptr;
-  unsigned char *update_dev = nullptr;
   // per-call parameters (5 double planes of max_channels + max_blocks update flags) travel through
   // pinned staging slots so kq_bank_process never has to synchronise the stream
   static constexpr int kSlots = 4;
@@ -165,7 +164,7 @@ struct kq_bank {
   int64_t out_abs = 0;      // absolute index of the next output sample
   unsigned last_blocks = 0;
 
-  bool timing = false;
+  int timing = 0;  // 0 off, 1 filter kernel only, >= 2 every scope
   std::vector<EventPair> ev_filter, ev_demod, ev_ingest;
   size_t ev_used[3] = {0, 0, 0};
   kq_timing acc = {};
@@ -324,7 +323,7 @@ struct Scope {
   EventPair *p = nullptr;
   hipStream_t st;
   Scope(kq_bank *bank, int k, hipStream_t stream) : b(bank), kind(k), st(stream) {
-    if (!b->timing) return;
+    if (!b->timing || (kind != 0 && b->timing < 2)) return;
     std::vector<EventPair> &v = kind == 0 ? b->ev_filter : kind == 1 ? b->ev_demod : b->ev_ingest;
     if (b->ev_used[kind] >= 512) drain_timing(b);
     if (ensure_events(v, b->ev_used[kind] + 1)) return;
@@ -378,8 +377,8 @@ int upload_call_params(kq_bank *b, double *osc_dst, int64_t n_w, const unsigned 
   }
   unsigned char *flags = b->stage_host[slot] + 8 * Cmax * sizeof(double);
   memcpy(flags, update, nblocks);
-  HIP_TRY(hipMemcpyAsync(osc_dst, b->stage_host[slot], 8 * Cmax * sizeof(double), hipMemcpyHostToDevice, b->stream));
-  HIP_TRY(hipMemcpyAsync(b->update_dev, flags, nblocks, hipMemcpyHostToDevice, b->stream));
+  // one copy: the per-block flags sit right behind the eight oscillator planes, in the staging slot and on the device
+  HIP_TRY(hipMemcpyAsync(osc_dst, b->stage_host[slot], 8 * Cmax * sizeof(double) + nblocks, hipMemcpyHostToDevice, b->stream));
   HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
   return 0;
 }
@@ -449,7 +448,8 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   if (upload_call_params(b, b->osc_dev2[pp], b->n_abs - (g.M - 1), update_host, nblocks)) return -1;
   {
     Scope t(b, 2, b->stream);
-    kq::launch_block_energy(b->stream, window + (g.M - 1), g.L, (int)nblocks, b->update_dev, b->energy_state, pl.if_power);
+    kq::launch_block_energy(b->stream, window + (g.M - 1), g.L, (int)nblocks,
+                            reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power);
   }
   {
     Scope t(b, 0, b->stream);
@@ -661,7 +661,8 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.noise_gain, C);
   b->chd.n0mask = nullptr;
   if (b->cfg.compute_n0 && kq::full16k_supported(g)) rc |= dev_alloc(&b->chd.n0mask, C * 512);
-  for (int k = 0; k < 2; k++) rc |= dev_alloc(&b->osc_dev2[k], 8 * C);
+  // eight oscillator planes + the per-block IF-power flags of one call
+  for (int k = 0; k < 2; k++) rc |= dev_alloc(&b->osc_dev2[k], 8 * C + (B + sizeof(double) - 1) / sizeof(double));
   b->chd.lo_phase = b->chd.lo_freq = b->chd.lo_rate = b->chd.sh_phase = b->chd.sh_freq = nullptr;  // set per call
   b->chd.hist_phase = b->chd.hist_freq = b->chd.hist_rate = nullptr;
   // Overlap is opt-in (KQ_DEMOD_OVERLAP=1): measured on MI355X the single-wave demodulator workgroups squat on
@@ -717,7 +718,6 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   }
   b->pl = b->pl2[0];
   rc |= dev_alloc(&b->energy_state, 2);
-  rc |= dev_alloc(&b->update_dev, B);
   for (int k = 0; k < 3; k++) rc |= dev_alloc(&b->list_dev[k], C);
   rc |= dev_alloc(&b->retune_list, C);
   if (b->fwd_mode == KQ_FWD_PRUNED) rc |= dev_alloc(&b->chan_tw, C * kq::pruned_table_elems(g));
@@ -768,7 +768,7 @@ int kq_bank_destroy(kq_bank *b) {
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
                   b->pl2[0].plout, b->pl2[1].plout, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
                   b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state,
-                  b->update_dev, b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->retune_list, b->list_pll_dev, b->pll_state, b->pll_rings,
+                  b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->retune_list, b->list_pll_dev, b->pll_state, b->pll_rings,
                   b->pll_side};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -1171,7 +1171,7 @@ void *kq_bank_status_device_ptr(kq_bank *b) { return b ? b->pl.status : nullptr;
 int kq_bank_enable_timing(kq_bank *b, int on) {
   if (!b) return -1;
   if (!on && b->timing) drain_timing(b);
-  b->timing = on != 0;
+  b->timing = on;  // 0 off, 1 filter kernel only, >= 2 every scope
   return 0;
 }
 

@@ -1,0 +1,118 @@
+"""Empty, ragged and limit-size inputs through the C ABI (the reference has no tests of its own; these pin the
+behaviour its callers rely on: proc_samples fills input.c[] sample by sample and runs the filter whenever a block
+completes, radio.c:139-146; packet.c:204-211 does the same for the AFSK master)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ka9q_sdr_amd as kq
+import kq_oracle as ko
+from common import bank_cfg, rel_rms, run_oracle
+from ka9q_sdr_amd import workload as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def _geom():
+    return dict(samprate=192000, L=512, M=513, D=4)
+
+
+def test_empty_and_ragged_pushes(gpu):
+    g = _geom()
+    plan = wl.channel_plan("cfg1", 1)
+    iq = wl.make_iq(g["samprate"], 5 * g["L"], seed=3)
+    want = run_oracle(plan, g, iq, 5)
+    bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], 1, 8)
+    bank.add_channel(bank_cfg(plan[0]))
+    assert bank.process() == 0                      # nothing pushed yet
+    bank.push_iq(iq[:0])                            # empty push
+    assert bank.blocks_ready() == 0 and bank.process() == 0
+    got = []
+    # one sample short of a block, then the missing sample, then ragged pieces crossing block boundaries
+    cuts = [0, g["L"] - 1, g["L"], g["L"] + 7, 3 * g["L"] - 1, 3 * g["L"] + 1, 5 * g["L"]]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        bank.push_iq(iq[a:b])
+        n = bank.process()
+        assert n == b // g["L"] - a // g["L"]
+        got += [bank.audio(0, k) for k in range(n)]
+    assert len(got) == 5
+    assert rel_rms(np.concatenate(got), np.concatenate(want[0][0])) < 1e-5
+    bank.close()
+
+
+def test_single_block_calls_and_full_batches_agree(gpu):
+    g = wl.GEOMETRY["cfg4"]
+    plan = wl.channel_plan("cfg4", 5)
+    nb = 6
+    iq = wl.make_iq(g["samprate"], nb * g["L"], seed=8)
+    outs = []
+    for per_call in (1, nb):
+        bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], len(plan), nb)
+        for p in plan:
+            bank.add_channel(bank_cfg(p))
+        res = [[] for _ in plan]
+        for s in range(0, nb, per_call):
+            bank.push_iq(iq[s * g["L"]:(s + per_call) * g["L"]])
+            assert bank.process() == per_call
+            for c in range(len(plan)):
+                res[c] += [(bank.audio(c, k), bank.status(c, k)) for k in range(per_call)]
+        outs.append(res)
+        bank.close()
+    for c in range(len(plan)):
+        # one block per call and six per call: the same state hand-over, so the same samples to rounding (the FM
+        # kernel pairs blocks within a call and the oscillators are rebased per call, so not bit for bit) and the
+        # same integer state
+        a1 = np.concatenate([a for a, _ in outs[0][c]])
+        a6 = np.concatenate([a for a, _ in outs[1][c]])
+        assert rel_rms(a1, a6) < 1e-5
+        for (_, s1), (_, s6) in zip(outs[0][c], outs[1][c]):
+            assert s1["squelch_count"] == s6["squelch_count"] and s1["nout"] == s6["nout"]
+            assert s1["blanked"] == s6["blanked"]
+
+
+def test_channel_limit_and_bad_arguments(gpu):
+    g = _geom()
+    bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], 2, 2)
+    cfg = bank_cfg(wl.channel_plan("cfg1", 1)[0])
+    assert bank.add_channel(cfg) == 0 and bank.add_channel(cfg) == 1
+    with pytest.raises(kq.KqError):
+        bank.add_channel(cfg)                       # bank full
+    with pytest.raises(kq.KqError):
+        bank.set_filter(5, -1000.0, 1000.0, 3.0)    # no such channel
+    with pytest.raises(kq.KqError):
+        bank.set_filter(0, float("nan"), 1000.0, 3.0)   # filter.c:504-505
+    x = np.zeros(3 * g["L"], np.complex64)
+    with pytest.raises(kq.KqError, match="ring overflow"):
+        bank.push_iq(x)                             # the ring holds max_blocks blocks
+    bank.push_iq(x[:2 * g["L"] - 5])                # capacity is exactly max_blocks * L pending samples
+    assert bank.blocks_ready() == 1
+    bank.push_iq(x[:5])
+    assert bank.blocks_ready() == 2 and bank.process() == 2
+    bank.push_iq(x[:g["L"]])
+    assert bank.process() == 1
+    bank.close()
+
+
+def test_decimator_and_afsk_degenerate_calls(gpu):
+    dec = kq.Decimator(3, 8, 1, max_out=16)
+    y, s16, e = dec.process(np.zeros(0, np.complex64))
+    assert len(y) == 0 and s16.shape == (0, 2)
+    with pytest.raises(ValueError):
+        dec.process(np.zeros(9, np.complex64))      # not a multiple of the decimation ratio
+    with pytest.raises(kq.KqError):
+        dec.process(np.zeros(17 << 3, np.complex64))    # beyond max_out
+    y, _, _ = dec.process(np.ones(8, np.complex64))     # a single output sample
+    fe = ko.FrontEndDecimator(3, 8, 1)
+    wy, _, _ = fe.process(np.ones(8, np.complex64))
+    assert np.array_equal(y, wy)
+    dec.close()
+    bank = kq.AfskBank(2, max_frames=1)
+    assert bank.push(np.zeros((2, 0), np.float32)) == 0
+    assert bank.push(np.zeros((2, 999), np.float32)) == 0
+    assert bank.push(np.zeros((2, 1), np.float32)) == 1
+    assert bank.frames(0) == [] and bank.state(1)["blocks"] == 1
+    with pytest.raises(kq.KqError):
+        bank.L.kq_afsk_push(bank.h, None, 0, 1, 10, 10, 0) and None
+        bank._chk(-1, "kq_afsk_push")
+    bank.close()

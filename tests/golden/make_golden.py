@@ -3,6 +3,9 @@
 
   osc_*.npz      : sequences produced by the REFERENCE's own osc.c + dsp.c (oracle/_ref/libref_osc.so):
                    they pin the oracle NCO wherever the tests run.
+  decimate_ref.npz : half-band cascades run through the REFERENCE's own decimate.c
+                   (oracle/_ref/libref_decimate.so): input, and for three stage mixes the output of two
+                   consecutive calls (state carried).
   chain_*.npz    : inputs and outputs of the oracle chain (oracle/libkq_oracle.so).  The reference's
                    filter / demodulator sources need FFTW headers this image lacks, so these are
                    oracle-generated regression vectors, NOT reference outputs (parity unpinned).
@@ -31,6 +34,19 @@ def osc():
         np.savez_compressed(os.path.join(HERE, "osc_%s.npz" % name), index=idx, phasor=seq[idx], steps=steps)
 
 
+def decimate():
+    assert ko.ref_decimate_lib() is not None, "build oracle/_ref first (make -C oracle ref)"
+    x = np.random.default_rng(2024).standard_normal(64 << 6).astype(np.float32)
+    out = {"x": x}
+    for key, (log_dec, thr) in {"l6_t8": (6, 8), "l6_t3": (6, 3), "l4_t0": (4, 0)}.items():
+        xs = x[: 64 << log_dec]
+        y, st = ko.halfband_cascade(xs, log_dec, thr, use_ref=True)
+        y2, _ = ko.halfband_cascade(xs, log_dec, thr, st, use_ref=True)
+        out[key] = np.concatenate([y, y2])
+        out[key + "_cfg"] = np.array([log_dec, thr])
+    np.savez_compressed(os.path.join(HERE, "decimate_ref.npz"), **out)
+
+
 def chain():
     geom = dict(samprate=192000, L=512, M=513, D=4)
     fs, L = geom["samprate"], geom["L"]
@@ -51,6 +67,7 @@ def chain():
 
 
 if __name__ == "__main__":
+    decimate()
     osc()
     chain()
     print("golden vectors written to", HERE)

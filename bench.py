@@ -84,6 +84,8 @@ def main():
     import torch
     import ka9q_sdr_amd as kq
     from ka9q_sdr_amd import workload as wl
+    if not os.path.exists(kq.library_path()) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        kq.build_library()      # sources-only checkout: build the product before anything is timed
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

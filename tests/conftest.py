@@ -13,10 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _ensure_library():
+    """The HIP library normally travels prebuilt in-tree; on a checkout without it (sources only) build it once
+    with hipcc -- building the product is not a fallback, the tests still fail without it."""
+    import ka9q_sdr_amd as kq
+    if not os.path.exists(kq.library_path()):
+        kq.build_library()
+    return kq
+
+
 def _gpu_present():
     try:
-        import ka9q_sdr_amd as kq
-        return kq.device_count() > 0
+        return _ensure_library().device_count() > 0
     except Exception:
         return False
 
@@ -24,7 +32,7 @@ def _gpu_present():
 @pytest.fixture(scope="session")
 def gpu():
     """GPU tests fail (not skip) when the HIP library or the device is missing: no silent fallback."""
-    import ka9q_sdr_amd as kq
+    kq = _ensure_library()
     kq.load_library()
     n = kq.device_count()
     assert n > 0, "no HIP device visible: -m gpu tests need the MI355X"

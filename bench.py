@@ -84,8 +84,14 @@ def main():
     import torch
     import ka9q_sdr_amd as kq
     from ka9q_sdr_amd import workload as wl
-    if not os.path.exists(kq.library_path()) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
-        kq.build_library()      # sources-only checkout: build the product before anything is timed
+    if not os.path.exists(kq.library_path()):   # sources-only checkout: build the product before anything is timed
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            kq.build_library()
+        else:
+            for _ in range(1200):
+                if os.path.exists(kq.library_path()):
+                    break
+                time.sleep(0.5)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

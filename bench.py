@@ -240,7 +240,7 @@ def main():
         }
         if n0_row:
             out["with_compute_n0"] = n0_row
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(a.config, geom, plan, iq_host[M - 1:], a.cpu_seconds)
         print(json.dumps(out), flush=True)
     bank.close()

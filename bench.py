@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--n0", type=int, default=0, help="1: also run the status-only compute_n0 every block")
     ap.add_argument("--no-n0-row", action="store_true", help="skip the secondary compute_n0=1 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise "
+                    "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
     return ap.parse_args()
 
@@ -100,12 +102,16 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
     assert torch.cuda.is_available(), "bench.py needs the MI355X: there is no CPU path to measure"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()   # == local_rank whenever there is a GPU per rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(a.backend)
 
     geom = dict(wl.GEOMETRY[a.config])
     L, M, D, fs = geom["L"], geom["M"], geom["D"], geom["samprate"]
@@ -119,7 +125,7 @@ def main():
     fwd = {"auto": kq.KQ_FWD_AUTO, "full": kq.KQ_FWD_FULL, "pruned": kq.KQ_FWD_PRUNED}[a.fwd]
     stream = torch.cuda.Stream(device=dev)     # an explicit (non-null) HIP stream handed to the library
     torch.cuda.set_stream(stream)
-    bank = kq.Bank(fs, L, M, D, C, B, device=local_rank, compute_n0=bool(a.n0), fwd_mode=fwd,
+    bank = kq.Bank(fs, L, M, D, C, B, device=dev_index, compute_n0=bool(a.n0), fwd_mode=fwd,
                    stream=stream.cuda_stream)
     for p in plan:
         bank.add_channel(wl.bank_channel_config(p))
@@ -181,7 +187,7 @@ def main():
     n0_row = None
     if world == 1 and not a.n0 and not a.no_n0_row:
         bank.close()
-        bank = kq.Bank(fs, L, M, D, C, B, device=local_rank, compute_n0=True, fwd_mode=kq.KQ_FWD_AUTO,
+        bank = kq.Bank(fs, L, M, D, C, B, device=dev_index, compute_n0=True, fwd_mode=kq.KQ_FWD_AUTO,
                        stream=stream.cuda_stream)
         for p in plan:
             bank.add_channel(wl.bank_channel_config(p))

@@ -49,7 +49,7 @@ __device__ __forceinline__ float rdlane(float v, int src) {
 __device__ __forceinline__ int bitrev6(int i) { return (int)(__brev((unsigned)i) >> 26); }
 
 __device__ __forceinline__ void put_status(kq_chan_status &st, const Geom &g, const ChanDev &ch, const Planes &pl, int c, int b,
-                                           int compute_n0, float n0_rate, float &n0) {
+                                           int compute_n0, double n0_rate, float &n0) {
   st.if_power = pl.if_power[b];
   st.noise_gain = ch.noise_gain[c];
   st.plfreq = NAN;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void put_status(kq_chan_status &st, const Geom &g, co
     if (isnan(n0))
       n0 = fresh;
     else
-      n0 += n0_rate * (fresh - n0);
+      n0 = (float)((double)n0 + n0_rate * (double)(fresh - n0));  // the reference's rate is a double literal
     st.n0 = n0;
   } else {
     st.n0 = NAN;
@@ -258,8 +258,8 @@ __device__ void fm_channel_pair(const Geom &g, const ChanDev &ch, const Planes &
     float const fresh0 = rdlane(n0raw_v, b & 63), fresh1 = rdlane(n0raw_v, (b + 1) & 63);
     float n0a = n0, n0b = n0;
     if (compute_n0) {  // fm.c:79-82, block after block
-      n0a = isnan(n0) ? fresh0 : n0 + .01f * (fresh0 - n0);
-      n0b = have1 ? (isnan(n0a) ? fresh1 : n0a + .01f * (fresh1 - n0a)) : n0a;
+      n0a = isnan(n0) ? fresh0 : (float)((double)n0 + .01 * (double)(fresh0 - n0));
+      n0b = have1 ? (isnan(n0a) ? fresh1 : (float)((double)n0a + .01 * (double)(fresh1 - n0a))) : n0a;
       n0 = n0b;
     }
     if (n == 0 && (h == 0 || have1)) {
@@ -394,7 +394,7 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
         float const sg = __shfl(sig, h * OLEN, 64), nz = __shfl(noi, h * OLEN, 64);
         if (lane == 0) {
           kq_chan_status st;
-          put_status(st, g, ch, pl, c, b0 + h, compute_n0, .001f, n0);
+          put_status(st, g, ch, pl, c, b0 + h, compute_n0, .001, n0);
           st.bb_power = (sg + nz) / (2.f * OLEN);
           st.snr = LINEAR ? NAN : 0.f;
           st.foffset = 0;

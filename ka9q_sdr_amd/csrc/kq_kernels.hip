@@ -269,7 +269,7 @@ void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const 
 
 // ---------------------------------------------------------------- demodulators
 __device__ __forceinline__ void status_common(kq_chan_status &st, const Geom &g, const ChanDev &ch, const Planes &pl, int c,
-                                              int b, int compute_n0, float n0_rate) {
+                                              int b, int compute_n0, double n0_rate) {
   st.if_power = pl.if_power[b];
   st.noise_gain = ch.noise_gain[c];
   st.plfreq = NAN;
@@ -282,7 +282,7 @@ __device__ __forceinline__ void status_common(kq_chan_status &st, const Geom &g,
     if (isnan(n0))
       n0 = fresh;  // fm.c:79-80
     else
-      n0 += n0_rate * (fresh - n0);  // fm.c:82 / am.c:47 / linear.c:124
+      n0 = (float)((double)n0 + n0_rate * (double)(fresh - n0));  // fm.c:82 / am.c:47 / linear.c:124: double literal
     ch.n0[c] = n0;
     st.n0 = n0;
   } else {
@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
     }
     if (lane == 0) {
       kq_chan_status st;
-      status_common(st, g, ch, pl, c, b, compute_n0, .01f);
+      status_common(st, g, ch, pl, c, b, compute_n0, .01);
       st.bb_power = bb;
       st.snr = snr;
       st.foffset = foffset;
@@ -570,7 +570,7 @@ __global__ void k_demod_am(Geom g, ChanDev ch, Planes pl, const int *__restrict_
       aud[n] = (samp - dc) * gain;
     }
     kq_chan_status st;
-    status_common(st, g, ch, pl, c, b, compute_n0, .001f);
+    status_common(st, g, ch, pl, c, b, compute_n0, .001);
     st.bb_power = signal / (2 * olen);  // am.c:78
     st.snr = 0;
     st.foffset = 0;
@@ -634,7 +634,7 @@ __global__ void k_demod_linear(Geom g, ChanDev ch, Planes pl, const int *__restr
       }
     }
     kq_chan_status st;
-    status_common(st, g, ch, pl, c, b, compute_n0, .001f);
+    status_common(st, g, ch, pl, c, b, compute_n0, .001);
     st.bb_power = (signal + noise) / (2 * olen);  // linear.c:302
     st.snr = NAN;                                 // linear.c:309
     st.foffset = 0;

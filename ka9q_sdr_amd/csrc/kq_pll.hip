@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(1024) k_demod_linear_pll(Geom g, ChanDev ch, P
       o.plfreq = NAN;
       if (compute_n0) {
         float const fresh = pl.n0raw[(size_t)c * g.max_blocks + b];
-        n0 = isnan(n0) ? fresh : n0 + .001f * (fresh - n0);
+        n0 = isnan(n0) ? fresh : (float)((double)n0 + .001 * (double)(fresh - n0));  // linear.c:124, double literal
         o.n0 = n0;
       } else {
         o.n0 = NAN;

@@ -254,14 +254,16 @@ static void capture_filt(kqo_chan *c){
     memcpy(c->cap_filt, c->slave->output_c, sizeof(float complex) * c->slave->olen);
 }
 
-static void update_n0(kqo_chan *c, float rate){
+/* rate is the double literal of the reference (.01 in fm.c:82, .001 in am.c:47 and linear.c:124): the update is
+ * evaluated in double and rounded to float on assignment */
+static void update_n0(kqo_chan *c, double rate){
   if(!c->cfg.compute_n0)
     return;
   float const fresh = kqo_compute_n0(c->master->fdomain, c->master->n, c->cfg.samprate, c->cfg.low, c->cfg.high);
   if(isnan(c->n0))
     c->n0 = fresh;                                                         /* fm.c:79-80, am.c:49 */
   else
-    c->n0 += rate * (fresh - c->n0);                                       /* fm.c:82, am.c:47 */
+    c->n0 += rate * (fresh - c->n0);                                       /* fm.c:82, am.c:47: float += double * float */
 }
 
 static int fm_block(kqo_chan *c, float *audio){

@@ -444,7 +444,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   chd.hist_freq = chd.lo_phase + 6 * Cmax;
   chd.hist_rate = chd.lo_phase + 7 * Cmax;
   // this parity's hand-over planes were last read by the demodulators two calls ago
-  HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[pp], 0));
+  if (b->stream2 != b->stream) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[pp], 0));
   if (upload_call_params(b, b->osc_dev2[pp], b->n_abs - (g.M - 1), update_host, nblocks)) return -1;
   {
     Scope t(b, 2, b->stream);
@@ -484,8 +484,10 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     b->acc.filter_launches++;
     b->acc.channel_blocks += (uint64_t)C * nblocks;
   }
-  HIP_TRY(hipEventRecord(b->ev_filter_done, b->stream));
-  HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_filter_done, 0));
+  if (b->stream2 != b->stream) {  // one stream: program order already is the dependency
+    HIP_TRY(hipEventRecord(b->ev_filter_done, b->stream));
+    HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_filter_done, 0));
+  }
   {
     Scope t(b, 1, b->stream2);
     int const nfm = (int)b->list_host[0].size(), nam = (int)b->list_host[1].size(), nlin = (int)b->list_host[2].size();
@@ -508,7 +510,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   if (g.pl_n > 0 && !b->list_host[0].empty())
     kq::launch_pl_track(b->stream2, g, chd, pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), (int)nblocks);
   if (b->pcm_on) kq::launch_pcm(b->stream2, g, pl, b->pcm, b->pcm_mask, C, (int)nblocks);
-  HIP_TRY(hipEventRecord(b->ev_demod_done[pp], b->stream2));
+  if (b->stream2 != b->stream) HIP_TRY(hipEventRecord(b->ev_demod_done[pp], b->stream2));
   b->pl = pl;  // what the pull functions read
   b->calls++;
   HIP_TRY(hipGetLastError());
@@ -1035,7 +1037,7 @@ int kq_bank_process_resident(kq_bank *b, const void *iq_dev, unsigned nblocks) {
 int kq_bank_join(kq_bank *b) {
   if (!b) return -1;
   if (b->calls == 0) return 0;
-  HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[(b->calls - 1) & 1], 0));
+  if (b->stream2 != b->stream) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[(b->calls - 1) & 1], 0));
   return 0;
 }
 

@@ -136,6 +136,24 @@ int kq_bank_set_filter(kq_bank *bank, int ch, float low_hz, float high_hz, float
 /* Append nsamples complex samples of the given format to the bank's input ring.  `iq` is a host
  * pointer, or a device pointer when is_device != 0.  Conversion/scaling as radio.c:110-122. */
 int kq_bank_push_iq(kq_bank *bank, const void *iq, size_t nsamples, int format, int is_device);
+/* One front-end datagram exactly as `radio` takes it off the wire: RTP header incl. CSRCs, extension
+ * and padding (multicast.c:242-277, main.c:318-328), payload type IQ_PT = 97 (int16 I/Q) or IQ_PT8 = 98 (int8 I/Q)
+ * (multicast.h:19-20; anything else is ignored, main.c:329-330), the obsolete 24-byte status block skipped
+ * (main.c:338-341, sdr.h:18-48), then proc_samples' bookkeeping (radio.c:62-104): rtp_process (multicast.c:305-340)
+ * decides whether the packet is a duplicate / stale (dropped), in sequence, or ahead with a timestamp gap -- in which
+ * case the lost samples are injected as zeros with the LOs kept running (kq_bank_push_zeros) before the payload is
+ * converted and appended (kq_bank_push_iq).  Packets are taken in arrival order; the reference's small
+ * sort-by-sequence queue (main.c:347-357) stays with the caller.
+ * Returns the number of samples appended (zeros + payload), 0 for an ignored or dropped datagram, -1 on error. */
+int kq_bank_push_rtp(kq_bank *bank, const void *datagram, size_t size);
+typedef struct kq_rtp_counters {   /* struct rtp_state (multicast.h:41-50) + demod->input.samples */
+  uint32_t ssrc;
+  uint16_t next_seq;
+  uint32_t next_timestamp;
+  int64_t packets, drops, dupes;
+  int64_t samples;
+} kq_rtp_counters;
+int kq_bank_rtp_counters(const kq_bank *bank, kq_rtp_counters *out);
 /* Lost-sample zero fill (radio.c:81-100): append `nsamples` zeros; LOs keep running. */
 int kq_bank_push_zeros(kq_bank *bank, size_t nsamples);
 /* Number of complete blocks waiting in the ring */

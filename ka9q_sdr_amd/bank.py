@@ -55,6 +55,12 @@ class ChanStatus(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class RtpCounters(C.Structure):
+    """struct rtp_state (multicast.h:41-50) + demod->input.samples"""
+    _fields_ = [("ssrc", C.c_uint32), ("next_seq", C.c_uint16), ("next_timestamp", C.c_uint32),
+                ("packets", C.c_int64), ("drops", C.c_int64), ("dupes", C.c_int64), ("samples", C.c_int64)]
+
+
 class Timing(C.Structure):
     _fields_ = [("filter_ms", C.c_double), ("demod_ms", C.c_double), ("ingest_ms", C.c_double),
                 ("filter_launches", C.c_uint64), ("channel_blocks", C.c_uint64)]
@@ -105,6 +111,8 @@ def load_library():
     L.kq_bank_set_filter.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float]
     L.kq_bank_push_iq.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     L.kq_bank_push_zeros.argtypes = [C.c_void_p, C.c_size_t]
+    L.kq_bank_push_rtp.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.kq_bank_rtp_counters.argtypes = [C.c_void_p, C.POINTER(RtpCounters)]
     L.kq_bank_blocks_ready.argtypes = [C.c_void_p]
     L.kq_bank_blocks_ready.restype = C.c_uint
     L.kq_bank_process.argtypes = [C.c_void_p]
@@ -224,6 +232,16 @@ class Bank:
 
     def push_iq_device(self, ptr, nsamples, fmt=KQ_IQ_CF32):
         self._chk(self.lib.kq_bank_push_iq(self.h, ptr, nsamples, fmt, 1), "kq_bank_push_iq")
+
+    def push_rtp(self, datagram):
+        """One front-end datagram (RTP header + 24-byte status block + int16 / int8 I/Q); returns samples appended"""
+        d = bytes(datagram)
+        return self._chk(self.lib.kq_bank_push_rtp(self.h, d, len(d)), "kq_bank_push_rtp")
+
+    def rtp_counters(self):
+        c = RtpCounters()
+        self._chk(self.lib.kq_bank_rtp_counters(self.h, C.byref(c)), "kq_bank_rtp_counters")
+        return {k: getattr(c, k) for k, _ in c._fields_}
 
     def push_zeros(self, n):
         self._chk(self.lib.kq_bank_push_zeros(self.h, n), "kq_bank_push_zeros")

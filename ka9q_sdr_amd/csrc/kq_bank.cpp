@@ -114,6 +114,9 @@ struct kq_bank {
   // The demodulators are latency-bound and independent of the next batch's filter pass, so they run on a
   // second stream: filter(k+1) overlaps demod(k).  Planes the two stages hand over are double buffered.
   hipStream_t stream2 = nullptr;
+  // front-end packet bookkeeping (struct rtp_state + demod->input.samples)
+  kq_rtp_counters rtp{};
+  bool rtp_init = false;
   hipEvent_t ev_filter_done = nullptr;
   hipEvent_t ev_demod_done[2] = {nullptr, nullptr};
   kq::Planes pl2[2];
@@ -992,6 +995,78 @@ int kq_bank_push_zeros(kq_bank *b, size_t nsamples) {
     }
   }
   b->pending += nsamples;
+  return 0;
+}
+
+int kq_bank_push_rtp(kq_bank *b, const void *datagram, size_t size) {
+  if (!b || !datagram) {
+    set_err("NULL argument");
+    return -1;
+  }
+  const unsigned char *p = static_cast<const unsigned char *>(datagram);
+  auto be16 = [](const unsigned char *q) { return (unsigned)((q[0] << 8) | q[1]); };
+  auto be32 = [](const unsigned char *q) { return ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3]; };
+  if (size < 12) return 0;  // RTP_MIN_SIZE, main.c:315-316
+  // RTP header (multicast.c:242-277)
+  bool const pad = (p[0] >> 5) & 1, ext = (p[0] >> 4) & 1;
+  unsigned const cc = p[0] & 0xf;
+  unsigned const type = p[1] & 0x7f;
+  uint16_t const seq = (uint16_t)be16(p + 2);
+  uint32_t const ts = be32(p + 4), ssrc = be32(p + 8);
+  size_t hdr = 12 + 4 * (size_t)cc;
+  if (ext) {
+    if (hdr + 4 > size) return 0;
+    hdr += 4 + 4 + be16(p + hdr + 2);  // type, length, and the reference's "4 + length" bytes
+  }
+  if (hdr > size) return 0;
+  size_t len = size - hdr;
+  if (pad && len > 0) {  // main.c:324-328
+    unsigned const npad = p[size - 1];
+    if (npad > len) return 0;
+    len -= npad;
+  }
+  if (type != 97 && type != 98) return 0;  // IQ_PT / IQ_PT8, main.c:329-330
+  if (len < 24) return 0;
+  hdr += 24;  // obsolete status block, main.c:338-341
+  len -= 24;
+  int const sampcount = (int)(type == 97 ? len / 4 : len / 2);  // radio.c:64-72
+
+  // proc_samples + rtp_process (radio.c:73-104, multicast.c:305-340)
+  kq_rtp_counters &r = b->rtp;
+  if (!b->rtp_init || ssrc != r.ssrc) {
+    r.samples = 0;  // radio.c:73-77 (a fresh state has ssrc 0, so the first packet lands here as well)
+    r.ssrc = ssrc;
+    r.packets = 0;
+    r.next_seq = seq;
+    r.next_timestamp = ts;
+    r.dupes = 0;
+    r.drops = 0;
+    b->rtp_init = true;
+  }
+  r.packets++;
+  short const seq_step = (short)(seq - r.next_seq);
+  if (seq_step < 0) {
+    r.dupes++;
+    return 0;
+  }
+  r.drops += seq_step;
+  r.next_seq = (uint16_t)(seq + 1);
+  int const time_step = (int)(ts - r.next_timestamp);
+  if (time_step < 0) return 0;  // old samples: dropped before the timestamp advances (multicast.c:334-336)
+  r.next_timestamp = ts + (uint32_t)sampcount;
+  if (time_step > 192000) return 0;  // radio.c:79-82
+  if (time_step > 0) {
+    if (kq_bank_push_zeros(b, (size_t)time_step)) return -1;  // radio.c:83-100
+    r.samples += time_step;
+  }
+  r.samples += sampcount;
+  if (sampcount > 0 && kq_bank_push_iq(b, p + hdr, (size_t)sampcount, type == 97 ? KQ_IQ_S16 : KQ_IQ_S8, 0)) return -1;
+  return time_step + sampcount;
+}
+
+int kq_bank_rtp_counters(const kq_bank *b, kq_rtp_counters *out) {
+  if (!b || !out) return -1;
+  *out = b->rtp;
   return 0;
 }
 

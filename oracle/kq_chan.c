@@ -639,6 +639,33 @@ int kqo_chan_block_i8(kqo_chan *c, const int8_t *iq, float *audio, kqo_status *s
   return 0;
 }
 
+/* proc_samples' per-sample loop over one packet payload of `count` samples (radio.c:104-147): fmt KQO_IQ_S16 or
+ * KQO_IQ_S8.  Every block that completes is demodulated; audio / st must hold count/L + 1 blocks.  Returns the
+ * number of blocks completed. */
+int kqo_chan_push_raw(kqo_chan *c, const void *iq, int count, int fmt, float *audio, kqo_status *st){
+  float const scale16 = 1. / SHRT_MAX, scale8 = 1. / 127;                  /* radio.c:38-39 */
+  unsigned const olen_max = 2 * c->slave->olen;
+  const int16_t *p16 = iq;
+  const int8_t *p8 = iq;
+  int blocks = 0;
+  c->samples += count;                                                     /* radio.c:104 */
+  for(int i = 0; i < count; i++){
+    float si, sq;
+    if(fmt == KQO_IQ_S8){
+      si = p8[2 * i] * scale8;
+      sq = p8[2 * i + 1] * scale8;
+    } else {
+      si = p16[2 * i] * scale16;
+      sq = p16[2 * i + 1] * scale16;
+    }
+    if(ingest_sample(c, (si + sq * _Complex_I) * c->cfg.gain_factor)){
+      demod_block(c, audio + (size_t)blocks * olen_max, st ? st + blocks : NULL, NULL, NULL);
+      blocks++;
+    }
+  }
+  return blocks;
+}
+
 int kqo_chan_zero_fill(kqo_chan *c, int count, float *audio, kqo_status *st){
   int blocks = 0;
   unsigned const olen_max = 2 * c->slave->olen;

@@ -165,6 +165,9 @@ int kqo_chan_block(kqo_chan *c, const float *iq, float *audio, kqo_status *st,
 /* int16 / int8 interleaved I/Q ingest (radio.c:110-122) -> same as above */
 int kqo_chan_block_i16(kqo_chan *c, const int16_t *iq, float *audio, kqo_status *st);
 int kqo_chan_block_i8(kqo_chan *c, const int8_t *iq, float *audio, kqo_status *st);
+/* One packet payload of `count` int16 / int8 I/Q samples through proc_samples' loop (radio.c:104-147); returns the
+ * number of blocks completed (each demodulated; audio / st hold count/L + 1 blocks) */
+int kqo_chan_push_raw(kqo_chan *c, const void *iq, int count, int fmt, float *audio, kqo_status *st);
 /* Lost-sample zero fill (radio.c:81-100): inject `count` zero samples, LOs keep running. Any
  * blocks completed meanwhile are demodulated; audio must hold ceil(count/L)+1 blocks.
  * Returns number of blocks completed. */
@@ -184,6 +187,32 @@ typedef struct {
 void kqo_hb15_init(kqo_hb15_state *st);
 void kqo_hb15_block(kqo_hb15_state *st, float *output, const float *input, int cnt);
 void kqo_hb3_block(float *state, float *output, const float *input, int cnt);
+
+/* I/Q packet ingest: RTP header, payload types, sequence / timestamp rules (multicast.c:242-277, 305-340;
+ * main.c:315-341; radio.c:62-104) */
+enum { KQO_IQ_S16 = 1, KQO_IQ_S8 = 2 };
+typedef struct {
+  int version;
+  uint8_t type;
+  uint16_t seq;
+  uint32_t timestamp;
+  uint32_t ssrc;
+  int marker, pad, extension, cc;
+} kqo_rtp_header;
+typedef struct {                     /* multicast.h:41-52 */
+  uint32_t ssrc;
+  int init;
+  uint16_t seq;
+  uint32_t timestamp;
+  long long packets, drops, dupes;
+} kqo_rtp_state;
+typedef struct {
+  kqo_rtp_state rtp;
+  long long samples;                 /* demod->input.samples */
+} kqo_iq_ingest;
+int kqo_ntoh_rtp(kqo_rtp_header *rtp, const unsigned char *data);
+int kqo_rtp_process(kqo_rtp_state *state, const kqo_rtp_header *rtp, int sampcnt);
+int kqo_iq_packet(kqo_iq_ingest *in, const unsigned char *packet, int size, int *zeros, int *offset, int *count, int *format);
 
 /* AFSK-1200 / HDLC packet decoder (packet.c:36-48, 201-212, 267-414; ax25.c:138-156) */
 #define KQO_AFSK_AL 1000        /* packet.c:42 */

@@ -64,7 +64,7 @@ class _Cplx(C.Structure):
 def build(force=False):
     """Compile the oracle (and oracle/_ref when /root/reference is present)."""
     so = os.path.join(_HERE, "libkq_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("kq_fft.c", "kq_osc.c", "kq_filter.c", "kq_chan.c", "kq_decimate.c", "kq_packet.c",
+    srcs = [os.path.join(_HERE, f) for f in ("kq_fft.c", "kq_osc.c", "kq_filter.c", "kq_chan.c", "kq_decimate.c", "kq_packet.c", "kq_rtp.c",
                                              "kq_oracle.h")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
@@ -127,6 +127,8 @@ def lib():
     L.kqo_notch_create.restype = C.c_void_p
     L.kqo_notch_create.argtypes = [C.c_double, C.c_float]
     L.kqo_notch_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.kqo_chan_push_raw.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, fp, C.POINTER(Status)]
+    L.kqo_iq_packet.argtypes = [C.POINTER(IqIngest), C.c_char_p, C.c_int] + [C.POINTER(C.c_int)] * 4
     L.kqo_crc_good.argtypes = [C.c_char_p, C.c_int]
     L.kqo_afsk_create.restype = C.c_void_p
     L.kqo_afsk_destroy.argtypes = [C.c_void_p]
@@ -232,6 +234,16 @@ class Channel:
         self.L.kqo_chan_block_i8(self.h, iq.ctypes.data_as(C.POINTER(C.c_int8)), _fp(audio), C.byref(st))
         return audio[:st.nout].copy(), st.as_dict()
 
+    def push_raw(self, raw, count, fmt):
+        """One packet payload (bytes; fmt 1 = int16, 2 = int8 interleaved I/Q) -> list of (audio, status) of the blocks
+        it completes"""
+        nb = count // self.cfg.L + 2
+        audio = np.zeros(nb * 2 * self.olen, np.float32)
+        sts = (Status * nb)()
+        buf = bytes(raw)
+        done = self.L.kqo_chan_push_raw(self.h, buf, count, fmt, _fp(audio), sts)
+        return [(audio[b * 2 * self.olen: b * 2 * self.olen + sts[b].nout].copy(), sts[b].as_dict()) for b in range(done)]
+
     def zero_fill(self, count):
         nb = count // self.cfg.L + 2
         audio = np.zeros(nb * 2 * self.olen, np.float32)
@@ -296,6 +308,23 @@ def make_kaiser(M, beta):
 def compute_n0(spec, samprate, low, high):
     spec = np.ascontiguousarray(spec, np.complex64)
     return lib().kqo_compute_n0(spec.ctypes.data, len(spec), samprate, low, high)
+
+
+class RtpState(C.Structure):
+    _fields_ = [("ssrc", C.c_uint32), ("init", C.c_int), ("seq", C.c_uint16), ("timestamp", C.c_uint32),
+                ("packets", C.c_longlong), ("drops", C.c_longlong), ("dupes", C.c_longlong)]
+
+
+class IqIngest(C.Structure):
+    """radio's packet bookkeeping: struct rtp_state + demod->input.samples"""
+    _fields_ = [("rtp", RtpState), ("samples", C.c_longlong)]
+
+    def packet(self, data):
+        """-> None when ignored / dropped, else (zeros, offset, count, fmt) as kqo_iq_packet reports them"""
+        z, o, n, f = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        data = bytes(data)
+        ok = lib().kqo_iq_packet(C.byref(self), data, len(data), C.byref(z), C.byref(o), C.byref(n), C.byref(f))
+        return (z.value, o.value, n.value, f.value) if ok else None
 
 
 class Afsk:

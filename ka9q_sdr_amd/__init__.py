@@ -28,3 +28,4 @@ from .bank import (  # noqa: F401
 )
 from .decimate import Decimator  # noqa: F401,E402
 from .packet import AfskBank, KQ_PCM_F32, KQ_PCM_S16BE  # noqa: F401,E402
+from . import iqfile  # noqa: F401,E402

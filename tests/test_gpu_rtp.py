@@ -62,3 +62,28 @@ def test_packet_stream_matches_oracle(gpu):
         np.testing.assert_allclose(gs["if_power"], ws["if_power"], rtol=2e-4, atol=1e-12)
     assert rel_rms(np.concatenate([a for a, _ in got]), np.concatenate([a for a, _ in want])) < 1e-5
     bank.close()
+
+
+def test_recording_file_playback(gpu, tmp_path):
+    """iqrecord-style file (s16le + xattrs) played into the bank == the same int16 samples pushed directly"""
+    from ka9q_sdr_amd import iqfile
+    g = dict(samprate=192000, L=512, M=513, D=4)
+    p = wl.channel_plan("cfg1", 1)[0]
+    iq = wl.make_iq(g["samprate"], 7 * g["L"] + 100, seed=33)
+    i16 = np.stack([np.round(iq.real * 20000), np.round(iq.imag * 20000)], axis=1).astype(np.int16)
+    path = str(tmp_path / "rec")
+    iqfile.write_recording(path, i16, g["samprate"], frequency=10.0e6)
+    a = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], 1, 4)
+    b = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], 1, 8)
+    a.add_channel(bank_cfg(p))
+    b.add_channel(bank_cfg(p))
+    got = []
+    for nb in iqfile.play_into(a, path, chunk_blocks=3):
+        got += [a.audio(0, k) for k in range(nb)]
+    b.push_iq(i16)
+    assert b.process() == 7
+    want = [b.audio(0, k) for k in range(7)]
+    assert len(got) == 7
+    assert rel_rms(np.concatenate(got), np.concatenate(want)) < 1e-6
+    a.close()
+    b.close()

@@ -185,6 +185,22 @@ int kq_bank_pull_status(kq_bank *bank, int ch, unsigned blk, kq_chan_status *st)
 int kq_bank_enable_pcm(kq_bank *bank, int on);
 int kq_bank_pull_pcm(kq_bank *bank, int ch, unsigned blk, int16_t *dst_be, size_t cap_words, size_t *nwords,
                      uint32_t *silent_mask);
+/* The datagrams send_mono_output / send_stereo_output (audio.c:32-132) would hand to send() for one channel-block,
+ * built on the host from the PCM plane: RTP header (multicast.c:282-294; payload type PCM_MONO_PT = 11 or
+ * PCM_STEREO_PT = 10, multicast.h:22-23), 480-word chunks, all-zero chunks skipped while the timestamp still
+ * advances, marker bit on the first packet after silence, sequence numbers on sent packets only.  Packets are written
+ * back to back as [2-byte little-endian length][bytes].  The per-channel state (demod->output.rtp, output.silent)
+ * advances, so call it once per channel-block, in order.  Returns the number of packets, or -1. */
+typedef struct kq_out_rtp_state {
+  uint32_t ssrc;
+  uint16_t seq;
+  uint32_t timestamp;
+  int32_t silent;
+  int64_t packets, bytes;
+} kq_out_rtp_state;
+int kq_bank_set_output_ssrc(kq_bank *bank, int ch, uint32_t ssrc);
+int kq_bank_pull_rtp_audio(kq_bank *bank, int ch, unsigned blk, unsigned char *dst, size_t cap, size_t *used);
+int kq_bank_output_rtp_state(const kq_bank *bank, int ch, kq_out_rtp_state *out);
 /* Pre-detection filter output (filter.out->output.c, olen complex) before demodulation */
 int kq_bank_pull_filter_output(kq_bank *bank, int ch, unsigned blk, float *dst_re_im, size_t cap_complex);
 /* Master spectrum fdomain[N] of one channel/block (only in KQ_FWD_FULL mode; radio.c:396) */

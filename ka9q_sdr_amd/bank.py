@@ -55,6 +55,12 @@ class ChanStatus(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class OutRtpState(C.Structure):
+    """demod->output.rtp + output.silent"""
+    _fields_ = [("ssrc", C.c_uint32), ("seq", C.c_uint16), ("timestamp", C.c_uint32), ("silent", C.c_int32),
+                ("packets", C.c_int64), ("bytes", C.c_int64)]
+
+
 class RtpCounters(C.Structure):
     """struct rtp_state (multicast.h:41-50) + demod->input.samples"""
     _fields_ = [("ssrc", C.c_uint32), ("next_seq", C.c_uint16), ("next_timestamp", C.c_uint32),
@@ -111,6 +117,9 @@ def load_library():
     L.kq_bank_set_filter.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float]
     L.kq_bank_push_iq.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
     L.kq_bank_push_zeros.argtypes = [C.c_void_p, C.c_size_t]
+    L.kq_bank_set_output_ssrc.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+    L.kq_bank_pull_rtp_audio.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.kq_bank_output_rtp_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(OutRtpState)]
     L.kq_bank_push_rtp.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.kq_bank_rtp_counters.argtypes = [C.c_void_p, C.POINTER(RtpCounters)]
     L.kq_bank_blocks_ready.argtypes = [C.c_void_p]
@@ -232,6 +241,26 @@ class Bank:
 
     def push_iq_device(self, ptr, nsamples, fmt=KQ_IQ_CF32):
         self._chk(self.lib.kq_bank_push_iq(self.h, ptr, nsamples, fmt, 1), "kq_bank_push_iq")
+
+    def set_output_ssrc(self, ch, ssrc):
+        self._chk(self.lib.kq_bank_set_output_ssrc(self.h, ch, ssrc), "kq_bank_set_output_ssrc")
+
+    def rtp_audio(self, ch, blk):
+        """The PCM datagrams of one channel-block as audio.c would send them (needs enable_pcm); advances the state"""
+        buf = C.create_string_buffer(8 * self.olen + 4096)
+        used = C.c_size_t()
+        self._chk(self.lib.kq_bank_pull_rtp_audio(self.h, ch, blk, buf, len(buf), C.byref(used)), "kq_bank_pull_rtp_audio")
+        blob, out, pos = buf.raw[:used.value], [], 0
+        while pos < len(blob):
+            ln = blob[pos] | (blob[pos + 1] << 8)
+            out.append(blob[pos + 2:pos + 2 + ln])
+            pos += 2 + ln
+        return out
+
+    def output_rtp_state(self, ch):
+        st = OutRtpState()
+        self._chk(self.lib.kq_bank_output_rtp_state(self.h, ch, C.byref(st)), "kq_bank_output_rtp_state")
+        return {k: getattr(st, k) for k, _ in st._fields_}
 
     def push_rtp(self, datagram):
         """One front-end datagram (RTP header + 24-byte status block + int16 / int8 I/Q); returns samples appended"""

@@ -94,6 +94,7 @@ struct HostChan {
   // the next block were mixed with these (radio.c:132-139)
   Osc lo2_old, dop_old;
   bool retuned = false;
+  kq_out_rtp_state out_rtp{};  // demod->output.rtp + output.silent (audio.c:32-132)
   int out_type;
   std::vector<kq::cfloat> resp, aresp;
   float noise_gain;
@@ -1180,6 +1181,77 @@ int kq_bank_pull_pcm(kq_bank *b, int ch, unsigned blk, int16_t *dst, size_t cap,
   if (nwords) *nwords = (size_t)st.nout;
   if (silent_mask) *silent_mask = m;
   return 0;
+}
+
+int kq_bank_set_output_ssrc(kq_bank *b, int ch, uint32_t ssrc) {
+  if (!valid_ch(b, ch)) {
+    set_err("bad channel");
+    return -1;
+  }
+  b->chans[ch].out_rtp.ssrc = ssrc;
+  return 0;
+}
+
+int kq_bank_output_rtp_state(const kq_bank *b, int ch, kq_out_rtp_state *out) {
+  if (!b || !out || ch < 0 || (size_t)ch >= b->chans.size()) return -1;
+  *out = b->chans[ch].out_rtp;
+  return 0;
+}
+
+int kq_bank_pull_rtp_audio(kq_bank *b, int ch, unsigned blk, unsigned char *dst, size_t cap, size_t *used) {
+  if (!valid_ch(b, ch) || !dst) {
+    set_err("bad channel or NULL buffer");
+    return -1;
+  }
+  std::vector<int16_t> words(2 * (size_t)b->g.olen);
+  size_t nwords = 0;
+  if (kq_bank_pull_pcm(b, ch, blk, words.data(), words.size(), &nwords, nullptr)) return -1;
+  bool const stereo = nwords == 2 * (size_t)b->g.olen;  // what the demodulator passed to send_stereo_output
+  kq_out_rtp_state &o = b->chans[ch].out_rtp;
+  const unsigned char *w = reinterpret_cast<const unsigned char *>(words.data());  // already network byte order
+  size_t pos = 0, left = nwords;
+  int packets = 0;
+  while (left > 0) {
+    size_t const chunk = std::min<size_t>(480, left);  // PCM_BUFSIZE words, audio.c:19,44,94
+    bool not_silent = false;
+    for (size_t i = 0; i < 2 * chunk; i++) not_silent |= w[i] != 0;
+    uint32_t const ts = o.timestamp;
+    o.timestamp += (uint32_t)(stereo ? chunk / 2 : chunk);  // audio.c:52-53,103-104: advances even when nothing is sent
+    if (not_silent) {
+      o.packets++;
+      o.bytes += (int64_t)(2 * chunk);
+      int marker = 0;
+      if (o.silent) {  // audio.c:57-61,109-113
+        o.silent = 0;
+        marker = 1;
+      }
+      uint16_t const seq = o.seq++;
+      size_t const len = 12 + 2 * chunk;
+      if (pos + 2 + len > cap) {
+        set_err("packet buffer too small");
+        return -1;
+      }
+      unsigned char *dp = dst + pos;
+      dp[0] = (unsigned char)len;
+      dp[1] = (unsigned char)(len >> 8);
+      dp += 2;
+      dp[0] = 2 << 6;  // RTP version 2; no padding, extension or CSRCs (multicast.c:285)
+      dp[1] = (unsigned char)((marker << 7) | (stereo ? 10 : 11));
+      dp[2] = (unsigned char)(seq >> 8);
+      dp[3] = (unsigned char)seq;
+      for (int k = 0; k < 4; k++) dp[4 + k] = (unsigned char)(ts >> (24 - 8 * k));
+      for (int k = 0; k < 4; k++) dp[8 + k] = (unsigned char)(o.ssrc >> (24 - 8 * k));
+      memcpy(dp + 12, w, 2 * chunk);
+      pos += 2 + len;
+      packets++;
+    } else {
+      o.silent = 1;
+    }
+    w += 2 * chunk;
+    left -= chunk;
+  }
+  if (used) *used = pos;
+  return packets;
 }
 
 int kq_bank_pull_filter_output(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap) {

@@ -715,6 +715,65 @@ int kqo_pcm_block(const float *audio, int nwords, int16_t *pcm_be, uint32_t *sil
   return chunks;
 }
 
+/* ---- PCM RTP packetising: audio.c:32-79 (stereo) and 82-132 (mono); header layout multicast.c:282-294 ----
+ * Emits the datagrams send_*_output would pass to send(): 480-word chunks, all-zero chunks skipped while the
+ * timestamp still advances, marker bit on the first packet after silence, sequence numbers on sent packets only.
+ * Packets are written back to back as [2-byte little-endian length][bytes].  Returns the number of packets. */
+int kqo_pcm_rtp(kqo_out_rtp *o, const float *audio, int nfloats, int stereo, unsigned char *dst, int cap, int *used){
+  int packets = 0, pos = 0;
+  int size = stereo ? nfloats / 2 : nfloats;                               /* frames */
+  while(size > 0){
+    int not_silent = 0;
+    int const chunk = stereo ? (480 < 2 * size ? 480 : 2 * size) : (480 < size ? 480 : size);
+    unsigned char words[2 * 480];
+    for(int i = 0; i < chunk; i++){
+      uint16_t const h = (uint16_t)scaleclip(*audio++);
+      words[2 * i] = (unsigned char)(h >> 8);                                /* htons */
+      words[2 * i + 1] = (unsigned char)h;
+      not_silent |= h;
+    }
+    uint32_t const ts = o->timestamp;
+    o->timestamp += stereo ? chunk / 2 : chunk;
+    if(not_silent){
+      o->packets++;
+      o->bytes += 2 * chunk;
+      int marker = 0;
+      if(o->silent){
+        o->silent = 0;
+        marker = 1;
+      }
+      uint16_t const seq = o->seq++;
+      int const len = 12 + 2 * chunk;
+      if(pos + 2 + len > cap)
+        return -1;
+      unsigned char *dp = dst + pos;
+      dp[0] = (unsigned char)len;
+      dp[1] = (unsigned char)(len >> 8);
+      dp += 2;
+      dp[0] = 2 << 6;                                                        /* RTP_VERS, no pad / extension / CSRC */
+      dp[1] = (unsigned char)((marker << 7) | (stereo ? 10 : 11));           /* PCM_STEREO_PT / PCM_MONO_PT */
+      dp[2] = (unsigned char)(seq >> 8);
+      dp[3] = (unsigned char)seq;
+      dp[4] = (unsigned char)(ts >> 24);
+      dp[5] = (unsigned char)(ts >> 16);
+      dp[6] = (unsigned char)(ts >> 8);
+      dp[7] = (unsigned char)ts;
+      dp[8] = (unsigned char)(o->ssrc >> 24);
+      dp[9] = (unsigned char)(o->ssrc >> 16);
+      dp[10] = (unsigned char)(o->ssrc >> 8);
+      dp[11] = (unsigned char)o->ssrc;
+      memcpy(dp + 12, words, 2 * chunk);
+      pos += 2 + len;
+      packets++;
+    } else
+      o->silent = 1;
+    size -= stereo ? chunk / 2 : chunk;
+  }
+  if(used)
+    *used = pos;
+  return packets;
+}
+
 /* ---- multi-channel CPU baseline (bench.py cpu_baseline leg only) ---- */
 struct bench_arg {
   const kqo_chan_cfg *cfgs;

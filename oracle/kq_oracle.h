@@ -236,6 +236,15 @@ void kqo_afsk_state(const kqo_afsk *a, int *symphase, int *frame_bit, int *flags
  * most 480 words; bit i of *silent_mask is set when chunk i is all zero (the reference then skips the packet but
  * still advances the RTP timestamp).  Returns the number of chunks. */
 int kqo_pcm_block(const float *audio, int nwords, int16_t *pcm_be, uint32_t *silent_mask);
+/* send_mono_output / send_stereo_output as datagram builders (audio.c:32-132); state = demod->output.{rtp,silent} */
+typedef struct {
+  uint32_t ssrc;
+  uint16_t seq;
+  uint32_t timestamp;
+  int silent;
+  long long packets, bytes;
+} kqo_out_rtp;
+int kqo_pcm_rtp(kqo_out_rtp *o, const float *audio, int nfloats, int stereo, unsigned char *dst, int cap, int *used);
 
 /* compute_n0 on a bare spectrum (radio.c:383-425) */
 float kqo_compute_n0(const float complex *fdomain, unsigned N, int samprate, float low, float high);

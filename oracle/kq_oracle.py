@@ -144,6 +144,7 @@ def lib():
     L.kqo_hb3_block.argtypes = [fp, fp, fp, C.c_int]
     L.kqo_pcm_block.argtypes = [fp, C.c_int, C.POINTER(C.c_int16), C.POINTER(C.c_uint32)]
     L.kqo_pcm_block.restype = C.c_int
+    L.kqo_pcm_rtp.argtypes = [C.POINTER(OutRtp), fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(C.c_int)]
     L.kqo_bench_channels.restype = C.c_double
     L.kqo_bench_channels.argtypes = [C.POINTER(ChanCfg), C.c_int, fp, C.c_int, C.c_int, C.POINTER(C.c_double)]
     _LIB = L
@@ -308,6 +309,31 @@ def make_kaiser(M, beta):
 def compute_n0(spec, samprate, low, high):
     spec = np.ascontiguousarray(spec, np.complex64)
     return lib().kqo_compute_n0(spec.ctypes.data, len(spec), samprate, low, high)
+
+
+class OutRtp(C.Structure):
+    """demod->output.rtp + output.silent (audio.c:32-132)"""
+    _fields_ = [("ssrc", C.c_uint32), ("seq", C.c_uint16), ("timestamp", C.c_uint32), ("silent", C.c_int),
+                ("packets", C.c_longlong), ("bytes", C.c_longlong)]
+
+    def packetize(self, audio, stereo):
+        """-> list of datagrams send_mono_output / send_stereo_output would send for this audio block"""
+        a = np.ascontiguousarray(audio, np.float32)
+        buf = C.create_string_buffer(4 * len(a) + 4096)
+        used = C.c_int()
+        n = lib().kqo_pcm_rtp(C.byref(self), _fp(a), len(a), int(stereo), C.cast(buf, C.POINTER(C.c_ubyte)), len(buf),
+                              C.byref(used))
+        assert n >= 0
+        return split_packets(buf.raw[:used.value])
+
+
+def split_packets(blob):
+    out, pos = [], 0
+    while pos < len(blob):
+        ln = blob[pos] | (blob[pos + 1] << 8)
+        out.append(blob[pos + 2:pos + 2 + ln])
+        pos += 2 + ln
+    return out
 
 
 class RtpState(C.Structure):

@@ -346,6 +346,54 @@ def test_pcm_output_stage(gpu):
     bank.close()
 
 
+def test_pcm_rtp_datagrams(gpu):
+    """SURVEY 8f-2, the rest of audio.c:32-132: the datagrams themselves -- header, 480-word chunks, skipped silent
+    chunks with the timestamp still advancing, marker bit on resume, sequence numbers on sent packets only -- byte for
+    byte against the oracle packetiser run on the same device audio (mono FM that squelches, stereo linear)."""
+    import kq_oracle as ko
+    g = dict(samprate=192000, L=2048, M=2049, D=4)        # olen = 512: chunks of 480 + 32 (mono), 480 + 480 + 64 (stereo)
+    fs, L = g["samprate"], g["L"]
+    nb = 8
+    t = np.arange(nb * L) / fs
+    sig = 0.2 * np.exp(1j * (2 * np.pi * 20000.0 * t + 3.0 * np.sin(2 * np.pi * 1000.0 * t)))
+    sig[3 * L:5 * L] = 0                                    # the carrier drops for two blocks, then comes back
+    rng = np.random.default_rng(18)
+    iq = (sig + 1e-4 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    plan = [dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-20000.0),
+            dict(demod="linear", low=-5000.0, high=5000.0, second_lo=-20000.0, hangtime=1.1, recovery_rate=6.0, channels=2)]
+    bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), 4, fwd_mode=kq.KQ_FWD_FULL)
+    bank.enable_pcm(True)
+    ssrc = [0xCAFE0001, 0x7FFFFFF2]
+    ora = []
+    for c, p in enumerate(plan):
+        bank.add_channel(bank_cfg(p))
+        bank.set_output_ssrc(c, ssrc[c])
+        ora.append(ko.OutRtp(ssrc=ssrc[c]))
+    sent = skipped = markers = 0
+    for call in range(2):                                   # state carries across process calls
+        bank.push_iq(iq[call * 4 * L:(call + 1) * 4 * L])
+        assert bank.process() == 4
+        for c in range(len(plan)):
+            for b in range(4):
+                a = bank.audio(c, b)
+                got = bank.rtp_audio(c, b)
+                want = ora[c].packetize(a, stereo=(c == 1))
+                assert got == want, (call, c, b)
+                nchunks = (len(a) + 479) // 480
+                sent += len(got)
+                skipped += nchunks - len(got)
+                markers += sum(1 for d in got if d[1] & 0x80)
+                for d in got:
+                    assert d[0] == 0x80 and (d[1] & 0x7F) == (10 if c == 1 else 11) and len(d) <= 12 + 960
+    for c in range(len(plan)):
+        st = bank.output_rtp_state(c)
+        assert (st["seq"], st["timestamp"], st["silent"], st["packets"], st["bytes"]) == \
+               (ora[c].seq, ora[c].timestamp, ora[c].silent, ora[c].packets, ora[c].bytes)
+        assert st["timestamp"] == nb * 512                  # every frame counted, sent or not
+    assert sent > 0 and skipped > 0 and markers > 0
+    bank.close()
+
+
 @pytest.mark.parametrize("name,mode", [("cfg4", "pruned"), ("cfg4", "full"), ("cfg5", "pruned")])
 def test_retune_mid_stream_is_sample_exact(gpu, name, mode):
     """osc.c:22-36 + radio.c:132-139: a retune changes only the samples mixed after it; the M-1 history samples of

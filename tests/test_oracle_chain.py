@@ -232,3 +232,23 @@ def test_linear_pll_known_answer():
     y = np.concatenate(auds[-20:])
     tone = 2 * np.abs(np.mean(y * np.exp(-2j * np.pi * 1000.0 * np.arange(len(y)) / 48000.0)))
     assert 0.3 < tone / np.abs(np.mean(y)) < 0.6             # 50 % modulation on top of the carrier (DC) level
+
+
+def test_pcm_rtp_packetiser_known_answers():
+    """audio.c:82-132 on a hand-built block: 480-word chunks, a silent chunk skipped with the timestamp advancing,
+    marker on resume, sequence number only on sent packets, wrap of both counters."""
+    import kq_oracle as ko
+    o = ko.OutRtp(ssrc=0x11223344, seq=65535, timestamp=0xFFFFFF00)
+    a = np.zeros(1000, np.float32)
+    a[500:700] = 0.5
+    p = o.packetize(a, stereo=False)
+    assert len(p) == 1 and len(p[0]) == 12 + 960
+    assert p[0][:12].hex() == "808bffff000000e011223344"     # v2, marker|PT 11, seq 65535, ts 0xffffff00+480 wrapped
+    assert (o.seq, o.timestamp, o.silent, o.packets, o.bytes) == (0, 0xFFFFFF00 + 1000 - (1 << 32), 1, 1, 960)
+    assert p[0][12:12 + 40] == bytes(40) and p[0][12 + 40:12 + 44] == bytes([0x3F, 0xFF, 0x3F, 0xFF])   # 0.5 -> 16383
+    # stereo: 480 words = 240 frames per packet, payload type 10, no marker when the previous chunk was sent
+    o = ko.OutRtp(ssrc=1)
+    p = o.packetize(np.full(2 * 500, -1.5, np.float32), stereo=True)
+    assert [len(d) for d in p] == [12 + 960, 12 + 960, 12 + 80]
+    assert [d[1] for d in p] == [10, 10, 10] and o.timestamp == 500
+    assert p[0][12:14] == bytes([0x80, 0x00])                 # clipped to SHRT_MIN

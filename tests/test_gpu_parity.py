@@ -168,6 +168,27 @@ def test_full_size_pruned_and_full_spectrum_agree_on_every_channel(gpu):
     assert worst > 0          # two different code paths, not one result read twice
 
 
+def test_long_run_phase_continuity(gpu):
+    """2.5 million input samples (300 blocks over five process calls, more than 150 renormalisation periods of the
+    reference's NCO recurrence): the closed-form oscillators of the bank must not drift away from the oracle's
+    sample-by-sample recurrence, on the pruned path and, with a swept Doppler, on the full path."""
+    g = wl.GEOMETRY["cfg4"]
+    nblocks = 300
+    iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=41)
+    plan = wl.channel_plan("cfg4", 3, first=500)
+    want = run_oracle(plan, g, iq, nblocks)
+    got, mode = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_PRUNED, per_call=64)
+    assert mode == kq.KQ_FWD_PRUNED
+    _compare(plan, got, want)
+    # the last blocks on their own: an accumulated phase error would show there first
+    for c in range(len(plan)):
+        assert rel_rms(np.concatenate(got[c]["audio"][-8:]), np.concatenate(want[c][0][-8:])) < AUDIO_TOL
+    swept = [dict(plan[0], doppler=4000.0, doppler_rate=-60.0, second_lo=plan[0]["second_lo"] - 4000.0)]
+    want = run_oracle(swept, g, iq[:100 * g["L"]], 100)
+    got, _ = _run_bank(swept, g, iq[:100 * g["L"]], 100, kq.KQ_FWD_FULL, per_call=32)
+    _compare(swept, got, want)
+
+
 def test_int16_ingest_and_zero_fill(gpu):
     """radio.c:110-122 int16 scaling + gain_factor, and the lost-packet zero fill of radio.c:81-100."""
     import kq_oracle as ko

@@ -32,6 +32,16 @@ void set_err(const char *fmt, ...) {
   g_err = buf;
 }
 
+// launch errors are sticky until read: name the launch group that failed
+#define LAUNCH_CHECK(what)                                                          \
+  do {                                                                              \
+    hipError_t e_ = hipGetLastError();                                              \
+    if (e_ != hipSuccess) {                                                         \
+      set_err("kernel launch failed in %s: %s", what, hipGetErrorString(e_));       \
+      return -1;                                                                    \
+    }                                                                               \
+  } while (0)
+
 #define HIP_TRY(expr)                                                                  \
   do {                                                                                 \
     hipError_t e_ = (expr);                                                            \
@@ -455,6 +465,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     kq::launch_block_energy(b->stream, window + (g.M - 1), g.L, (int)nblocks,
                             reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power);
   }
+  LAUNCH_CHECK("IF power");
   {
     Scope t(b, 0, b->stream);
     // full-spectrum path: the register-resident N = 16384 kernel where it applies (KQ_FULL_LDS=1 forces the LDS one)
@@ -485,6 +496,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
       full_launch(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, b->cfg.compute_n0, b->spec_dump, b->spec_ch,
                   nullptr);
     }
+    LAUNCH_CHECK("pre-detection filter");
     b->acc.filter_launches++;
     b->acc.channel_blocks += (uint64_t)C * nblocks;
   }
@@ -508,6 +520,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
                         (int)nblocks, b->cfg.compute_n0);
     }
   }
+  LAUNCH_CHECK("demodulators");
   if (!b->list_pll_host.empty())
     kq::launch_demod_pll(b->stream2, g, chd, pl, b->tw, b->list_pll_dev, (int)b->list_pll_host.size(), b->pll_state,
                          b->pll_rings, b->pll_side, (int)nblocks, b->cfg.compute_n0);
@@ -515,9 +528,9 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     kq::launch_pl_track(b->stream2, g, chd, pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), (int)nblocks);
   if (b->pcm_on) kq::launch_pcm(b->stream2, g, pl, b->pcm, b->pcm_mask, C, (int)nblocks);
   if (b->stream2 != b->stream) HIP_TRY(hipEventRecord(b->ev_demod_done[pp], b->stream2));
+  LAUNCH_CHECK("PLL / PL tone / PCM stage");
   b->pl = pl;  // what the pull functions read
   b->calls++;
-  HIP_TRY(hipGetLastError());
   b->n_abs += (int64_t)nblocks * g.L;
   b->out_abs += (int64_t)nblocks * g.olen;
   for (HostChan &h : b->chans) {
@@ -627,8 +640,8 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   } else if (cfg->fwd_mode == KQ_FWD_FULL) {
     b->fwd_mode = KQ_FWD_FULL;
   } else {
-    // N/D = 256 (cfg 2): the pruned kernel is correct but not yet faster than the full path (2.24 vs 2.12 ms
-    // per 16384 channel-blocks), so AUTO keeps the full path there; KQ_FWD_PRUNED still selects it explicitly
+    // N/D = 256 (cfg 2): the pruned kernel is correct but slower than the full-spectrum kernel (2.24 vs 0.45 ms per
+    // 16384 channel-blocks), so AUTO keeps the full path there; KQ_FWD_PRUNED still selects it explicitly
     b->fwd_mode = (can_prune && g.Ndec != 256) ? KQ_FWD_PRUNED : KQ_FWD_FULL;
   }
   if (b->fwd_mode == KQ_FWD_FULL && N > 16384 && (!kq::split_supported(g) || cfg->compute_n0)) {
@@ -811,6 +824,11 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
   }
   if (std::isnan(cfg->low) || std::isnan(cfg->high)) {  // filter.c:504-505
     set_err("NaN filter edge");
+    return -1;
+  }
+  if (cfg->demod_type == KQ_FM_DEMOD && !kq::demod64_supported(b->g) && kq::demod_fm_lds_bytes(b->g) > 160 * 1024) {
+    // the FM demodulator keeps one block of samples and the N/D-point audio master in LDS
+    set_err("FM needs N/decimate <= 4096 at this geometry (%zu bytes of LDS, the CU has 160 KiB)", kq::demod_fm_lds_bytes(b->g));
     return -1;
   }
   if (cfg->demod_type == KQ_LINEAR_DEMOD && cfg->pll) {

@@ -103,6 +103,7 @@ bool pruned_supported(const Geom &g);
 void launch_filter_pruned(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                           const float2 *chan_tw, int nchan, int nblocks, bool swept);
 void launch_pruned_tables(hipStream_t s, const Geom &g, const ChanDev &ch, float2 *chan_tw, int nchan);
+size_t demod_fm_lds_bytes(const Geom &g);
 void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw,
                    const int *list_fm, int n_fm, const int *list_am, int n_am, const int *list_lin, int n_lin,
                    int nblocks, int compute_n0);

@@ -741,11 +741,16 @@ void launch_pl_track(hipStream_t s, const Geom &g, const ChanDev &ch, const Plan
   hipLaunchKernelGGL(k_pl_track, dim3(n_fm), dim3(1024), 16384 * 8, s, g, ch, pl, tw, list_fm, nblocks);
 }
 
+// dynamic LDS of the generic FM demodulator (k_demod_fm): samples, masks, the audio master and its transform
+size_t demod_fm_lds_bytes(const Geom &g) {
+  return (size_t)g.olen * (8 + 4 + 4 + 4 + 4) + (size_t)g.Ndec * (8 + 4) + (size_t)g.pl_n * 8 + (size_t)(g.Ndec / 2) * 8 +
+         (size_t)(g.Ndec / 2 + 1) * 8;
+}
+
 void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_fm,
                    int n_fm, const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0) {
   if (n_fm > 0) {
-    size_t const lds_bytes = (size_t)g.olen * (8 + 4 + 4 + 4 + 4) + (size_t)g.Ndec * (8 + 4) + (size_t)g.pl_n * 8 +
-                             (size_t)(g.Ndec / 2) * 8 + (size_t)(g.Ndec / 2 + 1) * 8;
+    size_t const lds_bytes = demod_fm_lds_bytes(g);
     static size_t configured = 0;
     if (lds_bytes > configured) {
       (void)hipFuncSetAttribute((const void *)k_demod_fm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -168,6 +168,66 @@ def test_full_size_pruned_and_full_spectrum_agree_on_every_channel(gpu):
     assert worst > 0          # two different code paths, not one result read twice
 
 
+GEOMETRIES = [
+    # N,     L,     M,    D,   samprate, forward mode, compute_n0
+    (512,   256,   257,   2,   192000, "full", True),        # N/D = 256 on the LDS kernel
+    (1024,  768,   257,   4,   192000, "full", True),        # L != M - 1
+    (2048,  1024,  1025,  8,   384000, "full", False),
+    (4096,  3072,  1025,  16,  2000000, "full", True),
+    (4096,  2048,  2049,  64,  2000000, "pruned", False),    # pruned, R = 64
+    (8192,  4096,  4097,  128, 2000000, "pruned", False),    # pruned, R = 128
+    (8192,  4096,  4097,  64,  2000000, "auto", False),      # N/D = 128 below 65536: full path
+    (16384, 12288, 4097,  64,  2000000, "full", True),       # full-spectrum kernel, L != M - 1, N/D = 256
+    (16384, 8192,  8193,  32,  1000000, "full", True),       # N/D = 512
+    (16384, 8192,  8193,  2,   192000, "full", False),       # N/D = 8192: beyond the register kernel's epilogue, LDS kernel
+]
+
+
+def _sweep_case(N, L, M, D, fs):
+    ds = fs / D
+    bw = min(8000.0, 0.2 * ds)
+    f0 = 0.11 * fs
+    plan = [dict(demod="fm", low=-bw, high=bw, second_lo=-f0),
+            dict(demod="am", low=-0.6 * bw, high=0.6 * bw, second_lo=-f0 - 0.37 * ds, hangtime=0.0, recovery_rate=50.0),
+            dict(demod="linear", low=0.02 * bw, high=0.4 * bw, second_lo=-f0 + 0.21 * ds, hangtime=1.1, recovery_rate=6.0),
+            dict(demod="linear", low=-0.5 * bw, high=0.5 * bw, second_lo=-f0 - 1.3, isb=1, channels=2, hangtime=1.1,
+                 recovery_rate=6.0, shift=0.01 * ds)]
+    nblocks = 5
+    rng = np.random.default_rng(N + D)
+    t = np.arange(nblocks * L) / fs
+    dev = min(3000.0, 0.25 * bw)
+    sig = 0.3 * np.exp(1j * (2 * np.pi * f0 * t + (dev / 500.0) * np.sin(2 * np.pi * 500.0 * t)))
+    sig += 0.1 * np.exp(2j * np.pi * (f0 + 0.37 * ds) * t) * (1 + 0.5 * np.sin(2 * np.pi * 300.0 * t))
+    sig += 0.05 * np.exp(2j * np.pi * (f0 - 0.21 * ds + 0.2 * bw) * t)       # a tone inside the USB channel's passband
+    # 30 dB in-channel SNR on the FM carrier: with less noise the FM variance estimate (fm.c:101) is rounding noise
+    # and the squelch decision with it
+    sigma = 0.3 * 10 ** (-30 / 20) / np.sqrt(4 * bw / fs)
+    iq = (sig + sigma * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    return plan, iq, nblocks
+
+
+@pytest.mark.parametrize("N,L,M,D,fs,mode,n0", GEOMETRIES)
+def test_geometry_sweep(gpu, N, L, M, D, fs, mode, n0):
+    """Every kernel family over the geometries it claims: unequal L / M splits, small and large N/D, both sample-rate
+    regimes of compute_n0's wrapped mask, FM / AM / USB / ISB-stereo on each."""
+    assert L + M - 1 == N
+    g = dict(samprate=fs, L=L, M=M, D=D)
+    plan, iq, nblocks = _sweep_case(N, L, M, D, fs)
+    if N // D > 4096:
+        # the FM demodulator's working set (one block + the N/D-point audio master) must fit the CU's LDS
+        bank = kq.Bank(fs, L, M, D, 1, 1)
+        with pytest.raises(kq.KqError, match="FM needs N/decimate"):
+            bank.add_channel(bank_cfg(plan[0]))
+        bank.close()
+        plan = plan[1:]
+    want = run_oracle(plan, g, iq, nblocks, compute_n0=int(n0))
+    fwd = {"full": kq.KQ_FWD_FULL, "pruned": kq.KQ_FWD_PRUNED, "auto": kq.KQ_FWD_AUTO}[mode]
+    got, used = _run_bank(plan, g, iq, nblocks, fwd, compute_n0=n0, per_call=3)
+    if mode != "auto":
+        assert used == fwd
+    _compare(plan, got, want, check_n0=n0)
+
+
 def test_long_run_phase_continuity(gpu):
     """2.5 million input samples (300 blocks over five process calls, more than 150 renormalisation periods of the
     reference's NCO recurrence): the closed-form oscillators of the bank must not drift away from the oracle's

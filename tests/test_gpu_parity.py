@@ -180,6 +180,9 @@ GEOMETRIES = [
     (16384, 12288, 4097,  64,  2000000, "full", True),       # full-spectrum kernel, L != M - 1, N/D = 256
     (16384, 8192,  8193,  32,  1000000, "full", True),       # N/D = 512
     (16384, 8192,  8193,  2,   192000, "full", False),       # N/D = 8192: beyond the register kernel's epilogue, LDS kernel
+    (32768, 16384, 16385, 128, 4000000, "full", False),      # beyond one LDS block: split kernel, N/D = 256
+    (65536, 49152, 16385, 32,  8000000, "full", False),      # split kernel at its limits: N = 65536, N/D = 2048, L != M - 1
+    (65536, 32768, 32769, 512, 20000000, "auto", False),     # cfg 5 geometry with FM / AM on it too
 ]
 
 

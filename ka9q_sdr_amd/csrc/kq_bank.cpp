@@ -281,10 +281,11 @@ int upload_response(kq_bank *b, int c) {
 
 // Pre-detection response: set_filter with edges normalised to the output rate
 // (fm.c:35: low/dsamprate; am.c:41, linear.c:81: samptime*low)
-void design_channel(kq_bank *b, HostChan &h) {
+// `runtime`: a change made while running goes through display.c:161-177, which scales by samptime whatever the mode
+void design_channel(kq_bank *b, HostChan &h, bool runtime = false) {
   kq::Geom const &g = b->g;
   float lo_n, hi_n;
-  if (h.cfg.demod_type == KQ_FM_DEMOD) {
+  if (h.cfg.demod_type == KQ_FM_DEMOD && !runtime) {
     lo_n = h.cfg.low / g.dsamprate;
     hi_n = h.cfg.high / g.dsamprate;
   } else {
@@ -294,6 +295,7 @@ void design_channel(kq_bank *b, HostChan &h) {
   }
   h.resp = kq::design_response(g.N, g.olen, g.Mdec, h.out_type, lo_n, hi_n, h.cfg.kaiser_beta);
   h.noise_gain = kq::noise_gain(h.resp, g.N, g.Ndec, false, h.out_type);
+  if (runtime) return;  // the FM audio response is designed once, in the demodulator's prologue (fm.c:54-66)
   if (h.cfg.demod_type == KQ_FM_DEMOD && !h.cfg.flat)
     h.aresp = kq::design_fm_audio_response(g.olen, g.Mdec, g.dsamprate, h.cfg.kaiser_beta);
   else
@@ -934,7 +936,7 @@ int kq_bank_set_filter(kq_bank *b, int ch, float low, float high, float beta) {
   h.cfg.low = low;
   h.cfg.high = high;
   h.cfg.kaiser_beta = beta;
-  design_channel(b, h);
+  design_channel(b, h, true);
   float const fm_gain = (float)((h.cfg.headroom * M_1_PI * b->g.dsamprate) / fabsf(low - high));
   if (upload(b, b->chd.low + ch, &low, sizeof(float))) return -1;
   if (upload(b, b->chd.high + ch, &high, sizeof(float))) return -1;

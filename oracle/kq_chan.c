@@ -88,6 +88,21 @@ static void chan_set_shift(kqo_chan *c, double shift){
     kqo_set_osc(&c->shift, shift * c->cfg.D / (double)c->cfg.samprate, 0.0);
 }
 
+void kqo_chan_set_shift(kqo_chan *c, double shift_hz){                    /* radio.c:304-311 */
+  c->cfg.shift_hz = shift_hz;
+  chan_set_shift(c, shift_hz);
+}
+
+/* Run-time filter change as the UI does it (display.c:161-177): new edges into demod->filter.{low,high,kaiser_beta},
+ * then set_filter(filter.out, samptime*low, samptime*high, beta) -- samptime scaling whatever the mode.  The new
+ * response is picked up by the next execute_filter_output (filter.c:538-543). */
+void kqo_chan_set_filter(kqo_chan *c, float low, float high, float beta){
+  c->cfg.low = low;
+  c->cfg.high = high;
+  c->cfg.kaiser_beta = beta;
+  kqo_set_filter(c->slave, c->samptime * low, c->samptime * high, beta);
+}
+
 /* radio.c:383-425.  The reference forms n*samprate in int (radio.c:407,409), which overflows
  * for N/2*samprate >= 2^31 (all the multi-MS/s configs); the oracle reproduces the wrapped
  * 32-bit product that gcc emits, so passband exclusion matches the compiled reference. */

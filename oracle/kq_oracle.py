@@ -100,6 +100,8 @@ def lib():
     L.kqo_chan_audio_response.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
     L.kqo_chan_audio_response.restype = C.c_void_p
     L.kqo_chan_set_lo2.argtypes = [C.c_void_p, C.c_double]
+    L.kqo_chan_set_shift.argtypes = [C.c_void_p, C.c_double]
+    L.kqo_chan_set_filter.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
     L.kqo_chan_set_doppler.argtypes = [C.c_void_p, C.c_double, C.c_double]
     L.kqo_compute_n0.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.c_float, C.c_float]
     L.kqo_compute_n0.restype = C.c_float
@@ -257,6 +259,12 @@ class Channel:
 
     def set_lo2(self, hz):
         self.L.kqo_chan_set_lo2(self.h, hz)
+
+    def set_shift(self, hz):
+        self.L.kqo_chan_set_shift(self.h, hz)
+
+    def set_filter(self, low, high, beta):
+        self.L.kqo_chan_set_filter(self.h, low, high, beta)
 
     def set_doppler(self, hz, rate):
         self.L.kqo_chan_set_doppler(self.h, hz, rate)

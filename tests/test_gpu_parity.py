@@ -8,7 +8,8 @@ import pytest
 
 import ka9q_sdr_amd as kq
 from ka9q_sdr_amd import workload as wl
-from common import bank_cfg, rel_rms, run_oracle
+import kq_oracle as ko
+from common import bank_cfg, oracle_cfg, rel_rms, run_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -229,6 +230,50 @@ def test_geometry_sweep(gpu, N, L, M, D, fs, mode, n0):
     if mode != "auto":
         assert used == fwd
     _compare(plan, got, want, check_n0=n0)
+
+
+def test_filter_and_shift_changed_while_running(gpu):
+    """What the UI does between blocks (display.c:161-177, radio.c:304-311): new filter edges / Kaiser beta and a new
+    post-detection shift; the response is swapped at the next block (filter.c:538-543), the shift oscillator keeps
+    its phase (osc.c:24-27)."""
+    g = dict(samprate=192000, L=512, M=513, D=4)
+    fs, L = g["samprate"], g["L"]
+    nb = 9
+    plan = wl.channel_plan("cfg1", 1) + [dict(demod="linear", low=100.0, high=3000.0, second_lo=-20000.0, hangtime=1.1,
+                                               recovery_rate=6.0, shift=150.0),
+                                          dict(demod="am", low=-5000.0, high=5000.0, second_lo=-20000.0, recovery_rate=50.0)]
+    iq = wl.make_iq(fs, nb * L, seed=51)
+    t = np.arange(nb * L) / fs
+    iq = (iq + 0.2 * np.exp(2j * np.pi * 21000.0 * t) * (1 + 0.4 * np.sin(2 * np.pi * 400.0 * t))).astype(np.complex64)
+    bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), 3, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL)
+    chans = []
+    for p in plan:
+        bank.add_channel(bank_cfg(p))
+        chans.append(ko.Channel(oracle_cfg(p, fs, L, g["M"], g["D"], compute_n0=1)))
+    changes = {3: [("filter", 0, (-6000.0, 6000.0, 5.0)), ("filter", 1, (250.0, 2400.0, 3.0)), ("shift", 1, 300.0)],
+               6: [("filter", 2, (-3000.0, 4000.0, 1.0)), ("shift", 1, 0.0), ("filter", 0, (-9000.0, 7000.0, 3.0))]}
+    for first in range(0, nb, 3):
+        for kind, c, arg in changes.get(first, []):
+            if kind == "filter":
+                bank.set_filter(c, *arg)
+                chans[c].set_filter(*arg)
+            else:
+                bank.set_shift(c, arg)
+                chans[c].set_shift(arg)
+        bank.push_iq(iq[first * L:(first + 3) * L])
+        assert bank.process() == 3
+        for b in range(3):
+            for c, ch in enumerate(chans):
+                wa, ws, _, _ = ch.block(iq[(first + b) * L:(first + b + 1) * L])
+                ga, gs = bank.audio(c, b), bank.status(c, b)
+                assert gs["nout"] == ws["nout"]
+                if not (plan[c]["demod"] == "linear" and first + b == 0):       # AGC start-up, see _compare
+                    assert rel_rms(ga, wa) < AUDIO_TOL, (first + b, c, rel_rms(ga, wa))
+                np.testing.assert_allclose(gs["n0"], ws["n0"], rtol=2e-4)
+                np.testing.assert_allclose(gs["bb_power"], ws["bb_power"], rtol=2e-5)
+    for c, ch in enumerate(chans):
+        np.testing.assert_allclose(bank.response(c), ch.response(), rtol=0, atol=2e-9)
+    bank.close()
 
 
 def test_long_run_phase_continuity(gpu):

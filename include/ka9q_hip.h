@@ -125,6 +125,14 @@ int kq_bank_destroy(kq_bank *bank);                               /* filter.c:25
  *     Returns the channel index (>= 0) or -1. --- */
 int kq_bank_add_channel(kq_bank *bank, const kq_channel_config *cfg);
 unsigned kq_bank_num_channels(const kq_bank *bank);
+/* set_mode (radio.c:322-374) on a running channel: the demodulator is torn down and started afresh with the mode's
+ * demod_type, flat, isb, channels, pll, square, recovery_rate, hangtime, low / high (swapped when low > high),
+ * kaiser_beta, headroom and shift -- new slave and response, demodulator state back at its prologue values (AGC gain,
+ * squelch, FM state, audio filter history, carrier loop).  What struct demod keeps survives: both input
+ * oscillators keep running (second_lo / doppler of `mode` are ignored), the shift oscillator keeps its phase,
+ * sig.n0, sig.foffset and sig.pdeviation keep their values.  (The reference then re-runs set_freq to pull the second
+ * LO back into range, radio.c:370 -- control plane, left to the caller.) */
+int kq_bank_set_mode(kq_bank *bank, int ch, const kq_channel_config *mode);
 
 /* --- tuning, all phase continuous and effective from the next block (osc.c:22-36) --- */
 int kq_bank_set_second_lo(kq_bank *bank, int ch, double hz);                 /* radio.c:290 set_second_LO */

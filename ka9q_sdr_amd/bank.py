@@ -109,6 +109,7 @@ def load_library():
     L.kq_bank_create.argtypes = [C.POINTER(BankConfig)]
     L.kq_bank_destroy.argtypes = [C.c_void_p]
     L.kq_bank_add_channel.argtypes = [C.c_void_p, C.POINTER(ChannelConfig)]
+    L.kq_bank_set_mode.argtypes = [C.c_void_p, C.c_int, C.POINTER(ChannelConfig)]
     L.kq_bank_num_channels.argtypes = [C.c_void_p]
     L.kq_bank_num_channels.restype = C.c_uint
     L.kq_bank_set_second_lo.argtypes = [C.c_void_p, C.c_int, C.c_double]
@@ -205,6 +206,10 @@ class Bank:
 
     def add_channel(self, cfg):
         return self._chk(self.lib.kq_bank_add_channel(self.h, C.byref(cfg)), "kq_bank_add_channel")
+
+    def set_mode(self, ch, cfg):
+        """radio.c:322-374: restart channel `ch`'s demodulator with the mode described by `cfg`"""
+        self._chk(self.lib.kq_bank_set_mode(self.h, ch, C.byref(cfg)), "kq_bank_set_mode")
 
     @property
     def num_channels(self):

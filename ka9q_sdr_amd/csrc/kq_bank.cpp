@@ -231,7 +231,9 @@ int upload_n0mask(kq_bank *b, int c) {
 }
 
 // Derived per-channel constants, as each demod thread computes them in its prologue
-int upload_channel(kq_bank *b, int c) {
+// fresh = false: a new demodulator thread on an existing channel (set_mode): what struct demod keeps (sig.n0,
+// sig.foffset, sig.pdeviation) is left alone
+int upload_channel(kq_bank *b, int c, bool fresh = true) {
   if (sync_all(b)) return -1;  // quiesce both streams before touching per-channel state
   HostChan &h = b->chans[c];
   kq::Geom const &g = b->g;
@@ -260,8 +262,24 @@ int upload_channel(kq_bank *b, int c) {
   if (upload(b, b->chd.recovery + c, &recovery, sizeof(float))) return -1;
   if (upload(b, b->chd.hangmax + c, &hangmax, sizeof(int))) return -1;
   if (upload(b, b->chd.gain + c, &init_gain, sizeof(float))) return -1;
-  if (upload(b, b->chd.n0 + c, &nan, sizeof(float))) return -1;
+  if (fresh && upload(b, b->chd.n0 + c, &nan, sizeof(float))) return -1;
   if (upload(b, b->chd.fm_state + c, &one, sizeof(float2))) return -1;
+  // thread-local state of the demodulators at their prologue values (fm.c:26,68-69; am.c:26,33; linear.c:33)
+  HIP_TRY(hipMemsetAsync(b->chd.lastaudio + c, 0, sizeof(float), b->stream));
+  HIP_TRY(hipMemsetAsync(b->chd.sq_count + c, 0, sizeof(int), b->stream));
+  HIP_TRY(hipMemsetAsync(b->chd.hang + c, 0, sizeof(int), b->stream));
+  HIP_TRY(hipMemsetAsync(b->chd.dc + c, 0, sizeof(float), b->stream));
+  if (g.Mdec > 1) HIP_TRY(hipMemsetAsync(b->chd.ahist + (size_t)c * (g.Mdec - 1), 0, sizeof(float) * (g.Mdec - 1), b->stream));
+  if (fresh) {
+    HIP_TRY(hipMemsetAsync(b->chd.foffset + c, 0, sizeof(float), b->stream));
+    HIP_TRY(hipMemsetAsync(b->chd.pdev + c, 0, sizeof(float), b->stream));
+  }
+  if (g.pl_n > 0) {
+    HIP_TRY(hipMemsetAsync(b->chd.plring + (size_t)c * 16384, 0, sizeof(float) * 16384, b->stream));
+    HIP_TRY(hipMemsetAsync(b->chd.pl_ptr + c, 0, sizeof(*b->chd.pl_ptr), b->stream));
+    HIP_TRY(hipMemsetAsync(b->chd.pl_last + c, 0, sizeof(*b->chd.pl_last), b->stream));
+  }
+  if (upload(b, b->chd.plfreq + c, &nan, sizeof(float))) return -1;
   if (upload_n0mask(b, c)) return -1;
   if (sync_all(b)) return -1;  // also: the demod stream may still be reading the old parameters
   return 0;
@@ -878,6 +896,96 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
 }
 
 unsigned kq_bank_num_channels(const kq_bank *b) { return b ? (unsigned)b->chans.size() : 0; }
+
+namespace {
+bool is_pll(const kq_channel_config &c) { return c.demod_type == KQ_LINEAR_DEMOD && c.pll; }
+
+// PLL channels own the slot equal to their rank among the PLL channels (upload_lists): when a channel enters or
+// leaves that set the carried state of the channels behind it moves by one slot
+int move_pll_slot(kq_bank *b, int from, int to) {
+  HIP_TRY(hipMemcpy(b->pll_state + to, b->pll_state + from, sizeof(kq::PllState), hipMemcpyDeviceToDevice));
+  HIP_TRY(hipMemcpy(b->pll_rings + (size_t)to * 65536, b->pll_rings + (size_t)from * 65536, sizeof(float2) * 65536,
+                    hipMemcpyDeviceToDevice));
+  return 0;
+}
+}  // namespace
+
+int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
+  if (!valid_ch(b, ch) || !m) {
+    set_err("bad channel or NULL mode");
+    return -1;
+  }
+  if (m->demod_type < KQ_LINEAR_DEMOD || m->demod_type > KQ_FM_DEMOD) {
+    set_err("unknown demod_type %d", m->demod_type);
+    return -1;
+  }
+  if (std::isnan(m->low) || std::isnan(m->high)) {
+    set_err("NaN filter edge");
+    return -1;
+  }
+  if (m->demod_type == KQ_FM_DEMOD && !kq::demod64_supported(b->g) && kq::demod_fm_lds_bytes(b->g) > 160 * 1024) {
+    set_err("FM needs N/decimate <= 4096 at this geometry");
+    return -1;
+  }
+  if (sync_all(b)) return -1;  // pthread_join of the old demodulator thread (radio.c:335-337)
+  HostChan &h = b->chans[ch];
+  bool const was = is_pll(h.cfg), now = is_pll(*m);
+  int rank = 0, npll = 0;
+  for (int c = 0; c < (int)b->chans.size(); c++) {
+    if (c != ch && is_pll(b->chans[c].cfg)) {
+      npll++;
+      if (c < ch) rank++;
+    }
+  }
+  if (now) {
+    if (npll >= kq_bank::kMaxPll) {
+      set_err("at most %d carrier-tracking (pll) channels per bank", kq_bank::kMaxPll);
+      return -1;
+    }
+    float const samptime = (float)b->g.D / (float)b->g.samprate;
+    float const binsize = (float)(1. / (65536 * samptime));
+    if (2 * (int)round((m->square ? 2 : 1) * 300.f / binsize) + 1 > 4096) {
+      set_err("output rate too low for the PLL search window");
+      return -1;
+    }
+    if (!b->pll_state) {
+      if (dev_alloc(&b->pll_state, kq_bank::kMaxPll) || dev_alloc(&b->pll_rings, (size_t)kq_bank::kMaxPll * 65536) ||
+          dev_alloc(&b->pll_side, (size_t)kq_bank::kMaxPll * 4096) || dev_alloc(&b->list_pll_dev, kq_bank::kMaxPll))
+        return -1;
+    }
+  }
+  if (was && !now) {
+    for (int s = rank; s < npll; s++)
+      if (move_pll_slot(b, s + 1, s)) return -1;
+  } else if (!was && now) {
+    for (int s = npll; s > rank; s--)
+      if (move_pll_slot(b, s - 1, s)) return -1;
+  }
+  if (now) {  // a fresh loop (linear.c:97-112)
+    HIP_TRY(hipMemset(b->pll_state + rank, 0, sizeof(kq::PllState)));
+    HIP_TRY(hipMemset(b->pll_rings + (size_t)rank * 65536, 0, sizeof(float2) * 65536));
+  }
+  // the mode table entry (radio.c:341-363); the input oscillators are not touched
+  h.cfg.demod_type = m->demod_type;
+  h.cfg.low = m->low > m->high ? m->high : m->low;  // radio.c:343-349
+  h.cfg.high = m->low > m->high ? m->low : m->high;
+  h.cfg.flat = m->flat;
+  h.cfg.isb = m->isb;
+  h.cfg.channels = m->channels;
+  h.cfg.pll = m->pll;
+  h.cfg.square = m->square;
+  h.cfg.recovery_rate = m->recovery_rate;
+  h.cfg.hangtime = m->hangtime;
+  h.cfg.kaiser_beta = m->kaiser_beta;
+  h.cfg.headroom = m->headroom;
+  h.cfg.shift = m->shift;
+  h.out_type = (m->demod_type == KQ_LINEAR_DEMOD && m->isb) ? kq::FT_CROSS_CONJ : kq::FT_COMPLEX;
+  h.shift.set(m->shift == 0 ? 0.0 : m->shift * b->g.D / (double)b->g.samprate, 0.0, b->out_abs);  // radio.c:367
+  design_channel(b, h);
+  if (upload_channel(b, ch, false) || upload_response(b, ch)) return -1;
+  b->lists_dirty = true;
+  return 0;
+}
 
 int kq_bank_set_second_lo(kq_bank *b, int ch, double hz) {
   if (!valid_ch(b, ch) || std::isnan(hz)) {

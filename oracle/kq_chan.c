@@ -133,32 +133,17 @@ float kqo_compute_n0(const float complex *fdomain, unsigned N, int samprate, flo
   return avg / (2.0 * N * samprate);
 }
 
-kqo_chan *kqo_chan_create(const kqo_chan_cfg *cfg){
-  kqo_chan *c = calloc(1, sizeof(*c));
-  c->cfg = *cfg;
-  c->master = kqo_create_filter_input(cfg->L, cfg->M, KQO_COMPLEX);       /* main.c:232 */
-  if(!c->master){
-    free(c);
-    return NULL;
-  }
-  c->n0 = NAN;
-  c->snr = 0;
-  c->samptime = (float)cfg->D / (float)cfg->samprate;                      /* am.c:21, linear.c:29 */
-  c->dsamprate = (float)cfg->samprate / cfg->D;                            /* fm.c:27 */
-  /* struct osc zero-initialised => phasor not initialised => first set_osc sets it to 1 */
-  kqo_chan_set_lo2(c, cfg->lo2_hz);
-  kqo_chan_set_doppler(c, cfg->doppler_hz, cfg->doppler_rate);
-  chan_set_shift(c, cfg->shift_hz);
-
+/* What a demodulator thread owns and builds in its prologue (fm.c:21-70, am.c:15-41, linear.c:21-112): the slave
+ * with its response, the audio / PL filters, and the thread-local state.  What lives in struct demod (oscillators,
+ * sig.n0, sig.foffset, sig.pdeviation) is not touched here. */
+static int demod_start(kqo_chan *c){
+  kqo_chan_cfg const *cfg = &c->cfg;
   int out_type = KQO_COMPLEX;
   if(cfg->demod_type == KQO_LINEAR && cfg->isb)
     out_type = KQO_CROSS_CONJ;                                             /* linear.c:78-79 */
   c->slave = kqo_create_filter_output(c->master, NULL, cfg->D, out_type);
-  if(!c->slave){
-    kqo_delete_filter_input(c->master);
-    free(c);
-    return NULL;
-  }
+  if(!c->slave)
+    return -1;
   switch(cfg->demod_type){
   case KQO_FM:{
     kqo_set_filter(c->slave, cfg->low / c->dsamprate, cfg->high / c->dsamprate, cfg->kaiser_beta); /* fm.c:35 */
@@ -183,6 +168,7 @@ kqo_chan *kqo_chan_create(const kqo_chan_cfg *cfg){
       int const PL_decimate = 32;
       int const PL_N = AN / PL_decimate, PL_L = AL / PL_decimate, PL_M = PL_N - PL_L + 1;
       c->plfreq = NAN;
+      c->pl_fft_ptr = c->pl_last_fft = 0;
       if(PL_N >= 4 && PL_L >= 1 && (PL_N & (PL_N - 1)) == 0){
         c->pl_samprate = c->dsamprate / PL_decimate;
         float complex *plr = calloc(PL_N / 2 + 1, sizeof(float complex));
@@ -199,19 +185,23 @@ kqo_chan *kqo_chan_create(const kqo_chan_cfg *cfg){
         c->pl_plan = kqo_fft_create(pl_fft_size);
       }
     }
+    c->hangcount = 0;                                                      /* no such state in the FM thread */
     c->fm_state = 1;                                                       /* fm.c:26 */
-    c->pdeviation = 0;
-    c->foffset = 0;
+    c->lastaudio = 0;                                                      /* fm.c:68-69 */
+    c->snr_below_threshold = 0;
     break;
   }
   case KQO_AM:
     kqo_set_filter(c->slave, c->samptime * cfg->low, c->samptime * cfg->high, cfg->kaiser_beta); /* am.c:41 */
+    c->hangcount = 0;                                                      /* am.c:26 */
     c->recovery_factor = DB2VOLTAGE(cfg->recovery_rate * c->samptime);     /* am.c:27 */
     c->hangmax = cfg->hangtime / c->samptime;                              /* am.c:29 */
     c->agc_gain = DB2VOLTAGE(80.);                                         /* am.c:30 */
+    c->dc_filter = 0;                                                      /* am.c:33 */
     break;
   default:
     kqo_set_filter(c->slave, c->samptime * cfg->low, c->samptime * cfg->high, cfg->kaiser_beta); /* linear.c:81 */
+    c->hangcount = 0;                                                      /* linear.c:33 */
     c->recovery_factor = DB2VOLTAGE(cfg->recovery_rate * c->samptime);     /* linear.c:34 */
     c->hangmax = cfg->hangtime / c->samptime;                              /* linear.c:38 */
     c->agc_gain = DB2VOLTAGE(100.0);                                       /* linear.c:39 */
@@ -220,19 +210,22 @@ kqo_chan *kqo_chan_create(const kqo_chan_cfg *cfg){
       c->pll_fftin = calloc(1 << 16, sizeof(float complex));               /* linear.c:89-93 */
       c->pll_fftout = calloc(1 << 16, sizeof(float complex));
       c->pll_plan = kqo_fft_create(1 << 16);
+      memset(&c->pll_fine, 0, sizeof c->pll_fine);
+      memset(&c->pll_coarse, 0, sizeof c->pll_coarse);
       c->pll_fine.phasor = 1;                                              /* linear.c:97-105 */
       kqo_set_osc(&c->pll_fine, 0.0, 0.0);
       c->pll_coarse.phasor = 1;
       kqo_set_osc(&c->pll_coarse, 0.0, 0.0);
+      c->pll_integrator = c->pll_delta_f = c->pll_ramp = c->cphase = 0;
+      c->pll_lock_count = c->pll_lock = c->pll_fft_samples = c->pll_fft_ptr = 0;
     }
     break;
   }
-  return c;
+  return 0;
 }
 
-void kqo_chan_destroy(kqo_chan *c){
-  if(!c)
-    return;
+/* the thread's exit path (fm.c:175-183, am.c:80-82, linear.c:313-321) */
+static void demod_stop(kqo_chan *c){
   free(c->pll_fftin);
   free(c->pll_fftout);
   kqo_fft_destroy(c->pll_plan);
@@ -243,6 +236,75 @@ void kqo_chan_destroy(kqo_chan *c){
   kqo_delete_filter_output(c->audio_filter);
   kqo_delete_filter_input(c->audio_master);
   kqo_delete_filter_output(c->slave);
+  c->pll_fftin = c->pll_fftout = NULL;
+  c->pll_plan = NULL;
+  c->pl_filter = NULL;
+  c->pl_input = NULL;
+  c->pl_spectrum = NULL;
+  c->pl_plan = NULL;
+  c->audio_filter = NULL;
+  c->audio_master = NULL;
+  c->slave = NULL;
+}
+
+kqo_chan *kqo_chan_create(const kqo_chan_cfg *cfg){
+  kqo_chan *c = calloc(1, sizeof(*c));
+  c->cfg = *cfg;
+  c->master = kqo_create_filter_input(cfg->L, cfg->M, KQO_COMPLEX);       /* main.c:232 */
+  if(!c->master){
+    free(c);
+    return NULL;
+  }
+  c->n0 = NAN;
+  c->snr = 0;
+  c->samptime = (float)cfg->D / (float)cfg->samprate;                      /* am.c:21, linear.c:29 */
+  c->dsamprate = (float)cfg->samprate / cfg->D;                            /* fm.c:27 */
+  /* struct osc zero-initialised => phasor not initialised => first set_osc sets it to 1 */
+  kqo_chan_set_lo2(c, cfg->lo2_hz);
+  kqo_chan_set_doppler(c, cfg->doppler_hz, cfg->doppler_rate);
+  chan_set_shift(c, cfg->shift_hz);
+  c->pdeviation = 0;
+  c->foffset = 0;
+  if(demod_start(c) != 0){
+    kqo_delete_filter_input(c->master);
+    free(c);
+    return NULL;
+  }
+  return c;
+}
+
+/* set_mode (radio.c:322-374): the running demodulator thread is joined and a fresh one started with the new mode's
+ * parameters.  From `mode`: demod_type, flat, isb, channels, pll, square, recovery_rate, hangtime, low / high (swapped
+ * when low > high, radio.c:343-349), shift (set_shift keeps the shift oscillator's phase), kaiser_beta, headroom.
+ * The input oscillators keep running; sig.n0, sig.foffset and sig.pdeviation keep their values. */
+int kqo_chan_set_mode(kqo_chan *c, const kqo_chan_cfg *mode){
+  demod_stop(c);
+  c->cfg.demod_type = mode->demod_type;
+  if(mode->low > mode->high){
+    c->cfg.low = mode->high;
+    c->cfg.high = mode->low;
+  } else {
+    c->cfg.low = mode->low;
+    c->cfg.high = mode->high;
+  }
+  c->cfg.shift_hz = mode->shift_hz;
+  c->cfg.flat = mode->flat;
+  c->cfg.isb = mode->isb;
+  c->cfg.channels = mode->channels;
+  c->cfg.pll = mode->pll;
+  c->cfg.square = mode->square;
+  c->cfg.recovery_rate = mode->recovery_rate;
+  c->cfg.hangtime = mode->hangtime;
+  c->cfg.kaiser_beta = mode->kaiser_beta;
+  c->cfg.headroom = mode->headroom;
+  chan_set_shift(c, c->cfg.shift_hz);                                      /* radio.c:367 */
+  return demod_start(c);
+}
+
+void kqo_chan_destroy(kqo_chan *c){
+  if(!c)
+    return;
+  demod_stop(c);
   kqo_delete_filter_input(c->master);
   free(c);
 }

@@ -156,6 +156,8 @@ void kqo_chan_destroy(kqo_chan *c);
 /* Retune while running (phase continuous, osc.c:24-27) */
 void kqo_chan_set_lo2(kqo_chan *c, double lo2_hz);
 void kqo_chan_set_doppler(kqo_chan *c, double hz, double rate);
+/* set_mode (radio.c:322-374): fresh demodulator thread with the new mode, oscillators and sig.n0 carried over */
+int kqo_chan_set_mode(kqo_chan *c, const kqo_chan_cfg *mode);
 void kqo_chan_set_shift(kqo_chan *c, double shift_hz);                       /* radio.c:304-311 */
 void kqo_chan_set_filter(kqo_chan *c, float low, float high, float beta);    /* display.c:161-177 */
 /* Feed exactly L complex-float samples (re,im interleaved), run the whole chain for one block.

@@ -100,6 +100,7 @@ def lib():
     L.kqo_chan_audio_response.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
     L.kqo_chan_audio_response.restype = C.c_void_p
     L.kqo_chan_set_lo2.argtypes = [C.c_void_p, C.c_double]
+    L.kqo_chan_set_mode.argtypes = [C.c_void_p, C.c_void_p]
     L.kqo_chan_set_shift.argtypes = [C.c_void_p, C.c_double]
     L.kqo_chan_set_filter.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
     L.kqo_chan_set_doppler.argtypes = [C.c_void_p, C.c_double, C.c_double]
@@ -259,6 +260,11 @@ class Channel:
 
     def set_lo2(self, hz):
         self.L.kqo_chan_set_lo2(self.h, hz)
+
+    def set_mode(self, cfg):
+        """radio.c:322-374 with the fields of `cfg` (a ChanCfg) as the mode table entry"""
+        assert self.L.kqo_chan_set_mode(self.h, C.byref(cfg)) == 0
+        self.olen = self.L.kqo_chan_olen(self.h)
 
     def set_shift(self, hz):
         self.L.kqo_chan_set_shift(self.h, hz)

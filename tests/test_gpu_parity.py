@@ -276,6 +276,57 @@ def test_filter_and_shift_changed_while_running(gpu):
     bank.close()
 
 
+def test_set_mode_restarts_the_demodulator(gpu):
+    """set_mode on running channels (radio.c:322-374): FM -> AM, AM -> USB with a shift, USB -> FM, and a channel
+    entering a carrier-tracking mode ahead of an existing PLL channel (whose loop state has to move slots).  The new
+    demodulator starts from its prologue state; oscillators, n0, foffset and pdeviation carry over."""
+    g = wl.GEOMETRY["cfg1"]
+    fs, L = g["samprate"], g["L"]
+    nb, per = 24, 4
+    t = np.arange(nb * L) / fs
+    rng = np.random.default_rng(61)
+    sig = 0.1 * (1 + 0.5 * np.cos(2 * np.pi * 1000.0 * t)) * np.exp(2j * np.pi * (20000.0 + 23.0) * t)        # AM / CAM
+    sig += 0.2 * np.exp(1j * (2 * np.pi * 50000.0 * t + 3.0 * np.sin(2 * np.pi * 700.0 * t)))                  # FM
+    iq = (sig + 2e-3 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    fm = dict(demod="fm", low=-8000.0, high=8000.0)
+    am = dict(demod="am", low=-5000.0, high=5000.0, recovery_rate=50.0)
+    usb = dict(demod="linear", low=100.0, high=3000.0, hangtime=1.1, recovery_rate=6.0, shift=120.0)
+    cam = dict(demod="linear", low=-5000.0, high=5000.0, recovery_rate=50.0, pll=1)
+    plan = [dict(fm, second_lo=-50000.0), dict(am, second_lo=-20000.0), dict(usb, second_lo=-50000.0),
+            dict(cam, second_lo=-20000.0)]
+    # at block 8 the first three rotate modes; at block 16 channel 1 becomes a second PLL channel in front of channel 3
+    switch = {8: {0: am, 1: usb, 2: dict(fm, low=9000.0, high=-9000.0)}, 16: {1: dict(cam, square=0), 0: fm}}
+    bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), per, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL)
+    chans = []
+    for p in plan:
+        bank.add_channel(bank_cfg(p))
+        chans.append(ko.Channel(oracle_cfg(p, fs, L, g["M"], g["D"], compute_n0=1)))
+    cur = [dict(p) for p in plan]
+    since = [0] * len(plan)                                  # blocks since the channel's demodulator (re)started
+    for first in range(0, nb, per):
+        for c, m in switch.get(first, {}).items():
+            cur[c] = dict(m, second_lo=cur[c]["second_lo"])
+            bank.set_mode(c, bank_cfg(cur[c]))
+            chans[c].set_mode(oracle_cfg(cur[c], fs, L, g["M"], g["D"], compute_n0=1))
+            since[c] = 0
+        bank.push_iq(iq[first * L:(first + per) * L])
+        assert bank.process() == per
+        for b in range(per):
+            for c, ch in enumerate(chans):
+                wa, ws, _, _ = ch.block(iq[(first + b) * L:(first + b + 1) * L])
+                ga, gs = bank.audio(c, b), bank.status(c, b)
+                assert gs["nout"] == ws["nout"], (first + b, c)
+                assert (gs["squelch_count"], gs["hangcount"], gs["pll_lock"], gs["lock_count"]) == \
+                       (ws["squelch_count"], ws["hangcount"], ws["pll_lock"], ws["lock_count"]), (first + b, c)
+                np.testing.assert_allclose(gs["n0"], ws["n0"], rtol=2e-4)
+                linear = cur[c]["demod"] == "linear"
+                tol = 2e-5 if cur[c].get("pll") else AUDIO_TOL
+                if not (linear and since[c] == 0) and not (cur[c].get("pll") and since[c] < 6):
+                    assert rel_rms(ga, wa) < tol, (first + b, c, cur[c]["demod"], rel_rms(ga, wa))
+                since[c] += 1
+    bank.close()
+
+
 def test_long_run_phase_continuity(gpu):
     """2.5 million input samples (300 blocks over five process calls, more than 150 renormalisation periods of the
     reference's NCO recurrence): the closed-form oscillators of the bank must not drift away from the oracle's

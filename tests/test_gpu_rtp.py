@@ -87,3 +87,62 @@ def test_recording_file_playback(gpu, tmp_path):
     assert rel_rms(np.concatenate(got), np.concatenate(want)) < 1e-6
     a.close()
     b.close()
+
+
+def test_random_packet_sequences_keep_the_books_like_the_oracle(gpu):
+    """Differential test of the datagram bookkeeping (two independent implementations of multicast.c:305-340 and
+    radio.c:62-104): 600 datagrams with random duplicates, reordering, losses, timestamp jumps in both directions,
+    SSRC changes, both payload types, padding / CSRC / extension headers, and junk; after every datagram the library's
+    counters and the number of samples it queued must equal the oracle's."""
+    g = dict(samprate=192000, L=512, M=513, D=4)
+    bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], 1, 64)
+    bank.add_channel(bank_cfg(wl.channel_plan("cfg1", 1)[0]))
+    ing = ko.IqIngest()
+    rng = np.random.default_rng(77)
+    seq, ts, ssrc = 65000, 0xFFFFF000, 5
+    queued = 0
+    for k in range(600):
+        n = int(rng.integers(1, 200))
+        kind = 98 if rng.random() < 0.3 else 97
+        body = rng.integers(-100, 100, n * 2).astype("i1" if kind == 98 else "<i2").tobytes()
+        r = rng.random()
+        s_seq, s_ts, s_ssrc, ptype = seq, ts, ssrc, kind
+        if r < 0.08:
+            s_seq = seq - int(rng.integers(1, 5))                 # duplicate / late
+        elif r < 0.16:
+            s_seq = seq + int(rng.integers(1, 4))                 # datagrams lost
+            s_ts = ts + int(rng.integers(0, 3000))
+        elif r < 0.22:
+            s_ts = ts + int(rng.integers(1, 5000))                # timestamp gap
+        elif r < 0.26:
+            s_ts = ts - int(rng.integers(1, 5000))                # timestamp going backwards
+        elif r < 0.28:
+            s_ts = ts + 192001 + int(rng.integers(0, 1000))       # wild jump
+        elif r < 0.30:
+            s_ssrc = ssrc = int(rng.integers(1, 1 << 31))         # sender restarted
+            s_seq, s_ts = int(rng.integers(0, 65536)), int(rng.integers(0, 1 << 32))
+        elif r < 0.33:
+            ptype = 96                                            # not I/Q
+        extra = {}
+        if rng.random() < 0.1:
+            extra["csrc"] = tuple(range(int(rng.integers(1, 4))))
+        if rng.random() < 0.1:
+            extra["pad"] = int(rng.integers(1, 9))
+        if rng.random() < 0.05:
+            extra["ext"] = bytes(8)
+        pkt = rtp_packet(s_seq, s_ts, s_ssrc, body, ptype=ptype, **extra)
+        if rng.random() < 0.02:
+            pkt = pkt[:int(rng.integers(0, 12))]                  # truncated junk
+        want = ing.packet(pkt)
+        added = bank.push_rtp(pkt)
+        assert added == (0 if want is None else want[0] + want[2]), k
+        queued += added
+        if want is not None:                                      # the sender moves on from what was accepted
+            seq, ts = (s_seq + 1) & 0xFFFF, (s_ts + n) & 0xFFFFFFFF
+        c = bank.rtp_counters()
+        assert (c["samples"], c["packets"], c["dupes"], c["drops"], c["next_seq"], c["next_timestamp"], c["ssrc"]) == \
+               (ing.samples, ing.rtp.packets, ing.rtp.dupes, ing.rtp.drops, ing.rtp.seq, ing.rtp.timestamp, ing.rtp.ssrc), k
+        if bank.blocks_ready() >= 32:
+            queued -= bank.process() * g["L"]
+        assert bank.blocks_ready() == queued // g["L"]
+    bank.close()

@@ -96,3 +96,28 @@ def test_device_resident_feeds_bank(gpu):
     dec.close()
     bank.close()
     ref.close()
+
+
+def test_random_cascades_bit_exact(gpu):
+    """Twenty random cascades (1..11 stages, any switch point between the two filters, any rotation step, unit or
+    default attenuation) over random call sizes: still bit for bit."""
+    from ka9q_sdr_amd import Decimator
+    rng = np.random.default_rng(2025)
+    for trial in range(20):
+        log_dec = int(rng.integers(1, 12))
+        thr = int(rng.integers(0, 13))
+        offset = int(rng.integers(0, 4))
+        atten = float(rng.choice([0.0, 1.0, 0.37]))
+        max_out = 4096 >> max(0, log_dec - 6)
+        dec = Decimator(log_dec, thr, offset, filter_atten=atten, max_out=max_out)
+        fe = ko.FrontEndDecimator(log_dec, thr, offset, filter_atten=atten if atten else None)
+        for call in range(4):
+            n_out = int(rng.integers(1, max_out + 1))
+            x = _iq(n_out << log_dec, 1000 * trial + call, scale=0.02)
+            y, s16, e = dec.process(x)
+            wy, ws16, we = fe.process(x)
+            assert np.array_equal(y.view(np.uint32), wy.view(np.uint32)), (trial, log_dec, thr, offset, call)
+            ok = np.abs(np.float32(32767) * wy.real) < 32767
+            assert np.array_equal(s16[ok, 0], ws16[ok, 0])
+            np.testing.assert_allclose(e, we, rtol=5e-6)
+        dec.close()

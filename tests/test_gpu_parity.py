@@ -327,6 +327,54 @@ def test_set_mode_restarts_the_demodulator(gpu):
     bank.close()
 
 
+def _random_plan(rng, fs, n):
+    """Channels tuned on emitters of the synthetic band with randomised mode, filter, AGC and tuning details"""
+    plan = []
+    for _ in range(n):
+        e = int(rng.integers(0, 64))
+        kind = wl.emitter_kind(e)
+        off = float(rng.uniform(-40.0, 40.0))
+        p = dict(second_lo=-(wl.emitter_freq(e, fs) + off), kaiser_beta=float(rng.uniform(0.0, 8.0)),
+                 headroom=float(10 ** (-rng.uniform(6.0, 25.0) / 20)))
+        if kind == "fm":
+            w = float(rng.uniform(5000.0, 12000.0))
+            p.update(demod="fm", low=-w, high=float(rng.uniform(5000.0, 12000.0)), flat=int(rng.random() < 0.3))
+        elif kind == "am":
+            if rng.random() < 0.5:
+                p.update(demod="am", low=-float(rng.uniform(2500.0, 6000.0)), high=float(rng.uniform(2500.0, 6000.0)),
+                         hangtime=float(rng.choice([0.0, 0.02])), recovery_rate=float(rng.uniform(5.0, 60.0)))
+            else:    # an AM signal through the linear demodulator: mono, stereo I/Q or ISB
+                p.update(demod="linear", low=-float(rng.uniform(2500.0, 6000.0)), high=float(rng.uniform(2500.0, 6000.0)),
+                         hangtime=float(rng.choice([0.0, 0.02, 1.1])), recovery_rate=float(rng.uniform(3.0, 60.0)),
+                         channels=int(rng.choice([1, 2])), isb=int(rng.random() < 0.4),
+                         shift=float(rng.choice([0.0, rng.uniform(-500.0, 500.0)])))
+        else:
+            lo = float(rng.uniform(50.0, 400.0))
+            hi = float(rng.uniform(2200.0, 3500.0))
+            sgn = 1.0 if (e // 4) % 2 == 0 else -1.0
+            p.update(demod="linear", low=min(sgn * lo, sgn * hi), high=max(sgn * lo, sgn * hi),
+                     hangtime=float(rng.choice([0.0, 1.1])), recovery_rate=float(rng.uniform(3.0, 20.0)),
+                     channels=int(rng.choice([1, 2])), shift=float(rng.choice([0.0, rng.uniform(-300.0, 300.0)])))
+        plan.append(p)
+    return plan
+
+
+@pytest.mark.parametrize("seed,mode", [(1, "pruned"), (2, "full"), (3, "pruned"), (4, "full")])
+def test_random_channel_plans(gpu, seed, mode):
+    """24 channels with randomised modes, filter edges, Kaiser beta, headroom, hang / recovery, stereo / ISB, shift
+    and tuning offsets at the cfg 3 geometry, on both forward paths."""
+    g = wl.GEOMETRY["cfg3"]
+    rng = np.random.default_rng(1000 + seed)
+    plan = _random_plan(rng, g["samprate"], 24)
+    nblocks = 6
+    iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=100 + seed)
+    want = run_oracle(plan, g, iq, nblocks, compute_n0=int(mode == "full"))
+    fwd = kq.KQ_FWD_PRUNED if mode == "pruned" else kq.KQ_FWD_FULL
+    got, used = _run_bank(plan, g, iq, nblocks, fwd, compute_n0=(mode == "full"), per_call=4)
+    assert used == fwd
+    _compare(plan, got, want, check_n0=(mode == "full"))
+
+
 def test_long_run_phase_continuity(gpu):
     """2.5 million input samples (300 blocks over five process calls, more than 150 renormalisation periods of the
     reference's NCO recurrence): the closed-form oscillators of the bank must not drift away from the oracle's

@@ -116,3 +116,42 @@ def test_decimator_and_afsk_degenerate_calls(gpu):
         bank.L.kq_afsk_push(bank.h, None, 0, 1, 10, 10, 0) and None
         bank._chk(-1, "kq_afsk_push")
     bank.close()
+
+
+def test_handles_release_their_device_memory(gpu):
+    """create / use / destroy in a loop: free device memory must come back (no leak in any of the four handle types)"""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    g = wl.GEOMETRY["cfg3"]
+    plan = wl.channel_plan("cfg3", 16)
+    iq = wl.make_iq(g["samprate"], 2 * g["L"], seed=1)
+
+    def cycle():
+        for mode, n0 in ((kq.KQ_FWD_PRUNED, False), (kq.KQ_FWD_FULL, True)):
+            bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], len(plan), 2, compute_n0=n0, fwd_mode=mode)
+            bank.enable_pcm(True)
+            for p in plan:
+                bank.add_channel(bank_cfg(p))
+            bank.push_iq(iq)
+            assert bank.process() == 2
+            bank.sync()
+            bank.close()
+        dec = kq.Decimator(6, 8, 1, max_out=1024)
+        dec.process(np.zeros(1024 << 6, np.complex64))
+        dec.close()
+        af = kq.AfskBank(8)
+        af.push(np.zeros((8, 2000), np.float32))
+        af.close()
+
+    cycle()                                   # first use pays for one-off tables (twiddles, code objects)
+    before = free_bytes()
+    for _ in range(10):
+        cycle()
+    after = free_bytes()
+    assert before - after < 8 << 20, (before, after)

@@ -2,7 +2,10 @@
 // in-LDS power-of-two FFT (unnormalised, sign -1 forward / +1 backward: the convention of fftwf_plan_dft_1d that
 // filter.c:84,133 plans with).
 #pragma once
+#include <type_traits>
+
 #include "kq_device.hpp"
+#include "kq_lane.hpp"
 
 namespace kq {
 
@@ -24,25 +27,37 @@ __device__ __forceinline__ float2 phasor_turns(double turns) {
   return make_float2(c, s);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Butterfly reductions over the 64 lanes (every lane gets the result) by DPP / v_permlane exchanges (kq_lane.hpp):
+// same pairing order as the ds_bpermute versions they replace (32, 16, ..., 1), so the same rounding.
+template <class T, class Op>
+__device__ __forceinline__ T wave_reduce(T v, Op op) {
+  int const lane = threadIdx.x & 63;
+  auto x = [&](auto m) {
+    constexpr int M = decltype(m)::value;
+    if constexpr (sizeof(T) == 4 && std::is_same<T, float>::value)
+      return lane_xor<M>(v, lane);
+    else
+      return (T)lane_xor_i<M>((int)v, lane);
+  };
+  v = op(v, x(std::integral_constant<int, 32>{}));
+  v = op(v, x(std::integral_constant<int, 16>{}));
+  v = op(v, x(std::integral_constant<int, 8>{}));
+  v = op(v, x(std::integral_constant<int, 4>{}));
+  v = op(v, x(std::integral_constant<int, 2>{}));
+  v = op(v, x(std::integral_constant<int, 1>{}));
   return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  return wave_reduce(v, [](float a, float b) { return a + b; });
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return wave_reduce(v, [](int a, int b) { return a + b; });
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); });
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  return v;
+  return wave_reduce(v, [](float a, float b) { return fminf(a, b); });
 }
 
 // Block-wide sum of (float, int) pairs; red_f / red_i hold one slot per wave (<= 16 waves)

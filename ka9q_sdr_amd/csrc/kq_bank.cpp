@@ -132,6 +132,11 @@ struct kq_bank {
   hipEvent_t ev_demod_done[2] = {nullptr, nullptr};
   kq::Planes pl2[2];
   double *osc_dev2[2] = {nullptr, nullptr};
+  // generic FM path: detected samples of a call [C][B][olen] and the de-emphasis filter's history [C][Mdec-1],
+  // double buffered by call parity (read by every block-0 workgroup while the last block writes the next one)
+  float *fmout = nullptr;
+  float *fm_hist[2] = {nullptr, nullptr};
+  int fm_hist_cur = 0;
   uint64_t calls = 0;
 
   float2 *ring[2] = {nullptr, nullptr};
@@ -269,7 +274,12 @@ int upload_channel(kq_bank *b, int c, bool fresh = true) {
   HIP_TRY(hipMemsetAsync(b->chd.sq_count + c, 0, sizeof(int), b->stream));
   HIP_TRY(hipMemsetAsync(b->chd.hang + c, 0, sizeof(int), b->stream));
   HIP_TRY(hipMemsetAsync(b->chd.dc + c, 0, sizeof(float), b->stream));
-  if (g.Mdec > 1) HIP_TRY(hipMemsetAsync(b->chd.ahist + (size_t)c * (g.Mdec - 1), 0, sizeof(float) * (g.Mdec - 1), b->stream));
+  if (g.Mdec > 1) {
+    HIP_TRY(hipMemsetAsync(b->chd.ahist + (size_t)c * (g.Mdec - 1), 0, sizeof(float) * (g.Mdec - 1), b->stream));
+    for (int k = 0; k < 2; k++)
+      if (b->fm_hist[k])
+        HIP_TRY(hipMemsetAsync(b->fm_hist[k] + (size_t)c * (g.Mdec - 1), 0, sizeof(float) * (g.Mdec - 1), b->stream));
+  }
   if (fresh) {
     HIP_TRY(hipMemsetAsync(b->chd.foffset + c, 0, sizeof(float), b->stream));
     HIP_TRY(hipMemsetAsync(b->chd.pdev + c, 0, sizeof(float), b->stream));
@@ -534,10 +544,12 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
       kq::launch_demod64(b->stream2, g, chd, pl, b->list_dev[0], 0, b->list_dev[1], nam, b->list_dev[2], nlin, (int)nblocks,
                          b->cfg.compute_n0);
       kq::launch_demods(b->stream2, g, chd, pl, b->tw, b->list_dev[0], nfm, b->list_dev[1], 0, b->list_dev[2], 0, (int)nblocks,
-                        b->cfg.compute_n0);
+                        b->cfg.compute_n0, b->fmout, b->fm_hist[b->fm_hist_cur], b->fm_hist[b->fm_hist_cur ^ 1]);
+      if (nfm > 0) b->fm_hist_cur ^= 1;
     } else {
       kq::launch_demods(b->stream2, g, chd, pl, b->tw, b->list_dev[0], nfm, b->list_dev[1], nam, b->list_dev[2], nlin,
-                        (int)nblocks, b->cfg.compute_n0);
+                        (int)nblocks, b->cfg.compute_n0, b->fmout, b->fm_hist[b->fm_hist_cur], b->fm_hist[b->fm_hist_cur ^ 1]);
+      if (nfm > 0) b->fm_hist_cur ^= 1;
     }
   }
   LAUNCH_CHECK("demodulators");
@@ -729,6 +741,10 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.lastaudio, C);
   rc |= dev_alloc(&b->chd.sq_count, C);
   rc |= dev_alloc(&b->chd.ahist, C * (size_t)(g.Mdec > 1 ? g.Mdec - 1 : 1));
+  if (!kq::demod64_supported(g)) {
+    rc |= dev_alloc(&b->fmout, C * B * (size_t)g.olen);
+    for (int k = 0; k < 2; k++) rc |= dev_alloc(&b->fm_hist[k], C * (size_t)(g.Mdec > 1 ? g.Mdec - 1 : 1));
+  }
   rc |= dev_alloc(&b->chd.foffset, C);
   rc |= dev_alloc(&b->chd.pdev, C);
   rc |= dev_alloc(&b->chd.gain, C);
@@ -801,7 +817,7 @@ int kq_bank_destroy(kq_bank *b) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->stream2 && b->stream2 != b->stream) (void)hipStreamSynchronize(b->stream2);
   void *ptrs[] = {b->ring[0], b->ring[1], b->tw, b->chan_tw, b->chd.mode, b->chd.flags, b->chd.low, b->chd.high, b->chd.resp,
-                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.n0mask,
+                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.n0mask, b->fmout, b->fm_hist[0], b->fm_hist[1],
                   b->osc_dev2[0], b->osc_dev2[1], b->chd.fm_state,
                   b->chd.lastaudio, b->chd.sq_count, b->chd.ahist, b->chd.foffset, b->chd.pdev, b->chd.gain, b->chd.hang,
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
@@ -847,8 +863,8 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
     return -1;
   }
   if (cfg->demod_type == KQ_FM_DEMOD && !kq::demod64_supported(b->g) && kq::demod_fm_lds_bytes(b->g) > 160 * 1024) {
-    // the FM demodulator keeps one block of samples and the N/D-point audio master in LDS
-    set_err("FM needs N/decimate <= 4096 at this geometry (%zu bytes of LDS, the CU has 160 KiB)", kq::demod_fm_lds_bytes(b->g));
+    // the FM kernels keep one block of samples / the N/D-point audio master in LDS (N/D <= 8192)
+    set_err("FM working set of %zu bytes exceeds the 160 KiB of LDS at this geometry", kq::demod_fm_lds_bytes(b->g));
     return -1;
   }
   if (cfg->demod_type == KQ_LINEAR_DEMOD && cfg->pll) {
@@ -924,7 +940,7 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
     return -1;
   }
   if (m->demod_type == KQ_FM_DEMOD && !kq::demod64_supported(b->g) && kq::demod_fm_lds_bytes(b->g) > 160 * 1024) {
-    set_err("FM needs N/decimate <= 4096 at this geometry");
+    set_err("FM working set exceeds the LDS at this geometry");
     return -1;
   }
   if (sync_all(b)) return -1;  // pthread_join of the old demodulator thread (radio.c:335-337)

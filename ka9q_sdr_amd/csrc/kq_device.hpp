@@ -106,7 +106,7 @@ void launch_pruned_tables(hipStream_t s, const Geom &g, const ChanDev &ch, float
 size_t demod_fm_lds_bytes(const Geom &g);
 void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw,
                    const int *list_fm, int n_fm, const int *list_am, int n_am, const int *list_lin, int n_lin,
-                   int nblocks, int compute_n0);
+                   int nblocks, int compute_n0, float *fmout, const float *fm_hist_in, float *fm_hist_out);
 bool demod64_supported(const Geom &g);
 bool demod_agc_wave_supported(const Geom &g);
 void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const int *list_fm, int n_fm,

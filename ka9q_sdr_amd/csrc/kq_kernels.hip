@@ -8,6 +8,8 @@
 //   k_demod_fm/am/lin   demodulators with state carried across blocks in HBM (fm.c, am.c, linear.c)
 //
 // The pruned forward path lives in kq_pruned.hip.
+#include <algorithm>
+
 #include "kq_device.hpp"
 #include "kq_ldsfft.hpp"
 
@@ -290,42 +292,31 @@ __device__ __forceinline__ void status_common(kq_chan_status &st, const Geom &g,
   }
 }
 
-// FM: one wave per channel, blocks in sequence.  Dynamic LDS carve (floats):
-//   S float2[olen] | Y float[olen] | OUT float[olen] | LV int[olen] | PV int[olen] | AIN float[AN] | F float2[AN]
-__global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ tw,
+// FM, generic geometry, in two kernels.
+//   k_demod_fm   the part that is a chain through the blocks of a channel (fm.c:91-160): amplitude statistics,
+//                squelch, discriminator with the hold rule, frequency offset / deviation.  One wave per channel,
+//                blocks in sequence; the detected samples of every block go to `fmout`.
+//   k_fm_audio   the part that is not (fm.c:162-171, 219-234): the REAL->REAL de-emphasis overlap-save and the
+//                PL slave only need the detected samples of this block and the ones before it, so one wave per
+//                (channel, block) runs them all at once.
+// Dynamic LDS carve of k_demod_fm:  S float2[olen] | Y float[olen] | OUT float[olen] | LV int[olen] | PV int[olen]
+__global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, float *__restrict__ fmout,
                                                  const int *__restrict__ list, int nblocks, int compute_n0) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   int const c = list[blockIdx.x];
   int const lane = threadIdx.x;
-  int const olen = g.olen, AN = g.Ndec, AM = g.Mdec, AL = g.olen;
+  int const olen = g.olen;
   float2 *S = lds;
-  float2 *F = S + olen;
-  float *Y = reinterpret_cast<float *>(F + AN);
+  float *Y = reinterpret_cast<float *>(S + olen);
   float *OUT = Y + olen;
-  float *AIN = OUT + olen;
-  int *LV = reinterpret_cast<int *>(AIN + AN);
+  int *LV = reinterpret_cast<int *>(OUT + olen);
   int *PV = LV + olen;
-  float2 *PLB = reinterpret_cast<float2 *>(PV + olen);  // PL slave transform buffer, pl_n points
   // One wave walks the blocks of its channel in sequence, so every global round trip inside the loop is exposed
-  // latency: the AN-point twiddles and the de-emphasis response are staged in LDS once, and the next block's
-  // samples are fetched while the current one is processed.
-  float2 *TWL = PLB + g.pl_n;      // exp(-2 pi i k / AN), k < AN/2
-  float2 *HAL = TWL + AN / 2;      // audio response, AN/2 + 1 bins
-  bool const pl_on = g.pl_n > 0 && pl.plout != nullptr;
-  int log2pl = 0;
-  while ((1 << log2pl) < g.pl_n) log2pl++;
-
-  bool const flat = (ch.flags[c] & FLAG_FLAT) != 0;
-  float const gain = ch.fm_gain[c];
-  const float2 *HA = ch.aresp + (size_t)c * (AN / 2 + 1);
+  // latency: the next block's samples are fetched while the current one is processed.
   float2 state = ch.fm_state[c];
   float lastaudio = ch.lastaudio[c];
   int sq = ch.sq_count[c];
   float foffset = ch.foffset[c], pdev = ch.pdev[c];
-  float *hist = ch.ahist + (size_t)c * (AM - 1);
-  for (int i = lane; i < AM - 1; i += 64) AIN[i] = hist[i];
-  for (int k = lane; k < AN / 2; k += 64) TWL[k] = tw[(size_t)k << (g.tw_log2 - g.log2Ndec)];
-  for (int k = lane; k <= AN / 2; k += 64) HAL[k] = HA[k];
   constexpr int kPre = 4;  // samples per lane prefetched in registers (olen <= 256); longer blocks load in place
   bool const prefetch = olen <= 64 * kPre;
   float2 nxt[kPre];
@@ -450,67 +441,10 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
       for (int n = lane; n < olen; n += 64) OUT[n] = 0;
     }
     __syncthreads();
-    // post-detection overlap-save filter, REAL -> REAL (fm.c:162-171; filter.c:151,206-208,250)
-    for (int n = lane; n < AL; n += 64) AIN[AM - 1 + n] = OUT[n];
+    // the detected samples of this block: input of the post-detection filters (fm.c:131,141,162)
+    float *fo = fmout + ((size_t)c * g.max_blocks + b) * olen;
+    for (int n = lane; n < olen; n += 64) fo[n] = OUT[n];
     __syncthreads();
-    float *aud = pl.audio + ((size_t)c * g.max_blocks + b) * (2 * (size_t)olen);
-    if (!flat || pl_on) {  // forward transform of the audio master (fm.c:162, filter.c:151)
-      for (int i = lane; i < AN; i += 64) F[bitrev((unsigned)i, g.log2Ndec)] = make_float2(AIN[i], 0.f);
-      lds_fft<-1>(F, g.log2Ndec, TWL, g.log2Ndec);
-    }
-    if (pl_on) {
-      // PL slave: REAL -> REAL, decimate 32 (fm.c:219,234; filter.c:206-208 then c2r of pl_n points)
-      int const PN = g.pl_n;
-      for (int k = lane; k <= PN / 2; k += 64) {
-        float2 gk = cmul(ch.plresp[k], F[k]);
-        if (k == 0 || k == PN / 2) {
-          gk.y = 0.f;
-        } else {
-          PLB[bitrev((unsigned)(PN - k), log2pl)] = cconj(gk);
-        }
-        PLB[bitrev((unsigned)k, log2pl)] = gk;
-      }
-      lds_fft<+1>(PLB, log2pl, TWL, g.log2Ndec);
-      float *po = pl.plout + ((size_t)c * g.max_blocks + b) * g.pl_l;
-      for (int n = lane; n < g.pl_l; n += 64) po[n] = PLB[PN - g.pl_l + n].x;  // filter.c:140
-      __syncthreads();
-    }
-    if (!flat) {
-      // multiply DC..Nyquist (filter.c:206-208) and Hermitian-extend for the c2r transform, which
-      // ignores the imaginary parts of DC and Nyquist.  Lane k touches only F[k] and F[AN-k].
-      for (int k = lane; k <= AN / 2; k += 64) {
-        float2 const gk = cmul(HAL[k], F[k]);
-        if (k == 0 || k == AN / 2) {
-          F[k] = make_float2(gk.x, 0.f);
-        } else {
-          F[k] = gk;
-          F[AN - k] = cconj(gk);
-        }
-      }
-      __syncthreads();
-      // bit-reverse in place, then backward transform
-      for (int i = lane; i < AN; i += 64) {
-        unsigned const r = bitrev((unsigned)i, g.log2Ndec);
-        if (r > (unsigned)i) {
-          float2 const t = F[i];
-          F[i] = F[r];
-          F[r] = t;
-        }
-      }
-      lds_fft<+1>(F, g.log2Ndec, TWL, g.log2Ndec);
-      for (int n = lane; n < AL; n += 64) aud[n] = F[AN - AL + n].x * gain;  // fm.c:169-170
-    } else {
-      for (int n = lane; n < AL; n += 64) aud[n] = OUT[n];
-    }
-    __syncthreads();
-    // overlap-save history shift (filter.c:168)
-    for (int base = 0; base < AM - 1; base += 64) {
-      int const i = base + lane;
-      float const v = (i < AM - 1) ? AIN[AL + i] : 0.f;
-      __syncthreads();
-      if (i < AM - 1) AIN[i] = v;
-      __syncthreads();
-    }
     if (lane == 0) {
       kq_chan_status st;
       status_common(st, g, ch, pl, c, b, compute_n0, .01);
@@ -522,11 +456,10 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
       st.squelch_count = sq;
       st.hangcount = 0;
       st.blanked = blanked;
-      st.nout = AL;
+      st.nout = olen;
       pl.status[(size_t)c * g.max_blocks + b] = st;
     }
   }
-  for (int i = lane; i < AM - 1; i += 64) hist[i] = AIN[i];
   if (lane == 0) {
     ch.fm_state[c] = state;
     ch.lastaudio[c] = lastaudio;
@@ -534,6 +467,95 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
     ch.foffset[c] = foffset;
     ch.pdev[c] = pdev;
   }
+}
+
+
+// De-emphasis overlap-save and PL slave of one (channel, block): REAL -> REAL (fm.c:162-171, 219-234;
+// filter.c:151,206-208,250).  The filter input is the channel's stream of detected samples: `hist_in` holds the
+// AM-1 samples that precede block 0 of this call, `fmout` the blocks of the call.  The workgroup of the last block
+// writes the AM-1 samples that will precede the next call into `hist_out` (a different buffer: every block-0
+// workgroup of this launch is still reading hist_in).
+// Dynamic LDS carve:  F float2[AN] | AIN float[AN] | PLB float2[pl_n] | TWL float2[AN/2]
+__global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ tw,
+                                                 const float *__restrict__ fmout, const float *__restrict__ hist_in,
+                                                 float *__restrict__ hist_out, const int *__restrict__ list, int nblocks) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  int const c = list[blockIdx.x], b = blockIdx.y;
+  int const lane = threadIdx.x;
+  int const AN = g.Ndec, AM = g.Mdec, AL = g.olen;
+  float2 *F = lds;
+  float *AIN = reinterpret_cast<float *>(F + AN);
+  float2 *PLB = reinterpret_cast<float2 *>(AIN + AN);
+  float2 *TWL = PLB + g.pl_n;  // exp(-2 pi i k / AN), k < AN/2
+  bool const pl_on = g.pl_n > 0 && pl.plout != nullptr;
+  bool const flat = (ch.flags[c] & FLAG_FLAT) != 0;
+  const float *stream = fmout + (size_t)c * g.max_blocks * AL;  // detected samples of this call, block after block
+  const float *hin = hist_in + (size_t)c * (AM - 1);
+  // sample j of the stream, j >= -(AM-1)
+  auto sample = [&](long long j) { return j >= 0 ? stream[j] : hin[(AM - 1) + j]; };
+  if (b == nblocks - 1) {
+    float *ho = hist_out + (size_t)c * (AM - 1);
+    for (int i = lane; i < AM - 1; i += 64) ho[i] = sample((long long)nblocks * AL - (AM - 1) + i);
+  }
+  float *aud = pl.audio + ((size_t)c * g.max_blocks + b) * (2 * (size_t)AL);
+  if (flat && !pl_on) {
+    for (int n = lane; n < AL; n += 64) aud[n] = stream[(size_t)b * AL + n];
+    return;
+  }
+  for (int k = lane; k < AN / 2; k += 64) TWL[k] = tw[(size_t)k << (g.tw_log2 - g.log2Ndec)];
+  for (int i = lane; i < AN; i += 64) {
+    float const v = sample((long long)b * AL - (AM - 1) + i);
+    AIN[i] = v;
+    F[bitrev((unsigned)i, g.log2Ndec)] = make_float2(v, 0.f);
+  }
+  lds_fft<-1>(F, g.log2Ndec, TWL, g.log2Ndec);  // forward transform of the audio master (fm.c:162, filter.c:151)
+  if (pl_on) {
+    // PL slave: REAL -> REAL, decimate 32 (fm.c:219,234; filter.c:206-208 then c2r of pl_n points)
+    int const PN = g.pl_n;
+    int log2pl = 0;
+    while ((1 << log2pl) < PN) log2pl++;
+    for (int k = lane; k <= PN / 2; k += 64) {
+      float2 gk = cmul(ch.plresp[k], F[k]);
+      if (k == 0 || k == PN / 2) {
+        gk.y = 0.f;
+      } else {
+        PLB[bitrev((unsigned)(PN - k), log2pl)] = cconj(gk);
+      }
+      PLB[bitrev((unsigned)k, log2pl)] = gk;
+    }
+    lds_fft<+1>(PLB, log2pl, TWL, g.log2Ndec);
+    float *po = pl.plout + ((size_t)c * g.max_blocks + b) * g.pl_l;
+    for (int n = lane; n < g.pl_l; n += 64) po[n] = PLB[PN - g.pl_l + n].x;  // filter.c:140
+    __syncthreads();
+  }
+  if (flat) {
+    for (int n = lane; n < AL; n += 64) aud[n] = AIN[AM - 1 + n];
+    return;
+  }
+  // multiply DC..Nyquist (filter.c:206-208) and Hermitian-extend for the c2r transform, which ignores the
+  // imaginary parts of DC and Nyquist.  Lane k touches only F[k] and F[AN-k].
+  const float2 *HA = ch.aresp + (size_t)c * (AN / 2 + 1);
+  for (int k = lane; k <= AN / 2; k += 64) {
+    float2 const gk = cmul(HA[k], F[k]);
+    if (k == 0 || k == AN / 2) {
+      F[k] = make_float2(gk.x, 0.f);
+    } else {
+      F[k] = gk;
+      F[AN - k] = cconj(gk);
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < AN; i += 64) {  // bit-reverse in place, then backward transform
+    unsigned const r = bitrev((unsigned)i, g.log2Ndec);
+    if (r > (unsigned)i) {
+      float2 const t = F[i];
+      F[i] = F[r];
+      F[r] = t;
+    }
+  }
+  lds_fft<+1>(F, g.log2Ndec, TWL, g.log2Ndec);
+  float const gain = ch.fm_gain[c];
+  for (int n = lane; n < AL; n += 64) aud[n] = F[AN - AL + n].x * gain;  // fm.c:169-170
 }
 
 // AM: envelope, carrier removal, hang AGC -- a strictly sequential recurrence per channel
@@ -742,21 +764,29 @@ void launch_pl_track(hipStream_t s, const Geom &g, const ChanDev &ch, const Plan
 }
 
 // dynamic LDS of the generic FM demodulator (k_demod_fm): samples, masks, the audio master and its transform
-size_t demod_fm_lds_bytes(const Geom &g) {
-  return (size_t)g.olen * (8 + 4 + 4 + 4 + 4) + (size_t)g.Ndec * (8 + 4) + (size_t)g.pl_n * 8 + (size_t)(g.Ndec / 2) * 8 +
-         (size_t)(g.Ndec / 2 + 1) * 8;
+static size_t fm_disc_lds_bytes(const Geom &g) { return (size_t)g.olen * (8 + 4 + 4 + 4 + 4); }
+static size_t fm_audio_lds_bytes(const Geom &g) {
+  return (size_t)g.Ndec * (8 + 4) + (size_t)g.pl_n * 8 + (size_t)(g.Ndec / 2) * 8;
 }
+size_t demod_fm_lds_bytes(const Geom &g) { return std::max(fm_disc_lds_bytes(g), fm_audio_lds_bytes(g)); }
 
 void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_fm,
-                   int n_fm, const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0) {
+                   int n_fm, const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0,
+                   float *fmout, const float *fm_hist_in, float *fm_hist_out) {
   if (n_fm > 0) {
-    size_t const lds_bytes = demod_fm_lds_bytes(g);
-    static size_t configured = 0;
-    if (lds_bytes > configured) {
-      (void)hipFuncSetAttribute((const void *)k_demod_fm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      configured = lds_bytes;
+    size_t const lds_a = fm_disc_lds_bytes(g), lds_b = fm_audio_lds_bytes(g);
+    static size_t conf_a = 0, conf_b = 0;
+    if (lds_a > conf_a) {
+      (void)hipFuncSetAttribute((const void *)k_demod_fm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
+      conf_a = lds_a;
     }
-    hipLaunchKernelGGL(k_demod_fm, dim3(n_fm), dim3(64), lds_bytes, s, g, ch, pl, tw, list_fm, nblocks, compute_n0);
+    if (lds_b > conf_b) {
+      (void)hipFuncSetAttribute((const void *)k_fm_audio, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+      conf_b = lds_b;
+    }
+    hipLaunchKernelGGL(k_demod_fm, dim3(n_fm), dim3(64), lds_a, s, g, ch, pl, fmout, list_fm, nblocks, compute_n0);
+    hipLaunchKernelGGL(k_fm_audio, dim3(n_fm, nblocks), dim3(64), lds_b, s, g, ch, pl, tw, fmout, fm_hist_in, fm_hist_out,
+                       list_fm, nblocks);
   }
   if (n_am > 0)
     hipLaunchKernelGGL(k_demod_am, dim3((n_am + 63) / 64), dim3(64), 0, s, g, ch, pl, list_am, n_am, nblocks, compute_n0);

@@ -180,7 +180,7 @@ GEOMETRIES = [
     (8192,  4096,  4097,  64,  2000000, "auto", False),      # N/D = 128 below 65536: full path
     (16384, 12288, 4097,  64,  2000000, "full", True),       # full-spectrum kernel, L != M - 1, N/D = 256
     (16384, 8192,  8193,  32,  1000000, "full", True),       # N/D = 512
-    (16384, 8192,  8193,  2,   192000, "full", False),       # N/D = 8192: beyond the register kernel's epilogue, LDS kernel
+    (16384, 8192,  8193,  2,   192000, "full", False),       # N/D = 8192: LDS filter kernel, largest FM working set
     (32768, 16384, 16385, 128, 4000000, "full", False),      # beyond one LDS block: split kernel, N/D = 256
     (65536, 49152, 16385, 32,  8000000, "full", False),      # split kernel at its limits: N = 65536, N/D = 2048, L != M - 1
     (65536, 32768, 32769, 512, 20000000, "auto", False),     # cfg 5 geometry with FM / AM on it too
@@ -217,13 +217,6 @@ def test_geometry_sweep(gpu, N, L, M, D, fs, mode, n0):
     assert L + M - 1 == N
     g = dict(samprate=fs, L=L, M=M, D=D)
     plan, iq, nblocks = _sweep_case(N, L, M, D, fs)
-    if N // D > 4096:
-        # the FM demodulator's working set (one block + the N/D-point audio master) must fit the CU's LDS
-        bank = kq.Bank(fs, L, M, D, 1, 1)
-        with pytest.raises(kq.KqError, match="FM needs N/decimate"):
-            bank.add_channel(bank_cfg(plan[0]))
-        bank.close()
-        plan = plan[1:]
     want = run_oracle(plan, g, iq, nblocks, compute_n0=int(n0))
     fwd = {"full": kq.KQ_FWD_FULL, "pruned": kq.KQ_FWD_PRUNED, "auto": kq.KQ_FWD_AUTO}[mode]
     got, used = _run_bank(plan, g, iq, nblocks, fwd, compute_n0=n0, per_call=3)

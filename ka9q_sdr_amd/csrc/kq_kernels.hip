@@ -327,7 +327,15 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
   }
   __syncthreads();
 
+  float const noise_gain = ch.noise_gain[c];
+  float n0 = ch.n0[c];
+  float ifp_v = 0.f, n0raw_v = 0.f;
   for (int b = 0; b < nblocks; b++) {
+    if ((b & 63) == 0) {
+      int const bb2 = b + lane;
+      ifp_v = bb2 < nblocks ? pl.if_power[bb2] : 0.f;
+      n0raw_v = (compute_n0 && bb2 < nblocks) ? pl.n0raw[(size_t)c * g.max_blocks + bb2] : 0.f;
+    }
     const float2 *in = pl.filt + ((size_t)c * g.max_blocks + b) * olen;
     float2 cur[kPre];
     if (prefetch) {
@@ -445,9 +453,20 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
     float *fo = fmout + ((size_t)c * g.max_blocks + b) * olen;
     for (int n = lane; n < olen; n += 64) fo[n] = OUT[n];
     __syncthreads();
+    // status record: its per-block inputs come out of registers (lane i holds block b0 + i) -- a global load here
+    // would stall this in-order wave for a memory round trip on every block
+    float const ifp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ifp_v), b & 63));
+    float const fresh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n0raw_v), b & 63));
+    if (compute_n0) n0 = isnan(n0) ? fresh : (float)((double)n0 + .01 * (double)(fresh - n0));  // fm.c:79-82
     if (lane == 0) {
       kq_chan_status st;
-      status_common(st, g, ch, pl, c, b, compute_n0, .01);
+      st.if_power = ifp;
+      st.noise_gain = noise_gain;
+      st.plfreq = NAN;
+      st.cphase = 0;
+      st.pll_lock = 0;
+      st.lock_count = 0;
+      st.n0 = compute_n0 ? n0 : NAN;
       st.bb_power = bb;
       st.snr = snr;
       st.foffset = foffset;
@@ -461,6 +480,7 @@ __global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, 
     }
   }
   if (lane == 0) {
+    ch.n0[c] = n0;
     ch.fm_state[c] = state;
     ch.lastaudio[c] = lastaudio;
     ch.sq_count[c] = sq;

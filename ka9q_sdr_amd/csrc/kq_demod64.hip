@@ -340,6 +340,7 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
     if (!LINEAR) {
       // carrier tracking (am.c:62), serial; lane i keeps the value after sample i
       float dc_mine = dc;
+#pragma unroll 32
       for (int i = 0; i < nsamp; i++) {
         float const e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, env), i));
         dc += 0.0001f * (e - dc);
@@ -351,6 +352,7 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
     float g_mine = gain;
     float gain_end[2] = {gain, gain};
     int hang_end[2] = {hang, hang};
+#pragma unroll 32
     for (int i = 0; i < nsamp; i++) {
       float const lv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, level), i));
       float const iv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), i));

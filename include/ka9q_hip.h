@@ -124,6 +124,15 @@ int kq_bank_destroy(kq_bank *bank);                               /* filter.c:25
  *     am.c:21-41, linear.c:29-81): creates the slave, designs its response, arms the demodulator.
  *     Returns the channel index (>= 0) or -1. --- */
 int kq_bank_add_channel(kq_bank *bank, const kq_channel_config *cfg);
+/* The demodulator thread's epilogue once demod->terminate is set and it has been joined (fm.c:177-182, am.c:80,
+ * linear.c:319: delete_filter_output on its slaves).  The other channels keep their numbers; the slot is a hole that
+ * the next kq_bank_add_channel reuses (lowest hole first, with prologue state), and holes at the end are dropped.
+ * The pre-detection filter launch still spans holes, so a bank with many long-lived ones is better rebuilt.
+ * Every per-channel call on a removed channel fails with -1. */
+int kq_bank_remove_channel(kq_bank *bank, int ch);
+/* 1 when `ch` names a live channel, 0 for a hole or an index out of range */
+int kq_bank_channel_active(const kq_bank *bank, int ch);
+/* One past the highest live channel number (holes included) */
 unsigned kq_bank_num_channels(const kq_bank *bank);
 /* set_mode (radio.c:322-374) on a running channel: the demodulator is torn down and started afresh with the mode's
  * demod_type, flat, isb, channels, pll, square, recovery_rate, hangtime, low / high (swapped when low > high),

@@ -110,6 +110,8 @@ def load_library():
     L.kq_bank_destroy.argtypes = [C.c_void_p]
     L.kq_bank_add_channel.argtypes = [C.c_void_p, C.POINTER(ChannelConfig)]
     L.kq_bank_set_mode.argtypes = [C.c_void_p, C.c_int, C.POINTER(ChannelConfig)]
+    L.kq_bank_remove_channel.argtypes = [C.c_void_p, C.c_int]
+    L.kq_bank_channel_active.argtypes = [C.c_void_p, C.c_int]
     L.kq_bank_num_channels.argtypes = [C.c_void_p]
     L.kq_bank_num_channels.restype = C.c_uint
     L.kq_bank_set_second_lo.argtypes = [C.c_void_p, C.c_int, C.c_double]
@@ -206,6 +208,13 @@ class Bank:
 
     def add_channel(self, cfg):
         return self._chk(self.lib.kq_bank_add_channel(self.h, C.byref(cfg)), "kq_bank_add_channel")
+
+    def remove_channel(self, ch):
+        """fm.c:177-182 / am.c:80 / linear.c:319: end channel `ch`; its number is reused by a later add_channel"""
+        self._chk(self.lib.kq_bank_remove_channel(self.h, ch), "kq_bank_remove_channel")
+
+    def channel_active(self, ch):
+        return bool(self.lib.kq_bank_channel_active(self.h, ch))
 
     def set_mode(self, ch, cfg):
         """radio.c:322-374: restart channel `ch`'s demodulator with the mode described by `cfg`"""

@@ -104,6 +104,7 @@ struct HostChan {
   // the next block were mixed with these (radio.c:132-139)
   Osc lo2_old, dop_old;
   bool retuned = false;
+  bool active = true;  // false: a hole left by kq_bank_remove_channel, reused by the next kq_bank_add_channel
   kq_out_rtp_state out_rtp{};  // demod->output.rtp + output.silent (audio.c:32-132)
   int out_type;
   std::vector<kq::cfloat> resp, aresp;
@@ -431,6 +432,7 @@ int upload_lists(kq_bank *b) {
   for (int k = 0; k < 3; k++) b->list_host[k].clear();
   b->list_pll_host.clear();
   for (size_t c = 0; c < b->chans.size(); c++) {
+    if (!b->chans[c].active) continue;
     int const m = b->chans[c].cfg.demod_type;
     if (m == KQ_LINEAR_DEMOD && b->chans[c].cfg.pll)
       b->list_pll_host.push_back((int)c);  // slot = position in this list = order of creation
@@ -451,7 +453,9 @@ int upload_lists(kq_bank *b) {
 int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigned char *update_host) {
   kq::Geom const &g = b->g;
   int const C = (int)b->chans.size();
-  if (C == 0) {
+  bool any = false;
+  for (HostChan const &h : b->chans) any = any || h.active;
+  if (!any) {
     set_err("no channels in bank");
     return -1;
   }
@@ -459,6 +463,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   bool swept = false;
   if (b->fwd_mode == KQ_FWD_PRUNED)
     for (HostChan const &h : b->chans) {
+      if (!h.active) continue;
       double const r = h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0);
       if (r == 0) continue;
       swept = true;
@@ -575,7 +580,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   return (int)nblocks;
 }
 
-bool valid_ch(const kq_bank *b, int ch) { return b && ch >= 0 && (size_t)ch < b->chans.size(); }
+bool valid_ch(const kq_bank *b, int ch) { return b && ch >= 0 && (size_t)ch < b->chans.size() && b->chans[ch].active; }
 
 }  // namespace
 
@@ -845,12 +850,79 @@ int kq_bank_destroy(kq_bank *b) {
   return 0;
 }
 
+namespace {
+bool is_pll(const kq_channel_config &c) { return c.demod_type == KQ_LINEAR_DEMOD && c.pll; }
+
+// PLL channels own the slot equal to their rank among the PLL channels (upload_lists): when a channel enters or
+// leaves that set the carried state of the channels behind it moves by one slot
+int move_pll_slot(kq_bank *b, int from, int to) {
+  HIP_TRY(hipMemcpy(b->pll_state + to, b->pll_state + from, sizeof(kq::PllState), hipMemcpyDeviceToDevice));
+  HIP_TRY(hipMemcpy(b->pll_rings + (size_t)to * 65536, b->pll_rings + (size_t)from * 65536, sizeof(float2) * 65536,
+                    hipMemcpyDeviceToDevice));
+  return 0;
+}
+
+// slot channel `ch` has or would have among the PLL channels, and how many others there are
+void pll_rank(const kq_bank *b, int ch, int &rank, int &npll) {
+  rank = npll = 0;
+  for (int c = 0; c < (int)b->chans.size(); c++)
+    if (c != ch && b->chans[c].active && is_pll(b->chans[c].cfg)) {
+      npll++;
+      if (c < ch) rank++;
+    }
+}
+
+// checks and lazy allocations before a channel becomes a PLL channel (linear.c:51-56: the carrier search window is
+// +-300 Hz, x2 when squaring, in bins of the 65536-point transform)
+int pll_admit(kq_bank *b, const kq_channel_config &m, int npll) {
+  if (npll >= kq_bank::kMaxPll) {
+    set_err("at most %d carrier-tracking (pll) channels per bank", kq_bank::kMaxPll);
+    return -1;
+  }
+  float const samptime = (float)b->g.D / (float)b->g.samprate;
+  float const binsize = (float)(1. / (65536 * samptime));
+  int const nbins = 2 * (int)round((m.square ? 2 : 1) * 300.f / binsize) + 1;
+  if (nbins > 4096) {
+    set_err("output rate too low for the PLL search window (%d bins > 4096)", nbins);
+    return -1;
+  }
+  if (!b->pll_state) {
+    if (sync_all(b)) return -1;
+    if (dev_alloc(&b->pll_state, kq_bank::kMaxPll) || dev_alloc(&b->pll_rings, (size_t)kq_bank::kMaxPll * 65536) ||
+        dev_alloc(&b->pll_side, (size_t)kq_bank::kMaxPll * 4096) || dev_alloc(&b->list_pll_dev, kq_bank::kMaxPll))
+      return -1;
+  }
+  return 0;
+}
+
+// open slot `rank` for a fresh loop (linear.c:97-112) / close it; both streams are idle
+int pll_enter(kq_bank *b, int rank, int npll) {
+  for (int s = npll; s > rank; s--)
+    if (move_pll_slot(b, s - 1, s)) return -1;
+  HIP_TRY(hipMemset(b->pll_state + rank, 0, sizeof(kq::PllState)));
+  HIP_TRY(hipMemset(b->pll_rings + (size_t)rank * 65536, 0, sizeof(float2) * 65536));
+  return 0;
+}
+int pll_leave(kq_bank *b, int rank, int npll) {
+  for (int s = rank; s < npll; s++)
+    if (move_pll_slot(b, s + 1, s)) return -1;
+  return 0;
+}
+}  // namespace
+
 int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
   if (!b || !cfg) {
     set_err("NULL argument");
     return -1;
   }
-  if (b->chans.size() >= b->cfg.max_channels) {
+  // the lowest hole a removed channel left, else a new slot at the end
+  int c = (int)b->chans.size();
+  for (int k = 0; k < (int)b->chans.size(); k++)
+    if (!b->chans[k].active) {
+      c = k;
+      break;
+    }
+  if ((size_t)c >= b->cfg.max_channels) {
     set_err("bank is full (%u channels)", b->cfg.max_channels);
     return -1;
   }
@@ -867,29 +939,11 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
     set_err("FM working set of %zu bytes exceeds the 160 KiB of LDS at this geometry", kq::demod_fm_lds_bytes(b->g));
     return -1;
   }
-  if (cfg->demod_type == KQ_LINEAR_DEMOD && cfg->pll) {
-    size_t npll = 0;
-    for (HostChan const &o : b->chans) npll += (o.cfg.demod_type == KQ_LINEAR_DEMOD && o.cfg.pll) ? 1 : 0;
-    if (npll >= (size_t)kq_bank::kMaxPll) {
-      set_err("at most %d carrier-tracking (pll) channels per bank", kq_bank::kMaxPll);
-      return -1;
-    }
-    {
-      // carrier search window (linear.c:51-56): +-300 Hz (x2 when squaring) in bins of the 65536-point transform
-      float const samptime = (float)b->g.D / (float)b->g.samprate;
-      float const binsize = (float)(1. / (65536 * samptime));
-      int const nbins = 2 * (int)round((cfg->square ? 2 : 1) * 300.f / binsize) + 1;
-      if (nbins > 4096) {
-        set_err("output rate too low for the PLL search window (%d bins > 4096)", nbins);
-        return -1;
-      }
-    }
-    if (!b->pll_state) {
-      if (sync_all(b)) return -1;
-      if (dev_alloc(&b->pll_state, kq_bank::kMaxPll) || dev_alloc(&b->pll_rings, (size_t)kq_bank::kMaxPll * 65536) ||
-          dev_alloc(&b->pll_side, (size_t)kq_bank::kMaxPll * 4096) || dev_alloc(&b->list_pll_dev, kq_bank::kMaxPll))
-        return -1;
-    }
+  if (is_pll(*cfg)) {
+    int rank, npll;
+    pll_rank(b, c, rank, npll);
+    if (pll_admit(b, *cfg, npll)) return -1;
+    if (sync_all(b) || pll_enter(b, rank, npll)) return -1;
   }
   HostChan h;
   h.cfg = *cfg;
@@ -900,10 +954,21 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
   h.dop.set(-cfg->doppler / fs, -cfg->doppler_rate / (fs * fs), b->n_abs);
   h.shift.set(cfg->shift == 0 ? 0.0 : cfg->shift * b->g.D / fs, 0.0, b->out_abs);
   design_channel(b, h);
-  b->chans.push_back(h);
-  int const c = (int)b->chans.size() - 1;
+  bool const appended = c == (int)b->chans.size();
+  if (appended)
+    b->chans.push_back(h);
+  else
+    b->chans[c] = h;
   if (upload_channel(b, c) || upload_response(b, c)) {
-    b->chans.pop_back();
+    if (is_pll(*cfg)) {  // give the slot back
+      int rank, npll;
+      pll_rank(b, c, rank, npll);
+      (void)pll_leave(b, rank, npll);
+    }
+    if (appended)
+      b->chans.pop_back();
+    else
+      b->chans[c].active = false;
     return -1;
   }
   b->lists_dirty = true;
@@ -911,20 +976,32 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
   return c;
 }
 
-unsigned kq_bank_num_channels(const kq_bank *b) { return b ? (unsigned)b->chans.size() : 0; }
-
-namespace {
-bool is_pll(const kq_channel_config &c) { return c.demod_type == KQ_LINEAR_DEMOD && c.pll; }
-
-// PLL channels own the slot equal to their rank among the PLL channels (upload_lists): when a channel enters or
-// leaves that set the carried state of the channels behind it moves by one slot
-int move_pll_slot(kq_bank *b, int from, int to) {
-  HIP_TRY(hipMemcpy(b->pll_state + to, b->pll_state + from, sizeof(kq::PllState), hipMemcpyDeviceToDevice));
-  HIP_TRY(hipMemcpy(b->pll_rings + (size_t)to * 65536, b->pll_rings + (size_t)from * 65536, sizeof(float2) * 65536,
-                    hipMemcpyDeviceToDevice));
+// close_chan equivalent: the demodulator thread is joined and its struct demod freed (radio.c:335-337 does the join
+// for a mode change).  Channel numbers of the others do not change; the slot is a hole until an add reuses it.
+int kq_bank_remove_channel(kq_bank *b, int ch) {
+  if (!valid_ch(b, ch)) {
+    set_err("bad channel");
+    return -1;
+  }
+  if (sync_all(b)) return -1;
+  HostChan &h = b->chans[ch];
+  if (is_pll(h.cfg)) {
+    int rank, npll;
+    pll_rank(b, ch, rank, npll);
+    if (pll_leave(b, rank, npll)) return -1;
+  }
+  h.active = false;
+  h.retuned = false;
+  h.lo2 = h.dop = h.shift = h.lo2_old = h.dop_old = Osc{};
+  h.out_rtp = kq_out_rtp_state{};
+  while (!b->chans.empty() && !b->chans.back().active) b->chans.pop_back();  // holes at the end just go
+  b->lists_dirty = true;
   return 0;
 }
-}  // namespace
+
+int kq_bank_channel_active(const kq_bank *b, int ch) { return valid_ch(b, ch) ? 1 : 0; }
+
+unsigned kq_bank_num_channels(const kq_bank *b) { return b ? (unsigned)b->chans.size() : 0; }
 
 int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
   if (!valid_ch(b, ch) || !m) {
@@ -946,41 +1023,11 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
   if (sync_all(b)) return -1;  // pthread_join of the old demodulator thread (radio.c:335-337)
   HostChan &h = b->chans[ch];
   bool const was = is_pll(h.cfg), now = is_pll(*m);
-  int rank = 0, npll = 0;
-  for (int c = 0; c < (int)b->chans.size(); c++) {
-    if (c != ch && is_pll(b->chans[c].cfg)) {
-      npll++;
-      if (c < ch) rank++;
-    }
-  }
-  if (now) {
-    if (npll >= kq_bank::kMaxPll) {
-      set_err("at most %d carrier-tracking (pll) channels per bank", kq_bank::kMaxPll);
-      return -1;
-    }
-    float const samptime = (float)b->g.D / (float)b->g.samprate;
-    float const binsize = (float)(1. / (65536 * samptime));
-    if (2 * (int)round((m->square ? 2 : 1) * 300.f / binsize) + 1 > 4096) {
-      set_err("output rate too low for the PLL search window");
-      return -1;
-    }
-    if (!b->pll_state) {
-      if (dev_alloc(&b->pll_state, kq_bank::kMaxPll) || dev_alloc(&b->pll_rings, (size_t)kq_bank::kMaxPll * 65536) ||
-          dev_alloc(&b->pll_side, (size_t)kq_bank::kMaxPll * 4096) || dev_alloc(&b->list_pll_dev, kq_bank::kMaxPll))
-        return -1;
-    }
-  }
-  if (was && !now) {
-    for (int s = rank; s < npll; s++)
-      if (move_pll_slot(b, s + 1, s)) return -1;
-  } else if (!was && now) {
-    for (int s = npll; s > rank; s--)
-      if (move_pll_slot(b, s - 1, s)) return -1;
-  }
-  if (now) {  // a fresh loop (linear.c:97-112)
-    HIP_TRY(hipMemset(b->pll_state + rank, 0, sizeof(kq::PllState)));
-    HIP_TRY(hipMemset(b->pll_rings + (size_t)rank * 65536, 0, sizeof(float2) * 65536));
-  }
+  int rank, npll;
+  pll_rank(b, ch, rank, npll);
+  if (now && pll_admit(b, *m, npll)) return -1;
+  if (was && pll_leave(b, rank, npll)) return -1;  // a fresh loop either way (linear.c:97-112)
+  if (now && pll_enter(b, rank, npll)) return -1;
   // the mode table entry (radio.c:341-363); the input oscillators are not touched
   h.cfg.demod_type = m->demod_type;
   h.cfg.low = m->low > m->high ? m->high : m->low;  // radio.c:343-349
@@ -1337,7 +1384,7 @@ int kq_bank_set_output_ssrc(kq_bank *b, int ch, uint32_t ssrc) {
 }
 
 int kq_bank_output_rtp_state(const kq_bank *b, int ch, kq_out_rtp_state *out) {
-  if (!b || !out || ch < 0 || (size_t)ch >= b->chans.size()) return -1;
+  if (!out || !valid_ch(b, ch)) return -1;
   *out = b->chans[ch].out_rtp;
   return 0;
 }

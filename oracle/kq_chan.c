@@ -675,6 +675,24 @@ static inline int ingest_sample(kqo_chan *c, float complex samp){
   return 0;
 }
 
+/* Not a reference function.  The reference runs one demodulator per master, created together (main.c:232); the GPU
+ * bank shares one master among channels that come and go.  A channel that joins a running master sees the master's
+ * M-1 history samples in its first block: this loads them (`iq`: M-1 raw samples, oldest first) as if this
+ * channel's oscillators had been running before its creation and reach their initial phase at its first sample. */
+void kqo_chan_prime_history(kqo_chan *c, const float *iq){
+  int const h = (int)c->master->impulse_length - 1;
+  for(int i = 0; i < h; i++){
+    double const n = (double)(i - h);
+    float complex samp = (iq[2 * i] + iq[2 * i + 1] * _Complex_I) * c->cfg.gain_factor;
+    kqo_osc const *o = &c->second_lo;
+    samp *= o->freq == 0 ? o->phasor : o->phasor * cexp(2 * M_PI * _Complex_I * (o->freq * n + o->rate * (0.5 * n * (n - 1.0))));
+    o = &c->doppler;
+    if(o->freq != 0)
+      samp *= o->phasor * cexp(2 * M_PI * _Complex_I * (o->freq * n + o->rate * (0.5 * n * (n - 1.0))));
+    c->master->inbuf_c[i] = samp;
+  }
+}
+
 int kqo_chan_block(kqo_chan *c, const float *iq, float *audio, kqo_status *st, float *filt, float *spectrum){
   unsigned const L = c->master->ilen;
   int done = 0;

@@ -176,6 +176,8 @@ int kqo_chan_push_raw(kqo_chan *c, const void *iq, int count, int fmt, float *au
  * blocks completed meanwhile are demodulated; audio must hold ceil(count/L)+1 blocks.
  * Returns number of blocks completed. */
 int kqo_chan_zero_fill(kqo_chan *c, int count, float *audio, kqo_status *st);
+/* test helper for channels that join a running master (see kq_chan.c); iq: M-1 raw samples */
+void kqo_chan_prime_history(kqo_chan *c, const float *iq);
 unsigned kqo_chan_olen(const kqo_chan *c);
 float kqo_chan_noise_gain(const kqo_chan *c);
 const float complex *kqo_chan_response(const kqo_chan *c, unsigned *n);

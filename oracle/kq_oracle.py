@@ -89,6 +89,8 @@ def lib():
     L.kqo_chan_block.argtypes = [C.c_void_p, fp, fp, C.POINTER(Status), fp, fp]
     L.kqo_chan_block_i16.argtypes = [C.c_void_p, C.POINTER(C.c_int16), fp, C.POINTER(Status)]
     L.kqo_chan_block_i8.argtypes = [C.c_void_p, C.POINTER(C.c_int8), fp, C.POINTER(Status)]
+    L.kqo_chan_prime_history.argtypes = [C.c_void_p, fp]
+    L.kqo_chan_prime_history.restype = None
     L.kqo_chan_zero_fill.argtypes = [C.c_void_p, C.c_int, fp, C.POINTER(Status)]
     L.kqo_chan_zero_fill.restype = C.c_int
     L.kqo_chan_olen.argtypes = [C.c_void_p]
@@ -247,6 +249,12 @@ class Channel:
         buf = bytes(raw)
         done = self.L.kqo_chan_push_raw(self.h, buf, count, fmt, _fp(audio), sts)
         return [(audio[b * 2 * self.olen: b * 2 * self.olen + sts[b].nout].copy(), sts[b].as_dict()) for b in range(done)]
+
+    def prime_history(self, iq):
+        """the master's M-1 history samples for a channel created while the master runs (complex64, oldest first)"""
+        iq = np.ascontiguousarray(iq, np.complex64)
+        assert len(iq) == self.cfg.M - 1
+        self.L.kqo_chan_prime_history(self.h, _fp(iq.view(np.float32)))
 
     def zero_fill(self, count):
         nb = count // self.cfg.L + 2

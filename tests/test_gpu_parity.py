@@ -320,6 +320,74 @@ def test_set_mode_restarts_the_demodulator(gpu):
     bank.close()
 
 
+def test_channels_come_and_go(gpu):
+    """kq_bank_remove_channel / kq_bank_add_channel on a running bank.  The others keep their numbers and their
+    carried state -- including a carrier loop whose slot moves when a PLL channel ahead of it leaves or arrives; a new
+    channel takes the lowest hole and starts from its prologue state on the master's live history."""
+    g = wl.GEOMETRY["cfg1"]
+    fs, L, M = g["samprate"], g["L"], g["M"]
+    nb, per = 28, 4
+    t = np.arange(nb * L) / fs
+    rng = np.random.default_rng(67)
+    sig = 0.1 * (1 + 0.5 * np.cos(2 * np.pi * 1000.0 * t)) * np.exp(2j * np.pi * (20000.0 + 23.0) * t)        # AM / CAM
+    sig += 0.1 * (1 + 0.4 * np.cos(2 * np.pi * 600.0 * t)) * np.exp(2j * np.pi * (-30000.0 - 11.0) * t)       # AM / CAM
+    sig += 0.2 * np.exp(1j * (2 * np.pi * 50000.0 * t + 3.0 * np.sin(2 * np.pi * 700.0 * t)))                  # FM
+    iq = (sig + 2e-3 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    fm = dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-50000.0)
+    am = dict(demod="am", low=-5000.0, high=5000.0, recovery_rate=50.0, second_lo=-20000.0)
+    usb = dict(demod="linear", low=100.0, high=3000.0, hangtime=1.1, recovery_rate=6.0, shift=120.0, second_lo=-50000.0)
+    cam_a = dict(demod="linear", low=-5000.0, high=5000.0, recovery_rate=50.0, pll=1, second_lo=-20000.0)
+    cam_b = dict(cam_a, second_lo=30000.0)
+    bank = kq.Bank(fs, L, M, g["D"], 6, per, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL)
+    live = {}                                               # channel number -> [plan, oracle, blocks since start]
+
+    def add(p, first, expect):
+        c = bank.add_channel(bank_cfg(p))
+        assert c == expect
+        o = ko.Channel(oracle_cfg(p, fs, L, M, g["D"], compute_n0=1))
+        if first:
+            o.prime_history(iq[first * L - (M - 1):first * L])
+        live[c] = [p, o, 0]
+
+    def remove(c):
+        bank.remove_channel(c)
+        live.pop(c)[1].close()
+        assert not bank.channel_active(c)
+
+    for k, p in enumerate([fm, cam_a, usb, cam_b, dict(fm, flat=1)]):
+        add(p, 0, k)
+    events = {
+        8: lambda: (remove(1), remove(4)),                   # a PLL channel ahead of cam_b leaves; the last slot goes
+        12: lambda: (add(am, 12, 1), add(cam_a, 12, 4)),     # hole first, then the end (a carrier loop behind cam_b)
+        20: lambda: (remove(1), add(cam_a, 20, 1), remove(0)),   # a carrier loop arrives ahead of both others
+        24: lambda: add(dict(fm, second_lo=-50010.0), 24, 0),
+    }
+    for first in range(0, nb, per):
+        if first in events:
+            events[first]()
+            if first == 8:
+                assert bank.num_channels == 4
+                with pytest.raises(kq.KqError):
+                    bank.set_shift(1, 100.0)
+                with pytest.raises(kq.KqError):
+                    bank.remove_channel(1)
+        bank.push_iq(iq[first * L:(first + per) * L])
+        assert bank.process() == per
+        for b in range(per):
+            for c, (p, o, since) in sorted(live.items()):
+                wa, ws, _, _ = o.block(iq[(first + b) * L:(first + b + 1) * L])
+                ga, gs = bank.audio(c, b), bank.status(c, b)
+                assert gs["nout"] == ws["nout"], (first + b, c)
+                assert (gs["squelch_count"], gs["hangcount"], gs["pll_lock"], gs["lock_count"]) == \
+                       (ws["squelch_count"], ws["hangcount"], ws["pll_lock"], ws["lock_count"]), (first + b, c)
+                np.testing.assert_allclose(gs["n0"], ws["n0"], rtol=2e-4)
+                tol = 2e-5 if p.get("pll") else AUDIO_TOL
+                if not (p["demod"] == "linear" and since == 0) and not (p.get("pll") and since < 6):
+                    assert rel_rms(ga, wa) < tol, (first + b, c, p["demod"], rel_rms(ga, wa))
+                live[c][2] += 1
+    bank.close()
+
+
 def _random_plan(rng, fs, n):
     """Channels tuned on emitters of the synthetic band with randomised mode, filter, AGC and tuning details"""
     plan = []

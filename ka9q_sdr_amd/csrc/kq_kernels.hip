@@ -293,202 +293,271 @@ __device__ __forceinline__ void status_common(kq_chan_status &st, const Geom &g,
 }
 
 // FM, generic geometry, in two kernels.
-//   k_demod_fm   the part that is a chain through the blocks of a channel (fm.c:91-160): amplitude statistics,
-//                squelch, discriminator with the hold rule, frequency offset / deviation.  One wave per channel,
-//                blocks in sequence; the detected samples of every block go to `fmout`.
-//   k_fm_audio   the part that is not (fm.c:162-171, 219-234): the REAL->REAL de-emphasis overlap-save and the
-//                PL slave only need the detected samples of this block and the ones before it, so one wave per
-//                (channel, block) runs them all at once.
-// Dynamic LDS carve of k_demod_fm:  S float2[olen] | Y float[olen] | OUT float[olen] | LV int[olen] | PV int[olen]
-__global__ void __launch_bounds__(64) k_demod_fm(Geom g, ChanDev ch, Planes pl, float *__restrict__ fmout,
-                                                 const int *__restrict__ list, int nblocks, int compute_n0) {
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  int const c = list[blockIdx.x];
-  int const lane = threadIdx.x;
-  int const olen = g.olen;
-  float2 *S = lds;
-  float *Y = reinterpret_cast<float *>(S + olen);
-  float *OUT = Y + olen;
-  int *LV = reinterpret_cast<int *>(OUT + olen);
-  int *PV = LV + olen;
-  // One wave walks the blocks of its channel in sequence, so every global round trip inside the loop is exposed
-  // latency: the next block's samples are fetched while the current one is processed.
-  float2 state = ch.fm_state[c];
-  float lastaudio = ch.lastaudio[c];
-  int sq = ch.sq_count[c];
-  float foffset = ch.foffset[c], pdev = ch.pdev[c];
-  constexpr int kPre = 4;  // samples per lane prefetched in registers (olen <= 256); longer blocks load in place
-  bool const prefetch = olen <= 64 * kPre;
-  float2 nxt[kPre];
-  if (prefetch && nblocks > 0) {
-    const float2 *in0 = pl.filt + (size_t)c * g.max_blocks * olen;
-#pragma unroll
-    for (int j = 0; j < kPre; j++) nxt[j] = (lane + 64 * j < olen) ? in0[lane + 64 * j] : make_float2(0.f, 0.f);
-  }
-  __syncthreads();
+//   k_demod_fm   amplitude statistics, squelch, discriminator with the hold rule, frequency offset / deviation
+//                (fm.c:91-160); the detected samples of every block go to `fmout`.
+//   k_fm_audio   the REAL->REAL de-emphasis overlap-save and the PL slave (fm.c:162-171, 219-234), one wave per
+//                (channel, block).
+// k_demod_fm.  fm.c walks the blocks of a channel in sequence, but what one block hands to the next is small: the
+// squelch counter, the last strong sample (conjugated) and the last good audio value, and the offset / deviation
+// readings that are only refreshed while the squelch is fully open.  So a workgroup takes one channel and 64 blocks
+// at a time in four phases, with W waves sharing the blocks in the two heavy ones:
+//   A  (per block)   amplitude statistics -> bb, snr, threshold; the last two strong samples of the block
+//   B  (wave 0)      lanes = blocks: squelch counters from the snr flags; for every block the state and audio value it
+//                    starts from, found at the nearest earlier block that defines them (squelched: zeros; open with a
+//                    strong sample: that sample and its discriminator output)
+//   C  (per block)   discriminator, hold rule, sums -> fmout and the block's own offset / deviation
+//   D  (wave 0)      lanes = blocks: offset / deviation carried from the nearest block that measured them, the n0
+//                    smoother, status records
+// Every per-block expression and reduction order is that of the sequential loop, so results do not depend on W.
+// Dynamic LDS: per wave  S float2[olen] | Y float[olen].
+namespace {
+__device__ __forceinline__ void wave_sync() {  // LDS written by one lane of this wave, read by another
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int top_bit(unsigned long long m) { return 63 - __clzll((long long)m); }
+__device__ __forceinline__ unsigned long long bits_upto(int k) { return (2ull << k) - 1ull; }   // bits 0..k
+__device__ __forceinline__ unsigned long long bits_below(int k) { return (1ull << k) - 1ull; }  // bits 0..k-1
+}  // namespace
 
+__global__ void __launch_bounds__(1024) k_demod_fm(Geom g, ChanDev ch, Planes pl, float *__restrict__ fmout,
+                                                   const int *__restrict__ list, int nblocks, int compute_n0) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  // per-block records of the current 64-block chunk
+  __shared__ float r_bb[64], r_snr[64], r_amp[64], r_la_out[64], r_la_in[64], r_foff[64], r_pdev[64];
+  __shared__ int r_carry[64], r_pvc[64], r_sq[64], r_blanked[64];
+  __shared__ float2 r_sc[64], r_sp[64], r_st_out[64], r_st_in[64];
+  int const c = list[blockIdx.x];
+  int const lane = threadIdx.x & 63;
+  int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = blockDim.x >> 6;
+  int const olen = g.olen;
+  float2 *S = lds + (size_t)wave * olen;
+  float *Y = reinterpret_cast<float *>(lds + (size_t)W * olen) + (size_t)wave * olen;
+  // carried from block to block (fm.c:26,68-69 and struct demod); only wave 0 uses them
+  float2 c_state = ch.fm_state[c];
+  float c_la = ch.lastaudio[c];
+  int c_sq = ch.sq_count[c];
+  float c_foff = ch.foffset[c], c_pdev = ch.pdev[c];
+  float c_n0 = ch.n0[c];
   float const noise_gain = ch.noise_gain[c];
-  float n0 = ch.n0[c];
-  float ifp_v = 0.f, n0raw_v = 0.f;
-  for (int b = 0; b < nblocks; b++) {
-    if ((b & 63) == 0) {
-      int const bb2 = b + lane;
-      ifp_v = bb2 < nblocks ? pl.if_power[bb2] : 0.f;
-      n0raw_v = (compute_n0 && bb2 < nblocks) ? pl.n0raw[(size_t)c * g.max_blocks + bb2] : 0.f;
-    }
-    const float2 *in = pl.filt + ((size_t)c * g.max_blocks + b) * olen;
-    float2 cur[kPre];
-    if (prefetch) {
-#pragma unroll
-      for (int j = 0; j < kPre; j++) cur[j] = nxt[j];
-      if (b + 1 < nblocks) {
-#pragma unroll
-        for (int j = 0; j < kPre; j++) nxt[j] = (lane + 64 * j < olen) ? in[olen + lane + 64 * j] : make_float2(0.f, 0.f);
+
+  for (int b0 = 0; b0 < nblocks; b0 += 64) {
+    int const nb = min(64, nblocks - b0);
+    // ---- A: amplitude statistics (fm.c:91-103) and the last two strong samples of each block
+    for (int k = wave; k < nb; k += W) {
+      const float2 *in = pl.filt + ((size_t)c * g.max_blocks + b0 + k) * olen;
+      float sum_t = 0, sum_a = 0;
+      for (int n = lane; n < olen; n += 64) {
+        float2 const v = in[n];
+        S[n] = v;
+        float const t = cnrm(v);
+        sum_t += t;
+        sum_a += sqrtf(t);
       }
-    }
-    // amplitude statistics (fm.c:91-103)
-    float sum_t = 0, sum_a = 0;
-    auto take = [&](int n, float2 sv) {
-      S[n] = sv;
-      float const t = cnrm(sv);
-      sum_t += t;
-      sum_a += sqrtf(t);
-    };
-    if (prefetch) {
-#pragma unroll
-      for (int j = 0; j < kPre; j++)
-        if (lane + 64 * j < olen) take(lane + 64 * j, cur[j]);
-    } else {
-      for (int n = lane; n < olen; n += 64) take(n, in[n]);
-    }
-    sum_t = wave_sum(sum_t);
-    sum_a = wave_sum(sum_a);
-    float const bb = sum_t / (2 * olen);
-    float const amp = (float)((double)sum_a / (M_SQRT2 * olen));
-    float const variance = bb - amp * amp;
-    float snr = amp * amp / (2 * variance) - 1;
-    snr = (0.0f > snr) ? 0.0f : snr;  // misc.h max(): NaN propagates
-    if (snr > 2) {
-      sq = 0;  // fm.c:108-114
-    } else if (++sq > 1000) {
-      sq = 1000;
-    }
-    int blanked = 0;
-    __syncthreads();
-    if (sq < 2) {
+      sum_t = wave_sum(sum_t);
+      sum_a = wave_sum(sum_a);
+      float const bb = sum_t / (2 * olen);
+      float const amp = (float)((double)sum_a / (M_SQRT2 * olen));
+      float const variance = bb - amp * amp;
+      float snr = amp * amp / (2 * variance) - 1;
+      snr = (0.0f > snr) ? 0.0f : snr;  // misc.h max(): NaN propagates
       float const thr = (float)(0.55 * 0.55 * amp * amp);  // fm.c:121
-      // pass 1: for every sample the last valid index <= n (LV) and < n (PV), -1 = none in this block
-      int carry = -1;
+      int carry = -1, pvc = -1;  // last strong sample and the one before it
       for (int cb = 0; cb < olen; cb += 64) {
         int const n = cb + lane;
         bool const valid = n < olen && cnrm(S[n < olen ? n : 0]) > thr;
-        int idx = valid ? n : -1;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          int const up = __shfl_up(idx, o, 64);
-          if (lane >= o) idx = max(idx, up);
-        }
-        int ex = __shfl_up(idx, 1, 64);
-        if (lane == 0) ex = -1;
-        if (n < olen) {
-          LV[n] = max(idx, carry);
-          PV[n] = max(ex, carry);
-        }
-        carry = max(carry, __shfl(idx, 63, 64));
-      }
-      __syncthreads();
-      // pass 2: discriminator on valid samples (fm.c:130-132): arg(s_n * conj(s_prev_valid))
-      for (int n = lane; n < olen; n += 64) {
-        if (LV[n] == n) {
-          int const pv = PV[n];
-          float2 const st = (pv >= 0) ? cconj(S[pv]) : state;
-          float2 const pr = cmul(S[n], st);
-          Y[n] = atan2f(pr.y, pr.x);
+        unsigned long long const m = __ballot(valid);
+        if (m) {
+          int const top = top_bit(m);
+          unsigned long long const rest = m & ~(1ull << top);
+          pvc = rest ? cb + top_bit(rest) : carry;
+          carry = cb + top;
         }
       }
-      __syncthreads();
-      // pass 3: weak samples repeat the last good audio value (fm.c:141)
-      float sum_y = 0, vmax = -INFINITY, vmin = INFINITY;
-      for (int n = lane; n < olen; n += 64) {
-        int const lv = LV[n];
-        float const y = (lv >= 0) ? Y[lv] : lastaudio;
-        OUT[n] = y;
-        sum_y += y;
-        if (lv == n) {
-          if (n > 0) {
-            vmax = fmaxf(vmax, y);
-            vmin = fminf(vmin, y);
+      wave_sync();
+      if (lane == 0) {
+        r_bb[k] = bb;
+        r_snr[k] = snr;
+        r_amp[k] = amp;
+        r_carry[k] = carry;
+        r_pvc[k] = pvc;
+        r_sc[k] = carry >= 0 ? S[carry] : make_float2(0.f, 0.f);
+        r_sp[k] = pvc >= 0 ? S[pvc] : make_float2(0.f, 0.f);
+      }
+      wave_sync();
+    }
+    __syncthreads();
+    // ---- B: squelch counters and what every block starts from
+    if (wave == 0) {
+      bool const act = lane < nb;
+      bool const reset = act && r_snr[lane] > 2;  // fm.c:108-114
+      unsigned long long const rm = __ballot(reset), rl = rm & bits_upto(lane);
+      int const sq = rl ? lane - top_bit(rl) : min(c_sq + lane + 1, 1000);
+      bool const open = sq < 2;
+      int const carry = act ? r_carry[lane] : -1;
+      // a squelched block leaves zeros behind (fm.c:156-160), an open one with a strong sample leaves that sample
+      bool const def = act && (!open || carry >= 0);
+      float2 const sc = r_sc[lane];
+      r_st_out[lane] = open ? cconj(sc) : make_float2(0.f, 0.f);
+      unsigned long long const dm = __ballot(def), dl = dm & bits_below(lane);
+      int const j = dl ? top_bit(dl) : -1;
+      wave_sync();
+      float2 const st_in = j >= 0 ? r_st_out[j] : c_state;
+      float ylast = 0;
+      if (open && carry >= 0) {  // the discriminator output at the block's last strong sample (fm.c:130-132)
+        float2 const st = r_pvc[lane] >= 0 ? cconj(r_sp[lane]) : st_in;
+        float2 const pr = cmul(sc, st);
+        ylast = atan2f(pr.y, pr.x);
+      }
+      r_la_out[lane] = ylast;
+      wave_sync();
+      r_la_in[lane] = j >= 0 ? r_la_out[j] : c_la;
+      r_st_in[lane] = st_in;
+      r_sq[lane] = sq;
+      if (dm) {
+        int const jl = top_bit(dm);
+        c_state = r_st_out[jl];
+        c_la = r_la_out[jl];
+      }
+      c_sq = __shfl(sq, nb - 1, 64);
+    }
+    __syncthreads();
+    // ---- C: discriminator and hold rule (fm.c:116-160)
+    for (int k = wave; k < nb; k += W) {
+      const float2 *in = pl.filt + ((size_t)c * g.max_blocks + b0 + k) * olen;
+      float *fo = fmout + ((size_t)c * g.max_blocks + b0 + k) * olen;
+      int const sq = r_sq[k];
+      int blanked = 0;
+      float foff = 0, pdev = 0;
+      if (sq < 2) {
+        float const amp = r_amp[k];
+        float const thr = (float)(0.55 * 0.55 * amp * amp);
+        float2 const st_in = r_st_in[k];
+        float const la_in = r_la_in[k];
+        for (int n = lane; n < olen; n += 64) S[n] = in[n];
+        wave_sync();
+        int carry = -1;
+        for (int cb = 0; cb < olen; cb += 64) {
+          int const n = cb + lane;
+          float2 const v = S[n < olen ? n : 0];
+          bool const valid = n < olen && cnrm(v) > thr;
+          unsigned long long const m = __ballot(valid), ml = m & bits_below(lane);
+          if (valid) {  // arg(s_n * conj(previous strong sample)), fm.c:130-132
+            int const pv = ml ? cb + top_bit(ml) : carry;
+            float2 const st = pv >= 0 ? cconj(S[pv]) : st_in;
+            float2 const pr = cmul(v, st);
+            Y[n] = atan2f(pr.y, pr.x);
           }
-        } else {
-          blanked++;
+          if (m) carry = cb + top_bit(m);
+        }
+        wave_sync();
+        // weak samples repeat the last good audio value (fm.c:141)
+        float sum_y = 0, vmax = -INFINITY, vmin = INFINITY;
+        bool first_valid = false;
+        carry = -1;
+        for (int cb = 0; cb < olen; cb += 64) {
+          int const n = cb + lane;
+          bool const valid = n < olen && cnrm(S[n < olen ? n : 0]) > thr;
+          unsigned long long const m = __ballot(valid), mu = m & bits_upto(lane);
+          if (cb == 0) first_valid = (m & 1ull) != 0;
+          if (n < olen) {
+            int const lv = mu ? cb + top_bit(mu) : carry;
+            float const y = lv >= 0 ? Y[lv] : la_in;
+            fo[n] = y;
+            sum_y += y;
+            if (valid) {
+              if (n > 0) {
+                vmax = fmaxf(vmax, y);
+                vmin = fminf(vmin, y);
+              }
+            } else {
+              blanked++;
+            }
+          }
+          if (m) carry = cb + top_bit(m);
+        }
+        sum_y = wave_sum(sum_y);
+        vmax = wave_max(vmax);
+        vmin = wave_min(vmin);
+        blanked = wave_sum_i(blanked);
+        // peak-deviation seeds: sample 0 seeds both only when it is strong (fm.c:125-139)
+        float const seed = first_valid ? Y[0] : 0.0f;
+        float pdev_pos = fmaxf(seed, vmax), pdev_neg = fminf(seed, vmin);
+        float const avg_f = sum_y / olen;
+        if (sq < 1) {  // fm.c:146-154
+          foff = (float)(g.dsamprate * avg_f * (0.5 * M_1_PI));
+          pdev_pos -= avg_f;
+          pdev_neg -= avg_f;
+          float const mx = (pdev_pos > -pdev_neg) ? pdev_pos : -pdev_neg;
+          pdev = (float)(g.dsamprate * mx * (0.5 * M_1_PI));
+        }
+        wave_sync();  // S and Y are reused by this wave's next block
+      } else {
+        for (int n = lane; n < olen; n += 64) fo[n] = 0;  // fm.c:156-160
+      }
+      if (lane == 0) {
+        r_blanked[k] = blanked;
+        r_foff[k] = foff;
+        r_pdev[k] = pdev;
+      }
+    }
+    __syncthreads();
+    // ---- D: carried readings and the status records
+    if (wave == 0) {
+      bool const act = lane < nb;
+      int const sq = r_sq[lane];
+      bool const own = act && sq < 1;
+      unsigned long long const om = __ballot(own), ol = om & bits_upto(lane);
+      int const jo = ol ? top_bit(ol) : -1;
+      float const foffset = jo >= 0 ? r_foff[jo] : c_foff;
+      float const pdev = jo >= 0 ? r_pdev[jo] : c_pdev;
+      if (om) {
+        int const jl = top_bit(om);
+        c_foff = r_foff[jl];
+        c_pdev = r_pdev[jl];
+      }
+      float n0_mine = NAN;
+      if (compute_n0) {  // fm.c:79-82: a chain in double through the blocks
+        float const fresh_v = act ? pl.n0raw[(size_t)c * g.max_blocks + b0 + lane] : 0.f;
+        for (int k = 0; k < nb; k++) {
+          float const fresh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fresh_v), k));
+          c_n0 = isnan(c_n0) ? fresh : (float)((double)c_n0 + .01 * (double)(fresh - c_n0));
+          if (lane == k) n0_mine = c_n0;
         }
       }
-      sum_y = wave_sum(sum_y);
-      vmax = wave_max(vmax);
-      vmin = wave_min(vmin);
-      blanked = wave_sum_i(blanked);
-      __syncthreads();
-      // peak-deviation seeds: sample 0 seeds both only when it is valid (fm.c:125-139)
-      float const seed = (LV[0] == 0) ? Y[0] : 0.0f;
-      float pdev_pos = fmaxf(seed, vmax), pdev_neg = fminf(seed, vmin);
-      float const avg_f = sum_y / olen;
-      if (carry >= 0) {
-        state = cconj(S[carry]);
-        lastaudio = Y[carry];
+      if (act) {
+        kq_chan_status st;
+        st.if_power = pl.if_power[b0 + lane];
+        st.noise_gain = noise_gain;
+        st.plfreq = NAN;
+        st.cphase = 0;
+        st.pll_lock = 0;
+        st.lock_count = 0;
+        st.n0 = n0_mine;
+        st.bb_power = r_bb[lane];
+        st.snr = r_snr[lane];
+        st.foffset = foffset;
+        st.pdeviation = pdev;
+        st.agc_gain = 0;
+        st.squelch_count = sq;
+        st.hangcount = 0;
+        st.blanked = r_blanked[lane];
+        st.nout = olen;
+        pl.status[(size_t)c * g.max_blocks + b0 + lane] = st;
       }
-      if (sq < 1) {  // fm.c:146-154
-        foffset = (float)(g.dsamprate * avg_f * (0.5 * M_1_PI));
-        pdev_pos -= avg_f;
-        pdev_neg -= avg_f;
-        float const mx = (pdev_pos > -pdev_neg) ? pdev_pos : -pdev_neg;
-        pdev = (float)(g.dsamprate * mx * (0.5 * M_1_PI));
-      }
-    } else {
-      state = make_float2(0, 0);  // fm.c:156-160
-      lastaudio = 0;
-      for (int n = lane; n < olen; n += 64) OUT[n] = 0;
     }
     __syncthreads();
-    // the detected samples of this block: input of the post-detection filters (fm.c:131,141,162)
-    float *fo = fmout + ((size_t)c * g.max_blocks + b) * olen;
-    for (int n = lane; n < olen; n += 64) fo[n] = OUT[n];
-    __syncthreads();
-    // status record: its per-block inputs come out of registers (lane i holds block b0 + i) -- a global load here
-    // would stall this in-order wave for a memory round trip on every block
-    float const ifp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ifp_v), b & 63));
-    float const fresh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(n0raw_v), b & 63));
-    if (compute_n0) n0 = isnan(n0) ? fresh : (float)((double)n0 + .01 * (double)(fresh - n0));  // fm.c:79-82
-    if (lane == 0) {
-      kq_chan_status st;
-      st.if_power = ifp;
-      st.noise_gain = noise_gain;
-      st.plfreq = NAN;
-      st.cphase = 0;
-      st.pll_lock = 0;
-      st.lock_count = 0;
-      st.n0 = compute_n0 ? n0 : NAN;
-      st.bb_power = bb;
-      st.snr = snr;
-      st.foffset = foffset;
-      st.pdeviation = pdev;
-      st.agc_gain = 0;
-      st.squelch_count = sq;
-      st.hangcount = 0;
-      st.blanked = blanked;
-      st.nout = olen;
-      pl.status[(size_t)c * g.max_blocks + b] = st;
-    }
   }
-  if (lane == 0) {
-    ch.n0[c] = n0;
-    ch.fm_state[c] = state;
-    ch.lastaudio[c] = lastaudio;
-    ch.sq_count[c] = sq;
-    ch.foffset[c] = foffset;
-    ch.pdev[c] = pdev;
+  if (threadIdx.x == 0) {
+    ch.n0[c] = c_n0;
+    ch.fm_state[c] = c_state;
+    ch.lastaudio[c] = c_la;
+    ch.sq_count[c] = c_sq;
+    ch.foffset[c] = c_foff;
+    ch.pdev[c] = c_pdev;
   }
 }
-
 
 // De-emphasis overlap-save and PL slave of one (channel, block): REAL -> REAL (fm.c:162-171, 219-234;
 // filter.c:151,206-208,250).  The filter input is the channel's stream of detected samples: `hist_in` holds the
@@ -784,7 +853,12 @@ void launch_pl_track(hipStream_t s, const Geom &g, const ChanDev &ch, const Plan
 }
 
 // dynamic LDS of the generic FM demodulator (k_demod_fm): samples, masks, the audio master and its transform
-static size_t fm_disc_lds_bytes(const Geom &g) { return (size_t)g.olen * (8 + 4 + 4 + 4 + 4); }
+// waves per channel of k_demod_fm: as many as fit 96 KiB of LDS at 12 bytes a sample, at most 16 or one per block
+static int fm_disc_waves(const Geom &g, int nblocks) {
+  int const fit = (int)((96u * 1024u) / (12u * (unsigned)g.olen));
+  return std::max(1, std::min({16, fit, nblocks}));
+}
+static size_t fm_disc_lds_bytes(const Geom &g, int waves = 1) { return (size_t)g.olen * 12 * waves; }
 static size_t fm_audio_lds_bytes(const Geom &g) {
   return (size_t)g.Ndec * (8 + 4) + (size_t)g.pl_n * 8 + (size_t)(g.Ndec / 2) * 8;
 }
@@ -794,7 +868,8 @@ void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes
                    int n_fm, const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0,
                    float *fmout, const float *fm_hist_in, float *fm_hist_out) {
   if (n_fm > 0) {
-    size_t const lds_a = fm_disc_lds_bytes(g), lds_b = fm_audio_lds_bytes(g);
+    int const waves = fm_disc_waves(g, nblocks);
+    size_t const lds_a = fm_disc_lds_bytes(g, waves), lds_b = fm_audio_lds_bytes(g);
     static size_t conf_a = 0, conf_b = 0;
     if (lds_a > conf_a) {
       (void)hipFuncSetAttribute((const void *)k_demod_fm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
@@ -804,7 +879,7 @@ void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes
       (void)hipFuncSetAttribute((const void *)k_fm_audio, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
       conf_b = lds_b;
     }
-    hipLaunchKernelGGL(k_demod_fm, dim3(n_fm), dim3(64), lds_a, s, g, ch, pl, fmout, list_fm, nblocks, compute_n0);
+    hipLaunchKernelGGL(k_demod_fm, dim3(n_fm), dim3(64 * waves), lds_a, s, g, ch, pl, fmout, list_fm, nblocks, compute_n0);
     hipLaunchKernelGGL(k_fm_audio, dim3(n_fm, nblocks), dim3(64), lds_b, s, g, ch, pl, tw, fmout, fm_hist_in, fm_hist_out,
                        list_fm, nblocks);
   }

@@ -5,7 +5,7 @@
 //   k_filter_full       per (channel, block): NCO mix -> N-point FFT in LDS -> [compute_n0] ->
 //                       response multiply / CROSS_CONJ -> N/D-point IFFT -> last olen samples
 //                       (radio.c:132-139, filter.c:151, radio.c:383-425, filter.c:206-250)
-//   k_demod_fm/am/lin   demodulators with state carried across blocks in HBM (fm.c, am.c, linear.c)
+//   k_demod_fm/am/lin   demodulators with state carried across calls in HBM (fm.c, am.c, linear.c)
 //
 // The pruned forward path lives in kq_pruned.hip.
 #include <algorithm>
@@ -852,7 +852,8 @@ void launch_pl_track(hipStream_t s, const Geom &g, const ChanDev &ch, const Plan
   hipLaunchKernelGGL(k_pl_track, dim3(n_fm), dim3(1024), 16384 * 8, s, g, ch, pl, tw, list_fm, nblocks);
 }
 
-// dynamic LDS of the generic FM demodulator (k_demod_fm): samples, masks, the audio master and its transform
+// dynamic LDS of the generic FM demodulator: k_demod_fm's samples and discriminator outputs per wave; k_fm_audio's
+// audio master, its transform, the PL slave and the twiddles
 // waves per channel of k_demod_fm: as many as fit 96 KiB of LDS at 12 bytes a sample, at most 16 or one per block
 static int fm_disc_waves(const Geom &g, int nblocks) {
   int const fit = (int)((96u * 1024u) / (12u * (unsigned)g.olen));

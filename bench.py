@@ -42,7 +42,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(name, geom, plan, iq_host, target_s):
+def cpu_baseline(name, geom, plan, iq_host, target_s, compute_n0=0):
     """Oracle ('port') timed on this box's host cores on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -51,7 +51,7 @@ def cpu_baseline(name, geom, plan, iq_host, target_s):
     cores = os.cpu_count() or 1
     L = geom["L"]
     nchan = min(len(plan), 2 * cores)
-    cfgs = [oracle_cfg(p, geom["samprate"], L, geom["M"], geom["D"], compute_n0=0) for p in plan[:nchan]]
+    cfgs = [oracle_cfg(p, geom["samprate"], L, geom["M"], geom["D"], compute_n0=compute_n0) for p in plan[:nchan]]
     nblocks = 4
     t, _ = ko.cpu_baseline(cfgs, iq_host, nblocks, cores)            # calibration pass
     rate = nchan * nblocks / t
@@ -59,8 +59,9 @@ def cpu_baseline(name, geom, plan, iq_host, target_s):
     t, _ = ko.cpu_baseline(cfgs, iq_host, nblocks, cores)
     msps = nchan * nblocks * L / t / 1e6
     return {"value": round(msps, 3), "unit": "Msamples/s (channel-samples)", "cores": cores, "kind": "port",
-            "sample": "%d channels x %d blocks of %s (oracle C restatement, own radix-2 FFT, no compute_n0), "
-                      "%d threads, %.1f s" % (nchan, nblocks, name, cores, t)}
+            "sample": "%d channels x %d blocks of %s (oracle C restatement, own radix-2 FFT, %s), "
+                      "%d threads, %.1f s" % (nchan, nblocks, name, "compute_n0 every block" if compute_n0 else
+                                              "no compute_n0", cores, t)}
 
 
 def pmc_traffic(config, channels, blocks, fwd):
@@ -245,9 +246,12 @@ def main():
             },
         }
         if n0_row:
+            n0_row["roofline_frac_of_step"] = round(abytes / (n0_row["ms_per_step"] * 1e-3) / 8e12, 4)
             out["with_compute_n0"] = n0_row
         if not a.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(a.config, geom, plan, iq_host[M - 1:], a.cpu_seconds)
+            if n0_row:  # each GPU row beside the CPU path configured the same way
+                n0_row["cpu_baseline"] = cpu_baseline(a.config, geom, plan, iq_host[M - 1:], a.cpu_seconds / 2, compute_n0=1)
         print(json.dumps(out), flush=True)
     bank.close()
     if dist:

@@ -227,22 +227,26 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
         }
       }
     }
+    // bins inside the passband never count: +inf fails both passes' `< thr` (as do the NaN / inf bins the reference's
+    // comparison drops)
+#pragma unroll
+    for (int k3 = 0; k3 < 16; k3++) {
+      pa[k3] = ((incl_a >> k3) & 1) ? pa[k3] : INFINITY;
+      pb[k3] = ((incl_b >> k3) & 1) ? pb[k3] : INFINITY;
+    }
     float avg = INFINITY;
     for (int iter = 0; iter < 2; iter++) {
       float acc = 0;
-      int bins = 0;
+      int wave_bins = 0;  // counted on the scalar unit from the comparison masks
       float const thr = avg * 2;
 #pragma unroll
       for (int k3 = 0; k3 < 16; k3++) {
-        if (((incl_a >> k3) & 1) && pa[k3] < thr) {
-          acc += pa[k3];
-          bins++;
-        }
-        if (((incl_b >> k3) & 1) && pb[k3] < thr) {
-          acc += pb[k3];
-          bins++;
-        }
+        bool const ta = pa[k3] < thr, tb = pb[k3] < thr;
+        acc += ta ? pa[k3] : 0.f;
+        acc += tb ? pb[k3] : 0.f;
+        wave_bins += __popcll(__ballot(ta)) + __popcll(__ballot(tb));
       }
+      int bins = (t & 63) == 0 ? wave_bins : 0;
       block_sum_fi(acc, bins, red_f, red_i);
       avg = acc / bins;
     }

@@ -256,18 +256,27 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   // ---------------- slave (filter.c:206-250): the N/D bins it reads go to LDS as Xs[p], p = k mod N_dec
   float2 *Xs = xch;
   float2 *G = Xs + Ndec;
+  auto to_f2 = [](v2f a) { return make_float2(a.x, a.y); };
+  if (Ndec <= 1024) {
+    // the slave's bins all lie in the first and the last 1024: rows k3 = 0 and k3 = 15 only
+    if (ka <= Ndec / 2) Xs[ka] = to_f2(ya[0]);
+    if (kb <= Ndec / 2) Xs[kb] = to_f2(yb[0]);
+    if (ka + 15 * 1024 > kN - Ndec / 2) Xs[ka - 1024 + Ndec] = to_f2(ya[15]);
+    if (kb + 15 * 1024 > kN - Ndec / 2) Xs[kb - 1024 + Ndec] = to_f2(yb[15]);
+  } else {
 #pragma unroll
-  for (int k3 = 0; k3 < 16; k3++) {
-    // bins of this k3 lie in [1024 k3, 1024 k3 + 1023]: skip the rows that cannot hold a bin the slave reads
-    if (1024 * k3 > Ndec / 2 && 1024 * k3 + 1023 <= kN - Ndec / 2) continue;
+    for (int k3 = 0; k3 < 16; k3++) {
+      // bins of this k3 lie in [1024 k3, 1024 k3 + 1023]: skip the rows that cannot hold a bin the slave reads
+      if (1024 * k3 > Ndec / 2 && 1024 * k3 + 1023 <= kN - Ndec / 2) continue;
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-      int const n = (half ? kb : ka) + 1024 * k3;
-      float2 const val = half ? make_float2(yb[k3].x, yb[k3].y) : make_float2(ya[k3].x, ya[k3].y);
-      if (n <= Ndec / 2)
-        Xs[n] = val;
-      else if (n > kN - Ndec / 2)
-        Xs[n - kN + Ndec] = val;
+      for (int half = 0; half < 2; half++) {
+        int const n = (half ? kb : ka) + 1024 * k3;
+        float2 const val = to_f2(half ? yb[k3] : ya[k3]);
+        if (n <= Ndec / 2)
+          Xs[n] = val;
+        else if (n > kN - Ndec / 2)
+          Xs[n - kN + Ndec] = val;
+      }
     }
   }
   __syncthreads();

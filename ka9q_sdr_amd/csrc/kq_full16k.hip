@@ -23,8 +23,10 @@
 #include "kq_ldsfft.hpp"
 #include <cmath>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
+#include "kq_lane.hpp"
 #include "kq_regfft.hpp"
 
 namespace kq {
@@ -282,6 +284,38 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   __syncthreads();
   const float2 *H = ch.resp + (size_t)c * Ndec;
   bool const isb = (ch.flags[c] & FLAG_ISB) != 0;
+  if (Ndec == 64) {
+    // cfg 3 / 4: one wave multiplies and runs the 64-point inverse transform in its registers (lane exchanges, no
+    // barriers); the other seven are done
+    if (t >= 64) return;
+    int const q = (int)(__brev((unsigned)t) >> 26);  // decimation in time: bit-reversed in, natural out
+    float2 z = cmul(H[q], Xs[q]);
+    if (isb && q != 0 && q != 32) {  // filter.c:242-248
+      float2 const other = cmul(H[64 - q], Xs[64 - q]);
+      z = q < 32 ? cadd(z, cconj(other)) : csub(z, cconj(other));
+    }
+    auto xch2 = [&](float2 v, auto m) {
+      return make_float2(lane_xor<decltype(m)::value>(v.x, t), lane_xor<decltype(m)::value>(v.y, t));
+    };
+    auto stage = [&](auto m) {
+      constexpr int half = decltype(m)::value;
+      float sn, cs;
+      sincospif((float)(t & (half - 1)) / (float)half, &sn, &cs);
+      bool const up = (t & half) != 0;
+      float2 const v = up ? cmul(z, make_float2(cs, sn)) : z;
+      float2 const r = xch2(v, m);
+      z = up ? csub(r, v) : cadd(v, r);
+    };
+    stage(std::integral_constant<int, 1>{});
+    stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 4>{});
+    stage(std::integral_constant<int, 8>{});
+    stage(std::integral_constant<int, 16>{});
+    stage(std::integral_constant<int, 32>{});
+    float2 *o = pl.filt + ((size_t)c * g.max_blocks + b) * g.olen;
+    if (t >= 64 - g.olen) o[t - (64 - g.olen)] = z;  // filter.c:131
+    return;
+  }
   for (int p = t; p <= Ndec / 2; p += kT) {
     float2 gp = cmul(H[p], Xs[p]);
     if (p > 0 && p < Ndec / 2) {

@@ -84,8 +84,8 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
                                                        int compute_n0, float2 *__restrict__ spec_dump, int spec_ch,
                                                        const int *__restrict__ chan_list) {
   extern __shared__ __attribute__((aligned(16))) float2 xch[];
-  __shared__ float red_f[16];
-  __shared__ int red_i[16];
+  __shared__ float red_f[2][kT / 64];  // compute_n0: one slot per wave and pass
+  __shared__ int red_i[2][kT / 64];
   int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
   int const t = threadIdx.x;
   int const Ndec = g.Ndec;
@@ -248,9 +248,20 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
         acc += tb ? pb[k3] : 0.f;
         wave_bins += __popcll(__ballot(ta)) + __popcll(__ballot(tb));
       }
-      int bins = (t & 63) == 0 ? wave_bins : 0;
-      block_sum_fi(acc, bins, red_f, red_i);
-      avg = acc / bins;
+      acc = wave_sum(acc);
+      if ((t & 63) == 0) {
+        red_f[iter][t >> 6] = acc;
+        red_i[iter][t >> 6] = wave_bins;
+      }
+      __syncthreads();
+      float tf = 0;
+      int bins = 0;
+#pragma unroll
+      for (int k = 0; k < kT / 64; k++) {
+        tf += red_f[iter][k];
+        bins += red_i[iter][k];
+      }
+      avg = tf / bins;
     }
     if (t == 0) pl.n0raw[(size_t)c * g.max_blocks + b] = (float)(avg / (2.0 * kN * g.samprate));
   }

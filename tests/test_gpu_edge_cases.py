@@ -155,3 +155,55 @@ def test_handles_release_their_device_memory(gpu):
         cycle()
     after = free_bytes()
     assert before - after < 8 << 20, (before, after)
+
+
+@pytest.mark.parametrize("per_call", [150, 64, 7])
+def test_fm_hand_overs_across_many_blocks(gpu, per_call):
+    """The generic FM demodulator takes 64 blocks of a channel at a time and resolves what each block inherits from
+    the ones before it (squelch counter, last strong sample, last audio value, offset / deviation readings) by a
+    scan.  A signal that comes and goes, fades below the blanking threshold, and a stretch of exact zeros (an open
+    block without a single strong sample, then a squelched one) against the oracle's sequential loop; 150 blocks in
+    one call span three chunks, 7 per call leave every chunk ragged."""
+    g = dict(samprate=192000, L=512, M=513, D=4)            # N/D = 256, 128 samples per block
+    fs, L = g["samprate"], g["L"]
+    nb = 150
+    n = nb * L
+    t = np.arange(n) / fs
+    rng = np.random.default_rng(91)
+    blk = np.arange(n) // L
+    on = ((blk < 30) | ((blk >= 60) & (blk < 90)) | (blk >= 100)).astype(np.float64)
+    fade = 1.0 + 0.93 * np.cos(2 * np.pi * 211.0 * t)      # dips under 0.55 of the block average
+    sig = 0.2 * on * fade * np.exp(1j * (2 * np.pi * 30000.0 * t + 2.5 * np.sin(2 * np.pi * 900.0 * t)))
+    iq = sig + 1e-3 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    iq[(blk >= 90) & (blk < 100)] = 0                        # digital silence
+    iq = iq.astype(np.complex64)
+    plan = [dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-30000.0 - 13.0),
+            dict(demod="fm", low=-6000.0, high=9000.0, second_lo=-30000.0 + 7.0, flat=1)]
+    want = run_oracle(plan, g, iq, nb, compute_n0=1)
+    bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), per_call, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL)
+    for p in plan:
+        bank.add_channel(bank_cfg(p))
+    got = [[] for _ in plan]
+    for s in range(0, nb, per_call):
+        k = min(per_call, nb - s)
+        bank.push_iq(iq[s * L:(s + k) * L])
+        assert bank.process() == k
+        for c in range(len(plan)):
+            got[c] += [(bank.audio(c, b), bank.status(c, b)) for b in range(k)]
+    bank.close()
+    seen_closed = seen_blanked = 0
+    for c in range(len(plan)):
+        auds, sts, _ = want[c]
+        for b in range(nb):
+            ga, gs = got[c][b]
+            assert (gs["squelch_count"], gs["blanked"], gs["nout"]) == \
+                   (sts[b]["squelch_count"], sts[b]["blanked"], sts[b]["nout"]), (c, b)
+            np.testing.assert_allclose(gs["foffset"], sts[b]["foffset"], rtol=1e-4, atol=2e-2)
+            np.testing.assert_allclose(gs["pdeviation"], sts[b]["pdeviation"], rtol=1e-4, atol=2e-2)
+            if b < 90 or b >= 100:   # n0 of an all-zero spectrum is 0/0
+                np.testing.assert_allclose(gs["n0"], sts[b]["n0"], rtol=2e-4)
+            seen_closed += sts[b]["squelch_count"] >= 2
+            seen_blanked += sts[b]["blanked"] > 0 and sts[b]["squelch_count"] < 2
+        a_g, a_w = np.concatenate([a for a, _ in got[c]]), np.concatenate(auds)
+        assert rel_rms(a_g, a_w) < 1e-5, (c, rel_rms(a_g, a_w))
+    assert seen_closed > 20 and seen_blanked > 20           # the case exercises what it is meant to

@@ -48,7 +48,9 @@ typedef struct kq_bank kq_bank;   /* opaque */
  * called from main.c:232) plus demod->filter.decimate and demod->input.samprate
  * (radio_status.c:264-267), which the reference keeps per process. */
 typedef struct kq_bank_config {
-  int device;              /* HIP device ordinal */
+  int device;              /* HIP device ordinal.  A handle stays on its device: every call taking the handle runs
+                            * there and restores the calling thread's current device, so one process can drive
+                            * banks on several GPUs (kq_bank_create itself leaves `device` current). */
   int samprate;            /* front-end complex sample rate, Hz */
   unsigned L;              /* new samples per block            (demod->filter.L) */
   unsigned M;              /* impulse response length          (demod->filter.M); N = L+M-1 power of two */

@@ -343,6 +343,7 @@ kq_afsk_bank *kq_afsk_create(const kq_afsk_config *cfg) {
 }
 
 int kq_afsk_destroy(kq_afsk_bank *b) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return -1;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   void *ptrs[] = {b->pend, b->hist, b->resp, b->tw, b->last_out, b->mark_tab, b->space_tab, b->state,
@@ -355,6 +356,7 @@ int kq_afsk_destroy(kq_afsk_bank *b) {
 
 int kq_afsk_push(kq_afsk_bank *b, const void *samples, int format, unsigned nsessions, size_t nsamples,
                  size_t session_stride, int on_device) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || (!samples && nsamples)) {
     kq_internal_set_error("kq_afsk_push: null argument");
     return -1;
@@ -420,12 +422,14 @@ int kq_afsk_push(kq_afsk_bank *b, const void *samples, int format, unsigned nses
 }
 
 int kq_afsk_sync(kq_afsk_bank *b) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return -1;
   AF_TRY(hipStreamSynchronize(b->stream));
   return 0;
 }
 
 int kq_afsk_num_frames(kq_afsk_bank *b, unsigned session) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || session >= b->cfg.max_sessions) return -1;
   int n = 0;
   AF_TRY(hipStreamSynchronize(b->stream));
@@ -434,6 +438,7 @@ int kq_afsk_num_frames(kq_afsk_bank *b, unsigned session) {
 }
 
 int kq_afsk_dropped_frames(kq_afsk_bank *b, unsigned session) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || session >= b->cfg.max_sessions) return -1;
   int n = 0;
   AF_TRY(hipStreamSynchronize(b->stream));
@@ -442,6 +447,7 @@ int kq_afsk_dropped_frames(kq_afsk_bank *b, unsigned session) {
 }
 
 int kq_afsk_pull_frame(kq_afsk_bank *b, unsigned session, unsigned index, unsigned char *dst, size_t cap) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || !dst || session >= b->cfg.max_sessions) return -1;
   int const n = kq_afsk_num_frames(b, session);
   if (n < 0 || index >= (unsigned)n) {
@@ -457,6 +463,7 @@ int kq_afsk_pull_frame(kq_afsk_bank *b, unsigned session, unsigned index, unsign
 }
 
 int kq_afsk_clear_frames(kq_afsk_bank *b) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return -1;
   AF_TRY(hipMemsetAsync(b->nframes, 0, b->cfg.max_sessions * sizeof(int), b->stream));
   AF_TRY(hipMemsetAsync(b->dropped, 0, b->cfg.max_sessions * sizeof(int), b->stream));
@@ -464,6 +471,7 @@ int kq_afsk_clear_frames(kq_afsk_bank *b) {
 }
 
 int kq_afsk_pull_filter_output(kq_afsk_bank *b, unsigned session, float *dst_re_im, size_t cap_complex) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || !dst_re_im || session >= b->cfg.max_sessions || cap_complex < (size_t)AL) return -1;
   AF_TRY(hipStreamSynchronize(b->stream));
   AF_TRY(hipMemcpy(dst_re_im, b->last_out + (size_t)session * AL, AL * sizeof(float2), hipMemcpyDeviceToHost));
@@ -471,6 +479,7 @@ int kq_afsk_pull_filter_output(kq_afsk_bank *b, unsigned session, float *dst_re_
 }
 
 int kq_afsk_pull_state(kq_afsk_bank *b, unsigned session, kq_afsk_state *out) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || !out || session >= b->cfg.max_sessions) return -1;
   AfskState st;
   AF_TRY(hipStreamSynchronize(b->stream));

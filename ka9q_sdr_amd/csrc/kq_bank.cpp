@@ -818,6 +818,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
 }
 
 int kq_bank_destroy(kq_bank *b) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return 0;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->stream2 && b->stream2 != b->stream) (void)hipStreamSynchronize(b->stream2);
@@ -911,6 +912,7 @@ int pll_leave(kq_bank *b, int rank, int npll) {
 }  // namespace
 
 int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || !cfg) {
     set_err("NULL argument");
     return -1;
@@ -979,6 +981,7 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
 // close_chan equivalent: the demodulator thread is joined and its struct demod freed (radio.c:335-337 does the join
 // for a mode change).  Channel numbers of the others do not change; the slot is a hole until an add reuses it.
 int kq_bank_remove_channel(kq_bank *b, int ch) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch)) {
     set_err("bad channel");
     return -1;
@@ -1004,6 +1007,7 @@ int kq_bank_channel_active(const kq_bank *b, int ch) { return valid_ch(b, ch) ? 
 unsigned kq_bank_num_channels(const kq_bank *b) { return b ? (unsigned)b->chans.size() : 0; }
 
 int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || !m) {
     set_err("bad channel or NULL mode");
     return -1;
@@ -1051,6 +1055,7 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
 }
 
 int kq_bank_set_second_lo(kq_bank *b, int ch, double hz) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || std::isnan(hz)) {
     set_err("bad channel or NaN");
     return -1;
@@ -1067,6 +1072,7 @@ int kq_bank_set_second_lo(kq_bank *b, int ch, double hz) {
 }
 
 int kq_bank_set_doppler(kq_bank *b, int ch, double hz, double hz_per_s) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || std::isnan(hz) || std::isnan(hz_per_s)) {
     set_err("bad channel or NaN");
     return -1;
@@ -1085,6 +1091,7 @@ int kq_bank_set_doppler(kq_bank *b, int ch, double hz, double hz_per_s) {
 }
 
 int kq_bank_set_shift(kq_bank *b, int ch, double hz) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || std::isnan(hz)) {
     set_err("bad channel or NaN");
     return -1;
@@ -1095,6 +1102,7 @@ int kq_bank_set_shift(kq_bank *b, int ch, double hz) {
 }
 
 int kq_bank_set_filter(kq_bank *b, int ch, float low, float high, float beta) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch)) {
     set_err("bad channel");
     return -1;
@@ -1117,6 +1125,7 @@ int kq_bank_set_filter(kq_bank *b, int ch, float low, float high, float beta) {
 }
 
 int kq_bank_push_iq(kq_bank *b, const void *iq, size_t nsamples, int format, int is_device) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || (!iq && nsamples)) {
     set_err("NULL argument");
     return -1;
@@ -1164,6 +1173,7 @@ int kq_bank_push_iq(kq_bank *b, const void *iq, size_t nsamples, int format, int
 }
 
 int kq_bank_push_zeros(kq_bank *b, size_t nsamples) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) {
     set_err("NULL bank");
     return -1;
@@ -1191,6 +1201,7 @@ int kq_bank_push_zeros(kq_bank *b, size_t nsamples) {
 }
 
 int kq_bank_push_rtp(kq_bank *b, const void *datagram, size_t size) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || !datagram) {
     set_err("NULL argument");
     return -1;
@@ -1257,6 +1268,7 @@ int kq_bank_push_rtp(kq_bank *b, const void *datagram, size_t size) {
 }
 
 int kq_bank_rtp_counters(const kq_bank *b, kq_rtp_counters *out) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || !out) return -1;
   *out = b->rtp;
   return 0;
@@ -1265,6 +1277,7 @@ int kq_bank_rtp_counters(const kq_bank *b, kq_rtp_counters *out) {
 unsigned kq_bank_blocks_ready(const kq_bank *b) { return b ? (unsigned)(b->pending / b->g.L) : 0; }
 
 int kq_bank_process(kq_bank *b) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) {
     set_err("NULL bank");
     return -1;
@@ -1289,6 +1302,7 @@ int kq_bank_process(kq_bank *b) {
 }
 
 int kq_bank_process_resident(kq_bank *b, const void *iq_dev, unsigned nblocks) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || !iq_dev) {
     set_err("NULL argument");
     return -1;
@@ -1302,6 +1316,7 @@ int kq_bank_process_resident(kq_bank *b, const void *iq_dev, unsigned nblocks) {
 }
 
 int kq_bank_join(kq_bank *b) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return -1;
   if (b->calls == 0) return 0;
   if (b->stream2 != b->stream) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[(b->calls - 1) & 1], 0));
@@ -1309,6 +1324,7 @@ int kq_bank_join(kq_bank *b) {
 }
 
 int kq_bank_sync(kq_bank *b) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return -1;
   if (sync_all(b)) return -1;
   return 0;
@@ -1318,6 +1334,7 @@ unsigned kq_bank_olen(const kq_bank *b) { return b ? (unsigned)b->g.olen : 0; }
 unsigned kq_bank_last_blocks(const kq_bank *b) { return b ? b->last_blocks : 0; }
 
 int kq_bank_pull_status(kq_bank *b, int ch, unsigned blk, kq_chan_status *st) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || !st || blk >= b->last_blocks) {
     set_err("bad channel/block");
     return -1;
@@ -1328,6 +1345,7 @@ int kq_bank_pull_status(kq_bank *b, int ch, unsigned blk, kq_chan_status *st) {
 }
 
 int kq_bank_pull_audio(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap, size_t *n) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || !dst || blk >= b->last_blocks) {
     set_err("bad channel/block");
     return -1;
@@ -1345,6 +1363,7 @@ int kq_bank_pull_audio(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap,
 }
 
 int kq_bank_enable_pcm(kq_bank *b, int on) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return -1;
   if (on && !b->pcm) {
     size_t const CB = (size_t)b->cfg.max_channels * b->cfg.max_blocks;
@@ -1355,6 +1374,7 @@ int kq_bank_enable_pcm(kq_bank *b, int on) {
 }
 
 int kq_bank_pull_pcm(kq_bank *b, int ch, unsigned blk, int16_t *dst, size_t cap, size_t *nwords, uint32_t *silent_mask) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || !dst || blk >= b->last_blocks || !b->pcm_on) {
     set_err("bad channel/block, or PCM stage not enabled");
     return -1;
@@ -1375,6 +1395,7 @@ int kq_bank_pull_pcm(kq_bank *b, int ch, unsigned blk, int16_t *dst, size_t cap,
 }
 
 int kq_bank_set_output_ssrc(kq_bank *b, int ch, uint32_t ssrc) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch)) {
     set_err("bad channel");
     return -1;
@@ -1384,12 +1405,14 @@ int kq_bank_set_output_ssrc(kq_bank *b, int ch, uint32_t ssrc) {
 }
 
 int kq_bank_output_rtp_state(const kq_bank *b, int ch, kq_out_rtp_state *out) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!out || !valid_ch(b, ch)) return -1;
   *out = b->chans[ch].out_rtp;
   return 0;
 }
 
 int kq_bank_pull_rtp_audio(kq_bank *b, int ch, unsigned blk, unsigned char *dst, size_t cap, size_t *used) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || !dst) {
     set_err("bad channel or NULL buffer");
     return -1;
@@ -1446,6 +1469,7 @@ int kq_bank_pull_rtp_audio(kq_bank *b, int ch, unsigned blk, unsigned char *dst,
 }
 
 int kq_bank_pull_filter_output(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || !dst || blk >= b->last_blocks || cap < (size_t)b->g.olen) {
     set_err("bad channel/block/capacity");
     return -1;
@@ -1457,6 +1481,7 @@ int kq_bank_pull_filter_output(kq_bank *b, int ch, unsigned blk, float *dst, siz
 }
 
 int kq_bank_pull_spectrum(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || !dst || cap < (size_t)b->g.N) {
     set_err("bad channel/capacity");
     return -1;
@@ -1483,6 +1508,7 @@ int kq_bank_pull_spectrum(kq_bank *b, int ch, unsigned blk, float *dst, size_t c
 }
 
 int kq_bank_get_response(kq_bank *b, int ch, float *dst, size_t cap) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || !dst || cap < (size_t)b->g.Ndec) {
     set_err("bad channel/capacity");
     return -1;
@@ -1492,6 +1518,7 @@ int kq_bank_get_response(kq_bank *b, int ch, float *dst, size_t cap) {
 }
 
 int kq_bank_get_audio_response(kq_bank *b, int ch, float *dst, size_t cap) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || !dst) {
     set_err("bad channel");
     return -1;
@@ -1509,6 +1536,7 @@ void *kq_bank_audio_device_ptr(kq_bank *b) { return b ? b->pl.audio : nullptr; }
 void *kq_bank_status_device_ptr(kq_bank *b) { return b ? b->pl.status : nullptr; }
 
 int kq_bank_enable_timing(kq_bank *b, int on) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return -1;
   if (!on && b->timing) drain_timing(b);
   b->timing = on;  // 0 off, 1 filter kernel only, >= 2 every scope
@@ -1516,6 +1544,7 @@ int kq_bank_enable_timing(kq_bank *b, int on) {
 }
 
 int kq_bank_get_timing(kq_bank *b, kq_timing *t, int reset) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || !t) return -1;
   if (drain_timing(b)) return -1;
   *t = b->acc;

@@ -499,6 +499,7 @@ kq_decimator *kq_decim_create(const kq_decim_config *cfg) {
 }
 
 int kq_decim_destroy(kq_decimator *d) {
+  kq::DeviceScope dev_scope_(d ? d->cfg.device : -1);
   if (!d) return -1;
   if (d->stream) (void)hipStreamSynchronize(d->stream);
   for (Group &g : d->groups) {
@@ -516,6 +517,7 @@ int kq_decim_destroy(kq_decimator *d) {
 }
 
 int kq_decim_set_coeffs(kq_decimator *d, const float coeffs[4]) {
+  kq::DeviceScope dev_scope_(d ? d->cfg.device : -1);
   if (!d || !coeffs) return -1;
   for (int i = 0; i < 4; i++) d->coeffs[i] = coeffs[i];
   return 0;
@@ -523,6 +525,7 @@ int kq_decim_set_coeffs(kq_decimator *d, const float coeffs[4]) {
 
 int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t n_out, float *out_cf32,
                      int16_t *out_s16, float *out_energy) {
+  kq::DeviceScope dev_scope_(d ? d->cfg.device : -1);
   if (!d || !iq_in || !out_cf32) {
     kq_internal_set_error("kq_decim_process: null argument");
     return -1;
@@ -602,12 +605,14 @@ int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t 
 }
 
 int kq_decim_sync(kq_decimator *d) {
+  kq::DeviceScope dev_scope_(d ? d->cfg.device : -1);
   if (!d) return -1;
   DEC_TRY(hipStreamSynchronize(d->stream));
   return 0;
 }
 
 int kq_decim_reset(kq_decimator *d) {
+  kq::DeviceScope dev_scope_(d ? d->cfg.device : -1);
   if (!d) return -1;
   for (Group &g : d->groups)
     DEC_TRY(hipMemsetAsync(g.hist, 0, sizeof(float2) * g.halo, d->stream));

@@ -84,6 +84,26 @@ struct Planes {
   float *plout;         // [C][max_blocks][PL_L] PL filter outputs of the call (null when PL is off)
 };
 
+// Every entry point that takes a handle runs on the handle's device whatever the calling thread's current device is,
+// and leaves the thread's device as it found it.
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceScope(int device) {
+    if (device < 0) return;
+    if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope &) = delete;
+  DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
+// Raises the kernel's dynamic-LDS limit on the current device when `bytes` exceeds what was set before (the limit is
+// kept per kernel and device: a process may drive banks on several devices).
+void ensure_dynamic_lds(const void *kernel, size_t bytes);
+
 // launchers (kq_kernels.hip)
 void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size_t nsamples, float scale);
 void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nblocks, const unsigned char *update,

@@ -387,11 +387,7 @@ void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
                            const int *chan_list) {
   size_t const lds_bytes = (size_t)kXchElems * sizeof(float2);
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute((const void *)k_filter_full16k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    configured = true;
-  }
+  ensure_dynamic_lds((const void *)k_filter_full16k, (size_t)(lds_bytes));
   const float2 *tab = twiddle_tables();
   if (!tab) {  // cannot happen short of an allocation failure: fall back to the LDS kernel rather than fail the block
     launch_filter_full(s, g, ch, pl, window, tw, nchan, nblocks, compute_n0, spec_dump, spec_ch, chan_list);

@@ -9,11 +9,27 @@
 //
 // The pruned forward path lives in kq_pruned.hip.
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "kq_device.hpp"
 #include "kq_ldsfft.hpp"
 
 namespace kq {
+
+void ensure_dynamic_lds(const void *kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, size_t> limit;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(mu);
+  size_t &cur = limit[{kernel, dev}];
+  if (bytes > cur) {
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    cur = bytes;
+  }
+}
 
 // ---------------------------------------------------------------- ingest
 __global__ void k_ingest(const void *__restrict__ src, int format, float2 *__restrict__ dst, size_t n, float gain) {
@@ -178,11 +194,7 @@ void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const P
                         const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
                         const int *chan_list) {
   size_t const lds_bytes = (size_t)g.N * sizeof(float2);
-  static size_t configured = 0;
-  if (lds_bytes > configured) {
-    (void)hipFuncSetAttribute((const void *)k_filter_full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    configured = lds_bytes;
-  }
+  ensure_dynamic_lds((const void *)k_filter_full, lds_bytes);
   int const threads = g.N >= 4096 ? 1024 : 256;
   hipLaunchKernelGGL(k_filter_full, dim3(nchan, nblocks), dim3(threads), lds_bytes, s, g, ch, pl, window, tw, compute_n0,
                      spec_dump, spec_ch, chan_list);
@@ -260,11 +272,7 @@ void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const 
   int const log2N1 = 14;
   int const S = g.N >> log2N1;
   size_t const lds_bytes = ((size_t)(1 << log2N1) + g.Ndec) * sizeof(float2);
-  static size_t configured = 0;
-  if (lds_bytes > configured) {
-    (void)hipFuncSetAttribute((const void *)k_filter_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    configured = lds_bytes;
-  }
+  ensure_dynamic_lds((const void *)k_filter_split, lds_bytes);
   hipLaunchKernelGGL(k_filter_split, dim3(nchan, nblocks), dim3(1024), lds_bytes, s, g, ch, pl, window, tw, S, log2N1,
                      chan_list);
 }
@@ -844,11 +852,7 @@ __global__ void __launch_bounds__(1024) k_pl_track(Geom g, ChanDev ch, Planes pl
 void launch_pl_track(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_fm,
                      int n_fm, int nblocks) {
   if (n_fm <= 0 || g.pl_n <= 0) return;
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute((const void *)k_pl_track, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 8);
-    configured = true;
-  }
+  ensure_dynamic_lds((const void *)k_pl_track, (size_t)(16384 * 8));
   hipLaunchKernelGGL(k_pl_track, dim3(n_fm), dim3(1024), 16384 * 8, s, g, ch, pl, tw, list_fm, nblocks);
 }
 
@@ -871,15 +875,8 @@ void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes
   if (n_fm > 0) {
     int const waves = fm_disc_waves(g, nblocks);
     size_t const lds_a = fm_disc_lds_bytes(g, waves), lds_b = fm_audio_lds_bytes(g);
-    static size_t conf_a = 0, conf_b = 0;
-    if (lds_a > conf_a) {
-      (void)hipFuncSetAttribute((const void *)k_demod_fm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-      conf_a = lds_a;
-    }
-    if (lds_b > conf_b) {
-      (void)hipFuncSetAttribute((const void *)k_fm_audio, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-      conf_b = lds_b;
-    }
+    ensure_dynamic_lds((const void *)k_demod_fm, lds_a);
+    ensure_dynamic_lds((const void *)k_fm_audio, lds_b);
     hipLaunchKernelGGL(k_demod_fm, dim3(n_fm), dim3(64 * waves), lds_a, s, g, ch, pl, fmout, list_fm, nblocks, compute_n0);
     hipLaunchKernelGGL(k_fm_audio, dim3(n_fm, nblocks), dim3(64), lds_b, s, g, ch, pl, tw, fmout, fm_hist_in, fm_hist_out,
                        list_fm, nblocks);
@@ -943,11 +940,7 @@ __global__ void k_fft_single(const float2 *__restrict__ in, float2 *__restrict__
 
 void launch_fft_single(hipStream_t s, const float2 *in, float2 *out, int log2n, int sign, const float2 *tw, int tw_log2) {
   size_t const lds_bytes = sizeof(float2) << log2n;
-  static size_t configured = 0;
-  if (lds_bytes > configured) {
-    (void)hipFuncSetAttribute((const void *)k_fft_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    configured = lds_bytes;
-  }
+  ensure_dynamic_lds((const void *)k_fft_single, lds_bytes);
   int const threads = (1 << log2n) >= 4096 ? 1024 : 256;
   hipLaunchKernelGGL(k_fft_single, dim3(1), dim3(threads), lds_bytes, s, in, out, log2n, sign, tw, tw_log2);
 }
@@ -997,11 +990,7 @@ void launch_slave_single(hipStream_t s, const float2 *fdomain, const float2 *res
   int log2Ndec = 0;
   while ((1 << log2Ndec) < Ndec) log2Ndec++;
   size_t const lds_bytes = sizeof(float2) * (size_t)Ndec;
-  static size_t configured = 0;
-  if (lds_bytes > configured) {
-    (void)hipFuncSetAttribute((const void *)k_slave_single, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    configured = lds_bytes;
-  }
+  ensure_dynamic_lds((const void *)k_slave_single, lds_bytes);
   int const threads = Ndec >= 4096 ? 1024 : 256;
   hipLaunchKernelGGL(k_slave_single, dim3(1), dim3(threads), lds_bytes, s, fdomain, resp, out, N, Ndec, log2Ndec, in_real,
                      out_type, tw, tw_log2);

@@ -318,11 +318,7 @@ void launch_demod_pll(hipStream_t s, const Geom &g, const ChanDev &ch, const Pla
                       int n_pll, PllState *state, float2 *rings, float2 *side, int nblocks, int compute_n0) {
   if (n_pll <= 0) return;
   size_t const lds_bytes = ((size_t)16384 + g.olen) * sizeof(float2);
-  static size_t configured = 0;
-  if (lds_bytes > configured) {
-    (void)hipFuncSetAttribute((const void *)k_demod_linear_pll, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    configured = lds_bytes;
-  }
+  ensure_dynamic_lds((const void *)k_demod_linear_pll, lds_bytes);
   hipLaunchKernelGGL(k_demod_linear_pll, dim3(n_pll), dim3(1024), lds_bytes, s, g, ch, pl, tw, list_pll, state, rings, side,
                      nblocks, compute_n0);
 }

@@ -766,12 +766,7 @@ void launch_resident(hipStream_t s, const Geom &g, const ChanDev &ch, const Plan
                      int nchan, int nblocks) {
   constexpr int NWAVES = 8, CPW = 4;
   size_t const lds_bytes = (size_t)64 * R * sizeof(float2) + (size_t)NWAVES * Tab<64>::kWaveF4 * sizeof(float4);
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute((const void *)k_pruned_resident<NWAVES, CPW, R, SWEPT>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    configured = true;
-  }
+  ensure_dynamic_lds((const void *)k_pruned_resident<NWAVES, CPW, R, SWEPT>, (size_t)(lds_bytes));
   int const per_wg = NWAVES * CPW;
   hipLaunchKernelGGL((k_pruned_resident<NWAVES, CPW, R, SWEPT>), dim3((nchan + per_wg - 1) / per_wg, nblocks),
                      dim3(NWAVES * 64), lds_bytes, s, g, ch, pl, window, tab, nchan);
@@ -781,12 +776,7 @@ void launch_resident256(hipStream_t s, const Geom &g, const ChanDev &ch, const P
                         const float *tab, int nchan, int nblocks) {
   constexpr int NWAVES = 8, CPW = 4;
   size_t const lds_bytes = (size_t)16384 * sizeof(float2) + (size_t)NWAVES * 256 * sizeof(float2);
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute((const void *)k_pruned_resident256<NWAVES, CPW>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    configured = true;
-  }
+  ensure_dynamic_lds((const void *)k_pruned_resident256<NWAVES, CPW>, (size_t)(lds_bytes));
   int const per_wg = NWAVES * CPW;
   hipLaunchKernelGGL((k_pruned_resident256<NWAVES, CPW>), dim3((nchan + per_wg - 1) / per_wg, nblocks),
                      dim3(NWAVES * 64), lds_bytes, s, g, ch, pl, window, tab, nchan);
@@ -798,12 +788,7 @@ void launch_stream(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes
   constexpr int NWAVES = 8, R = 512;
   size_t const lds_bytes = (size_t)2 * 128 * 64 * sizeof(float2) + (size_t)NWAVES * (Tab<128>::kWaveF4 + 64) * sizeof(float4) +
                            128 * sizeof(float2);
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute((const void *)k_pruned_stream<NWAVES, R, SWEPT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_bytes);
-    configured = true;
-  }
+  ensure_dynamic_lds((const void *)k_pruned_stream<NWAVES, R, SWEPT>, (size_t)(lds_bytes));
   hipLaunchKernelGGL((k_pruned_stream<NWAVES, R, SWEPT>), dim3((nchan + NWAVES - 1) / NWAVES, nblocks), dim3(NWAVES * 64),
                      lds_bytes, s, g, ch, pl, window, tab, nchan);
 }

@@ -436,6 +436,22 @@ def test_random_channel_plans(gpu, seed, mode):
     _compare(plan, got, want, check_n0=(mode == "full"))
 
 
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_random_channel_plans_generic_demodulators(gpu, seed):
+    """The same randomised plans at the cfg 2 geometry (N/D = 256, 128 samples per block), where the block-parallel
+    FM demodulator, its audio / PL kernels and the LDS AM / linear demodulators run instead of the wave-per-channel
+    ones; ten blocks in calls of four."""
+    g = wl.GEOMETRY["cfg2"]
+    rng = np.random.default_rng(2000 + seed)
+    plan = _random_plan(rng, g["samprate"], 18)
+    nblocks = 10
+    iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=200 + seed)
+    want = run_oracle(plan, g, iq, nblocks, compute_n0=1)
+    got, used = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_AUTO, compute_n0=True, per_call=4)
+    assert used == kq.KQ_FWD_FULL
+    _compare(plan, got, want, check_n0=True)
+
+
 def test_long_run_phase_continuity(gpu):
     """2.5 million input samples (300 blocks over five process calls, more than 150 renormalisation periods of the
     reference's NCO recurrence): the closed-form oscillators of the bank must not drift away from the oracle's

@@ -352,8 +352,17 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
     float g_mine = gain;
     float gain_end[2] = {gain, gain};
     int hang_end[2] = {hang, hang};
+    // While the hang counter outlasts the group and no sample attacks, the gain does not move (am.c:67-70,
+    // linear.c:273-275): the 64 comparisons are made at once and the counter drops by the group length.  This is
+    // the usual state of an SSB channel (hang time 1.1 s).
+    bool const held = !isnan(gain) && hang >= nsamp &&
+                      __ballot(lane < nsamp && (LINEAR ? level * gain > headroom : gain * level > headroom)) == 0ull;
+    if (held) {
+      hang_end[0] = hang - OLEN;
+      hang -= nsamp;
+    }
 #pragma unroll 32
-    for (int i = 0; i < nsamp; i++) {
+    for (int i = 0; i < (held ? 0 : nsamp); i++) {
       float const lv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, level), i));
       float const iv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), i));
       bool const nan_gain = isnan(gain);

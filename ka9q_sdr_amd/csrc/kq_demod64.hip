@@ -361,8 +361,23 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
       hang_end[0] = hang - OLEN;
       hang -= nsamp;
     }
+    // No hang time (the AM entry of modes.txt) and no NaN in sight: the counter stays at zero and the NaN test of
+    // the gain cannot fire (the gain is either an attack value of this group or a product with the recovery
+    // factor), which leaves multiply / compare / select per sample.
+    bool const plain = !held && hangmax == 0 && hang == 0 && !isnan(gain) && __ballot(lane < nsamp && isnan(inv)) == 0ull;
+    if (plain) {
 #pragma unroll 32
-    for (int i = 0; i < (held ? 0 : nsamp); i++) {
+      for (int i = 0; i < nsamp; i++) {
+        float const lv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, level), i));
+        float const iv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), i));
+        bool const attack = LINEAR ? lv * gain > headroom : gain * lv > headroom;
+        gain = attack ? iv : gain * recovery;
+        g_mine = (lane == i) ? gain : g_mine;
+        if (i == OLEN - 1) gain_end[0] = gain;
+      }
+    }
+#pragma unroll 32
+    for (int i = 0; i < ((held || plain) ? 0 : nsamp); i++) {
       float const lv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, level), i));
       float const iv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), i));
       bool const nan_gain = isnan(gain);

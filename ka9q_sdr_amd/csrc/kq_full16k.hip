@@ -237,6 +237,9 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
       pb[k3] = ((incl_b >> k3) & 1) ? pb[k3] : INFINITY;
     }
     float avg = INFINITY;
+    // Both passes run the same loop body.  (Left to itself the compiler peels the first one and, with thr = inf known,
+    // counts bins with `p != inf` -- which a NaN bin would pass -- while still summing with an ordered compare.)
+    asm volatile("" : "+v"(avg));
     for (int iter = 0; iter < 2; iter++) {
       float acc = 0;
       int wave_bins = 0;  // counted on the scalar unit from the comparison masks

@@ -209,16 +209,17 @@ def test_fm_hand_overs_across_many_blocks(gpu, per_call):
     assert seen_closed > 20 and seen_blanked > 20           # the case exercises what it is meant to
 
 
-@pytest.mark.parametrize("D", [16, 4])
-def test_nan_sample_propagates_like_the_reference(gpu, D):
+@pytest.mark.parametrize("L,D,pruned", [(512, 16, 0), (512, 4, 0), (8192, 256, 0), (8192, 256, 1)])
+def test_nan_sample_propagates_like_the_reference(gpu, L, D, pruned):
     """One NaN sample in the input: every comparison in the chain that the reference makes with a NaN operand (squelch
     `snr > 2`, blanking threshold, AGC `isnan(gain)` and `gain*level > headroom`, compute_n0's `< 2*mean`, the AM
     carrier filter that never recovers) has to fall the same way.  Outputs must be NaN in the same places, equal
-    where finite, and the integer state identical; D = 16 runs the wave-per-channel demodulators, D = 4 the generic ones."""
-    g = dict(samprate=192000, L=512, M=513, D=D)
-    fs, L = g["samprate"], g["L"]
+    where finite, and the integer state identical.  N = 1024 with D = 16 runs the wave-per-channel demodulators, D = 4 the
+    generic ones; N = 16384 the register-resident full-spectrum kernel and the pruned kernel."""
+    g = dict(samprate=192000 if L == 512 else 10000000, L=L, M=L + 1, D=D)
+    fs = g["samprate"]
     nb = 9
-    iq = wl.make_iq(fs, nb * L, seed=17, emitters=range(24, 40)).copy()
+    iq = wl.make_iq(fs, nb * L, seed=17, emitters=range(24, 40) if L == 512 else None).copy()
     iq[3 * L + 100] = np.nan + 0j
     plan = []
     for e, kind in ((28, "fm"), (29, "fm"), (30, "am"), (31, "ssb"), (35, "ssb")):
@@ -227,8 +228,9 @@ def test_nan_sample_propagates_like_the_reference(gpu, D):
         plan.append(p)
     plan[1]["flat"] = 1
     plan[4].update(hangtime=0.0)
-    want = run_oracle(plan, g, iq, nb, compute_n0=1)
-    bank = kq.Bank(fs, L, g["M"], D, len(plan), 4, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL)
+    want = run_oracle(plan, g, iq, nb, compute_n0=int(not pruned))
+    bank = kq.Bank(fs, L, g["M"], D, len(plan), 4, compute_n0=not pruned,
+                   fwd_mode=kq.KQ_FWD_PRUNED if pruned else kq.KQ_FWD_FULL)
     for p in plan:
         bank.add_channel(bank_cfg(p))
     got = [[] for _ in plan]

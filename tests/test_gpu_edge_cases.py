@@ -157,14 +157,15 @@ def test_handles_release_their_device_memory(gpu):
     assert before - after < 8 << 20, (before, after)
 
 
-@pytest.mark.parametrize("per_call", [150, 64, 7])
-def test_fm_hand_overs_across_many_blocks(gpu, per_call):
+@pytest.mark.parametrize("per_call,D", [(150, 4), (64, 4), (7, 4), (150, 16), (7, 16)])
+def test_fm_hand_overs_across_many_blocks(gpu, per_call, D):
     """The generic FM demodulator takes 64 blocks of a channel at a time and resolves what each block inherits from
     the ones before it (squelch counter, last strong sample, last audio value, offset / deviation readings) by a
     scan.  A signal that comes and goes, fades below the blanking threshold, and a stretch of exact zeros (an open
     block without a single strong sample, then a squelched one) against the oracle's sequential loop; 150 blocks in
-    one call span three chunks, 7 per call leave every chunk ragged."""
-    g = dict(samprate=192000, L=512, M=513, D=4)            # N/D = 256, 128 samples per block
+    one call span three chunks, 7 per call leave every chunk ragged.  D = 16 (N/D = 64) runs the same signal through
+    the wave-per-channel demodulator, which pairs blocks instead."""
+    g = dict(samprate=192000, L=512, M=513, D=D)            # D = 4: N/D = 256, 128 samples per block
     fs, L = g["samprate"], g["L"]
     nb = 150
     n = nb * L
@@ -177,8 +178,9 @@ def test_fm_hand_overs_across_many_blocks(gpu, per_call):
     iq = sig + 1e-3 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
     iq[(blk >= 90) & (blk < 100)] = 0                        # digital silence
     iq = iq.astype(np.complex64)
-    plan = [dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-30000.0 - 13.0),
-            dict(demod="fm", low=-6000.0, high=9000.0, second_lo=-30000.0 + 7.0, flat=1)]
+    w = 8000.0 if D == 4 else 4500.0
+    plan = [dict(demod="fm", low=-w, high=w, second_lo=-30000.0 - 13.0),
+            dict(demod="fm", low=-0.75 * w, high=w, second_lo=-30000.0 + 7.0, flat=1)]
     want = run_oracle(plan, g, iq, nb, compute_n0=1)
     bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), per_call, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL)
     for p in plan:

@@ -382,11 +382,12 @@ struct Scope {
 
 // Per-call parameters: oscillator phase/step/sweep for a call whose first window starts at absolute
 // sample n_w, the shift oscillator at the first output sample, and the IF-power update flags.
-int upload_call_params(kq_bank *b, double *osc_dst, int64_t n_w, const unsigned char *update, unsigned nblocks) {
+// Filled into the next pinned staging slot (returned in *slot_out); the first kernel of the call copies it to the device.
+int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsigned nblocks, int *slot_out) {
   size_t const C = b->chans.size(), Cmax = b->cfg.max_channels;
   int const slot = b->stage_next;
   b->stage_next = (slot + 1) % kq_bank::kSlots;
-  HIP_TRY(hipEventSynchronize(b->stage_ev[slot]));  // the copy that last used this slot has completed
+  HIP_TRY(hipEventSynchronize(b->stage_ev[slot]));  // the kernel that last read this slot has completed
   double *pl = reinterpret_cast<double *>(b->stage_host[slot]);
   double *ph = pl, *fr = pl + Cmax, *rt = pl + 2 * Cmax, *sp = pl + 3 * Cmax, *sf = pl + 4 * Cmax;
   double *hph = pl + 5 * Cmax, *hfr = pl + 6 * Cmax, *hrt = pl + 7 * Cmax;
@@ -422,9 +423,8 @@ int upload_call_params(kq_bank *b, double *osc_dst, int64_t n_w, const unsigned 
   }
   unsigned char *flags = b->stage_host[slot] + 8 * Cmax * sizeof(double);
   memcpy(flags, update, nblocks);
-  // one copy: the per-block flags sit right behind the eight oscillator planes, in the staging slot and on the device
-  HIP_TRY(hipMemcpyAsync(osc_dst, b->stage_host[slot], 8 * Cmax * sizeof(double) + nblocks, hipMemcpyHostToDevice, b->stream));
-  HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
+  // the per-block flags sit right behind the eight oscillator planes, in the staging slot and on the device
+  *slot_out = slot;
   return 0;
 }
 
@@ -494,12 +494,15 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   chd.hist_rate = chd.lo_phase + 7 * Cmax;
   // this parity's hand-over planes were last read by the demodulators two calls ago
   if (b->stream2 != b->stream) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[pp], 0));
-  if (upload_call_params(b, b->osc_dev2[pp], b->n_abs - (g.M - 1), update_host, nblocks)) return -1;
+  int slot = 0;
+  if (stage_call_params(b, b->n_abs - (g.M - 1), update_host, nblocks, &slot)) return -1;
   {
     Scope t(b, 2, b->stream);
     kq::launch_block_energy(b->stream, window + (g.M - 1), g.L, (int)nblocks,
-                            reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power);
+                            reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power,
+                            b->stage_host[slot], b->osc_dev2[pp], 8 * Cmax * sizeof(double) + nblocks);
   }
+  HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
   LAUNCH_CHECK("IF power");
   {
     Scope t(b, 0, b->stream);
@@ -734,7 +737,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     set_err("second stream / event creation failed");
     rc = -1;
   }
-  b->stage_bytes = 8 * C * sizeof(double) + B;
+  b->stage_bytes = 8 * C * sizeof(double) + ((B + 7) & ~(size_t)7);  // copied in 8-byte words
   for (int k = 0; k < kq_bank::kSlots && !rc; k++) {
     if (hipHostMalloc((void **)&b->stage_host[k], b->stage_bytes, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&b->stage_ev[k], hipEventDisableTiming) != hipSuccess) {

@@ -106,8 +106,11 @@ void ensure_dynamic_lds(const void *kernel, size_t bytes);
 
 // launchers (kq_kernels.hip)
 void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size_t nsamples, float scale);
+// `update` points into the device copy of the parameter block that the first kernel makes from `params_host`
+// (pinned, device-visible) into `params_dev`
 void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nblocks, const unsigned char *update,
-                         float *energy_state, float *if_power);
+                         float *energy_state, float *if_power, const void *params_host, void *params_dev,
+                         size_t params_bytes);
 void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                         const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
                         const int *chan_list);

@@ -59,8 +59,18 @@ void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size
   hipLaunchKernelGGL(k_ingest, dim3((unsigned)blocks), dim3(threads), 0, s, src, format, dst, nsamples, gain);
 }
 
-// Sum |s|^2 over the L new samples of each block (radio.c:123)
-__global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *__restrict__ sums) {
+// Sum |s|^2 over the L new samples of each block (radio.c:123).  The workgroups behind the nblocks summing ones carry
+// the call's parameter block (oscillator planes + update flags) from the pinned host staging slot into device
+// memory, 8 bytes per thread straight over the bus: a hipMemcpyAsync in front of this kernel cost ~25 us of idle
+// stream per call (copy-engine start-up), this costs nothing.
+__global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *__restrict__ sums, int nblocks,
+                                   const unsigned long long *__restrict__ params_host,
+                                   unsigned long long *__restrict__ params_dev, unsigned nwords) {
+  if ((int)blockIdx.x >= nblocks) {
+    unsigned const i = (blockIdx.x - nblocks) * blockDim.x + threadIdx.x;
+    if (i < nwords) params_dev[i] = params_host[i];
+    return;
+  }
   __shared__ float red_f[16];
   __shared__ int red_i[16];
   const float2 *p = x + (size_t)blockIdx.x * L;
@@ -102,9 +112,14 @@ __global__ void k_block_energy_iir(const float *sums, const unsigned char *__res
 }
 
 void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nblocks, const unsigned char *update,
-                         float *energy_state, float *if_power) {
+                         float *energy_state, float *if_power, const void *params_host, void *params_dev,
+                         size_t params_bytes) {
   // if_power doubles as scratch for the per-block sums: the IIR pass reads sums[b] before writing if_power[b]
-  hipLaunchKernelGGL(k_block_energy_sum, dim3(nblocks), dim3(1024), 0, s, newsamples, L, if_power);
+  unsigned const nwords = (unsigned)((params_bytes + 7) / 8);
+  int const copy_wgs = (int)((nwords + 1023) / 1024);
+  hipLaunchKernelGGL(k_block_energy_sum, dim3(nblocks + copy_wgs), dim3(1024), 0, s, newsamples, L, if_power, nblocks,
+                     static_cast<const unsigned long long *>(params_host), static_cast<unsigned long long *>(params_dev),
+                     nwords);
   hipLaunchKernelGGL(k_block_energy_iir, dim3(1), dim3(64), 0, s, if_power, update, nblocks, L, energy_state, if_power);
 }
 

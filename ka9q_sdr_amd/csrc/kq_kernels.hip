@@ -95,9 +95,9 @@ __global__ void k_block_energy_iir(const float *sums, const unsigned char *__res
     int const up = i < nblocks ? update[i] : 0;
     float mine = 0.f;
     int const cnt = min(64, nblocks - base);
-    for (int k = 0; k < cnt; k++) {
-      e += __shfl(sm, k, 64);
-      if (__shfl(up, k, 64)) {
+    for (int k = 0; k < cnt; k++) {  // k is wave-uniform: v_readlane, not a trip through the LDS crossbar
+      e += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), k));
+      if (__builtin_amdgcn_readlane(up, k)) {
         e *= 0.5f;
         last = e / L;
       }

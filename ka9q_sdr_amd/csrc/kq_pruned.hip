@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "kq_device.hpp"
+#include "kq_lane.hpp"
 #include "kq_regfft.hpp"
 
 namespace kq {
@@ -486,6 +487,13 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident(Geom g, ChanDev
     float4 *dst = reinterpret_cast<float4 *>(lds);
     for (int i = threadIdx.x; i < N / 2; i += NWAVES * 64) dst[i] = src[i];
   }
+  // twiddles of the 64-point inverse transform, exp(+j pi k / 32): behind the wave slots
+  float2 *itw = lds + N + NWAVES * Tab<ND>::kWaveF4 * 2;
+  if (threadIdx.x < 32) {
+    float sw, cw;
+    sincospif((float)threadIdx.x / 32.f, &sw, &cw);
+    itw[threadIdx.x] = make_float2(cw, sw);
+  }
   __syncthreads();
   int const wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float4 *wtab = reinterpret_cast<float4 *>(lds + N) + wave * Tab<ND>::kWaveF4;
@@ -504,7 +512,7 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident(Geom g, ChanDev
     const float4 *wT = wtab + Tab<ND>::kA / 4;
     float const kap_lane = SWEPT ? (float)(2.0 * kPi * r * (double)R) : 0.f;  // times b = 64 j + lane below
 
-    float2 ypass[2];
+    float2 y_even = make_float2(0.f, 0.f), y_odd = make_float2(0.f, 0.f);  // two named values: an array here ends up in scratch
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
       float2 acc[32];
@@ -524,11 +532,14 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident(Geom g, ChanDev
           horner(acc, v, wT + pass * 16);
         }
       }
-      ypass[pass] = (pass == 0) ? lane_reduce<ND, 0, SWEPT>(acc, tL, th, lane) : lane_reduce<ND, 1, SWEPT>(acc, tL, th, lane);
+      if (pass == 0)
+        y_even = lane_reduce<ND, 0, SWEPT>(acc, tL, th, lane);
+      else
+        y_odd = lane_reduce<ND, 1, SWEPT>(acc, tL, th, lane);
     }
     // lane holds bin 2*rev5(lane>>1) + pass for both passes; keep pass = lane bit 0, then move bin bitrev6(lane)
     // into each lane for the decimation-in-time inverse transform
-    float2 y = b0 ? ypass[1] : ypass[0];
+    float2 y = make_float2(b0 ? y_odd.x : y_even.x, b0 ? y_odd.y : y_even.y);
     int const q = (int)(__brev((unsigned)lane) >> 26);
     {
       int const src = (int)((__brev((unsigned)(q >> 1)) >> 27) << 1) | (q & 1);
@@ -553,18 +564,28 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident(Geom g, ChanDev
       }
     }
     // ---- 64-point inverse FFT across lanes: decimation in time on bit-reversed input
-#pragma unroll
-    for (int s = 0; s < 6; s++) {
-      int const half = 1 << s;
-      int const bit = (lane >> s) & 1;
-      float sw, cw;
-      sincospif((float)(lane & (half - 1)) / (float)half, &sw, &cw);
-      float2 const v = bit ? cmul(y, make_float2(cw, sw)) : y;
+    // twiddle exp(+j pi (lane & (half - 1)) / half) from the staged table (the same sincospif values); partners by DPP
+    // / permlane exchanges instead of the LDS crossbar
+    auto stage = [&](auto hc) {
+      constexpr int half = decltype(hc)::value;
+      constexpr int sh = (half == 1) ? 5 : (half == 2) ? 4 : (half == 4) ? 3 : (half == 8) ? 2 : (half == 16) ? 1 : 0;
+      bool const bit = (lane & half) != 0;
+      float2 v = y;
+      if (half > 1) {
+        float2 const w = itw[(lane & (half - 1)) << sh];
+        v = bit ? cmul(y, w) : y;
+      }
       float2 rr;
-      rr.x = __shfl_xor(v.x, half, 64);
-      rr.y = __shfl_xor(v.y, half, 64);
+      rr.x = lane_xor<half>(v.x, lane);
+      rr.y = lane_xor<half>(v.y, lane);
       y = bit ? csub(rr, v) : cadd(v, rr);
-    }
+    };
+    stage(std::integral_constant<int, 1>{});
+    stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 4>{});
+    stage(std::integral_constant<int, 8>{});
+    stage(std::integral_constant<int, 16>{});
+    stage(std::integral_constant<int, 32>{});
     int const first = 64 - g.olen;  // the last olen samples are the output (filter.c:131)
     if (lane >= first) pl.filt[((size_t)c * g.max_blocks + blk) * g.olen + (lane - first)] = y;
   }
@@ -765,7 +786,8 @@ template <int R, bool SWEPT>
 void launch_resident(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window, const float *tab,
                      int nchan, int nblocks) {
   constexpr int NWAVES = 8, CPW = 4;
-  size_t const lds_bytes = (size_t)64 * R * sizeof(float2) + (size_t)NWAVES * Tab<64>::kWaveF4 * sizeof(float4);
+  size_t const lds_bytes = (size_t)64 * R * sizeof(float2) + (size_t)NWAVES * Tab<64>::kWaveF4 * sizeof(float4) +
+                           32 * sizeof(float2);  // window, wave slots, inverse-transform twiddles
   ensure_dynamic_lds((const void *)k_pruned_resident<NWAVES, CPW, R, SWEPT>, (size_t)(lds_bytes));
   int const per_wg = NWAVES * CPW;
   hipLaunchKernelGGL((k_pruned_resident<NWAVES, CPW, R, SWEPT>), dim3((nchan + per_wg - 1) / per_wg, nblocks),

@@ -247,6 +247,7 @@ def main():
         }
         if n0_row:
             n0_row["roofline_frac_of_step"] = round(abytes / (n0_row["ms_per_step"] * 1e-3) / 8e12, 4)
+            n0_row["traffic"], n0_row["traffic_source"] = pmc_traffic(a.config, C, B, "full")
             out["with_compute_n0"] = n0_row
         if not a.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(a.config, geom, plan, iq_host[M - 1:], a.cpu_seconds)

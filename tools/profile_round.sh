@@ -25,6 +25,13 @@ done
 F=$(find $OUT/raw_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 W=$(find $OUT/raw_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python3 $R/tools/pmc_summary.py $F $W $OUT/pmc_pruned_cfg4.json k_pruned cfg4 1024 64 pruned > /dev/null
+# the same two passes for the full-spectrum kernel with compute_n0 (the bench's second row)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $OUT/raw_pmcn0_$c -o pmcn0_$c --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --n0 1 --no-cpu-baseline > $OUT/pmcn0_$c.log 2>&1
+done
+F=$(find $OUT/raw_pmcn0_FETCH_SIZE -name "*counter_collection.csv" | head -1)
+W=$(find $OUT/raw_pmcn0_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python3 $R/tools/pmc_summary.py $F $W $OUT/pmc_full16k_n0_cfg4.json k_filter_full16k cfg4 1024 64 full > /dev/null
 rm -rf $OUT/raw_*
 ls -la $OUT
 for f in $OUT/*_bench.json; do echo "== $f"; tail -1 $f | cut -c1-600; done

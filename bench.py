@@ -243,6 +243,9 @@ def main():
                 "kernel": "pre-detection filter (mix + forward FFT + response + IFFT)",
                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": abytes,
                 "demod_ms": round(tm2["demod_ms"] / max(1, tm2["filter_launches"]), 4),
+                "note": "algorithmic bytes count the N-sample window once per channel (SURVEY 8d); all channels share one "
+                        "input, served from L2 / LDS, so HBM traffic is far below them and frac can exceed 1. The kernel's "
+                        "own limiter is vector-ALU issue (profiles/r01/pmc_sq_*.json).",
             },
         }
         if n0_row:

@@ -154,7 +154,6 @@ struct kq_bank {
   kq::ChanDev chd;
   kq::Planes pl;
   int *list_dev[3] = {nullptr, nullptr, nullptr};  // fm, am, linear (without PLL)
-  int *retune_list = nullptr;
   // carrier-tracking linear channels (linear.c:129-246): own list, 65536-sample search ring per channel
   static constexpr int kMaxPll = 64;
   int *list_pll_dev = nullptr;
@@ -383,7 +382,7 @@ struct Scope {
 // Per-call parameters: oscillator phase/step/sweep for a call whose first window starts at absolute
 // sample n_w, the shift oscillator at the first output sample, and the IF-power update flags.
 // Filled into the next pinned staging slot (returned in *slot_out); the first kernel of the call copies it to the device.
-int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsigned nblocks, int *slot_out) {
+int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsigned nblocks, int *slot_out, int *nret_out) {
   size_t const C = b->chans.size(), Cmax = b->cfg.max_channels;
   int const slot = b->stage_next;
   b->stage_next = (slot + 1) % kq_bank::kSlots;
@@ -423,7 +422,13 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
   }
   unsigned char *flags = b->stage_host[slot] + 8 * Cmax * sizeof(double);
   memcpy(flags, update, nblocks);
-  // the per-block flags sit right behind the eight oscillator planes, in the staging slot and on the device
+  // the per-block flags sit right behind the eight oscillator planes, in the staging slot and on the device; behind
+  // them the channels retuned since the last call (their first block is redone on the per-sample path)
+  int *ret = reinterpret_cast<int *>(flags + ((b->cfg.max_blocks + 7) & ~7u));
+  int nret = 0;
+  for (size_t c = 0; c < C; c++)
+    if (b->chans[c].active && b->chans[c].retuned) ret[nret++] = (int)c;
+  *nret_out = nret;
   *slot_out = slot;
   return 0;
 }
@@ -494,13 +499,15 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   chd.hist_rate = chd.lo_phase + 7 * Cmax;
   // this parity's hand-over planes were last read by the demodulators two calls ago
   if (b->stream2 != b->stream) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[pp], 0));
-  int slot = 0;
-  if (stage_call_params(b, b->n_abs - (g.M - 1), update_host, nblocks, &slot)) return -1;
+  int slot = 0, nret = 0;
+  if (stage_call_params(b, b->n_abs - (g.M - 1), update_host, nblocks, &slot, &nret)) return -1;
+  size_t const ret_off = 8 * Cmax * sizeof(double) + ((b->cfg.max_blocks + 7) & ~7u);
+  const int *retune_list = reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(b->osc_dev2[pp]) + ret_off);
   {
     Scope t(b, 2, b->stream);
     kq::launch_block_energy(b->stream, window + (g.M - 1), g.L, (int)nblocks,
                             reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power,
-                            b->stage_host[slot], b->osc_dev2[pp], 8 * Cmax * sizeof(double) + nblocks);
+                            b->stage_host[slot], b->osc_dev2[pp], nret ? ret_off + nret * sizeof(int) : 8 * Cmax * sizeof(double) + nblocks);
   }
   HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
   LAUNCH_CHECK("IF power");
@@ -517,16 +524,11 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
       kq::launch_filter_pruned(b->stream, g, chd, pl, window, b->chan_tw, C, (int)nblocks, swept);
       // The pruned kernels assume one oscillator over the whole window.  For the first block after a retune the
       // history half still carries the old one: redo just those channel-blocks on the per-sample path.
-      std::vector<int> ret;
-      for (int c = 0; c < C; c++)
-        if (b->chans[c].retuned) ret.push_back(c);
-      if (!ret.empty()) {
-        if (upload(b, b->retune_list, ret.data(), ret.size() * sizeof(int))) return -1;
-        HIP_TRY(hipStreamSynchronize(b->stream));  // `ret` is about to die; retunes are rare
+      if (nret > 0) {
         if (g.N > 16384)
-          kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, (int)ret.size(), 1, b->retune_list);
+          kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, nret, 1, retune_list);
         else
-          full_launch(b->stream, g, chd, pl, window, b->tw, (int)ret.size(), 1, 0, nullptr, -1, b->retune_list);
+          full_launch(b->stream, g, chd, pl, window, b->tw, nret, 1, 0, nullptr, -1, retune_list);
       }
     } else if (g.N > 16384) {
       kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, nullptr);
@@ -721,7 +723,9 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   b->chd.n0mask = nullptr;
   if (b->cfg.compute_n0 && kq::full16k_supported(g)) rc |= dev_alloc(&b->chd.n0mask, C * 512);
   // eight oscillator planes + the per-block IF-power flags of one call
-  for (int k = 0; k < 2; k++) rc |= dev_alloc(&b->osc_dev2[k], 8 * C + (B + sizeof(double) - 1) / sizeof(double));
+  // eight oscillator planes | the per-block IF-power flags | the list of channels retuned since the last call
+  for (int k = 0; k < 2; k++)
+    rc |= dev_alloc(&b->osc_dev2[k], 8 * C + (B + sizeof(double) - 1) / sizeof(double) + (C * sizeof(int) + 7) / 8);
   b->chd.lo_phase = b->chd.lo_freq = b->chd.lo_rate = b->chd.sh_phase = b->chd.sh_freq = nullptr;  // set per call
   b->chd.hist_phase = b->chd.hist_freq = b->chd.hist_rate = nullptr;
   // Overlap is opt-in (KQ_DEMOD_OVERLAP=1): measured on MI355X the single-wave demodulator workgroups squat on
@@ -737,7 +741,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     set_err("second stream / event creation failed");
     rc = -1;
   }
-  b->stage_bytes = 8 * C * sizeof(double) + ((B + 7) & ~(size_t)7);  // copied in 8-byte words
+  b->stage_bytes = 8 * C * sizeof(double) + ((B + 7) & ~(size_t)7) + ((C * sizeof(int) + 7) & ~(size_t)7);  // copied in 8-byte words
   for (int k = 0; k < kq_bank::kSlots && !rc; k++) {
     if (hipHostMalloc((void **)&b->stage_host[k], b->stage_bytes, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&b->stage_ev[k], hipEventDisableTiming) != hipSuccess) {
@@ -782,7 +786,6 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   b->pl = b->pl2[0];
   rc |= dev_alloc(&b->energy_state, 2);
   for (int k = 0; k < 3; k++) rc |= dev_alloc(&b->list_dev[k], C);
-  rc |= dev_alloc(&b->retune_list, C);
   if (b->fwd_mode == KQ_FWD_PRUNED) rc |= dev_alloc(&b->chan_tw, C * kq::pruned_table_elems(g));
   if (rc) {
     kq_bank_destroy(b);
@@ -832,7 +835,7 @@ int kq_bank_destroy(kq_bank *b) {
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
                   b->pl2[0].plout, b->pl2[1].plout, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
                   b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state,
-                  b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->retune_list, b->list_pll_dev, b->pll_state, b->pll_rings,
+                  b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->list_pll_dev, b->pll_state, b->pll_rings,
                   b->pll_side};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);

@@ -361,6 +361,30 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
       hang_end[0] = hang - OLEN;
       hang -= nsamp;
     }
+    // Coasting: the counter runs out inside (or before) the group and still no sample attacks, so the gain only holds
+    // and then recovers, gain *= recovery per sample once the counter is at zero (am.c:71-73, linear.c:276-278).  The
+    // products are formed in sequence, as the reference forms them; every lane keeps the value after its own sample,
+    // takes the one before it from its neighbour, and one ballot checks that indeed nothing attacks.  Tried only for
+    // channels with a hang time (for the others a group without an attack is the exception).
+    bool coast = false;
+    if (!held && hangmax != 0 && hang < nsamp && !isnan(gain)) {
+      float g = gain, after = gain;
+#pragma unroll 32
+      for (int i = 0; i < nsamp; i++) {
+        g = (i >= hang) ? g * recovery : g;
+        after = (lane == i) ? g : after;
+      }
+      float before = __shfl_up(after, 1, 64);
+      before = (lane == 0) ? gain : before;
+      coast = __ballot(lane < nsamp && (LINEAR ? level * before > headroom : before * level > headroom)) == 0ull;
+      if (coast) {
+        g_mine = after;
+        gain_end[0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, after), OLEN - 1));
+        hang_end[0] = hang > OLEN ? hang - OLEN : 0;
+        gain = g;
+        hang = 0;
+      }
+    }
     // No hang time (the AM entry of modes.txt) and no NaN in sight: the counter stays at zero and the NaN test of
     // the gain cannot fire (the gain is either an attack value of this group or a product with the recovery
     // factor), which leaves multiply / compare / select per sample.
@@ -377,7 +401,7 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
       }
     }
 #pragma unroll 32
-    for (int i = 0; i < ((held || plain) ? 0 : nsamp); i++) {
+    for (int i = 0; i < ((held || plain || coast) ? 0 : nsamp); i++) {
       float const lv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, level), i));
       float const iv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, inv), i));
       bool const nan_gain = isnan(gain);

@@ -261,3 +261,64 @@ def test_nan_sample_propagates_like_the_reference(gpu, L, D, pruned):
                 # NaN passes through, dividing by whatever the first finite sample is
                 assert rel_rms(ga[fin], wa[fin]) < 1e-5, (c, b, p["demod"], rel_rms(ga[fin], wa[fin]))
     assert nan_blocks >= 2 * len(plan)
+
+
+@pytest.mark.parametrize("L,D", [(8192, 256), (512, 8)])
+def test_agc_hold_coast_and_attack_regimes(gpu, L, D):
+    """AM / linear AGC with short hang times on a signal that fades in and out: groups of samples in which the gain
+    is held by the hang counter, coasts (counter runs out, recovery, no attack), or attacks -- the three paths of the
+    wave-per-channel AGC -- in every order, against the oracle's sample-by-sample loop.  Hang counter exact per
+    block, gain and audio to the parity tolerance.  (8192, 256): 32 samples per block, two blocks per group;
+    (512, 8): 64 samples per block."""
+    fs = 10000000 if L == 8192 else 192000
+    g = dict(samprate=fs, L=L, M=L + 1, D=D)
+    nb = 48
+    n = nb * L
+    t = np.arange(n) / fs
+    rng = np.random.default_rng(77)
+    f0 = 0.11 * fs
+    drate = fs / D
+    # two-tone SSB-like signal and an AM carrier next to it, both under a slow fade with a period of ~12 blocks
+    fade = 0.55 + 0.45 * np.cos(2 * np.pi * t / (12.3 * L / fs))
+    tone = lambda f: np.exp(2j * np.pi * (f0 + f) * t)      # noqa: E731
+    sig = 0.1 * fade * (tone(0.02 * drate) + 0.7 * tone(0.05 * drate))
+    sig += 0.1 * fade * (1 + 0.5 * np.cos(2 * np.pi * 0.03 * drate * t)) * np.exp(2j * np.pi * (f0 + 2.5 * drate) * t)
+    iq = (sig + 1e-4 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    w = 0.1 * drate
+    plan = []
+    for hangtime, rec in ((0.002 * 39062.5 / drate, 20.0), (0.0007 * 39062.5 / drate, 60.0), (0.0, 30.0)):
+        plan.append(dict(demod="linear", low=0.005 * drate, high=w, hangtime=hangtime, recovery_rate=rec, second_lo=-f0))
+        plan.append(dict(demod="am", low=-w, high=w, hangtime=hangtime, recovery_rate=rec, second_lo=-(f0 + 2.5 * drate)))
+    plan.append(dict(demod="linear", low=-w, high=w, hangtime=0.001 * 39062.5 / drate, recovery_rate=15.0, channels=2,
+                     second_lo=-f0, shift=0.01 * drate))
+    want = run_oracle(plan, g, iq, nb)
+    bank = kq.Bank(fs, L, g["M"], D, len(plan), 7, fwd_mode=kq.KQ_FWD_AUTO)
+    for p in plan:
+        bank.add_channel(bank_cfg(p))
+    got = [[] for _ in plan]
+    for s in range(0, nb, 7):
+        k = min(7, nb - s)
+        bank.push_iq(iq[s * L:(s + k) * L])
+        assert bank.process() == k
+        for c in range(len(plan)):
+            got[c] += [(bank.audio(c, b), bank.status(c, b)) for b in range(k)]
+    bank.close()
+    olen = L // D
+    for c, p in enumerate(plan):
+        auds, sts, _ = want[c]
+        hangs = [sts[b]["hangcount"] for b in range(nb)]
+        # the linear channels really visit "counter running", "counter at zero" and "re-armed" (the AM carrier filter is
+        # still charging over these 48 blocks, so its level rises with every sample and every sample attacks)
+        if p["hangtime"] > 0 and p["demod"] == "linear":
+            hm = int(p["hangtime"] / (D / fs))
+            assert 0 in hangs[2:] and hm in hangs[2:] and any(0 < h < hm for h in hangs[2:]), (c, hm, hangs)
+        for b in range(nb):
+            ga, gs = got[c][b]
+            assert gs["hangcount"] == sts[b]["hangcount"], (c, b, p["demod"], gs["hangcount"], sts[b]["hangcount"])
+            assert gs["nout"] == sts[b]["nout"] == olen * p.get("channels", 1)
+            if b > 0:
+                np.testing.assert_allclose(gs["agc_gain"], sts[b]["agc_gain"], rtol=2e-5)
+        sk = 1 if p["demod"] == "linear" else 0
+        a_g = np.concatenate([a for a, _ in got[c][sk:]])
+        a_w = np.concatenate(auds[sk:])
+        assert rel_rms(a_g, a_w) < 1e-5, (c, p["demod"], rel_rms(a_g, a_w))

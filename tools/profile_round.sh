@@ -20,14 +20,14 @@ run_stats pruned_cfg3 $R/bench.py --steps 10 --config cfg3 --no-cpu-baseline --n
 run_stats stream_cfg5 $R/bench.py --steps 10 --config cfg5 --blocks 16 --no-cpu-baseline --no-n0-row
 run_stats decim_log6 $R/tools/bench_decim.py
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $OUT/raw_pmc_$c -o pmc_$c --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-n0-row > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c -d $OUT/raw_pmc_$c -o pmc_$c --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --spinup 0 --no-cpu-baseline --no-n0-row > $OUT/pmc_$c.log 2>&1
 done
 F=$(find $OUT/raw_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 W=$(find $OUT/raw_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python3 $R/tools/pmc_summary.py $F $W $OUT/pmc_pruned_cfg4.json k_pruned cfg4 1024 64 pruned > /dev/null
 # the same two passes for the full-spectrum kernel with compute_n0 (the bench's second row)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $OUT/raw_pmcn0_$c -o pmcn0_$c --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --n0 1 --no-cpu-baseline > $OUT/pmcn0_$c.log 2>&1
+  rocprofv3 --pmc $c -d $OUT/raw_pmcn0_$c -o pmcn0_$c --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --spinup 0 --n0 1 --no-cpu-baseline > $OUT/pmcn0_$c.log 2>&1
 done
 F=$(find $OUT/raw_pmcn0_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 W=$(find $OUT/raw_pmcn0_WRITE_SIZE -name "*counter_collection.csv" | head -1)

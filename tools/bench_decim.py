@@ -17,8 +17,8 @@ def main():
     ap.add_argument("--log", type=int, default=6)
     ap.add_argument("--thr", type=int, default=8)
     ap.add_argument("--out", type=int, default=1 << 20)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=400, help="untimed calls: enough (~60 ms) to be at sustained clocks")
     a = ap.parse_args()
     import torch
     from ka9q_sdr_amd import Decimator

@@ -27,7 +27,7 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--spinup", type=int, default=300,
                     help="untimed steps run before the warm-up steps so that the GPU is at its sustained clocks when the "

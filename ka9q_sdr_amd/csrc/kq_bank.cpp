@@ -219,6 +219,7 @@ int upload_n0mask(kq_bank *b, int c) {
   kq::Geom const &g = b->g;
   float const low = b->chans[c].cfg.low, high = b->chans[c].cfg.high;
   std::vector<unsigned> m(512, 0u);
+  unsigned rows = 0, outside = 0;  // rows of 1024 bins holding a passband bin; bins outside the passband
   for (int t = 0; t < 512; t++) {
     int const ka = (t >> 5) + 32 * (t & 31);
     for (int half = 0; half < 2; half++)
@@ -227,10 +228,17 @@ int upload_n0mask(kq_bank *b, int c) {
         int const k = (n <= g.N / 2) ? n : n - g.N;
         int const prod = (int)((unsigned)k * (unsigned)g.samprate);
         float const f = (float)prod / g.N;
-        if (!(f >= low && f <= high)) m[t] |= 1u << (16 * half + k3);
+        if (!(f >= low && f <= high)) {
+          m[t] |= 1u << (16 * half + k3);
+          outside++;
+        } else {
+          rows |= 1u << k3;
+        }
       }
   }
+  unsigned const meta = (rows << 16) | outside;  // outside <= 16384
   if (upload(b, b->chd.n0mask + (size_t)c * 512, m.data(), m.size() * sizeof(unsigned))) return -1;
+  if (upload(b, b->chd.n0meta + c, &meta, sizeof meta)) return -1;
   HIP_TRY(hipStreamSynchronize(b->stream));  // `m` is about to die
   return 0;
 }
@@ -721,7 +729,11 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.hangmax, C);
   rc |= dev_alloc(&b->chd.noise_gain, C);
   b->chd.n0mask = nullptr;
-  if (b->cfg.compute_n0 && kq::full16k_supported(g)) rc |= dev_alloc(&b->chd.n0mask, C * 512);
+  b->chd.n0meta = nullptr;
+  if (b->cfg.compute_n0 && kq::full16k_supported(g)) {
+    rc |= dev_alloc(&b->chd.n0mask, C * 512);
+    rc |= dev_alloc(&b->chd.n0meta, C);
+  }
   // eight oscillator planes + the per-block IF-power flags of one call
   // eight oscillator planes | the per-block IF-power flags | the list of channels retuned since the last call
   for (int k = 0; k < 2; k++)
@@ -829,7 +841,7 @@ int kq_bank_destroy(kq_bank *b) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->stream2 && b->stream2 != b->stream) (void)hipStreamSynchronize(b->stream2);
   void *ptrs[] = {b->ring[0], b->ring[1], b->tw, b->chan_tw, b->chd.mode, b->chd.flags, b->chd.low, b->chd.high, b->chd.resp,
-                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.n0mask, b->fmout, b->fm_hist[0], b->fm_hist[1],
+                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.n0mask, b->chd.n0meta, b->fmout, b->fm_hist[0], b->fm_hist[1],
                   b->osc_dev2[0], b->osc_dev2[1], b->chd.fm_state,
                   b->chd.lastaudio, b->chd.sq_count, b->chd.ahist, b->chd.foffset, b->chd.pdev, b->chd.gain, b->chd.hang,
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,

@@ -49,7 +49,8 @@ struct ChanDev {
   float *recovery;      // am.c:27 / linear.c:34 recovery_factor
   int *hangmax;
   float *noise_gain;
-  unsigned *n0mask;     // [C][512] compute_n0 passband mask in k_filter_full16k's bin order (null: computed in the kernel)
+  unsigned *n0mask;     // [C][512] compute_n0 passband mask in k_filter_full16k's bin order (null: compute_n0 off)
+  unsigned *n0meta;     // [C] rows of 1024 bins that hold a passband bin << 16 | number of bins outside the passband
   // oscillator phase (turns), step (cycles/sample) and sweep (cycles/sample^2) at sample 0 of the
   // first window of the call; second LO and Doppler already summed (they multiply, so phases add)
   double *lo_phase, *lo_freq, *lo_rate;

@@ -36,9 +36,10 @@ namespace {
 constexpr int kN = 16384, kT = 512;
 // Both transposes move complex (8-byte) elements in two half rounds, so the buffer holds half of the data.
 constexpr int kRow1 = 528;    // transpose 1: [k1 & 15][16 n2 + n3]; rows 4224 B apart alternate 128-byte bank halves
-constexpr int kCol2 = 33;     // transpose 2: [n3][33 (k1 & 15) + k2], rows kRow2 apart: 16 n3 x 2 k1 lanes hit
-constexpr int kRow2 = 546;    //   32 distinct 8-byte bank pairs (546 = 2 mod 32, 33 = 1 mod 32)
-constexpr int kXchElems = 16 * kRow2;  // float2 elements; 16 * kRow1 fits as well
+constexpr int kCol2 = 32;     // transpose 2: [n3][32 (k1 & 15) + k2], rows kRow2 apart.  A ds_write_b64 is served in groups of
+constexpr int kRow2 = 513;    //   16 consecutive lanes over 32 banks (16 eight-byte slots): the 16 n3 of a group need an odd pitch;
+                              //   the reads are 32 consecutive elements per lane group whatever the pitches
+constexpr int kXchElems = 16 * kRow1;  // float2 elements; 16 * kRow2 fits as well
 
 using rfft::pk_cmul;
 using rfft::v2f;
@@ -48,23 +49,38 @@ __device__ __forceinline__ v2f ld2(const float2 *p) {
   return (v2f){f.x, f.y};
 }
 
+// Buffer loads: address = base (scalar registers) + lane offset (one VGPR, 32 bit) + row offset (scalar / literal).
+// The 32 window rows and the twiddle rows are 4 KiB and more apart, beyond the immediate offset of a global load,
+// which the compiler then serves with a 64-bit vector add (v_add_co / v_addc) per row; here no vector instruction
+// is spent on addresses at all.  Reads past `bytes` return zero.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ v2f buf_ld2(rsrc_t r, unsigned lane_off, unsigned row_off) {
+  return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_off, (int)row_off, 0));
+}
+
 // Twiddle tables (float2), computed in double on the host.  Pass 1, thread t: lo1[l-1][t] = W_N^{l t}, l = 1..3;
 // hi1[h-1][t] = W_N^{4 h t}, h = 1..7.  Pass 2, n3 = t & 15: lo2[l-1][n3] = W_N^{32 l n3}, hi2[h-1][n3] = W_N^{128 h n3}.
 // (Loading all 31 twiddles of a pass directly -- 31 coalesced loads, no products -- was measured 20 % slower: the
 // loads' latency is exposed, the 24 extra products are not.)
-constexpr int kTabLo1 = 0, kTabHi1 = 3 * kT, kTabLo2 = 10 * kT, kTabHi2 = 10 * kT + 3 * 16, kTabSize = 10 * kT + 10 * 16;
+constexpr int kTabLo1 = 0, kTabHi1 = 3 * kT, kTabLo2 = 10 * kT, kTabHi2 = 10 * kT + 3 * 16;
+// N/D = 64 epilogue (one wave, lane t): epi[s-1][t], s = 1..5 = twiddle of inverse-transform stage s (span 2^s) as lane t
+// applies it: exp(+j pi (t mod 2^s) / 2^s) in the upper lane of a butterfly pair (t & 2^s), 1 in the lower one
+constexpr int kTabEpi = 10 * kT + 10 * 16, kTabSize = kTabEpi + 5 * 64;
 
-// v[q] *= W^{q}, q = 0..31, W^{q} = lo[q & 3] * hi[q >> 2]; lo/hi rows are `stride` entries apart
-__device__ __forceinline__ void twiddle32(v2f (&v)[32], const float2 *__restrict__ lo_tab, const float2 *__restrict__ hi_tab,
-                                          int stride) {
+// v[q] *= W^{q}, q = 0..31, W^{q} = lo[q & 3] * hi[q >> 2]; lo/hi rows start at element lo_row / hi_row of the
+// table and are `stride` elements apart; lane_off = byte offset of the thread's column
+__device__ __forceinline__ void twiddle32(v2f (&v)[32], rsrc_t tab, unsigned lane_off, int lo_row, int hi_row, int stride) {
   v2f lo[4];
 #pragma unroll
-  for (int l = 1; l < 4; l++) lo[l] = ld2(lo_tab + (l - 1) * stride);
+  for (int l = 1; l < 4; l++) lo[l] = buf_ld2(tab, lane_off, (unsigned)(lo_row + (l - 1) * stride) * 8u);
 #pragma unroll
   for (int l = 1; l < 4; l++) v[l] = pk_cmul(v[l], lo[l]);
 #pragma unroll
   for (int h = 1; h < 8; h++) {
-    v2f const hi = ld2(hi_tab + (h - 1) * stride);
+    v2f const hi = buf_ld2(tab, lane_off, (unsigned)(hi_row + (h - 1) * stride) * 8u);
     v[4 * h] = pk_cmul(v[4 * h], hi);
 #pragma unroll
     for (int l = 1; l < 4; l++) v[4 * h + l] = pk_cmul(v[4 * h + l], pk_cmul(hi, lo[l]));
@@ -78,13 +94,17 @@ __device__ __forceinline__ v2f phasor2(double turns) {
 
 }  // namespace
 
-// grid (channel, block); dynamic LDS = kXchElems float2 (the epilogue's 2 * N_dec float2 fit in it)
+// grid (channel, block); dynamic LDS = kXchElems float2 (the epilogue's 2 * N_dec float2 fit in it).
+// N0: compute_n0 on every block (needs ch.n0mask / ch.n0meta); DUMP: copy one channel's spectra out (tests).
+template <bool N0, bool DUMP>
 __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,
                                                        const float2 *__restrict__ tw, const float2 *__restrict__ tab,
-                                                       int compute_n0, float2 *__restrict__ spec_dump, int spec_ch,
+                                                       float2 *__restrict__ spec_dump, int spec_ch,
                                                        const int *__restrict__ chan_list) {
   extern __shared__ __attribute__((aligned(16))) float2 xch[];
+  __shared__ __attribute__((aligned(16))) float2 stab[(kT / 64) * 32];  // per wave: S^{n1}, see the mix
   __shared__ float red_f[2][kT / 64];  // compute_n0: one slot per wave and pass
+  __shared__ float red_c[kT / 64];     //   bins counted by the fast second pass (exact in float: at most 16384)
   __shared__ int red_i[2][kT / 64];
   int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
   int const t = threadIdx.x;
@@ -95,34 +115,28 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   {
     double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c], r = ch.lo_rate[c];
     double const hp0 = ch.hist_phase[c], hf0 = ch.hist_freq[c], hr = ch.hist_rate[c];
-    const float2 *x = window + (size_t)b * g.L + t;
+    rsrc_t const xr = make_rsrc(window + (size_t)b * g.L, kN * (unsigned)sizeof(float2));
+    unsigned const toff = (unsigned)t * (unsigned)sizeof(float2);
+    auto ldx = [&](int n1) { return buf_ld2(xr, toff, (unsigned)n1 * (unsigned)(512 * sizeof(float2))); };
     double const mbase = (double)b * g.L;
     bool const retuned = b == 0 && (hp0 != ph0 || hf0 != f0 || hr != r);
     if (r == 0.0 && !retuned) {
+      // The phasor of sample 512 n1 + t is P_t S^{n1}, S = exp(j 2 pi 512 f0).  Lane n1 of each wave evaluates S^{n1}
+      // from the double-precision phase into the wave's own LDS slot; every lane then reads entry n1 (a broadcast
+      // read).  One phasor evaluation and one product per sample, each power exact to float rounding.
+      // The window loads go out first; the phasors are evaluated while they are in flight.
+#pragma unroll
+      for (int n1 = 0; n1 < 32; n1++) v[rfft::bitrev5(n1)] = ldx(n1);
+      float2 *const sw = stab + (t >> 6) * 32;
+      if ((t & 63) < 32) sw[t & 63] = phasor_turns(f0 * (double)(512 * (t & 63)));
       v2f const pt = phasor2(ph0 + f0 * (mbase + t));
-      // S^(2^j), j = 0..4, S = exp(j 2 pi 512 f0): lane j of every wave evaluates one, the wave shares them
-      v2f const sj = phasor2(f0 * (double)(512 << (t & 7)));
-      auto rl = [](float x, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane)); };
-      auto bc = [&](int lane) { return (v2f){rl(sj.x, lane), rl(sj.y, lane)}; };
-      v2f const s1 = bc(0), s2 = bc(1), s4 = bc(2), s8 = bc(3), s16 = bc(4);
-      v2f lo[4];
-      lo[0] = pt;
-      lo[1] = pk_cmul(pt, s1);
-      lo[2] = pk_cmul(pt, s2);
-      lo[3] = pk_cmul(lo[2], s1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int h = 0; h < 8; h++) {
-        // S^{4h} from s4, s8, s16
-        v2f hi = (v2f){1.f, 0.f};
-        if (h & 1) hi = s4;
-        if (h & 2) hi = (h & 1) ? pk_cmul(hi, s8) : s8;
-        if (h & 4) hi = (h & 3) ? pk_cmul(hi, s16) : s16;
-#pragma unroll
-        for (int l = 0; l < 4; l++) {
-          int const n1 = 4 * h + l;
-          v2f const p = h ? pk_cmul(lo[l], hi) : lo[l];
-          v[rfft::bitrev5(n1)] = pk_cmul(ld2(x + 512 * n1), p);
-        }
+      for (int n1 = 0; n1 < 32; n1++) {
+        v2f const p = n1 ? pk_cmul(pt, ld2(sw + n1)) : pt;
+        v[rfft::bitrev5(n1)] = pk_cmul(v[rfft::bitrev5(n1)], p);
       }
     } else {
 #pragma unroll
@@ -133,14 +147,15 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
         double const rr = old ? hr : r;
         double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
         if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
-        v[rfft::bitrev5(n1)] = pk_cmul(ld2(x + 512 * n1), phasor2(turns));
+        v[rfft::bitrev5(n1)] = pk_cmul(ldx(n1), phasor2(turns));
       }
     }
   }
 
   // ---------------- pass 1: 32-point transforms over n1, twiddle W_N^{t k1}
   rfft::fft_dit_pk<32>(v);
-  twiddle32(v, tab + kTabLo1 + t, tab + kTabHi1 + t, kT);
+  rsrc_t const tabr = make_rsrc(tab, kTabSize * (unsigned)sizeof(float2));
+  twiddle32(v, tabr, (unsigned)t * 8u, kTabLo1, kTabHi1, kT);
 
   // ---------------- transpose 1: [k1][t] -> thread (k1 = t >> 4, n3 = t & 15) gathers n2 = 0..31.
   // Half round A carries k1 < 16 (read by threads t < 256), half round B the rest.
@@ -162,7 +177,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
 
   // ---------------- pass 2: 32-point transforms over n2, twiddle W_512^{n3 k2} = W_N^{32 n3 k2}
   rfft::fft_dit_pk<32>(u);
-  twiddle32(u, tab + kTabLo2 + (t & 15), tab + kTabHi2 + (t & 15), 16);
+  twiddle32(u, tabr, (unsigned)(t & 15) * 8u, kTabLo2, kTabHi2, 16);
 
   // ---------------- transpose 2: [n3][k1][k2] -> thread (k1 = t >> 5 (+16), k2 = t & 31) gathers n3 = 0..15.
   // Half round A is written by the threads holding k1 < 16 (t < 256) and yields ya, half round B yields yb.
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   rfft::fft_dit_pk<16>(yb);
   int const ka = (t >> 5) + 32 * (t & 31), kb = ka + 16;  // k1 + 32 k2 with k1 = t >> 5 and 16 + (t >> 5)
 
-  if (spec_dump != nullptr && c == spec_ch) {
+  if (DUMP && c == spec_ch) {
     float2 *o = spec_dump + (size_t)b * kN;
 #pragma unroll
     for (int k3 = 0; k3 < 16; k3++) {
@@ -197,79 +212,8 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     }
   }
 
-  // ---------------- compute_n0 (radio.c:383-425), status only
-  if (compute_n0) {
-    float const low = ch.low[c], high = ch.high[c];
-    unsigned incl_a = 0, incl_b = 0;  // bit k3: bin outside the passband
-    float pa[16], pb[16];
-#pragma unroll
-    for (int k3 = 0; k3 < 16; k3++) {
-      pa[k3] = ya[k3].x * ya[k3].x + ya[k3].y * ya[k3].y;
-      pb[k3] = yb[k3].x * yb[k3].x + yb[k3].y * yb[k3].y;
-    }
-    if (ch.n0mask) {
-      // precomputed per channel on the host (kq_bank.cpp upload_n0mask): it depends only on the filter edges
-      unsigned const m = ch.n0mask[(size_t)c * kT + t];
-      incl_a = m & 0xffffu;
-      incl_b = m >> 16;
-    } else {
-      // The reference forms k*samprate in int (radio.c:407,409) with k the signed bin: keep its 32-bit wrap.
-      // n*samprate - (n > N/2 ? N*samprate : 0) modulo 2^32, built by additions from the thread's first bin.
-      unsigned const sr = (unsigned)g.samprate;
-      unsigned const prod_a0 = (unsigned)ka * sr, prod_b0 = (unsigned)kb * sr;
-#pragma unroll
-      for (int k3 = 0; k3 < 16; k3++) {
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-          // n = k + 1024 k3 <= N/2  <=>  k3 < 8, or k3 == 8 and k == 0 (only ka can be 0)
-          bool const neg = k3 > 8 || (k3 == 8 && (half || ka != 0));
-          unsigned const prod = (half ? prod_b0 : prod_a0) + (unsigned)(1024 * k3) * sr - (neg ? (unsigned)kN * sr : 0u);
-          float const f = (float)(int)prod / kN;
-          if (!(f >= low && f <= high)) (half ? incl_b : incl_a) |= 1u << k3;
-        }
-      }
-    }
-    // bins inside the passband never count: +inf fails both passes' `< thr` (as do the NaN / inf bins the reference's
-    // comparison drops)
-#pragma unroll
-    for (int k3 = 0; k3 < 16; k3++) {
-      pa[k3] = ((incl_a >> k3) & 1) ? pa[k3] : INFINITY;
-      pb[k3] = ((incl_b >> k3) & 1) ? pb[k3] : INFINITY;
-    }
-    float avg = INFINITY;
-    // Both passes run the same loop body.  (Left to itself the compiler peels the first one and, with thr = inf known,
-    // counts bins with `p != inf` -- which a NaN bin would pass -- while still summing with an ordered compare.)
-    asm volatile("" : "+v"(avg));
-    for (int iter = 0; iter < 2; iter++) {
-      float acc = 0;
-      int wave_bins = 0;  // counted on the scalar unit from the comparison masks
-      float const thr = avg * 2;
-#pragma unroll
-      for (int k3 = 0; k3 < 16; k3++) {
-        bool const ta = pa[k3] < thr, tb = pb[k3] < thr;
-        acc += ta ? pa[k3] : 0.f;
-        acc += tb ? pb[k3] : 0.f;
-        wave_bins += __popcll(__ballot(ta)) + __popcll(__ballot(tb));
-      }
-      acc = wave_sum(acc);
-      if ((t & 63) == 0) {
-        red_f[iter][t >> 6] = acc;
-        red_i[iter][t >> 6] = wave_bins;
-      }
-      __syncthreads();
-      float tf = 0;
-      int bins = 0;
-#pragma unroll
-      for (int k = 0; k < kT / 64; k++) {
-        tf += red_f[iter][k];
-        bins += red_i[iter][k];
-      }
-      avg = tf / bins;
-    }
-    if (t == 0) pl.n0raw[(size_t)c * g.max_blocks + b] = (float)(avg / (2.0 * kN * g.samprate));
-  }
-
   // ---------------- slave (filter.c:206-250): the N/D bins it reads go to LDS as Xs[p], p = k mod N_dec
+  // (the exchange buffer is free since the last barrier of transpose 2; done first so that ya / yb die before compute_n0)
   float2 *Xs = xch;
   float2 *G = Xs + Ndec;
   auto to_f2 = [](v2f a) { return make_float2(a.x, a.y); };
@@ -295,39 +239,181 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
       }
     }
   }
-  __syncthreads();
+  // N/D = 64: the wave that will run the inverse transform fetches what it needs now, under compute_n0
   const float2 *H = ch.resp + (size_t)c * Ndec;
   bool const isb = (ch.flags[c] & FLAG_ISB) != 0;
+  v2f epi_h = {0.f, 0.f}, epi_h2 = {0.f, 0.f}, epi_w[5] = {};
+  if (Ndec == 64 && t < 64) {
+    int const q = (int)(__brev((unsigned)t) >> 26);
+    epi_h = ld2(H + q);
+    if (isb) epi_h2 = ld2(H + ((64 - q) & 63));
+#pragma unroll
+    for (int st = 0; st < 5; st++) epi_w[st] = buf_ld2(tabr, (unsigned)t * 8u, (unsigned)(kTabEpi + st * 64) * 8u);
+  }
+
+  // ---------------- compute_n0 (radio.c:383-425), status only.  pp[k3] = (|X[ka + 1024 k3]|^2, |X[kb + 1024 k3]|^2)
+  bool n0_fast = false;
+  if constexpr (N0) {
+    v2f pp[16];
+#pragma unroll
+    for (int k3 = 0; k3 < 16; k3++) {
+      // spelled out: given `x*x + y*y` on both halves the compiler pairs the two additions into one v_pk_add_f32
+      // behind three register moves
+      v2f sa, sb;
+      float p0, p1;
+      asm("v_pk_mul_f32 %0, %1, %1" : "=v"(sa) : "v"(ya[k3]));
+      asm("v_pk_mul_f32 %0, %1, %1" : "=v"(sb) : "v"(yb[k3]));
+      asm("v_add_f32 %0, %1, %2" : "=v"(p0) : "v"(sa.x), "v"(sa.y));
+      asm("v_add_f32 %0, %1, %2" : "=v"(p1) : "v"(sb.x), "v"(sb.y));
+      pp[k3] = (v2f){p0, p1};
+    }
+    // Passband exclusion (radio.c:405-411), precomputed per channel on the host (kq_bank.cpp upload_n0mask: it depends
+    // only on the filter edges): bit k3 / 16 + k3 of `m` clear = the thread's bin of row k3 lies inside the passband.
+    // The passband is a few dozen of the 16384 bins around DC: they sit in rows 0 and 15 (bins 0..1023 and
+    // -1024..-1), which are always looked at; `meta` >> 16 flags the rows that hold a passband bin, so that one
+    // wave-uniform test covers the other fourteen.  Its low half counts the bins outside the passband.
+    unsigned const m = ch.n0mask[(size_t)c * kT + t];
+    unsigned const meta = ch.n0meta[c];
+    bool const wide = (meta & 0x7ffe0000u) != 0;
+    auto mark_row = [&](int k3, float marker) {
+      pp[k3].x = ((m >> k3) & 1) ? pp[k3].x : marker;
+      pp[k3].y = ((m >> (16 + k3)) & 1) ? pp[k3].y : marker;
+    };
+    auto mark_passband = [&](float marker) {
+      mark_row(0, marker);
+      mark_row(15, marker);
+      if (wide) {
+        asm volatile("; passband beyond +-1024 bins");  // keeps this a branch: flattened, it is 84 selects nobody needs
+#pragma unroll
+        for (int k3 = 1; k3 < 15; k3++) mark_row(k3, marker);
+      }
+    };
+    // First pass: avg_n = inf, so `s < avg_n * 2` keeps every finite bin.  Sum them all; when the total comes out
+    // finite no bin was inf or NaN (powers are >= 0, nothing cancels) and the count is the precomputed one.
+    mark_passband(0.f);
+    v2f s2;
+    {
+      v2f const a0 = pp[0] + pp[1], a1 = pp[2] + pp[3], a2 = pp[4] + pp[5], a3 = pp[6] + pp[7];
+      v2f const a4 = pp[8] + pp[9], a5 = pp[10] + pp[11], a6 = pp[12] + pp[13], a7 = pp[14] + pp[15];
+      s2 = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    }
+    float const tot = wave_sum_to63(s2.x + s2.y);
+    if ((t & 63) == 63) red_f[0][t >> 6] = tot;
+    __syncthreads();
+    float total = 0;
+#pragma unroll
+    for (int k = 0; k < kT / 64; k++) total += red_f[0][k];
+    int const bins1 = (int)(meta & 0xffffu);
+    float const thr = (total / bins1) * 2;
+    // Second pass: sum and count of the bins with s < thr.  For a normal, finite threshold the comparison is done in
+    // packed arithmetic: with scale = 2^(40 - exponent(thr)), clamp(thr * scale - s * scale) is exactly 1 for every
+    // float s < thr (the difference is at least 2^16 after scaling; the fused multiply-add rounds once, so its sign is
+    // that of thr - s), exactly 0 for s >= thr, and 0 for the passband marker.  Three packed instructions per pair of
+    // bins instead of compare / select / add per bin.  Anything else -- a NaN or inf bin, an all-zero or denormal
+    // spectrum, an empty bin set -- takes the loop that spells the reference's comparisons out.
+    n0_fast = total < INFINITY && thr < INFINITY && thr >= 1e-26f;
+    if (n0_fast) {
+      mark_passband(3.4028234664e38f);
+      int const e = (__float_as_int(thr) >> 23) & 0xff;  // biased exponent, 1..254 here
+      float const scale = __int_as_float((127 + 40 + 127 - e) << 23);
+      float const cs = thr * scale;  // exact: a power-of-two scaling inside the normal range
+      v2f const nsc = (v2f){-scale, -scale}, c2 = (v2f){cs, cs};
+      v2f acc_e = (v2f){0.f, 0.f}, acc_o = acc_e, cnt_e = acc_e, cnt_o = acc_e;
+#pragma unroll
+      for (int k3 = 0; k3 < 16; k3++) {
+        v2f keep;
+        asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(keep) : "v"(nsc), "v"(pp[k3]), "v"(c2));
+        if (k3 & 1) {
+          acc_o = rfft::pk_fma(keep, pp[k3], acc_o);
+          cnt_o += keep;
+        } else {
+          acc_e = rfft::pk_fma(keep, pp[k3], acc_e);
+          cnt_e += keep;
+        }
+      }
+      v2f const acc2 = acc_e + acc_o, cnt2 = cnt_e + cnt_o;
+      float const acc = wave_sum_to63(acc2.x + acc2.y), cnt = wave_sum_to63(cnt2.x + cnt2.y);
+      if ((t & 63) == 63) {
+        red_f[1][t >> 6] = acc;
+        red_c[t >> 6] = cnt;
+      }
+      // the sums meet behind the barrier that also publishes the slave's bins, below
+    } else {
+      mark_passband(INFINITY);  // fails both passes' `< thr`, as do the NaN / inf bins the reference's comparison drops
+      float avg = INFINITY;
+      // Both passes run the same loop body.  (Left to itself the compiler peels the first one and, with thr = inf
+      // known, counts bins with `p != inf` -- which a NaN bin would pass -- while still summing with an ordered compare.)
+      asm volatile("" : "+v"(avg));
+      for (int iter = 0; iter < 2; iter++) {
+        float acc = 0;
+        int wave_bins = 0;  // counted on the scalar unit from the comparison masks
+        float const th = avg * 2;
+#pragma unroll
+        for (int k3 = 0; k3 < 16; k3++) {
+          bool const ta = pp[k3].x < th, tb = pp[k3].y < th;
+          acc += ta ? pp[k3].x : 0.f;
+          acc += tb ? pp[k3].y : 0.f;
+          wave_bins += __popcll(__ballot(ta)) + __popcll(__ballot(tb));
+        }
+        acc = wave_sum(acc);
+        __syncthreads();  // the previous round's slots have been read
+        if ((t & 63) == 0) {
+          red_f[iter][t >> 6] = acc;
+          red_i[iter][t >> 6] = wave_bins;
+        }
+        __syncthreads();
+        float tf = 0;
+        int bins = 0;
+#pragma unroll
+        for (int k = 0; k < kT / 64; k++) {
+          tf += red_f[iter][k];
+          bins += red_i[iter][k];
+        }
+        avg = tf / bins;
+      }
+      if (t == 0) pl.n0raw[(size_t)c * g.max_blocks + b] = (float)(avg / (2.0 * kN * g.samprate));
+    }
+  }
+
+  // ---------------- slave, continued: response multiply, CROSS_CONJ, inverse transform
+  __syncthreads();
+  if (N0 && n0_fast && t == 0) {
+    float tf = 0, bins = 0;
+#pragma unroll
+    for (int k = 0; k < kT / 64; k++) {
+      tf += red_f[1][k];
+      bins += red_c[k];
+    }
+    float const avg = tf / bins;  // new_avg_n /= noisebins, radio.c:421
+    pl.n0raw[(size_t)c * g.max_blocks + b] = (float)(avg / (2.0 * kN * g.samprate));
+  }
   if (Ndec == 64) {
     // cfg 3 / 4: one wave multiplies and runs the 64-point inverse transform in its registers (lane exchanges, no
-    // barriers); the other seven are done
+    // barriers); the other seven are done.  Its response bins and stage twiddles were fetched before compute_n0
+    // (epi_*), so nothing here waits for memory: the workgroup's slot on the CU is held by this tail alone.
     if (t >= 64) return;
     int const q = (int)(__brev((unsigned)t) >> 26);  // decimation in time: bit-reversed in, natural out
-    float2 z = cmul(H[q], Xs[q]);
+    v2f z = pk_cmul(epi_h, ld2(Xs + q));
     if (isb && q != 0 && q != 32) {  // filter.c:242-248
-      float2 const other = cmul(H[64 - q], Xs[64 - q]);
-      z = q < 32 ? cadd(z, cconj(other)) : csub(z, cconj(other));
+      v2f const other = pk_cmul(epi_h2, ld2(Xs + 64 - q));
+      v2f const oc = (v2f){other.x, -other.y};
+      z = q < 32 ? z + oc : z - oc;
     }
-    auto xch2 = [&](float2 v, auto m) {
-      return make_float2(lane_xor<decltype(m)::value>(v.x, t), lane_xor<decltype(m)::value>(v.y, t));
+    auto stage = [&](auto mm, v2f w, bool first) {
+      constexpr int half = decltype(mm)::value;
+      v2f const v = first ? z : pk_cmul(z, w);  // w = 1 in the lower lane of a pair
+      v2f const r = (v2f){lane_xor<half>(v.x, t), lane_xor<half>(v.y, t)};
+      float const sg = __int_as_float(0x3f800000 | ((t & half) ? 0x80000000 : 0));  // z = up ? r - v : r + v
+      z = rfft::pk_fma(v, (v2f){sg, sg}, r);
     };
-    auto stage = [&](auto m) {
-      constexpr int half = decltype(m)::value;
-      float sn, cs;
-      sincospif((float)(t & (half - 1)) / (float)half, &sn, &cs);
-      bool const up = (t & half) != 0;
-      float2 const v = up ? cmul(z, make_float2(cs, sn)) : z;
-      float2 const r = xch2(v, m);
-      z = up ? csub(r, v) : cadd(v, r);
-    };
-    stage(std::integral_constant<int, 1>{});
-    stage(std::integral_constant<int, 2>{});
-    stage(std::integral_constant<int, 4>{});
-    stage(std::integral_constant<int, 8>{});
-    stage(std::integral_constant<int, 16>{});
-    stage(std::integral_constant<int, 32>{});
+    stage(std::integral_constant<int, 1>{}, z, true);
+    stage(std::integral_constant<int, 2>{}, epi_w[0], false);
+    stage(std::integral_constant<int, 4>{}, epi_w[1], false);
+    stage(std::integral_constant<int, 8>{}, epi_w[2], false);
+    stage(std::integral_constant<int, 16>{}, epi_w[3], false);
+    stage(std::integral_constant<int, 32>{}, epi_w[4], false);
     float2 *o = pl.filt + ((size_t)c * g.max_blocks + b) * g.olen;
-    if (t >= 64 - g.olen) o[t - (64 - g.olen)] = z;  // filter.c:131
+    if (t >= 64 - g.olen) o[t - (64 - g.olen)] = make_float2(z.x, z.y);  // filter.c:131
     return;
   }
   for (int p = t; p <= Ndec / 2; p += kT) {
@@ -376,6 +462,12 @@ static const float2 *twiddle_tables() {
     for (int l = 1; l < 4; l++) h[kTabLo2 + (l - 1) * 16 + n3] = w(32LL * l * n3);
     for (int hh = 1; hh < 8; hh++) h[kTabHi2 + (hh - 1) * 16 + n3] = w(128LL * hh * n3);
   }
+  for (int st = 1; st <= 5; st++)
+    for (int t = 0; t < 64; t++) {
+      int const half = 1 << st;
+      double const ang = M_PI * (double)(t & (half - 1)) / half;
+      h[kTabEpi + (st - 1) * 64 + t] = (t & half) ? make_float2((float)cos(ang), (float)sin(ang)) : make_float2(1.f, 0.f);
+    }
   float2 *d = nullptr;
   if (hipMalloc(&d, h.size() * sizeof(float2)) != hipSuccess) return nullptr;
   if (hipMemcpy(d, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
@@ -390,14 +482,22 @@ void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
                            const int *chan_list) {
   size_t const lds_bytes = (size_t)kXchElems * sizeof(float2);
-  ensure_dynamic_lds((const void *)k_filter_full16k, (size_t)(lds_bytes));
   const float2 *tab = twiddle_tables();
   if (!tab) {  // cannot happen short of an allocation failure: fall back to the LDS kernel rather than fail the block
     launch_filter_full(s, g, ch, pl, window, tw, nchan, nblocks, compute_n0, spec_dump, spec_ch, chan_list);
     return;
   }
-  hipLaunchKernelGGL(k_filter_full16k, dim3(nchan, nblocks), dim3(kT), lds_bytes, s, g, ch, pl, window, tw, tab,
-                     compute_n0, spec_dump, spec_ch, chan_list);
+  bool const n0 = compute_n0 && ch.n0mask && ch.n0meta;  // the bank uploads both whenever it was created with compute_n0
+  bool const dump = spec_dump != nullptr;
+  auto go = [&](auto kernel) {
+    ensure_dynamic_lds((const void *)kernel, lds_bytes);
+    hipLaunchKernelGGL(kernel, dim3(nchan, nblocks), dim3(kT), lds_bytes, s, g, ch, pl, window, tw, tab, spec_dump, spec_ch,
+                       chan_list);
+  };
+  if (n0)
+    dump ? go(k_filter_full16k<true, true>) : go(k_filter_full16k<true, false>);
+  else
+    dump ? go(k_filter_full16k<false, true>) : go(k_filter_full16k<false, false>);
 }
 
 }  // namespace kq

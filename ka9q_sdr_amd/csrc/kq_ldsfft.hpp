@@ -50,6 +50,29 @@ __device__ __forceinline__ T wave_reduce(T v, Op op) {
 __device__ __forceinline__ float wave_sum(float v) {
   return wave_reduce(v, [](float a, float b) { return a + b; });
 }
+// Sum over the 64 lanes delivered to lane 63 only (the other lanes hold partial sums): seven v_add_f32 with DPP
+// operands -- shifts by 1, 2, 3 inside each row of 16, by 4 and 8 into the upper banks, then the row totals broadcast
+// into the rows above -- a third of the instructions of the butterfly that leaves the sum in every lane.  All lanes
+// must be active.  (The s_nop are the two wait states a DPP read needs behind the write of its source register.)
+__device__ __forceinline__ float wave_sum_to63(float v) {
+  float r;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_add_f32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+      : "=&v"(r)
+      : "v"(v));
+  return r;
+}
 __device__ __forceinline__ int wave_sum_i(int v) {
   return wave_reduce(v, [](int a, int b) { return a + b; });
 }

@@ -87,8 +87,25 @@ __device__ __forceinline__ void fft_dit(float2 (&v)[NP]) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-// a * b, complex
-__device__ __forceinline__ v2f pk_cmul(v2f a, v2f b) { return pk_fma((v2f){-a.y, a.y}, b.yx, a.xx * b); }
+// a * b, complex, for compile-time or scalar-register operands (the compiler picks the encodings)
+__device__ __forceinline__ v2f pk_cmul_any(v2f a, v2f b) { return pk_fma((v2f){-a.y, a.y}, b.yx, a.xx * b); }
+// a * b, complex, both in vector registers: exactly two instructions.  The half selects and the sign of a.y ride on
+// the VOP3P operand modifiers (op_sel / op_sel_hi / neg_lo); written out because the compiler, given the vector form
+// above, materialises {-a.y, a.y} with a v_xor_b32 and a v_mov_b32 whenever `a` has a second use.
+//   t = (a.x b.x, a.x b.y);  d = (-a.y b.y + t.x, a.y b.x + t.y)
+__device__ __forceinline__ v2f pk_cmul(v2f a, v2f b) {
+  v2f t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));
+  return d;
+}
+// a * conj(b)
+__device__ __forceinline__ v2f pk_cmul_conj(v2f a, v2f b) {
+  v2f t, d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));  // (a.x b.x, -a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(t));  // (+a.y b.y, +a.y b.x)
+  return d;
+}
 
 template <int NP, int LEN, int I>
 __device__ __forceinline__ void bfly_pk(v2f (&v)[NP]) {

@@ -146,6 +146,9 @@ unsigned kq_bank_num_channels(const kq_bank *bank);
 int kq_bank_set_mode(kq_bank *bank, int ch, const kq_channel_config *mode);
 
 /* --- tuning, all phase continuous and effective from the next block (osc.c:22-36) --- */
+/* demod->filter.isb and demod->output.channels of a running linear channel (linear.c:117-120, 291-300): the slave's
+ * out_type and the mono / stereo hand-off change from the next block on; AGC state and response are left alone. */
+int kq_bank_set_linear_options(kq_bank *bank, int ch, int isb, int channels);
 int kq_bank_set_second_lo(kq_bank *bank, int ch, double hz);                 /* radio.c:290 set_second_LO */
 int kq_bank_set_doppler(kq_bank *bank, int ch, double hz, double hz_per_s);  /* radio.c:180 set_doppler */
 int kq_bank_set_shift(kq_bank *bank, int ch, double hz);                     /* radio.c:304 set_shift */

@@ -1072,6 +1072,35 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
   return 0;
 }
 
+// linear.c:117-120 copies demod->filter.isb into the slave's out_type before every block, and linear.c:291-300 looks
+// at demod->output.channels after it: both may change while the demodulator runs, without touching its AGC or the
+// response (which keeps the gain it was designed with until the next set_filter, as in the reference).
+int kq_bank_set_linear_options(kq_bank *b, int ch, int isb, int channels) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  if (!valid_ch(b, ch) || (channels != 1 && channels != 2)) {
+    set_err("bad channel, or channels not 1 or 2");
+    return -1;
+  }
+  HostChan &h = b->chans[ch];
+  if (h.cfg.demod_type != KQ_LINEAR_DEMOD) {
+    set_err("not a linear channel");
+    return -1;
+  }
+  if ((h.cfg.isb != 0) == (isb != 0) && h.cfg.channels == channels) return 0;
+  if (sync_all(b)) return -1;
+  h.cfg.isb = isb != 0;
+  h.cfg.channels = channels;
+  h.out_type = h.cfg.isb ? kq::FT_CROSS_CONJ : kq::FT_COMPLEX;
+  int flags = 0;
+  if (h.cfg.flat) flags |= kq::FLAG_FLAT;
+  if (h.cfg.isb) flags |= kq::FLAG_ISB;
+  if (h.cfg.channels == 2) flags |= kq::FLAG_STEREO;
+  if (h.cfg.square) flags |= kq::FLAG_SQUARE;
+  if (upload(b, b->chd.flags + ch, &flags, sizeof(int))) return -1;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
 int kq_bank_set_second_lo(kq_bank *b, int ch, double hz) {
   kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || std::isnan(hz)) {

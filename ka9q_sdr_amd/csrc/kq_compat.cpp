@@ -11,7 +11,7 @@
 #include <mutex>
 #include <vector>
 
-#include "../../include/ka9q_hip_compat.h"
+#include "../../include/ka9q_hip_radio.h"
 #include "kq_design.hpp"
 #include "kq_device.hpp"
 
@@ -19,7 +19,9 @@ namespace {
 
 struct DevCtx {
   bool ok = false;
+  int device = 0;
   hipStream_t stream = nullptr;
+  float *d_scalar = nullptr;  // one float of device scratch (kq_compat_compute_n0)
   std::map<int, float2 *> tw;  // log2(T) -> table of T/2 twiddles
   std::mutex mu;
 };
@@ -38,7 +40,9 @@ bool ctx_init() {
     fprintf(stderr, "ka9q_hip: no HIP device; the filter API has no CPU fallback\n");
     return false;
   }
+  if (hipGetDevice(&c.device) != hipSuccess) return false;
   if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) return false;
+  if (hipMalloc((void **)&c.d_scalar, sizeof(float)) != hipSuccess) return false;
   c.ok = true;
   return true;
 }
@@ -70,6 +74,7 @@ int ilog2(unsigned v) {
 struct MasterDev {
   int N, log2N;
   float2 *d_in = nullptr, *d_fdomain = nullptr;
+  float2 *d_tmp = nullptr;  // N > 16384: scratch of the two-pass transform
   std::vector<float2> stage;
   float2 *tw = nullptr;
 };
@@ -84,17 +89,48 @@ inline float im(kq_cfloat z) { return __imag__ z; }
 
 }  // namespace
 
+namespace kq {
+
+int compat_master_device(void) { return ctx().ok ? ctx().device : -1; }
+
+int compat_snapshot_window(struct filter_in *m, float2 *dst) {
+  if (!m || !m->fwd_plan || !dst) return -1;
+  kq::DeviceScope dev_scope_(ctx().ok ? ctx().device : -1);
+  MasterDev *d = (MasterDev *)m->fwd_plan;
+  hipStream_t s = ctx().stream;
+  if (hipMemcpyAsync(dst, d->d_in, (size_t)d->N * sizeof(float2), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+  return d->N;
+}
+
+}  // namespace kq
+
 extern "C" {
 
 float Kaiser_beta = 3.0;
 
+float kq_compat_compute_n0(struct filter_in *m, int samprate, float low, float high) {
+  if (!m || !m->fwd_plan || m->in_type != COMPLEX || samprate <= 0) return NAN;
+  kq::DeviceScope dev_scope_(ctx().ok ? ctx().device : -1);
+  MasterDev *d = (MasterDev *)m->fwd_plan;
+  DevCtx &c = ctx();
+  float r = NAN;
+  std::lock_guard<std::mutex> lk(c.mu);  // one scratch float
+  kq::launch_n0_single(c.stream, d->d_fdomain, d->N, samprate, low, high, c.d_scalar);
+  if (hipMemcpyAsync(&r, c.d_scalar, sizeof r, hipMemcpyDeviceToHost, c.stream) != hipSuccess) return NAN;
+  if (hipStreamSynchronize(c.stream) != hipSuccess) return NAN;
+  return r;
+}
+
+
 struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filtertype in_type) {
   unsigned const N = L + M - 1;
-  if (L == 0 || M == 0 || (N & (N - 1)) != 0 || N > 16384 || N < 4) {
-    fprintf(stderr, "ka9q_hip: create_filter_input: N=%u must be a power of two in 4..16384\n", N);
+  if (L == 0 || M == 0 || (N & (N - 1)) != 0 || N > (1u << 22) || N < 4) {
+    fprintf(stderr, "ka9q_hip: create_filter_input: N=%u must be a power of two in 4..4194304\n", N);
     return NULL;
   }
   if (!ctx_init()) return NULL;
+  kq::DeviceScope dev_scope_(ctx().ok ? ctx().device : -1);
   struct filter_in *m = (struct filter_in *)calloc(1, sizeof(*m));
   if (!m) return NULL;
   pthread_mutex_init(&m->filter_mutex, NULL);
@@ -112,7 +148,10 @@ struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filte
   d->tw = twiddles(d->log2N);
   d->stage.resize(N);
   if (!d->tw || hipMalloc((void **)&d->d_in, N * sizeof(float2)) != hipSuccess ||
-      hipMalloc((void **)&d->d_fdomain, N * sizeof(float2)) != hipSuccess) {
+      hipMalloc((void **)&d->d_fdomain, N * sizeof(float2)) != hipSuccess ||
+      (N > 16384 && hipMalloc((void **)&d->d_tmp, N * sizeof(float2)) != hipSuccess)) {
+    (void)hipFree(d->d_in);
+    (void)hipFree(d->d_fdomain);
     delete d;
     free(m);
     return NULL;
@@ -132,6 +171,7 @@ struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filte
 
 int execute_filter_input(struct filter_in *m) {
   if (m == NULL) return -1;  // filter.c:148-149
+  kq::DeviceScope dev_scope_(ctx().ok ? ctx().device : -1);
   MasterDev *d = (MasterDev *)m->fwd_plan;
   hipStream_t s = ctx().stream;
   int const N = d->N;
@@ -143,7 +183,10 @@ int execute_filter_input(struct filter_in *m) {
     src = m->input_buffer.c;
   }
   if (hipMemcpyAsync(d->d_in, src, N * sizeof(float2), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
-  kq::launch_fft_single(s, d->d_in, d->d_fdomain, d->log2N, -1, d->tw, d->log2N);
+  if (N > 16384)
+    kq::launch_fft_large(s, d->d_in, d->d_fdomain, d->d_tmp, d->log2N, -1, d->tw, d->log2N);
+  else
+    kq::launch_fft_single(s, d->d_in, d->d_fdomain, d->log2N, -1, d->tw, d->log2N);
   size_t const bins = (m->in_type == REAL) ? N / 2 + 1 : N;
   if (hipMemcpyAsync(m->fdomain, d->d_fdomain, bins * sizeof(float2), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
@@ -162,10 +205,12 @@ int execute_filter_input(struct filter_in *m) {
 
 int delete_filter_input(struct filter_in *m) {
   if (m == NULL) return 0;
+  kq::DeviceScope dev_scope_(ctx().ok ? ctx().device : -1);
   MasterDev *d = (MasterDev *)m->fwd_plan;
   if (d) {
     (void)hipFree(d->d_in);
     (void)hipFree(d->d_fdomain);
+    (void)hipFree(d->d_tmp);
     delete d;
   }
   free(m->input_buffer.c);  // same storage either way (union), as filter.c:259
@@ -189,11 +234,12 @@ float noise_gain(struct filter_out const *f) {
 struct filter_out *create_filter_output(struct filter_in *master, kq_cfloat *response, unsigned int decimate,
                                         enum filtertype out_type) {
   if (master == NULL || decimate == 0) return NULL;  // filter.c:99-100
+  kq::DeviceScope dev_scope_(ctx().ok ? ctx().device : -1);
   int const N = (int)(master->ilen + master->impulse_length - 1);
   int const nd = N / (int)decimate;
   if ((N % decimate) != 0) fprintf(stderr, "Warning: FFT size %d is not divisible by decimation ratio %u\n", N, decimate);
-  if ((nd & (nd - 1)) != 0 || nd < 4) {
-    fprintf(stderr, "ka9q_hip: create_filter_output: N/decimate=%d must be a power of two >= 4\n", nd);
+  if ((nd & (nd - 1)) != 0 || nd < 4 || nd > 16384) {
+    fprintf(stderr, "ka9q_hip: create_filter_output: N/decimate=%d must be a power of two in 4..16384\n", nd);
     return NULL;
   }
   struct filter_out *s = (struct filter_out *)calloc(1, sizeof(*s));
@@ -208,7 +254,10 @@ struct filter_out *create_filter_output(struct filter_in *master, kq_cfloat *res
   SlaveDev *d = new SlaveDev();
   d->Ndec = nd;
   if (hipMalloc((void **)&d->d_resp, nd * sizeof(float2)) != hipSuccess ||
-      hipMalloc((void **)&d->d_out, nd * sizeof(float2)) != hipSuccess) {
+      hipMalloc((void **)&d->d_out, nd * sizeof(float2)) != hipSuccess ||
+      hipMemset(d->d_resp, 0, nd * sizeof(float2)) != hipSuccess) {
+    (void)hipFree(d->d_resp);
+    (void)hipFree(d->d_out);
     delete d;
     free(s);
     return NULL;
@@ -226,6 +275,7 @@ struct filter_out *create_filter_output(struct filter_in *master, kq_cfloat *res
 
 int execute_filter_output(struct filter_out *s) {
   if (s == NULL) return -1;
+  kq::DeviceScope dev_scope_(ctx().ok ? ctx().device : -1);
   struct filter_in *m = s->master;
   MasterDev *md = (MasterDev *)m->fwd_plan;
   SlaveDev *sd = (SlaveDev *)s->rev_plan;
@@ -238,7 +288,9 @@ int execute_filter_output(struct filter_out *s) {
 
   int const nd = sd->Ndec;
   bool const real_out = s->out_type == REAL;
-  size_t const rbins = real_out ? nd / 2 + 1 : nd;
+  // REAL in / REAL out reads N_dec/2+1 response bins (filter.c:209-212); every other combination reads all N_dec,
+  // COMPLEX in / REAL out included: it folds in H[N_dec - p] X[N - p] (filter.c:232-234).  The same rule as noise_gain().
+  size_t const rbins = (real_out && m->in_type == REAL) ? nd / 2 + 1 : nd;
   pthread_mutex_lock(&s->response_mutex);  // filter.c:201
   if (s->response == NULL) {
     pthread_mutex_unlock(&s->response_mutex);
@@ -259,6 +311,7 @@ int execute_filter_output(struct filter_out *s) {
 
 int delete_filter_output(struct filter_out *s) {
   if (s == NULL) return 0;
+  kq::DeviceScope dev_scope_(ctx().ok ? ctx().device : -1);
   SlaveDev *d = (SlaveDev *)s->rev_plan;
   if (d) {
     (void)hipFree(d->d_resp);

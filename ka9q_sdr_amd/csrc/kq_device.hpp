@@ -14,6 +14,8 @@
 
 #include "../../include/ka9q_hip.h"
 
+struct filter_in;  // include/ka9q_hip_compat.h
+
 namespace kq {
 
 enum { FLAG_FLAT = 1, FLAG_ISB = 2, FLAG_STEREO = 4, FLAG_SQUARE = 8 };
@@ -142,8 +144,19 @@ void launch_pl_track(hipStream_t s, const Geom &g, const ChanDev &ch, const Plan
                      int n_fm, int nblocks);
 // single transforms for the compat surface
 void launch_fft_single(hipStream_t s, const float2 *in, float2 *out, int log2n, int sign, const float2 *tw, int tw_log2);
+// the same for 2^15 .. 2^22 points, through global memory (`tmp`: N elements of scratch)
+void launch_fft_large(hipStream_t s, const float2 *in, float2 *out, float2 *tmp, int log2n, int sign, const float2 *tw,
+                      int tw_log2);
+void launch_n0_single(hipStream_t s, const float2 *fdomain, int N, int samprate, float low, float high, float *out);
 void launch_slave_single(hipStream_t s, const float2 *fdomain, const float2 *resp, float2 *out, int N, int Ndec,
                          int in_real, int out_type, const float2 *tw, int tw_log2);
 size_t pruned_table_elems(const Geom &g);
+
+
+// ---- compat surface internals shared with the demodulator entry points (kq_compat.cpp, kq_radio.cpp)
+// Copies the master's device-resident input window (N samples: M-1 history, L new) of the block last transformed to
+// `dst` (device), ordered behind that transform on the compat stream, and waits for it.  Returns N, or -1.
+int compat_snapshot_window(struct filter_in *master, float2 *dst);
+int compat_master_device(void);  // device the compat surface runs on (the calling thread's current device at first use)
 
 }  // namespace kq

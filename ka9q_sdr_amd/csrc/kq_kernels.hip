@@ -960,6 +960,81 @@ void launch_fft_single(hipStream_t s, const float2 *in, float2 *out, int log2n, 
   hipLaunchKernelGGL(k_fft_single, dim3(1), dim3(threads), lds_bytes, s, in, out, log2n, sign, tw, tw_log2);
 }
 
+// Transforms beyond the 16384 points one workgroup holds in LDS (compat masters up to 2^22 points): N = Na * Nb through
+// global memory.  With n = Nb n1 + n2 and k = k1 + Na k2:
+//   X[k1 + Na k2] = sum_n2 W_Nb^{n2 k2} W_N^{n2 k1} sum_n1 x[Nb n1 + n2] W_Na^{n1 k1}
+// k_fft_cols: one workgroup per n2 runs the Na-point transform over n1, applies W_N^{n2 k1}, stores tmp[k1][n2];
+// k_fft_rows: one workgroup per k1 runs the Nb-point transform over n2 and scatters to out[k1 + Na k2].
+__global__ void k_fft_cols(const float2 *__restrict__ in, float2 *__restrict__ tmp, int log2na, int log2nb, int sign,
+                           const float2 *__restrict__ tw, int tw_log2) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  int const na = 1 << log2na, nb = 1 << log2nb, n2 = blockIdx.x;
+  for (int i = threadIdx.x; i < na; i += blockDim.x) lds[bitrev((unsigned)i, log2na)] = in[(size_t)nb * i + n2];
+  if (sign < 0)
+    lds_fft<-1>(lds, log2na, tw, tw_log2);
+  else
+    lds_fft<+1>(lds, log2na, tw, tw_log2);
+  unsigned const half = 1u << (tw_log2 - 1), shift = (unsigned)(tw_log2 - log2na - log2nb);
+  for (int k1 = threadIdx.x; k1 < na; k1 += blockDim.x) {
+    unsigned e = ((unsigned)n2 * (unsigned)k1) << shift;  // exponent on the table's period, < 2^tw_log2
+    float2 w = tw[e & (half - 1)];
+    if (e & half) w = make_float2(-w.x, -w.y);
+    if (sign > 0) w.y = -w.y;
+    tmp[(size_t)k1 * nb + n2] = cmul(lds[k1], w);
+  }
+}
+__global__ void k_fft_rows(const float2 *__restrict__ tmp, float2 *__restrict__ out, int log2na, int log2nb, int sign,
+                           const float2 *__restrict__ tw, int tw_log2) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  int const na = 1 << log2na, nb = 1 << log2nb, k1 = blockIdx.x;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) lds[bitrev((unsigned)i, log2nb)] = tmp[(size_t)k1 * nb + i];
+  if (sign < 0)
+    lds_fft<-1>(lds, log2nb, tw, tw_log2);
+  else
+    lds_fft<+1>(lds, log2nb, tw, tw_log2);
+  for (int k2 = threadIdx.x; k2 < nb; k2 += blockDim.x) out[(size_t)k1 + (size_t)na * k2] = lds[k2];
+}
+
+void launch_fft_large(hipStream_t s, const float2 *in, float2 *out, float2 *tmp, int log2n, int sign, const float2 *tw,
+                      int tw_log2) {
+  int const log2na = (log2n + 1) / 2, log2nb = log2n - log2na;
+  size_t const lds_a = sizeof(float2) << log2na, lds_b = sizeof(float2) << log2nb;
+  ensure_dynamic_lds((const void *)k_fft_cols, lds_a);
+  ensure_dynamic_lds((const void *)k_fft_rows, lds_b);
+  int const ta = (1 << log2na) >= 1024 ? 256 : 64, tb = (1 << log2nb) >= 1024 ? 256 : 64;
+  hipLaunchKernelGGL(k_fft_cols, dim3(1u << log2nb), dim3(ta), lds_a, s, in, tmp, log2na, log2nb, sign, tw, tw_log2);
+  hipLaunchKernelGGL(k_fft_rows, dim3(1u << log2na), dim3(tb), lds_b, s, tmp, out, log2na, log2nb, sign, tw, tw_log2);
+}
+
+// compute_n0 (radio.c:383-425) on one resident master spectrum (the compat surface and the demodulator entry points)
+__global__ void k_n0_single(const float2 *__restrict__ X, int N, int samprate, float low, float high, float *__restrict__ out) {
+  __shared__ float red_f[16];
+  __shared__ int red_i[16];
+  float avg = INFINITY;
+  for (int iter = 0; iter < 2; iter++) {
+    float acc = 0;
+    int bins = 0;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+      int const k = (n <= N / 2) ? n : n - N;
+      int const prod = (int)((unsigned)k * (unsigned)samprate);  // the reference's 32-bit product, wrap included
+      float const f = (float)prod / N;
+      if (f >= low && f <= high) continue;
+      float const p = cnrm(X[n]);
+      if (p < avg * 2) {
+        acc += p;
+        bins++;
+      }
+    }
+    block_sum_fi(acc, bins, red_f, red_i);
+    avg = acc / bins;
+  }
+  if (threadIdx.x == 0) *out = (float)(avg / (2.0 * N * samprate));
+}
+
+void launch_n0_single(hipStream_t s, const float2 *fdomain, int N, int samprate, float low, float high, float *out) {
+  hipLaunchKernelGGL(k_n0_single, dim3(1), dim3(1024), 0, s, fdomain, N, samprate, low, high, out);
+}
+
 // One slave execution on a resident master spectrum: all four in/out type combinations of
 // filter.c:206-250.  out: N_dec float2 (complex out) or N_dec floats packed in float2[N_dec/2] (real out).
 __global__ void k_slave_single(const float2 *__restrict__ X, const float2 *__restrict__ H, float2 *__restrict__ out, int N,

@@ -46,6 +46,24 @@ def test_compat_symbols_exported(lib):
     assert C.c_float.in_dll(lib, "Kaiser_beta").value == 3.0     # filter.c:279
 
 
+def test_radio_thread_entry_points_exported(lib):
+    """radio.h:235-237: the three thread entry points radio.c's Demodtab[] binds, plus the library's compute_n0."""
+    decl = _declared("ka9q_hip_radio.h")
+    for n in ("demod_fm", "demod_am", "demod_linear", "kq_compat_compute_n0"):
+        assert n in decl
+        assert hasattr(lib, n), "libka9q_hip.so does not export %s" % n
+    # the two hand-off functions stay with the host program (audio.c:32,82): referenced weakly, never defined here
+    assert {"send_mono_output", "send_stereo_output"} <= decl
+    import subprocess
+    syms = subprocess.run(["nm", "-D", kq.library_path()], capture_output=True, text=True, check=True).stdout
+    for n in ("send_mono_output", "send_stereo_output"):
+        assert re.search(r"^\s+w %s$" % n, syms, flags=re.M), "%s must be a weak undefined reference" % n
+    # a NULL argument returns at once (no thread state, no device work)
+    lib.demod_am.restype = C.c_void_p
+    lib.demod_am.argtypes = [C.c_void_p]
+    assert lib.demod_am(None) is None
+
+
 def test_version_and_errors(lib):
     assert b"gfx950" in lib.kq_version()
     # argument validation happens before any device work

@@ -39,9 +39,14 @@ def lib(gpu):
     return L
 
 
-@pytest.mark.parametrize("in_type,out_type,D", [(1, 1, 4), (1, 2, 4), (1, 3, 4), (1, 1, 16), (3, 3, 1), (3, 1, 1)])
-def test_compat_filter_matches_oracle(lib, in_type, out_type, D):
-    Lb, M = 512, 513
+# (1, 3, 4) -- COMPLEX in, REAL out -- runs first: it reads all N_dec response bins (filter.c:232-234), which a
+# preceding case of the same size would otherwise have left behind in the allocator's recycled block.
+# The last two are the master sizes past one LDS block: cfg 5's N = 65536 (create_filter_input has no size limit,
+# filter.c:54-91) and 2^17.
+@pytest.mark.parametrize("in_type,out_type,D,Lb", [(1, 3, 4, 512), (1, 1, 4, 512), (1, 2, 4, 512), (1, 1, 16, 512),
+                                                    (3, 3, 1, 512), (3, 1, 1, 512), (1, 1, 512, 32768), (1, 2, 64, 65536)])
+def test_compat_filter_matches_oracle(lib, in_type, out_type, D, Lb):
+    M = Lb + 1
     N = Lb + M - 1
     O = ko.lib()
     m = lib.create_filter_input(Lb, M, in_type)

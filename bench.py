@@ -6,9 +6,13 @@ FM/AM/linear demodulators) over one batch of `--blocks` overlap-save blocks for 
 this GPU, with the front-end I/Q already resident in HBM.
 
 Default workload (N=1): BASELINE.json configs[3] per-GPU share = the north_star target shape:
-1024 FM channels, 16384-point overlap-save (L=8192, M=8193), decimate 256, 10 MS/s synthetic I/Q.
+1024 FM channels, 16384-point overlap-save (L=8192, M=8193), decimate 256, 10 MS/s synthetic I/Q,
+with compute_n0 (radio.c:383-425) on every channel-block as the reference's demodulator threads run it
+(fm.c:78-82) -- the full-spectrum forward path.  The same workload without the status-only noise
+estimate (pruned forward transform) is reported beside it as `without_compute_n0`, never as `value`.
 With --gpus N the channels are sharded (1024 per GPU, weak scaling, configs[3] at N=8) and every
-batch of front-end I/Q is broadcast from rank 0 over RCCL (torch.distributed backend "nccl").
+batch of front-end I/Q is broadcast from rank 0 over RCCL (torch.distributed backend "nccl");
+started without torch.distributed.run, `--gpus N` launches its own N ranks.
 
 Prints ONE JSON line on rank 0.
 """
@@ -36,8 +40,9 @@ def parse():
     ap.add_argument("--channels", type=int, default=None, help="channels per GPU (default: the config's)")
     ap.add_argument("--blocks", type=int, default=64, help="overlap-save blocks per step")
     ap.add_argument("--fwd", default="auto", choices=["auto", "full", "pruned"])
-    ap.add_argument("--n0", type=int, default=0, help="1: also run the status-only compute_n0 every block")
-    ap.add_argument("--no-n0-row", action="store_true", help="skip the secondary compute_n0=1 measurement")
+    ap.add_argument("--n0", type=int, default=1, help="1 (default): compute_n0 every block, as the reference does; 0: off")
+    ap.add_argument("--no-n0-row", "--no-second-row", dest="no_second_row", action="store_true",
+                    help="skip the secondary measurement (the same workload without compute_n0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
@@ -46,7 +51,8 @@ def parse():
 
 
 def cpu_baseline(name, geom, plan, iq_host, target_s, compute_n0=0):
-    """Oracle ('port') timed on this box's host cores on a bounded sample of the same workload."""
+    """Oracle ('port') timed on this box's host cores on a bounded sample of the same workload: channel set-up outside
+    the clock, 20 warm-up blocks, then >= 200 timed blocks per channel."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import kq_oracle as ko
@@ -55,16 +61,19 @@ def cpu_baseline(name, geom, plan, iq_host, target_s, compute_n0=0):
     L = geom["L"]
     nchan = min(len(plan), 2 * cores)
     cfgs = [oracle_cfg(p, geom["samprate"], L, geom["M"], geom["D"], compute_n0=compute_n0) for p in plan[:nchan]]
-    nblocks = 4
-    t, _ = ko.cpu_baseline(cfgs, iq_host, nblocks, cores)            # calibration pass
-    rate = nchan * nblocks / t
-    nblocks = int(max(4, min(len(iq_host) // L, target_s * rate / nchan)))
-    t, _ = ko.cpu_baseline(cfgs, iq_host, nblocks, cores)
-    msps = nchan * nblocks * L / t / 1e6
+    avail = len(iq_host) // L
+    t, _ = ko.cpu_baseline(cfgs, iq_host, avail, 2, 8, cores)            # calibration pass
+    rate = nchan * 8 / t
+    timed = int(max(200, target_s * rate / nchan))
+    t, _ = ko.cpu_baseline(cfgs, iq_host, avail, 20, timed, cores)
+    msps = nchan * timed * L / t / 1e6
     return {"value": round(msps, 3), "unit": "Msamples/s (channel-samples)", "cores": cores, "kind": "port",
-            "sample": "%d channels x %d blocks of %s (oracle C restatement, own radix-2 FFT, %s), "
-                      "%d threads, %.1f s" % (nchan, nblocks, name, "compute_n0 every block" if compute_n0 else
-                                              "no compute_n0", cores, t)}
+            "per_core": round(msps / cores, 3),
+            "channels_at_realtime": int(msps * 1e6 / geom["samprate"]),
+            "sample": "%d channels x %d timed blocks (20 warm-up, set-up outside the clock) of %s: oracle C restatement in the "
+                      "reference's structure (per-sample FP64 NCO, full N-point FFT per channel, %s), own radix-4 autosort "
+                      "FFT (no libfftw3f in the image), %d threads, %.1f s" %
+                      (nchan, timed, name, "compute_n0 every block" if compute_n0 else "no compute_n0", cores, t)}
 
 
 def pmc_traffic(config, channels, blocks, fwd):
@@ -85,8 +94,25 @@ def pmc_traffic(config, channels, blocks, fwd):
     return best if best else (None, None)
 
 
+def self_launch(a):
+    """`bench.py --gpus N` started as a plain process: start the N ranks ourselves (one child per GPU through
+    torch.distributed.run) BEFORE anything here touches the GPU, pass rank 0's JSON line through, exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)
     import torch
     import ka9q_sdr_amd as kq
     from ka9q_sdr_amd import workload as wl
@@ -102,9 +128,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (a.gpus, a.gpus))
+    assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (a.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs the MI355X: there is no CPU path to measure"
     dev_index = local_rank % torch.cuda.device_count()   # == local_rank whenever there is a GPU per rank
     torch.cuda.set_device(dev_index)
@@ -119,6 +143,9 @@ def main():
 
     geom = dict(wl.GEOMETRY[a.config])
     L, M, D, fs = geom["L"], geom["M"], geom["D"], geom["samprate"]
+    if L + M - 1 > 16384:
+        a.n0 = 0        # the bank computes compute_n0 inside its 16384-point full-spectrum kernel only (cfg 5: N = 65536)
+        a.no_second_row = True
     C = a.channels or geom["channels"]
     B = a.blocks
     from ka9q_sdr_amd.shard import FrontEndFanout, shard_range
@@ -189,30 +216,34 @@ def main():
     tm2 = bank.timing(reset=True)
     bank.enable_timing(0)
 
-    # Secondary row (1 GPU only): the same workload with the status-only noise estimate of radio.c:383-425 computed
-    # every block, as the reference's demod threads do.  It needs all N bins of every channel's mixed spectrum, so
-    # the bank runs its full-FFT path; reported beside the headline, never as `value`.
+    # Secondary row (1 GPU only): the same workload with compute_n0 switched the other way.  The headline computes
+    # the noise estimate of radio.c:383-425 on every channel-block, as the reference's demod threads do, which needs
+    # all N bins of every channel's mixed spectrum (full forward transform); without it the bank prunes the forward
+    # transform to the N/D bins the slave reads.  Reported beside the headline, never as `value`.
     fwd_used = {1: "full", 2: "pruned"}[bank.fwd_mode]
-    n0_row = None
-    if world == 1 and not a.n0 and not a.no_n0_row:
+    second = None
+    if world == 1 and not a.no_second_row and a.fwd == "auto":
         bank.close()
-        bank = kq.Bank(fs, L, M, D, C, B, device=dev_index, compute_n0=True, fwd_mode=kq.KQ_FWD_AUTO,
+        bank = kq.Bank(fs, L, M, D, C, B, device=dev_index, compute_n0=not a.n0, fwd_mode=kq.KQ_FWD_AUTO,
                        stream=stream.cuda_stream)
         for p in plan:
             bank.add_channel(wl.bank_channel_config(p))
-        n0_steps = max(2, min(20, a.steps))
+        fwd2 = {1: "full", 2: "pruned"}[bank.fwd_mode]
+        n2 = max(2, min(50, a.steps))
         for k in range(2 + spin // 4):     # setting the bank up again left the GPU idle: back to sustained clocks
             bank.process_resident(bufs[0].data_ptr(), B)
         torch.cuda.synchronize()
+        bank.enable_timing(1)
+        bank.timing(reset=True)
         t2 = time.perf_counter()
-        for k in range(n0_steps):
+        for k in range(n2):
             bank.process_resident(bufs[0].data_ptr(), B)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t2) / n0_steps
-        n0_row = {"value": round(C * B * L / dt / 1e6, 1), "unit": "Msamples/s (channel-samples)",
-                  "ms_per_step": round(dt * 1e3, 4), "steps": n0_steps,
-                  "note": "compute_n0 (radio.c:383-425, status only) on every channel-block: full N-point spectrum per "
-                          "channel, fwd=full"}
+        dt = (time.perf_counter() - t2) / n2
+        tm_b = bank.timing(reset=True)
+        second = {"compute_n0": int(not a.n0), "fwd": fwd2, "value": round(C * B * L / dt / 1e6, 1),
+                  "unit": "Msamples/s (channel-samples)", "ms_per_step": round(dt * 1e3, 4), "steps": n2,
+                  "kernel_ms": round(tm_b["filter_ms"] / max(1, tm_b["filter_launches"]), 4)}
 
     if rank == 0:
         total_ch = C * world
@@ -223,9 +254,36 @@ def main():
         for p in plan:
             per_kind[p["demod"]] = per_kind.get(p["demod"], 0) + 1
         abytes = sum(wl.algorithmic_bytes(geom, p["demod"], p.get("channels", 1) == 2) for p in plan) * B
+
+        def flops(n0, pruned):
+            return sum(wl.algorithmic_flops(geom, p["demod"], bool(p.get("doppler", 0.0)), n0, pruned) for p in plan) * B
+
+        def roofline(k_ms, n0, fwd_name, demod_ms=None):
+            """SURVEY 8d's HBM figure (algorithmic bytes / kernel time; the shared input makes it exceed what crosses the
+            memory side) and, beside it, the bounds that do bind: vector-ALU rate against the 157.3 TFLOP/s FP32 peak,
+            and the HBM traffic the PMC counters measured."""
+            traffic, src = pmc_traffic(a.config, C, B, fwd_name)
+            ach = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+            fl = flops(n0, fwd_name == "pruned")
+            r = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                 "traffic": traffic, "traffic_source": src,
+                 "kernel": "pre-detection filter (NCO mix + forward FFT%s + response + IFFT), %s path" %
+                           (" + compute_n0" if n0 else "", fwd_name),
+                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": abytes,
+                 "algorithmic_flops_per_launch": int(fl),
+                 "valu_tflops": round(fl / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else 0.0,
+                 "valu_peak_tflops": 157.3,
+                 "valu_frac": round(fl / (k_ms * 1e-3) / 157.3e12, 4) if k_ms > 0 else 0.0,
+                 "hbm_frac_measured": round(traffic / (k_ms * 1e-3) / 8e12, 4) if (traffic and k_ms > 0) else None,
+                 "note": "frac = algorithmic bytes (SURVEY 8d: the N-sample window counted once per channel) / kernel time / "
+                         "8 TB/s; every channel reads the one shared input through L2, so the bytes that cross the memory "
+                         "side (hbm_frac_measured, from the FETCH_SIZE / WRITE_SIZE passes in profiles/) are ~1 % of peak and "
+                         "HBM is not what limits the kernel; valu_frac prices the same launch against the FP32 vector peak."}
+            if demod_ms is not None:
+                r["demod_ms"] = round(demod_ms, 4)
+            return r
+
         k_ms = tm["filter_ms"] / max(1, tm["filter_launches"])
-        traffic, traffic_src = pmc_traffic(a.config, C, B, fwd_used)
-        achieved = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "input Msamples/s + channels @ real-time, 16384-pt overlap-save",
             "value": round(value, 1),
@@ -245,25 +303,15 @@ def main():
                 "channels_at_realtime": int(total_ch * front_end_msps * 1e6 / fs),
                 "parallelism": "channels sharded x%d, front-end I/Q broadcast over RCCL" % world if world > 1 else "1 GPU",
             },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "pre-detection filter (mix + forward FFT + response + IFFT)",
-                "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": abytes,
-                "demod_ms": round(tm2["demod_ms"] / max(1, tm2["filter_launches"]), 4),
-                "note": "algorithmic bytes count the N-sample window once per channel (SURVEY 8d); all channels share one "
-                        "input, served from L2 / LDS, so HBM traffic is far below them and frac can exceed 1. The kernel's "
-                        "own limiter is vector-ALU issue (profiles/r01/pmc_sq_*.json).",
-            },
+            "roofline": roofline(k_ms, bool(a.n0), fwd_used, tm2["demod_ms"] / max(1, tm2["filter_launches"])),
         }
-        if n0_row:
-            n0_row["roofline_frac_of_step"] = round(abytes / (n0_row["ms_per_step"] * 1e-3) / 8e12, 4)
-            n0_row["traffic"], n0_row["traffic_source"] = pmc_traffic(a.config, C, B, "full")
-            out["with_compute_n0"] = n0_row
+        if second:
+            second["roofline"] = roofline(second["kernel_ms"], bool(second["compute_n0"]), second["fwd"])
+            second["note"] = ("the same workload %s compute_n0 (radio.c:383-425, status only): the bank then runs its %s "
+                              "forward path" % ("with" if second["compute_n0"] else "without", second["fwd"]))
+            out["with_compute_n0" if second["compute_n0"] else "without_compute_n0"] = second
         if not a.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(a.config, geom, plan, iq_host[M - 1:], a.cpu_seconds)
-            if n0_row:  # each GPU row beside the CPU path configured the same way
-                n0_row["cpu_baseline"] = cpu_baseline(a.config, geom, plan, iq_host[M - 1:], a.cpu_seconds / 2, compute_n0=1)
+            out["cpu_baseline"] = cpu_baseline(a.config, geom, plan, iq_host[M - 1:], a.cpu_seconds, compute_n0=a.n0)
         print(json.dumps(out), flush=True)
     bank.close()
     if dist:

@@ -105,6 +105,24 @@ def algorithmic_bytes(name_or_geom, demod="fm", stereo=False):
     return b
 
 
+def algorithmic_flops(name_or_geom, demod="fm", doppler=False, compute_n0=True, pruned=False):
+    """Floating-point operations per channel-block (secondary row): NCO mix 8 L (+ 8 L with Doppler),
+    forward transform 5 N log2 N, response multiply 6 N_dec, inverse 5 N_dec log2 N_dec, demodulator ~ 30 olen;
+    compute_n0 adds 3 N for the bin powers and 2 N per pass.  The pruned forward path computes only the N_dec bins
+    the slave reads: 5 N log2 N_dec + 14 N."""
+    import math
+    g = GEOMETRY[name_or_geom] if isinstance(name_or_geom, str) else name_or_geom
+    N = g["L"] + g["M"] - 1
+    ndec = N // g["D"]
+    olen = g["L"] // g["D"]
+    mix = 8 * N * (2 if doppler else 1)     # the kernels mix the whole N-sample window of each block
+    fwd = (5 * N * math.log2(ndec) + 14 * N) if pruned else 5 * N * math.log2(N)
+    f = mix + fwd + 6 * ndec + 5 * ndec * math.log2(ndec) + 30 * olen
+    if compute_n0 and not pruned:
+        f += 3 * N + 2 * 2 * N
+    return f
+
+
 def bank_channel_config(p):
     """Plan entry -> kq_channel_config for kq_bank_add_channel."""
     from . import bank as _b

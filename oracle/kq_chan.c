@@ -869,57 +869,90 @@ int kqo_pcm_rtp(kqo_out_rtp *o, const float *audio, int nfloats, int stereo, uns
   return packets;
 }
 
-/* ---- multi-channel CPU baseline (bench.py cpu_baseline leg only) ---- */
+/* ---- multi-channel CPU baseline (bench.py cpu_baseline leg only) ----
+ * The reference runs one `radio` process per channel; here `nthreads` workers share the channels and walk them block
+ * by block, as a real-time receiver would.  Channel set-up (response design, transform plans) and `warm` blocks per
+ * channel happen before the clock starts; `timed` blocks per channel are timed between two barriers.  The input
+ * holds nblocks_avail blocks and is cycled. */
 struct bench_arg {
   const kqo_chan_cfg *cfgs;
-  int first, last, nblocks;
+  int first, last, nblocks_avail, warm, timed;
   const float *iq;
   double checksum;
+  pthread_barrier_t *bar;
 };
 
 static void *bench_worker(void *p){
   struct bench_arg *a = p;
-  double sum = 0;
-  for(int ch = a->first; ch < a->last; ch++){
-    kqo_chan *c = kqo_chan_create(&a->cfgs[ch]);
-    unsigned const L = a->cfgs[ch].L;
-    float *audio = malloc(sizeof(float) * 2 * (kqo_chan_olen(c) + 1));
-    for(int b = 0; b < a->nblocks; b++){
-      kqo_status st;
-      kqo_chan_block(c, a->iq + (size_t)2 * L * b, audio, &st, NULL, NULL);
-      for(int n = 0; n < st.nout; n++)
-        sum += audio[n];
-    }
-    free(audio);
-    kqo_chan_destroy(c);
+  int const n = a->last - a->first;
+  kqo_chan **c = calloc((size_t)(n > 0 ? n : 1), sizeof(*c));
+  unsigned L = 0, omax = 0;
+  for(int i = 0; i < n; i++){
+    c[i] = kqo_chan_create(&a->cfgs[a->first + i]);
+    L = a->cfgs[a->first + i].L;
+    if(kqo_chan_olen(c[i]) > omax)
+      omax = kqo_chan_olen(c[i]);
   }
+  float *audio = malloc(sizeof(float) * 2 * (omax + 1));
+  double sum = 0;
+  pthread_barrier_wait(a->bar);                         /* everyone is set up */
+  for(int b = 0; b < a->warm + a->timed; b++){
+    if(b == a->warm)
+      pthread_barrier_wait(a->bar);                     /* the clock starts behind this one */
+    const float *blk = a->iq + (size_t)2 * L * (size_t)(b % a->nblocks_avail);
+    for(int i = 0; i < n; i++){
+      kqo_status st;
+      kqo_chan_block(c[i], blk, audio, &st, NULL, NULL);
+      for(int k = 0; k < st.nout; k++)
+        sum += audio[k];
+    }
+  }
+  pthread_barrier_wait(a->bar);                         /* ... and stops behind this one */
+  free(audio);
+  for(int i = 0; i < n; i++)
+    kqo_chan_destroy(c[i]);
+  free(c);
   a->checksum = sum;
   return NULL;
 }
 
-double kqo_bench_channels(const kqo_chan_cfg *cfgs, int nchan, const float *iq, int nblocks, int nthreads, double *checksum){
+double kqo_bench_channels(const kqo_chan_cfg *cfgs, int nchan, const float *iq, int nblocks_avail, int warm, int timed,
+                          int nthreads, int fast_fft, double *checksum){
   if(nthreads < 1)
     nthreads = 1;
   if(nthreads > nchan)
     nthreads = nchan;
+  if(nblocks_avail < 1 || timed < 1)
+    return -1;
+  kqo_fft_set_fast(fast_fft);
   pthread_t *tid = malloc(sizeof(pthread_t) * nthreads);
   struct bench_arg *args = calloc(nthreads, sizeof(*args));
-  struct timespec t0, t1;
-  clock_gettime(CLOCK_MONOTONIC, &t0);
+  pthread_barrier_t bar;
+  pthread_barrier_init(&bar, NULL, (unsigned)nthreads + 1);
   for(int t = 0; t < nthreads; t++){
     args[t].cfgs = cfgs;
     args[t].first = (int)((long long)nchan * t / nthreads);
     args[t].last = (int)((long long)nchan * (t + 1) / nthreads);
-    args[t].nblocks = nblocks;
+    args[t].nblocks_avail = nblocks_avail;
+    args[t].warm = warm;
+    args[t].timed = timed;
     args[t].iq = iq;
+    args[t].bar = &bar;
     pthread_create(&tid[t], NULL, bench_worker, &args[t]);
   }
+  struct timespec t0, t1;
+  pthread_barrier_wait(&bar);
+  pthread_barrier_wait(&bar);
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  pthread_barrier_wait(&bar);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
   double sum = 0;
   for(int t = 0; t < nthreads; t++){
     pthread_join(tid[t], NULL);
     sum += args[t].checksum;
   }
-  clock_gettime(CLOCK_MONOTONIC, &t1);
+  kqo_fft_set_fast(0);
+  pthread_barrier_destroy(&bar);
   if(checksum)
     *checksum = sum;
   free(tid);

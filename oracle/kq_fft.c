@@ -18,6 +18,8 @@ struct kqo_fft {
   float complex *tw;      /* tw[k] = exp(-2*pi*i*k/n), k < n/2 */
   unsigned *rev;          /* bit reversal */
   float complex *scratch; /* n, for r2c/c2r and in-place safety */
+  float *work;            /* 4 n floats: split re / im ping-pong buffers of the fast variant */
+  float *twr, *twi;       /* n floats each: exp(-2*pi*i*k/n) split, k < n (the radix-4 pass reads up to 3 j m < n) */
 };
 
 kqo_fft *kqo_fft_create(unsigned n){
@@ -30,6 +32,15 @@ kqo_fft *kqo_fft_create(unsigned n){
   p->tw = malloc(sizeof(float complex) * (n / 2 + 1));
   p->rev = malloc(sizeof(unsigned) * n);
   p->scratch = malloc(sizeof(float complex) * n);
+  p->work = malloc(sizeof(float) * 4 * n);
+  p->twr = malloc(sizeof(float) * n);
+  p->twi = malloc(sizeof(float) * n);
+  for(unsigned k = 0; k < n; k++){
+    double s, c;
+    sincos(-2.0 * M_PI * (double)k / (double)n, &s, &c);
+    p->twr[k] = (float)c;
+    p->twi[k] = (float)s;
+  }
   for(unsigned k = 0; k < n / 2 + 1; k++){
     double s, c;
     sincos(-2.0 * M_PI * (double)k / (double)n, &s, &c);
@@ -51,6 +62,9 @@ void kqo_fft_destroy(kqo_fft *p){
   free(p->tw);
   free(p->rev);
   free(p->scratch);
+  free(p->work);
+  free(p->twr);
+  free(p->twi);
   free(p);
 }
 
@@ -59,8 +73,100 @@ static inline float complex cmulf_(float complex a, float complex b){
   return (ar * br - ai * bi) + (ar * bi + ai * br) * _Complex_I;
 }
 
+/* ---- fast variant, used by the CPU-baseline leg of bench.py only (kqo_fft_set_fast(1)) ----
+ * The parity path keeps the plain radix-2 transform above and below: its rounding is what the committed oracle
+ * vectors were generated with.  The baseline times the same chain with a radix-4 (plus one radix-2 pass when
+ * log2 n is odd) Stockham autosort transform: no bit-reversal pass, unit-stride inner loops over split re / im
+ * arrays that the compiler vectorises (function clones for AVX2 / AVX-512 are picked at load time).  Same
+ * conventions, results equal to the plain transform to float rounding (tests/test_oracle_filter.py). */
+static int Fast;
+void kqo_fft_set_fast(int on){ Fast = on; }
+
+#define KQO_CLONES __attribute__((target_clones("avx512f", "avx2,fma", "default")))
+
+/* one radix-4 pass: n = 4 * l * m; x[(4 j + q) * m + k] -> y[(j + q l) * m + k], twiddles w^{j m q} */
+KQO_CLONES static void pass4(unsigned l, unsigned m, const float *restrict xr, const float *restrict xi, float *restrict yr,
+                             float *restrict yi, const float *restrict twr, const float *restrict twi, unsigned tstride, float sgn){
+  for(unsigned j = 0; j < l; j++){
+    float const w1r = twr[j * tstride], w1i = sgn * twi[j * tstride];
+    float const w2r = twr[2 * j * tstride], w2i = sgn * twi[2 * j * tstride];
+    float const w3r = twr[3 * j * tstride], w3i = sgn * twi[3 * j * tstride];
+    const float *ar = xr + (size_t)4 * j * m, *ai = xi + (size_t)4 * j * m;
+    float *o0r = yr + (size_t)j * m, *o0i = yi + (size_t)j * m;
+    float *o1r = o0r + (size_t)l * m, *o1i = o0i + (size_t)l * m;
+    float *o2r = o1r + (size_t)l * m, *o2i = o1i + (size_t)l * m;
+    float *o3r = o2r + (size_t)l * m, *o3i = o2i + (size_t)l * m;
+    for(unsigned k = 0; k < m; k++){
+      float const a0r = ar[k], a0i = ai[k];
+      float const b1r = ar[m + k], b1i = ai[m + k], b2r = ar[2 * m + k], b2i = ai[2 * m + k], b3r = ar[3 * m + k], b3i = ai[3 * m + k];
+      float const a1r = b1r * w1r - b1i * w1i, a1i = b1r * w1i + b1i * w1r;
+      float const a2r = b2r * w2r - b2i * w2i, a2i = b2r * w2i + b2i * w2r;
+      float const a3r = b3r * w3r - b3i * w3i, a3i = b3r * w3i + b3i * w3r;
+      float const s02r = a0r + a2r, s02i = a0i + a2i, d02r = a0r - a2r, d02i = a0i - a2i;
+      float const s13r = a1r + a3r, s13i = a1i + a3i, d13r = a1r - a3r, d13i = a1i - a3i;
+      o0r[k] = s02r + s13r;
+      o0i[k] = s02i + s13i;
+      o2r[k] = s02r - s13r;
+      o2i[k] = s02i - s13i;
+      /* times -i (forward) or +i (backward): sgn = +1 forward */
+      o1r[k] = d02r + sgn * d13i;
+      o1i[k] = d02i - sgn * d13r;
+      o3r[k] = d02r - sgn * d13i;
+      o3i[k] = d02i + sgn * d13r;
+    }
+  }
+}
+KQO_CLONES static void pass2(unsigned l, unsigned m, const float *restrict xr, const float *restrict xi, float *restrict yr,
+                             float *restrict yi, const float *restrict twr, const float *restrict twi, unsigned tstride, float sgn){
+  for(unsigned j = 0; j < l; j++){
+    float const wr = twr[j * tstride], wi = sgn * twi[j * tstride];
+    const float *ar = xr + (size_t)2 * j * m, *ai = xi + (size_t)2 * j * m;
+    float *o0r = yr + (size_t)j * m, *o0i = yi + (size_t)j * m, *o1r = o0r + (size_t)l * m, *o1i = o0i + (size_t)l * m;
+    for(unsigned k = 0; k < m; k++){
+      float const br = ar[m + k] * wr - ai[m + k] * wi, bi = ar[m + k] * wi + ai[m + k] * wr;
+      o0r[k] = ar[k] + br;
+      o0i[k] = ai[k] + bi;
+      o1r[k] = ar[k] - br;
+      o1i[k] = ai[k] - bi;
+    }
+  }
+}
+
+/* decimation in time, Stockham: after the pass with sub-transform count l the data holds l-point transforms of the
+ * m = n / (r l) interleaved sub-sequences */
+static void fft_fast(const kqo_fft *p, const float complex *in, float complex *out, int sign){
+  unsigned const n = p->n;
+  float *ar = p->work, *ai = ar + n, *br = ai + n, *bi = br + n;
+  for(unsigned i = 0; i < n; i++){
+    ar[i] = crealf(in[i]);
+    ai[i] = cimagf(in[i]);
+  }
+  float const sgn = sign > 0 ? -1.f : 1.f;   /* the table holds the forward twiddles */
+  unsigned l = 1, m = n;
+  /* x[n1*m' + k]: at each pass split the current length-m sub-sequences by the radix r: m' = m / r */
+  while(m > 1){
+    unsigned const r = (m % 4 == 0) ? 4 : 2;
+    m /= r;
+    /* twiddle exponent: w_{r l}^{j q} = W_n^{j q n / (r l)} = W_n^{j q m} */
+    if(r == 4)
+      pass4(l, m, ar, ai, br, bi, p->twr, p->twi, m, sgn);
+    else
+      pass2(l, m, ar, ai, br, bi, p->twr, p->twi, m, sgn);
+    float *t;
+    t = ar; ar = br; br = t;
+    t = ai; ai = bi; bi = t;
+    l *= r;
+  }
+  for(unsigned i = 0; i < n; i++)
+    out[i] = ar[i] + ai[i] * _Complex_I;
+}
+
 void kqo_fft_c2c(const kqo_fft *p, const float complex *in, float complex *out, int sign){
   unsigned const n = p->n;
+  if(Fast && n >= 4){
+    fft_fast(p, in, out, sign);
+    return;
+  }
   if(in == out){
     for(unsigned i = 0; i < n; i++){
       unsigned r = p->rev[i];

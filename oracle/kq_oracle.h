@@ -36,6 +36,8 @@
 typedef struct kqo_fft kqo_fft;
 kqo_fft *kqo_fft_create(unsigned n);           /* n must be a power of two >= 1 */
 void kqo_fft_destroy(kqo_fft *p);
+/* 1: kqo_fft_c2c (and r2c / c2r through it) use the radix-4 autosort variant -- CPU-baseline timing only */
+void kqo_fft_set_fast(int on);
 /* out-of-place or in-place (in == out) complex transform; sign -1 forward, +1 backward */
 void kqo_fft_c2c(const kqo_fft *p, const float complex *in, float complex *out, int sign);
 /* real -> n/2+1 complex bins (forward) */
@@ -255,9 +257,11 @@ int kqo_pcm_rtp(kqo_out_rtp *o, const float *audio, int nfloats, int stereo, uns
 /* compute_n0 on a bare spectrum (radio.c:383-425) */
 float kqo_compute_n0(const float complex *fdomain, unsigned N, int samprate, float low, float high);
 
-/* Multi-channel CPU baseline: nchan channels over `nthreads` pthreads, each channel fed the same
- * nblocks*L input; returns wall seconds (used only by bench.py cpu_baseline). */
-double kqo_bench_channels(const kqo_chan_cfg *cfgs, int nchan, const float *iq, int nblocks, int nthreads,
-                          double *checksum);
+/* Multi-channel CPU baseline (used only by bench.py cpu_baseline): nchan channels over `nthreads` pthreads; set-up and
+ * `warm` blocks per channel untimed, then `timed` blocks per channel between two barriers; the nblocks_avail blocks of
+ * `iq` are cycled.  fast_fft: time with the radix-4 autosort transform instead of the parity path's radix-2 one.
+ * Returns the timed wall seconds. */
+double kqo_bench_channels(const kqo_chan_cfg *cfgs, int nchan, const float *iq, int nblocks_avail, int warm, int timed,
+                          int nthreads, int fast_fft, double *checksum);
 
 #endif

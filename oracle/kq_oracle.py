@@ -151,7 +151,9 @@ def lib():
     L.kqo_pcm_block.restype = C.c_int
     L.kqo_pcm_rtp.argtypes = [C.POINTER(OutRtp), fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(C.c_int)]
     L.kqo_bench_channels.restype = C.c_double
-    L.kqo_bench_channels.argtypes = [C.POINTER(ChanCfg), C.c_int, fp, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.kqo_bench_channels.argtypes = [C.POINTER(ChanCfg), C.c_int, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(C.c_double)]
+    L.kqo_fft_set_fast.argtypes = [C.c_int]
     _LIB = L
     return L
 
@@ -527,10 +529,12 @@ def pcm_block(audio):
     return out, mask.value, n
 
 
-def cpu_baseline(cfgs, iq, nblocks, nthreads):
-    """Times nchan oracle channels over nthreads host threads; returns (seconds, checksum)."""
+def cpu_baseline(cfgs, iq, nblocks_avail, warm, timed, nthreads, fast_fft=True):
+    """Times nchan oracle channels over nthreads host threads: `timed` blocks per channel after `warm` untimed ones,
+    channel set-up outside the clock; returns (seconds, checksum)."""
     arr = (ChanCfg * len(cfgs))(*cfgs)
     iq = np.ascontiguousarray(iq, np.complex64)
     cs = C.c_double()
-    t = lib().kqo_bench_channels(arr, len(cfgs), _fp(iq.view(np.float32)), nblocks, nthreads, C.byref(cs))
+    t = lib().kqo_bench_channels(arr, len(cfgs), _fp(iq.view(np.float32)), nblocks_avail, warm, timed, nthreads,
+                                 int(fast_fft), C.byref(cs))
     return t, cs.value

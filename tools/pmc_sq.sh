@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of one kernel (substring match), one small pass per counter group (no trace domains with --pmc).
-#   bash tools/pmc_sq.sh k_pruned_resident bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-n0-row
+#   bash tools/pmc_sq.sh k_pruned_resident bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-second-row
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 K=$1; shift

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round profile: rocprofv3 --kernel-trace --stats of the default bench (pruned headline + compute_n0 row), of the
-# full-spectrum path, of the half-band cascade, and the FETCH_SIZE / WRITE_SIZE PMC passes of the headline kernel.
+# Round profile: rocprofv3 --kernel-trace --stats of the default bench (compute_n0 headline + the pruned row), of the
+# other configurations, of the half-band cascade, and the FETCH_SIZE / WRITE_SIZE PMC passes of the headline kernel.
 # Usage on the GPU box: bash tools/profile_round.sh r01     (writes gpurun_out/profiles_<tag>/; copy into profiles/<tag>/)
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
@@ -13,21 +13,22 @@ run_stats() {  # name, program args...
   local f=$(find $OUT/raw_$name -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${name}_kernel_stats.csv
 }
-run_stats pruned_cfg4 $R/bench.py --steps 10 --cpu-seconds 4
-run_stats full_n0_cfg4 $R/bench.py --steps 5 --n0 1 --no-cpu-baseline
-run_stats full_cfg2 $R/bench.py --steps 10 --config cfg2 --no-cpu-baseline --no-n0-row
-run_stats pruned_cfg3 $R/bench.py --steps 10 --config cfg3 --no-cpu-baseline --no-n0-row
-run_stats stream_cfg5 $R/bench.py --steps 10 --config cfg5 --blocks 16 --no-cpu-baseline --no-n0-row
+run_stats full_n0_cfg4 $R/bench.py --steps 10 --cpu-seconds 4
+run_stats pruned_cfg4 $R/bench.py --steps 10 --n0 0 --no-cpu-baseline --no-second-row
+run_stats full_n0_cfg2 $R/bench.py --steps 10 --config cfg2 --no-cpu-baseline --no-second-row
+run_stats full_n0_cfg3 $R/bench.py --steps 10 --config cfg3 --no-cpu-baseline --no-second-row
+run_stats pruned_cfg3 $R/bench.py --steps 10 --config cfg3 --n0 0 --no-cpu-baseline --no-second-row
+run_stats stream_cfg5 $R/bench.py --steps 10 --config cfg5 --blocks 16 --no-cpu-baseline --no-second-row
 run_stats decim_log6 $R/tools/bench_decim.py
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $OUT/raw_pmc_$c -o pmc_$c --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --spinup 0 --no-cpu-baseline --no-n0-row > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c -d $OUT/raw_pmc_$c -o pmc_$c --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --spinup 0 --n0 0 --no-cpu-baseline --no-second-row > $OUT/pmc_$c.log 2>&1
 done
 F=$(find $OUT/raw_pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 W=$(find $OUT/raw_pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python3 $R/tools/pmc_summary.py $F $W $OUT/pmc_pruned_cfg4.json k_pruned cfg4 1024 64 pruned > /dev/null
 # the same two passes for the full-spectrum kernel with compute_n0 (the bench's second row)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $OUT/raw_pmcn0_$c -o pmcn0_$c --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --spinup 0 --n0 1 --no-cpu-baseline > $OUT/pmcn0_$c.log 2>&1
+  rocprofv3 --pmc $c -d $OUT/raw_pmcn0_$c -o pmcn0_$c --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --spinup 0 --no-cpu-baseline --no-second-row > $OUT/pmcn0_$c.log 2>&1
 done
 F=$(find $OUT/raw_pmcn0_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 W=$(find $OUT/raw_pmcn0_WRITE_SIZE -name "*counter_collection.csv" | head -1)

@@ -244,6 +244,33 @@ int kq_bank_get_timing(kq_bank *bank, kq_timing *t, int reset);
 /* Which forward path the bank resolved to (enum kq_fwd_mode, never AUTO) */
 int kq_bank_fwd_mode(const kq_bank *bank);
 
+/* ---- multi-GPU: channel shards and the front-end fan-out ------------------------------------------------------------
+ * The reference runs one `radio` process per channel and fans the front-end I/Q stream out to them by UDP multicast
+ * (multicast.c:143-237, README.md:470-477).  Here one process (or thread) per GPU owns a contiguous range of the
+ * channels and every batch of front-end samples is broadcast from the ingest rank over RCCL / xGMI (ncclBroadcast on a
+ * side stream, two slots so that batch k+1 travels while batch k is processed).  Channels are independent: this is
+ * the only exchange on the path.  librccl is loaded on first use.
+ *
+ *   rank `root`:  kq_fanout_unique_id(id)  -> hand the 128 bytes to the other ranks (file, socket, MPI ...)
+ *   every rank:   f = kq_fanout_create(device, rank, world, root, id, samples_per_batch);
+ *                 kq_shard_range(total_channels, world, rank, &first, &count) -> add channels first .. first+count-1
+ *   per batch k:  slot = k & 1
+ *                 kq_fanout_post(f, slot, iq, n, is_device)      queue the broadcast (iq: read on the root rank only)
+ *                 p = kq_fanout_acquire(f, slot, bank_stream, &n)                  bank_stream waits for the batch
+ *                 kq_bank_process_resident(bank, p, nblocks)                       (window layout: M-1 history + blocks)
+ *                 kq_fanout_release(f, slot, bank_stream)                          the slot may be overwritten after this
+ * `bank_stream` is the hipStream_t the bank was created on (kq_bank_config.stream). */
+#define KQ_FANOUT_ID_BYTES 128
+typedef struct kq_fanout kq_fanout;
+/* contiguous, balanced range of `rank`: the first total % world ranks hold one channel more */
+int kq_shard_range(unsigned total, unsigned world, unsigned rank, unsigned *first, unsigned *count);
+int kq_fanout_unique_id(void *id128);
+kq_fanout *kq_fanout_create(int device, int rank, int world, int root, const void *id128, size_t max_samples);
+int kq_fanout_destroy(kq_fanout *f);
+int kq_fanout_post(kq_fanout *f, int slot, const void *iq_cf32, size_t nsamples, int src_is_device);
+const void *kq_fanout_acquire(kq_fanout *f, int slot, void *consumer_stream, size_t *nsamples);
+int kq_fanout_release(kq_fanout *f, int slot, void *consumer_stream);
+
 /* --- front-end half-band decimator cascade ---------------------------------------------------
  * What hackrf.c:260-330 does to every block of raw A/D samples before they reach the channel filter: rotate by
  * +offset*Fs/4 (hackrf.c:272-291), run log_decimate half-band stages -- hb3_block (decimate.c:146-160) while the

@@ -1,0 +1,200 @@
+// kq_fanout.cpp -- front-end I/Q fan-out for a C host on several GPUs (include/ka9q_hip.h, kq_fanout_*).
+//
+// The reference fans the front-end stream out to its one-process-per-channel receivers by UDP multicast
+// (multicast.c:143-237).  Here the channels are sharded over one process (or thread) per GPU and every batch of
+// front-end samples is broadcast from the ingest rank with ncclBroadcast -- RCCL over xGMI -- on a side stream,
+// double buffered: batch k+1 travels while batch k is processed.  Channels are independent, so this is the only
+// exchange on the path.  Same protocol as ka9q_sdr_amd/shard.py (which bench.py drives through torch.distributed).
+//
+// librccl is loaded on first use (dlopen), so that a single-GPU host never maps it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/ka9q_hip.h"
+#include "kq_device.hpp"
+
+void kq_internal_set_error(const char *fmt, ...);
+
+namespace {
+
+struct Rccl {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+Rccl &rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.handle) break;
+    }
+    if (!r.handle) return;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+    r.Broadcast = (decltype(r.Broadcast))dlsym(r.handle, "ncclBroadcast");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Broadcast && r.GetErrorString;
+  });
+  return r;
+}
+
+}  // namespace
+
+struct kq_fanout {
+  int device = 0, rank = 0, world = 1, root = 0;
+  size_t max_samples = 0;
+  ncclComm_t comm = nullptr;
+  hipStream_t side = nullptr;
+  float2 *buf[2] = {nullptr, nullptr};
+  hipEvent_t ready[2] = {nullptr, nullptr}, freed[2] = {nullptr, nullptr};
+  size_t count[2] = {0, 0};
+};
+
+extern "C" {
+
+int kq_shard_range(unsigned total, unsigned world, unsigned rank, unsigned *first, unsigned *count) {
+  if (world < 1 || rank >= world || !first || !count) {
+    kq_internal_set_error("kq_shard_range: bad world / rank");
+    return -1;
+  }
+  unsigned const base = total / world, extra = total % world;
+  *first = rank * base + (rank < extra ? rank : extra);
+  *count = base + (rank < extra ? 1u : 0u);
+  return 0;
+}
+
+int kq_fanout_unique_id(void *id128) {
+  if (!id128) return -1;
+  Rccl &r = rccl();
+  if (!r.ok) {
+    kq_internal_set_error("librccl not available: %s", dlerror());
+    return -1;
+  }
+  ncclUniqueId id;
+  ncclResult_t const e = r.GetUniqueId(&id);
+  if (e != ncclSuccess) {
+    kq_internal_set_error("ncclGetUniqueId: %s", r.GetErrorString(e));
+    return -1;
+  }
+  static_assert(sizeof id == KQ_FANOUT_ID_BYTES, "ncclUniqueId size");
+  memcpy(id128, &id, sizeof id);
+  return 0;
+}
+
+kq_fanout *kq_fanout_create(int device, int rank, int world, int root, const void *id128, size_t max_samples) {
+  if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || max_samples == 0 || (world > 1 && !id128)) {
+    kq_internal_set_error("kq_fanout_create: bad arguments");
+    return nullptr;
+  }
+  kq::DeviceScope scope(device);
+  kq_fanout *f = new kq_fanout();
+  f->device = device;
+  f->rank = rank;
+  f->world = world;
+  f->root = root;
+  f->max_samples = max_samples;
+  bool ok = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < 2 && ok; i++) {
+    ok = hipMalloc((void **)&f->buf[i], max_samples * sizeof(float2)) == hipSuccess &&
+         hipEventCreateWithFlags(&f->ready[i], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&f->freed[i], hipEventDisableTiming) == hipSuccess;
+  }
+  if (ok && (world > 1 || id128 != nullptr)) {  // with an id even a world of one goes through RCCL (tests)
+    Rccl &r = rccl();
+    if (!r.ok) {
+      kq_internal_set_error("librccl not available");
+      ok = false;
+    } else {
+      ncclUniqueId id;
+      memcpy(&id, id128, sizeof id);
+      ncclResult_t const e = r.CommInitRank(&f->comm, world, id, rank);
+      if (e != ncclSuccess) {
+        kq_internal_set_error("ncclCommInitRank: %s", r.GetErrorString(e));
+        ok = false;
+      }
+    }
+  }
+  if (!ok) {
+    if (f->comm == nullptr && world == 1) kq_internal_set_error("kq_fanout_create: device allocation failed");
+    kq_fanout_destroy(f);
+    return nullptr;
+  }
+  return f;
+}
+
+int kq_fanout_destroy(kq_fanout *f) {
+  if (!f) return 0;
+  kq::DeviceScope scope(f->device);
+  if (f->side) (void)hipStreamSynchronize(f->side);
+  if (f->comm) (void)rccl().CommDestroy(f->comm);
+  for (int i = 0; i < 2; i++) {
+    if (f->buf[i]) (void)hipFree(f->buf[i]);
+    if (f->ready[i]) (void)hipEventDestroy(f->ready[i]);
+    if (f->freed[i]) (void)hipEventDestroy(f->freed[i]);
+  }
+  if (f->side) (void)hipStreamDestroy(f->side);
+  delete f;
+  return 0;
+}
+
+int kq_fanout_post(kq_fanout *f, int slot, const void *src, size_t nsamples, int src_is_device) {
+  if (!f || slot < 0 || slot > 1 || nsamples == 0 || nsamples > f->max_samples || (f->rank == f->root && !src)) {
+    kq_internal_set_error("kq_fanout_post: bad arguments");
+    return -1;
+  }
+  kq::DeviceScope scope(f->device);
+  // the slot's previous consumer (kq_fanout_release) must be done before it is overwritten
+  if (hipStreamWaitEvent(f->side, f->freed[slot], 0) != hipSuccess) return -1;
+  if (f->rank == f->root) {
+    hipMemcpyKind const kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (src != f->buf[slot] &&
+        hipMemcpyAsync(f->buf[slot], src, nsamples * sizeof(float2), kind, f->side) != hipSuccess) {
+      kq_internal_set_error("kq_fanout_post: copy into the slot failed");
+      return -1;
+    }
+  }
+  if (f->comm) {
+    ncclResult_t const e =
+        rccl().Broadcast(f->buf[slot], f->buf[slot], 2 * nsamples, ncclFloat32, f->root, f->comm, f->side);
+    if (e != ncclSuccess) {
+      kq_internal_set_error("ncclBroadcast: %s", rccl().GetErrorString(e));
+      return -1;
+    }
+  }
+  f->count[slot] = nsamples;
+  if (hipEventRecord(f->ready[slot], f->side) != hipSuccess) return -1;
+  return 0;
+}
+
+const void *kq_fanout_acquire(kq_fanout *f, int slot, void *consumer_stream, size_t *nsamples) {
+  if (!f || slot < 0 || slot > 1) {
+    kq_internal_set_error("kq_fanout_acquire: bad arguments");
+    return nullptr;
+  }
+  kq::DeviceScope scope(f->device);
+  if (hipStreamWaitEvent((hipStream_t)consumer_stream, f->ready[slot], 0) != hipSuccess) return nullptr;
+  if (nsamples) *nsamples = f->count[slot];
+  return f->buf[slot];
+}
+
+int kq_fanout_release(kq_fanout *f, int slot, void *consumer_stream) {
+  if (!f || slot < 0 || slot > 1) return -1;
+  kq::DeviceScope scope(f->device);
+  return hipEventRecord(f->freed[slot], (hipStream_t)consumer_stream) == hipSuccess ? 0 : -1;
+}
+
+}  // extern "C"

@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2 gloo.  Rank 0 owns the front-end stream and fans it out with
+"""N > 1 path on CPU: gloo, world sizes 2 and 4 (the latter with uneven shards).  Rank 0 owns the front-end stream and fans it out with
 FrontEndFanout (the same class bench.py uses over RCCL); each rank processes its own channel shard.
 The per-shard compute here is the CPU oracle (the GPU library needs a device); what is under test is the
 sharding + fan-out logic: every rank sees identical I/Q, shards cover the plan exactly once, and a sharded
@@ -10,8 +10,9 @@ import numpy as np
 import pytest
 
 
-def _worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, out_dir, total=6):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      KQ_TEST_TOTAL=str(total))
     here = os.path.dirname(os.path.abspath(__file__))
     root = os.path.dirname(here)
     sys.path[:0] = [root, os.path.join(root, "oracle"), here]
@@ -24,7 +25,7 @@ def _worker(rank, world, port, out_dir):
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     geom = dict(samprate=192000, L=512, M=513, D=4)
-    total, nblocks, nbatches = 6, 3, 2
+    total, nblocks, nbatches = int(os.environ.get("KQ_TEST_TOTAL", "6")), 3, 2
     first, count = shard_range(total, world, rank)
     fs, L = geom["samprate"], geom["L"]
     plan = []
@@ -77,3 +78,32 @@ def test_sharded_fanout_world2(tmp_path):
     x = np.concatenate([wl.make_iq(fs, 3 * L, seed=40, start=k * 3 * L, emitters=range(24, 40)) for k in range(2)])
     auds, _, _ = ko.run_chain(oracle_cfg(p, fs, L, 513, 4), x.reshape(6, L))
     assert np.array_equal(np.concatenate(auds), r1["audio4"])
+
+
+def test_sharded_fanout_world4_uneven_shards(tmp_path):
+    """10 channels over 4 ranks: shards of 3, 3, 2, 2 -- contiguous, disjoint, covering the plan; every rank sees the
+    same samples; the C host's kq_shard_range (kq_fanout.cpp) agrees with the Python one."""
+    import ctypes as C
+    import torch.multiprocessing as mp
+    import ka9q_sdr_amd as kq
+    from ka9q_sdr_amd.shard import shard_range
+    total, world = 10, 4
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), total), nprocs=world, join=True)
+    rs = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    assert [int(r["count"]) for r in rs] == [3, 3, 2, 2]
+    nxt = 0
+    for r in rs:
+        assert int(r["first"]) == nxt
+        nxt += int(r["count"])
+        assert np.array_equal(r["sums"], rs[0]["sums"])
+        assert sorted(k for k in r.files if k.startswith("audio")) == sorted("audio%d" % c for c in
+                                                                              range(int(r["first"]), int(r["first"]) + int(r["count"])))
+    assert nxt == total
+    lib = kq.load_library()
+    for tot, w in ((10, 4), (1024, 8), (8192, 8), (5, 8), (0, 3)):
+        for rank in range(w):
+            f, c = C.c_uint(), C.c_uint()
+            assert lib.kq_shard_range(tot, w, rank, C.byref(f), C.byref(c)) == 0
+            assert (f.value, c.value) == shard_range(tot, w, rank)
+    assert lib.kq_shard_range(4, 2, 2, C.byref(f), C.byref(c)) == -1

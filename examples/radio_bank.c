@@ -35,11 +35,18 @@ int main(void){
   size_t const n = (size_t)L * nblocks;
   float complex *iq = malloc(n * sizeof *iq);
   double phase = 0;
+  unsigned lcg = 12345u;
   for(size_t i = 0; i < n; i++){
     double const t = (double)i / 192000.;
     double const f = 20000. + 3000. * cos(2 * M_PI * 1000. * t);            /* instantaneous frequency */
     phase += 2 * M_PI * f / 192000.;
-    iq[i] = 0.5f * (float)cos(phase) + 0.5f * (float)sin(phase) * I;
+    /* a little noise, as every real signal has: the FM SNR estimate (fm.c:100-102) divides by the envelope's variance,
+     * which for a synthetic constant envelope is float rounding of either sign -- and a negative one reads as SNR 0 */
+    lcg = lcg * 1664525u + 1013904223u;
+    float const nr = ((lcg >> 8) & 0xffff) / 65536.f - 0.5f;
+    lcg = lcg * 1664525u + 1013904223u;
+    float const ni = ((lcg >> 8) & 0xffff) / 65536.f - 0.5f;
+    iq[i] = (0.5f * (float)cos(phase) + 2e-3f * nr) + (0.5f * (float)sin(phase) + 2e-3f * ni) * I;
   }
   if(kq_bank_push_iq(bank, iq, n, KQ_IQ_CF32, 0) != 0 || kq_bank_process(bank) != (int)nblocks || kq_bank_sync(bank) != 0){
     fprintf(stderr, "processing failed: %s\n", kq_last_error());

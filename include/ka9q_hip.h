@@ -50,7 +50,7 @@ typedef struct kq_bank kq_bank;   /* opaque */
 typedef struct kq_bank_config {
   int device;              /* HIP device ordinal.  A handle stays on its device: every call taking the handle runs
                             * there and restores the calling thread's current device, so one process can drive
-                            * banks on several GPUs (kq_bank_create itself leaves `device` current). */
+                            * banks on several GPUs (kq_bank_create included). */
   int samprate;            /* front-end complex sample rate, Hz */
   unsigned L;              /* new samples per block            (demod->filter.L) */
   unsigned M;              /* impulse response length          (demod->filter.M); N = L+M-1 power of two */
@@ -166,7 +166,9 @@ int kq_bank_push_iq(kq_bank *bank, const void *iq, size_t nsamples, int format, 
  * case the lost samples are injected as zeros with the LOs kept running (kq_bank_push_zeros) before the payload is
  * converted and appended (kq_bank_push_iq).  Packets are taken in arrival order; the reference's small
  * sort-by-sequence queue (main.c:347-357) stays with the caller.
- * Returns the number of samples appended (zeros + payload), 0 for an ignored or dropped datagram, -1 on error. */
+ * Returns the number of samples appended (zeros + payload), 0 for an ignored or dropped datagram, -1 on error, and
+ * -2 when the ring has no room for the packet's zero fill + payload right now: nothing has been consumed then --
+ * sequence, timestamp and counters are untouched -- so run kq_bank_process and hand the same datagram in again. */
 int kq_bank_push_rtp(kq_bank *bank, const void *datagram, size_t size);
 typedef struct kq_rtp_counters {   /* struct rtp_state (multicast.h:41-50) + demod->input.samples */
   uint32_t ssrc;
@@ -203,7 +205,8 @@ int kq_bank_pull_status(kq_bank *bank, int ch, unsigned blk, kq_chan_status *st)
 /* PCM output stage (audio.c:22-28 scaleclip, audio.c:45-50 / 95-100): once enabled, every process call
  * also converts the audio plane to clipped int16 in network byte order on the device.  kq_bank_pull_pcm returns the
  * status.nout words of one channel-block and a mask whose bit i is set when the i-th 480-word chunk is all zero --
- * send_mono_output / send_stereo_output skip such a packet but still advance the RTP timestamp (audio.c:101-104). */
+ * send_mono_output / send_stereo_output skip such a packet but still advance the RTP timestamp (audio.c:101-104).
+ * Geometries with more than 32 packets per block (2 * olen > 15360 words) are refused. */
 int kq_bank_enable_pcm(kq_bank *bank, int on);
 int kq_bank_pull_pcm(kq_bank *bank, int ch, unsigned blk, int16_t *dst_be, size_t cap_words, size_t *nwords,
                      uint32_t *silent_mask);

@@ -277,9 +277,13 @@ class Bank:
         return {k: getattr(st, k) for k, _ in st._fields_}
 
     def push_rtp(self, datagram):
-        """One front-end datagram (RTP header + 24-byte status block + int16 / int8 I/Q); returns samples appended"""
+        """One front-end datagram (RTP header + 24-byte status block + int16 / int8 I/Q); returns samples appended,
+        or None when the ring has no room for it right now (nothing consumed: process, then push it again)"""
         d = bytes(datagram)
-        return self._chk(self.lib.kq_bank_push_rtp(self.h, d, len(d)), "kq_bank_push_rtp")
+        rc = self.lib.kq_bank_push_rtp(self.h, d, len(d))
+        if rc == -2:
+            return None
+        return self._chk(rc, "kq_bank_push_rtp")
 
     def rtp_counters(self):
         c = RtpCounters()

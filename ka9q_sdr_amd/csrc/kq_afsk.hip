@@ -269,7 +269,7 @@ struct kq_afsk_bank {
 static int afsk_alloc(kq_afsk_bank *b) {
   kq_afsk_config const &c = b->cfg;
   size_t const S = c.max_sessions;
-  AF_TRY(hipSetDevice(c.device));
+  kq::DeviceScope dev_scope_(c.device);  // the caller's current device is restored on return
   if (c.stream)
     b->stream = (hipStream_t)c.stream;
   else {

@@ -318,7 +318,7 @@ int upload_response(kq_bank *b, int c) {
 // Pre-detection response: set_filter with edges normalised to the output rate
 // (fm.c:35: low/dsamprate; am.c:41, linear.c:81: samptime*low)
 // `runtime`: a change made while running goes through display.c:161-177, which scales by samptime whatever the mode
-void design_channel(kq_bank *b, HostChan &h, bool runtime = false) {
+int design_channel(kq_bank *b, HostChan &h, bool runtime = false) {
   kq::Geom const &g = b->g;
   float lo_n, hi_n;
   if (h.cfg.demod_type == KQ_FM_DEMOD && !runtime) {
@@ -329,13 +329,16 @@ void design_channel(kq_bank *b, HostChan &h, bool runtime = false) {
     lo_n = samptime * h.cfg.low;
     hi_n = samptime * h.cfg.high;
   }
-  h.resp = kq::design_response(g.N, g.olen, g.Mdec, h.out_type, lo_n, hi_n, h.cfg.kaiser_beta);
-  h.noise_gain = kq::noise_gain(h.resp, g.N, g.Ndec, false, h.out_type);
-  if (runtime) return;  // the FM audio response is designed once, in the demodulator's prologue (fm.c:54-66)
-  if (h.cfg.demod_type == KQ_FM_DEMOD && !h.cfg.flat)
+  h.resp = kq::design_response(g.N, g.olen, g.Mdec, h.out_type, lo_n, hi_n, h.cfg.kaiser_beta, &h.noise_gain);
+  if (h.resp.empty()) return -1;
+  if (runtime) return 0;  // the FM audio response is designed once, in the demodulator's prologue (fm.c:54-66)
+  if (h.cfg.demod_type == KQ_FM_DEMOD && !h.cfg.flat) {
     h.aresp = kq::design_fm_audio_response(g.olen, g.Mdec, g.dsamprate, h.cfg.kaiser_beta);
-  else
+    if (h.aresp.empty()) return -1;
+  } else {
     h.aresp.clear();
+  }
+  return 0;
 }
 
 int ensure_events(std::vector<EventPair> &v, size_t need) {
@@ -650,9 +653,15 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     set_err("device %d out of range (%d visible)", cfg->device, ndev);
     return nullptr;
   }
-  if (hipSetDevice(cfg->device) != hipSuccess) {
-    set_err("hipSetDevice(%d) failed", cfg->device);
-    return nullptr;
+  // the handle lives on cfg->device; the calling thread's current device is put back on the way out, error paths
+  // included, like every other entry point (kq_device.hpp DeviceScope)
+  kq::DeviceScope dev_scope_(cfg->device);
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != cfg->device) {
+      set_err("hipSetDevice(%d) failed", cfg->device);
+      return nullptr;
+    }
   }
 
   kq_bank *b = new kq_bank();
@@ -811,7 +820,10 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
       float const f = (float)j * g.dsamprate / g.Ndec;
       if (f > 0 && f < 300) r[j] = 1;
     }
-    kq::window_rfilter(g.pl_l, PL_M, r, 2.0);
+    if (kq::window_rfilter(g.pl_l, PL_M, r, 2.0)) {
+      kq_bank_destroy(b);
+      return nullptr;
+    }
     (void)hipMemcpy(b->chd.plresp, r.data(), r.size() * sizeof(float2), hipMemcpyHostToDevice);
   }
   {
@@ -973,7 +985,7 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
   h.lo2.set(cfg->second_lo == 0 ? 0.0 : cfg->second_lo / fs, 0.0, b->n_abs);
   h.dop.set(-cfg->doppler / fs, -cfg->doppler_rate / (fs * fs), b->n_abs);
   h.shift.set(cfg->shift == 0 ? 0.0 : cfg->shift * b->g.D / fs, 0.0, b->out_abs);
-  design_channel(b, h);
+  if (design_channel(b, h)) return -1;
   bool const appended = c == (int)b->chans.size();
   if (appended)
     b->chans.push_back(h);
@@ -1066,7 +1078,7 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
   h.cfg.shift = m->shift;
   h.out_type = (m->demod_type == KQ_LINEAR_DEMOD && m->isb) ? kq::FT_CROSS_CONJ : kq::FT_COMPLEX;
   h.shift.set(m->shift == 0 ? 0.0 : m->shift * b->g.D / (double)b->g.samprate, 0.0, b->out_abs);  // radio.c:367
-  design_channel(b, h);
+  if (design_channel(b, h)) return -1;
   if (upload_channel(b, ch, false) || upload_response(b, ch)) return -1;
   b->lists_dirty = true;
   return 0;
@@ -1162,7 +1174,7 @@ int kq_bank_set_filter(kq_bank *b, int ch, float low, float high, float beta) {
   h.cfg.low = low;
   h.cfg.high = high;
   h.cfg.kaiser_beta = beta;
-  design_channel(b, h, true);
+  if (design_channel(b, h, true)) return -1;
   float const fm_gain = (float)((h.cfg.headroom * M_1_PI * b->g.dsamprate) / fabsf(low - high));
   if (upload(b, b->chd.low + ch, &low, sizeof(float))) return -1;
   if (upload(b, b->chd.high + ch, &high, sizeof(float))) return -1;
@@ -1283,6 +1295,22 @@ int kq_bank_push_rtp(kq_bank *b, const void *datagram, size_t size) {
 
   // proc_samples + rtp_process (radio.c:73-104, multicast.c:305-340)
   kq_rtp_counters &r = b->rtp;
+  {
+    // Room for the whole packet -- a timestamp gap's zero fill (radio.c:83-100, at most 192000 samples) plus its
+    // payload -- is checked BEFORE the sequence / timestamp state moves: a caller told -2 runs kq_bank_process and
+    // hands the same datagram in again, and it is then neither a duplicate nor short of its zeros.
+    bool const fresh = !b->rtp_init || ssrc != r.ssrc;
+    short const sstep = fresh ? 0 : (short)(seq - r.next_seq);
+    int const tstep = fresh ? 0 : (int)(ts - r.next_timestamp);
+    if (sstep >= 0 && tstep >= 0 && tstep <= 192000) {
+      size_t const need = (size_t)tstep + (size_t)(sampcount > 0 ? sampcount : 0);
+      if ((size_t)(b->g.M - 1) + b->pending + need > b->ring_cap) {
+        set_err("ring full: %zu samples pending, the packet brings %zu (zero fill %d): run kq_bank_process first",
+                b->pending, need, tstep);
+        return need > b->ring_cap - (size_t)(b->g.M - 1) ? -1 : -2;  // -1: can never fit this bank's max_blocks
+      }
+    }
+  }
   if (!b->rtp_init || ssrc != r.ssrc) {
     r.samples = 0;  // radio.c:73-77 (a fresh state has ssrc 0, so the first packet lands here as well)
     r.ssrc = ssrc;
@@ -1412,6 +1440,11 @@ int kq_bank_pull_audio(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap,
 int kq_bank_enable_pcm(kq_bank *b, int on) {
   kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return -1;
+  if (on && 2 * (size_t)b->g.olen > 32 * 480) {
+    // the silent-packet mask of kq_bank_pull_pcm is 32 bits: one per 480-word packet of a block
+    set_err("PCM stage: %d output samples per block make more than 32 packets", b->g.olen);
+    return -1;
+  }
   if (on && !b->pcm) {
     size_t const CB = (size_t)b->cfg.max_channels * b->cfg.max_blocks;
     if (dev_alloc(&b->pcm, CB * 2 * (size_t)b->g.olen) || dev_alloc(&b->pcm_mask, CB)) return -1;

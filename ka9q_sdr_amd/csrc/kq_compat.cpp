@@ -327,12 +327,15 @@ int delete_filter_output(struct filter_out *s) {
 
 int make_kaiser(float *window, unsigned int M, float beta) {
   if (window == NULL) return -1;
-  kq::make_kaiser(window, M, beta);
-  return 0;
+  if (!ctx_init()) return -1;
+  kq::DeviceScope dev_scope_(ctx().device);
+  return kq::make_kaiser(window, M, beta);
 }
 
 int window_filter(int L, int M, kq_cfloat *response, float beta) {
   if (response == NULL) return -1;
+  if (!ctx_init()) return -1;
+  kq::DeviceScope dev_scope_(ctx().device);
   int const N = L + M - 1;
   std::vector<kq::cfloat> r(N);
   memcpy((void *)r.data(), response, N * sizeof(kq_cfloat));
@@ -343,6 +346,8 @@ int window_filter(int L, int M, kq_cfloat *response, float beta) {
 
 int window_rfilter(int L, int M, kq_cfloat *response, float beta) {
   if (response == NULL) return -1;
+  if (!ctx_init()) return -1;
+  kq::DeviceScope dev_scope_(ctx().device);
   int const N = L + M - 1;
   std::vector<kq::cfloat> r(N / 2 + 1);
   memcpy((void *)r.data(), response, r.size() * sizeof(kq_cfloat));
@@ -358,7 +363,9 @@ int set_filter(struct filter_out *s, float low, float high, float kaiser_beta) {
   int const L_dec = (int)s->olen;
   int const M_dec = (int)((m->impulse_length - 1) / s->decimate + 1);
   int const N = (int)(m->ilen + m->impulse_length - 1);
+  kq::DeviceScope dev_scope_(ctx().ok ? ctx().device : -1);
   std::vector<kq::cfloat> r = kq::design_response(N, L_dec, M_dec, (int)s->out_type, low, high, kaiser_beta);
+  if (r.empty()) return -1;
   kq_cfloat *fresh = (kq_cfloat *)malloc(r.size() * sizeof(kq_cfloat));
   if (!fresh) return -1;
   memcpy(fresh, r.data(), r.size() * sizeof(kq_cfloat));

@@ -437,7 +437,7 @@ void kq_internal_set_error(const char *fmt, ...);
 
 static int decim_alloc(kq_decimator *d) {
   kq_decim_config const &c = d->cfg;
-  DEC_TRY(hipSetDevice(c.device));
+  kq::DeviceScope dev_scope_(c.device);  // the caller's current device is restored on return
   {
     hipDeviceProp_t prop;
     DEC_TRY(hipGetDeviceProperties(&prop, c.device));

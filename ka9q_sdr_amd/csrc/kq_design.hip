@@ -1,0 +1,271 @@
+// kq_design.hip -- filter response design on the device (control plane: runs per retune, never per block).
+//
+// What the reference does on the CPU with FFTW in set_filter / window_filter / window_rfilter / make_kaiser / noise_gain
+// (filter.c:282-546) and in the FM demodulator's prologue (fm.c:54-66): a target spectrum -- a brick wall between two
+// edges, the 300 Hz / -6 dB-per-octave de-emphasis curve, or one the caller supplies -- is taken to the time domain,
+// rotated so that the impulse response sits in the first M taps, shaped by a Kaiser window, zero padded and taken
+// back.  Here one workgroup designs one response in LDS: target spectrum -> inverse transform -> taps -> forward
+// transform -> response + sum |H|^2 for noise_gain; a launch designs a batch (every channel of a bank retuning at
+// once costs one launch).  Arithmetic is float, like the reference's; the responses agree with the oracle's to a few
+// 1e-12 absolute (response peak 1/N ~ 6e-5).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "kq_design.hpp"
+#include "kq_device.hpp"
+#include "kq_ldsfft.hpp"
+
+void kq_internal_set_error(const char *fmt, ...);
+
+namespace kq {
+
+namespace {
+
+enum { SPEC_GIVEN = 0, SPEC_BAND = 1, SPEC_DEEMPH = 2 };
+
+// modified Bessel function of the first kind, order 0: power series sum_k (x^2/4)^k / (k!)^2 in float, cut off where
+// a term drops below 1e-12 of the sum or after 40 terms (the truncation rule of filter.c:282-293)
+__device__ float bessel_i0(float x) {
+#pragma clang fp contract(off)  // one rounding per operation, as the host compiler evaluates the reference's float code
+  float const q = 0.25f * x * x;
+  float term = q, sum = 1.f + q;
+  for (int k = 2; k < 40; k++) {
+    term *= q / (float)(k * k);
+    sum += term;
+    if (term < 1e-12f * sum) break;
+  }
+  return sum;
+}
+
+// Kaiser window tap n of M (filter.c:337-357): symmetric about the middle, which is exactly 1 for odd M
+__device__ float kaiser_tap(int n, int M, float beta) {
+#pragma clang fp contract(off)
+  int const m = min(n, M - 1 - n);
+  if ((M & 1) && m == (M - 1) / 2) return 1.f;
+  float const arg = 3.14159265358979323846f * beta;
+  float const pos = (2.0f / (float)(M - 1)) * (float)m - 1.f;  // -1 at the edge .. 0 at the middle
+  return bessel_i0(arg * sqrtf(1.f - pos * pos)) * (1.f / bessel_i0(arg));
+}
+
+__global__ void k_kaiser(float *__restrict__ w, int M, float beta) {
+  int const n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < M) w[n] = kaiser_tap(n, M, beta);
+}
+
+// grid: one workgroup per response.  REAL: the taps are real (window_rfilter): the spectrum is N/2+1 bins in and out.
+// dynamic LDS: N float2
+template <bool REAL>
+__global__ void k_design(int log2n, int M, int spec, const DesignJob *__restrict__ jobs, const float2 *__restrict__ given,
+                         float2 *__restrict__ out, float2 *__restrict__ scratch, float *__restrict__ sumsq, int nsum,
+                         const float2 *__restrict__ tw, int tw_log2) {
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  __shared__ float red_f[16];
+  __shared__ int red_i[16];
+  int const N = 1 << log2n, nbins = REAL ? N / 2 + 1 : N;
+  DesignJob const job = jobs[blockIdx.x];
+  const float2 *in = given ? given + (size_t)blockIdx.x * nbins : nullptr;
+  float2 *res = out + (size_t)blockIdx.x * nbins;
+  float2 *taps = scratch + (size_t)blockIdx.x * N;
+
+  // ---- target spectrum, bin i of N (both halves: the inverse transform below is complex)
+  for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    float2 s = make_float2(0.f, 0.f);
+    int const j = i <= N / 2 ? i : N - i;  // the bin a real signal's Hermitian half mirrors to
+    if (spec == SPEC_BAND) {               // filter.c:525-535: gain where low <= f <= high, f the signed bin over N
+      float const f = i <= N / 2 ? (float)i / (float)N : (float)(i - N) / (float)N;
+      if (f >= job.low && f <= job.high) s.x = job.gain;
+    } else if (spec == SPEC_DEEMPH) {      // fm.c:59-63: gain * 300 / f between 300 and 6000 Hz (job.low = rate / N)
+      float const f = (float)j * job.low;
+      if (f >= 300.f && f <= 6000.f) s.x = job.gain * 300.f / f;
+    } else if (REAL) {                     // c2r semantics: Hermitian extension, DC and Nyquist taken as real
+      float2 const v = in[j];
+      s = (j == 0 || j == N / 2) ? make_float2(v.x, 0.f) : (i <= N / 2 ? v : make_float2(v.x, -v.y));
+    } else {
+      s = in[i];
+    }
+    lds[bitrev((unsigned)i, log2n)] = s;
+  }
+  lds_fft<+1>(lds, log2n, tw, tw_log2);
+
+  // ---- taps: rotate by M/2 so the response is causal, window, scale by 1/N (filter.c:377-386); zero beyond M
+  float const inv_n = 1.0f / (float)N;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    float2 t = make_float2(0.f, 0.f);
+    if (n < M) {
+      float2 const x = lds[(n - M / 2 + N) & (N - 1)];
+      float const w = kaiser_tap(n, M, job.beta);
+      t = REAL ? make_float2(x.x * w * inv_n, 0.f) : make_float2(x.x * w * inv_n, x.y * w * inv_n);
+    }
+    taps[n] = t;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {  // read back what other threads of the workgroup just wrote
+    const volatile float *q = reinterpret_cast<const volatile float *>(taps + n);
+    lds[bitrev((unsigned)n, log2n)] = make_float2(q[0], q[1]);
+  }
+  lds_fft<-1>(lds, log2n, tw, tw_log2);
+
+  // ---- response, and the sum of |H|^2 noise_gain is built from (filter.c:472-497: nsum bins)
+  float acc = 0;
+  int dummy = 0;
+  for (int k = threadIdx.x; k < nbins; k += blockDim.x) {
+    float2 const h = lds[k];
+    res[k] = h;
+    if (k < nsum) acc += h.x * h.x + h.y * h.y;
+  }
+  block_sum_fi(acc, dummy, red_f, red_i);
+  if (threadIdx.x == 0 && sumsq) sumsq[blockIdx.x] = acc;
+}
+
+// twiddle tables exp(-2 pi i k / T), k < T/2, per device and size (built in double, rounded once)
+const float2 *design_twiddles(int log2T) {
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, float2 *> tabs;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = tabs.find({dev, log2T});
+  if (it != tabs.end()) return it->second;
+  size_t const T = (size_t)1 << log2T;
+  std::vector<float2> h(T / 2 ? T / 2 : 1);
+  for (size_t k = 0; k < T / 2; k++) {
+    double const a = -2.0 * M_PI * (double)k / (double)T;
+    h[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  float2 *d = nullptr;
+  if (hipMalloc((void **)&d, h.size() * sizeof(float2)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(d);
+    return nullptr;
+  }
+  tabs[{dev, log2T}] = d;
+  return d;
+}
+
+struct DevBuf {
+  void *p = nullptr;
+  explicit DevBuf(size_t bytes) {
+    if (bytes && hipMalloc(&p, bytes) != hipSuccess) p = nullptr;
+  }
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+};
+
+}  // namespace
+
+// Designs jobs.size() responses of N = L + M - 1 points on the current device; `given`: jobs.size() * nbins target
+// bins (SPEC_GIVEN) or null.  Returns 0 and fills `out` (jobs.size() * nbins) and, when asked, the |H|^2 sums.
+int design_batch(int L, int M, bool real_taps, int spec, const std::vector<DesignJob> &jobs, const cfloat *given,
+                 std::vector<cfloat> &out, std::vector<float> *sumsq, int nsum) {
+  int const N = L + M - 1;
+  int log2n = 0;
+  while ((1 << log2n) < N) log2n++;
+  if (N < 2 || (1 << log2n) != N || N > 16384 || M < 1 || jobs.empty()) {
+    kq_internal_set_error("response design: N = %d must be a power of two in 2..16384", N);
+    return -1;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    kq_internal_set_error("response design: no HIP device (the design kernels are the only path)");
+    return -1;
+  }
+  size_t const count = jobs.size(), nbins = real_taps ? (size_t)N / 2 + 1 : (size_t)N;
+  const float2 *tw = design_twiddles(log2n);
+  DevBuf d_jobs(count * sizeof(DesignJob)), d_in(given ? count * nbins * sizeof(float2) : 0), d_out(count * nbins * sizeof(float2)),
+      d_scratch(count * (size_t)N * sizeof(float2)), d_sum(count * sizeof(float));
+  if (!tw || !d_jobs.p || !d_out.p || !d_scratch.p || !d_sum.p || (given && !d_in.p)) {
+    kq_internal_set_error("response design: device allocation failed");
+    return -1;
+  }
+  bool ok = hipMemcpy(d_jobs.p, jobs.data(), count * sizeof(DesignJob), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok && given) ok = hipMemcpy(d_in.p, given, count * nbins * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) {
+    size_t const lds_bytes = (size_t)N * sizeof(float2);
+    int const threads = N >= 1024 ? 256 : 64;
+    auto go = [&](auto kernel) {
+      ensure_dynamic_lds((const void *)kernel, lds_bytes);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)count), dim3(threads), lds_bytes, 0, log2n, M, spec, (const DesignJob *)d_jobs.p,
+                         (const float2 *)d_in.p, (float2 *)d_out.p, (float2 *)d_scratch.p, (float *)d_sum.p, nsum, tw, log2n);
+    };
+    real_taps ? go(k_design<true>) : go(k_design<false>);
+    ok = hipGetLastError() == hipSuccess;
+  }
+  out.resize(count * nbins);
+  if (ok) ok = hipMemcpy((void *)out.data(), d_out.p, count * nbins * sizeof(float2), hipMemcpyDeviceToHost) == hipSuccess;
+  if (ok && sumsq) {
+    sumsq->resize(count);
+    ok = hipMemcpy(sumsq->data(), d_sum.p, count * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  if (!ok) kq_internal_set_error("response design: %s", hipGetErrorString(hipGetLastError()));
+  return ok ? 0 : -1;
+}
+
+int make_kaiser(float *window, unsigned M, float beta) {
+  if (M == 0) return 0;
+  DevBuf d(M * sizeof(float));
+  if (!d.p) return -1;
+  hipLaunchKernelGGL(k_kaiser, dim3((M + 255) / 256), dim3(256), 0, 0, (float *)d.p, (int)M, beta);
+  return hipMemcpy(window, d.p, M * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+
+int window_filter(int L, int M, std::vector<cfloat> &response, float beta) {
+  if ((int)response.size() != L + M - 1) return -1;
+  std::vector<cfloat> out;
+  if (design_batch(L, M, false, SPEC_GIVEN, {DesignJob{0, 0, beta, 0}}, response.data(), out, nullptr, 0)) return -1;
+  response.swap(out);
+  return 0;
+}
+
+int window_rfilter(int L, int M, std::vector<cfloat> &response, float beta) {
+  if ((int)response.size() != (L + M - 1) / 2 + 1) return -1;
+  std::vector<cfloat> out;
+  if (design_batch(L, M, true, SPEC_GIVEN, {DesignJob{0, 0, beta, 0}}, response.data(), out, nullptr, 0)) return -1;
+  response.swap(out);
+  return 0;
+}
+
+// set_filter's design step for a batch of slaves of one geometry (filter.c:500-546): unity passband between the
+// edges (cycles per output sample), scaled 1/N for the unnormalised transforms and by a further 1/sqrt(2) where two
+// sidebands add (REAL and CROSS_CONJ outputs, filter.c:518-522); noise gains as filter.c:472-497 (complex master).
+int design_responses(int N, int L_dec, int M_dec, int out_type, const std::vector<BandEdges> &edges, std::vector<cfloat> &responses,
+                     std::vector<float> &noise_gains) {
+  bool const two_sided = out_type == FT_REAL || out_type == FT_CROSS_CONJ;
+  float gain = 1.0f / (float)N;
+  if (two_sided) gain *= (float)M_SQRT1_2;
+  std::vector<DesignJob> jobs;
+  for (BandEdges const &e : edges) jobs.push_back(DesignJob{e.low, e.high, e.beta, gain});
+  std::vector<float> sums;
+  int const n_dec = L_dec + M_dec - 1;
+  if (design_batch(L_dec, M_dec, false, SPEC_BAND, jobs, nullptr, responses, &sums, n_dec)) return -1;
+  noise_gains.resize(sums.size());
+  for (size_t i = 0; i < sums.size(); i++) noise_gains[i] = (two_sided ? 2.f : 1.f) * (float)N * sums[i];
+  return 0;
+}
+
+std::vector<cfloat> design_response(int N, int L_dec, int M_dec, int out_type, float low, float high, float beta,
+                                    float *noise_gain_out) {
+  std::vector<cfloat> r;
+  std::vector<float> ng;
+  if (design_responses(N, L_dec, M_dec, out_type, {BandEdges{low, high, beta}}, r, ng)) return {};
+  if (noise_gain_out) *noise_gain_out = ng[0];
+  return r;
+}
+
+std::vector<cfloat> design_fm_audio_response(int AL, int AM, float dsamprate, float beta) {
+  int const AN = AL + AM - 1;
+  std::vector<cfloat> r;
+  // fm.c:42: 10 / AN brings the subjective level up; job.low carries the bin spacing in Hz
+  if (design_batch(AL, AM, true, SPEC_DEEMPH, {DesignJob{dsamprate / (float)AN, 0, beta, 10.0f / (float)AN}}, nullptr, r, nullptr, 0))
+    return {};
+  return r;
+}
+
+}  // namespace kq

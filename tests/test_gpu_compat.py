@@ -108,3 +108,30 @@ def test_compat_filter_matches_oracle(lib, in_type, out_type, D, Lb):
     assert lib.delete_filter_output(s) == 0 and lib.delete_filter_input(m) == 0
     O.kqo_delete_filter_output(os_)
     O.kqo_delete_filter_input(om)
+
+
+def test_design_entry_points_run_on_the_device(lib):
+    """make_kaiser / window_filter / window_rfilter of the compat surface: the design kernels (kq_design.hip) against
+    the oracle's restatement of filter.c:337-469."""
+    w = np.zeros(129, np.float32)
+    lib.make_kaiser.argtypes = [C.c_void_p, C.c_uint, C.c_float]
+    assert lib.make_kaiser(w.ctypes.data, 129, 3.0) == 0
+    np.testing.assert_allclose(w, ko.make_kaiser(129, 3.0), rtol=3e-7)
+    assert w[64] == 1.0 and np.array_equal(w, w[::-1])             # exactly symmetric, centre exactly one (filter.c:354-356)
+    w2 = np.zeros(64, np.float32)
+    assert lib.make_kaiser(w2.ctypes.data, 64, 7.5) == 0
+    np.testing.assert_allclose(w2, ko.make_kaiser(64, 7.5), rtol=3e-7)
+    assert lib.make_kaiser(None, 129, 3.0) == -1
+    rng = np.random.default_rng(0)
+    r = (rng.standard_normal(256) + 1j * rng.standard_normal(256)).astype(np.complex64)
+    r2 = r.copy()
+    lib.window_filter.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_float]
+    assert lib.window_filter(128, 129, r.ctypes.data, 3.0) == 0
+    ko.lib().kqo_window_filter(128, 129, r2.ctypes.data, 3.0)
+    assert np.abs(r - r2).max() / np.abs(r2).max() < 1e-6
+    h = (rng.standard_normal(129) + 1j * rng.standard_normal(129)).astype(np.complex64)
+    h2 = h.copy()
+    lib.window_rfilter.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_float]
+    assert lib.window_rfilter(128, 129, h.ctypes.data, 2.0) == 0
+    ko.lib().kqo_window_rfilter(128, 129, h2.ctypes.data, 2.0)
+    assert np.abs(h - h2).max() / np.abs(h2).max() < 1e-6

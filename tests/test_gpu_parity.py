@@ -60,7 +60,8 @@ def _compare(plan, got, want, skip_blocks=0, check_n0=False):
         sk = max(skip_blocks, 1) if p["demod"] == "linear" else skip_blocks
         a_g = np.concatenate(g["audio"][sk:])
         a_w = np.concatenate(auds[sk:])
-        assert rel_rms(a_g, a_w) < AUDIO_TOL, ("audio", c, p["demod"], rel_rms(a_g, a_w))
+        assert rel_rms(a_g, a_w) < AUDIO_TOL, ("audio (linear channels: from block 1 on; block 0 is compared through its "
+                                               "filter output and integer state only)", c, p["demod"], rel_rms(a_g, a_w))
         for b in range(nb):
             sg, sw = g["status"][b], sts[b]
             assert sg["squelch_count"] == sw["squelch_count"], (c, b)

@@ -1,0 +1,68 @@
+"""Parity at the sizes the bench runs, and the decision-flip count SURVEY.md 8d asks for.
+
+* 256 channels of cfg 4 (the bench's default workload: FM, compute_n0 on every block, full-spectrum path) and 256
+  mixed channels of cfg 3 on both forward paths, every channel against the oracle with the tolerances of
+  test_gpu_parity._compare (filter output and audio 1e-5 relative RMS; counts, squelch / hang state, blanked samples
+  exact).
+* Randomised plans in bulk: the reference's algorithm holds comparisons that sit within one float rounding of their
+  threshold for a few inputs (a leakage-skirt bin at compute_n0's 2 x mean cut, radio.c:414-420; `gain * amplitude >
+  headroom` with the gain riding at the limit, linear.c:271) -- two correct float transforms then decide differently.
+  They are counted, channel by channel, and the test fails when more than FLIP_BUDGET of the channels differ, or when
+  any channel differs in something that is not one of those ties (sample counts, squelch state, filter output)."""
+import numpy as np
+import pytest
+
+import ka9q_sdr_amd as kq
+from common import rel_rms, run_oracle
+from ka9q_sdr_amd import workload as wl
+from test_gpu_parity import FILT_TOL, _compare, _random_plan, _run_bank
+
+pytestmark = pytest.mark.gpu
+
+FLIP_BUDGET = 0.004      # fraction of randomised channels allowed to differ through a threshold tie (observed: 3 of 5 760)
+
+
+@pytest.mark.parametrize("name,mode,n0", [("cfg4", "full", True), ("cfg3", "full", True), ("cfg3", "pruned", False)])
+def test_256_channels_at_bench_geometry(gpu, name, mode, n0):
+    g = wl.GEOMETRY[name]
+    plan = wl.channel_plan(name, 256)
+    nblocks = 4
+    iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=0x6B61)
+    want = run_oracle(plan, g, iq, nblocks, compute_n0=int(n0))
+    fwd = kq.KQ_FWD_FULL if mode == "full" else kq.KQ_FWD_PRUNED
+    got, used = _run_bank(plan, g, iq, nblocks, fwd, compute_n0=n0, per_call=nblocks)
+    assert used == fwd
+    _compare(plan, got, want, check_n0=n0)
+    # the status scalars the tolerances of _compare are wide for: how close they really are at this size
+    worst_if = max(abs(got[c]["status"][b]["if_power"] / want[c][1][b]["if_power"] - 1) for c in range(len(plan))
+                   for b in range(nblocks))
+    assert worst_if < 1e-4, worst_if      # the reference sums 8192 floats in sequence; the kernel sums them as a tree
+
+
+def test_decision_flips_stay_within_budget(gpu):
+    g = wl.GEOMETRY["cfg3"]
+    nblocks, per_plan, seeds = 6, 24, range(40, 56)
+    total, flips = 0, []
+    for seed in seeds:
+        rng = np.random.default_rng(1000 + seed)
+        plan = _random_plan(rng, g["samprate"], per_plan)
+        iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=100 + seed)
+        for mode in ("pruned", "full"):
+            n0 = mode == "full"
+            want = run_oracle(plan, g, iq, nblocks, compute_n0=int(n0))
+            fwd = kq.KQ_FWD_PRUNED if mode == "pruned" else kq.KQ_FWD_FULL
+            got, _ = _run_bank(plan, g, iq, nblocks, fwd, compute_n0=n0, per_call=4)
+            for c, p in enumerate(plan):
+                total += 1
+                try:
+                    _compare([p], [got[c]], [want[c]], check_n0=n0)
+                except AssertionError as e:
+                    # a tie may move the noise estimate or a linear channel's gain track; nothing else
+                    filt = rel_rms(np.concatenate(got[c]["filt"]), np.concatenate(want[c][2]))
+                    same_counts = all(got[c]["status"][b]["nout"] == want[c][1][b]["nout"] and
+                                      got[c]["status"][b]["squelch_count"] == want[c][1][b]["squelch_count"]
+                                      for b in range(nblocks))
+                    assert filt < FILT_TOL and same_counts, ("not a threshold tie", seed, mode, c, p, str(e)[:300])
+                    flips.append((seed, mode, c, p["demod"], str(e)[:120]))
+    assert len(flips) <= FLIP_BUDGET * total, (len(flips), total, flips)
+    print("decision flips: %d of %d randomised channels" % (len(flips), total), flips)

@@ -146,3 +146,29 @@ def test_random_packet_sequences_keep_the_books_like_the_oracle(gpu):
             queued -= bank.process() * g["L"]
         assert bank.blocks_ready() == queued // g["L"]
     bank.close()
+
+
+def test_gap_larger_than_the_free_ring_is_retried_not_lost(gpu):
+    """A timestamp gap whose zero fill does not fit the ring right now: the datagram is refused with nothing
+    consumed (it must not count as a duplicate when handed in again), and after a process call it goes through with
+    the reference's sample count (radio.c:83-100 always injects the zeros)."""
+    g = dict(samprate=192000, L=512, M=513, D=4)
+    bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], 1, 2)          # room for 2 blocks = 1024 samples
+    bank.add_channel(bank_cfg(wl.channel_plan("cfg1", 1)[0]))
+    ing = ko.IqIngest()
+    body = lambda n: np.full(2 * n, 1000, "<i2").tobytes()
+    first = rtp_packet(10, 1000, 5, body(600))
+    assert bank.push_rtp(first) == 600 and ing.packet(first) is not None
+    gap = rtp_packet(11, 1600 + 300, 5, body(200))                        # 300 lost samples + 200: 1100 > 1024
+    before = bank.rtp_counters()
+    assert bank.push_rtp(gap) is None
+    assert bank.rtp_counters() == before                                   # sequence / timestamp state untouched
+    assert bank.process() == 1                                             # one block out, 88 samples stay
+    want = ing.packet(gap)
+    assert bank.push_rtp(gap) == want[0] + want[2] == 500
+    c = bank.rtp_counters()
+    assert (c["samples"], c["dupes"], c["next_seq"], c["next_timestamp"]) == (ing.samples, 0, 12, 2100)
+    huge = rtp_packet(12, 2100 + 5000, 5, body(10))                        # can never fit this bank: an error
+    with pytest.raises(kq.KqError):
+        bank.push_rtp(huge)
+    bank.close()

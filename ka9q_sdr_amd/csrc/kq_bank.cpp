@@ -526,7 +526,20 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     Scope t(b, 0, b->stream);
     // full-spectrum path: the register-resident N = 16384 kernel where it applies (KQ_FULL_LDS=1 forces the LDS one)
     static bool const lds_only = getenv("KQ_FULL_LDS") && atoi(getenv("KQ_FULL_LDS")) != 0;
-    auto const full_launch = (!lds_only && kq::full16k_supported(g)) ? kq::launch_filter_full16k : kq::launch_filter_full;
+    bool const use16k = !lds_only && kq::full16k_supported(g);
+    // No sweep anywhere: the register-resident kernel runs without its per-sample oscillator path; the first block of
+    // a channel retuned since the last call (history still on the old oscillator) is then redone below with the
+    // general variant, as the pruned path does.
+    bool plain = true;
+    for (HostChan const &h : b->chans)
+      if (h.active && h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0) != 0) plain = false;
+    auto const full_launch = [&](hipStream_t st, const kq::Geom &gg, const kq::ChanDev &cd, const kq::Planes &pp, const float2 *win,
+                                 const float2 *twp, int nch, int nbl, int n0, float2 *dump, int dump_ch, const int *list) {
+      if (use16k)
+        kq::launch_filter_full16k(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list, plain && list == nullptr);
+      else
+        kq::launch_filter_full(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list);
+    };
     if (b->fwd_mode == KQ_FWD_PRUNED) {
       if (b->chan_tw_dirty) {  // the tables depend only on each channel's LO step: rebuild after a retune
         kq::launch_pruned_tables(b->stream, g, chd, b->chan_tw, C);
@@ -546,6 +559,8 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     } else {
       full_launch(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, b->cfg.compute_n0, b->spec_dump, b->spec_ch,
                   nullptr);
+      if (use16k && plain && nret > 0)
+        full_launch(b->stream, g, chd, pl, window, b->tw, nret, 1, b->cfg.compute_n0, b->spec_dump, b->spec_ch, retune_list);
     }
     LAUNCH_CHECK("pre-detection filter");
     b->acc.filter_launches++;

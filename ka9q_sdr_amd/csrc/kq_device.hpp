@@ -119,9 +119,10 @@ void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const P
                         const int *chan_list);
 // register-resident N = 16384 variant of the same (kq_full16k.hip)
 bool full16k_supported(const Geom &g);
+// plain: no channel of the launch has a sweep rate or a retune pending (a leaner kernel variant serves that case)
 void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
-                           const int *chan_list);
+                           const int *chan_list, bool plain);
 bool split_supported(const Geom &g);
 void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                          const float2 *tw, int nchan, int nblocks, const int *chan_list);

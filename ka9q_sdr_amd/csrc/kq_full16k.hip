@@ -95,8 +95,11 @@ __device__ __forceinline__ v2f phasor2(double turns) {
 }  // namespace
 
 // grid (channel, block); dynamic LDS = kXchElems float2 (the epilogue's 2 * N_dec float2 fit in it).
-// N0: compute_n0 on every block (needs ch.n0mask / ch.n0meta); DUMP: copy one channel's spectra out (tests).
-template <bool N0, bool DUMP>
+// N0: compute_n0 on every block (needs ch.n0mask / ch.n0meta); DUMP: copy one channel's spectra out (tests); PLAIN: the
+// host vouches that no channel of the launch sweeps or was retuned since the last call -- the steady state of a
+// receiver -- so the per-sample oscillator path (2000 instructions of double arithmetic) is left out and the window
+// loads can be issued before anything else (with that path in the kernel they cost it 24 spilled registers).
+template <bool N0, bool DUMP, bool PLAIN>
 __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,
                                                        const float2 *__restrict__ tw, const float2 *__restrict__ tab,
                                                        float2 *__restrict__ spec_dump, int spec_ch,
@@ -106,27 +109,33 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   __shared__ float red_f[2][kT / 64];  // compute_n0: one slot per wave and pass
   __shared__ float red_c[kT / 64];     //   bins counted by the fast second pass (exact in float: at most 16384)
   __shared__ int red_i[2][kT / 64];
-  int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
   int const t = threadIdx.x;
   int const Ndec = g.Ndec;
 
-  // ---------------- load + NCO mix (radio.c:132-139), samples n = 512 n1 + t into v[bitrev5(n1)]
+  // ---------------- load: samples n = 512 n1 + t into v[bitrev5(n1)].  The 32 window loads need nothing but the kernel
+  // arguments, so they go out before the channel's parameters are even asked for: a workgroup's first microsecond is
+  // otherwise two memory latencies in a row (parameters, then samples) with nothing to compute.
   v2f v[32];
+  rsrc_t const xr = make_rsrc(window + (size_t)blockIdx.y * g.L, kN * (unsigned)sizeof(float2));
+  unsigned const toff = (unsigned)t * (unsigned)sizeof(float2);
+  auto load_window = [&]() {
+#pragma unroll
+    for (int n1 = 0; n1 < 32; n1++) v[rfft::bitrev5(n1)] = buf_ld2(xr, toff, (unsigned)n1 * (unsigned)(512 * sizeof(float2)));
+  };
+  if constexpr (PLAIN) load_window();
+  int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
+
+  // ---------------- NCO mix (radio.c:132-139)
   {
     double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c], r = ch.lo_rate[c];
     double const hp0 = ch.hist_phase[c], hf0 = ch.hist_freq[c], hr = ch.hist_rate[c];
-    rsrc_t const xr = make_rsrc(window + (size_t)b * g.L, kN * (unsigned)sizeof(float2));
-    unsigned const toff = (unsigned)t * (unsigned)sizeof(float2);
-    auto ldx = [&](int n1) { return buf_ld2(xr, toff, (unsigned)n1 * (unsigned)(512 * sizeof(float2))); };
     double const mbase = (double)b * g.L;
     bool const retuned = b == 0 && (hp0 != ph0 || hf0 != f0 || hr != r);
-    if (r == 0.0 && !retuned) {
+    if (PLAIN || (r == 0.0 && !retuned)) {
+      if constexpr (!PLAIN) load_window();
       // The phasor of sample 512 n1 + t is P_t S^{n1}, S = exp(j 2 pi 512 f0).  Lane n1 of each wave evaluates S^{n1}
       // from the double-precision phase into the wave's own LDS slot; every lane then reads entry n1 (a broadcast
       // read).  One phasor evaluation and one product per sample, each power exact to float rounding.
-      // The window loads go out first; the phasors are evaluated while they are in flight.
-#pragma unroll
-      for (int n1 = 0; n1 < 32; n1++) v[rfft::bitrev5(n1)] = ldx(n1);
       float2 *const sw = stab + (t >> 6) * 32;
       if ((t & 63) < 32) sw[t & 63] = phasor_turns(f0 * (double)(512 * (t & 63)));
       v2f const pt = phasor2(ph0 + f0 * (mbase + t));
@@ -138,7 +147,9 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
         v2f const p = n1 ? pk_cmul(pt, ld2(sw + n1)) : pt;
         v[rfft::bitrev5(n1)] = pk_cmul(v[rfft::bitrev5(n1)], p);
       }
-    } else {
+    } else if constexpr (!PLAIN) {
+      // swept channels, and the first block after a retune (history still on the old oscillator): closed-form phase
+      // per sample
 #pragma unroll
       for (int n1 = 0; n1 < 32; n1++) {
         int const i = 512 * n1 + t;
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
         double const rr = old ? hr : r;
         double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
         if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
-        v[rfft::bitrev5(n1)] = pk_cmul(ldx(n1), phasor2(turns));
+        v[rfft::bitrev5(n1)] = pk_cmul(buf_ld2(xr, toff, (unsigned)n1 * (unsigned)(512 * sizeof(float2))), phasor2(turns));
       }
     }
   }
@@ -480,7 +491,7 @@ static const float2 *twiddle_tables() {
 
 void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
-                           const int *chan_list) {
+                           const int *chan_list, bool plain) {
   size_t const lds_bytes = (size_t)kXchElems * sizeof(float2);
   const float2 *tab = twiddle_tables();
   if (!tab) {  // cannot happen short of an allocation failure: fall back to the LDS kernel rather than fail the block
@@ -494,10 +505,16 @@ void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
     hipLaunchKernelGGL(kernel, dim3(nchan, nblocks), dim3(kT), lds_bytes, s, g, ch, pl, window, tw, tab, spec_dump, spec_ch,
                        chan_list);
   };
+  auto pick = [&](auto n0c, auto dumpc) {
+    constexpr bool kN0 = decltype(n0c)::value, kDump = decltype(dumpc)::value;
+    plain ? go(k_filter_full16k<kN0, kDump, true>) : go(k_filter_full16k<kN0, kDump, false>);
+  };
+  using T = std::true_type;
+  using F = std::false_type;
   if (n0)
-    dump ? go(k_filter_full16k<true, true>) : go(k_filter_full16k<true, false>);
+    dump ? pick(T{}, T{}) : pick(T{}, F{});
   else
-    dump ? go(k_filter_full16k<false, true>) : go(k_filter_full16k<false, false>);
+    dump ? pick(F{}, T{}) : pick(F{}, F{});
 }
 
 }  // namespace kq

@@ -63,27 +63,33 @@ __device__ __forceinline__ v2f buf_ld2(rsrc_t r, unsigned lane_off, unsigned row
 
 // Twiddle tables (float2), computed in double on the host.  Pass 1, thread t: lo1[l-1][t] = W_N^{l t}, l = 1..3;
 // hi1[h-1][t] = W_N^{4 h t}, h = 1..7.  Pass 2, n3 = t & 15: lo2[l-1][n3] = W_N^{32 l n3}, hi2[h-1][n3] = W_N^{128 h n3}.
-// (Loading all 31 twiddles of a pass directly -- 31 coalesced loads, no products -- was measured 20 % slower: the
-// loads' latency is exposed, the 24 extra products are not.)
+// (Loading all 31 twiddles of pass 1 directly -- 31 coalesced loads, no products -- was measured 20 % slower: the
+// loads' latency is exposed, the 24 extra products are not.  Pass 2's depend on n3 = t & 15 only: all 512 of them sit
+// in LDS, kTabTw2, and lo2 / hi2 are unused.)
 constexpr int kTabLo1 = 0, kTabHi1 = 3 * kT, kTabLo2 = 10 * kT, kTabHi2 = 10 * kT + 3 * 16;
 // N/D = 64 epilogue (one wave, lane t): epi[s-1][t], s = 1..5 = twiddle of inverse-transform stage s (span 2^s) as lane t
 // applies it: exp(+j pi (t mod 2^s) / 2^s) in the upper lane of a butterfly pair (t & 2^s), 1 in the lower one
-constexpr int kTabEpi = 10 * kT + 10 * 16, kTabSize = kTabEpi + 5 * 64;
+constexpr int kTabEpi = 10 * kT + 10 * 16;
+// all of pass 2's twiddles: tw2[n3][k2] = W_N^{32 n3 k2} (n3 < 16, k2 < 32), copied into LDS by every workgroup
+constexpr int kTabTw2 = kTabEpi + 5 * 64, kTabSize = kTabTw2 + 512;
+constexpr int kTw2Pitch = 34;  // LDS row pitch (elements): lane n3 reads 16 bytes at 272 n3 + 8 k2, distinct 16-byte slots
 
-// v[q] *= W^{q}, q = 0..31, W^{q} = lo[q & 3] * hi[q >> 2]; lo/hi rows start at element lo_row / hi_row of the
-// table and are `stride` elements apart; lane_off = byte offset of the thread's column
-__device__ __forceinline__ void twiddle32(v2f (&v)[32], rsrc_t tab, unsigned lane_off, int lo_row, int hi_row, int stride) {
+// v[q] *= c W^{q}, q = 0..31, W^{q} = lo[q & 3] * hi[q >> 2]; lo/hi rows start at element lo_row / hi_row of the
+// table and are `stride` elements apart; lane_off = byte offset of the thread's column.  The common factor c is the
+// thread's NCO phasor P_t: folded into the four `lo` values here it costs 11 products more than the bare twiddles,
+// where multiplying it into the 31 row phasors S^{n1} before the transform cost 31.
+__device__ __forceinline__ void twiddle32(v2f (&v)[32], rsrc_t tab, unsigned lane_off, int lo_row, int hi_row, int stride, v2f c) {
   v2f lo[4];
+  lo[0] = c;
 #pragma unroll
-  for (int l = 1; l < 4; l++) lo[l] = buf_ld2(tab, lane_off, (unsigned)(lo_row + (l - 1) * stride) * 8u);
+  for (int l = 1; l < 4; l++) lo[l] = pk_cmul(c, buf_ld2(tab, lane_off, (unsigned)(lo_row + (l - 1) * stride) * 8u));
 #pragma unroll
-  for (int l = 1; l < 4; l++) v[l] = pk_cmul(v[l], lo[l]);
+  for (int l = 0; l < 4; l++) v[l] = pk_cmul(v[l], lo[l]);
 #pragma unroll
   for (int h = 1; h < 8; h++) {
     v2f const hi = buf_ld2(tab, lane_off, (unsigned)(hi_row + (h - 1) * stride) * 8u);
-    v[4 * h] = pk_cmul(v[4 * h], hi);
 #pragma unroll
-    for (int l = 1; l < 4; l++) v[4 * h + l] = pk_cmul(v[4 * h + l], pk_cmul(hi, lo[l]));
+    for (int l = 0; l < 4; l++) v[4 * h + l] = pk_cmul(v[4 * h + l], pk_cmul(hi, lo[l]));
   }
 }
 
@@ -106,6 +112,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
                                                        const int *__restrict__ chan_list) {
   extern __shared__ __attribute__((aligned(16))) float2 xch[];
   __shared__ __attribute__((aligned(16))) float2 stab[(kT / 64) * 32];  // per wave: S^{n1}, see the mix
+  __shared__ __attribute__((aligned(16))) float2 tw2[16 * kTw2Pitch];   // pass 2's twiddles W_N^{32 n3 k2} at [n3][k2]
   __shared__ float red_f[2][kT / 64];  // compute_n0: one slot per wave and pass
   __shared__ float red_c[kT / 64];     //   bins counted by the fast second pass (exact in float: at most 16384)
   __shared__ int red_i[2][kT / 64];
@@ -123,9 +130,14 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     for (int n1 = 0; n1 < 32; n1++) v[rfft::bitrev5(n1)] = buf_ld2(xr, toff, (unsigned)n1 * (unsigned)(512 * sizeof(float2)));
   };
   if constexpr (PLAIN) load_window();
+  {  // pass 2's twiddle table into LDS (read behind transpose 1's barriers)
+    v2f const w = buf_ld2(make_rsrc(tab, kTabSize * (unsigned)sizeof(float2)), (unsigned)t * 8u, (unsigned)kTabTw2 * 8u);
+    tw2[(t >> 5) * kTw2Pitch + (t & 31)] = make_float2(w.x, w.y);
+  }
   int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
 
   // ---------------- NCO mix (radio.c:132-139)
+  v2f pt = (v2f){1.f, 0.f};
   {
     double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c], r = ch.lo_rate[c];
     double const hp0 = ch.hist_phase[c], hf0 = ch.hist_freq[c], hr = ch.hist_rate[c];
@@ -138,15 +150,14 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
       // read).  One phasor evaluation and one product per sample, each power exact to float rounding.
       float2 *const sw = stab + (t >> 6) * 32;
       if ((t & 63) < 32) sw[t & 63] = phasor_turns(f0 * (double)(512 * (t & 63)));
-      v2f const pt = phasor2(ph0 + f0 * (mbase + t));
+      // (P_t, the same for the thread's 32 samples, commutes with the transform over n1: it rides on pass 1's
+      // twiddles below)
+      pt = phasor2(ph0 + f0 * (mbase + t));
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int n1 = 0; n1 < 32; n1++) {
-        v2f const p = n1 ? pk_cmul(pt, ld2(sw + n1)) : pt;
-        v[rfft::bitrev5(n1)] = pk_cmul(v[rfft::bitrev5(n1)], p);
-      }
+      for (int n1 = 1; n1 < 32; n1++) v[rfft::bitrev5(n1)] = pk_cmul(v[rfft::bitrev5(n1)], ld2(sw + n1));
     } else if constexpr (!PLAIN) {
       // swept channels, and the first block after a retune (history still on the old oscillator): closed-form phase
       // per sample
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   // ---------------- pass 1: 32-point transforms over n1, twiddle W_N^{t k1}
   rfft::fft_dit_pk<32>(v);
   rsrc_t const tabr = make_rsrc(tab, kTabSize * (unsigned)sizeof(float2));
-  twiddle32(v, tabr, (unsigned)t * 8u, kTabLo1, kTabHi1, kT);
+  twiddle32(v, tabr, (unsigned)t * 8u, kTabLo1, kTabHi1, kT, pt);
 
   // ---------------- transpose 1: [k1][t] -> thread (k1 = t >> 4, n3 = t & 15) gathers n2 = 0..31.
   // Half round A carries k1 < 16 (read by threads t < 256), half round B the rest.
@@ -188,7 +199,16 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
 
   // ---------------- pass 2: 32-point transforms over n2, twiddle W_512^{n3 k2} = W_N^{32 n3 k2}
   rfft::fft_dit_pk<32>(u);
-  twiddle32(u, tabr, (unsigned)(t & 15) * 8u, kTabLo2, kTabHi2, 16);
+  {
+    // all 31 from the workgroup's LDS copy of the table (two per 16-byte read): no products of table entries
+    const float4 *row = reinterpret_cast<const float4 *>(tw2 + (t & 15) * kTw2Pitch);
+#pragma unroll
+    for (int k2 = 0; k2 < 32; k2 += 2) {
+      float4 const w = row[k2 / 2];
+      if (k2) u[k2] = pk_cmul(u[k2], (v2f){w.x, w.y});
+      u[k2 + 1] = pk_cmul(u[k2 + 1], (v2f){w.z, w.w});
+    }
+  }
 
   // ---------------- transpose 2: [n3][k1][k2] -> thread (k1 = t >> 5 (+16), k2 = t & 31) gathers n3 = 0..15.
   // Half round A is written by the threads holding k1 < 16 (t < 256) and yields ya, half round B yields yb.
@@ -473,6 +493,8 @@ static const float2 *twiddle_tables() {
     for (int l = 1; l < 4; l++) h[kTabLo2 + (l - 1) * 16 + n3] = w(32LL * l * n3);
     for (int hh = 1; hh < 8; hh++) h[kTabHi2 + (hh - 1) * 16 + n3] = w(128LL * hh * n3);
   }
+  for (int n3 = 0; n3 < 16; n3++)
+    for (int k2 = 0; k2 < 32; k2++) h[kTabTw2 + 32 * n3 + k2] = w(32LL * n3 * k2);
   for (int st = 1; st <= 5; st++)
     for (int t = 0; t < 64; t++) {
       int const half = 1 << st;

@@ -45,6 +45,9 @@ namespace {
 __device__ __forceinline__ rfft::v2f as_v2f(float2 a) { return (rfft::v2f){a.x, a.y}; }
 __device__ __forceinline__ float2 as_f2(rfft::v2f a) { return make_float2(a.x, a.y); }
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return as_f2(rfft::pk_cmul(as_v2f(a), as_v2f(b))); }
+// the same left to the compiler: for operands that are compile-time rotations or wave-uniform (the asm form would
+// force them into fresh vector registers)
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { return as_f2(rfft::pk_cmul_any(as_v2f(a), as_v2f(b))); }
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
@@ -210,10 +213,10 @@ __device__ __forceinline__ void column_pass(const float2 *col, const float4 *tab
                             : rot == 2 ? make_float2(-A.x, -A.y)
                                        : make_float2(-A.y, A.x);
           if (e8 & 1) {
-            ro = first_o ? cmul(x[s], As) : cfma(x[s], As, ro);
+            ro = first_o ? cmulc(x[s], As) : cfma(x[s], As, ro);
             first_o = false;
           } else {
-            re = first_e ? cmul(x[s], As) : cfma(x[s], As, re);
+            re = first_e ? cmulc(x[s], As) : cfma(x[s], As, re);
             first_e = false;
           }
         }

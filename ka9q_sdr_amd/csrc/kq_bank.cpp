@@ -212,8 +212,8 @@ int upload(kq_bank *b, void *dst, const void *src, size_t bytes) {
 }
 
 // compute_n0's passband exclusion (radio.c:405-411) depends only on the channel's filter edges: one bit per bin,
-// in the order k_filter_full16k holds the bins (thread t: bins ka + 1024 k3 in bits 0..15, ka + 16 + 1024 k3 in
-// bits 16..31, ka = (t >> 5) + 32 (t & 31)).  Same arithmetic as the kernel's fallback, int wrap included.
+// in the order k_filter_full16k holds the bins (thread t: bins ka + 1024 k3 in bits 0..15, ka + kFull16kHalf + 1024 k3
+// in bits 16..31, ka = full16k_bin(t)).  Same arithmetic as the kernel's fallback, int wrap included.
 int upload_n0mask(kq_bank *b, int c) {
   if (!b->chd.n0mask) return 0;
   kq::Geom const &g = b->g;
@@ -221,10 +221,10 @@ int upload_n0mask(kq_bank *b, int c) {
   std::vector<unsigned> m(512, 0u);
   unsigned rows = 0, outside = 0;  // rows of 1024 bins holding a passband bin; bins outside the passband
   for (int t = 0; t < 512; t++) {
-    int const ka = (t >> 5) + 32 * (t & 31);
+    int const ka = kq::full16k_bin(t);
     for (int half = 0; half < 2; half++)
       for (int k3 = 0; k3 < 16; k3++) {
-        int const n = ka + 16 * half + 1024 * k3;
+        int const n = ka + kq::kFull16kHalf * half + 1024 * k3;
         int const k = (n <= g.N / 2) ? n : n - g.N;
         int const prod = (int)((unsigned)k * (unsigned)g.samprate);
         float const f = (float)prod / g.N;

@@ -36,9 +36,11 @@ namespace {
 constexpr int kN = 16384, kT = 512;
 // Both transposes move complex (8-byte) elements in two half rounds, so the buffer holds half of the data.
 constexpr int kRow1 = 528;    // transpose 1: [k1 & 15][16 n2 + n3]; rows 4224 B apart alternate 128-byte bank halves
-constexpr int kCol2 = 32;     // transpose 2: [n3][32 (k1 & 15) + k2], rows kRow2 apart.  A ds_write_b64 is served in groups of
-constexpr int kRow2 = 513;    //   16 consecutive lanes over 32 banks (16 eight-byte slots): the 16 n3 of a group need an odd pitch;
-                              //   the reads are 32 consecutive elements per lane group whatever the pitches
+constexpr int kWave2 = 65;    // transpose 2, per wave: [n3][16 (k1 & 3) + (k2 & 15)]; row n3 of wave w starts at n3 kRow2 + w kWave2.
+constexpr int kRow2 = 521;    //   A ds_write_b64 is served in groups of 16 consecutive lanes over 32 banks (16 eight-byte slots):
+                              //   the 16 n3 of a group need an odd pitch; a read is 64 consecutive elements.  (The waves' rows
+                              //   are interleaved so that rows are more than 255 elements apart: with a pitch of 65 the compiler
+                              //   pairs the reads into ds_read2_b64, which occupy the LDS 12 cycles where two ds_read_b64 take 8.)
 constexpr int kXchElems = 16 * kRow1;  // float2 elements; 16 * kRow2 fits as well
 
 using rfft::pk_cmul;
@@ -74,23 +76,31 @@ constexpr int kTabEpi = 10 * kT + 10 * 16;
 constexpr int kTabTw2 = kTabEpi + 5 * 64, kTabSize = kTabTw2 + 512;
 constexpr int kTw2Pitch = 34;  // LDS row pitch (elements): lane n3 reads 16 bytes at 272 n3 + 8 k2, distinct 16-byte slots
 
-// v[q] *= c W^{q}, q = 0..31, W^{q} = lo[q & 3] * hi[q >> 2]; lo/hi rows start at element lo_row / hi_row of the
-// table and are `stride` elements apart; lane_off = byte offset of the thread's column.  The common factor c is the
-// thread's NCO phasor P_t: folded into the four `lo` values here it costs 11 products more than the bare twiddles,
-// where multiplying it into the 31 row phasors S^{n1} before the transform cost 31.
-__device__ __forceinline__ void twiddle32(v2f (&v)[32], rsrc_t tab, unsigned lane_off, int lo_row, int hi_row, int stride, v2f c) {
+// Pass 1's twiddles.  lo/hi rows start at element lo_row / hi_row of the table and are `stride` elements apart; lane_off =
+// byte offset of the thread's column.  The common factor c is the thread's NCO phasor P_t: folded into the four `lo`
+// values here it costs 11 products more than the bare twiddles, where multiplying it into the 31 row phasors S^{n1}
+// before the transform cost 31.
+// v[q] *= c W^{q}, q = 0..31, W^{q} = lo[q & 3] * hi[q >> 2]; tlo = W^1..W^3, thi = W^4, W^8 .. W^28 of the thread's column.
+__device__ __forceinline__ void twiddle32(v2f (&v)[32], const v2f (&tlo)[3], const v2f (&thi)[7], v2f c) {
   v2f lo[4];
   lo[0] = c;
 #pragma unroll
-  for (int l = 1; l < 4; l++) lo[l] = pk_cmul(c, buf_ld2(tab, lane_off, (unsigned)(lo_row + (l - 1) * stride) * 8u));
+  for (int l = 1; l < 4; l++) lo[l] = pk_cmul(c, tlo[l - 1]);
 #pragma unroll
   for (int l = 0; l < 4; l++) v[l] = pk_cmul(v[l], lo[l]);
 #pragma unroll
   for (int h = 1; h < 8; h++) {
-    v2f const hi = buf_ld2(tab, lane_off, (unsigned)(hi_row + (h - 1) * stride) * 8u);
 #pragma unroll
-    for (int l = 0; l < 4; l++) v[4 * h + l] = pk_cmul(v[4 * h + l], pk_cmul(hi, lo[l]));
+    for (int l = 0; l < 4; l++) v[4 * h + l] = pk_cmul(v[4 * h + l], pk_cmul(thi[h - 1], lo[l]));
   }
+}
+// its ten table entries: requested right behind the window loads -- asked for where they are used, after the transform,
+// each batch is a full trip to L2 with nothing to overlap it
+__device__ __forceinline__ void twiddle32_fetch(v2f (&tlo)[3], v2f (&thi)[7], rsrc_t tab, unsigned lane_off, int lo_row, int hi_row, int stride) {
+#pragma unroll
+  for (int l = 0; l < 3; l++) tlo[l] = buf_ld2(tab, lane_off, (unsigned)(lo_row + l * stride) * 8u);
+#pragma unroll
+  for (int h = 0; h < 7; h++) thi[h] = buf_ld2(tab, lane_off, (unsigned)(hi_row + h * stride) * 8u);
 }
 
 __device__ __forceinline__ v2f phasor2(double turns) {
@@ -113,6 +123,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   extern __shared__ __attribute__((aligned(16))) float2 xch[];
   __shared__ __attribute__((aligned(16))) float2 stab[(kT / 64) * 32];  // per wave: S^{n1}, see the mix
   __shared__ __attribute__((aligned(16))) float2 tw2[16 * kTw2Pitch];   // pass 2's twiddles W_N^{32 n3 k2} at [n3][k2]
+  __shared__ __attribute__((aligned(16))) float2 xs_small[128];         // the slave's bins and its transform when N/D <= 64
   __shared__ float red_f[2][kT / 64];  // compute_n0: one slot per wave and pass
   __shared__ float red_c[kT / 64];     //   bins counted by the fast second pass (exact in float: at most 16384)
   __shared__ int red_i[2][kT / 64];
@@ -129,9 +140,12 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
 #pragma unroll
     for (int n1 = 0; n1 < 32; n1++) v[rfft::bitrev5(n1)] = buf_ld2(xr, toff, (unsigned)n1 * (unsigned)(512 * sizeof(float2)));
   };
+  rsrc_t const tabr = make_rsrc(tab, kTabSize * (unsigned)sizeof(float2));
+  v2f tlo[3], thi[7];
   if constexpr (PLAIN) load_window();
+  twiddle32_fetch(tlo, thi, tabr, toff, kTabLo1, kTabHi1, kT);
   {  // pass 2's twiddle table into LDS (read behind transpose 1's barriers)
-    v2f const w = buf_ld2(make_rsrc(tab, kTabSize * (unsigned)sizeof(float2)), (unsigned)t * 8u, (unsigned)kTabTw2 * 8u);
+    v2f const w = buf_ld2(tabr, toff, (unsigned)kTabTw2 * 8u);
     tw2[(t >> 5) * kTw2Pitch + (t & 31)] = make_float2(w.x, w.y);
   }
   int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
@@ -176,8 +190,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
 
   // ---------------- pass 1: 32-point transforms over n1, twiddle W_N^{t k1}
   rfft::fft_dit_pk<32>(v);
-  rsrc_t const tabr = make_rsrc(tab, kTabSize * (unsigned)sizeof(float2));
-  twiddle32(v, tabr, (unsigned)t * 8u, kTabLo1, kTabHi1, kT, pt);
+  twiddle32(v, tlo, thi, pt);
 
   // ---------------- transpose 1: [k1][t] -> thread (k1 = t >> 4, n3 = t & 15) gathers n2 = 0..31.
   // Half round A carries k1 < 16 (read by threads t < 256), half round B the rest.
@@ -210,29 +223,34 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     }
   }
 
-  // ---------------- transpose 2: [n3][k1][k2] -> thread (k1 = t >> 5 (+16), k2 = t & 31) gathers n3 = 0..15.
-  // Half round A is written by the threads holding k1 < 16 (t < 256) and yields ya, half round B yields yb.
+  // ---------------- transpose 2: thread (k1 = t >> 4, n3 = t & 15) holds k2 = 0..31 -> thread (k1 = t >> 4, k2 = t & 15
+  // (+16)) gathers n3 = 0..15.  The 64 threads of a wave hold four k1 with all their n3 before and after: the exchange
+  // stays inside the wave, in the wave's own slice of the buffer, and needs no workgroup barrier (a wave's LDS
+  // operations complete in order).  Half round A carries k2 < 16 and yields ya, half round B the rest and yields yb.
   v2f ya[16], yb[16];
   {
-    int const wr = (t & 15) * kRow2 + ((t >> 4) & 15) * kCol2;
-    int const rd = (t >> 5) * kCol2 + (t & 31);
+    float2 *const xw = xch + (t >> 6) * kWave2;
+    int const wr = (t & 15) * kRow2 + ((t >> 4) & 3) * 16;
+    int const rd = t & 63;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-      if ((t >> 8) == half) {
 #pragma unroll
-        for (int k2 = 0; k2 < 32; k2++) xch[wr + k2] = make_float2(u[k2].x, u[k2].y);
-      }
-      __syncthreads();
+      for (int k2 = 0; k2 < 16; k2++) xw[wr + k2] = make_float2(u[16 * half + k2].x, u[16 * half + k2].y);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int n3 = 0; n3 < 16; n3++) (half ? yb : ya)[rfft::bitrev4(n3)] = ld2(xch + n3 * kRow2 + rd);
-      __syncthreads();
+      for (int n3 = 0; n3 < 16; n3++) (half ? yb : ya)[rfft::bitrev4(n3)] = ld2(xw + n3 * kRow2 + rd);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
   }
 
   // ---------------- pass 3: 16-point transforms over n3.  ya[k3] = X[ka + 1024 k3], yb[k3] = X[kb + 1024 k3]
   rfft::fft_dit_pk<16>(ya);
   rfft::fft_dit_pk<16>(yb);
-  int const ka = (t >> 5) + 32 * (t & 31), kb = ka + 16;  // k1 + 32 k2 with k1 = t >> 5 and 16 + (t >> 5)
+  int const ka = full16k_bin(t), kb = ka + kFull16kHalf;  // k1 + 32 k2 with k1 = t >> 4 and k2 = t & 15, 16 + (t & 15)
 
   if (DUMP && c == spec_ch) {
     float2 *o = spec_dump + (size_t)b * kN;
@@ -244,8 +262,10 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   }
 
   // ---------------- slave (filter.c:206-250): the N/D bins it reads go to LDS as Xs[p], p = k mod N_dec
-  // (the exchange buffer is free since the last barrier of transpose 2; done first so that ya / yb die before compute_n0)
-  float2 *Xs = xch;
+  // (done first so that ya / yb die before compute_n0; the barrier: other waves may still be inside transpose 2)
+  // N/D <= 64 has its own 1 KiB for them, so that no wave waits here
+  if (Ndec > 64) __syncthreads();
+  float2 *Xs = Ndec > 64 ? xch : xs_small;
   float2 *G = Xs + Ndec;
   auto to_f2 = [](v2f a) { return make_float2(a.x, a.y); };
   if (Ndec <= 1024) {

@@ -1,13 +1,19 @@
 // valu_rate.hip -- issue rate of the vector instructions the FFT kernels are made of, per SIMD, on the device at hand.
 //   hipcc -O3 --offload-arch=gfx950 tools/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
-// Every wave runs a loop of 8 independent instructions of one kind (no dependent issue stalls), 8 waves per SIMD.
+// Every wave runs a loop of 8 independent instructions of one kind (no dependent issue stalls); one workgroup per CU with
+// 1, 2 or 4 waves per SIMD.  Cycles are counted by the shader's own clock counter (s_memtime) inside every wave -- mean
+// (min-max) over the waves of [cycles the wave ran / instructions its SIMD issued meanwhile] -- and the frequency the
+// counter ran at comes from the constant 100 MHz counter (s_memrealtime) beside it.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int KIND>
-__global__ __launch_bounds__(512) void k(float *out, int iters, float seed) {
+__global__ __launch_bounds__(1024) void k(float *out, int iters, float seed, unsigned long long *clk) {
+  // shader-clock (s_memtime) and 100 MHz (s_memrealtime) counters around the loop: their ratio is the clock the shader
+  // really ran at, whatever hipDeviceProp_t::clockRate says
+  unsigned long long const c0 = clock64(), r0 = wall_clock64();
   v2f a[8], b = {seed, 1.0f + seed}, c = {0.5f, 0.25f};
   v2f sconst = {1.0001f, 0.9999f};
   for (int i = 0; i < 8; i++) a[i] = (v2f){seed + i, seed - i};
@@ -30,35 +36,45 @@ __global__ __launch_bounds__(512) void k(float *out, int iters, float seed) {
   }
   float s = 0;
   for (int i = 0; i < 8; i++) s += a[i].x + a[i].y + f[i];
+  if ((threadIdx.x & 63) == 0) {
+    int const wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    clk[2 * wave] = clock64() - c0;
+    clk[2 * wave + 1] = wall_clock64() - r0;
+  }
   if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
 template <int KIND>
-double run(const char *name) {
+void run(const char *name) {
   int dev = 0;
   hipDeviceProp_t p;
-  hipGetDeviceProperties(&p, dev);
-  int const cus = p.multiProcessorCount, iters = 20000;
+  (void)hipGetDeviceProperties(&p, dev);
+  int const cus = p.multiProcessorCount, iters = 100000;
   float *out;
-  hipMalloc(&out, 4096);
-  dim3 grid(cus * 4), block(512);   // 4 workgroups of 8 waves per CU = 8 waves per SIMD
-  hipLaunchKernelGGL(k<KIND>, grid, block, 0, 0, out, 100, 1.0f);
-  hipDeviceSynchronize();
-  hipEvent_t e0, e1;
-  hipEventCreate(&e0);
-  hipEventCreate(&e1);
-  hipEventRecord(e0);
-  hipLaunchKernelGGL(k<KIND>, grid, block, 0, 0, out, iters, 1.0f);
-  hipEventRecord(e1);
-  hipEventSynchronize(e1);
-  float ms;
-  hipEventElapsedTime(&ms, e0, e1);
-  double const wave_instrs_per_simd = 8.0 * iters * 8;    // 8 waves x iters x 8 instructions
-  double const clk = p.clockRate * 1e3;                   // Hz
-  double const cyc = ms * 1e-3 * clk / wave_instrs_per_simd;
-  printf("%-46s %.3f ms  %.2f cycles per wave-instruction per SIMD (at %.0f MHz)\n", name, ms, cyc, clk / 1e6);
-  hipFree(out);
-  return cyc;
+  unsigned long long *clk;
+  (void)hipMalloc(&out, 4096);
+  (void)hipMalloc(&clk, sizeof(unsigned long long) * 2 * 16 * cus);
+  printf("%-46s", name);
+  for (int w = 1; w <= 4; w *= 2) {   // waves per SIMD: one workgroup of 4 w waves per CU
+    std::vector<unsigned long long> h(2 * 4 * w * cus);
+    dim3 grid(cus), block(256 * w);
+    hipLaunchKernelGGL(k<KIND>, grid, block, 0, 0, out, 1000, 1.0f, clk);
+    hipLaunchKernelGGL(k<KIND>, grid, block, 0, 0, out, iters, 1.0f, clk);
+    (void)hipMemcpy(h.data(), clk, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost);
+    double cyc = 0, mhz = 0, lo = 1e30, hi = 0;
+    int const nw = 4 * w * cus;
+    for (int i = 0; i < nw; i++) {
+      double const c = (double)h[2 * i] / ((double)iters * 8 * w);   // shader cycles the wave ran / instructions its SIMD issued meanwhile
+      cyc += c / nw;
+      lo = c < lo ? c : lo;
+      hi = c > hi ? c : hi;
+      mhz += (double)h[2 * i] / ((double)h[2 * i + 1] / 100e6) / 1e6 / nw;
+    }
+    printf("  %d/SIMD: %.2f (%.2f-%.2f) @%4.0f MHz", w, cyc, lo, hi, mhz);
+  }
+  printf("\n");
+  (void)hipFree(out);
+  (void)hipFree(clk);
 }
 
 int main() {

@@ -121,8 +121,8 @@ void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const P
 bool full16k_supported(const Geom &g);
 // where k_filter_full16k leaves the spectrum: thread t holds bins full16k_bin(t) + kFull16kHalf * half + 1024 * k3
 // (half = 0, 1; k3 = 0..15); ChanDev::n0mask is laid out to match (bit 16 * half + k3 of word t)
-constexpr int kFull16kHalf = 512;
-constexpr int full16k_bin(int t) { return (t >> 4) + 32 * (t & 15); }
+constexpr int kFull16kHalf = 16;
+constexpr int full16k_bin(int t) { return (t >> 5) + 32 * (t & 31); }
 // plain: no channel of the launch has a sweep rate or a retune pending (a leaner kernel variant serves that case)
 void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,

@@ -29,6 +29,24 @@
 #include "kq_lane.hpp"
 #include "kq_regfft.hpp"
 
+// -DKQ_TIMELINE (never in a shipped build): wave 0..7 of 64 sampled workgroups stamp the shader clock between the phases;
+// tools/timeline.py reads the stamps back through kq_debug_timeline.
+#ifdef KQ_TIMELINE
+__device__ unsigned long long kq_timeline[64][8][12];
+#define KQ_STAMP(i)                                                                        \
+  do {                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    if (blockIdx.y == 40 && (blockIdx.x & 15) == 0 && (threadIdx.x & 63) == 0)            \
+      kq_timeline[blockIdx.x >> 4][threadIdx.x >> 6][i] = clock64();                       \
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+  } while (0)
+extern "C" int kq_debug_timeline(unsigned long long *dst) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(kq_timeline), sizeof(kq_timeline)) == hipSuccess ? 0 : -1;
+}
+#else
+#define KQ_STAMP(i)
+#endif
+
 namespace kq {
 
 namespace {
@@ -36,11 +54,9 @@ namespace {
 constexpr int kN = 16384, kT = 512;
 // Both transposes move complex (8-byte) elements in two half rounds, so the buffer holds half of the data.
 constexpr int kRow1 = 528;    // transpose 1: [k1 & 15][16 n2 + n3]; rows 4224 B apart alternate 128-byte bank halves
-constexpr int kWave2 = 65;    // transpose 2, per wave: [n3][16 (k1 & 3) + (k2 & 15)]; row n3 of wave w starts at n3 kRow2 + w kWave2.
-constexpr int kRow2 = 521;    //   A ds_write_b64 is served in groups of 16 consecutive lanes over 32 banks (16 eight-byte slots):
-                              //   the 16 n3 of a group need an odd pitch; a read is 64 consecutive elements.  (The waves' rows
-                              //   are interleaved so that rows are more than 255 elements apart: with a pitch of 65 the compiler
-                              //   pairs the reads into ds_read2_b64, which occupy the LDS 12 cycles where two ds_read_b64 take 8.)
+constexpr int kCol2 = 32;     // transpose 2: [n3][32 (k1 & 15) + k2], rows kRow2 apart.  A ds_write_b64 is served in groups of
+constexpr int kRow2 = 513;    //   16 consecutive lanes over 32 banks (16 eight-byte slots): the 16 n3 of a group need an odd pitch;
+                              //   the reads are 32 consecutive elements per lane group whatever the pitches
 constexpr int kXchElems = 16 * kRow1;  // float2 elements; 16 * kRow2 fits as well
 
 using rfft::pk_cmul;
@@ -123,7 +139,6 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   extern __shared__ __attribute__((aligned(16))) float2 xch[];
   __shared__ __attribute__((aligned(16))) float2 stab[(kT / 64) * 32];  // per wave: S^{n1}, see the mix
   __shared__ __attribute__((aligned(16))) float2 tw2[16 * kTw2Pitch];   // pass 2's twiddles W_N^{32 n3 k2} at [n3][k2]
-  __shared__ __attribute__((aligned(16))) float2 xs_small[128];         // the slave's bins and its transform when N/D <= 64
   __shared__ float red_f[2][kT / 64];  // compute_n0: one slot per wave and pass
   __shared__ float red_c[kT / 64];     //   bins counted by the fast second pass (exact in float: at most 16384)
   __shared__ int red_i[2][kT / 64];
@@ -133,6 +148,12 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   // ---------------- load: samples n = 512 n1 + t into v[bitrev5(n1)].  The 32 window loads need nothing but the kernel
   // arguments, so they go out before the channel's parameters are even asked for: a workgroup's first microsecond is
   // otherwise two memory latencies in a row (parameters, then samples) with nothing to compute.
+  KQ_STAMP(0);
+  // A young workgroup's first instructions -- addresses, the loads, the oscillator table -- are few, and everything it
+  // does later waits for what they start; the CU's other workgroup is older and would be served first.  So the waves
+  // run at raised priority until their samples are mixed (measured: -1.8 %; dropped earlier or later, the
+  // instruction's side effect on the compiler's schedule costs more than the priority gains).
+  __builtin_amdgcn_s_setprio(3);
   v2f v[32];
   rsrc_t const xr = make_rsrc(window + (size_t)blockIdx.y * g.L, kN * (unsigned)sizeof(float2));
   unsigned const toff = (unsigned)t * (unsigned)sizeof(float2);
@@ -148,6 +169,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     v2f const w = buf_ld2(tabr, toff, (unsigned)kTabTw2 * 8u);
     tw2[(t >> 5) * kTw2Pitch + (t & 31)] = make_float2(w.x, w.y);
   }
+  KQ_STAMP(10);  // loads issued
   int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
 
   // ---------------- NCO mix (radio.c:132-139)
@@ -167,6 +189,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
       // (P_t, the same for the thread's 32 samples, commutes with the transform over n1: it rides on pass 1's
       // twiddles below)
       pt = phasor2(ph0 + f0 * (mbase + t));
+      KQ_STAMP(11);  // oscillator table and P_t evaluated
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -188,10 +211,13 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     }
   }
 
+  KQ_STAMP(1);  // mixed: every window load has landed
+  __builtin_amdgcn_s_setprio(0);
   // ---------------- pass 1: 32-point transforms over n1, twiddle W_N^{t k1}
   rfft::fft_dit_pk<32>(v);
   twiddle32(v, tlo, thi, pt);
 
+  KQ_STAMP(2);
   // ---------------- transpose 1: [k1][t] -> thread (k1 = t >> 4, n3 = t & 15) gathers n2 = 0..31.
   // Half round A carries k1 < 16 (read by threads t < 256), half round B the rest.
   v2f u[32];
@@ -210,6 +236,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     }
   }
 
+  KQ_STAMP(3);
   // ---------------- pass 2: 32-point transforms over n2, twiddle W_512^{n3 k2} = W_N^{32 n3 k2}
   rfft::fft_dit_pk<32>(u);
   {
@@ -223,34 +250,34 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     }
   }
 
-  // ---------------- transpose 2: thread (k1 = t >> 4, n3 = t & 15) holds k2 = 0..31 -> thread (k1 = t >> 4, k2 = t & 15
-  // (+16)) gathers n3 = 0..15.  The 64 threads of a wave hold four k1 with all their n3 before and after: the exchange
-  // stays inside the wave, in the wave's own slice of the buffer, and needs no workgroup barrier (a wave's LDS
-  // operations complete in order).  Half round A carries k2 < 16 and yields ya, half round B the rest and yields yb.
+  KQ_STAMP(4);
+  // ---------------- transpose 2: [n3][k1][k2] -> thread (k1 = t >> 5 (+16), k2 = t & 31) gathers n3 = 0..15.
+  // (A wave holds four k1 with all their n3 before this exchange; laid out so that it also does afterwards, the
+  // exchange needs no workgroup barrier at all -- measured 1.6 % slower than this version: the waves drift apart and
+  // the workgroup, which holds its LDS until its last wave is done, lives longer.)
+  // Half round A is written by the threads holding k1 < 16 (t < 256) and yields ya, half round B yields yb.
   v2f ya[16], yb[16];
   {
-    float2 *const xw = xch + (t >> 6) * kWave2;
-    int const wr = (t & 15) * kRow2 + ((t >> 4) & 3) * 16;
-    int const rd = t & 63;
+    int const wr = (t & 15) * kRow2 + ((t >> 4) & 15) * kCol2;
+    int const rd = (t >> 5) * kCol2 + (t & 31);
 #pragma unroll
     for (int half = 0; half < 2; half++) {
+      if ((t >> 8) == half) {
 #pragma unroll
-      for (int k2 = 0; k2 < 16; k2++) xw[wr + k2] = make_float2(u[16 * half + k2].x, u[16 * half + k2].y);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k2 = 0; k2 < 32; k2++) xch[wr + k2] = make_float2(u[k2].x, u[k2].y);
+      }
+      __syncthreads();
 #pragma unroll
-      for (int n3 = 0; n3 < 16; n3++) (half ? yb : ya)[rfft::bitrev4(n3)] = ld2(xw + n3 * kRow2 + rd);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int n3 = 0; n3 < 16; n3++) (half ? yb : ya)[rfft::bitrev4(n3)] = ld2(xch + n3 * kRow2 + rd);
+      __syncthreads();
     }
   }
 
+  KQ_STAMP(5);
   // ---------------- pass 3: 16-point transforms over n3.  ya[k3] = X[ka + 1024 k3], yb[k3] = X[kb + 1024 k3]
   rfft::fft_dit_pk<16>(ya);
   rfft::fft_dit_pk<16>(yb);
-  int const ka = full16k_bin(t), kb = ka + kFull16kHalf;  // k1 + 32 k2 with k1 = t >> 4 and k2 = t & 15, 16 + (t & 15)
+  int const ka = full16k_bin(t), kb = ka + kFull16kHalf;  // k1 + 32 k2 with k1 = t >> 5 and 16 + (t >> 5), k2 = t & 31
 
   if (DUMP && c == spec_ch) {
     float2 *o = spec_dump + (size_t)b * kN;
@@ -261,11 +288,10 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     }
   }
 
+  KQ_STAMP(6);
   // ---------------- slave (filter.c:206-250): the N/D bins it reads go to LDS as Xs[p], p = k mod N_dec
-  // (done first so that ya / yb die before compute_n0; the barrier: other waves may still be inside transpose 2)
-  // N/D <= 64 has its own 1 KiB for them, so that no wave waits here
-  if (Ndec > 64) __syncthreads();
-  float2 *Xs = Ndec > 64 ? xch : xs_small;
+  // (the exchange buffer is free since the last barrier of transpose 2; done first so that ya / yb die before compute_n0)
+  float2 *Xs = xch;
   float2 *G = Xs + Ndec;
   auto to_f2 = [](v2f a) { return make_float2(a.x, a.y); };
   if (Ndec <= 1024) {
@@ -426,8 +452,10 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     }
   }
 
+  KQ_STAMP(7);
   // ---------------- slave, continued: response multiply, CROSS_CONJ, inverse transform
   __syncthreads();
+  KQ_STAMP(8);
   if (N0 && n0_fast && t == 0) {
     float tf = 0, bins = 0;
 #pragma unroll
@@ -465,6 +493,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     stage(std::integral_constant<int, 32>{}, epi_w[4], false);
     float2 *o = pl.filt + ((size_t)c * g.max_blocks + b) * g.olen;
     if (t >= 64 - g.olen) o[t - (64 - g.olen)] = make_float2(z.x, z.y);  // filter.c:131
+    KQ_STAMP(9);
     return;
   }
   for (int p = t; p <= Ndec / 2; p += kT) {

@@ -157,38 +157,55 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   v2f v[32];
   rsrc_t const xr = make_rsrc(window + (size_t)blockIdx.y * g.L, kN * (unsigned)sizeof(float2));
   unsigned const toff = (unsigned)t * (unsigned)sizeof(float2);
-  auto load_window = [&]() {
+  auto load_rows = [&](int first, int last) {
 #pragma unroll
-    for (int n1 = 0; n1 < 32; n1++) v[rfft::bitrev5(n1)] = buf_ld2(xr, toff, (unsigned)n1 * (unsigned)(512 * sizeof(float2)));
+    for (int n1 = first; n1 < last; n1++) v[rfft::bitrev5(n1)] = buf_ld2(xr, toff, (unsigned)n1 * (unsigned)(512 * sizeof(float2)));
   };
+  auto load_window = [&]() { load_rows(0, 32); };
   rsrc_t const tabr = make_rsrc(tab, kTabSize * (unsigned)sizeof(float2));
   v2f tlo[3], thi[7];
-  if constexpr (PLAIN) load_window();
-  twiddle32_fetch(tlo, thi, tabr, toff, kTabLo1, kTabHi1, kT);
-  {  // pass 2's twiddle table into LDS (read behind transpose 1's barriers)
-    v2f const w = buf_ld2(tabr, toff, (unsigned)kTabTw2 * 8u);
-    tw2[(t >> 5) * kTw2Pitch + (t & 31)] = make_float2(w.x, w.y);
-  }
-  KQ_STAMP(10);  // loads issued
   int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
+  v2f pt = (v2f){1.f, 0.f};
+  if constexpr (PLAIN) {
+    // The channel's two parameters are asked for before the samples, and the oscillator's table and phasor -- two
+    // double-precision evaluations, the only arithmetic a wave has before its samples arrive -- sit between the batches
+    // of loads: the memory pipeline takes the workgroup's 350 load instructions at about one per 14 cycles and a wave
+    // cannot run ahead of a load it cannot issue yet, so they cost nothing there (-1 % against parameters, table and
+    // phasor behind the last load).  The phasor of sample 512 n1 + t is P_t S^{n1}, S = exp(j 2 pi 512 f0): lane n1 of
+    // each wave evaluates S^{n1} from the double-precision phase into the wave's own LDS slot.
+    double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c];
+    load_rows(0, 12);
+    __builtin_amdgcn_sched_barrier(0);
+    float2 *const sw = stab + (t >> 6) * 32;
+    if ((t & 63) < 32) sw[t & 63] = phasor_turns(f0 * (double)(512 * (t & 63)));
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(12, 22);
+    __builtin_amdgcn_sched_barrier(0);
+    pt = phasor2(ph0 + f0 * ((double)b * g.L + t));
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(22, 32);
+  }
+  twiddle32_fetch(tlo, thi, tabr, toff, kTabLo1, kTabHi1, kT);
+  // pass 2's twiddle table goes into LDS: requested here, stored on the way into transpose 1
+  v2f const tw2_mine = buf_ld2(tabr, toff, (unsigned)kTabTw2 * 8u);
+  KQ_STAMP(10);  // loads issued
 
   // ---------------- NCO mix (radio.c:132-139)
-  v2f pt = (v2f){1.f, 0.f};
   {
     double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c], r = ch.lo_rate[c];
     double const hp0 = ch.hist_phase[c], hf0 = ch.hist_freq[c], hr = ch.hist_rate[c];
     double const mbase = (double)b * g.L;
     bool const retuned = b == 0 && (hp0 != ph0 || hf0 != f0 || hr != r);
     if (PLAIN || (r == 0.0 && !retuned)) {
-      if constexpr (!PLAIN) load_window();
-      // The phasor of sample 512 n1 + t is P_t S^{n1}, S = exp(j 2 pi 512 f0).  Lane n1 of each wave evaluates S^{n1}
-      // from the double-precision phase into the wave's own LDS slot; every lane then reads entry n1 (a broadcast
-      // read).  One phasor evaluation and one product per sample, each power exact to float rounding.
       float2 *const sw = stab + (t >> 6) * 32;
-      if ((t & 63) < 32) sw[t & 63] = phasor_turns(f0 * (double)(512 * (t & 63)));
-      // (P_t, the same for the thread's 32 samples, commutes with the transform over n1: it rides on pass 1's
-      // twiddles below)
-      pt = phasor2(ph0 + f0 * (mbase + t));
+      if constexpr (!PLAIN) {
+        load_window();
+        if ((t & 63) < 32) sw[t & 63] = phasor_turns(f0 * (double)(512 * (t & 63)));
+        pt = phasor2(ph0 + f0 * (mbase + t));
+      }
+      // One phasor evaluation and one product per sample, each power exact to float rounding; every lane reads entry n1
+      // of its wave's table (a broadcast read).  P_t, the same for the thread's 32 samples, commutes with the transform
+      // over n1: it rides on pass 1's twiddles below.
       KQ_STAMP(11);  // oscillator table and P_t evaluated
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -221,6 +238,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   // ---------------- transpose 1: [k1][t] -> thread (k1 = t >> 4, n3 = t & 15) gathers n2 = 0..31.
   // Half round A carries k1 < 16 (read by threads t < 256), half round B the rest.
   v2f u[32];
+  tw2[(t >> 5) * kTw2Pitch + (t & 31)] = make_float2(tw2_mine.x, tw2_mine.y);  // read behind transpose 1's barriers
   {
     int const rd = ((t >> 4) & 15) * kRow1 + (t & 15);
 #pragma unroll

@@ -352,14 +352,14 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     v2f pp[16];
 #pragma unroll
     for (int k3 = 0; k3 < 16; k3++) {
-      // spelled out: given `x*x + y*y` on both halves the compiler pairs the two additions into one v_pk_add_f32
-      // behind three register moves
-      v2f sa, sb;
+      // spelled out (given `x*x + y*y` on both halves the compiler pairs the additions into one v_pk_add_f32 behind three
+      // register moves).  Unpacked on purpose: a packed instruction occupies the SIMD twice as long as a plain one
+      // (tools/valu_rate.hip), so v_mul + v_fma per bin beats v_pk_mul + v_add.
       float p0, p1;
-      asm("v_pk_mul_f32 %0, %1, %1" : "=v"(sa) : "v"(ya[k3]));
-      asm("v_pk_mul_f32 %0, %1, %1" : "=v"(sb) : "v"(yb[k3]));
-      asm("v_add_f32 %0, %1, %2" : "=v"(p0) : "v"(sa.x), "v"(sa.y));
-      asm("v_add_f32 %0, %1, %2" : "=v"(p1) : "v"(sb.x), "v"(sb.y));
+      asm("v_mul_f32 %0, %1, %1" : "=v"(p0) : "v"(ya[k3].x));
+      asm("v_mul_f32 %0, %1, %1" : "=v"(p1) : "v"(yb[k3].x));
+      asm("v_fma_f32 %0, %1, %1, %0" : "+v"(p0) : "v"(ya[k3].y));
+      asm("v_fma_f32 %0, %1, %1, %0" : "+v"(p1) : "v"(yb[k3].y));
       pp[k3] = (v2f){p0, p1};
     }
     // Passband exclusion (radio.c:405-411), precomputed per channel on the host (kq_bank.cpp upload_n0mask: it depends

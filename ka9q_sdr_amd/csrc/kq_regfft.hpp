@@ -115,10 +115,13 @@ __device__ __forceinline__ void bfly_pk(v2f (&v)[NP]) {
   if constexpr (t == 0) {
     v[base + j] = a + b;
     v[base + j + half] = a - b;
-  } else if constexpr (t == 16) {  // w = -i
-    v2f const r = (v2f){b.y, -b.x};
-    v[base + j] = a + r;
-    v[base + j + half] = a - r;
+  } else if constexpr (t == 16) {  // w = -i: a +- (b.y, -b.x).  The swap and the sign ride on the operand modifiers; given the
+    // vector expression the compiler builds (b.y, -b.x) in registers first (a v_xor_b32 and a v_mov_b32 per butterfly)
+    v2f x, y;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(x) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(y) : "v"(a), "v"(b));
+    v[base + j] = x;
+    v[base + j + half] = y;
   } else {
     constexpr float wr = tw_re(t, 64), wi = tw_im(t, 64);
     v2f const u = pk_fma((v2f){-wi, wi}, b.yx, pk_fma((v2f){wr, wr}, b, a));

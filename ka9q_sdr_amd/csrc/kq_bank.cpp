@@ -157,6 +157,8 @@ struct kq_bank {
   // carrier-tracking linear channels (linear.c:129-246): own list, 65536-sample search ring per channel
   static constexpr int kMaxPll = 64;
   int *list_pll_dev = nullptr;
+  int *list_active_dev = nullptr;      // the active channels, for the filter launch, when remove_channel has left holes
+  std::vector<int> list_active_host;   // empty: no holes, the launch covers slots 0 .. chans.size() - 1
   std::vector<int> list_pll_host;
   kq::PllState *pll_state = nullptr;
   float2 *pll_rings = nullptr, *pll_side = nullptr;
@@ -447,14 +449,20 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
 int upload_lists(kq_bank *b) {
   for (int k = 0; k < 3; k++) b->list_host[k].clear();
   b->list_pll_host.clear();
+  b->list_active_host.clear();
   for (size_t c = 0; c < b->chans.size(); c++) {
     if (!b->chans[c].active) continue;
+    b->list_active_host.push_back((int)c);
     int const m = b->chans[c].cfg.demod_type;
     if (m == KQ_LINEAR_DEMOD && b->chans[c].cfg.pll)
       b->list_pll_host.push_back((int)c);  // slot = position in this list = order of creation
     else
       b->list_host[m == KQ_FM_DEMOD ? 0 : m == KQ_AM_DEMOD ? 1 : 2].push_back((int)c);
   }
+  if (b->list_active_host.size() == b->chans.size())
+    b->list_active_host.clear();  // no holes
+  else if (upload(b, b->list_active_dev, b->list_active_host.data(), b->list_active_host.size() * sizeof(int)))
+    return -1;
   if (!b->list_pll_host.empty())
     if (upload(b, b->list_pll_dev, b->list_pll_host.data(), b->list_pll_host.size() * sizeof(int))) return -1;
   for (int k = 0; k < 3; k++)
@@ -533,10 +541,12 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     bool plain = true;
     for (HostChan const &h : b->chans)
       if (h.active && h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0) != 0) plain = false;
+    // `redo`: the list names channels retuned since the last call, which need the general variant
     auto const full_launch = [&](hipStream_t st, const kq::Geom &gg, const kq::ChanDev &cd, const kq::Planes &pp, const float2 *win,
-                                 const float2 *twp, int nch, int nbl, int n0, float2 *dump, int dump_ch, const int *list) {
+                                 const float2 *twp, int nch, int nbl, int n0, float2 *dump, int dump_ch, const int *list,
+                                 bool redo = true) {
       if (use16k)
-        kq::launch_filter_full16k(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list, plain && list == nullptr);
+        kq::launch_filter_full16k(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list, plain && !redo);
       else
         kq::launch_filter_full(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list);
     };
@@ -557,8 +567,10 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     } else if (g.N > 16384) {
       kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, nullptr);
     } else {
-      full_launch(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, b->cfg.compute_n0, b->spec_dump, b->spec_ch,
-                  nullptr);
+      // slots emptied by remove_channel are skipped: the launch goes over the list of active channels then
+      bool const holes = !b->list_active_host.empty();
+      full_launch(b->stream, g, chd, pl, window, b->tw, holes ? (int)b->list_active_host.size() : C, (int)nblocks,
+                  b->cfg.compute_n0, b->spec_dump, b->spec_ch, holes ? b->list_active_dev : nullptr, false);
       if (use16k && plain && nret > 0)
         full_launch(b->stream, g, chd, pl, window, b->tw, nret, 1, b->cfg.compute_n0, b->spec_dump, b->spec_ch, retune_list);
     }
@@ -822,6 +834,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   b->pl = b->pl2[0];
   rc |= dev_alloc(&b->energy_state, 2);
   for (int k = 0; k < 3; k++) rc |= dev_alloc(&b->list_dev[k], C);
+  rc |= dev_alloc(&b->list_active_dev, C);
   if (b->fwd_mode == KQ_FWD_PRUNED) rc |= dev_alloc(&b->chan_tw, C * kq::pruned_table_elems(g));
   if (rc) {
     kq_bank_destroy(b);
@@ -874,7 +887,7 @@ int kq_bank_destroy(kq_bank *b) {
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
                   b->pl2[0].plout, b->pl2[1].plout, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
                   b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state,
-                  b->list_dev[0], b->list_dev[1], b->list_dev[2], b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->list_pll_dev, b->pll_state, b->pll_rings,
+                  b->list_dev[0], b->list_dev[1], b->list_dev[2], b->list_active_dev, b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->list_pll_dev, b->pll_state, b->pll_rings,
                   b->pll_side};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);

@@ -11,6 +11,7 @@
 // Blocks of one channel are processed in sequence with the state carried in registers, and written back
 // to HBM at the end of the launch.
 #include "kq_device.hpp"
+#include <cstdlib>
 #include "kq_lane.hpp"
 
 namespace kq {
@@ -294,6 +295,235 @@ __device__ void fm_channel_pair(const Geom &g, const ChanDev &ch, const Planes &
   }
 }
 
+// The same demodulator on TWO waves per channel (de-emphasised channels): wave 0 runs statistics, squelch and the
+// discriminator of block pair i while wave 1 runs the de-emphasis transforms, the audio store and the status records of
+// pair i - 1, handed over through LDS behind one barrier per pair.  A wave issues at most one vector instruction per 8
+// cycles (tools/valu_rate.hip), and with one channel per SIMD that rate is all this kernel gets: splitting the ~800
+// dependent instructions of a pair over two waves is worth what the longer half takes.  Every value is computed by the
+// same expressions as in fm_channel_pair.
+__device__ void fm_channel_two_waves(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
+  __shared__ float s_out[2][64], s_y[2][64];  // the discriminator's output after / before the hold (fm.c:128-144)
+  __shared__ float s_stat[2][2][5];           // [parity][half]: bb_power, snr, mask of valid samples, squelch_count, blanked
+  int const lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+  int const h = lane >> 5, n = lane & 31;
+  int const npairs = (nblocks + 1) / 2;
+  if (role == 0) {
+    float2 state = ch.fm_state[c];
+    float lastaudio = ch.lastaudio[c];
+    int sq = ch.sq_count[c];
+    const float2 *in = pl.filt + (size_t)c * g.max_blocks * 32;
+    float2 s_next = (h < nblocks) ? in[lane] : make_float2(0.f, 0.f);
+    for (int it = 0; it <= npairs; it++) {
+      if (it < npairs) {
+        int const b = 2 * it;
+        bool const have1 = b + 1 < nblocks;
+        float2 const S = s_next;
+        if (b + 2 < nblocks) s_next = (b + 2 + h < nblocks) ? in[(size_t)(b + 2) * 32 + lane] : make_float2(0.f, 0.f);
+
+        // ---- amplitude statistics and squelch (fm.c:91-114), per half
+        float const t = cnrm(S);
+        float const sum_t = hsum(t), sum_a = hsum(sqrtf(t));
+        float const bbp = sum_t / 64.f;                                  // / (2*olen), fm.c:99
+        float const amp = (float)((double)sum_a / (M_SQRT2 * 32));       // fm.c:100
+        float const variance = bbp - amp * amp;
+        float snr = amp * amp / (2 * variance) - 1;
+        snr = (0.0f > snr) ? 0.0f : snr;
+        float const snr0 = rdlane(snr, 0), snr1 = rdlane(snr, 32);
+        int nsq = sq + 1;
+        nsq = nsq > 1000 ? 1000 : nsq;
+        int const sq0 = (snr0 > 2) ? 0 : nsq;
+        nsq = sq0 + 1;
+        nsq = nsq > 1000 ? 1000 : nsq;
+        int const sq1 = have1 ? ((snr1 > 2) ? 0 : nsq) : sq0;
+        bool const open0 = sq0 < 2, open1 = have1 && sq1 < 2;
+        bool const my_open = h ? open1 : open0;
+
+        // ---- discriminator with hold (fm.c:117-144)
+        float const thr = (float)(0.55 * 0.55 * amp * amp);
+        unsigned long long const raw = __ballot(t > thr);
+        unsigned long long const m_lo = open0 ? (raw & 0xffffffffull) : 0ull;
+        unsigned long long const m_hi = open1 ? (raw >> 32) : 0ull;
+        unsigned long long const mask = m_lo | (m_hi << 32);
+        bool const valid = (mask >> lane) & 1ull;
+        unsigned long long const below = mask & ((1ull << lane) - 1ull);
+        unsigned long long const upto = mask & ((2ull << lane) - 1ull);
+        int const pv = below ? 63 - __clzll((long long)below) : -1;
+        int const lv = upto ? 63 - __clzll((long long)upto) : -1;
+        float2 const state_fb = (h && !open0) ? make_float2(0.f, 0.f) : state;
+        float const la_fb = (h && !open0) ? 0.f : lastaudio;
+        float2 const sp = shfl2(S, pv >= 0 ? pv : 0);
+        float2 const stc = pv >= 0 ? cconj(sp) : state_fb;
+        float2 const pr = cmul(S, stc);
+        float const y = valid ? atan2f(pr.y, pr.x) : 0.f;
+        float const yl = __shfl(y, lv >= 0 ? lv : 0, 64);
+        float const out = my_open ? (lv >= 0 ? yl : la_fb) : 0.f;
+
+        // ---- carried state after the pair (fm.c:133-144, 156-160)
+        {
+          int const last0 = m_lo ? 63 - __clzll((long long)m_lo) : 0;
+          int const last1 = m_hi ? 95 - __clzll((long long)m_hi) : 0;
+          float2 const sl0 = cconj(make_float2(rdlane(S.x, last0), rdlane(S.y, last0)));
+          float2 const sl1 = cconj(make_float2(rdlane(S.x, last1), rdlane(S.y, last1)));
+          float const yl0 = rdlane(y, last0), yl1 = rdlane(y, last1);
+          float2 st0 = open0 ? (m_lo ? sl0 : state) : make_float2(0.f, 0.f);
+          float la0 = open0 ? (m_lo ? yl0 : lastaudio) : 0.f;
+          if (have1) {
+            st0 = open1 ? (m_hi ? sl1 : st0) : make_float2(0.f, 0.f);
+            la0 = open1 ? (m_hi ? yl1 : la0) : 0.f;
+          }
+          state = st0;
+          lastaudio = la0;
+        }
+        sq = sq1;
+
+        // ---- hand-over
+        int const par = it & 1;
+        s_out[par][lane] = out;
+        s_y[par][lane] = y;
+        if (n == 0) {
+          float *st = s_stat[par][h];
+          st[0] = bbp;
+          st[1] = snr;
+          st[2] = __int_as_float((int)(unsigned)(mask >> (32 * h)));   // this half's mask of valid samples
+          st[3] = __int_as_float(h ? sq1 : sq0);
+          st[4] = __int_as_float(my_open ? 32 - __popcll((mask >> (32 * h)) & 0xffffffffull) : 0);
+        }
+      }
+      __syncthreads();
+    }
+    if (lane == 0) {
+      ch.fm_state[c] = state;
+      ch.lastaudio[c] = lastaudio;
+      ch.sq_count[c] = sq;
+    }
+    return;
+  }
+
+  // ---------------- wave 1: frequency offset and deviation, de-emphasis (fm.c:146-171), audio, status
+  float const gain = ch.fm_gain[c];
+  float const noise_gain = ch.noise_gain[c];
+  int const kbin = bitrev6(lane);
+  int const herm_src = bitrev6((64 - kbin) & 63);
+  float2 HAf;
+  {
+    float2 const t = ch.aresp[(size_t)c * 33 + (kbin <= 32 ? kbin : 64 - kbin)];
+    HAf = kbin <= 32 ? t : cconj(t);
+  }
+  bool const real_bin = kbin == 0 || kbin == 32;
+  float2 wf[6], wi[6];
+#pragma unroll
+  for (int s = 0; s < 6; s++) {
+    int const half = 1 << s;
+    float sn, cs;
+    sincospif((float)(lane & (half - 1)) / (float)half, &sn, &cs);
+    wf[s] = make_float2(cs, -sn);
+    wi[s] = make_float2(cs, sn);
+  }
+  float n0 = ch.n0[c];
+  float foffset = ch.foffset[c], pdev = ch.pdev[c];
+  float hist = h ? 0.f : ch.ahist[(size_t)c * 32 + lane];  // lanes 0-31: the block before b
+  float ifp_v = 0.f, n0raw_v = 0.f;
+  for (int it = 0; it <= npairs; it++) {
+    if (it >= 1) {
+      int const b = 2 * (it - 1), par = (it - 1) & 1;
+      bool const have1 = b + 1 < nblocks;
+      if ((b & 63) == 0) {  // per-block status inputs, lane i holds block b + i
+        int const bb = b + lane;
+        ifp_v = bb < nblocks ? pl.if_power[bb] : 0.f;
+        n0raw_v = (compute_n0 && bb < nblocks) ? pl.n0raw[(size_t)c * g.max_blocks + bb] : 0.f;
+      }
+      float const out = s_out[par][lane], y = s_y[par][lane];
+      unsigned const mask_h = (unsigned)__float_as_int(s_stat[par][h][2]);
+      int const sq0 = __float_as_int(s_stat[par][0][3]), sq1 = __float_as_int(s_stat[par][1][3]);
+      bool const valid = (mask_h >> n) & 1u;
+
+      // ---- frequency offset and peak deviation (fm.c:125-154), per half
+      float const sum_y = hsum(out);
+      float const vmax = hreduce((valid && n > 0) ? y : -INFINITY, [](float a, float b2) { return fmaxf(a, b2); });
+      float const vmin = hreduce((valid && n > 0) ? y : INFINITY, [](float a, float b2) { return fminf(a, b2); });
+      float const y_first = h ? rdlane(y, 32) : rdlane(y, 0);
+      float const seed = (mask_h & 1u) ? y_first : 0.f;
+      float pdev_pos = fmaxf(seed, vmax), pdev_neg = fminf(seed, vmin);
+      float const avg_f = sum_y / 32.f;
+      pdev_pos -= avg_f;
+      pdev_neg -= avg_f;
+      float const mx = (pdev_pos > -pdev_neg) ? pdev_pos : -pdev_neg;
+      float const fo_new = (float)(g.dsamprate * avg_f * (0.5 * M_1_PI));
+      float const pd_new = (float)(g.dsamprate * mx * (0.5 * M_1_PI));
+      float const fo0 = (sq0 < 1) ? rdlane(fo_new, 0) : foffset, pd0 = (sq0 < 1) ? rdlane(pd_new, 0) : pdev;
+      float const fo1 = (have1 && sq1 < 1) ? rdlane(fo_new, 32) : fo0, pd1 = (have1 && sq1 < 1) ? rdlane(pd_new, 32) : pd0;
+      foffset = fo1;
+      pdev = pd1;
+
+      float const xo = lane_xor<32>(out, lane);  // lanes 0-31: block b+1, lanes 32-63: block b
+      float2 z = make_float2(h ? xo : hist, out);  // real: [hist | b], imaginary: [b | b+1]
+#pragma unroll
+      for (int s = 5; s >= 0; s--) {  // forward, decimation in frequency: natural in, bit-reversed out
+        float2 const r = xor2_pow(z, s, lane);
+        z = ((lane >> s) & 1) ? cmul(csub(r, z), wf[s]) : cadd(z, r);
+      }
+      float2 const zm = cconj(shfl2(z, herm_src));  // conj(Z[64 - k])
+      float2 const z1 = make_float2(0.5f * (z.x + zm.x), 0.5f * (z.y + zm.y));     // spectrum of the real part
+      float2 const z2 = make_float2(0.5f * (z.y - zm.y), -0.5f * (z.x - zm.x));    // spectrum of the imaginary part
+      float2 g1 = cmul(HAf, z1), g2 = cmul(HAf, z2);  // filter.c:206-208 on both
+      if (real_bin) g1.y = g2.y = 0.f;                // the c2r transform ignores these imaginary parts
+      z = make_float2(g1.x - g2.y, g1.y + g2.x);      // g1 + j g2
+#pragma unroll
+      for (int s = 0; s < 6; s++) {  // backward, decimation in time: bit-reversed in, natural out
+        int const bit = (lane >> s) & 1;
+        float2 const v = bit ? cmul(z, wi[s]) : z;
+        float2 const r = xor2_pow(v, s, lane);
+        z = bit ? csub(r, v) : cadd(v, r);
+      }
+      // lanes 32-63 hold the kept halves: real part block b, imaginary part block b+1 (fm.c:169-170)
+      float const a0 = z.x * gain, a1 = z.y * gain;
+      if (h) {
+        pl.audio[((size_t)c * g.max_blocks + b) * 64 + n] = a0;
+        if (have1) pl.audio[((size_t)c * g.max_blocks + b + 1) * 64 + n] = a1;
+      }
+      hist = have1 ? xo : out;  // lanes 0-31: the last block processed becomes the history (filter.c:168)
+
+      // ---- status records: lane 0 writes block b, lane 32 block b+1
+      float const ifp = h ? rdlane(ifp_v, (b + 1) & 63) : rdlane(ifp_v, b & 63);
+      float const fresh0 = rdlane(n0raw_v, b & 63), fresh1 = rdlane(n0raw_v, (b + 1) & 63);
+      float n0a = n0, n0b = n0;
+      if (compute_n0) {  // fm.c:79-82, block after block
+        n0a = isnan(n0) ? fresh0 : (float)((double)n0 + .01 * (double)(fresh0 - n0));
+        n0b = have1 ? (isnan(n0a) ? fresh1 : (float)((double)n0a + .01 * (double)(fresh1 - n0a))) : n0a;
+        n0 = n0b;
+      }
+      if (n == 0 && (h == 0 || have1)) {
+        const float *st = s_stat[par][h];
+        kq_chan_status rec;
+        rec.if_power = ifp;
+        rec.noise_gain = noise_gain;
+        rec.plfreq = NAN;  // N/D = 64: the PL slave would have 2 points (fm.c:203), measurement off
+        rec.cphase = 0;
+        rec.pll_lock = 0;
+        rec.lock_count = 0;
+        rec.n0 = compute_n0 ? (h ? n0b : n0a) : NAN;
+        rec.bb_power = st[0];
+        rec.snr = st[1];
+        rec.foffset = h ? fo1 : fo0;
+        rec.pdeviation = h ? pd1 : pd0;
+        rec.agc_gain = 0;
+        rec.squelch_count = __float_as_int(st[3]);
+        rec.hangcount = 0;
+        rec.blanked = __float_as_int(st[4]);
+        rec.nout = 32;
+        pl.status[(size_t)c * g.max_blocks + b + h] = rec;
+      }
+    }
+    __syncthreads();
+  }
+  if (!h) ch.ahist[(size_t)c * 32 + lane] = hist;
+  if (lane == 0) {
+    ch.n0[c] = n0;
+    ch.foffset[c] = foffset;
+    ch.pdev[c] = pdev;
+  }
+}
+
 __device__ void fm_channel(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
   if (ch.flags[c] & FLAG_FLAT)
     fm_channel_pair<true>(g, ch, pl, c, nblocks, compute_n0);
@@ -469,19 +699,27 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
 
 }  // namespace
 
-// grid = n_fm + n_am + n_lin workgroups of one wave (one channel each)
-template <int OLEN>
-__global__ void __launch_bounds__(64) k_demod64(Geom g, ChanDev ch, Planes pl, const int *__restrict__ list_fm, int n_fm,
-                                                const int *__restrict__ list_am, int n_am,
-                                                const int *__restrict__ list_lin, int n_lin, int nblocks, int compute_n0) {
+// grid = n_fm + n_am + n_lin workgroups, one channel each: one wave, or two (THREADS = 128) of which the second joins
+// in on de-emphasised FM channels and leaves at once everywhere else
+template <int OLEN, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_demod64(Geom g, ChanDev ch, Planes pl, const int *__restrict__ list_fm, int n_fm,
+                                                     const int *__restrict__ list_am, int n_am,
+                                                     const int *__restrict__ list_lin, int n_lin, int nblocks, int compute_n0) {
   int wg = blockIdx.x;
   if (OLEN == 32) {
     if (wg < n_fm) {
-      fm_channel(g, ch, pl, list_fm[wg], nblocks, compute_n0);
+      int const c = list_fm[wg];
+      if (THREADS == 128 && !(ch.flags[c] & FLAG_FLAT)) {
+        fm_channel_two_waves(g, ch, pl, c, nblocks, compute_n0);
+        return;
+      }
+      if (threadIdx.x >= 64) return;
+      fm_channel(g, ch, pl, c, nblocks, compute_n0);
       return;
     }
     wg -= n_fm;
   }
+  if (threadIdx.x >= 64) return;
   if (wg < n_am) {
     agc_channel<false, OLEN>(g, ch, pl, list_am[wg], nblocks, compute_n0);
     return;
@@ -499,12 +737,18 @@ void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Plane
   if (g.olen == 32) {
     int const wgs = n_fm + n_am + n_lin;
     if (wgs == 0) return;
-    hipLaunchKernelGGL(k_demod64<32>, dim3(wgs), dim3(64), 0, s, g, ch, pl, list_fm, n_fm, list_am, n_am, list_lin, n_lin,
-                       nblocks, compute_n0);
+    // KQ_DEMOD_ONE_WAVE=1: the one-wave form of the FM demodulator (A/B switch)
+    static bool const one_wave = getenv("KQ_DEMOD_ONE_WAVE") && atoi(getenv("KQ_DEMOD_ONE_WAVE")) != 0;
+    if (n_fm > 0 && !one_wave)
+      hipLaunchKernelGGL((k_demod64<32, 128>), dim3(wgs), dim3(128), 0, s, g, ch, pl, list_fm, n_fm, list_am, n_am, list_lin,
+                         n_lin, nblocks, compute_n0);
+    else
+      hipLaunchKernelGGL((k_demod64<32, 64>), dim3(wgs), dim3(64), 0, s, g, ch, pl, list_fm, n_fm, list_am, n_am, list_lin, n_lin,
+                         nblocks, compute_n0);
   } else {  // olen = 64: AM / linear only; FM stays on the generic kernel (launch_demods)
     int const wgs = n_am + n_lin;
     if (wgs == 0) return;
-    hipLaunchKernelGGL(k_demod64<64>, dim3(wgs), dim3(64), 0, s, g, ch, pl, list_fm, 0, list_am, n_am, list_lin, n_lin,
+    hipLaunchKernelGGL((k_demod64<64, 64>), dim3(wgs), dim3(64), 0, s, g, ch, pl, list_fm, 0, list_am, n_am, list_lin, n_lin,
                        nblocks, compute_n0);
   }
 }

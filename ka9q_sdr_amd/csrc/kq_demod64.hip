@@ -295,32 +295,35 @@ __device__ void fm_channel_pair(const Geom &g, const ChanDev &ch, const Planes &
   }
 }
 
-// The same demodulator on TWO waves per channel (de-emphasised channels): wave 0 runs statistics, squelch and the
-// discriminator of block pair i while wave 1 runs the de-emphasis transforms, the audio store and the status records of
-// pair i - 1, handed over through LDS behind one barrier per pair.  A wave issues at most one vector instruction per 8
-// cycles (tools/valu_rate.hip), and with one channel per SIMD that rate is all this kernel gets: splitting the ~800
-// dependent instructions of a pair over two waves is worth what the longer half takes.  Every value is computed by the
-// same expressions as in fm_channel_pair.
-__device__ void fm_channel_two_waves(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
-  __shared__ float s_out[2][64], s_y[2][64];  // the discriminator's output after / before the hold (fm.c:128-144)
-  __shared__ float s_stat[2][2][5];           // [parity][half]: bb_power, snr, mask of valid samples, squelch_count, blanked
+// The same demodulator on FOUR waves per channel (de-emphasised channels), a pipeline over the block pairs: in one
+// iteration wave 0 runs statistics and squelch of pair i, wave 1 the discriminator of pair i - 1, wave 2 deviation and
+// the forward half of the de-emphasis filter of pair i - 2, wave 3 its inverse half, the audio store and the status
+// records of pair i - 3; each hand-over goes through LDS behind the iteration's one barrier.  A wave issues at most one
+// vector instruction per 8 cycles (tools/valu_rate.hip), and with one channel per SIMD that rate is all this kernel gets:
+// splitting the ~800 dependent instructions of a pair four ways is worth what the longest quarter takes.  Every value
+// is computed by the same expressions as in fm_channel_pair.
+__device__ void fm_channel_four_waves(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
+  // [parity][...]; scalars per half: see the stages
+  __shared__ float2 s_S[2][64];                 // 0 -> 1: the pair's samples
+  __shared__ float s_a[2][2][4];                // 0 -> 1: amplitude, bb_power, snr, squelch_count
+  __shared__ float s_out[2][64], s_y[2][64];    // 1 -> 2: the discriminator's output after / before the hold (fm.c:128-144)
+  __shared__ float s_b[2][2][5];                // 1 -> 2: bb_power, snr, mask of valid samples, squelch_count, blanked
+  __shared__ float2 s_z[2][64];                 // 2 -> 3: filtered spectra of both windows, g1 + j g2
+  __shared__ float s_c[2][2][6];                // 2 -> 3: bb_power, snr, foffset, pdeviation, squelch_count, blanked
   int const lane = threadIdx.x & 63, role = threadIdx.x >> 6;
   int const h = lane >> 5, n = lane & 31;
-  int const npairs = (nblocks + 1) / 2;
-  if (role == 0) {
-    float2 state = ch.fm_state[c];
-    float lastaudio = ch.lastaudio[c];
+  int const npairs = (nblocks + 1) / 2, niter = npairs + 3;
+
+  if (role == 0) {  // ---------------- statistics and squelch (fm.c:91-114), per half
     int sq = ch.sq_count[c];
     const float2 *in = pl.filt + (size_t)c * g.max_blocks * 32;
     float2 s_next = (h < nblocks) ? in[lane] : make_float2(0.f, 0.f);
-    for (int it = 0; it <= npairs; it++) {
+    for (int it = 0; it < niter; it++) {
       if (it < npairs) {
-        int const b = 2 * it;
+        int const b = 2 * it, par = it & 1;
         bool const have1 = b + 1 < nblocks;
         float2 const S = s_next;
         if (b + 2 < nblocks) s_next = (b + 2 + h < nblocks) ? in[(size_t)(b + 2) * 32 + lane] : make_float2(0.f, 0.f);
-
-        // ---- amplitude statistics and squelch (fm.c:91-114), per half
         float const t = cnrm(S);
         float const sum_t = hsum(t), sum_a = hsum(sqrtf(t));
         float const bbp = sum_t / 64.f;                                  // / (2*olen), fm.c:99
@@ -335,10 +338,35 @@ __device__ void fm_channel_two_waves(const Geom &g, const ChanDev &ch, const Pla
         nsq = sq0 + 1;
         nsq = nsq > 1000 ? 1000 : nsq;
         int const sq1 = have1 ? ((snr1 > 2) ? 0 : nsq) : sq0;
+        sq = sq1;
+        s_S[par][lane] = S;
+        if (n == 0) {
+          float *st = s_a[par][h];
+          st[0] = amp;
+          st[1] = bbp;
+          st[2] = snr;
+          st[3] = __int_as_float(h ? sq1 : sq0);
+        }
+      }
+      __syncthreads();
+    }
+    if (lane == 0) ch.sq_count[c] = sq;
+    return;
+  }
+
+  if (role == 1) {  // ---------------- discriminator with hold (fm.c:117-144)
+    float2 state = ch.fm_state[c];
+    float lastaudio = ch.lastaudio[c];
+    for (int it = 0; it < niter; it++) {
+      if (it >= 1 && it - 1 < npairs) {
+        int const b = 2 * (it - 1), par = (it - 1) & 1;
+        bool const have1 = b + 1 < nblocks;
+        float2 const S = s_S[par][lane];
+        float const amp = s_a[par][h][0];
+        int const sq0 = __float_as_int(s_a[par][0][3]), sq1 = __float_as_int(s_a[par][1][3]);
         bool const open0 = sq0 < 2, open1 = have1 && sq1 < 2;
         bool const my_open = h ? open1 : open0;
-
-        // ---- discriminator with hold (fm.c:117-144)
+        float const t = cnrm(S);
         float const thr = (float)(0.55 * 0.55 * amp * amp);
         unsigned long long const raw = __ballot(t > thr);
         unsigned long long const m_lo = open0 ? (raw & 0xffffffffull) : 0ull;
@@ -349,6 +377,8 @@ __device__ void fm_channel_two_waves(const Geom &g, const ChanDev &ch, const Pla
         unsigned long long const upto = mask & ((2ull << lane) - 1ull);
         int const pv = below ? 63 - __clzll((long long)below) : -1;
         int const lv = upto ? 63 - __clzll((long long)upto) : -1;
+        // with no predecessor in the mask: block b falls back on the carried state, block b+1 on what block b leaves
+        // behind when it has no valid sample either -- the carried state if b is open, zero if it is squelched
         float2 const state_fb = (h && !open0) ? make_float2(0.f, 0.f) : state;
         float const la_fb = (h && !open0) ? 0.f : lastaudio;
         float2 const sp = shfl2(S, pv >= 0 ? pv : 0);
@@ -357,8 +387,7 @@ __device__ void fm_channel_two_waves(const Geom &g, const ChanDev &ch, const Pla
         float const y = valid ? atan2f(pr.y, pr.x) : 0.f;
         float const yl = __shfl(y, lv >= 0 ? lv : 0, 64);
         float const out = my_open ? (lv >= 0 ? yl : la_fb) : 0.f;
-
-        // ---- carried state after the pair (fm.c:133-144, 156-160)
+        // carried state after the pair (fm.c:133-144, 156-160)
         {
           int const last0 = m_lo ? 63 - __clzll((long long)m_lo) : 0;
           int const last1 = m_hi ? 95 - __clzll((long long)m_hi) : 0;
@@ -374,16 +403,12 @@ __device__ void fm_channel_two_waves(const Geom &g, const ChanDev &ch, const Pla
           state = st0;
           lastaudio = la0;
         }
-        sq = sq1;
-
-        // ---- hand-over
-        int const par = it & 1;
         s_out[par][lane] = out;
         s_y[par][lane] = y;
         if (n == 0) {
-          float *st = s_stat[par][h];
-          st[0] = bbp;
-          st[1] = snr;
+          float *st = s_b[par][h];
+          st[0] = s_a[par][h][1];
+          st[1] = s_a[par][h][2];
           st[2] = __int_as_float((int)(unsigned)(mask >> (32 * h)));   // this half's mask of valid samples
           st[3] = __int_as_float(h ? sq1 : sq0);
           st[4] = __int_as_float(my_open ? 32 - __popcll((mask >> (32 * h)) & 0xffffffffull) : 0);
@@ -394,80 +419,111 @@ __device__ void fm_channel_two_waves(const Geom &g, const ChanDev &ch, const Pla
     if (lane == 0) {
       ch.fm_state[c] = state;
       ch.lastaudio[c] = lastaudio;
-      ch.sq_count[c] = sq;
     }
     return;
   }
 
-  // ---------------- wave 1: frequency offset and deviation, de-emphasis (fm.c:146-171), audio, status
+  int const kbin = bitrev6(lane);
+  if (role == 2) {  // ---------------- frequency offset and deviation (fm.c:125-154); de-emphasis, forward half (fm.c:162-171)
+    int const herm_src = bitrev6((64 - kbin) & 63);
+    float2 HAf;
+    {
+      float2 const t = ch.aresp[(size_t)c * 33 + (kbin <= 32 ? kbin : 64 - kbin)];
+      HAf = kbin <= 32 ? t : cconj(t);
+    }
+    bool const real_bin = kbin == 0 || kbin == 32;
+    float2 wf[6];
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+      int const half = 1 << s;
+      float sn, cs;
+      sincospif((float)(lane & (half - 1)) / (float)half, &sn, &cs);
+      wf[s] = make_float2(cs, -sn);
+    }
+    float foffset = ch.foffset[c], pdev = ch.pdev[c];
+    float hist = h ? 0.f : ch.ahist[(size_t)c * 32 + lane];  // lanes 0-31: the block before b
+    for (int it = 0; it < niter; it++) {
+      if (it >= 2 && it - 2 < npairs) {
+        int const b = 2 * (it - 2), par = (it - 2) & 1;
+        bool const have1 = b + 1 < nblocks;
+        float const out = s_out[par][lane], y = s_y[par][lane];
+        unsigned const mask_h = (unsigned)__float_as_int(s_b[par][h][2]);
+        int const sq0 = __float_as_int(s_b[par][0][3]), sq1 = __float_as_int(s_b[par][1][3]);
+        bool const valid = (mask_h >> n) & 1u;
+        float const sum_y = hsum(out);
+        float const vmax = hreduce((valid && n > 0) ? y : -INFINITY, [](float a, float b2) { return fmaxf(a, b2); });
+        float const vmin = hreduce((valid && n > 0) ? y : INFINITY, [](float a, float b2) { return fminf(a, b2); });
+        float const y_first = h ? rdlane(y, 32) : rdlane(y, 0);
+        float const seed = (mask_h & 1u) ? y_first : 0.f;
+        float pdev_pos = fmaxf(seed, vmax), pdev_neg = fminf(seed, vmin);
+        float const avg_f = sum_y / 32.f;
+        pdev_pos -= avg_f;
+        pdev_neg -= avg_f;
+        float const mx = (pdev_pos > -pdev_neg) ? pdev_pos : -pdev_neg;
+        float const fo_new = (float)(g.dsamprate * avg_f * (0.5 * M_1_PI));
+        float const pd_new = (float)(g.dsamprate * mx * (0.5 * M_1_PI));
+        float const fo0 = (sq0 < 1) ? rdlane(fo_new, 0) : foffset, pd0 = (sq0 < 1) ? rdlane(pd_new, 0) : pdev;
+        float const fo1 = (have1 && sq1 < 1) ? rdlane(fo_new, 32) : fo0, pd1 = (have1 && sq1 < 1) ? rdlane(pd_new, 32) : pd0;
+        foffset = fo1;
+        pdev = pd1;
+
+        float const xo = lane_xor<32>(out, lane);    // lanes 0-31: block b+1, lanes 32-63: block b
+        float2 z = make_float2(h ? xo : hist, out);  // real: [hist | b], imaginary: [b | b+1]
+#pragma unroll
+        for (int s = 5; s >= 0; s--) {  // forward, decimation in frequency: natural in, bit-reversed out
+          float2 const r = xor2_pow(z, s, lane);
+          z = ((lane >> s) & 1) ? cmul(csub(r, z), wf[s]) : cadd(z, r);
+        }
+        float2 const zm = cconj(shfl2(z, herm_src));  // conj(Z[64 - k])
+        float2 const z1 = make_float2(0.5f * (z.x + zm.x), 0.5f * (z.y + zm.y));     // spectrum of the real part
+        float2 const z2 = make_float2(0.5f * (z.y - zm.y), -0.5f * (z.x - zm.x));    // spectrum of the imaginary part
+        float2 g1 = cmul(HAf, z1), g2 = cmul(HAf, z2);  // filter.c:206-208 on both
+        if (real_bin) g1.y = g2.y = 0.f;                // the c2r transform ignores these imaginary parts
+        s_z[par][lane] = make_float2(g1.x - g2.y, g1.y + g2.x);  // g1 + j g2
+        hist = have1 ? xo : out;  // lanes 0-31: the last block processed becomes the history (filter.c:168)
+        if (n == 0) {
+          float *st = s_c[par][h];
+          st[0] = s_b[par][h][0];
+          st[1] = s_b[par][h][1];
+          st[2] = h ? fo1 : fo0;
+          st[3] = h ? pd1 : pd0;
+          st[4] = s_b[par][h][3];
+          st[5] = s_b[par][h][4];
+        }
+      }
+      __syncthreads();
+    }
+    if (!h) ch.ahist[(size_t)c * 32 + lane] = hist;
+    if (lane == 0) {
+      ch.foffset[c] = foffset;
+      ch.pdev[c] = pdev;
+    }
+    return;
+  }
+
+  // ---------------- wave 3: de-emphasis, inverse half; audio; status records
   float const gain = ch.fm_gain[c];
   float const noise_gain = ch.noise_gain[c];
-  int const kbin = bitrev6(lane);
-  int const herm_src = bitrev6((64 - kbin) & 63);
-  float2 HAf;
-  {
-    float2 const t = ch.aresp[(size_t)c * 33 + (kbin <= 32 ? kbin : 64 - kbin)];
-    HAf = kbin <= 32 ? t : cconj(t);
-  }
-  bool const real_bin = kbin == 0 || kbin == 32;
-  float2 wf[6], wi[6];
+  float2 wi[6];
 #pragma unroll
   for (int s = 0; s < 6; s++) {
     int const half = 1 << s;
     float sn, cs;
     sincospif((float)(lane & (half - 1)) / (float)half, &sn, &cs);
-    wf[s] = make_float2(cs, -sn);
     wi[s] = make_float2(cs, sn);
   }
   float n0 = ch.n0[c];
-  float foffset = ch.foffset[c], pdev = ch.pdev[c];
-  float hist = h ? 0.f : ch.ahist[(size_t)c * 32 + lane];  // lanes 0-31: the block before b
   float ifp_v = 0.f, n0raw_v = 0.f;
-  for (int it = 0; it <= npairs; it++) {
-    if (it >= 1) {
-      int const b = 2 * (it - 1), par = (it - 1) & 1;
+  for (int it = 0; it < niter; it++) {
+    if (it >= 3) {
+      int const b = 2 * (it - 3), par = (it - 3) & 1;
       bool const have1 = b + 1 < nblocks;
       if ((b & 63) == 0) {  // per-block status inputs, lane i holds block b + i
         int const bb = b + lane;
         ifp_v = bb < nblocks ? pl.if_power[bb] : 0.f;
         n0raw_v = (compute_n0 && bb < nblocks) ? pl.n0raw[(size_t)c * g.max_blocks + bb] : 0.f;
       }
-      float const out = s_out[par][lane], y = s_y[par][lane];
-      unsigned const mask_h = (unsigned)__float_as_int(s_stat[par][h][2]);
-      int const sq0 = __float_as_int(s_stat[par][0][3]), sq1 = __float_as_int(s_stat[par][1][3]);
-      bool const valid = (mask_h >> n) & 1u;
-
-      // ---- frequency offset and peak deviation (fm.c:125-154), per half
-      float const sum_y = hsum(out);
-      float const vmax = hreduce((valid && n > 0) ? y : -INFINITY, [](float a, float b2) { return fmaxf(a, b2); });
-      float const vmin = hreduce((valid && n > 0) ? y : INFINITY, [](float a, float b2) { return fminf(a, b2); });
-      float const y_first = h ? rdlane(y, 32) : rdlane(y, 0);
-      float const seed = (mask_h & 1u) ? y_first : 0.f;
-      float pdev_pos = fmaxf(seed, vmax), pdev_neg = fminf(seed, vmin);
-      float const avg_f = sum_y / 32.f;
-      pdev_pos -= avg_f;
-      pdev_neg -= avg_f;
-      float const mx = (pdev_pos > -pdev_neg) ? pdev_pos : -pdev_neg;
-      float const fo_new = (float)(g.dsamprate * avg_f * (0.5 * M_1_PI));
-      float const pd_new = (float)(g.dsamprate * mx * (0.5 * M_1_PI));
-      float const fo0 = (sq0 < 1) ? rdlane(fo_new, 0) : foffset, pd0 = (sq0 < 1) ? rdlane(pd_new, 0) : pdev;
-      float const fo1 = (have1 && sq1 < 1) ? rdlane(fo_new, 32) : fo0, pd1 = (have1 && sq1 < 1) ? rdlane(pd_new, 32) : pd0;
-      foffset = fo1;
-      pdev = pd1;
-
-      float const xo = lane_xor<32>(out, lane);  // lanes 0-31: block b+1, lanes 32-63: block b
-      float2 z = make_float2(h ? xo : hist, out);  // real: [hist | b], imaginary: [b | b+1]
-#pragma unroll
-      for (int s = 5; s >= 0; s--) {  // forward, decimation in frequency: natural in, bit-reversed out
-        float2 const r = xor2_pow(z, s, lane);
-        z = ((lane >> s) & 1) ? cmul(csub(r, z), wf[s]) : cadd(z, r);
-      }
-      float2 const zm = cconj(shfl2(z, herm_src));  // conj(Z[64 - k])
-      float2 const z1 = make_float2(0.5f * (z.x + zm.x), 0.5f * (z.y + zm.y));     // spectrum of the real part
-      float2 const z2 = make_float2(0.5f * (z.y - zm.y), -0.5f * (z.x - zm.x));    // spectrum of the imaginary part
-      float2 g1 = cmul(HAf, z1), g2 = cmul(HAf, z2);  // filter.c:206-208 on both
-      if (real_bin) g1.y = g2.y = 0.f;                // the c2r transform ignores these imaginary parts
-      z = make_float2(g1.x - g2.y, g1.y + g2.x);      // g1 + j g2
+      float2 z = s_z[par][lane];
 #pragma unroll
       for (int s = 0; s < 6; s++) {  // backward, decimation in time: bit-reversed in, natural out
         int const bit = (lane >> s) & 1;
@@ -481,9 +537,7 @@ __device__ void fm_channel_two_waves(const Geom &g, const ChanDev &ch, const Pla
         pl.audio[((size_t)c * g.max_blocks + b) * 64 + n] = a0;
         if (have1) pl.audio[((size_t)c * g.max_blocks + b + 1) * 64 + n] = a1;
       }
-      hist = have1 ? xo : out;  // lanes 0-31: the last block processed becomes the history (filter.c:168)
-
-      // ---- status records: lane 0 writes block b, lane 32 block b+1
+      // status records: lane 0 writes block b, lane 32 block b+1
       float const ifp = h ? rdlane(ifp_v, (b + 1) & 63) : rdlane(ifp_v, b & 63);
       float const fresh0 = rdlane(n0raw_v, b & 63), fresh1 = rdlane(n0raw_v, (b + 1) & 63);
       float n0a = n0, n0b = n0;
@@ -493,7 +547,7 @@ __device__ void fm_channel_two_waves(const Geom &g, const ChanDev &ch, const Pla
         n0 = n0b;
       }
       if (n == 0 && (h == 0 || have1)) {
-        const float *st = s_stat[par][h];
+        const float *st = s_c[par][h];
         kq_chan_status rec;
         rec.if_power = ifp;
         rec.noise_gain = noise_gain;
@@ -504,24 +558,19 @@ __device__ void fm_channel_two_waves(const Geom &g, const ChanDev &ch, const Pla
         rec.n0 = compute_n0 ? (h ? n0b : n0a) : NAN;
         rec.bb_power = st[0];
         rec.snr = st[1];
-        rec.foffset = h ? fo1 : fo0;
-        rec.pdeviation = h ? pd1 : pd0;
+        rec.foffset = st[2];
+        rec.pdeviation = st[3];
         rec.agc_gain = 0;
-        rec.squelch_count = __float_as_int(st[3]);
+        rec.squelch_count = __float_as_int(st[4]);
         rec.hangcount = 0;
-        rec.blanked = __float_as_int(st[4]);
+        rec.blanked = __float_as_int(st[5]);
         rec.nout = 32;
         pl.status[(size_t)c * g.max_blocks + b + h] = rec;
       }
     }
     __syncthreads();
   }
-  if (!h) ch.ahist[(size_t)c * 32 + lane] = hist;
-  if (lane == 0) {
-    ch.n0[c] = n0;
-    ch.foffset[c] = foffset;
-    ch.pdev[c] = pdev;
-  }
+  if (lane == 0) ch.n0[c] = n0;
 }
 
 __device__ void fm_channel(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
@@ -699,8 +748,8 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
 
 }  // namespace
 
-// grid = n_fm + n_am + n_lin workgroups, one channel each: one wave, or two (THREADS = 128) of which the second joins
-// in on de-emphasised FM channels and leaves at once everywhere else
+// grid = n_fm + n_am + n_lin workgroups, one channel each: one wave, or four (THREADS = 256) of which the other three
+// join in on de-emphasised FM channels and leave at once everywhere else
 template <int OLEN, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_demod64(Geom g, ChanDev ch, Planes pl, const int *__restrict__ list_fm, int n_fm,
                                                      const int *__restrict__ list_am, int n_am,
@@ -709,8 +758,8 @@ __global__ void __launch_bounds__(THREADS) k_demod64(Geom g, ChanDev ch, Planes 
   if (OLEN == 32) {
     if (wg < n_fm) {
       int const c = list_fm[wg];
-      if (THREADS == 128 && !(ch.flags[c] & FLAG_FLAT)) {
-        fm_channel_two_waves(g, ch, pl, c, nblocks, compute_n0);
+      if (THREADS == 256 && !(ch.flags[c] & FLAG_FLAT)) {
+        fm_channel_four_waves(g, ch, pl, c, nblocks, compute_n0);
         return;
       }
       if (threadIdx.x >= 64) return;
@@ -740,7 +789,7 @@ void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Plane
     // KQ_DEMOD_ONE_WAVE=1: the one-wave form of the FM demodulator (A/B switch)
     static bool const one_wave = getenv("KQ_DEMOD_ONE_WAVE") && atoi(getenv("KQ_DEMOD_ONE_WAVE")) != 0;
     if (n_fm > 0 && !one_wave)
-      hipLaunchKernelGGL((k_demod64<32, 128>), dim3(wgs), dim3(128), 0, s, g, ch, pl, list_fm, n_fm, list_am, n_am, list_lin,
+      hipLaunchKernelGGL((k_demod64<32, 256>), dim3(wgs), dim3(256), 0, s, g, ch, pl, list_fm, n_fm, list_am, n_am, list_lin,
                          n_lin, nblocks, compute_n0);
     else
       hipLaunchKernelGGL((k_demod64<32, 64>), dim3(wgs), dim3(64), 0, s, g, ch, pl, list_fm, n_fm, list_am, n_am, list_lin, n_lin,

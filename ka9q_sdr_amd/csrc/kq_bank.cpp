@@ -165,6 +165,7 @@ struct kq_bank {
   std::vector<int> list_host[3];
   bool lists_dirty = true;
   float *energy_state = nullptr;
+  float2 *win_paired = nullptr;  // row-paired copy of a call's samples for k_filter_full16k (full16k_paired_supported)
   // per-call parameters (5 double planes of max_channels + max_blocks update flags) travel through
   // pinned staging slots so kq_bank_process never has to synchronise the stream
   static constexpr int kSlots = 4;
@@ -530,23 +531,31 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   }
   HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
   LAUNCH_CHECK("IF power");
+  // full-spectrum path: the register-resident N = 16384 kernel where it applies (KQ_FULL_LDS=1 forces the LDS one)
+  static bool const lds_only = getenv("KQ_FULL_LDS") && atoi(getenv("KQ_FULL_LDS")) != 0;
+  bool const use16k = !lds_only && kq::full16k_supported(g);
+  // No sweep anywhere: the register-resident kernel runs without its per-sample oscillator path; the first block of
+  // a channel retuned since the last call (history still on the old oscillator) is then redone below with the
+  // general variant, as the pruned path does.
+  bool plain = true;
+  for (HostChan const &h : b->chans)
+    if (h.active && h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0) != 0) plain = false;
+  // That steady-state variant loads its samples 16 bytes at a time from a copy of the call's samples whose 512-sample
+  // rows are interleaved in pairs: one small kernel in front of the filter (4 MB each way per 64 blocks)
+  const float2 *paired = nullptr;
+  if (use16k && plain && b->win_paired && b->fwd_mode != KQ_FWD_PRUNED) {
+    kq::launch_rowpair_interleave(b->stream, window, b->win_paired, (size_t)(g.M - 1) + (size_t)nblocks * g.L);
+    paired = b->win_paired;
+  }
   {
     Scope t(b, 0, b->stream);
-    // full-spectrum path: the register-resident N = 16384 kernel where it applies (KQ_FULL_LDS=1 forces the LDS one)
-    static bool const lds_only = getenv("KQ_FULL_LDS") && atoi(getenv("KQ_FULL_LDS")) != 0;
-    bool const use16k = !lds_only && kq::full16k_supported(g);
-    // No sweep anywhere: the register-resident kernel runs without its per-sample oscillator path; the first block of
-    // a channel retuned since the last call (history still on the old oscillator) is then redone below with the
-    // general variant, as the pruned path does.
-    bool plain = true;
-    for (HostChan const &h : b->chans)
-      if (h.active && h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0) != 0) plain = false;
     // `redo`: the list names channels retuned since the last call, which need the general variant
     auto const full_launch = [&](hipStream_t st, const kq::Geom &gg, const kq::ChanDev &cd, const kq::Planes &pp, const float2 *win,
                                  const float2 *twp, int nch, int nbl, int n0, float2 *dump, int dump_ch, const int *list,
                                  bool redo = true) {
       if (use16k)
-        kq::launch_filter_full16k(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list, plain && !redo);
+        kq::launch_filter_full16k(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list, plain && !redo,
+                                  redo ? nullptr : paired);
       else
         kq::launch_filter_full(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list);
     };
@@ -833,6 +842,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   }
   b->pl = b->pl2[0];
   rc |= dev_alloc(&b->energy_state, 2);
+  if (kq::full16k_paired_supported(b->g)) rc |= dev_alloc(&b->win_paired, (size_t)(b->g.M - 1) + (size_t)B * b->g.L);
   for (int k = 0; k < 3; k++) rc |= dev_alloc(&b->list_dev[k], C);
   rc |= dev_alloc(&b->list_active_dev, C);
   if (b->fwd_mode == KQ_FWD_PRUNED) rc |= dev_alloc(&b->chan_tw, C * kq::pruned_table_elems(g));
@@ -886,7 +896,7 @@ int kq_bank_destroy(kq_bank *b) {
                   b->chd.lastaudio, b->chd.sq_count, b->chd.ahist, b->chd.foffset, b->chd.pdev, b->chd.gain, b->chd.hang,
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
                   b->pl2[0].plout, b->pl2[1].plout, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
-                  b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state,
+                  b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state, b->win_paired,
                   b->list_dev[0], b->list_dev[1], b->list_dev[2], b->list_active_dev, b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->list_pll_dev, b->pll_state, b->pll_rings,
                   b->pll_side};
   for (void *p : ptrs)

@@ -78,6 +78,13 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *base, unsigned bytes) {
 __device__ __forceinline__ v2f buf_ld2(rsrc_t r, unsigned lane_off, unsigned row_off) {
   return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, (int)lane_off, (int)row_off, 0));
 }
+// two adjacent complex values in one 16-byte load
+__device__ __forceinline__ void buf_ld4(v2f &a, v2f &b, rsrc_t r, unsigned lane_off, unsigned row_off) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f const q = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)row_off, 0));
+  a = (v2f){q.x, q.y};
+  b = (v2f){q.z, q.w};
+}
 
 // Twiddle tables (float2), computed in double on the host.  Pass 1, thread t: lo1[l-1][t] = W_N^{l t}, l = 1..3;
 // hi1[h-1][t] = W_N^{4 h t}, h = 1..7.  Pass 2, n3 = t & 15: lo2[l-1][n3] = W_N^{32 l n3}, hi2[h-1][n3] = W_N^{128 h n3}.
@@ -131,7 +138,7 @@ __device__ __forceinline__ v2f phasor2(double turns) {
 // host vouches that no channel of the launch sweeps or was retuned since the last call -- the steady state of a
 // receiver -- so the per-sample oscillator path (2000 instructions of double arithmetic) is left out and the window
 // loads can be issued before anything else (with that path in the kernel they cost it 24 spilled registers).
-template <bool N0, bool DUMP, bool PLAIN>
+template <bool N0, bool DUMP, bool PLAIN, bool PAIRED>
 __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,
                                                        const float2 *__restrict__ tw, const float2 *__restrict__ tab,
                                                        float2 *__restrict__ spec_dump, int spec_ch,
@@ -158,8 +165,17 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   rsrc_t const xr = make_rsrc(window + (size_t)blockIdx.y * g.L, kN * (unsigned)sizeof(float2));
   unsigned const toff = (unsigned)t * (unsigned)sizeof(float2);
   auto load_rows = [&](int first, int last) {
+    if constexpr (PAIRED) {
+      // `window` is the row-paired copy (launch_rowpair_interleave): rows 2r and 2r + 1 of the window interleaved sample
+      // by sample, so that one 16-byte load fetches the thread's samples of both.  The memory pipeline's cost is per
+      // instruction (tools/l1_fill.hip): the 128 KiB of a window arrive in half the time (-3.4 % on the kernel).
 #pragma unroll
-    for (int n1 = first; n1 < last; n1++) v[rfft::bitrev5(n1)] = buf_ld2(xr, toff, (unsigned)n1 * (unsigned)(512 * sizeof(float2)));
+      for (int n1 = first; n1 < last; n1 += 2)
+        buf_ld4(v[rfft::bitrev5(n1)], v[rfft::bitrev5(n1 + 1)], xr, 2 * toff, (unsigned)(n1 / 2) * (unsigned)(1024 * sizeof(float2)));
+    } else {
+#pragma unroll
+      for (int n1 = first; n1 < last; n1++) v[rfft::bitrev5(n1)] = buf_ld2(xr, toff, (unsigned)n1 * (unsigned)(512 * sizeof(float2)));
+    }
   };
   auto load_window = [&]() { load_rows(0, 32); };
   rsrc_t const tabr = make_rsrc(tab, kTabSize * (unsigned)sizeof(float2));
@@ -578,9 +594,26 @@ static const float2 *twiddle_tables() {
   return d;
 }
 
+// out[1024 r + 2 c + e] = in[512 (2 r + e) + c]: the window's 512-sample rows interleaved in pairs (see PAIRED)
+__global__ __launch_bounds__(256) void k_rowpair_interleave(const float2 *__restrict__ in, float4 *__restrict__ out, unsigned npairs) {
+  unsigned const i = blockIdx.x * 256u + threadIdx.x;  // r * 512 + c
+  if (i >= npairs) return;
+  unsigned const r = i >> 9, c = i & 511u;
+  float2 const a = in[(size_t)(2 * r) * 512 + c], b = in[(size_t)(2 * r + 1) * 512 + c];
+  out[i] = make_float4(a.x, a.y, b.x, b.y);
+}
+
+bool full16k_paired_supported(const Geom &g) { return full16k_supported(g) && g.L % 1024 == 0; }
+
+void launch_rowpair_interleave(hipStream_t s, const float2 *window, float2 *paired, size_t nsamples) {
+  unsigned const npairs = (unsigned)(nsamples / 2);  // nsamples is a multiple of 1024
+  hipLaunchKernelGGL(k_rowpair_interleave, dim3((npairs + 255) / 256), dim3(256), 0, s, window, reinterpret_cast<float4 *>(paired),
+                     npairs);
+}
+
 void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
-                           const int *chan_list, bool plain) {
+                           const int *chan_list, bool plain, const float2 *window_paired) {
   size_t const lds_bytes = (size_t)kXchElems * sizeof(float2);
   const float2 *tab = twiddle_tables();
   if (!tab) {  // cannot happen short of an allocation failure: fall back to the LDS kernel rather than fail the block
@@ -589,14 +622,18 @@ void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
   }
   bool const n0 = compute_n0 && ch.n0mask && ch.n0meta;  // the bank uploads both whenever it was created with compute_n0
   bool const dump = spec_dump != nullptr;
+  bool const paired = plain && window_paired != nullptr;  // only the steady-state variant reads the row-paired copy
   auto go = [&](auto kernel) {
     ensure_dynamic_lds((const void *)kernel, lds_bytes);
-    hipLaunchKernelGGL(kernel, dim3(nchan, nblocks), dim3(kT), lds_bytes, s, g, ch, pl, window, tw, tab, spec_dump, spec_ch,
-                       chan_list);
+    hipLaunchKernelGGL(kernel, dim3(nchan, nblocks), dim3(kT), lds_bytes, s, g, ch, pl, paired ? window_paired : window, tw, tab,
+                       spec_dump, spec_ch, chan_list);
   };
   auto pick = [&](auto n0c, auto dumpc) {
     constexpr bool kN0 = decltype(n0c)::value, kDump = decltype(dumpc)::value;
-    plain ? go(k_filter_full16k<kN0, kDump, true>) : go(k_filter_full16k<kN0, kDump, false>);
+    if (paired)
+      go(k_filter_full16k<kN0, kDump, true, true>);
+    else
+      plain ? go(k_filter_full16k<kN0, kDump, true, false>) : go(k_filter_full16k<kN0, kDump, false, false>);
   };
   using T = std::true_type;
   using F = std::false_type;

@@ -86,23 +86,23 @@ __device__ __forceinline__ void buf_ld4(v2f &a, v2f &b, rsrc_t r, unsigned lane_
   b = (v2f){q.z, q.w};
 }
 
-// Twiddle tables (float2), computed in double on the host.  Pass 1, thread t: lo1[l-1][t] = W_N^{l t}, l = 1..3;
-// hi1[h-1][t] = W_N^{4 h t}, h = 1..7.  Pass 2, n3 = t & 15: lo2[l-1][n3] = W_N^{32 l n3}, hi2[h-1][n3] = W_N^{128 h n3}.
-// (Loading all 31 twiddles of pass 1 directly -- 31 coalesced loads, no products -- was measured 20 % slower: the
-// loads' latency is exposed, the 24 extra products are not.  Pass 2's depend on n3 = t & 15 only: all 512 of them sit
-// in LDS, kTabTw2, and lo2 / hi2 are unused.)
-constexpr int kTabLo1 = 0, kTabHi1 = 3 * kT, kTabLo2 = 10 * kT, kTabHi2 = 10 * kT + 3 * 16;
+// Twiddle tables (float2), computed in double on the host.  Pass 1, thread t: ten entries e = 0..9 -- W_N^{l t}, l = 1..3,
+// then W_N^{4 h t}, h = 1..7 -- stored in pairs, element kTabP1 + 2 (512 j + t) + (e & 1), j = e >> 1, so that one
+// 16-byte load per lane fetches two of them (the memory pipeline's cost is per load instruction, tools/l1_fill.hip:
+// -1.0 % on the kernel against ten 8-byte loads).
+// (Loading all 31 twiddles of pass 1 directly -- no products -- was measured 20 % slower in round 1, and would hold 62
+// registers through the transform.  Pass 2's depend on n3 = t & 15 only: all 512 of them sit in LDS, kTabTw2.)
+constexpr int kTabP1 = 0;
 // N/D = 64 epilogue (one wave, lane t): epi[s-1][t], s = 1..5 = twiddle of inverse-transform stage s (span 2^s) as lane t
 // applies it: exp(+j pi (t mod 2^s) / 2^s) in the upper lane of a butterfly pair (t & 2^s), 1 in the lower one
-constexpr int kTabEpi = 10 * kT + 10 * 16;
+constexpr int kTabEpi = kTabP1 + 10 * kT;
 // all of pass 2's twiddles: tw2[n3][k2] = W_N^{32 n3 k2} (n3 < 16, k2 < 32), copied into LDS by every workgroup
 constexpr int kTabTw2 = kTabEpi + 5 * 64, kTabSize = kTabTw2 + 512;
 constexpr int kTw2Pitch = 34;  // LDS row pitch (elements): lane n3 reads 16 bytes at 272 n3 + 8 k2, distinct 16-byte slots
 
-// Pass 1's twiddles.  lo/hi rows start at element lo_row / hi_row of the table and are `stride` elements apart; lane_off =
-// byte offset of the thread's column.  The common factor c is the thread's NCO phasor P_t: folded into the four `lo`
-// values here it costs 11 products more than the bare twiddles, where multiplying it into the 31 row phasors S^{n1}
-// before the transform cost 31.
+// Pass 1's twiddles.  The common factor c is the thread's NCO phasor P_t: folded into the four `lo` values here it costs
+// 11 products more than the bare twiddles, where multiplying it into the 31 row phasors S^{n1} before the transform
+// cost 31.
 // v[q] *= c W^{q}, q = 0..31, W^{q} = lo[q & 3] * hi[q >> 2]; tlo = W^1..W^3, thi = W^4, W^8 .. W^28 of the thread's column.
 __device__ __forceinline__ void twiddle32(v2f (&v)[32], const v2f (&tlo)[3], const v2f (&thi)[7], v2f c) {
   v2f lo[4];
@@ -119,11 +119,14 @@ __device__ __forceinline__ void twiddle32(v2f (&v)[32], const v2f (&tlo)[3], con
 }
 // its ten table entries: requested right behind the window loads -- asked for where they are used, after the transform,
 // each batch is a full trip to L2 with nothing to overlap it
-__device__ __forceinline__ void twiddle32_fetch(v2f (&tlo)[3], v2f (&thi)[7], rsrc_t tab, unsigned lane_off, int lo_row, int hi_row, int stride) {
+__device__ __forceinline__ void twiddle32_fetch(v2f (&tlo)[3], v2f (&thi)[7], rsrc_t tab, int t) {
+  v2f e[10];
 #pragma unroll
-  for (int l = 0; l < 3; l++) tlo[l] = buf_ld2(tab, lane_off, (unsigned)(lo_row + l * stride) * 8u);
+  for (int j = 0; j < 5; j++) buf_ld4(e[2 * j], e[2 * j + 1], tab, (unsigned)t * 16u, (unsigned)(kTabP1 + 2 * kT * j) * 8u);
 #pragma unroll
-  for (int h = 0; h < 7; h++) thi[h] = buf_ld2(tab, lane_off, (unsigned)(hi_row + h * stride) * 8u);
+  for (int l = 0; l < 3; l++) tlo[l] = e[l];
+#pragma unroll
+  for (int h = 0; h < 7; h++) thi[h] = e[3 + h];
 }
 
 __device__ __forceinline__ v2f phasor2(double turns) {
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     __builtin_amdgcn_sched_barrier(0);
     load_rows(22, 32);
   }
-  twiddle32_fetch(tlo, thi, tabr, toff, kTabLo1, kTabHi1, kT);
+  twiddle32_fetch(tlo, thi, tabr, t);
   // pass 2's twiddle table goes into LDS: requested here, stored on the way into transpose 1
   v2f const tw2_mine = buf_ld2(tabr, toff, (unsigned)kTabTw2 * 8u);
   KQ_STAMP(10);  // loads issued
@@ -568,14 +571,9 @@ static const float2 *twiddle_tables() {
     double const ang = -2.0 * M_PI * (double)(e % kN) / kN;
     return make_float2((float)cos(ang), (float)sin(ang));
   };
-  for (int t = 0; t < kT; t++) {
-    for (int l = 1; l < 4; l++) h[kTabLo1 + (l - 1) * kT + t] = w((long long)l * t);
-    for (int hh = 1; hh < 8; hh++) h[kTabHi1 + (hh - 1) * kT + t] = w(4LL * hh * t);
-  }
-  for (int n3 = 0; n3 < 16; n3++) {
-    for (int l = 1; l < 4; l++) h[kTabLo2 + (l - 1) * 16 + n3] = w(32LL * l * n3);
-    for (int hh = 1; hh < 8; hh++) h[kTabHi2 + (hh - 1) * 16 + n3] = w(128LL * hh * n3);
-  }
+  for (int t = 0; t < kT; t++)
+    for (int e = 0; e < 10; e++)
+      h[kTabP1 + 2 * (kT * (e >> 1) + t) + (e & 1)] = e < 3 ? w((long long)(e + 1) * t) : w(4LL * (e - 2) * t);
   for (int n3 = 0; n3 < 16; n3++)
     for (int k2 = 0; k2 < 32; k2++) h[kTabTw2 + 32 * n3 + k2] = w(32LL * n3 * k2);
   for (int st = 1; st <= 5; st++)

@@ -523,14 +523,6 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   if (stage_call_params(b, b->n_abs - (g.M - 1), update_host, nblocks, &slot, &nret)) return -1;
   size_t const ret_off = 8 * Cmax * sizeof(double) + ((b->cfg.max_blocks + 7) & ~7u);
   const int *retune_list = reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(b->osc_dev2[pp]) + ret_off);
-  {
-    Scope t(b, 2, b->stream);
-    kq::launch_block_energy(b->stream, window + (g.M - 1), g.L, (int)nblocks,
-                            reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power,
-                            b->stage_host[slot], b->osc_dev2[pp], nret ? ret_off + nret * sizeof(int) : 8 * Cmax * sizeof(double) + nblocks);
-  }
-  HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
-  LAUNCH_CHECK("IF power");
   // full-spectrum path: the register-resident N = 16384 kernel where it applies (KQ_FULL_LDS=1 forces the LDS one)
   static bool const lds_only = getenv("KQ_FULL_LDS") && atoi(getenv("KQ_FULL_LDS")) != 0;
   bool const use16k = !lds_only && kq::full16k_supported(g);
@@ -541,12 +533,17 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   for (HostChan const &h : b->chans)
     if (h.active && h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0) != 0) plain = false;
   // That steady-state variant loads its samples 16 bytes at a time from a copy of the call's samples whose 512-sample
-  // rows are interleaved in pairs: one small kernel in front of the filter (4 MB each way per 64 blocks)
-  const float2 *paired = nullptr;
-  if (use16k && plain && b->win_paired && b->fwd_mode != KQ_FWD_PRUNED) {
-    kq::launch_rowpair_interleave(b->stream, window, b->win_paired, (size_t)(g.M - 1) + (size_t)nblocks * g.L);
-    paired = b->win_paired;
+  // rows are interleaved in pairs; the IF-power kernel, which reads every new sample anyway, writes it
+  float2 *const paired = (use16k && plain && b->win_paired && b->fwd_mode != KQ_FWD_PRUNED) ? b->win_paired : nullptr;
+  {
+    Scope t(b, 2, b->stream);
+    kq::launch_block_energy(b->stream, window + (g.M - 1), g.L, (int)nblocks,
+                            reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power,
+                            b->stage_host[slot], b->osc_dev2[pp], nret ? ret_off + nret * sizeof(int) : 8 * Cmax * sizeof(double) + nblocks,
+                            paired, (int)(g.M - 1));
   }
+  HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
+  LAUNCH_CHECK("IF power");
   {
     Scope t(b, 0, b->stream);
     // `redo`: the list names channels retuned since the last call, which need the general variant

@@ -113,7 +113,7 @@ void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size
 // (pinned, device-visible) into `params_dev`
 void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nblocks, const unsigned char *update,
                          float *energy_state, float *if_power, const void *params_host, void *params_dev,
-                         size_t params_bytes);
+                         size_t params_bytes, float2 *paired, int hist);
 void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                         const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
                         const int *chan_list);
@@ -124,13 +124,12 @@ bool full16k_supported(const Geom &g);
 constexpr int kFull16kHalf = 16;
 constexpr int full16k_bin(int t) { return (t >> 5) + 32 * (t & 31); }
 // plain: no channel of the launch has a sweep rate or a retune pending (a leaner kernel variant serves that case);
-// window_paired: the same samples with their 512-sample rows interleaved in pairs (launch_rowpair_interleave), which
+// window_paired: the same samples with their 512-sample rows interleaved in pairs (launch_block_energy writes it), which
 // the plain variant loads 16 bytes at a time; null: it reads `window`
 void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
                            const int *chan_list, bool plain, const float2 *window_paired);
 bool full16k_paired_supported(const Geom &g);
-void launch_rowpair_interleave(hipStream_t s, const float2 *window, float2 *paired, size_t nsamples);
 bool split_supported(const Geom &g);
 void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                          const float2 *tw, int nchan, int nblocks, const int *chan_list);

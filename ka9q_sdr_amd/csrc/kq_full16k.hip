@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   unsigned const toff = (unsigned)t * (unsigned)sizeof(float2);
   auto load_rows = [&](int first, int last) {
     if constexpr (PAIRED) {
-      // `window` is the row-paired copy (launch_rowpair_interleave): rows 2r and 2r + 1 of the window interleaved sample
+      // `window` is the row-paired copy (written by k_block_energy_sum): rows 2r and 2r + 1 of the window interleaved sample
       // by sample, so that one 16-byte load fetches the thread's samples of both.  The memory pipeline's cost is per
       // instruction (tools/l1_fill.hip): the 128 KiB of a window arrive in half the time (-3.4 % on the kernel).
 #pragma unroll
@@ -592,22 +592,8 @@ static const float2 *twiddle_tables() {
   return d;
 }
 
-// out[1024 r + 2 c + e] = in[512 (2 r + e) + c]: the window's 512-sample rows interleaved in pairs (see PAIRED)
-__global__ __launch_bounds__(256) void k_rowpair_interleave(const float2 *__restrict__ in, float4 *__restrict__ out, unsigned npairs) {
-  unsigned const i = blockIdx.x * 256u + threadIdx.x;  // r * 512 + c
-  if (i >= npairs) return;
-  unsigned const r = i >> 9, c = i & 511u;
-  float2 const a = in[(size_t)(2 * r) * 512 + c], b = in[(size_t)(2 * r + 1) * 512 + c];
-  out[i] = make_float4(a.x, a.y, b.x, b.y);
-}
-
+// the row-paired copy (see PAIRED) needs whole pairs of rows in every block; k_block_energy_sum writes it
 bool full16k_paired_supported(const Geom &g) { return full16k_supported(g) && g.L % 1024 == 0; }
-
-void launch_rowpair_interleave(hipStream_t s, const float2 *window, float2 *paired, size_t nsamples) {
-  unsigned const npairs = (unsigned)(nsamples / 2);  // nsamples is a multiple of 1024
-  hipLaunchKernelGGL(k_rowpair_interleave, dim3((npairs + 255) / 256), dim3(256), 0, s, window, reinterpret_cast<float4 *>(paired),
-                     npairs);
-}
 
 void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,

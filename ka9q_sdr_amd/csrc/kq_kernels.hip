@@ -63,9 +63,20 @@ void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size
 // the call's parameter block (oscillator planes + update flags) from the pinned host staging slot into device
 // memory, 8 bytes per thread straight over the bus: a hipMemcpyAsync in front of this kernel cost ~25 us of idle
 // stream per call (copy-engine start-up), this costs nothing.
+// Workgroups 0 .. nblocks-1: energy of one block's new samples; then the copy of the call's staged parameters; then
+// (paired != null) the window's history rows.  `paired`: the samples written out once more with their 512-sample rows
+// interleaved in pairs, for k_filter_full16k's 16-byte loads (kq_full16k.hip: out[1024 r + 2 c + e] = in[512 (2 r + e)
+// + c]) -- the kernel reads every new sample anyway.  L and hist are multiples of 1024 then.
 __global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *__restrict__ sums, int nblocks,
                                    const unsigned long long *__restrict__ params_host,
-                                   unsigned long long *__restrict__ params_dev, unsigned nwords) {
+                                   unsigned long long *__restrict__ params_dev, unsigned nwords, int copy_wgs,
+                                   float2 *__restrict__ paired, int hist) {
+  int const pcol = 2 * (threadIdx.x & 511) + (threadIdx.x >> 9);  // place of sample (row parity, column) within its pair of rows
+  if ((int)blockIdx.x >= nblocks + copy_wgs) {  // history: copy only, 8192 samples per workgroup
+    int const base = ((int)blockIdx.x - nblocks - copy_wgs) * 8192;
+    for (int j = 0; j < 8 && base + 1024 * j < hist; j++) paired[base + 1024 * j + pcol] = (x - hist)[base + 1024 * j + threadIdx.x];
+    return;
+  }
   if ((int)blockIdx.x >= nblocks) {
     unsigned const i = (blockIdx.x - nblocks) * blockDim.x + threadIdx.x;
     if (i < nwords) params_dev[i] = params_host[i];
@@ -76,7 +87,16 @@ __global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *_
   const float2 *p = x + (size_t)blockIdx.x * L;
   float acc = 0;
   int dummy = 0;
-  for (int i = threadIdx.x; i < L; i += blockDim.x) acc += cnrm(p[i]);
+  if (paired) {
+    float2 *o = paired + hist + (size_t)blockIdx.x * L;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {  // blockDim.x = 1024 = one pair of rows per trip
+      float2 const v = p[i];
+      acc += cnrm(v);
+      o[(i - (int)threadIdx.x) + pcol] = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < L; i += blockDim.x) acc += cnrm(p[i]);
+  }
   block_sum_fi(acc, dummy, red_f, red_i);
   if (threadIdx.x == 0) sums[blockIdx.x] = acc;
 }
@@ -113,13 +133,14 @@ __global__ void k_block_energy_iir(const float *sums, const unsigned char *__res
 
 void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nblocks, const unsigned char *update,
                          float *energy_state, float *if_power, const void *params_host, void *params_dev,
-                         size_t params_bytes) {
+                         size_t params_bytes, float2 *paired, int hist) {
   // if_power doubles as scratch for the per-block sums: the IIR pass reads sums[b] before writing if_power[b]
   unsigned const nwords = (unsigned)((params_bytes + 7) / 8);
   int const copy_wgs = (int)((nwords + 1023) / 1024);
-  hipLaunchKernelGGL(k_block_energy_sum, dim3(nblocks + copy_wgs), dim3(1024), 0, s, newsamples, L, if_power, nblocks,
+  int const hist_wgs = paired ? (hist + 8191) / 8192 : 0;
+  hipLaunchKernelGGL(k_block_energy_sum, dim3(nblocks + copy_wgs + hist_wgs), dim3(1024), 0, s, newsamples, L, if_power, nblocks,
                      static_cast<const unsigned long long *>(params_host), static_cast<unsigned long long *>(params_dev),
-                     nwords);
+                     nwords, copy_wgs, paired, hist);
   hipLaunchKernelGGL(k_block_energy_iir, dim3(1), dim3(64), 0, s, if_power, update, nblocks, L, energy_state, if_power);
 }
 

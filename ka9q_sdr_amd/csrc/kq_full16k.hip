@@ -493,7 +493,9 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   // ---------------- slave, continued: response multiply, CROSS_CONJ, inverse transform
   __syncthreads();
   KQ_STAMP(8);
-  if (N0 && n0_fast && t == 0) {
+  // (the last wave's first lane: wave 0 has the inverse transform to run, and this division -- float, then double -- would
+  // sit in front of it on the workgroup's critical path)
+  if (N0 && n0_fast && t == kT - 64) {
     float tf = 0, bins = 0;
 #pragma unroll
     for (int k = 0; k < kT / 64; k++) {

@@ -139,6 +139,31 @@ __device__ __forceinline__ void swap32(float &a, float &b) {
   b = __uint_as_float(r[1]);
 }
 
+__device__ __forceinline__ void swap16(float &a, float &b) {
+  // v_permlane16_swap: the odd rows (of 16 lanes) of a <-> the even rows of b
+  auto const r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+// One level of the reduce-scatter across lane bit I (3 or 2) without selects: on return `e` holds, in every lane, the
+// value of the pair's LOWER lane (its own e, or the partner's o) and `o` that of the UPPER lane (the partner's e, or
+// its own o) -- two DPP moves each, their bank masks picking the lanes with the bit clear or set.
+template <int I>
+__device__ __forceinline__ void pair_dpp(float &e, float &o) {
+  static_assert(I == 3 || I == 2, "lane bits 3 and 2: whole banks of four lanes");
+  int const ei = __float_as_int(e), oi = __float_as_int(o);
+  int lo, up;
+  if constexpr (I == 3) {
+    lo = __builtin_amdgcn_update_dpp(ei, oi, 0x128, 0xF, 0xC, false);  // row_ror:8 into lanes 8..15 of each row
+    up = __builtin_amdgcn_update_dpp(oi, ei, 0x128, 0xF, 0x3, false);  //            into lanes 0..7
+  } else {
+    lo = __builtin_amdgcn_update_dpp(ei, oi, 0x114, 0xF, 0xA, false);  // row_shr:4 into banks 1 and 3 (bit 2 set: lane - 4)
+    up = __builtin_amdgcn_update_dpp(oi, ei, 0x104, 0xF, 0x5, false);  // row_shl:4 into banks 0 and 2 (bit 2 clear: lane + 4)
+  }
+  e = __int_as_float(lo);
+  o = __int_as_float(up);
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -288,12 +313,29 @@ __device__ __forceinline__ float2 lane_reduce(float2 (&acc)[32], const float2 *t
     const float2 *tl = tL + (size_t)i * ND;
 #pragma unroll
     for (int m = 0; m < cnt; m++) {
-      float2 const e = z[2 * m], o = z[2 * m + 1];
-      float2 const keep = bit ? o : e, send = bit ? e : o;
-      float2 recv;
-      recv.x = __shfl_xor(send.x, 1 << i, 64);
-      recv.y = __shfl_xor(send.y, 1 << i, 64);
-      float2 const lo = bit ? recv : keep, hi = bit ? keep : recv;
+      float2 lo, hi;  // the pair's lower lane's even entry, its upper lane's odd entry
+      if (i >= 2) {   // exchanges without selects: lane-half swap (bit 4), bank-masked DPP moves (bits 3 and 2)
+        lo = z[2 * m];
+        hi = z[2 * m + 1];
+        if (i == 4) {
+          swap16(lo.x, hi.x);
+          swap16(lo.y, hi.y);
+        } else if (i == 3) {
+          pair_dpp<3>(lo.x, hi.x);
+          pair_dpp<3>(lo.y, hi.y);
+        } else {
+          pair_dpp<2>(lo.x, hi.x);
+          pair_dpp<2>(lo.y, hi.y);
+        }
+      } else {
+        float2 const e = z[2 * m], o = z[2 * m + 1];
+        float2 const keep = bit ? o : e, send = bit ? e : o;
+        float2 recv;
+        recv.x = __shfl_xor(send.x, 1 << i, 64);
+        recv.y = __shfl_xor(send.y, 1 << i, 64);
+        lo = bit ? recv : keep;
+        hi = bit ? keep : recv;
+      }
       int const qp = (((2 * m + bit) << t) | qlow);
       float2 w = tl[P * qp + PASS];
       if (SWEPT) w = cmul(w, th[i]);
@@ -337,12 +379,29 @@ __device__ __forceinline__ float2 lane_reduce_rt(float2 (&acc)[32], const float2
     const float2 *tl = tL + (size_t)i * ND + pass;
 #pragma unroll
     for (int m = 0; m < cnt; m++) {
-      float2 const e = z[2 * m], o = z[2 * m + 1];
-      float2 const keep = bit ? o : e, send = bit ? e : o;
-      float2 recv;
-      recv.x = __shfl_xor(send.x, 1 << i, 64);
-      recv.y = __shfl_xor(send.y, 1 << i, 64);
-      float2 const lo = bit ? recv : keep, hi = bit ? keep : recv;
+      float2 lo, hi;
+      if (i >= 2) {
+        lo = z[2 * m];
+        hi = z[2 * m + 1];
+        if (i == 4) {
+          swap16(lo.x, hi.x);
+          swap16(lo.y, hi.y);
+        } else if (i == 3) {
+          pair_dpp<3>(lo.x, hi.x);
+          pair_dpp<3>(lo.y, hi.y);
+        } else {
+          pair_dpp<2>(lo.x, hi.x);
+          pair_dpp<2>(lo.y, hi.y);
+        }
+      } else {
+        float2 const e = z[2 * m], o = z[2 * m + 1];
+        float2 const keep = bit ? o : e, send = bit ? e : o;
+        float2 recv;
+        recv.x = __shfl_xor(send.x, 1 << i, 64);
+        recv.y = __shfl_xor(send.y, 1 << i, 64);
+        lo = bit ? recv : keep;
+        hi = bit ? keep : recv;
+      }
       int const qp = (((2 * m + bit) << t) | qlow);
       z[m] = cfma(tl[P * qp], hi, lo);
     }

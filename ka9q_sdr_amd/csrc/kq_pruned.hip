@@ -52,6 +52,8 @@ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 // a + b*c
+// the same with every operand in a vector register (table entry times lane value): exactly two packed instructions
+__device__ __forceinline__ float2 cfma_v(float2 b, float2 c, float2 a) { return as_f2(rfft::pk_cmadd(as_v2f(b), as_v2f(c), as_v2f(a))); }
 __device__ __forceinline__ float2 cfma(float2 b, float2 c, float2 a) {
   rfft::v2f const bb = as_v2f(b), cc = as_v2f(c);
   return as_f2(rfft::pk_fma((rfft::v2f){-bb.y, bb.y}, cc.yx, rfft::pk_fma(bb.xx, cc, as_v2f(a))));
@@ -302,7 +304,7 @@ __device__ __forceinline__ float2 lane_reduce(float2 (&acc)[32], const float2 *t
       // lower lanes: e = own even, o = partner's even; upper lanes: e = partner's odd, o = own odd
       float2 w = tl[P * (2 * m + bit) + PASS];
       if (SWEPT) w = cmul(w, th[5]);
-      z[m] = cfma(w, o, e);
+      z[m] = cfma_v(w, o, e);
     }
   }
 #pragma unroll
@@ -339,7 +341,7 @@ __device__ __forceinline__ float2 lane_reduce(float2 (&acc)[32], const float2 *t
       int const qp = (((2 * m + bit) << t) | qlow);
       float2 w = tl[P * qp + PASS];
       if (SWEPT) w = cmul(w, th[i]);
-      z[m] = cfma(w, hi, lo);
+      z[m] = cfma_v(w, hi, lo);
     }
     qlow |= bit << t;
   }
@@ -350,7 +352,7 @@ __device__ __forceinline__ float2 lane_reduce(float2 (&acc)[32], const float2 *t
   float2 const lo = b0 ? recv : z[0], hi = b0 ? z[0] : recv;
   float2 w = tL[P * qlow + PASS];
   if (SWEPT) w = cmul(w, th[0]);
-  return cfma(w, hi, lo);
+  return cfma_v(w, hi, lo);
 }
 
 // lane_reduce with the pass as a run-time value (rolled pass loop of the N/D = 256 kernel), unswept only
@@ -368,7 +370,7 @@ __device__ __forceinline__ float2 lane_reduce_rt(float2 (&acc)[32], const float2
       float2 e = acc[2 * m], o = acc[2 * m + 1];
       swap32(e.x, o.x);
       swap32(e.y, o.y);
-      z[m] = cfma(tl[P * (2 * m + bit)], o, e);
+      z[m] = cfma_v(tl[P * (2 * m + bit)], o, e);
     }
   }
 #pragma unroll
@@ -403,7 +405,7 @@ __device__ __forceinline__ float2 lane_reduce_rt(float2 (&acc)[32], const float2
         hi = bit ? keep : recv;
       }
       int const qp = (((2 * m + bit) << t) | qlow);
-      z[m] = cfma(tl[P * qp], hi, lo);
+      z[m] = cfma_v(tl[P * qp], hi, lo);
     }
     qlow |= bit << t;
   }
@@ -412,7 +414,7 @@ __device__ __forceinline__ float2 lane_reduce_rt(float2 (&acc)[32], const float2
   recv.y = __shfl_xor(z[0].y, 1, 64);
   int const b0 = lane & 1;
   float2 const lo = b0 ? recv : z[0], hi = b0 ? z[0] : recv;
-  return cfma(tL[P * qlow + pass], hi, lo);
+  return cfma_v(tL[P * qlow + pass], hi, lo);
 }
 
 // Fill the wave's LDS slot (A and T) and the per-level sweep factors for channel c, block blk

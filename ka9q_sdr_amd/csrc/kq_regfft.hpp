@@ -107,6 +107,14 @@ __device__ __forceinline__ v2f pk_cmul_conj(v2f a, v2f b) {
   return d;
 }
 
+// c + a * b, complex, all in vector registers: two instructions (the product's first half accumulates onto c)
+__device__ __forceinline__ v2f pk_cmadd(v2f a, v2f b, v2f c) {
+  v2f t, d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(b), "v"(c));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(t));
+  return d;
+}
+
 template <int NP, int LEN, int I>
 __device__ __forceinline__ void bfly_pk(v2f (&v)[NP]) {
   constexpr int half = LEN / 2, base = (I / half) * LEN, j = I % half;

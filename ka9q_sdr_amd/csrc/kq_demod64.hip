@@ -585,7 +585,7 @@ __device__ void fm_channel(const Geom &g, const ChanDev &ch, const Planes &pl, i
 // lane-parallel and coalesced; only the AGC recurrence itself (am.c:64-74, linear.c:269-279: one multiply, one
 // compare, two selects per sample) runs serially, wave-uniform, reading its per-sample inputs with v_readlane.
 // The arithmetic per sample is exactly the reference's, in the reference's order.
-template <bool LINEAR, int OLEN>
+template <bool LINEAR, int OLEN, bool SPLIT>
 __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
   int const lane = threadIdx.x & 63;
   constexpr int BPI = 64 / OLEN;  // blocks per iteration
@@ -599,35 +599,74 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
   float n0 = ch.n0[c];
   const float2 *in = pl.filt + (size_t)c * g.max_blocks * OLEN;
   float2 s_next = (half < nblocks) ? in[lane] : make_float2(0.f, 0.f);
-  for (int b0 = 0; b0 < nblocks; b0 += BPI) {
+  // SPLIT: two waves per channel.  Wave 0 runs the front of iteration i -- envelope, power sums, the carrier filter's
+  // recurrence, the attack gains -- while wave 1 runs the AGC recurrence, the audio and the status of iteration i - 1;
+  // the six per-sample values cross in LDS behind one barrier per iteration.  A wave issues one instruction per 8
+  // cycles (tools/valu_rate.hip) and the two recurrences are what an AM channel's time consists of.
+  __shared__ float s_hand[SPLIT ? 2 : 1][7][64];
+  int const role = SPLIT ? (int)(threadIdx.x >> 6) : 0;
+  int const niter = (nblocks + BPI - 1) / BPI;
+  for (int it = 0; it < niter + (SPLIT ? 1 : 0); it++) {
+    float2 S = make_float2(0.f, 0.f);
+    float level = 0.f, env = 0.f, sig = 0.f, noi = 0.f, inv = 0.f;
+    if (role == 0 && it < niter) {
+      int const b0 = it * BPI;
+      int const blk = b0 + half;
+      int const nsamp = (b0 + BPI <= nblocks) ? 64 : OLEN;  // wave-uniform
+      S = s_next;
+      if (b0 + BPI < nblocks) s_next = (blk + BPI < nblocks) ? in[(size_t)(b0 + BPI) * OLEN + lane] : make_float2(0.f, 0.f);
+      float const rp = S.x * S.x, ip = S.y * S.y;
+      level = sqrtf(LINEAR ? rp + ip : S.x * S.x + S.y * S.y);  // amplitude (linear.c:260) / envelope (am.c:58)
+      env = level;
+      // per-block power sums over each OLEN-lane group
+      sig = LINEAR ? rp : rp + ip;
+      noi = LINEAR ? ip : 0.f;
+      if (!LINEAR) sig = S.x * S.x + S.y * S.y;
+#pragma unroll
+      for (int o = OLEN / 2; o > 0; o >>= 1) {
+        sig += __shfl_xor(sig, o, 64);
+        noi += __shfl_xor(noi, o, 64);
+      }
+      if (!LINEAR) {
+        // carrier tracking (am.c:62), serial; lane i keeps the value after sample i
+        float dc_mine = dc;
+#pragma unroll 32
+        for (int i = 0; i < nsamp; i++) {
+          float const e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, env), i));
+          dc += 0.0001f * (e - dc);
+          dc_mine = (lane == i) ? dc : dc_mine;
+        }
+        level = dc_mine;
+      }
+      inv = headroom / level;
+      if (SPLIT) {
+        float(*hb)[64] = s_hand[it & 1];
+        hb[0][lane] = S.x;
+        hb[1][lane] = S.y;
+        hb[2][lane] = level;
+        hb[3][lane] = env;
+        hb[4][lane] = sig;
+        hb[5][lane] = noi;
+        hb[6][lane] = inv;
+      }
+    }
+    if (SPLIT) {
+      if (role == 1 && it >= 1) {
+        float(*hb)[64] = s_hand[(it - 1) & 1];
+        S = make_float2(hb[0][lane], hb[1][lane]);
+        level = hb[2][lane];
+        env = hb[3][lane];
+        sig = hb[4][lane];
+        noi = hb[5][lane];
+        inv = hb[6][lane];
+      }
+      __syncthreads();
+      if (role == 0 || it == 0) continue;
+    }
+    int const b0 = (SPLIT ? it - 1 : it) * BPI;
     int const blk = b0 + half;
     bool const active = blk < nblocks;
     int const nsamp = (b0 + BPI <= nblocks) ? 64 : OLEN;  // wave-uniform
-    float2 const S = s_next;
-    if (b0 + BPI < nblocks) s_next = (blk + BPI < nblocks) ? in[(size_t)(b0 + BPI) * OLEN + lane] : make_float2(0.f, 0.f);
-    float const rp = S.x * S.x, ip = S.y * S.y;
-    float level = sqrtf(LINEAR ? rp + ip : S.x * S.x + S.y * S.y);  // amplitude (linear.c:260) / envelope (am.c:58)
-    float const env = level;
-    // per-block power sums over each OLEN-lane group
-    float sig = LINEAR ? rp : rp + ip, noi = LINEAR ? ip : 0.f;
-    if (!LINEAR) sig = S.x * S.x + S.y * S.y;
-#pragma unroll
-    for (int o = OLEN / 2; o > 0; o >>= 1) {
-      sig += __shfl_xor(sig, o, 64);
-      noi += __shfl_xor(noi, o, 64);
-    }
-    if (!LINEAR) {
-      // carrier tracking (am.c:62), serial; lane i keeps the value after sample i
-      float dc_mine = dc;
-#pragma unroll 32
-      for (int i = 0; i < nsamp; i++) {
-        float const e = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, env), i));
-        dc += 0.0001f * (e - dc);
-        dc_mine = (lane == i) ? dc : dc_mine;
-      }
-      level = dc_mine;
-    }
-    float const inv = headroom / level;
     float g_mine = gain;
     float gain_end[2] = {gain, gain};
     int hang_end[2] = {hang, hang};
@@ -739,10 +778,12 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
     }
   }
   if (lane == 0) {
-    ch.gain[c] = gain;
-    if (!LINEAR) ch.dc[c] = dc;
-    ch.hang[c] = hang;
-    ch.n0[c] = n0;
+    if (!SPLIT || role == 1) {
+      ch.gain[c] = gain;
+      ch.hang[c] = hang;
+      ch.n0[c] = n0;
+    }
+    if (!LINEAR && role == 0) ch.dc[c] = dc;
   }
 }
 
@@ -768,13 +809,18 @@ __global__ void __launch_bounds__(THREADS) k_demod64(Geom g, ChanDev ch, Planes 
     }
     wg -= n_fm;
   }
-  if (threadIdx.x >= 64) return;
   if (wg < n_am) {
-    agc_channel<false, OLEN>(g, ch, pl, list_am[wg], nblocks, compute_n0);
+    if (THREADS == 256) {  // two of the four waves share an AM channel's two recurrences
+      if (threadIdx.x < 128) agc_channel<false, OLEN, true>(g, ch, pl, list_am[wg], nblocks, compute_n0);
+      return;
+    }
+    if (threadIdx.x >= 64) return;
+    agc_channel<false, OLEN, false>(g, ch, pl, list_am[wg], nblocks, compute_n0);
     return;
   }
+  if (threadIdx.x >= 64) return;
   wg -= n_am;
-  if (wg < n_lin) agc_channel<true, OLEN>(g, ch, pl, list_lin[wg], nblocks, compute_n0);
+  if (wg < n_lin) agc_channel<true, OLEN, false>(g, ch, pl, list_lin[wg], nblocks, compute_n0);
 }
 
 // Register-resident demodulators exist for olen = 32 (all three types) and olen = 64 (AM / linear)
@@ -786,9 +832,9 @@ void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Plane
   if (g.olen == 32) {
     int const wgs = n_fm + n_am + n_lin;
     if (wgs == 0) return;
-    // KQ_DEMOD_ONE_WAVE=1: the one-wave form of the FM demodulator (A/B switch)
+    // KQ_DEMOD_ONE_WAVE=1: the one-wave forms of the FM and AM demodulators (A/B switch)
     static bool const one_wave = getenv("KQ_DEMOD_ONE_WAVE") && atoi(getenv("KQ_DEMOD_ONE_WAVE")) != 0;
-    if (n_fm > 0 && !one_wave)
+    if (n_fm + n_am > 0 && !one_wave)
       hipLaunchKernelGGL((k_demod64<32, 256>), dim3(wgs), dim3(256), 0, s, g, ch, pl, list_fm, n_fm, list_am, n_am, list_lin,
                          n_lin, nblocks, compute_n0);
     else

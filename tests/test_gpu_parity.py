@@ -181,6 +181,7 @@ GEOMETRIES = [
     (8192,  4096,  4097,  64,  2000000, "auto", False),      # N/D = 128 below 65536: full path
     (16384, 12288, 4097,  64,  2000000, "full", True),       # full-spectrum kernel, L != M - 1, N/D = 256
     (16384, 8192,  8193,  32,  1000000, "full", True),       # N/D = 512
+    (16384, 12800, 3585,  64,  2000000, "full", True),       # L not a multiple of 1024: no row-paired copy, 8-byte window loads
     (16384, 8192,  8193,  2,   192000, "full", False),       # N/D = 8192: LDS filter kernel, largest FM working set
     (32768, 16384, 16385, 128, 4000000, "full", False),      # beyond one LDS block: split kernel, N/D = 256
     (65536, 49152, 16385, 32,  8000000, "full", False),      # split kernel at its limits: N = 65536, N/D = 2048, L != M - 1

@@ -50,6 +50,28 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host threads this process can really run at once: its affinity mask, cut to the container's CPU quota (cgroup
+    cpu.max / cfs_quota_us) -- a GPU box shows all 256 logical CPUs of the host to a container that may use 16 of them,
+    and 256 threads on a quota of 16 spend their time being throttled.  Returns (usable, visible)."""
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    usable = visible if quota is None else max(1, min(visible, int(quota + 0.5)))
+    return usable, visible
+
+
 def cpu_baseline(name, geom, plan, iq_host, target_s, compute_n0=0):
     """Oracle ('port') timed on this box's host cores on a bounded sample of the same workload: channel set-up outside
     the clock, 20 warm-up blocks, then >= 200 timed blocks per channel."""
@@ -57,7 +79,7 @@ def cpu_baseline(name, geom, plan, iq_host, target_s, compute_n0=0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import kq_oracle as ko
     from common import oracle_cfg
-    cores = os.cpu_count() or 1
+    cores, visible = usable_cores()
     L = geom["L"]
     nchan = min(len(plan), 2 * cores)
     cfgs = [oracle_cfg(p, geom["samprate"], L, geom["M"], geom["D"], compute_n0=compute_n0) for p in plan[:nchan]]
@@ -67,13 +89,19 @@ def cpu_baseline(name, geom, plan, iq_host, target_s, compute_n0=0):
     timed = int(max(200, target_s * rate / nchan))
     t, _ = ko.cpu_baseline(cfgs, iq_host, avail, 20, timed, cores)
     msps = nchan * timed * L / t / 1e6
+    # one channel on one otherwise idle core, for scale: all threads together run far below cores x this (SMT pairs,
+    # all-core clocks, 0.7 MB of working set per channel against the shared caches)
+    t1, _ = ko.cpu_baseline(cfgs[:1], iq_host, avail, 2, 8, 1)
+    n1 = int(max(50, 2.0 * 8 / max(t1, 1e-6)))
+    t1, _ = ko.cpu_baseline(cfgs[:1], iq_host, avail, 20, n1, 1)
+    single = n1 * L / t1 / 1e6
     return {"value": round(msps, 3), "unit": "Msamples/s (channel-samples)", "cores": cores, "kind": "port",
-            "per_core": round(msps / cores, 3),
+            "per_core": round(msps / cores, 3), "single_thread_alone": round(single, 3),
             "channels_at_realtime": int(msps * 1e6 / geom["samprate"]),
             "sample": "%d channels x %d timed blocks (20 warm-up, set-up outside the clock) of %s: oracle C restatement in the "
                       "reference's structure (per-sample FP64 NCO, full N-point FFT per channel, %s), own radix-4 autosort "
-                      "FFT (no libfftw3f in the image), %d threads, %.1f s" %
-                      (nchan, timed, name, "compute_n0 every block" if compute_n0 else "no compute_n0", cores, t)}
+                      "FFT (no libfftw3f in the image), %d threads (%d logical CPUs visible, CPU quota of the container %d), %.1f s" %
+                      (nchan, timed, name, "compute_n0 every block" if compute_n0 else "no compute_n0", cores, visible, cores, t)}
 
 
 def pmc_traffic(config, channels, blocks, fwd):

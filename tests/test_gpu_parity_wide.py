@@ -1,6 +1,6 @@
 """Parity at the sizes the bench runs, and the decision-flip count SURVEY.md 8d asks for.
 
-* 256 channels of cfg 4 (the bench's default workload: FM, compute_n0 on every block, full-spectrum path) and 256
+* all 1024 channels of cfg 4 (the bench's default workload: FM, compute_n0 on every block, full-spectrum path) and 256
   mixed channels of cfg 3 on both forward paths, every channel against the oracle with the tolerances of
   test_gpu_parity._compare (filter output and audio 1e-5 relative RMS; counts, squelch / hang state, blanked samples
   exact).
@@ -22,17 +22,31 @@ pytestmark = pytest.mark.gpu
 FLIP_BUDGET = 0.004      # fraction of randomised channels allowed to differ through a threshold tie (observed: 3 of 5 760)
 
 
-@pytest.mark.parametrize("name,mode,n0", [("cfg4", "full", True), ("cfg3", "full", True), ("cfg3", "pruned", False)])
-def test_256_channels_at_bench_geometry(gpu, name, mode, n0):
+@pytest.mark.parametrize("name,mode,n0,nchan", [("cfg4", "full", True, 1024), ("cfg3", "full", True, 256),
+                                               ("cfg3", "pruned", False, 256)])
+def test_channels_at_bench_geometry(gpu, name, mode, n0, nchan):
+    """cfg 4: all 1024 channels of the bench's headline workload, each against the oracle."""
     g = wl.GEOMETRY[name]
-    plan = wl.channel_plan(name, 256)
+    plan = wl.channel_plan(name, nchan)
     nblocks = 4
     iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=0x6B61)
     want = run_oracle(plan, g, iq, nblocks, compute_n0=int(n0))
     fwd = kq.KQ_FWD_FULL if mode == "full" else kq.KQ_FWD_PRUNED
     got, used = _run_bank(plan, g, iq, nblocks, fwd, compute_n0=n0, per_call=nblocks)
     assert used == fwd
-    _compare(plan, got, want, check_n0=n0)
+    # channel by channel, with the same allowance as test_decision_flips_stay_within_budget below: a bin that sits
+    # within one float rounding of compute_n0's 2 x mean cut (radio.c:414-420) moves n0 by one bin's worth (0.2 %) in
+    # a few channels per thousand; everything else of such a channel still has to agree
+    flips = []
+    for c, p in enumerate(plan):
+        try:
+            _compare([p], [got[c]], [want[c]], check_n0=n0)
+        except AssertionError as e:
+            _compare([p], [got[c]], [want[c]], check_n0=False)          # audio, filter output, counts, other status
+            worst = max(abs(got[c]["status"][b]["n0"] / want[c][1][b]["n0"] - 1) for b in range(nblocks))
+            assert n0 and worst < 5e-3, ("not a threshold tie", c, p, worst, str(e)[:300])
+            flips.append((c, worst))
+    assert len(flips) <= FLIP_BUDGET * len(plan), flips
     # the status scalars the tolerances of _compare are wide for: how close they really are at this size
     worst_if = max(abs(got[c]["status"][b]["if_power"] / want[c][1][b]["if_power"] - 1) for c in range(len(plan))
                    for b in range(nblocks))

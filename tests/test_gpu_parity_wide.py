@@ -1,7 +1,7 @@
 """Parity at the sizes the bench runs, and the decision-flip count SURVEY.md 8d asks for.
 
-* all 1024 channels of cfg 4 (the bench's default workload: FM, compute_n0 on every block, full-spectrum path) and 256
-  mixed channels of cfg 3 on both forward paths, every channel against the oracle with the tolerances of
+* all 1024 channels of cfg 4 (the bench's default workload: FM, compute_n0 on every block, full-spectrum path), all
+  1024 mixed channels of cfg 3 (256 of them once more on the pruned path) and all 256 channels of cfg 2, every channel against the oracle with the tolerances of
   test_gpu_parity._compare (filter output and audio 1e-5 relative RMS; counts, squelch / hang state, blanked samples
   exact).
 * Randomised plans in bulk: the reference's algorithm holds comparisons that sit within one float rounding of their
@@ -22,10 +22,12 @@ pytestmark = pytest.mark.gpu
 FLIP_BUDGET = 0.004      # fraction of randomised channels allowed to differ through a threshold tie (observed: 3 of 5 760)
 
 
-@pytest.mark.parametrize("name,mode,n0,nchan", [("cfg4", "full", True, 1024), ("cfg3", "full", True, 256),
-                                               ("cfg3", "pruned", False, 256)])
+@pytest.mark.parametrize("name,mode,n0,nchan", [("cfg4", "full", True, 1024), ("cfg3", "full", True, 1024),
+                                               ("cfg3", "pruned", False, 256), ("cfg2", "full", True, 256),
+                                               ("cfg5", "pruned", False, 128)])
 def test_channels_at_bench_geometry(gpu, name, mode, n0, nchan):
-    """cfg 4: all 1024 channels of the bench's headline workload, each against the oracle."""
+    """cfg 4, cfg 3, cfg 2 at BASELINE.json's per-GPU channel counts (1024 FM; 512 FM + 256 AM + 256 SSB; 256 FM at
+    N/D = 256), every channel against the oracle; 128 of cfg 5's swept SSB channels at N = 65536."""
     g = wl.GEOMETRY[name]
     plan = wl.channel_plan(name, nchan)
     nblocks = 4

@@ -1,7 +1,7 @@
 // clock_probe.hip -- the rate of the shader's cycle counter (s_memtime) against the constant 100 MHz counter while
 // something else loads the device.  Measured on MI355X: 2.39-2.41 GHz on every box, idle or under the filter kernel --
-// the counter does not follow the power-managed clock; that one is better estimated as GRBM_GUI_ACTIVE (rocprofv3
-// --pmc) over the kernel's duration (2.2-2.35 GHz under this load, differing from box to box).
+// whatever makes the same build 7 % slower on some boxes of the pool than on others does not show here
+// (GRBM_GUI_ACTIVE from rocprofv3 --pmc over the kernel's duration gives 2.2-2.35 GHz).
 //   hipcc -O3 --offload-arch=gfx950 tools/clock_probe.hip -o /tmp/clock_probe
 //   python bench.py --steps 4000 --no-cpu-baseline & sleep 15; /tmp/clock_probe 40
 // One wave spins for 100 ms of the constant 100 MHz counter (s_memrealtime) and reports how far the shader-clock counter

@@ -166,6 +166,10 @@ struct kq_bank {
   bool lists_dirty = true;
   float *energy_state = nullptr;
   float2 *win_paired = nullptr;  // row-paired copy of a call's samples for k_filter_full16k (full16k_paired_supported)
+  // N = 65536 full-spectrum path (four sibling workgroups per channel-block, kq_full16k.hip): what the siblings hand to
+  // each other and to k_epilogue64k; big.err is pinned host memory the kernel writes when a sibling never showed up
+  bool use64k = false;
+  kq::Big64 big{};
   // per-call parameters (5 double planes of max_channels + max_blocks update flags) travel through
   // pinned staging slots so kq_bank_process never has to synchronise the stream
   static constexpr int kSlots = 4;
@@ -221,6 +225,34 @@ int upload_n0mask(kq_bank *b, int c) {
   if (!b->chd.n0mask) return 0;
   kq::Geom const &g = b->g;
   float const low = b->chans[c].cfg.low, high = b->chans[c].cfg.high;
+  if (b->use64k) {
+    // N = 65536: sub-transform r holds bins 4 q + r, q in the 16384-point kernel's order; one mask and one meta word each
+    std::vector<unsigned> m(4 * 512, 0u), meta(4, 0u);
+    for (int r = 0; r < 4; r++) {
+      unsigned rows = 0, outside = 0;
+      for (int t = 0; t < 512; t++) {
+        int const ka = kq::full16k_bin(t);
+        for (int half = 0; half < 2; half++)
+          for (int k3 = 0; k3 < 16; k3++) {
+            int const n = 4 * (ka + kq::kFull16kHalf * half + 1024 * k3) + r;
+            int const k = (n <= g.N / 2) ? n : n - g.N;
+            int const prod = (int)((unsigned)k * (unsigned)g.samprate);  // radio.c:407,409: int arithmetic, wraps
+            float const f = (float)prod / g.N;
+            if (!(f >= low && f <= high)) {
+              m[512 * r + t] |= 1u << (16 * half + k3);
+              outside++;
+            } else {
+              rows |= 1u << k3;
+            }
+          }
+      }
+      meta[r] = (rows << 16) | outside;  // outside <= 16384
+    }
+    if (upload(b, b->chd.n0mask + (size_t)c * 2048, m.data(), m.size() * sizeof(unsigned))) return -1;
+    if (upload(b, b->chd.n0meta + (size_t)c * 4, meta.data(), meta.size() * sizeof(unsigned))) return -1;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+  }
   std::vector<unsigned> m(512, 0u);
   unsigned rows = 0, outside = 0;  // rows of 1024 bins holding a passband bin; bins outside the passband
   for (int t = 0; t < 512; t++) {
@@ -530,11 +562,20 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   // a channel retuned since the last call (history still on the old oscillator) is then redone below with the
   // general variant, as the pruned path does.
   bool plain = true;
-  for (HostChan const &h : b->chans)
-    if (h.active && h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0) != 0) plain = false;
+  bool swept64k = false;  // N = 65536: the steady-state variant takes sweeps up to full64k_sweep_limit() itself
+  for (HostChan const &h : b->chans) {
+    if (!h.active) continue;
+    double const r = h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0);
+    if (b->use64k) {
+      if (r != 0) swept64k = true;
+      if (std::fabs(r) > kq::full64k_sweep_limit()) plain = false;
+    } else if (r != 0) {
+      plain = false;
+    }
+  }
   // That steady-state variant loads its samples 16 bytes at a time from a copy of the call's samples whose 512-sample
   // rows are interleaved in pairs; the IF-power kernel, which reads every new sample anyway, writes it
-  float2 *const paired = (use16k && plain && b->win_paired && b->fwd_mode != KQ_FWD_PRUNED) ? b->win_paired : nullptr;
+  float2 *const paired = ((use16k || b->use64k) && plain && b->win_paired && b->fwd_mode != KQ_FWD_PRUNED) ? b->win_paired : nullptr;
   {
     Scope t(b, 2, b->stream);
     kq::launch_block_energy(b->stream, window + (g.M - 1), g.L, (int)nblocks,
@@ -570,6 +611,19 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
         else
           full_launch(b->stream, g, chd, pl, window, b->tw, nret, 1, 0, nullptr, -1, retune_list);
       }
+    } else if (b->use64k) {
+      bool const holes = !b->list_active_host.empty();
+      auto const launch64k = [&](int nch, int nbl, const int *list, bool steady) {
+        kq::Big64 big = b->big;
+        big.epoch = ++b->big.epoch;  // never 0: the words start out zeroed
+        if (big.epoch == 0) big.epoch = ++b->big.epoch;
+        kq::launch_filter_full64k(b->stream, g, chd, pl, window, b->tw, nch, nbl, b->cfg.compute_n0, b->spec_dump, b->spec_ch,
+                                  list, steady, swept64k, steady ? paired : nullptr, big);
+      };
+      launch64k(holes ? (int)b->list_active_host.size() : C, (int)nblocks, holes ? b->list_active_dev : nullptr, plain);
+      // the steady-state variant mixes a whole window with one oscillator: the first block of a channel retuned since
+      // the last call (history still on the old one) is redone with the per-sample variant
+      if (plain && nret > 0) launch64k(nret, 1, retune_list, false);
     } else if (g.N > 16384) {
       kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, nullptr);
     } else {
@@ -721,6 +775,10 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   g.max_blocks = (int)cfg->max_blocks;
   g.dsamprate = (float)cfg->samprate / cfg->decimate;
 
+  // N = 65536 with compute_n0 (cfg 5 as the reference runs it), or the full path asked for by name: the 16384-point
+  // register kernel in four sibling workgroups per channel-block (KQ_FULL_SPLIT=1 keeps the older split kernel, no n0)
+  static bool const split_only = getenv("KQ_FULL_SPLIT") && atoi(getenv("KQ_FULL_SPLIT")) != 0;
+  bool const can64k = kq::full64k_supported(g) && !split_only;
   bool const can_prune = kq::pruned_supported(g) && !cfg->compute_n0;
   if (cfg->fwd_mode == KQ_FWD_PRUNED) {
     if (!can_prune) {
@@ -736,8 +794,9 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     // 16384 channel-blocks), so AUTO keeps the full path there; KQ_FWD_PRUNED still selects it explicitly
     b->fwd_mode = (can_prune && g.Ndec != 256) ? KQ_FWD_PRUNED : KQ_FWD_FULL;
   }
-  if (b->fwd_mode == KQ_FWD_FULL && N > 16384 && (!kq::split_supported(g) || cfg->compute_n0)) {
-    set_err("N = %u: the full path beyond 16384 points needs N <= 65536, N/D <= 2048 and compute_n0 off", N);
+  b->use64k = b->fwd_mode == KQ_FWD_FULL && can64k;
+  if (b->fwd_mode == KQ_FWD_FULL && N > 16384 && !b->use64k && (!kq::split_supported(g) || cfg->compute_n0)) {
+    set_err("N = %u: the full path beyond 16384 points needs N = 65536, or N = 32768 with N/D <= 2048 and compute_n0 off", N);
     delete b;
     return nullptr;
   }
@@ -775,6 +834,21 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   if (b->cfg.compute_n0 && kq::full16k_supported(g)) {
     rc |= dev_alloc(&b->chd.n0mask, C * 512);
     rc |= dev_alloc(&b->chd.n0meta, C);
+  }
+  if (b->use64k) {
+    if (b->cfg.compute_n0) {
+      rc |= dev_alloc(&b->chd.n0mask, C * 4 * 512);
+      rc |= dev_alloc(&b->chd.n0meta, C * 4);
+    }
+    rc |= dev_alloc(&b->big.sync, C * cfg->max_blocks * 12);
+    rc |= dev_alloc(&b->big.n0part, C * cfg->max_blocks * 4);
+    rc |= dev_alloc(&b->big.xs, C * cfg->max_blocks * (size_t)g.Ndec);
+    if (hipHostMalloc((void **)&b->big.err, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+      set_err("pinned allocation failed");
+      rc = -1;
+    } else {
+      *b->big.err = 0;
+    }
   }
   // eight oscillator planes + the per-block IF-power flags of one call
   // eight oscillator planes | the per-block IF-power flags | the list of channels retuned since the last call
@@ -894,6 +968,7 @@ int kq_bank_destroy(kq_bank *b) {
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
                   b->pl2[0].plout, b->pl2[1].plout, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
                   b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state, b->win_paired,
+                  b->big.sync, b->big.n0part, b->big.xs,
                   b->list_dev[0], b->list_dev[1], b->list_dev[2], b->list_active_dev, b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->list_pll_dev, b->pll_state, b->pll_rings,
                   b->pll_side};
   for (void *p : ptrs)
@@ -903,6 +978,7 @@ int kq_bank_destroy(kq_bank *b) {
       (void)hipEventDestroy(p.a);
       (void)hipEventDestroy(p.b);
     }
+  if (b->big.err) (void)hipHostFree(b->big.err);
   for (int k = 0; k < kq_bank::kSlots; k++) {
     if (b->stage_host[k]) (void)hipHostFree(b->stage_host[k]);
     if (b->stage_ev[k]) (void)hipEventDestroy(b->stage_ev[k]);
@@ -1437,6 +1513,11 @@ int kq_bank_sync(kq_bank *b) {
   kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return -1;
   if (sync_all(b)) return -1;
+  if (b->big.err && *b->big.err) {
+    *b->big.err = 0;
+    set_err("N = 65536 filter: a sibling workgroup's compute_n0 sum never arrived (n0 of that call is NaN)");
+    return -1;
+  }
   return 0;
 }
 

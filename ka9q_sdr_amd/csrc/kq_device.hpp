@@ -51,8 +51,10 @@ struct ChanDev {
   float *recovery;      // am.c:27 / linear.c:34 recovery_factor
   int *hangmax;
   float *noise_gain;
-  unsigned *n0mask;     // [C][512] compute_n0 passband mask in k_filter_full16k's bin order (null: compute_n0 off)
+  unsigned *n0mask;     // [C][512] compute_n0 passband mask in k_filter_full16k's bin order (null: compute_n0 off);
+                        //   N = 65536: [C][4][512], one mask per sub-transform (bins 4 q + r)
   unsigned *n0meta;     // [C] rows of 1024 bins that hold a passband bin << 16 | number of bins outside the passband
+                        //   (N = 65536: [C][4], per sub-transform)
   // oscillator phase (turns), step (cycles/sample) and sweep (cycles/sample^2) at sample 0 of the
   // first window of the call; second LO and Doppler already summed (they multiply, so phases add)
   double *lo_phase, *lo_freq, *lo_rate;
@@ -130,6 +132,22 @@ void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
                            const int *chan_list, bool plain, const float2 *window_paired);
 bool full16k_paired_supported(const Geom &g);
+// N = 65536 on the same kernel: four sibling workgroups per channel-block, each the 16384-point transform of one residue
+// class of bins (k = 4 q + r); what they share travels through these planes (kq_full16k.hip)
+struct Big64 {
+  unsigned long long *sync;  // [C][max_blocks][3][4] tagged words: first-pass sums of compute_n0 handed between the siblings
+  float2 *n0part;            // [C][max_blocks][4] second pass: (sum, count) per sub-transform
+  float2 *xs;                // [C][max_blocks][N_dec] the bins the slave reads, index k mod N_dec
+  int *err;                  // set when a sibling's word never arrived
+  unsigned epoch;            // tag of this launch
+};
+bool full64k_supported(const Geom &g);
+// plain: no channel of the launch was retuned since the last call and every sweep rate is inside full64k_sweep_limit();
+// swept: some channel sweeps
+void launch_filter_full64k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
+                           const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
+                           const int *chan_list, bool plain, bool swept, const float2 *window_paired, const Big64 &big);
+double full64k_sweep_limit();  // |rate| in cycles per sample^2 up to which the table path's first-order cross term holds
 bool split_supported(const Geom &g);
 void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                          const float2 *tw, int nchan, int nblocks, const int *chan_list);

@@ -19,6 +19,20 @@
 // NCO: without sweep the phasor of sample 512 n1 + t is P_t S^{n1}; S^{n1} is built from S, S^2, S^4, S^8, S^16
 // (each from the double-precision phase), at most four products deep.  Swept channels and the first block after a
 // retune (history still on the old oscillator) evaluate the closed-form phase per sample, as k_filter_full does.
+//
+// N = 65536 (BIG; cfg 5: compute_n0 needs every bin there too, linear.c:123-126).  64 Ki complex values are 512 KiB -- more
+// than a CU's LDS, as much as its whole register file -- so the transform is split by decimation in frequency over the
+// first radix-4 stage, ACROSS four sibling workgroups: bins k = 4 q + r are the 16384-point transform of
+//   z_r[m] = W_N^{r m} sum_j (-i)^{r j} xm[m + 16384 j],   xm = samples times the oscillator,
+// and the four residue classes need nothing from each other afterwards.  Workgroup (channel, block, r) forms z_r while it
+// loads -- every sample meets its row's phasor T[j][n1] (oscillator at the row start, (-i)^{r j} and the row part of
+// W_N^{r m} in one table entry per row, evaluated in double per wave); the column part rides on pass 1's twiddles with
+// P_t as before -- and then runs the body below unchanged.  A sweep adds the cross term rate * (row start) * (column):
+// its wave part goes into the wave's table, the lane part (below 1e-3 rad inside full64k_sweep_limit()) is applied to
+// first order on the row sum.  compute_n0's first pass needs the sum over all four classes: each sibling publishes its
+// part in a tagged 64-bit word (agent-scope atomic store), reads the other three (bounded spin: siblings are adjacent
+// workgroup ids, dispatched together) and adds the four in a fixed order, so all four use the same threshold; the second
+// pass' (sum, count) and the bins the slave reads go to global memory, where k_epilogue64k finishes them.
 #include "kq_device.hpp"
 #include "kq_ldsfft.hpp"
 #include <cmath>
@@ -134,6 +148,37 @@ __device__ __forceinline__ v2f phasor2(double turns) {
   return (v2f){p.x, p.y};
 }
 
+// N = 65536: largest sweep (cycles per sample^2) the table path takes.  The lane part of the cross term,
+// theta = 2 pi rate R lane with R <= 65024 and lane <= 63, is applied as 1 + i theta: its error theta^2 / 2 stays below 5e-8.
+constexpr double kSweepLimit64k = 1.1e-11;
+
+// N = 65536: hands one 32-bit value to the three sibling workgroups of the channel-block and collects all four into
+// out[0..3] (LDS), in sub-transform order.  `slots` = this channel-block's four words of one exchange round; a word is
+// (launch tag << 32 | value), written and read with agent-scope atomics (the siblings sit on other XCDs: other L2s).
+// The siblings are adjacent workgroup ids of one launch and are dispatched together; the spin is bounded all the same,
+// so that a lost sibling shows as an error flag and a NaN, never as a hung device.  Two barriers; every thread calls.
+__device__ __forceinline__ void sibling_exchange(unsigned long long *slots, int r4, unsigned value, unsigned tag, float *out,
+                                                 int *err) {
+  int const t = threadIdx.x;
+  if (t == 0)
+    __hip_atomic_store(slots + r4, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t < 4) {
+    unsigned long long w = 0;
+    int it = 0;
+    for (;;) {
+      w = __hip_atomic_load(slots + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(w >> 32) == tag || ++it > (1 << 18)) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if ((unsigned)(w >> 32) != tag) {
+      *err = 1;
+      w = 0x7fc00000u;  // NaN
+    }
+    out[t] = __uint_as_float((unsigned)w);
+  }
+  __syncthreads();
+}
+
 }  // namespace
 
 // grid (channel, block); dynamic LDS = kXchElems float2 (the epilogue's 2 * N_dec float2 fit in it).
@@ -141,13 +186,19 @@ __device__ __forceinline__ v2f phasor2(double turns) {
 // host vouches that no channel of the launch sweeps or was retuned since the last call -- the steady state of a
 // receiver -- so the per-sample oscillator path (2000 instructions of double arithmetic) is left out and the window
 // loads can be issued before anything else (with that path in the kernel they cost it 24 spilled registers).
-template <bool N0, bool DUMP, bool PLAIN, bool PAIRED>
+// BIG: 0 = N 16384; 1 = N 65536 (four sibling workgroups per channel-block, blockIdx.x = 4 * channel + r); 2 = the same,
+// PLAIN launch with swept channels
+template <bool N0, bool DUMP, bool PLAIN, bool PAIRED, int BIG>
 __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,
                                                        const float2 *__restrict__ tw, const float2 *__restrict__ tab,
                                                        float2 *__restrict__ spec_dump, int spec_ch,
-                                                       const int *__restrict__ chan_list) {
+                                                       const int *__restrict__ chan_list, Big64 big) {
   extern __shared__ __attribute__((aligned(16))) float2 xch[];
-  __shared__ __attribute__((aligned(16))) float2 stab[(kT / 64) * 32];  // per wave: S^{n1}, see the mix
+  // per wave: S^{n1}, see the mix (BIG: the 128 row phasors T[j][n1])
+  __shared__ __attribute__((aligned(16))) float2 stab[(kT / 64) * (BIG ? 128 : 32)];
+  __shared__ float sib_f[BIG ? 12 : 1];  // BIG: what the siblings published, see sibling_exchange
+  constexpr int kNfull = BIG ? 4 * kN : kN;
+  int const r4 = BIG ? (int)(blockIdx.x & 3) : 0;  // residue class of this workgroup's bins
   __shared__ __attribute__((aligned(16))) float2 tw2[16 * kTw2Pitch];   // pass 2's twiddles W_N^{32 n3 k2} at [n3][k2]
   __shared__ float red_f[2][kT / 64];  // compute_n0: one slot per wave and pass
   __shared__ float red_c[kT / 64];     //   bins counted by the fast second pass (exact in float: at most 16384)
@@ -165,7 +216,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   // instruction's side effect on the compiler's schedule costs more than the priority gains).
   __builtin_amdgcn_s_setprio(3);
   v2f v[32];
-  rsrc_t const xr = make_rsrc(window + (size_t)blockIdx.y * g.L, kN * (unsigned)sizeof(float2));
+  rsrc_t const xr = make_rsrc(window + (size_t)blockIdx.y * g.L, kNfull * (unsigned)sizeof(float2));
   unsigned const toff = (unsigned)t * (unsigned)sizeof(float2);
   auto load_rows = [&](int first, int last) {
     if constexpr (PAIRED) {
@@ -183,9 +234,119 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   auto load_window = [&]() { load_rows(0, 32); };
   rsrc_t const tabr = make_rsrc(tab, kTabSize * (unsigned)sizeof(float2));
   v2f tlo[3], thi[7];
-  int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
+  int const cidx = BIG ? (int)(blockIdx.x >> 2) : (int)blockIdx.x;
+  int const c = chan_list ? chan_list[cidx] : cidx, b = blockIdx.y;
   v2f pt = (v2f){1.f, 0.f};
-  if constexpr (PLAIN) {
+  if constexpr (BIG != 0) {
+    // ---------------- N = 65536: z_r[m] = sum_j T[j][n1] x[16384 j + 512 n1 + t] (1 + i theta), m = 512 n1 + t
+    double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c], rs = ch.lo_rate[c];
+    double const hp0 = ch.hist_phase[c], hf0 = ch.hist_freq[c], hr = ch.hist_rate[c];
+    double const mbase = (double)b * g.L;
+    bool const retuned = b == 0 && (hp0 != ph0 || hf0 != f0 || hr != rs);
+    if (PLAIN || (!retuned && fabs(rs) <= kSweepLimit64k)) {
+      constexpr bool kSwept = !PLAIN || BIG == 2;
+      // staging for two steps of loads (a step = the row pair 2 i, 2 i + 1 of all four quarters): sa = even row, sb = odd
+      v2f sa[2][4], sb[2][4];
+      auto issue = [&](int i, int slot) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if constexpr (PAIRED) {
+            buf_ld4(sa[slot][j], sb[slot][j], xr, 2 * toff, (unsigned)(16 * j + i) * (unsigned)(1024 * sizeof(float2)));
+          } else {
+            sa[slot][j] = buf_ld2(xr, toff, (unsigned)(32 * j + 2 * i) * (unsigned)(512 * sizeof(float2)));
+            sb[slot][j] = buf_ld2(xr, toff, (unsigned)(32 * j + 2 * i + 1) * (unsigned)(512 * sizeof(float2)));
+          }
+        }
+      };
+      issue(0, 0);
+      issue(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // Row phasors, per wave (lane e and e + 64 evaluate entries e, e + 64; entry 32 j + n1 belongs to the row that starts
+      // at R = 16384 j + 512 n1).  With u = mbase + R + t the sample's index in the call:
+      //   phase(u) = [ph0 + (f0 + rs mbase) t + rs t (t - 1) / 2]  +  [f0 U + rs U (U - 1) / 2]  +  rs R t,   U = mbase + R
+      // first bracket = P_t, second = the row's entry; of the cross term rs R t, t = 64 w + lane, the wave's share
+      // rs R 64 w goes into the entry as well.  DIF: W_N^{r m} (-i)^{r j} = exp(-2 pi i (r (512 n1 + t) / N + r j / 4)).
+      float2 *const sw = stab + (t >> 6) * 128;
+      {
+        int const lane = t & 63;
+        double const wv = (double)(64 * (t >> 6));
+#pragma unroll
+        for (int e2 = 0; e2 < 2; e2++) {
+          int const e = lane + 64 * e2, j = e >> 5, n1 = e & 31;
+          double const R = (double)(16384 * j + 512 * n1), U = mbase + R;
+          double turns = f0 * U - (double)(r4 * n1) * (1.0 / 128.0) - 0.25 * (double)(r4 * j);
+          if (kSwept) turns += rs * (0.5 * U * (U - 1.0) + R * wv);
+          sw[e] = phasor_turns(turns);
+        }
+      }
+      {
+        double const td = (double)t;
+        double turns = ph0 + f0 * td - (double)(r4 * t) * (1.0 / 65536.0);
+        if (kSwept) turns += rs * (mbase * td + 0.5 * td * (td - 1.0));
+        pt = phasor2(turns);
+      }
+      // first-order lane part of the cross term: theta = 2 pi rs R lane = kb (16384 j + 512 n1) / 16384
+      float const kbf = kSwept ? (float)(2.0 * M_PI * 16384.0 * rs * (double)(t & 63)) : 0.f;
+      v2f const kb = (v2f){kbf, kbf};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const float4 *const tp = reinterpret_cast<const float4 *>(sw);
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        int const slot = i & 1;
+        float4 tt[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) tt[j] = tp[16 * j + i];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          int const n1 = 2 * i + e;
+          v2f x[4], w[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            x[j] = e ? sb[slot][j] : sa[slot][j];
+            w[j] = e ? (v2f){tt[j].z, tt[j].w} : (v2f){tt[j].x, tt[j].y};
+          }
+          v2f z;
+          if constexpr (kSwept) {
+            // sum_j y_j (1 + i kappa R_j), R_j = 16384 j + 512 n1:  S + i kb (W + n1 / 32 S), W = y1 + 2 y2 + 3 y3
+            v2f const y0 = pk_cmul(x[0], w[0]), y1 = pk_cmul(x[1], w[1]), y2 = pk_cmul(x[2], w[2]), y3 = pk_cmul(x[3], w[3]);
+            v2f const a = y1 + y3, bb = y2 + y3;
+            v2f const S = (y0 + y2) + a;
+            v2f const W = rfft::pk_fma(bb, (v2f){2.f, 2.f}, a);
+            v2f const Uu = n1 ? rfft::pk_fma(S, (v2f){n1 / 32.f, n1 / 32.f}, W) : W;
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(z) : "v"(Uu), "v"(kb), "v"(S));
+          } else {
+            z = pk_cmul(x[0], w[0]);
+            z = rfft::pk_cmadd(x[1], w[1], z);
+            z = rfft::pk_cmadd(x[2], w[2], z);
+            z = rfft::pk_cmadd(x[3], w[3], z);
+          }
+          v[rfft::bitrev5(n1)] = z;
+        }
+        if (i + 2 < 16) issue(i + 2, slot);
+      }
+    } else {
+      // first block after a retune (history still on the old oscillator), or a sweep beyond the table path's reach:
+      // closed-form phase per sample
+#pragma unroll
+      for (int n1 = 0; n1 < 32; n1++) {
+        v2f acc = (v2f){0.f, 0.f};
+        for (int j = 0; j < 4; j++) {
+          int const i = 16384 * j + 512 * n1 + t;
+          double const m = mbase + i;
+          bool const old = (b == 0) && i < g.M - 1;
+          double const rr = old ? hr : rs;
+          double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
+          if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
+          turns -= (double)(r4 * (512 * n1 + t)) * (1.0 / 65536.0) + 0.25 * (double)(r4 * j);
+          acc = rfft::pk_cmadd(buf_ld2(xr, toff, (unsigned)(32 * j + n1) * (unsigned)(512 * sizeof(float2))), phasor2(turns), acc);
+        }
+        v[rfft::bitrev5(n1)] = acc;
+      }
+    }
+  }
+  if constexpr (PLAIN && BIG == 0) {
     // The channel's two parameters are asked for before the samples, and the oscillator's table and phasor -- two
     // double-precision evaluations, the only arithmetic a wave has before its samples arrive -- sit between the batches
     // of loads: the memory pipeline takes the workgroup's 350 load instructions at about one per 14 cycles and a wave
@@ -210,7 +371,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   KQ_STAMP(10);  // loads issued
 
   // ---------------- NCO mix (radio.c:132-139)
-  {
+  if constexpr (BIG == 0) {
     double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c], r = ch.lo_rate[c];
     double const hp0 = ch.hist_phase[c], hf0 = ch.hist_freq[c], hr = ch.hist_rate[c];
     double const mbase = (double)b * g.L;
@@ -317,11 +478,12 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   int const ka = full16k_bin(t), kb = ka + kFull16kHalf;  // k1 + 32 k2 with k1 = t >> 5 and 16 + (t >> 5), k2 = t & 31
 
   if (DUMP && c == spec_ch) {
-    float2 *o = spec_dump + (size_t)b * kN;
+    float2 *o = spec_dump + (size_t)b * kNfull;
+    constexpr int kStep = BIG ? 4 : 1;  // BIG: bin 4 q + r4
 #pragma unroll
     for (int k3 = 0; k3 < 16; k3++) {
-      o[ka + 1024 * k3] = make_float2(ya[k3].x, ya[k3].y);
-      o[kb + 1024 * k3] = make_float2(yb[k3].x, yb[k3].y);
+      o[kStep * (ka + 1024 * k3) + r4] = make_float2(ya[k3].x, ya[k3].y);
+      o[kStep * (kb + 1024 * k3) + r4] = make_float2(yb[k3].x, yb[k3].y);
     }
   }
 
@@ -331,7 +493,29 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   float2 *Xs = xch;
   float2 *G = Xs + Ndec;
   auto to_f2 = [](v2f a) { return make_float2(a.x, a.y); };
-  if (Ndec <= 1024) {
+  if constexpr (BIG != 0) {
+    // bins k = 4 q + r4 of this sub-transform that the slave reads, to global memory at k mod N_dec (k_epilogue64k)
+    float2 *const Xg = big.xs + ((size_t)c * g.max_blocks + b) * Ndec;
+    auto put = [&](int q, v2f val) {
+      int const k = 4 * q + r4;
+      if (k <= Ndec / 2)
+        Xg[k] = to_f2(val);
+      else if (k > kNfull - Ndec / 2)
+        Xg[k - kNfull + Ndec] = to_f2(val);
+    };
+    if (Ndec <= 4096) {  // sub-transform rows k3 = 0 and k3 = 15 only
+      put(ka, ya[0]);
+      put(kb, yb[0]);
+      put(ka + 15 * 1024, ya[15]);
+      put(kb + 15 * 1024, yb[15]);
+    } else {
+#pragma unroll
+      for (int k3 = 0; k3 < 16; k3++) {
+        put(ka + 1024 * k3, ya[k3]);
+        put(kb + 1024 * k3, yb[k3]);
+      }
+    }
+  } else if (Ndec <= 1024) {
     // the slave's bins all lie in the first and the last 1024: rows k3 = 0 and k3 = 15 only
     if (ka <= Ndec / 2) Xs[ka] = to_f2(ya[0]);
     if (kb <= Ndec / 2) Xs[kb] = to_f2(yb[0]);
@@ -357,7 +541,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   const float2 *H = ch.resp + (size_t)c * Ndec;
   bool const isb = (ch.flags[c] & FLAG_ISB) != 0;
   v2f epi_h = {0.f, 0.f}, epi_h2 = {0.f, 0.f}, epi_w[5] = {};
-  if (Ndec == 64 && t < 64) {
+  if (BIG == 0 && Ndec == 64 && t < 64) {
     int const q = (int)(__brev((unsigned)t) >> 26);
     epi_h = ld2(H + q);
     if (isb) epi_h2 = ld2(H + ((64 - q) & 63));
@@ -386,8 +570,8 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     // The passband is a few dozen of the 16384 bins around DC: they sit in rows 0 and 15 (bins 0..1023 and
     // -1024..-1), which are always looked at; `meta` >> 16 flags the rows that hold a passband bin, so that one
     // wave-uniform test covers the other fourteen.  Its low half counts the bins outside the passband.
-    unsigned const m = ch.n0mask[(size_t)c * kT + t];
-    unsigned const meta = ch.n0meta[c];
+    unsigned const m = ch.n0mask[((size_t)c * (BIG ? 4 : 1) + r4) * kT + t];
+    unsigned const meta = ch.n0meta[c * (BIG ? 4 : 1) + r4];
     bool const wide = (meta & 0x7ffe0000u) != 0;
     auto mark_row = [&](int k3, float marker) {
       pp[k3].x = ((m >> k3) & 1) ? pp[k3].x : marker;
@@ -417,7 +601,15 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     float total = 0;
 #pragma unroll
     for (int k = 0; k < kT / 64; k++) total += red_f[0][k];
-    int const bins1 = (int)(meta & 0xffffu);
+    int bins1 = (int)(meta & 0xffffu);
+    unsigned long long *const slots = BIG ? big.sync + ((size_t)c * g.max_blocks + b) * 12 : nullptr;
+    if constexpr (BIG != 0) {
+      // the mean runs over the bins of all four sub-transforms: same four numbers, same order in every sibling
+      sibling_exchange(slots, r4, __float_as_uint(total), big.epoch, sib_f, big.err);
+      total = (sib_f[0] + sib_f[1]) + (sib_f[2] + sib_f[3]);
+      const unsigned *const mt = ch.n0meta + c * 4;
+      bins1 = (int)((mt[0] & 0xffffu) + (mt[1] & 0xffffu) + (mt[2] & 0xffffu) + (mt[3] & 0xffffu));
+    }
     float const thr = (total / bins1) * 2;
     // Second pass: sum and count of the bins with s < thr.  For a normal, finite threshold the comparison is done in
     // packed arithmetic: with scale = 2^(40 - exponent(thr)), clamp(thr * scale - s * scale) is exactly 1 for every
@@ -455,6 +647,8 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     } else {
       mark_passband(INFINITY);  // fails both passes' `< thr`, as do the NaN / inf bins the reference's comparison drops
       float avg = INFINITY;
+      float tf_last = 0;
+      int bins_last = 0;
       // Both passes run the same loop body.  (Left to itself the compiler peels the first one and, with thr = inf
       // known, counts bins with `p != inf` -- which a NaN bin would pass -- while still summing with an ordered compare.)
       asm volatile("" : "+v"(avg));
@@ -483,9 +677,21 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
           tf += red_f[iter][k];
           bins += red_i[iter][k];
         }
+        if (BIG != 0 && iter == 0) {  // first pass: sum and count over all four sub-transforms
+          sibling_exchange(slots + 4, r4, __float_as_uint(tf), big.epoch, sib_f + 4, big.err);
+          sibling_exchange(slots + 8, r4, (unsigned)bins, big.epoch, sib_f + 8, big.err);
+          tf = (sib_f[4] + sib_f[5]) + (sib_f[6] + sib_f[7]);
+          bins = (int)(__float_as_uint(sib_f[8]) + __float_as_uint(sib_f[9]) + __float_as_uint(sib_f[10]) + __float_as_uint(sib_f[11]));
+        }
         avg = tf / bins;
+        tf_last = tf;
+        bins_last = bins;
       }
-      if (t == 0) pl.n0raw[(size_t)c * g.max_blocks + b] = (float)(avg / (2.0 * kN * g.samprate));
+      if constexpr (BIG != 0) {
+        if (t == 0) big.n0part[((size_t)c * g.max_blocks + b) * 4 + r4] = make_float2(tf_last, (float)bins_last);
+      } else {
+        if (t == 0) pl.n0raw[(size_t)c * g.max_blocks + b] = (float)(avg / (2.0 * kN * g.samprate));
+      }
     }
   }
 
@@ -502,9 +708,14 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
       tf += red_f[1][k];
       bins += red_c[k];
     }
-    float const avg = tf / bins;  // new_avg_n /= noisebins, radio.c:421
-    pl.n0raw[(size_t)c * g.max_blocks + b] = (float)(avg / (2.0 * kN * g.samprate));
+    if constexpr (BIG != 0) {
+      big.n0part[((size_t)c * g.max_blocks + b) * 4 + r4] = make_float2(tf, bins);  // summed over the siblings in k_epilogue64k
+    } else {
+      float const avg = tf / bins;  // new_avg_n /= noisebins, radio.c:421
+      pl.n0raw[(size_t)c * g.max_blocks + b] = (float)(avg / (2.0 * kN * g.samprate));
+    }
   }
+  if constexpr (BIG != 0) return;  // response multiply and inverse transform: k_epilogue64k
   if (Ndec == 64) {
     // cfg 3 / 4: one wave multiplies and runs the 64-point inverse transform in its registers (lane exchanges, no
     // barriers); the other seven are done.  Its response bins and stage twiddles were fetched before compute_n0
@@ -555,6 +766,44 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   for (int i = t; i < g.olen; i += kT) o[i] = G[Ndec - g.olen + i];  // filter.c:131
 }
 
+// N = 65536: what is left of a channel-block once its four sibling workgroups are done -- the response multiply,
+// CROSS_CONJ and the N/D-point inverse transform of execute_filter_output (filter.c:206-250) on the bins they dropped
+// at big.xs, and the division that ends compute_n0 (radio.c:421-424) on their second-pass sums.
+// grid (channel, block); dynamic LDS = N_dec float2.
+__global__ void k_epilogue64k(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ tw, Big64 big,
+                              const int *__restrict__ chan_list, int compute_n0) {
+  extern __shared__ __attribute__((aligned(16))) float2 G[];
+  int const t = threadIdx.x, Ndec = g.Ndec;
+  int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
+  size_t const cb = (size_t)c * g.max_blocks + b;
+  if (compute_n0 && t == 0) {
+    const float2 *p = big.n0part + cb * 4;
+    float const tf = (p[0].x + p[1].x) + (p[2].x + p[3].x), bins = (p[0].y + p[1].y) + (p[2].y + p[3].y);
+    float const avg = tf / bins;  // new_avg_n /= noisebins, radio.c:421
+    pl.n0raw[cb] = (float)(avg / (2.0 * 65536.0 * g.samprate));
+  }
+  const float2 *Xs = big.xs + cb * Ndec;
+  const float2 *H = ch.resp + (size_t)c * Ndec;
+  bool const isb = (ch.flags[c] & FLAG_ISB) != 0;
+  for (int p = t; p <= Ndec / 2; p += blockDim.x) {
+    float2 gp = cmul(H[p], Xs[p]);
+    if (p > 0 && p < Ndec / 2) {
+      int const k = Ndec - p;
+      float2 gn = cmul(H[k], Xs[k]);
+      if (isb) {  // filter.c:242-248
+        float2 const pos = gp, neg = gn;
+        gp = cadd(pos, cconj(neg));
+        gn = csub(neg, cconj(pos));
+      }
+      G[bitrev((unsigned)k, g.log2Ndec)] = gn;
+    }
+    G[bitrev((unsigned)p, g.log2Ndec)] = gp;
+  }
+  lds_fft<+1>(G, g.log2Ndec, tw, g.tw_log2);  // filter.c:250
+  float2 *o = pl.filt + cb * g.olen;
+  for (int i = t; i < g.olen; i += blockDim.x) o[i] = G[Ndec - g.olen + i];  // filter.c:131
+}
+
 bool full16k_supported(const Geom &g) {
   // the epilogue keeps Xs[N_dec] and G[N_dec] in the exchange buffer
   return g.N == kN && 2 * g.Ndec <= kXchElems && g.Ndec >= 4;
@@ -595,7 +844,12 @@ static const float2 *twiddle_tables() {
 }
 
 // the row-paired copy (see PAIRED) needs whole pairs of rows in every block; k_block_energy_sum writes it
-bool full16k_paired_supported(const Geom &g) { return full16k_supported(g) && g.L % 1024 == 0; }
+bool full16k_paired_supported(const Geom &g) {
+  return (full16k_supported(g) || full64k_supported(g)) && g.L % 1024 == 0 && (g.M - 1) % 1024 == 0;
+}
+
+bool full64k_supported(const Geom &g) { return g.N == 4 * kN && g.Ndec >= 4 && g.Ndec <= 16384; }
+double full64k_sweep_limit() { return kSweepLimit64k; }
 
 void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
@@ -612,14 +866,14 @@ void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
   auto go = [&](auto kernel) {
     ensure_dynamic_lds((const void *)kernel, lds_bytes);
     hipLaunchKernelGGL(kernel, dim3(nchan, nblocks), dim3(kT), lds_bytes, s, g, ch, pl, paired ? window_paired : window, tw, tab,
-                       spec_dump, spec_ch, chan_list);
+                       spec_dump, spec_ch, chan_list, Big64{});
   };
   auto pick = [&](auto n0c, auto dumpc) {
     constexpr bool kN0 = decltype(n0c)::value, kDump = decltype(dumpc)::value;
     if (paired)
-      go(k_filter_full16k<kN0, kDump, true, true>);
+      go(k_filter_full16k<kN0, kDump, true, true, 0>);
     else
-      plain ? go(k_filter_full16k<kN0, kDump, true, false>) : go(k_filter_full16k<kN0, kDump, false, false>);
+      plain ? go(k_filter_full16k<kN0, kDump, true, false, 0>) : go(k_filter_full16k<kN0, kDump, false, false, 0>);
   };
   using T = std::true_type;
   using F = std::false_type;
@@ -627,6 +881,43 @@ void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
     dump ? pick(T{}, T{}) : pick(T{}, F{});
   else
     dump ? pick(F{}, T{}) : pick(F{}, F{});
+}
+
+// N = 65536: four workgroups per channel-block (blockIdx.x = 4 * channel + sub-transform: siblings are adjacent ids, which
+// sibling_exchange relies on), then the epilogue kernel.
+void launch_filter_full64k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
+                           const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
+                           const int *chan_list, bool plain, bool swept, const float2 *window_paired, const Big64 &big) {
+  size_t const lds_bytes = (size_t)kXchElems * sizeof(float2);
+  const float2 *tab = twiddle_tables();
+  if (!tab) return;  // allocation failure: the caller's launch check reports it
+  bool const n0 = compute_n0 && ch.n0mask && ch.n0meta;
+  bool const dump = spec_dump != nullptr;
+  bool const paired = plain && window_paired != nullptr;
+  auto go = [&](auto kernel) {
+    ensure_dynamic_lds((const void *)kernel, lds_bytes);
+    hipLaunchKernelGGL(kernel, dim3(4 * nchan, nblocks), dim3(kT), lds_bytes, s, g, ch, pl, paired ? window_paired : window, tw,
+                       tab, spec_dump, spec_ch, chan_list, big);
+  };
+  auto pick = [&](auto n0c, auto dumpc) {
+    constexpr bool kN0 = decltype(n0c)::value, kDump = decltype(dumpc)::value;
+    if (!plain)
+      go(k_filter_full16k<kN0, kDump, false, false, 1>);
+    else if (paired)
+      swept ? go(k_filter_full16k<kN0, kDump, true, true, 2>) : go(k_filter_full16k<kN0, kDump, true, true, 1>);
+    else
+      swept ? go(k_filter_full16k<kN0, kDump, true, false, 2>) : go(k_filter_full16k<kN0, kDump, true, false, 1>);
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  if (n0)
+    dump ? pick(T{}, T{}) : pick(T{}, F{});
+  else
+    dump ? pick(F{}, T{}) : pick(F{}, F{});
+  int const threads = g.Ndec >= 1024 ? 256 : 64;
+  size_t const epi_lds = (size_t)g.Ndec * sizeof(float2);
+  ensure_dynamic_lds((const void *)k_epilogue64k, epi_lds);
+  hipLaunchKernelGGL(k_epilogue64k, dim3(nchan, nblocks), dim3(threads), epi_lds, s, g, ch, pl, tw, big, chan_list, n0 ? 1 : 0);
 }
 
 }  // namespace kq

@@ -41,6 +41,24 @@ def run_oracle(plan, geom, iq, nblocks, compute_n0=0, gain_factor=1.0):
     return out
 
 
+def n0_float64(spec, samprate, low, high):
+    """compute_n0 (radio.c:383-425) in float64 on a given N-point spectrum: bin powers from the float32 bins, the
+    reference's int-wrapped k * samprate in the passband test (radio.c:407,409), mean of the bins outside the passband,
+    then mean of those below twice that.  Exact-arithmetic yardstick for threshold ties: the float32 oracle sums 65536
+    bins in sequence and is 1e-4 off this in the first-pass mean, the GPU kernel sums as a tree."""
+    spec = np.asarray(spec, np.complex64)
+    N = len(spec)
+    p = spec.real.astype(np.float32) ** 2 + spec.imag.astype(np.float32) ** 2      # cnrmf in float, as the reference forms it
+    n = np.arange(N, dtype=np.int64)
+    k = np.where(n <= N // 2, n, n - N)
+    prod = ((k * int(samprate)) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    f = prod.astype(np.float32) / np.float32(N)
+    out = ~((f >= np.float32(low)) & (f <= np.float32(high)))
+    pw = p[out].astype(np.float64)
+    thr = 2.0 * pw.mean()
+    return float(pw[pw < thr].mean() / (2.0 * N * samprate))
+
+
 # ---- AX.25 / AFSK-1200 test signal (Bell 202: mark 1200 Hz, space 2200 Hz, NRZI, HDLC bit stuffing) ----
 def ax25_fcs(payload):
     """CRC-16/X.25 of the frame body; appended low byte first, the receiver's residue is 0xf0b8 (ax25.c:138-156)."""

@@ -15,7 +15,7 @@ import pytest
 import ka9q_sdr_amd as kq
 from common import rel_rms, run_oracle
 from ka9q_sdr_amd import workload as wl
-from test_gpu_parity import FILT_TOL, _compare, _random_plan, _run_bank
+from test_gpu_parity import FILT_TOL, _compare, _compare_counting_ties, _n0_ties_are_ties, _random_plan, _run_bank
 
 pytestmark = pytest.mark.gpu
 
@@ -24,10 +24,12 @@ FLIP_BUDGET = 0.004      # fraction of randomised channels allowed to differ thr
 
 @pytest.mark.parametrize("name,mode,n0,nchan", [("cfg4", "full", True, 1024), ("cfg3", "full", True, 1024),
                                                ("cfg3", "pruned", False, 256), ("cfg2", "full", True, 256),
-                                               ("cfg5", "pruned", False, 128)])
+                                               ("cfg5", "pruned", False, 128), ("cfg5", "full", True, 128),
+                                               ("cfg5", "full", True, 512)])
 def test_channels_at_bench_geometry(gpu, name, mode, n0, nchan):
     """cfg 4, cfg 3, cfg 2 at BASELINE.json's per-GPU channel counts (1024 FM; 512 FM + 256 AM + 256 SSB; 256 FM at
-    N/D = 256), every channel against the oracle; 128 of cfg 5's swept SSB channels at N = 65536."""
+    N/D = 256), every channel against the oracle; 128 of cfg 5's swept SSB channels at N = 65536 on the pruned path, and
+    128 and all 512 (BASELINE.json's per-GPU share) on the full-spectrum path with compute_n0, as linear.c:123-126 runs it."""
     g = wl.GEOMETRY[name]
     plan = wl.channel_plan(name, nchan)
     nblocks = 4
@@ -39,16 +41,16 @@ def test_channels_at_bench_geometry(gpu, name, mode, n0, nchan):
     # channel by channel, with the same allowance as test_decision_flips_stay_within_budget below: a bin that sits
     # within one float rounding of compute_n0's 2 x mean cut (radio.c:414-420) moves n0 by one bin's worth (0.2 %) in
     # a few channels per thousand; everything else of such a channel still has to agree
-    flips = []
-    for c, p in enumerate(plan):
-        try:
-            _compare([p], [got[c]], [want[c]], check_n0=n0)
-        except AssertionError as e:
-            _compare([p], [got[c]], [want[c]], check_n0=False)          # audio, filter output, counts, other status
-            worst = max(abs(got[c]["status"][b]["n0"] / want[c][1][b]["n0"] - 1) for b in range(nblocks))
-            assert n0 and worst < 5e-3, ("not a threshold tie", c, p, worst, str(e)[:300])
-            flips.append((c, worst))
-    assert len(flips) <= FLIP_BUDGET * len(plan), flips
+    flips = _compare_counting_ties(plan, got, want, nblocks, check_n0=n0)
+    print("threshold ties: %d of %d channels" % (len(flips), len(plan)), flips)
+    big = g["L"] + g["M"] - 1 > 16384
+    # N = 65536: the float32 oracle sums its first pass over 62 000 bins in sequence and lands 1e-4 below the exact mean
+    # (at 16384 bins: 3e-5), so a bin within 1e-4 of the cut is decided differently: 2 - 3 % of the channels.  Each of them
+    # is then checked against float64 arithmetic on the kernel's own spectrum: the kernel's n0 is the exact one.
+    budget = 0.04 if big else FLIP_BUDGET
+    assert len(flips) <= budget * len(plan), flips
+    if big and n0:
+        _n0_ties_are_ties(plan, g, iq, nblocks, flips, 0.001)
     # the status scalars the tolerances of _compare are wide for: how close they really are at this size
     worst_if = max(abs(got[c]["status"][b]["if_power"] / want[c][1][b]["if_power"] - 1) for c in range(len(plan))
                    for b in range(nblocks))

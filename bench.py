@@ -171,9 +171,6 @@ def main():
 
     geom = dict(wl.GEOMETRY[a.config])
     L, M, D, fs = geom["L"], geom["M"], geom["D"], geom["samprate"]
-    if L + M - 1 > 16384:
-        a.n0 = 0        # the bank computes compute_n0 inside its 16384-point full-spectrum kernel only (cfg 5: N = 65536)
-        a.no_second_row = True
     C = a.channels or geom["channels"]
     B = a.blocks
     from ka9q_sdr_amd.shard import FrontEndFanout, shard_range

@@ -218,63 +218,34 @@ int upload(kq_bank *b, void *dst, const void *src, size_t bytes) {
   return 0;
 }
 
-// compute_n0's passband exclusion (radio.c:405-411) depends only on the channel's filter edges: one bit per bin,
-// in the order k_filter_full16k holds the bins (thread t: bins ka + 1024 k3 in bits 0..15, ka + kFull16kHalf + 1024 k3
-// in bits 16..31, ka = full16k_bin(t)).  Same arithmetic as the kernel's fallback, int wrap included.
+// compute_n0's passband exclusion (radio.c:405-411) depends only on the channel's filter edges: one bit per bin, as
+// 64-bit lane masks in the order k_filter_full16k holds the bins (kq_device.hpp ChanDev::n0lane).  Same arithmetic as
+// the reference, int wrap of k * samprate included (radio.c:407,409).  N = 65536: sub-transform r holds bins 4 q + r.
 int upload_n0mask(kq_bank *b, int c) {
-  if (!b->chd.n0mask) return 0;
+  if (!b->chd.n0lane) return 0;
   kq::Geom const &g = b->g;
   float const low = b->chans[c].cfg.low, high = b->chans[c].cfg.high;
-  if (b->use64k) {
-    // N = 65536: sub-transform r holds bins 4 q + r, q in the 16384-point kernel's order; one mask and one meta word each
-    std::vector<unsigned> m(4 * 512, 0u), meta(4, 0u);
-    for (int r = 0; r < 4; r++) {
-      unsigned rows = 0, outside = 0;
-      for (int t = 0; t < 512; t++) {
-        int const ka = kq::full16k_bin(t);
-        for (int half = 0; half < 2; half++)
-          for (int k3 = 0; k3 < 16; k3++) {
-            int const n = 4 * (ka + kq::kFull16kHalf * half + 1024 * k3) + r;
-            int const k = (n <= g.N / 2) ? n : n - g.N;
-            int const prod = (int)((unsigned)k * (unsigned)g.samprate);  // radio.c:407,409: int arithmetic, wraps
-            float const f = (float)prod / g.N;
-            if (!(f >= low && f <= high)) {
-              m[512 * r + t] |= 1u << (16 * half + k3);
-              outside++;
-            } else {
-              rows |= 1u << k3;
-            }
+  int const nsub = b->use64k ? 4 : 1;
+  std::vector<unsigned long long> m((size_t)nsub * 256, 0ull);
+  std::vector<unsigned> meta(nsub, 0u);
+  for (int r = 0; r < nsub; r++)
+    for (int t = 0; t < 512; t++) {
+      int const ka = kq::full16k_bin(t);
+      for (int half = 0; half < 2; half++)
+        for (int k3 = 0; k3 < 16; k3++) {
+          int const n = nsub * (ka + kq::kFull16kHalf * half + 1024 * k3) + r;
+          int const k = (n <= g.N / 2) ? n : n - g.N;
+          int const prod = (int)((unsigned)k * (unsigned)g.samprate);
+          float const f = (float)prod / g.N;
+          if (!(f >= low && f <= high)) {
+            m[((size_t)r * 8 + (t >> 6)) * 32 + 16 * half + k3] |= 1ull << (t & 63);
+            meta[r]++;
           }
-      }
-      meta[r] = (rows << 16) | outside;  // outside <= 16384
-    }
-    if (upload(b, b->chd.n0mask + (size_t)c * 2048, m.data(), m.size() * sizeof(unsigned))) return -1;
-    if (upload(b, b->chd.n0meta + (size_t)c * 4, meta.data(), meta.size() * sizeof(unsigned))) return -1;
-    HIP_TRY(hipStreamSynchronize(b->stream));
-    return 0;
-  }
-  std::vector<unsigned> m(512, 0u);
-  unsigned rows = 0, outside = 0;  // rows of 1024 bins holding a passband bin; bins outside the passband
-  for (int t = 0; t < 512; t++) {
-    int const ka = kq::full16k_bin(t);
-    for (int half = 0; half < 2; half++)
-      for (int k3 = 0; k3 < 16; k3++) {
-        int const n = ka + kq::kFull16kHalf * half + 1024 * k3;
-        int const k = (n <= g.N / 2) ? n : n - g.N;
-        int const prod = (int)((unsigned)k * (unsigned)g.samprate);
-        float const f = (float)prod / g.N;
-        if (!(f >= low && f <= high)) {
-          m[t] |= 1u << (16 * half + k3);
-          outside++;
-        } else {
-          rows |= 1u << k3;
         }
-      }
-  }
-  unsigned const meta = (rows << 16) | outside;  // outside <= 16384
-  if (upload(b, b->chd.n0mask + (size_t)c * 512, m.data(), m.size() * sizeof(unsigned))) return -1;
-  if (upload(b, b->chd.n0meta + c, &meta, sizeof meta)) return -1;
-  HIP_TRY(hipStreamSynchronize(b->stream));  // `m` is about to die
+    }
+  if (upload(b, b->chd.n0lane + (size_t)c * nsub * 256, m.data(), m.size() * sizeof(m[0]))) return -1;
+  if (upload(b, b->chd.n0meta + (size_t)c * nsub, meta.data(), meta.size() * sizeof(unsigned))) return -1;
+  HIP_TRY(hipStreamSynchronize(b->stream));  // the vectors are about to die
   return 0;
 }
 
@@ -829,15 +800,15 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.recovery, C);
   rc |= dev_alloc(&b->chd.hangmax, C);
   rc |= dev_alloc(&b->chd.noise_gain, C);
-  b->chd.n0mask = nullptr;
+  b->chd.n0lane = nullptr;
   b->chd.n0meta = nullptr;
   if (b->cfg.compute_n0 && kq::full16k_supported(g)) {
-    rc |= dev_alloc(&b->chd.n0mask, C * 512);
+    rc |= dev_alloc(&b->chd.n0lane, C * 256);
     rc |= dev_alloc(&b->chd.n0meta, C);
   }
   if (b->use64k) {
     if (b->cfg.compute_n0) {
-      rc |= dev_alloc(&b->chd.n0mask, C * 4 * 512);
+      rc |= dev_alloc(&b->chd.n0lane, C * 4 * 256);
       rc |= dev_alloc(&b->chd.n0meta, C * 4);
     }
     rc |= dev_alloc(&b->big.sync, C * cfg->max_blocks * 12);
@@ -962,7 +933,7 @@ int kq_bank_destroy(kq_bank *b) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->stream2 && b->stream2 != b->stream) (void)hipStreamSynchronize(b->stream2);
   void *ptrs[] = {b->ring[0], b->ring[1], b->tw, b->chan_tw, b->chd.mode, b->chd.flags, b->chd.low, b->chd.high, b->chd.resp,
-                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.n0mask, b->chd.n0meta, b->fmout, b->fm_hist[0], b->fm_hist[1],
+                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.n0lane, b->chd.n0meta, b->fmout, b->fm_hist[0], b->fm_hist[1],
                   b->osc_dev2[0], b->osc_dev2[1], b->chd.fm_state,
                   b->chd.lastaudio, b->chd.sq_count, b->chd.ahist, b->chd.foffset, b->chd.pdev, b->chd.gain, b->chd.hang,
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,

@@ -51,10 +51,11 @@ struct ChanDev {
   float *recovery;      // am.c:27 / linear.c:34 recovery_factor
   int *hangmax;
   float *noise_gain;
-  unsigned *n0mask;     // [C][512] compute_n0 passband mask in k_filter_full16k's bin order (null: compute_n0 off);
-                        //   N = 65536: [C][4][512], one mask per sub-transform (bins 4 q + r)
-  unsigned *n0meta;     // [C] rows of 1024 bins that hold a passband bin << 16 | number of bins outside the passband
-                        //   (N = 65536: [C][4], per sub-transform)
+  // compute_n0's passband exclusion for k_filter_full16k (null: compute_n0 off): per (wave w, bin slot s = 16 half + k3) one
+  // 64-bit lane mask, bit l set = thread t = 64 w + l's bin full16k_bin(t) + kFull16kHalf half + 1024 k3 lies OUTSIDE the
+  // passband.  [C][8][32]; N = 65536: [C][4][8][32], one set per sub-transform (bins 4 q + r)
+  unsigned long long *n0lane;
+  unsigned *n0meta;     // [C] number of bins outside the passband (N = 65536: [C][4], per sub-transform)
   // oscillator phase (turns), step (cycles/sample) and sweep (cycles/sample^2) at sample 0 of the
   // first window of the call; second LO and Doppler already summed (they multiply, so phases add)
   double *lo_phase, *lo_freq, *lo_rate;
@@ -122,7 +123,7 @@ void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const P
 // register-resident N = 16384 variant of the same (kq_full16k.hip)
 bool full16k_supported(const Geom &g);
 // where k_filter_full16k leaves the spectrum: thread t holds bins full16k_bin(t) + kFull16kHalf * half + 1024 * k3
-// (half = 0, 1; k3 = 0..15); ChanDev::n0mask is laid out to match (bit 16 * half + k3 of word t)
+// (half = 0, 1; k3 = 0..15); ChanDev::n0lane is laid out to match
 constexpr int kFull16kHalf = 16;
 constexpr int full16k_bin(int t) { return (t >> 5) + 32 * (t & 31); }
 // plain: no channel of the launch has a sweep rate or a retune pending (a leaner kernel variant serves that case);

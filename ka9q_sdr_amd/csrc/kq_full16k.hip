@@ -182,7 +182,7 @@ __device__ __forceinline__ void sibling_exchange(unsigned long long *slots, int 
 }  // namespace
 
 // grid (channel, block); dynamic LDS = kXchElems float2 (the epilogue's 2 * N_dec float2 fit in it).
-// N0: compute_n0 on every block (needs ch.n0mask / ch.n0meta); DUMP: copy one channel's spectra out (tests); PLAIN: the
+// N0: compute_n0 on every block (needs ch.n0lane / ch.n0meta); DUMP: copy one channel's spectra out (tests); PLAIN: the
 // host vouches that no channel of the launch sweeps or was retuned since the last call -- the steady state of a
 // receiver -- so the per-sample oscillator path (2000 instructions of double arithmetic) is left out and the window
 // loads can be issued before anything else (with that path in the kernel they cost it 24 spilled registers).
@@ -551,8 +551,14 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
 
   // ---------------- compute_n0 (radio.c:383-425), status only.  pp[k3] = (|X[ka + 1024 k3]|^2, |X[kb + 1024 k3]|^2)
   bool n0_fast = false;
+  int outside = 0;  // this transform's bins outside the passband
   if constexpr (N0) {
     v2f pp[16];
+    // (read through the constant address space: nothing writes the masks while a kernel runs, and only then may the
+    // compiler fetch them with scalar loads this late in the kernel, behind global stores it cannot tell apart from them)
+    typedef const unsigned long long __attribute__((address_space(4))) *lane_masks;
+    lane_masks const lm = (lane_masks)(
+        ch.n0lane + ((size_t)(c * (BIG ? 4 : 1) + r4) * (kT / 64) + __builtin_amdgcn_readfirstlane(t >> 6)) * 32);
 #pragma unroll
     for (int k3 = 0; k3 < 16; k3++) {
       // spelled out (given `x*x + y*y` on both halves the compiler pairs the additions into one v_pk_add_f32 behind three
@@ -563,32 +569,20 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
       asm("v_mul_f32 %0, %1, %1" : "=v"(p1) : "v"(yb[k3].x));
       asm("v_fma_f32 %0, %1, %1, %0" : "+v"(p0) : "v"(ya[k3].y));
       asm("v_fma_f32 %0, %1, %1, %0" : "+v"(p1) : "v"(yb[k3].y));
+      // Passband exclusion (radio.c:405-411): the bin counts as 0 from here on.  Which bins lie inside the passband
+      // depends only on the channel's filter edges and is precomputed on the host (kq_bank.cpp upload_n0mask) as one
+      // 64-bit LANE mask per (wave, bin slot): scalar loads, and one v_cndmask with the mask as its condition per bin.
+      // (With the reference's 32-bit wrap of k * samprate the "passband" is scattered over the whole spectrum at
+      // 10 MS/s -- 6 % of all bins -- so there are no rows to skip; a bit mask per thread took and / compare / select
+      // per bin and was applied twice: 192 instructions per wave where these are 32.)
+      asm("v_cndmask_b32_e64 %0, 0, %0, %1" : "+v"(p0) : "s"(lm[k3]));
+      asm("v_cndmask_b32_e64 %0, 0, %0, %1" : "+v"(p1) : "s"(lm[16 + k3]));
       pp[k3] = (v2f){p0, p1};
     }
-    // Passband exclusion (radio.c:405-411), precomputed per channel on the host (kq_bank.cpp upload_n0mask: it depends
-    // only on the filter edges): bit k3 / 16 + k3 of `m` clear = the thread's bin of row k3 lies inside the passband.
-    // The passband is a few dozen of the 16384 bins around DC: they sit in rows 0 and 15 (bins 0..1023 and
-    // -1024..-1), which are always looked at; `meta` >> 16 flags the rows that hold a passband bin, so that one
-    // wave-uniform test covers the other fourteen.  Its low half counts the bins outside the passband.
-    unsigned const m = ch.n0mask[((size_t)c * (BIG ? 4 : 1) + r4) * kT + t];
-    unsigned const meta = ch.n0meta[c * (BIG ? 4 : 1) + r4];
-    bool const wide = (meta & 0x7ffe0000u) != 0;
-    auto mark_row = [&](int k3, float marker) {
-      pp[k3].x = ((m >> k3) & 1) ? pp[k3].x : marker;
-      pp[k3].y = ((m >> (16 + k3)) & 1) ? pp[k3].y : marker;
-    };
-    auto mark_passband = [&](float marker) {
-      mark_row(0, marker);
-      mark_row(15, marker);
-      if (wide) {
-        asm volatile("; passband beyond +-1024 bins");  // keeps this a branch: flattened, it is 84 selects nobody needs
-#pragma unroll
-        for (int k3 = 1; k3 < 15; k3++) mark_row(k3, marker);
-      }
-    };
-    // First pass: avg_n = inf, so `s < avg_n * 2` keeps every finite bin.  Sum them all; when the total comes out
-    // finite no bin was inf or NaN (powers are >= 0, nothing cancels) and the count is the precomputed one.
-    mark_passband(0.f);
+    outside = (int)ch.n0meta[c * (BIG ? 4 : 1) + r4];
+    // First pass: avg_n = inf, so `s < avg_n * 2` keeps every finite bin.  Sum them all (the passband's count as 0); when
+    // the total comes out finite no bin was inf or NaN (powers are >= 0, nothing cancels) and the count is the
+    // precomputed one.
     v2f s2;
     {
       v2f const a0 = pp[0] + pp[1], a1 = pp[2] + pp[3], a2 = pp[4] + pp[5], a3 = pp[6] + pp[7];
@@ -601,25 +595,25 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     float total = 0;
 #pragma unroll
     for (int k = 0; k < kT / 64; k++) total += red_f[0][k];
-    int bins1 = (int)(meta & 0xffffu);
+    int bins1 = outside;
     unsigned long long *const slots = BIG ? big.sync + ((size_t)c * g.max_blocks + b) * 12 : nullptr;
     if constexpr (BIG != 0) {
       // the mean runs over the bins of all four sub-transforms: same four numbers, same order in every sibling
       sibling_exchange(slots, r4, __float_as_uint(total), big.epoch, sib_f, big.err);
       total = (sib_f[0] + sib_f[1]) + (sib_f[2] + sib_f[3]);
       const unsigned *const mt = ch.n0meta + c * 4;
-      bins1 = (int)((mt[0] & 0xffffu) + (mt[1] & 0xffffu) + (mt[2] & 0xffffu) + (mt[3] & 0xffffu));
+      bins1 = (int)(mt[0] + mt[1] + mt[2] + mt[3]);
     }
     float const thr = (total / bins1) * 2;
     // Second pass: sum and count of the bins with s < thr.  For a normal, finite threshold the comparison is done in
     // packed arithmetic: with scale = 2^(40 - exponent(thr)), clamp(thr * scale - s * scale) is exactly 1 for every
     // float s < thr (the difference is at least 2^16 after scaling; the fused multiply-add rounds once, so its sign is
-    // that of thr - s), exactly 0 for s >= thr, and 0 for the passband marker.  Three packed instructions per pair of
+    // that of thr - s), exactly 0 for s >= thr.  A passband bin, held as 0, adds nothing to the sum and 1 to the count: the
+    // count is put right by their known number at the end.  Three packed instructions per pair of
     // bins instead of compare / select / add per bin.  Anything else -- a NaN or inf bin, an all-zero or denormal
     // spectrum, an empty bin set -- takes the loop that spells the reference's comparisons out.
     n0_fast = total < INFINITY && thr < INFINITY && thr >= 1e-26f;
     if (n0_fast) {
-      mark_passband(3.4028234664e38f);
       int const e = (__float_as_int(thr) >> 23) & 0xff;  // biased exponent, 1..254 here
       float const scale = __int_as_float((127 + 40 + 127 - e) << 23);
       float const cs = thr * scale;  // exact: a power-of-two scaling inside the normal range
@@ -645,7 +639,15 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
       }
       // the sums meet behind the barrier that also publishes the slave's bins, below
     } else {
-      mark_passband(INFINITY);  // fails both passes' `< thr`, as do the NaN / inf bins the reference's comparison drops
+      // the passband's bins become inf: fails both passes' `< thr`, as do the NaN / inf bins the reference's comparison drops
+      {
+        float const inf = INFINITY;
+#pragma unroll
+        for (int k3 = 0; k3 < 16; k3++) {
+          asm("v_cndmask_b32_e64 %0, %2, %0, %1" : "+v"(pp[k3].x) : "s"(lm[k3]), "v"(inf));
+          asm("v_cndmask_b32_e64 %0, %2, %0, %1" : "+v"(pp[k3].y) : "s"(lm[16 + k3]), "v"(inf));
+        }
+      }
       float avg = INFINITY;
       float tf_last = 0;
       int bins_last = 0;
@@ -708,6 +710,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
       tf += red_f[1][k];
       bins += red_c[k];
     }
+    bins -= (float)(kN - outside);  // the passband's bins, held as 0, were counted as kept
     if constexpr (BIG != 0) {
       big.n0part[((size_t)c * g.max_blocks + b) * 4 + r4] = make_float2(tf, bins);  // summed over the siblings in k_epilogue64k
     } else {
@@ -860,7 +863,7 @@ void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
     launch_filter_full(s, g, ch, pl, window, tw, nchan, nblocks, compute_n0, spec_dump, spec_ch, chan_list);
     return;
   }
-  bool const n0 = compute_n0 && ch.n0mask && ch.n0meta;  // the bank uploads both whenever it was created with compute_n0
+  bool const n0 = compute_n0 && ch.n0lane && ch.n0meta;  // the bank uploads both whenever it was created with compute_n0
   bool const dump = spec_dump != nullptr;
   bool const paired = plain && window_paired != nullptr;  // only the steady-state variant reads the row-paired copy
   auto go = [&](auto kernel) {
@@ -891,7 +894,7 @@ void launch_filter_full64k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
   size_t const lds_bytes = (size_t)kXchElems * sizeof(float2);
   const float2 *tab = twiddle_tables();
   if (!tab) return;  // allocation failure: the caller's launch check reports it
-  bool const n0 = compute_n0 && ch.n0mask && ch.n0meta;
+  bool const n0 = compute_n0 && ch.n0lane && ch.n0meta;
   bool const dump = spec_dump != nullptr;
   bool const paired = plain && window_paired != nullptr;
   auto go = [&](auto kernel) {

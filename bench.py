@@ -11,8 +11,11 @@ with compute_n0 (radio.c:383-425) on every channel-block as the reference's demo
 (fm.c:78-82) -- the full-spectrum forward path.  The same workload without the status-only noise
 estimate (pruned forward transform) is reported beside it as `without_compute_n0`, never as `value`.
 With --gpus N the channels are sharded (1024 per GPU, weak scaling, configs[3] at N=8) and every
-batch of front-end I/Q is broadcast from rank 0 over RCCL (torch.distributed backend "nccl");
-started without torch.distributed.run, `--gpus N` launches its own N ranks.
+batch of front-end I/Q is broadcast from rank 0 over RCCL by the product's own fan-out (kq_fanout_* of
+include/ka9q_hip.h: ncclBroadcast on the library's side stream, two slots; `--fanout torch` selects the
+torch.distributed twin); started without torch.distributed.run, `--gpus N` launches its own N ranks.
+At N=1 the line also carries `with_host_io` (the same step fed from pinned host memory and delivering audio + status
+to pinned host memory every step, copies overlapped), `cold_first_steps_ms` (no spin-up) and the CPU baseline rows.
 
 Prints ONE JSON line on rank 0.
 """
@@ -46,7 +49,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU time of each baseline row")
+    ap.add_argument("--fanout", default="c", choices=["c", "torch"],
+                    help="front-end fan-out: c = the library's kq_fanout_* (ncclBroadcast, the product path); torch = "
+                         "ka9q_sdr_amd/shard.py's torch.distributed twin (always used with --backend gloo)")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the with_host_io measurement")
     return ap.parse_args()
 
 
@@ -81,7 +88,7 @@ def cpu_baseline(name, geom, plan, iq_host, target_s, compute_n0=0):
     from common import oracle_cfg
     cores, visible = usable_cores()
     L = geom["L"]
-    nchan = min(len(plan), 2 * cores)
+    nchan = min(len(plan), 4 * cores)      # min(C, 4 x cores) channels over all cores
     cfgs = [oracle_cfg(p, geom["samprate"], L, geom["M"], geom["D"], compute_n0=compute_n0) for p in plan[:nchan]]
     avail = len(iq_host) // L
     t, _ = ko.cpu_baseline(cfgs, iq_host, avail, 2, 8, cores)            # calibration pass
@@ -196,23 +203,58 @@ def main():
         bufs[1].copy_(bufs[0])
     # Front-end fan-out (the reference's UDP multicast, multicast.c:143-237): rank 0 -> all over RCCL,
     # double buffered on a side stream so batch k+1 travels while batch k is processed
-    fan = FrontEndFanout(bufs, src=0)
+    use_c = a.fanout == "c" and (world == 1 or a.backend == "nccl")
+    if use_c:
+        import ctypes
+        from ka9q_sdr_amd.shard import CFanout, share_unique_id
+        lib = kq.load_library()
 
-    def step(k):
-        i = k & 1
-        buf = fan.acquire(i, stream)
-        bank.process_resident(buf.data_ptr(), B)
-        fan.release(i, stream)
-        fan.post(i, stream)       # refill this buffer for step k+2 while step k+1 computes
+        def make_id():
+            buf = ctypes.create_string_buffer(128)
+            if lib.kq_fanout_unique_id(buf) != 0:
+                raise RuntimeError("kq_fanout_unique_id: " + (lib.kq_last_error() or b"").decode())
+            return buf.raw
 
-    for i in range(2):
-        fan.release(i, stream)
-        fan.post(i, stream)
+        ident = share_unique_id(make_id, rank, 0, dist, dev) if world > 1 else None
+        fan = CFanout(lib, dev_index, rank, world, nwin, ident)         # collective: every rank is here
+        for i in range(2):                                                # the batch goes into both slots once
+            fan.fill(i, bufs[0].data_ptr() if rank == 0 else None)
+        cs = stream.cuda_stream
+
+        def step(k):
+            i = k & 1
+            p = fan.acquire(i, cs)
+            bank.process_resident(p, B)
+            fan.release(i, cs)
+            fan.post(i)           # refill this slot for step k+2 while step k+1 computes
+    else:
+        fan = FrontEndFanout(bufs, src=0)
+
+        def step(k):
+            i = k & 1
+            buf = fan.acquire(i, stream)
+            bank.process_resident(buf.data_ptr(), B)
+            fan.release(i, stream)
+            fan.post(i, stream)       # refill this buffer for step k+2 while step k+1 computes
+
+        for i in range(2):
+            fan.release(i, stream)
+            fan.post(i, stream)
+    # the first steps of an idle GPU, one by one (no spin-up): what a receiver sees when it starts
+    cold = []
+    for k in range(4):
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        step(k)
+        torch.cuda.synchronize()
+        cold.append(round((time.perf_counter() - tc) * 1e3, 4))
     # Spin-up, then the W warm-up steps, then the K timed steps: one continuous sequence of identical steps.  The
     # spin-up count is even so that the double buffers are at the same parity whatever its length.
     spin = 2 * (max(0, a.spinup) // 2)
     for k in range(spin):
-        step(k)
+        step(4 + k)
+    spin_reported = spin
+    spin += 4       # the four cold steps kept the slot parity
     for k in range(a.warmup):
         step(spin + k)
     torch.cuda.synchronize()
@@ -228,10 +270,16 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    rank_ms = [elapsed / a.steps * 1e3] * 2      # fastest / slowest rank
     if dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tdev = dev if a.backend == "nccl" else "cpu"
+        tt = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
+        tmin = tt.clone()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
         elapsed = float(tt.item())
+        rank_ms = [float(tmin.item()) / a.steps * 1e3, elapsed / a.steps * 1e3]
+    fan_stats = fan.stats() if use_c else None
     tm = bank.timing(reset=True)
     # the demodulator kernels' time comes from a few extra, untimed steps with the full set of events
     bank.enable_timing(2)
@@ -240,6 +288,44 @@ def main():
     torch.cuda.synchronize()
     tm2 = bank.timing(reset=True)
     bank.enable_timing(0)
+
+    # The path to its real ends (1 GPU only): the reference's path starts at a host packet (radio.c:106-147) and ends in a
+    # host float buffer per block (audio.c:82).  Same step, but the batch comes from pinned host memory
+    # (kq_bank_push_iq_async -> ring -> kq_bank_process) and audio + status of every step go back to pinned host memory
+    # (kq_bank_pull_planes_async); the copies ride on the bank's copy streams under the kernels.  Beside `value`, never it.
+    host_io = None
+    if world == 1 and not a.no_host_io:
+        import ctypes
+        olen = L // D
+        iq_pin = torch.from_numpy(np.ascontiguousarray(iq_host[M - 1:M - 1 + B * L])).pin_memory()
+        audio_pin = torch.empty(C * B * 2 * olen, dtype=torch.float32).pin_memory()
+        status_pin = torch.empty(C * B * ctypes.sizeof(kq.ChanStatus), dtype=torch.uint8).pin_memory()
+
+        def io_step():
+            bank.push_iq_async(iq_pin.data_ptr(), B * L)
+            assert bank.process() == B
+            bank.pull_planes_async(audio_pin.data_ptr(), status_pin.data_ptr())
+
+        n_io = max(2, min(50, a.steps))
+        for k in range(20):
+            io_step()
+        bank.host_io_wait()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for k in range(n_io):
+            io_step()
+        bank.host_io_wait()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t3) / n_io
+        h2d, d2h = iq_pin.numel() * 8, audio_pin.numel() * 4 + status_pin.numel()
+        host_io = {"value": round(C * B * L / dt / 1e6, 1), "unit": "Msamples/s (channel-samples)",
+                   "ms_per_step": round(dt * 1e3, 4), "steps": n_io,
+                   "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": d2h,
+                   "h2d_GBps": round(h2d / dt / 1e9, 2), "d2h_GBps": round(d2h / dt / 1e9, 2),
+                   "audio_checksum": float(audio_pin[:C * B * 2 * olen:997].abs().sum()),
+                   "note": "input from pinned host memory (kq_bank_push_iq_async + kq_bank_process, ring path with its "
+                           "history copy), audio [C][B][2 olen] float + status [C][B] planes to pinned host memory every "
+                           "step (kq_bank_pull_planes_async); copies on the bank's copy streams, overlapped with the kernels"}
 
     # Secondary row (1 GPU only): the same workload with compute_n0 switched the other way.  The headline computes
     # the noise estimate of radio.c:383-425 on every channel-block, as the reference's demod threads do, which needs
@@ -313,7 +399,7 @@ def main():
             "metric": "input Msamples/s + channels @ real-time, 16384-pt overlap-save",
             "value": round(value, 1),
             "unit": "Msamples/s (channel-samples: front-end input samples x channels, all GPUs)",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "spinup_steps": spin,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "spinup_steps": spin_reported,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -329,7 +415,21 @@ def main():
                 "parallelism": "channels sharded x%d, front-end I/Q broadcast over RCCL" % world if world > 1 else "1 GPU",
             },
             "roofline": roofline(k_ms, bool(a.n0), fwd_used, tm2["demod_ms"] / max(1, tm2["filter_launches"])),
+            "cold_first_steps_ms": cold,
+            "ms_per_step_ranks": {"min": round(rank_ms[0], 4), "max": round(rank_ms[1], 4)},
+            "fanout": "kq_fanout (C ABI, ncclBroadcast on the library's side stream)" if use_c else
+                      "torch.distributed.broadcast (%s)" % a.backend,
         }
+        if fan_stats is not None:
+            out["rccl"] = {"ranks": fan_stats["rccl_ranks"], "world": world, "version": fan_stats["rccl_version"],
+                           "broadcasts": fan_stats["broadcasts"],
+                           "bcast_ms": round(fan_stats["broadcast_ms"] / max(1, fan_stats["broadcasts"]), 4),
+                           "bytes_per_broadcast": nwin * 8,
+                           "note": "ranks = ncclCommCount of the fan-out's communicator (0: one rank, no communicator); "
+                                   "bcast_ms = HIP events around ncclBroadcast on the side stream, rank 0"}
+        if host_io:
+            host_io["fraction_of_value"] = round(host_io["value"] / max(value, 1e-9), 4)
+            out["with_host_io"] = host_io
         if second:
             second["roofline"] = roofline(second["kernel_ms"], bool(second["compute_n0"]), second["fwd"])
             second["note"] = ("the same workload %s compute_n0 (radio.c:383-425, status only): the bank then runs its %s "
@@ -337,8 +437,14 @@ def main():
             out["with_compute_n0" if second["compute_n0"] else "without_compute_n0"] = second
         if not a.no_cpu_baseline and world == 1:   # the CPU leg runs on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(a.config, geom, plan, iq_host[M - 1:], a.cpu_seconds, compute_n0=a.n0)
+            # SURVEY 8d's second row: compute_n0 the other way, next to the GPU row configured the same way
+            other = cpu_baseline(a.config, geom, plan, iq_host[M - 1:], a.cpu_seconds / 2, compute_n0=int(not a.n0))
+            out["cpu_baseline"]["with_compute_n0" if not a.n0 else "without_compute_n0"] = {
+                k: other[k] for k in ("value", "unit", "cores", "per_core", "sample")}
         print(json.dumps(out), flush=True)
     bank.close()
+    if use_c:
+        fan.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

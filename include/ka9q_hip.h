@@ -194,6 +194,22 @@ int kq_bank_process_resident(kq_bank *bank, const void *iq_dev, unsigned nblocks
  * kq_bank_sync blocks the host until everything issued so far has finished. */
 int kq_bank_join(kq_bank *bank);
 int kq_bank_sync(kq_bank *bank);
+/* --- streaming host I/O ---
+ * Both ends of the path are host buffers in the reference: a packet's samples in (radio.c:106-147), one float buffer
+ * per block out (audio.c:82 send_mono_output(demod, samples, olen)).  These three move whole batches between PINNED host
+ * memory (hipHostMalloc / hipHostRegister) and the bank on copy streams of their own, under the kernels of the
+ * neighbouring calls; nothing here blocks the host but kq_bank_host_io_wait.
+ *  kq_bank_push_iq_async:     kq_bank_push_iq from host memory without the wait: the samples travel on the input copy
+ *                             stream into one of two staging buffers, the conversion kernel follows them on the bank's
+ *                             stream.  `iq` must stay unchanged until kq_bank_host_io_wait or until two more pushes
+ *                             have been queued.
+ *  kq_bank_pull_planes_async: queues the copy of the last call's outputs -- audio [channels][max_blocks][2 * olen] float
+ *                             and status [channels][max_blocks] (either may be NULL) -- on the output copy stream;
+ *                             the next call's demodulators wait for it on the device before they overwrite the planes.
+ *  kq_bank_host_io_wait:      blocks until every queued copy has landed. */
+int kq_bank_push_iq_async(kq_bank *bank, const void *iq_pinned, size_t nsamples, int format);
+int kq_bank_pull_planes_async(kq_bank *bank, float *audio_pinned, kq_chan_status *status_pinned);
+int kq_bank_host_io_wait(kq_bank *bank);
 
 /* --- results of the last kq_bank_process call (replace send_mono_output/send_stereo_output,
  *     audio.c:82 / audio.c:32, and the sig.* fields read by radio_status.c:170-203) --- */
@@ -256,6 +272,9 @@ int kq_bank_fwd_mode(const kq_bank *bank);
  *
  *   rank `root`:  kq_fanout_unique_id(id)  -> hand the 128 bytes to the other ranks (file, socket, MPI ...)
  *   every rank:   f = kq_fanout_create(device, rank, world, root, id, samples_per_batch);
+ *                 COLLECTIVE: ncclCommInitRank inside returns only once all `world` ranks have called it with the same
+ *                 id -- one thread or process per rank, all calling concurrently (one thread creating the fan-outs of
+ *                 several ranks one after the other would wait on itself for ever)
  *                 kq_shard_range(total_channels, world, rank, &first, &count) -> add channels first .. first+count-1
  *   per batch k:  slot = k & 1
  *                 kq_fanout_post(f, slot, iq, n, is_device)      queue the broadcast (iq: read on the root rank only)
@@ -273,6 +292,16 @@ int kq_fanout_destroy(kq_fanout *f);
 int kq_fanout_post(kq_fanout *f, int slot, const void *iq_cf32, size_t nsamples, int src_is_device);
 const void *kq_fanout_acquire(kq_fanout *f, int slot, void *consumer_stream, size_t *nsamples);
 int kq_fanout_release(kq_fanout *f, int slot, void *consumer_stream);
+/* what the fan-out has done so far: the world as RCCL itself counts it (ncclCommCount; 0 without a communicator), the
+ * library's version code (ncclGetVersion) and the time the broadcasts took on the side stream (HIP events around
+ * ncclBroadcast; a broadcast still in flight when its slot was posted again is not counted).  Waits for the side stream. */
+typedef struct kq_fanout_info {
+  int world, rank;
+  int rccl_ranks, rccl_version;
+  unsigned long long broadcasts;
+  double broadcast_ms;
+} kq_fanout_info;
+int kq_fanout_stats(kq_fanout *f, kq_fanout_info *out);
 
 /* --- front-end half-band decimator cascade ---------------------------------------------------
  * What hackrf.c:260-330 does to every block of raw A/D samples before they reach the channel filter: rotate by

@@ -10,6 +10,7 @@ from .bank import (  # noqa: F401
     BankConfig,
     ChannelConfig,
     ChanStatus,
+    FanoutInfo,
     KQ_AM_DEMOD,
     KQ_FM_DEMOD,
     KQ_FWD_AUTO,

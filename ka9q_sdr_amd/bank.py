@@ -151,8 +151,27 @@ def load_library():
     L.kq_bank_enable_timing.argtypes = [C.c_void_p, C.c_int]
     L.kq_bank_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing), C.c_int]
     L.kq_bank_fwd_mode.argtypes = [C.c_void_p]
+    L.kq_bank_push_iq_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L.kq_bank_pull_planes_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kq_bank_host_io_wait.argtypes = [C.c_void_p]
+    L.kq_shard_range.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    L.kq_fanout_unique_id.argtypes = [C.c_void_p]
+    L.kq_fanout_create.restype = C.c_void_p
+    L.kq_fanout_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    L.kq_fanout_post.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
+    L.kq_fanout_acquire.restype = C.c_void_p
+    L.kq_fanout_acquire.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_size_t)]
+    L.kq_fanout_release.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.kq_fanout_destroy.argtypes = [C.c_void_p]
+    L.kq_fanout_stats.argtypes = [C.c_void_p, C.POINTER(FanoutInfo)]
     _lib = L
     return L
+
+
+class FanoutInfo(C.Structure):
+    """kq_fanout_info (include/ka9q_hip.h)"""
+    _fields_ = [("world", C.c_int), ("rank", C.c_int), ("rccl_ranks", C.c_int), ("rccl_version", C.c_int),
+                ("broadcasts", C.c_ulonglong), ("broadcast_ms", C.c_double)]
 
 
 def device_count():
@@ -252,6 +271,17 @@ class Bank:
         else:
             raise TypeError("unsupported I/Q dtype %s" % iq.dtype)
         self._chk(self.lib.kq_bank_push_iq(self.h, iq.ctypes.data, n, fmt, 0), "kq_bank_push_iq")
+
+    def push_iq_async(self, ptr, nsamples, fmt=KQ_IQ_CF32):
+        """ptr: PINNED host memory that stays unchanged until host_io_wait() (kq_bank_push_iq_async)"""
+        self._chk(self.lib.kq_bank_push_iq_async(self.h, ptr, nsamples, fmt), "kq_bank_push_iq_async")
+
+    def pull_planes_async(self, audio_ptr, status_ptr):
+        """queues the copy of the last call's audio [C][max_blocks][2 olen] / status [C][max_blocks] planes to pinned host memory"""
+        self._chk(self.lib.kq_bank_pull_planes_async(self.h, audio_ptr, status_ptr), "kq_bank_pull_planes_async")
+
+    def host_io_wait(self):
+        self._chk(self.lib.kq_bank_host_io_wait(self.h), "kq_bank_host_io_wait")
 
     def push_iq_device(self, ptr, nsamples, fmt=KQ_IQ_CF32):
         self._chk(self.lib.kq_bank_push_iq(self.h, ptr, nsamples, fmt, 1), "kq_bank_push_iq")

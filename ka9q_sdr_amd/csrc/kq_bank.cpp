@@ -184,6 +184,15 @@ struct kq_bank {
   unsigned *pcm_mask = nullptr;  // [C][max_blocks]
   void *stage_dev = nullptr;  // staging for host-side raw I/Q before conversion
   size_t stage_cap = 0;
+  // streaming host I/O (kq_bank_push_iq_async / kq_bank_pull_planes_async): copy streams of their own, two input staging
+  // buffers, events that order them against the kernels
+  hipStream_t copy_in = nullptr, copy_out = nullptr;
+  void *in_stage[2] = {nullptr, nullptr};
+  size_t in_stage_cap[2] = {0, 0};
+  hipEvent_t in_ready[2] = {nullptr, nullptr}, in_free[2] = {nullptr, nullptr};
+  int in_next = 0;
+  hipEvent_t out_ready = nullptr, out_done = nullptr;
+  bool out_pending = false;  // a plane copy is queued that the next call's demodulators must wait for
 
   std::vector<HostChan> chans;
   int64_t n_abs = 0;        // absolute index of the first new (not yet processed) sample
@@ -564,7 +573,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
                                  bool redo = true) {
       if (use16k)
         kq::launch_filter_full16k(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list, plain && !redo,
-                                  redo ? nullptr : paired);
+                                  redo ? nullptr : paired, b->big);
       else
         kq::launch_filter_full(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list);
     };
@@ -612,6 +621,10 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   if (b->stream2 != b->stream) {  // one stream: program order already is the dependency
     HIP_TRY(hipEventRecord(b->ev_filter_done, b->stream));
     HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_filter_done, 0));
+  }
+  if (b->out_pending) {  // kq_bank_pull_planes_async is still reading the audio / status planes of the last call
+    HIP_TRY(hipStreamWaitEvent(b->stream2, b->out_done, 0));
+    b->out_pending = false;
   }
   {
     Scope t(b, 1, b->stream2);
@@ -950,6 +963,18 @@ int kq_bank_destroy(kq_bank *b) {
       (void)hipEventDestroy(p.b);
     }
   if (b->big.err) (void)hipHostFree(b->big.err);
+  for (hipStream_t st : {b->copy_in, b->copy_out})
+    if (st) {
+      (void)hipStreamSynchronize(st);
+      (void)hipStreamDestroy(st);
+    }
+  for (int k = 0; k < 2; k++) {
+    if (b->in_stage[k]) (void)hipFree(b->in_stage[k]);
+    if (b->in_ready[k]) (void)hipEventDestroy(b->in_ready[k]);
+    if (b->in_free[k]) (void)hipEventDestroy(b->in_free[k]);
+  }
+  if (b->out_ready) (void)hipEventDestroy(b->out_ready);
+  if (b->out_done) (void)hipEventDestroy(b->out_done);
   for (int k = 0; k < kq_bank::kSlots; k++) {
     if (b->stage_host[k]) (void)hipHostFree(b->stage_host[k]);
     if (b->stage_ev[k]) (void)hipEventDestroy(b->stage_ev[k]);
@@ -1310,6 +1335,102 @@ int kq_bank_push_iq(kq_bank *b, const void *iq, size_t nsamples, int format, int
     }
   }
   b->pending += nsamples;
+  return 0;
+}
+
+namespace {
+int host_io_setup(kq_bank *b) {
+  if (b->copy_in) return 0;
+  HIP_TRY(hipStreamCreateWithFlags(&b->copy_in, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&b->copy_out, hipStreamNonBlocking));
+  for (int k = 0; k < 2; k++) {
+    HIP_TRY(hipEventCreateWithFlags(&b->in_ready[k], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&b->in_free[k], hipEventDisableTiming));
+  }
+  HIP_TRY(hipEventCreateWithFlags(&b->out_ready, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&b->out_done, hipEventDisableTiming));
+  return 0;
+}
+// block completion bookkeeping for the IF-power rule (radio.c:140-146 against radio.c:94-98)
+void note_pushed(kq_bank *b, size_t nsamples, unsigned char zero) {
+  size_t fill = b->pending % b->g.L, left = nsamples;
+  while (left) {
+    size_t const take = std::min(left, (size_t)b->g.L - fill);
+    fill += take;
+    left -= take;
+    if (fill == (size_t)b->g.L) {
+      b->zero_tail.push_back(zero);
+      fill = 0;
+    }
+  }
+  b->pending += nsamples;
+}
+}  // namespace
+
+int kq_bank_push_iq_async(kq_bank *b, const void *iq, size_t nsamples, int format) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  if (!b || (!iq && nsamples)) {
+    set_err("NULL argument");
+    return -1;
+  }
+  if (format < KQ_IQ_CF32 || format > KQ_IQ_S8) {
+    set_err("unknown I/Q format %d", format);
+    return -1;
+  }
+  kq::Geom const &g = b->g;
+  size_t const used = (size_t)(g.M - 1) + b->pending;
+  if (used + nsamples > b->ring_cap) {
+    set_err("ring overflow: %zu pending + %zu pushed > %zu", b->pending, nsamples, b->ring_cap - (g.M - 1));
+    return -1;
+  }
+  if (nsamples == 0) return 0;
+  if (host_io_setup(b)) return -1;
+  size_t const bps = format == KQ_IQ_CF32 ? 8 : format == KQ_IQ_S16 ? 4 : 2;
+  int const k = b->in_next;
+  b->in_next ^= 1;
+  if (b->in_stage_cap[k] < nsamples * bps) {
+    HIP_TRY(hipStreamSynchronize(b->copy_in));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->in_stage[k]) (void)hipFree(b->in_stage[k]);
+    b->in_stage_cap[k] = nsamples * bps;
+    HIP_TRY(hipMalloc(&b->in_stage[k], b->in_stage_cap[k]));
+  }
+  HIP_TRY(hipStreamWaitEvent(b->copy_in, b->in_free[k], 0));  // the conversion kernel that last read this buffer
+  HIP_TRY(hipMemcpyAsync(b->in_stage[k], iq, nsamples * bps, hipMemcpyHostToDevice, b->copy_in));
+  HIP_TRY(hipEventRecord(b->in_ready[k], b->copy_in));
+  HIP_TRY(hipStreamWaitEvent(b->stream, b->in_ready[k], 0));
+  {
+    Scope t(b, 2, b->stream);
+    kq::launch_ingest(b->stream, b->in_stage[k], format, b->ring[b->cur] + used, nsamples, b->cfg.gain_factor);
+  }
+  HIP_TRY(hipEventRecord(b->in_free[k], b->stream));
+  note_pushed(b, nsamples, 0);
+  return 0;
+}
+
+int kq_bank_pull_planes_async(kq_bank *b, float *audio, kq_chan_status *status) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  if (!b || b->calls == 0) {
+    set_err("nothing processed yet");
+    return -1;
+  }
+  if (host_io_setup(b)) return -1;
+  size_t const n = b->chans.size() * (size_t)b->g.max_blocks;
+  HIP_TRY(hipEventRecord(b->out_ready, b->stream2));  // behind the last call's demodulators
+  HIP_TRY(hipStreamWaitEvent(b->copy_out, b->out_ready, 0));
+  if (audio)
+    HIP_TRY(hipMemcpyAsync(audio, b->pl.audio, n * 2 * (size_t)b->g.olen * sizeof(float), hipMemcpyDeviceToHost, b->copy_out));
+  if (status) HIP_TRY(hipMemcpyAsync(status, b->pl.status, n * sizeof(kq_chan_status), hipMemcpyDeviceToHost, b->copy_out));
+  HIP_TRY(hipEventRecord(b->out_done, b->copy_out));
+  b->out_pending = true;
+  return 0;
+}
+
+int kq_bank_host_io_wait(kq_bank *b) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  if (!b) return -1;
+  if (b->copy_in) HIP_TRY(hipStreamSynchronize(b->copy_in));
+  if (b->copy_out) HIP_TRY(hipStreamSynchronize(b->copy_out));
   return 0;
 }
 

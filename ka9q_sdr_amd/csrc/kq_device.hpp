@@ -120,6 +120,15 @@ void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nbl
 void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                         const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
                         const int *chan_list);
+// N = 65536 on the same kernel: four sibling workgroups per channel-block, each the 16384-point transform of one residue
+// class of bins (k = 4 q + r); what they share travels through these planes (kq_full16k.hip)
+struct Big64 {
+  unsigned long long *sync;  // [C][max_blocks][3][4] tagged words: first-pass sums of compute_n0 handed between the siblings
+  float2 *n0part;            // [C][max_blocks][4] second pass: (sum, count) per sub-transform
+  float2 *xs;                // [C][max_blocks][N_dec] the bins the slave reads, index k mod N_dec
+  int *err;                  // set when a sibling's word never arrived
+  unsigned epoch;            // tag of this launch
+};
 // register-resident N = 16384 variant of the same (kq_full16k.hip)
 bool full16k_supported(const Geom &g);
 // where k_filter_full16k leaves the spectrum: thread t holds bins full16k_bin(t) + kFull16kHalf * half + 1024 * k3
@@ -131,17 +140,8 @@ constexpr int full16k_bin(int t) { return (t >> 5) + 32 * (t & 31); }
 // the plain variant loads 16 bytes at a time; null: it reads `window`
 void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
-                           const int *chan_list, bool plain, const float2 *window_paired);
+                           const int *chan_list, bool plain, const float2 *window_paired, const Big64 &big);
 bool full16k_paired_supported(const Geom &g);
-// N = 65536 on the same kernel: four sibling workgroups per channel-block, each the 16384-point transform of one residue
-// class of bins (k = 4 q + r); what they share travels through these planes (kq_full16k.hip)
-struct Big64 {
-  unsigned long long *sync;  // [C][max_blocks][3][4] tagged words: first-pass sums of compute_n0 handed between the siblings
-  float2 *n0part;            // [C][max_blocks][4] second pass: (sum, count) per sub-transform
-  float2 *xs;                // [C][max_blocks][N_dec] the bins the slave reads, index k mod N_dec
-  int *err;                  // set when a sibling's word never arrived
-  unsigned epoch;            // tag of this launch
-};
 bool full64k_supported(const Geom &g);
 // plain: no channel of the launch was retuned since the last call and every sweep rate is inside full64k_sweep_limit();
 // swept: some channel sweeps

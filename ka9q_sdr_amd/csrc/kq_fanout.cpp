@@ -30,6 +30,8 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int *) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   bool ok = false;
 };
 
@@ -47,6 +49,8 @@ Rccl &rccl() {
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
     r.Broadcast = (decltype(r.Broadcast))dlsym(r.handle, "ncclBroadcast");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+    r.GetVersion = (decltype(r.GetVersion))dlsym(r.handle, "ncclGetVersion");
+    r.CommCount = (decltype(r.CommCount))dlsym(r.handle, "ncclCommCount");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Broadcast && r.GetErrorString;
   });
   return r;
@@ -62,7 +66,29 @@ struct kq_fanout {
   float2 *buf[2] = {nullptr, nullptr};
   hipEvent_t ready[2] = {nullptr, nullptr}, freed[2] = {nullptr, nullptr};
   size_t count[2] = {0, 0};
+  // broadcast timing: events around ncclBroadcast on the side stream, read back when the slot is posted again
+  hipEvent_t t0[2] = {nullptr, nullptr}, t1[2] = {nullptr, nullptr};
+  bool timed[2] = {false, false};
+  double bcast_ms = 0;
+  unsigned long long bcasts = 0;
 };
+
+namespace {
+int fail(const char *what, hipError_t e) {
+  kq_internal_set_error("%s: %s", what, hipGetErrorString(e));
+  return -1;
+}
+// collects the slot's last broadcast time if it has completed (never waits)
+void harvest(kq_fanout *f, int slot) {
+  if (!f->timed[slot]) return;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, f->t0[slot], f->t1[slot]) == hipSuccess) {
+    f->bcast_ms += ms;
+    f->bcasts++;
+  }
+  f->timed[slot] = false;
+}
+}  // namespace
 
 extern "C" {
 
@@ -107,29 +133,37 @@ kq_fanout *kq_fanout_create(int device, int rank, int world, int root, const voi
   f->world = world;
   f->root = root;
   f->max_samples = max_samples;
-  bool ok = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking) == hipSuccess;
-  for (int i = 0; i < 2 && ok; i++) {
-    ok = hipMalloc((void **)&f->buf[i], max_samples * sizeof(float2)) == hipSuccess &&
-         hipEventCreateWithFlags(&f->ready[i], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&f->freed[i], hipEventDisableTiming) == hipSuccess;
+  // every failure names its step (kq_last_error); nothing below is overwritten by a later, vaguer message
+  hipError_t e = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking);
+  const char *step = "kq_fanout_create: hipStreamCreate";
+  for (int i = 0; i < 2 && e == hipSuccess; i++) {
+    step = "kq_fanout_create: slot allocation (hipMalloc / hipEventCreate)";
+    e = hipMalloc((void **)&f->buf[i], max_samples * sizeof(float2));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ready[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->freed[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&f->t0[i]);
+    if (e == hipSuccess) e = hipEventCreate(&f->t1[i]);
   }
+  bool ok = e == hipSuccess;
+  if (!ok) fail(step, e);
   if (ok && (world > 1 || id128 != nullptr)) {  // with an id even a world of one goes through RCCL (tests)
     Rccl &r = rccl();
     if (!r.ok) {
-      kq_internal_set_error("librccl not available");
+      kq_internal_set_error("kq_fanout_create: librccl not available");
       ok = false;
     } else {
       ncclUniqueId id;
       memcpy(&id, id128, sizeof id);
-      ncclResult_t const e = r.CommInitRank(&f->comm, world, id, rank);
-      if (e != ncclSuccess) {
-        kq_internal_set_error("ncclCommInitRank: %s", r.GetErrorString(e));
+      // collective: returns once every rank of the world has called it with the same id
+      ncclResult_t const ne = r.CommInitRank(&f->comm, world, id, rank);
+      if (ne != ncclSuccess) {
+        kq_internal_set_error("kq_fanout_create: ncclCommInitRank(rank %d of %d): %s", rank, world, r.GetErrorString(ne));
+        f->comm = nullptr;
         ok = false;
       }
     }
   }
   if (!ok) {
-    if (f->comm == nullptr && world == 1) kq_internal_set_error("kq_fanout_create: device allocation failed");
     kq_fanout_destroy(f);
     return nullptr;
   }
@@ -145,6 +179,8 @@ int kq_fanout_destroy(kq_fanout *f) {
     if (f->buf[i]) (void)hipFree(f->buf[i]);
     if (f->ready[i]) (void)hipEventDestroy(f->ready[i]);
     if (f->freed[i]) (void)hipEventDestroy(f->freed[i]);
+    if (f->t0[i]) (void)hipEventDestroy(f->t0[i]);
+    if (f->t1[i]) (void)hipEventDestroy(f->t1[i]);
   }
   if (f->side) (void)hipStreamDestroy(f->side);
   delete f;
@@ -157,26 +193,27 @@ int kq_fanout_post(kq_fanout *f, int slot, const void *src, size_t nsamples, int
     return -1;
   }
   kq::DeviceScope scope(f->device);
+  harvest(f, slot);
   // the slot's previous consumer (kq_fanout_release) must be done before it is overwritten
-  if (hipStreamWaitEvent(f->side, f->freed[slot], 0) != hipSuccess) return -1;
+  if (hipError_t e = hipStreamWaitEvent(f->side, f->freed[slot], 0); e != hipSuccess) return fail("kq_fanout_post: hipStreamWaitEvent", e);
   if (f->rank == f->root) {
     hipMemcpyKind const kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (src != f->buf[slot] &&
-        hipMemcpyAsync(f->buf[slot], src, nsamples * sizeof(float2), kind, f->side) != hipSuccess) {
-      kq_internal_set_error("kq_fanout_post: copy into the slot failed");
-      return -1;
-    }
+    if (src != f->buf[slot])
+      if (hipError_t e = hipMemcpyAsync(f->buf[slot], src, nsamples * sizeof(float2), kind, f->side); e != hipSuccess)
+        return fail("kq_fanout_post: copy into the slot", e);
   }
   if (f->comm) {
+    (void)hipEventRecord(f->t0[slot], f->side);
     ncclResult_t const e =
         rccl().Broadcast(f->buf[slot], f->buf[slot], 2 * nsamples, ncclFloat32, f->root, f->comm, f->side);
     if (e != ncclSuccess) {
-      kq_internal_set_error("ncclBroadcast: %s", rccl().GetErrorString(e));
+      kq_internal_set_error("kq_fanout_post: ncclBroadcast: %s", rccl().GetErrorString(e));
       return -1;
     }
+    f->timed[slot] = hipEventRecord(f->t1[slot], f->side) == hipSuccess;
   }
   f->count[slot] = nsamples;
-  if (hipEventRecord(f->ready[slot], f->side) != hipSuccess) return -1;
+  if (hipError_t e = hipEventRecord(f->ready[slot], f->side); e != hipSuccess) return fail("kq_fanout_post: hipEventRecord", e);
   return 0;
 }
 
@@ -186,7 +223,10 @@ const void *kq_fanout_acquire(kq_fanout *f, int slot, void *consumer_stream, siz
     return nullptr;
   }
   kq::DeviceScope scope(f->device);
-  if (hipStreamWaitEvent((hipStream_t)consumer_stream, f->ready[slot], 0) != hipSuccess) return nullptr;
+  if (hipError_t e = hipStreamWaitEvent((hipStream_t)consumer_stream, f->ready[slot], 0); e != hipSuccess) {
+    fail("kq_fanout_acquire: hipStreamWaitEvent", e);
+    return nullptr;
+  }
   if (nsamples) *nsamples = f->count[slot];
   return f->buf[slot];
 }
@@ -194,7 +234,29 @@ const void *kq_fanout_acquire(kq_fanout *f, int slot, void *consumer_stream, siz
 int kq_fanout_release(kq_fanout *f, int slot, void *consumer_stream) {
   if (!f || slot < 0 || slot > 1) return -1;
   kq::DeviceScope scope(f->device);
-  return hipEventRecord(f->freed[slot], (hipStream_t)consumer_stream) == hipSuccess ? 0 : -1;
+  if (hipError_t e = hipEventRecord(f->freed[slot], (hipStream_t)consumer_stream); e != hipSuccess)
+    return fail("kq_fanout_release: hipEventRecord", e);
+  return 0;
+}
+
+int kq_fanout_stats(kq_fanout *f, kq_fanout_info *out) {
+  if (!f || !out) return -1;
+  kq::DeviceScope scope(f->device);
+  (void)hipStreamSynchronize(f->side);
+  harvest(f, 0);
+  harvest(f, 1);
+  memset(out, 0, sizeof *out);
+  out->world = f->world;
+  out->rank = f->rank;
+  out->rccl_ranks = 0;
+  if (f->comm) {
+    Rccl &r = rccl();
+    if (r.CommCount) (void)r.CommCount(f->comm, &out->rccl_ranks);  // what RCCL itself holds the world to be
+    if (r.GetVersion) (void)r.GetVersion(&out->rccl_version);
+  }
+  out->broadcasts = f->bcasts;
+  out->broadcast_ms = f->bcast_ms;
+  return 0;
 }
 
 }  // extern "C"

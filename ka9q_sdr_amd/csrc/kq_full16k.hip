@@ -856,7 +856,7 @@ double full64k_sweep_limit() { return kSweepLimit64k; }
 
 void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
-                           const int *chan_list, bool plain, const float2 *window_paired) {
+                           const int *chan_list, bool plain, const float2 *window_paired, const Big64 &big) {
   size_t const lds_bytes = (size_t)kXchElems * sizeof(float2);
   const float2 *tab = twiddle_tables();
   if (!tab) {  // cannot happen short of an allocation failure: fall back to the LDS kernel rather than fail the block
@@ -869,7 +869,7 @@ void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
   auto go = [&](auto kernel) {
     ensure_dynamic_lds((const void *)kernel, lds_bytes);
     hipLaunchKernelGGL(kernel, dim3(nchan, nblocks), dim3(kT), lds_bytes, s, g, ch, pl, paired ? window_paired : window, tw, tab,
-                       spec_dump, spec_ch, chan_list, Big64{});
+                       spec_dump, spec_ch, chan_list, big);
   };
   auto pick = [&](auto n0c, auto dumpc) {
     constexpr bool kN0 = decltype(n0c)::value, kDump = decltype(dumpc)::value;

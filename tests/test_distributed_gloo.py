@@ -107,3 +107,52 @@ def test_sharded_fanout_world4_uneven_shards(tmp_path):
             assert lib.kq_shard_range(tot, w, rank, C.byref(f), C.byref(c)) == 0
             assert (f.value, c.value) == shard_range(tot, w, rank)
     assert lib.kq_shard_range(4, 2, 2, C.byref(f), C.byref(c)) == -1
+
+
+def _id_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here)]
+    import torch.distributed as dist
+    from ka9q_sdr_amd.shard import ID_BYTES, share_unique_id
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def make_id():                      # stands for kq_fanout_unique_id: must run on the root rank only
+        calls.append(rank)
+        return bytes((7 * i + 3) & 0xFF for i in range(ID_BYTES))
+
+    ident = share_unique_id(make_id, rank, 0, dist, "cpu")
+    with open(os.path.join(out_dir, "id%d.bin" % rank), "wb") as f:
+        f.write(ident)
+    with open(os.path.join(out_dir, "calls%d.txt" % rank), "w") as f:
+        f.write(",".join(map(str, calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unique_id_hand_off_world3(tmp_path):
+    """bench.py --gpus N: rank 0 makes the fan-out's 128-byte identifier (kq_fanout_unique_id) and every rank needs the
+    same bytes before the collective kq_fanout_create -- share_unique_id carries them over the process group."""
+    import torch.multiprocessing as mp
+    from ka9q_sdr_amd.shard import ID_BYTES, share_unique_id
+    port = 29500 + ((os.getpid() + 977) % 2000)
+    mp.spawn(_id_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    want = bytes((7 * i + 3) & 0xFF for i in range(ID_BYTES))
+    for r in range(3):
+        assert (tmp_path / ("id%d.bin" % r)).read_bytes() == want
+        assert (tmp_path / ("calls%d.txt" % r)).read_text() == ("0" if r == 0 else "")
+    # one rank, no process group: the maker is called directly
+    assert share_unique_id(lambda: want, 0) == want
+
+
+def test_c_fanout_wrapper_refuses_without_a_device():
+    """CFanout (the ctypes front of kq_fanout_*) fails loudly where there is no GPU: no silent fallback to the twin."""
+    import ka9q_sdr_amd as kq
+    from ka9q_sdr_amd.shard import CFanout
+    lib = kq.load_library()
+    if kq.device_count() > 0:
+        pytest.skip("a GPU is present: covered by tests/test_gpu_fanout.py")
+    with pytest.raises(RuntimeError):
+        CFanout(lib, 0, 0, 1, 4096)

@@ -70,3 +70,80 @@ def test_fanout_of_one_through_rccl_feeds_a_bank(gpu):
         assert rel_rms(np.concatenate(got[c]), np.concatenate(want[c][0])) < 1e-5
     assert lib.kq_fanout_destroy(f) == 0
     bank.close()
+
+
+def test_c_fanout_wrapper_stats_and_rccl_view(gpu):
+    """ka9q_sdr_amd.shard.CFanout -- what bench.py --gpus N drives -- over a communicator of one: RCCL's own count of
+    the world (ncclCommCount), its version, and the broadcasts timed on the side stream."""
+    from ka9q_sdr_amd.shard import CFanout, share_unique_id
+    lib = kq.load_library()
+
+    def make_id():
+        buf = C.create_string_buffer(128)
+        assert lib.kq_fanout_unique_id(buf) == 0, lib.kq_last_error()
+        return buf.raw
+
+    ident = share_unique_id(make_id, 0)
+    n = 4096
+    fan = CFanout(lib, 0, 0, 1, n, ident)
+    stream = torch.cuda.Stream()
+    src = torch.arange(2 * n, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for i in range(2):
+        fan.fill(i, src.data_ptr())
+    for k in range(6):
+        i = k & 1
+        p = fan.acquire(i, stream.cuda_stream)
+        assert p
+        fan.release(i, stream.cuda_stream)
+        fan.post(i)
+    st = fan.stats()
+    assert st["world"] == 1 and st["rccl_ranks"] == 1 and st["rccl_version"] > 0, st
+    assert st["broadcasts"] >= 6 and st["broadcast_ms"] > 0, st
+    # the slot holds what the root put there
+    back = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(ctypes.c_void_p(back.data_ptr()), ctypes.c_void_p(fan.ptr[0]), ctypes.c_size_t(8 * n), 3) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(back, src)
+    fan.close()
+
+
+def test_streaming_host_io_equals_the_blocking_calls(gpu):
+    """kq_bank_push_iq_async / kq_bank_pull_planes_async (pinned host memory, copy streams) against kq_bank_push_iq /
+    kq_bank_pull_audio / kq_bank_pull_status on the same input: same audio, same status, call after call."""
+    g = dict(samprate=192000, L=512, M=513, D=4)
+    fs, L, M = g["samprate"], g["L"], g["M"]
+    plan = wl.channel_plan("cfg1", 3)
+    plan[1] = dict(plan[1], demod="am", low=-5000.0, high=5000.0, recovery_rate=50.0)
+    nblocks, ncalls = 4, 5
+    iq = wl.make_iq(fs, ncalls * nblocks * L, seed=91)
+    olen = L // g["D"]
+    ref = kq.Bank(fs, L, M, g["D"], len(plan), nblocks, compute_n0=True)
+    bank = kq.Bank(fs, L, M, g["D"], len(plan), nblocks, compute_n0=True)
+    for p in plan:
+        ref.add_channel(bank_cfg(p))
+        bank.add_channel(bank_cfg(p))
+    pinned = torch.from_numpy(iq.copy()).pin_memory()
+    audio = [torch.zeros(len(plan) * nblocks * 2 * olen, dtype=torch.float32).pin_memory() for _ in range(2)]
+    status = [torch.zeros(len(plan) * nblocks * C.sizeof(kq.ChanStatus), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    for k in range(ncalls):
+        # queue call k (input copy, kernels, output copy) without waiting for call k - 1's copies
+        bank.push_iq_async(pinned.data_ptr() + 8 * k * nblocks * L, nblocks * L)
+        assert bank.process() == nblocks
+        bank.pull_planes_async(audio[k & 1].data_ptr(), status[k & 1].data_ptr())
+        ref.push_iq(iq[k * nblocks * L:(k + 1) * nblocks * L])
+        assert ref.process() == nblocks
+        bank.host_io_wait()
+        a = audio[k & 1].numpy().reshape(len(plan), nblocks, 2 * olen)
+        st = np.frombuffer(status[k & 1].numpy().tobytes(), dtype=np.dtype(kq.ChanStatus)).reshape(len(plan), nblocks)
+        for c in range(len(plan)):
+            for b in range(nblocks):
+                want = ref.audio(c, b)
+                assert np.array_equal(a[c, b, :len(want)], want), (k, c, b)
+                ws = ref.status(c, b)
+                assert st[c, b]["nout"] == ws["nout"] and st[c, b]["squelch_count"] == ws["squelch_count"]
+                assert st[c, b]["bb_power"] == np.float32(ws["bb_power"]) and st[c, b]["n0"] == np.float32(ws["n0"])
+    ref.close()
+    bank.close()

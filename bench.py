@@ -298,15 +298,16 @@ def main():
         import ctypes
         olen = L // D
         iq_pin = torch.from_numpy(np.ascontiguousarray(iq_host[M - 1:M - 1 + B * L])).pin_memory()
-        audio_pin = torch.empty(C * B * 2 * olen, dtype=torch.float32).pin_memory()
+        audio_pin = torch.zeros(C * B * 2 * olen, dtype=torch.float32).pin_memory()
         status_pin = torch.empty(C * B * ctypes.sizeof(kq.ChanStatus), dtype=torch.uint8).pin_memory()
 
-        def io_step():
-            bank.push_iq_async(iq_pin.data_ptr(), B * L)
+        def io_step():     # the call order include/ka9q_hip.h asks for: the next batch is on its way before this one's planes leave
             assert bank.process() == B
+            bank.push_iq_async(iq_pin.data_ptr(), B * L)
             bank.pull_planes_async(audio_pin.data_ptr(), status_pin.data_ptr())
 
         n_io = max(2, min(50, a.steps))
+        bank.push_iq_async(iq_pin.data_ptr(), B * L)
         for k in range(20):
             io_step()
         bank.host_io_wait()
@@ -317,15 +318,17 @@ def main():
         bank.host_io_wait()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t3) / n_io
-        h2d, d2h = iq_pin.numel() * 8, audio_pin.numel() * 4 + status_pin.numel()
+        # of each channel-block's 2 olen floats the nout that hold samples travel (mono olen, stereo 2 olen), plus the status plane
+        h2d = iq_pin.numel() * 8
+        d2h = sum((2 if p.get("channels", 1) == 2 else 1) * olen * 4 for p in plan) * B + status_pin.numel()
         host_io = {"value": round(C * B * L / dt / 1e6, 1), "unit": "Msamples/s (channel-samples)",
                    "ms_per_step": round(dt * 1e3, 4), "steps": n_io,
                    "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": d2h,
                    "h2d_GBps": round(h2d / dt / 1e9, 2), "d2h_GBps": round(d2h / dt / 1e9, 2),
                    "audio_checksum": float(audio_pin[:C * B * 2 * olen:997].abs().sum()),
                    "note": "input from pinned host memory (kq_bank_push_iq_async + kq_bank_process, ring path with its "
-                           "history copy), audio [C][B][2 olen] float + status [C][B] planes to pinned host memory every "
-                           "step (kq_bank_pull_planes_async); copies on the bank's copy streams, overlapped with the kernels"}
+                           "history copy), audio (nout floats per channel-block) + status [C][B] planes to pinned host memory "
+                           "every step (kq_bank_pull_planes_async); copies on the bank's copy streams, overlapped with the kernels"}
 
     # Secondary row (1 GPU only): the same workload with compute_n0 switched the other way.  The headline computes
     # the noise estimate of radio.c:383-425 on every channel-block, as the reference's demod threads do, which needs

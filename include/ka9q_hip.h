@@ -204,9 +204,13 @@ int kq_bank_sync(kq_bank *bank);
  *                             stream.  `iq` must stay unchanged until kq_bank_host_io_wait or until two more pushes
  *                             have been queued.
  *  kq_bank_pull_planes_async: queues the copy of the last call's outputs -- audio [channels][max_blocks][2 * olen] float
- *                             and status [channels][max_blocks] (either may be NULL) -- on the output copy stream;
+ *                             (of each channel-block the first status.nout floats are written, the rest of its row is
+ *                             left as it was) and status [channels][max_blocks] (either may be NULL) -- on the output copy stream;
  *                             the next call's demodulators wait for it on the device before they overwrite the planes.
- *  kq_bank_host_io_wait:      blocks until every queued copy has landed. */
+ *  kq_bank_host_io_wait:      blocks until every queued copy has landed.
+ * Call order for full overlap: process batch k, push batch k+1, then pull the planes of batch k --
+ *     push(0); for k: { process(); push(k + 1); pull_planes(k); }
+ * an input copy queued behind an output copy may share its hardware queue and then waits with it for the demodulators. */
 int kq_bank_push_iq_async(kq_bank *bank, const void *iq_pinned, size_t nsamples, int format);
 int kq_bank_pull_planes_async(kq_bank *bank, float *audio_pinned, kq_chan_status *status_pinned);
 int kq_bank_host_io_wait(kq_bank *bank);

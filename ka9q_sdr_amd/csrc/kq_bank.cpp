@@ -1341,6 +1341,12 @@ int kq_bank_push_iq(kq_bank *b, const void *iq, size_t nsamples, int format, int
 namespace {
 int host_io_setup(kq_bank *b) {
   if (b->copy_in) return 0;
+  // Streams share a handful of hardware queues, handed out in creation order, and a queue runs in order: the two copy
+  // streams can land on one queue.  Then an input copy queued BEHIND an output copy waits with it for that call's
+  // demodulators, and every step runs input copy, kernels and output copy one after the other (rocprofv3 timeline,
+  // tools/hostio_trace.sh) -- hence the call order the header asks for: push batch k+1 before pulling the planes of
+  // batch k.  (Streams of different priority come from different queue pools, but with a high-priority output stream
+  // the filter kernel itself ran 40 % slower for the whole step, measured.)
   HIP_TRY(hipStreamCreateWithFlags(&b->copy_in, hipStreamNonBlocking));
   HIP_TRY(hipStreamCreateWithFlags(&b->copy_out, hipStreamNonBlocking));
   for (int k = 0; k < 2; k++) {
@@ -1418,9 +1424,16 @@ int kq_bank_pull_planes_async(kq_bank *b, float *audio, kq_chan_status *status) 
   size_t const n = b->chans.size() * (size_t)b->g.max_blocks;
   HIP_TRY(hipEventRecord(b->out_ready, b->stream2));  // behind the last call's demodulators
   HIP_TRY(hipStreamWaitEvent(b->copy_out, b->out_ready, 0));
-  if (audio)
+  // of every channel-block's 2 * olen floats only the status.nout that hold samples travel (mono: half): the kernel
+  // moves 16 bytes per lane, so olen must be a multiple of 4 for it -- other geometries take the plain copy
+  size_t const sbytes = n * sizeof(kq_chan_status), s16 = sbytes & ~(size_t)15;
+  bool const rows_ok = b->g.olen % 4 == 0;
+  kq::launch_copy_to_host(b->copy_out, b->pl.audio, rows_ok ? audio : nullptr, 2 * b->g.olen, b->pl.status, status, n);
+  LAUNCH_CHECK("plane copy");
+  if (audio && !rows_ok)
     HIP_TRY(hipMemcpyAsync(audio, b->pl.audio, n * 2 * (size_t)b->g.olen * sizeof(float), hipMemcpyDeviceToHost, b->copy_out));
-  if (status) HIP_TRY(hipMemcpyAsync(status, b->pl.status, n * sizeof(kq_chan_status), hipMemcpyDeviceToHost, b->copy_out));
+  if (status && sbytes > s16)
+    HIP_TRY(hipMemcpyAsync((char *)status + s16, (const char *)b->pl.status + s16, sbytes - s16, hipMemcpyDeviceToHost, b->copy_out));
   HIP_TRY(hipEventRecord(b->out_done, b->copy_out));
   b->out_pending = true;
   return 0;

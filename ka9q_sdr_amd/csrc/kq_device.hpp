@@ -111,6 +111,10 @@ struct DeviceScope {
 void ensure_dynamic_lds(const void *kernel, size_t bytes);
 
 // launchers (kq_kernels.hip)
+// output planes to pinned host memory (a null host pointer skips its plane): of every audio row of `row` floats the
+// first status.nout, and the status plane up to its last whole 16 bytes
+void launch_copy_to_host(hipStream_t s, const float *audio, float *haudio, int row, const kq_chan_status *status, void *hstatus,
+                         size_t rows);
 void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size_t nsamples, float scale);
 // `update` points into the device copy of the parameter block that the first kernel makes from `params_host`
 // (pinned, device-visible) into `params_dev`

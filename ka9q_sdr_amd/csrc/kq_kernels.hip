@@ -144,6 +144,42 @@ void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nbl
   hipLaunchKernelGGL(k_block_energy_iir, dim3(1), dim3(64), 0, s, if_power, update, nblocks, L, energy_state, if_power);
 }
 
+// Device planes -> pinned host memory, 16 bytes per thread and trip, by a handful of workgroups that stay resident
+// (kq_bank_pull_planes_async).  hipMemcpyAsync was measured first: with the filter kernel of the next call filling
+// every CU the runtime served these device-to-host copies with its own blit kernel, whose workgroups queued behind the
+// filter's -- 1.1 ms for 17 MB, and the filter kernel disturbed (rocprofv3 --memory-copy-trace: __amd_rocclr_copyBuffer,
+// no SDMA transfer).  These few workgroups are launched the moment the demodulators finish, take their slots before the
+// next filter launch fills the rest, and stream at the link's rate (the stores are posted writes over PCIe).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// audio: rows of `row` floats per channel-block of which the first status.nout hold samples (mono: half of a row) -- only
+// those travel; 16 lanes take one row, 16 bytes per lane and trip.  status: the whole plane.  rows = channels * max_blocks.
+__global__ void __launch_bounds__(256) k_copy_to_host(const float *__restrict__ audio, float *__restrict__ haudio, int row,
+                                                      const kq_chan_status *__restrict__ status, u32x4 *__restrict__ hstatus,
+                                                      size_t rows, size_t status16) {
+  size_t const stride = (size_t)gridDim.x * blockDim.x;
+  size_t const tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (haudio) {
+    int const sub = (int)(tid & 15);
+    for (size_t r = tid >> 4; r < rows; r += stride >> 4) {
+      int const n = min(status[r].nout, row);
+      const float *src = audio + r * row;
+      float *dst = haudio + r * row;
+      for (int i = 4 * sub; i < n; i += 64) {  // row and nout are multiples of 4 here (the caller checks), rows 16-byte aligned
+        u32x4 const v = *reinterpret_cast<const u32x4 *>(src + i);
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst + i));
+      }
+    }
+  }
+  const u32x4 *sp = reinterpret_cast<const u32x4 *>(status);
+  if (hstatus)
+    for (size_t i = tid; i < status16; i += stride) __builtin_nontemporal_store(sp[i], hstatus + i);
+}
+void launch_copy_to_host(hipStream_t s, const float *audio, float *haudio, int row, const kq_chan_status *status, void *hstatus,
+                         size_t rows) {
+  hipLaunchKernelGGL(k_copy_to_host, dim3(32), dim3(256), 0, s, audio, haudio, row, status, (u32x4 *)hstatus, rows,
+                     rows * sizeof(kq_chan_status) / 16);
+}
+
 // ---------------------------------------------------------------- full-FFT pre-detection filter
 // grid (channel, block); dynamic LDS = N float2.
 __global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,

@@ -166,9 +166,15 @@ int kq_bank_push_iq(kq_bank *bank, const void *iq, size_t nsamples, int format, 
  * case the lost samples are injected as zeros with the LOs kept running (kq_bank_push_zeros) before the payload is
  * converted and appended (kq_bank_push_iq).  Packets are taken in arrival order; the reference's small
  * sort-by-sequence queue (main.c:347-357) stays with the caller.
- * Returns the number of samples appended (zeros + payload), 0 for an ignored or dropped datagram, -1 on error, and
- * -2 when the ring has no room for the packet's zero fill + payload right now: nothing has been consumed then --
- * sequence, timestamp and counters are untouched -- so run kq_bank_process and hand the same datagram in again. */
+ * Returns the number of samples appended by this call (zeros + payload), 0 for an ignored or dropped datagram, -1 on
+ * error, and -2 when the ring has no room right now: run kq_bank_process and hand the SAME datagram in again, until it
+ * is taken --   while ((n = kq_bank_push_rtp(b, pkt, len)) == -2) kq_bank_process(b);
+ * The ring holds max_blocks * L samples plus L - 1 of slack, so a partly filled block never stands in the way of a packet
+ * that fits the ring as such.  With whole blocks waiting, -2 leaves sequence, timestamp and counters untouched.  With
+ * none waiting the gap's zero fill (up to 192000 samples, radio.c:79-100) is itself larger than the ring: each call then
+ * puts in as many zeros as fit and moves the timestamp past them before it returns -2, so every round brings the gap a
+ * ring closer to its end, sample for sample as the reference fills it; the packet is counted once.  A payload larger
+ * than the whole ring is an error (-1; its samples become a gap that the next packet fills with zeros). */
 int kq_bank_push_rtp(kq_bank *bank, const void *datagram, size_t size);
 typedef struct kq_rtp_counters {   /* struct rtp_state (multicast.h:41-50) + demod->input.samples */
   uint32_t ssrc;

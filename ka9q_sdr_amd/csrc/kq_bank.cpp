@@ -129,6 +129,9 @@ struct kq_bank {
   // front-end packet bookkeeping (struct rtp_state + demod->input.samples)
   kq_rtp_counters rtp{};
   bool rtp_init = false;
+  bool rtp_retry = false;          // the last datagram was sent back with -2: the same one comes again
+  uint16_t rtp_retry_seq = 0;
+  uint32_t rtp_retry_ts = 0;
   hipEvent_t ev_filter_done = nullptr;
   hipEvent_t ev_demod_done[2] = {nullptr, nullptr};
   kq::Planes pl2[2];
@@ -797,7 +800,9 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   }
 
   size_t const C = cfg->max_channels, B = cfg->max_blocks;
-  b->ring_cap = (size_t)(g.M - 1) + B * (size_t)g.L;
+  // max_blocks blocks plus L - 1 samples of slack: a partly filled block never stands in the way of a batch that fits the
+  // ring as such (kq_bank_push_rtp); kq_bank_process still takes at most max_blocks blocks per call
+  b->ring_cap = (size_t)(g.M - 1) + B * (size_t)g.L + (size_t)(g.L - 1);
   int rc = 0;
   rc |= dev_alloc(&b->ring[0], b->ring_cap);
   rc |= dev_alloc(&b->ring[1], b->ring_cap);
@@ -1475,6 +1480,8 @@ int kq_bank_push_zeros(kq_bank *b, size_t nsamples) {
   return 0;
 }
 
+static inline size_t g_M1(const kq_bank *b) { return (size_t)(b->g.M - 1); }
+
 int kq_bank_push_rtp(kq_bank *b, const void *datagram, size_t size) {
   kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || !datagram) {
@@ -1511,22 +1518,6 @@ int kq_bank_push_rtp(kq_bank *b, const void *datagram, size_t size) {
 
   // proc_samples + rtp_process (radio.c:73-104, multicast.c:305-340)
   kq_rtp_counters &r = b->rtp;
-  {
-    // Room for the whole packet -- a timestamp gap's zero fill (radio.c:83-100, at most 192000 samples) plus its
-    // payload -- is checked BEFORE the sequence / timestamp state moves: a caller told -2 runs kq_bank_process and
-    // hands the same datagram in again, and it is then neither a duplicate nor short of its zeros.
-    bool const fresh = !b->rtp_init || ssrc != r.ssrc;
-    short const sstep = fresh ? 0 : (short)(seq - r.next_seq);
-    int const tstep = fresh ? 0 : (int)(ts - r.next_timestamp);
-    if (sstep >= 0 && tstep >= 0 && tstep <= 192000) {
-      size_t const need = (size_t)tstep + (size_t)(sampcount > 0 ? sampcount : 0);
-      if ((size_t)(b->g.M - 1) + b->pending + need > b->ring_cap) {
-        set_err("ring full: %zu samples pending, the packet brings %zu (zero fill %d): run kq_bank_process first",
-                b->pending, need, tstep);
-        return need > b->ring_cap - (size_t)(b->g.M - 1) ? -1 : -2;  // -1: can never fit this bank's max_blocks
-      }
-    }
-  }
   if (!b->rtp_init || ssrc != r.ssrc) {
     r.samples = 0;  // radio.c:73-77 (a fresh state has ssrc 0, so the first packet lands here as well)
     r.ssrc = ssrc;
@@ -1536,19 +1527,71 @@ int kq_bank_push_rtp(kq_bank *b, const void *datagram, size_t size) {
     r.dupes = 0;
     r.drops = 0;
     b->rtp_init = true;
+    b->rtp_retry = false;
   }
-  r.packets++;
+  // A datagram handed in again after -2 is the same packet, not a new one: it is counted once.
+  bool const retry = b->rtp_retry && seq == b->rtp_retry_seq && ts == b->rtp_retry_ts;
+  b->rtp_retry = false;
   short const seq_step = (short)(seq - r.next_seq);
   if (seq_step < 0) {
+    r.packets++;
     r.dupes++;
     return 0;
   }
+  int const time_step = (int)(ts - r.next_timestamp);
+  if (time_step < 0 || time_step > 192000) {  // old samples (multicast.c:334-336) / a jump too far to fill (radio.c:79-82)
+    if (!retry) r.packets++;
+    r.drops += seq_step;
+    r.next_seq = (uint16_t)(seq + 1);
+    if (time_step >= 0) r.next_timestamp = ts + (uint32_t)sampcount;
+    return 0;
+  }
+  // Room.  The ring takes max_blocks * L samples plus L - 1 of slack, so that a partly filled block never stands in the
+  // way of a packet that fits the ring as such.  What does not fit now:
+  //  * whole blocks are waiting (pending >= L): nothing moves, -2 -- kq_bank_process frees them, then the same datagram
+  //    fits or falls under the next case;
+  //  * no whole block is waiting, so the zero fill of the gap (radio.c:83-100) is itself larger than the ring: as many
+  //    zeros as fit go in now and the timestamp moves past them, -2 -- every retry after a kq_bank_process brings the
+  //    gap a ring closer to its end, with the oscillators running through it sample by sample as in the reference;
+  //  * the gap is filled and the payload alone is larger than the ring (max_blocks * L below one packet): -1, the
+  //    sequence number moves on, the timestamp does not, so the next packet fills these samples with zeros.
+  size_t const room = b->ring_cap - (size_t)(g_M1(b)) - b->pending;
+  size_t const payload = (size_t)(sampcount > 0 ? sampcount : 0);
+  if ((size_t)time_step + payload > room) {
+    auto remember = [&]() {
+      b->rtp_retry = true;
+      b->rtp_retry_seq = seq;
+      b->rtp_retry_ts = ts;
+    };
+    if (b->pending >= (size_t)b->g.L) {  // nothing has moved: not the sequence number, not the timestamp, not a counter
+      b->rtp_retry = retry;
+      set_err("ring full: %zu samples pending, the packet brings %zu (zero fill %d): run kq_bank_process, then push it again",
+              b->pending, (size_t)time_step + payload, time_step);
+      return -2;
+    }
+    if (time_step > 0) {
+      size_t const z = std::min((size_t)time_step, room);
+      if (kq_bank_push_zeros(b, z)) return -1;
+      if (!retry) r.packets++;
+      r.samples += (int)z;
+      r.next_timestamp += (uint32_t)z;
+      r.drops += seq_step;
+      r.next_seq = seq;  // the retry is in sequence
+      remember();
+      set_err("the gap's zero fill is larger than the ring: %zu of %d samples in, run kq_bank_process, then push it again", z,
+              time_step);
+      return -2;
+    }
+    if (!retry) r.packets++;
+    r.drops += seq_step;
+    r.next_seq = (uint16_t)(seq + 1);
+    set_err("a packet of %zu samples does not fit a ring of %zu: raise max_blocks", payload, b->ring_cap - (size_t)g_M1(b));
+    return -1;
+  }
+  if (!retry) r.packets++;
   r.drops += seq_step;
   r.next_seq = (uint16_t)(seq + 1);
-  int const time_step = (int)(ts - r.next_timestamp);
-  if (time_step < 0) return 0;  // old samples: dropped before the timestamp advances (multicast.c:334-336)
   r.next_timestamp = ts + (uint32_t)sampcount;
-  if (time_step > 192000) return 0;  // radio.c:79-82
   if (time_step > 0) {
     if (kq_bank_push_zeros(b, (size_t)time_step)) return -1;  // radio.c:83-100
     r.samples += time_step;

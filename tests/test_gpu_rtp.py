@@ -149,26 +149,128 @@ def test_random_packet_sequences_keep_the_books_like_the_oracle(gpu):
 
 
 def test_gap_larger_than_the_free_ring_is_retried_not_lost(gpu):
-    """A timestamp gap whose zero fill does not fit the ring right now: the datagram is refused with nothing
-    consumed (it must not count as a duplicate when handed in again), and after a process call it goes through with
-    the reference's sample count (radio.c:83-100 always injects the zeros)."""
+    """A timestamp gap whose zero fill does not fit the ring right now, with whole blocks waiting: the datagram is
+    refused with nothing consumed (it must not count as a duplicate when handed in again), and after a process call it
+    goes through with the reference's sample count (radio.c:83-100 always injects the zeros)."""
     g = dict(samprate=192000, L=512, M=513, D=4)
-    bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], 1, 2)          # room for 2 blocks = 1024 samples
+    bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], 1, 2)          # 2 blocks + 511 samples of slack = 1535
     bank.add_channel(bank_cfg(wl.channel_plan("cfg1", 1)[0]))
     ing = ko.IqIngest()
     body = lambda n: np.full(2 * n, 1000, "<i2").tobytes()
-    first = rtp_packet(10, 1000, 5, body(600))
-    assert bank.push_rtp(first) == 600 and ing.packet(first) is not None
-    gap = rtp_packet(11, 1600 + 300, 5, body(200))                        # 300 lost samples + 200: 1100 > 1024
+    first = rtp_packet(10, 1000, 5, body(1100))
+    assert bank.push_rtp(first) == 1100 and ing.packet(first) is not None
+    gap = rtp_packet(11, 2100 + 300, 5, body(200))                        # 300 lost samples + 200: 1600 > 1535
     before = bank.rtp_counters()
     assert bank.push_rtp(gap) is None
-    assert bank.rtp_counters() == before                                   # sequence / timestamp state untouched
-    assert bank.process() == 1                                             # one block out, 88 samples stay
+    assert bank.rtp_counters() == before                                   # sequence / timestamp / counters untouched
+    assert bank.process() == 2                                             # two blocks out, 76 samples stay
     want = ing.packet(gap)
     assert bank.push_rtp(gap) == want[0] + want[2] == 500
     c = bank.rtp_counters()
-    assert (c["samples"], c["dupes"], c["next_seq"], c["next_timestamp"]) == (ing.samples, 0, 12, 2100)
-    huge = rtp_packet(12, 2100 + 5000, 5, body(10))                        # can never fit this bank: an error
-    with pytest.raises(kq.KqError):
-        bank.push_rtp(huge)
+    assert (c["samples"], c["packets"], c["dupes"], c["next_seq"], c["next_timestamp"]) == (ing.samples, 2, 0, 12, 2600)
     bank.close()
+
+
+@pytest.mark.parametrize("max_blocks", [1, 2])
+def test_partly_filled_block_never_blocks_a_packet_that_fits_the_ring(gpu, max_blocks):
+    """The two stuck states of the earlier room check: (pending % L) + need > max_blocks * L with need <= max_blocks * L
+    and no whole block waiting (a retry could never succeed), e.g. pending = 500, need = 600 with two blocks of 512; and a
+    bank of one block, where any packet that straddles a block end did this.  The ring's L - 1 samples of slack take it."""
+    g = dict(samprate=192000, L=512, M=513, D=4)
+    bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], 1, max_blocks)
+    bank.add_channel(bank_cfg(wl.channel_plan("cfg1", 1)[0]))
+    ing = ko.IqIngest()
+    body = lambda n: np.full(2 * n, 500, "<i2").tobytes()
+    seq, ts, total = 1, 100, 0
+    need = 600 if max_blocks == 2 else 400
+    for i, n in enumerate((500, need - 100, 300, 512, 37, 480)):
+        gapn = 100 if i == 1 else 0                                           # the second packet also brings a 100-sample gap
+        ts += gapn
+        pkt = rtp_packet(seq, ts, 9, body(n))
+        want = ing.packet(pkt)
+        tries = 0
+        while True:
+            got = bank.push_rtp(pkt)
+            if got is not None:
+                break
+            tries += 1
+            assert tries < 4 and bank.process() >= 1                          # -2 only ever with a whole block waiting
+        assert got == want[0] + want[2] == gapn + n
+        total += got
+        seq, ts = seq + 1, ts + n
+        c = bank.rtp_counters()
+        assert (c["samples"], c["packets"], c["drops"], c["next_seq"], c["next_timestamp"]) == \
+               (ing.samples, ing.rtp.packets, ing.rtp.drops, ing.rtp.seq, ing.rtp.timestamp)
+    assert total == ing.samples
+    bank.close()
+
+
+def test_gap_larger_than_the_whole_ring_is_filled_ring_by_ring(gpu):
+    """A 5000-sample gap into a ring of 2 x 512 (+ 511): rtp state must not freeze (the earlier check refused the packet,
+    and every later one, until the gap passed 192000).  Each round fills the ring with zeros and moves the timestamp on;
+    the audio is the oracle's, whose zero fill runs the oscillators and the filter through the gap (radio.c:83-100)."""
+    g = dict(samprate=192000, L=512, M=513, D=4)
+    fs, L = g["samprate"], g["L"]
+    plan = wl.channel_plan("cfg1", 1)
+    bank = kq.Bank(fs, L, g["M"], g["D"], 1, 2)
+    bank.add_channel(bank_cfg(plan[0]))
+    ch = ko.Channel(oracle_cfg(plan[0], fs, L, g["M"], g["D"]))
+    ing = ko.IqIngest()
+    rng = np.random.default_rng(5)
+    seq, ts = 100, 50000
+    got, want = [], []
+    for k in range(8):
+        n = 700
+        raw = rng.integers(-3000, 3000, 2 * n).astype("<i2")
+        if k == 3:
+            ts += 5000                                                        # lost: far more than the ring holds
+        if k == 6:
+            seq += 2                                                          # and two packets lost later on (800 samples)
+            ts += 800
+        pkt = rtp_packet(seq, ts, 77, raw.tobytes())
+        r = ing.packet(pkt)
+        zeros, off, count, fmt = r
+        if zeros:
+            want += ch.zero_fill(zeros)
+        want += ch.push_raw(pkt[off:off + 4 * count], count, fmt)
+        appended, rounds = 0, 0
+        while True:
+            before = bank.rtp_counters()
+            res = bank.push_rtp(pkt)
+            if res is not None:
+                appended += res
+                break
+            after = bank.rtp_counters()
+            appended += after["samples"] - before["samples"]
+            rounds += 1
+            assert rounds < 12
+            nb = bank.process()
+            assert nb >= 1
+            got += [bank.audio(0, b) for b in range(nb)]
+        assert rounds >= 3 if k == 3 else rounds <= (1 if k == 6 else 0), (k, rounds)
+        c = bank.rtp_counters()
+        assert (c["samples"], c["packets"], c["dupes"], c["drops"], c["next_seq"], c["next_timestamp"]) == \
+               (ing.samples, ing.rtp.packets, ing.rtp.dupes, ing.rtp.drops, ing.rtp.seq, ing.rtp.timestamp), k
+        seq, ts = seq + 1, ts + n
+        nb = bank.process()
+        got += [bank.audio(0, b) for b in range(nb)]
+    assert len(got) == len(want) == ing.samples // L
+    for b, (ga, (wa, _ws)) in enumerate(zip(got, want)):
+        assert rel_rms(ga, wa) < 1e-5 or np.abs(wa).max() < 1e-9, b
+    # a payload that can never fit (a ring of one block against a 2000-sample packet) is an error, and the stream goes on
+    small = kq.Bank(fs, L, g["M"], g["D"], 1, 1)
+    small.add_channel(bank_cfg(plan[0]))
+    with pytest.raises(kq.KqError, match="does not fit"):
+        small.push_rtp(rtp_packet(1, 10, 3, np.zeros(4000, "<i2").tobytes()))
+    nxt, total = rtp_packet(2, 2010, 3, np.zeros(400, "<i2").tobytes()), 0      # its 2000 samples are a gap for the next one
+    for _ in range(8):
+        before = small.rtp_counters()["samples"]
+        res = small.push_rtp(nxt)
+        total += (res if res is not None else small.rtp_counters()["samples"] - before)
+        if res is not None:
+            break
+        assert small.process() >= 1
+    assert total == 2000 + 200 and small.rtp_counters()["next_timestamp"] == 2210
+    small.close()
+    bank.close()
+    ch.close()

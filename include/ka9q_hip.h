@@ -153,6 +153,9 @@ int kq_bank_set_second_lo(kq_bank *bank, int ch, double hz);                 /* 
 int kq_bank_set_doppler(kq_bank *bank, int ch, double hz, double hz_per_s);  /* radio.c:180 set_doppler */
 int kq_bank_set_shift(kq_bank *bank, int ch, double hz);                     /* radio.c:304 set_shift */
 int kq_bank_set_filter(kq_bank *bank, int ch, float low_hz, float high_hz, float kaiser_beta); /* filter.c:500 set_filter */
+/* demod->sig.n0 as the demodulator finds it when it starts: NaN = the first compute_n0 result is taken as it comes,
+ * anything else = the smoothing goes on from there (fm.c:78-82, am.c:46-49, linear.c:123-126).  A fresh channel has NaN. */
+int kq_bank_set_n0(kq_bank *bank, int ch, float n0);
 
 /* --- data path --- */
 /* Append nsamples complex samples of the given format to the bank's input ring.  `iq` is a host

@@ -151,6 +151,7 @@ def load_library():
     L.kq_bank_enable_timing.argtypes = [C.c_void_p, C.c_int]
     L.kq_bank_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing), C.c_int]
     L.kq_bank_fwd_mode.argtypes = [C.c_void_p]
+    L.kq_bank_set_n0.argtypes = [C.c_void_p, C.c_int, C.c_float]
     L.kq_bank_push_iq_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.kq_bank_pull_planes_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.kq_bank_host_io_wait.argtypes = [C.c_void_p]
@@ -271,6 +272,9 @@ class Bank:
         else:
             raise TypeError("unsupported I/Q dtype %s" % iq.dtype)
         self._chk(self.lib.kq_bank_push_iq(self.h, iq.ctypes.data, n, fmt, 0), "kq_bank_push_iq")
+
+    def set_n0(self, ch, n0):
+        self._chk(self.lib.kq_bank_set_n0(self.h, ch, n0), "kq_bank_set_n0")
 
     def push_iq_async(self, ptr, nsamples, fmt=KQ_IQ_CF32):
         """ptr: PINNED host memory that stays unchanged until host_io_wait() (kq_bank_push_iq_async)"""

@@ -1272,6 +1272,17 @@ int kq_bank_set_shift(kq_bank *b, int ch, double hz) {
   return 0;
 }
 
+int kq_bank_set_n0(kq_bank *b, int ch, float n0) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  if (!valid_ch(b, ch)) {
+    set_err("bad channel");
+    return -1;
+  }
+  if (sync_all(b)) return -1;  // the demodulators of a call in flight own the state
+  HIP_TRY(hipMemcpy(b->chd.n0 + ch, &n0, sizeof n0, hipMemcpyHostToDevice));
+  return 0;
+}
+
 int kq_bank_set_filter(kq_bank *b, int ch, float low, float high, float beta) {
   kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch)) {

@@ -77,6 +77,10 @@ struct MasterDev {
   float2 *d_tmp = nullptr;  // N > 16384: scratch of the two-pass transform
   std::vector<float2> stage;
   float2 *tw = nullptr;
+  // which block's samples d_in holds, as of the work queued so far: the upload and this number move together under
+  // in_mu, so a reader that queues its copy under the same lock knows which block it will get (compat_snapshot_window)
+  std::mutex in_mu;
+  unsigned in_block = 0;
 };
 
 struct SlaveDev {
@@ -93,12 +97,18 @@ namespace kq {
 
 int compat_master_device(void) { return ctx().ok ? ctx().device : -1; }
 
-int compat_snapshot_window(struct filter_in *m, float2 *dst) {
+int compat_snapshot_window(struct filter_in *m, float2 *dst, unsigned *block) {
   if (!m || !m->fwd_plan || !dst) return -1;
   kq::DeviceScope dev_scope_(ctx().ok ? ctx().device : -1);
   MasterDev *d = (MasterDev *)m->fwd_plan;
   hipStream_t s = ctx().stream;
-  if (hipMemcpyAsync(dst, d->d_in, (size_t)d->N * sizeof(float2), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+  {
+    // The master may already have queued the next block's upload (it does not wait for its consumers, filter.c:146-172):
+    // the copy lands in stream order, so the block it carries is the one recorded with the last upload queued.
+    std::lock_guard<std::mutex> lk(d->in_mu);
+    if (hipMemcpyAsync(dst, d->d_in, (size_t)d->N * sizeof(float2), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+    if (block) *block = d->in_block;
+  }
   if (hipStreamSynchronize(s) != hipSuccess) return -1;
   return d->N;
 }
@@ -182,7 +192,11 @@ int execute_filter_input(struct filter_in *m) {
   } else {
     src = m->input_buffer.c;
   }
-  if (hipMemcpyAsync(d->d_in, src, N * sizeof(float2), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+  {
+    std::lock_guard<std::mutex> lk(d->in_mu);
+    if (hipMemcpyAsync(d->d_in, src, N * sizeof(float2), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    d->in_block = m->blocknum + 1;  // only this thread moves blocknum (below, once the transform is done)
+  }
   if (N > 16384)
     kq::launch_fft_large(s, d->d_in, d->d_fdomain, d->d_tmp, d->log2N, -1, d->tw, d->log2N);
   else

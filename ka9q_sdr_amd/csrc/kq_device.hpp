@@ -187,7 +187,8 @@ size_t pruned_table_elems(const Geom &g);
 // ---- compat surface internals shared with the demodulator entry points (kq_compat.cpp, kq_radio.cpp)
 // Copies the master's device-resident input window (N samples: M-1 history, L new) of the block last transformed to
 // `dst` (device), ordered behind that transform on the compat stream, and waits for it.  Returns N, or -1.
-int compat_snapshot_window(struct filter_in *master, float2 *dst);
+// *block: the master's block number the copied window belongs to (the master may be one block ahead of its consumers)
+int compat_snapshot_window(struct filter_in *master, float2 *dst, unsigned *block);
 int compat_master_device(void);  // device the compat surface runs on (the calling thread's current device at first use)
 
 }  // namespace kq

@@ -37,7 +37,9 @@ struct Session {
   int isb = 0, channels = 1;
   double shift_freq = 0;
   int type = KQ_LINEAR_DEMOD;  // which of the three threads this is
-  bool host_n0 = false;  // N > 16384: the bank's split path has no compute_n0; the single-spectrum kernel supplies it
+  bool host_n0 = false;  // N = 32768: the bank's split path has no compute_n0; the single-spectrum kernel supplies it
+  bool have_block = false;  // next_block: the master's block number of the window demodulated last
+  unsigned last_block = 0;
 
   ~Session() {
     if (bank) kq_bank_destroy(bank);
@@ -87,7 +89,10 @@ bool start(Session &s, struct demod *demod, int demod_type, enum filtertype out_
   bc.max_blocks = 1;
   bc.device = s.dev;
   bc.gain_factor = 1.f;
-  s.host_n0 = (size_t)m->ilen + m->impulse_length - 1 > 16384;
+  {
+    size_t const Nm = (size_t)m->ilen + m->impulse_length - 1;
+    s.host_n0 = Nm > 16384 && Nm != 65536;  // the bank computes it up to 16384 points and at 65536 (kq_full16k.hip)
+  }
   bc.compute_n0 = s.host_n0 ? 0 : 1;
   bc.fwd_mode = KQ_FWD_FULL;
   s.bank = kq_bank_create(&bc);
@@ -116,6 +121,12 @@ bool start(Session &s, struct demod *demod, int demod_type, enum filtertype out_
     fail(demod, "kq_bank_add_channel failed");
     return false;
   }
+  // sig.n0 lives in struct demod, not in the thread: a thread started by set_mode goes on smoothing from the value
+  // the last one left (fm.c:78-82, am.c:46-49, linear.c:123-126 test it for NaN, nothing ever resets it)
+  if (!s.host_n0 && kq_bank_set_n0(s.bank, 0, demod->sig.n0)) {
+    fail(demod, "kq_bank_set_n0 failed");
+    return false;
+  }
   s.low = cc.low;
   s.high = cc.high;
   s.beta = cc.kaiser_beta;
@@ -140,8 +151,20 @@ bool next_block(Session &s, kq_chan_status *st, std::vector<float> &audio, size_
     s.beta = demod->filter.kaiser_beta;
     if (kq_bank_set_filter(s.bank, 0, s.low, s.high, s.beta)) return false;
   }
-  if (execute_filter_output(s.slave)) return false;  // blocks until the master has a new block; refreshes output.c
-  if (kq::compat_snapshot_window(demod->filter.in, s.d_window) < 0) return false;
+  // The master does not wait for its consumers (filter.c:146-172): by the time this thread wakes it may have queued the
+  // next block already, and the window copied here is then that one.  A window is demodulated once: when the copy
+  // turns out to be the block done last time round, wait for the next.  (A thread that falls further behind skips
+  // blocks, as the reference's equality test on blocknum does, filter.c:195-199.)
+  for (;;) {
+    if (execute_filter_output(s.slave)) return false;  // blocks until the master has a new block; refreshes output.c
+    if (demod->terminate) return false;
+    unsigned blk = 0;
+    if (kq::compat_snapshot_window(demod->filter.in, s.d_window, &blk) < 0) return false;
+    if (s.have_block && blk == s.last_block) continue;
+    s.have_block = true;
+    s.last_block = blk;
+    break;
+  }
   if (kq_bank_process_resident(s.bank, s.d_window, 1) != 1) return false;
   audio.resize(2 * (size_t)s.olen);
   if (kq_bank_pull_audio(s.bank, 0, 0, audio.data(), audio.size(), nout)) return false;

@@ -78,7 +78,8 @@ static inline float complex cmulf_(float complex a, float complex b){
  * vectors were generated with.  The baseline times the same chain with a radix-4 (plus one radix-2 pass when
  * log2 n is odd) Stockham autosort transform: no bit-reversal pass, unit-stride inner loops over split re / im
  * arrays that the compiler vectorises (function clones for AVX2 / AVX-512 are picked at load time).  Same
- * conventions, results equal to the plain transform to float rounding (tests/test_oracle_filter.py). */
+ * conventions, results equal to the plain transform to float rounding
+ * (tests/test_oracle_filter.py::test_fast_transform_equals_the_plain_one).  Writes the plan's scratch: one plan per thread. */
 static int Fast;
 void kqo_fft_set_fast(int on){ Fast = on; }
 

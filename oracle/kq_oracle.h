@@ -36,7 +36,9 @@
 typedef struct kqo_fft kqo_fft;
 kqo_fft *kqo_fft_create(unsigned n);           /* n must be a power of two >= 1 */
 void kqo_fft_destroy(kqo_fft *p);
-/* 1: kqo_fft_c2c (and r2c / c2r through it) use the radix-4 autosort variant -- CPU-baseline timing only */
+/* 1: kqo_fft_c2c (and r2c / c2r through it) use the radix-4 autosort variant -- CPU-baseline timing only
+ * (tests/test_oracle_filter.py::test_fast_transform_equals_the_plain_one).  A plan carries its own scratch buffers, which
+ * both variants write through the const handle: one plan per thread -- a plan shared between threads races. */
 void kqo_fft_set_fast(int on);
 /* out-of-place or in-place (in == out) complex transform; sign -1 forward, +1 backward */
 void kqo_fft_c2c(const kqo_fft *p, const float complex *in, float complex *out, int sign);

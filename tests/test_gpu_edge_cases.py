@@ -85,7 +85,7 @@ def test_channel_limit_and_bad_arguments(gpu):
     x = np.zeros(3 * g["L"], np.complex64)
     with pytest.raises(kq.KqError, match="ring overflow"):
         bank.push_iq(x)                             # the ring holds max_blocks blocks
-    bank.push_iq(x[:2 * g["L"] - 5])                # capacity is exactly max_blocks * L pending samples
+    bank.push_iq(x[:2 * g["L"] - 5])                # (the ring takes max_blocks * L samples plus L - 1 of slack)
     assert bank.blocks_ready() == 1
     bank.push_iq(x[:5])
     assert bank.blocks_ready() == 2 and bank.process() == 2
@@ -322,3 +322,34 @@ def test_agc_hold_coast_and_attack_regimes(gpu, L, D):
         a_g = np.concatenate([a for a, _ in got[c][sk:]])
         a_w = np.concatenate(auds[sk:])
         assert rel_rms(a_g, a_w) < 1e-5, (c, p["demod"], rel_rms(a_g, a_w))
+
+
+def test_n0_smoothing_continues_from_a_seeded_value(gpu):
+    """sig.n0 belongs to struct demod, not to the demodulator thread: a thread that set_mode starts goes on smoothing from
+    what the last one left (fm.c:78-82, am.c:46-49; only NaN takes the first value as it comes).  kq_bank_set_n0 is that
+    hand-over; the thread entry points use it at start-up."""
+    g = _geom()
+    fs, L = g["samprate"], g["L"]
+    plan = wl.channel_plan("cfg1", 2)
+    plan[1] = dict(plan[1], demod="am", low=-5000.0, high=5000.0, recovery_rate=50.0)
+    iq = wl.make_iq(fs, 3 * L, seed=3)
+    fresh = kq.Bank(fs, L, g["M"], g["D"], 2, 3, compute_n0=True)
+    seeded = kq.Bank(fs, L, g["M"], g["D"], 2, 3, compute_n0=True)
+    for p in plan:
+        fresh.add_channel(bank_cfg(p))
+        seeded.add_channel(bank_cfg(p))
+    seed = 3.0e-9
+    seeded.set_n0(0, seed)
+    seeded.set_n0(1, seed)
+    for bank in (fresh, seeded):
+        bank.push_iq(iq)
+        assert bank.process() == 3
+    for c, rate in ((0, 0.01), (1, 0.001)):
+        raw0 = fresh.status(c, 0)["n0"]                       # a fresh channel takes the first value as it comes
+        want = np.float32(seed + rate * (np.float64(raw0) - seed))
+        got = seeded.status(c, 0)["n0"]
+        assert abs(got / want - 1) < 1e-6, (c, got, want)
+        # two blocks later the seeded channel is still near its seed (the raw values are 10 x larger here), the fresh one near raw
+        assert abs(seeded.status(c, 2)["n0"] / seed - 1) < 30 * rate + 0.01 and abs(fresh.status(c, 2)["n0"] / raw0 - 1) < 0.5
+    fresh.close()
+    seeded.close()

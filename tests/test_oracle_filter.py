@@ -214,3 +214,41 @@ def test_compute_n0_white_noise():
     a1 = P[out].mean()
     a2 = P[out & (P < 2 * a1)].mean()
     np.testing.assert_allclose(n0, a2 / (2.0 * N * fs), rtol=2e-4)
+
+
+@pytest.mark.parametrize("log2n", [2, 3, 5, 8, 11, 12, 14, 15, 16])
+def test_fast_transform_equals_the_plain_one(log2n):
+    """oracle/kq_fft.c has two transforms: the plain radix-2 one the parity vectors were made with, and the radix-4
+    autosort one that bench.py's cpu_baseline times (kqo_fft_set_fast).  Same conventions, both signs, odd and even
+    log2 n, and the r2c / c2r wrappers on top: equal to float rounding, and both equal to numpy's float64 transform."""
+    import ctypes as C
+    L = ko.lib()
+    n = 1 << log2n
+    rng = np.random.default_rng(log2n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    xr = rng.standard_normal(n).astype(np.float32)
+    p = L.kqo_fft_create(n)
+    try:
+        res = {}
+        for fast in (0, 1):
+            L.kqo_fft_set_fast(fast)
+            for sign in (-1, 1):
+                out = np.zeros(n, np.complex64)
+                L.kqo_fft_c2c(p, x.ctypes.data, out.ctypes.data, sign)
+                res[fast, sign] = out
+            half = np.zeros(n // 2 + 1, np.complex64)
+            L.kqo_fft_r2c(p, xr.ctypes.data, half.ctypes.data)
+            back = np.zeros(n, np.float32)
+            L.kqo_fft_c2r(p, half.ctypes.data, back.ctypes.data)
+            res[fast, "r2c"], res[fast, "c2r"] = half, back
+    finally:
+        L.kqo_fft_set_fast(0)
+        L.kqo_fft_destroy(p)
+    want = {-1: np.fft.fft(x.astype(np.complex128)), 1: np.fft.ifft(x.astype(np.complex128)) * n,
+            "r2c": np.fft.rfft(xr.astype(np.float64)), "c2r": xr.astype(np.float64) * n}
+    tol = 4e-7 * max(1, log2n) ** 0.5
+    for key, w in want.items():
+        scale = np.sqrt(np.mean(np.abs(w) ** 2))
+        for fast in (0, 1):
+            assert np.sqrt(np.mean(np.abs(res[fast, key] - w) ** 2)) / scale < tol, (key, fast)
+        assert np.sqrt(np.mean(np.abs(res[1, key] - res[0, key]) ** 2)) / scale < tol, key

@@ -37,3 +37,21 @@ def gpu():
     n = kq.device_count()
     assert n > 0, "no HIP device visible: -m gpu tests need the MI355X"
     return n
+
+
+# Threshold ties (decision flips are counted, not hidden in a tolerance): the parity tests append
+# (test, ties, channels, what) here and the run's summary prints the list, so the tail of a GPU test log shows the count.
+TIES = []
+
+
+def note_ties(test, flips, channels):
+    TIES.append((test, len(flips), channels, ", ".join("ch %d %s %.2g" % f for f in flips[:6])))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not TIES:
+        return
+    terminalreporter.write_sep("-", "threshold ties of the reference's own comparisons (counted, each checked to be one)")
+    for test, n, channels, what in TIES:
+        terminalreporter.write_line("%-64s %3d of %4d channels%s" % (test, n, channels, ("  [" + what + "]") if what else ""))
+    terminalreporter.write_line("total: %d ties in %d channel runs" % (sum(t[1] for t in TIES), sum(t[2] for t in TIES)))

@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
 
 AUDIO_TOL = 1e-5      # relative RMS, north_star
 FILT_TOL = 1e-5
+FIRST_LINEAR_TOL = 2e-3   # audio of a linear channel's first block (AGC start-up on numerically-zero samples, linear.c:271-272)
+EXACT_TOL = 2e-6          # status sums against float64 arithmetic on the kernel's own samples
 
 
 def _run_bank(plan, geom, iq, nblocks, fwd_mode, compute_n0=False, per_call=None):
@@ -55,13 +57,20 @@ def _compare(plan, got, want, skip_blocks=0, check_n0=False):
         assert rel_rms(filt_g, filt_w) < FILT_TOL, ("filter", c, p["demod"], rel_rms(filt_g, filt_w))
         # Linear AGC start-up: with an all-zero history the first filter outputs are numerically zero and
         # the AGC (linear.c:271-272) divides by them, turning float rounding noise into O(1e-4) gain
-        # differences until the first real attack.  Audio of that first block is excluded for linear
-        # channels; its integer state and every later block are still compared.
+        # differences until the first real attack.  Audio of that first block is held to FIRST_LINEAR_TOL (below)
+        # instead of 1e-5; its filter output, its integer state and every later block are compared like any other.
         sk = max(skip_blocks, 1) if p["demod"] == "linear" else skip_blocks
         a_g = np.concatenate(g["audio"][sk:])
         a_w = np.concatenate(auds[sk:])
-        assert rel_rms(a_g, a_w) < AUDIO_TOL, ("audio (linear channels: from block 1 on; block 0 is compared through its "
-                                               "filter output and integer state only)", c, p["demod"], rel_rms(a_g, a_w))
+        assert rel_rms(a_g, a_w) < AUDIO_TOL, ("audio (linear channels: from block 1 on)", c, p["demod"], rel_rms(a_g, a_w))
+        if p["demod"] == "linear" and skip_blocks == 0:
+            # That first block, explicitly: its filter output to 1e-5 (the rounding noise of a window that is half zeros),
+            # its sample count and hang counter exactly (below), and its audio to FIRST_LINEAR_TOL -- the gain the AGC lands
+            # on after dividing by those near-zero samples, relative to the block's own RMS.
+            assert rel_rms(g["filt"][0], filts[0]) < FILT_TOL, ("first linear block, filter", c, rel_rms(g["filt"][0], filts[0]))
+            if np.abs(auds[0]).max() > 0:
+                e0 = rel_rms(g["audio"][0], auds[0])
+                assert e0 < FIRST_LINEAR_TOL, ("first linear block, audio", c, e0)
         for b in range(nb):
             sg, sw = g["status"][b], sts[b]
             assert sg["squelch_count"] == sw["squelch_count"], (c, b)
@@ -70,7 +79,12 @@ def _compare(plan, got, want, skip_blocks=0, check_n0=False):
             assert np.isnan(sg["plfreq"]) == np.isnan(sw["plfreq"]), (c, b, sg["plfreq"], sw["plfreq"])
             if not np.isnan(sw["plfreq"]):
                 assert sg["plfreq"] == sw["plfreq"], (c, b)        # same peak bin (fm.c:260-267)
-            np.testing.assert_allclose(sg["bb_power"], sw["bb_power"], rtol=2e-5)
+            np.testing.assert_allclose(sg["bb_power"], sw["bb_power"], rtol=1e-5)
+            # (the oracle sums in sequence, fm.c:93-97, the kernel as a tree: observed 5e-7 apart.)  Against float64
+            # arithmetic on the samples the kernel itself produced, bb_power = sum |s|^2 / (2 olen) holds to EXACT_TOL
+            exact = float(np.sum(np.abs(g["filt"][b].astype(np.complex128)) ** 2) / (2 * len(g["filt"][b])))
+            np.testing.assert_allclose(sg["bb_power"], exact, rtol=EXACT_TOL, err_msg="bb_power vs float64 (%d, %d)" % (c, b))
+            # (the block-level comparison above already covers this block's filter output)
             np.testing.assert_allclose(sg["if_power"], sw["if_power"], rtol=2e-4)
             if p["demod"] == "fm":
                 # snr = a^2/(2(bb - a^2)) - 1 (fm.c:101-102) cancels catastrophically at high SNR: compare the
@@ -638,7 +652,8 @@ def test_cfg5_geometry_full_spectrum_with_n0(gpu, variant):
     # (one of these nine channels has a bin 5e-5 below the cut in its first block -- checked in float64 on the kernel's
     # own spectrum, tests/diag_n0_64k.py: the kernel keeps it, the oracle's sequential float sum, 1.3e-4 low, drops it)
     flips = _compare_counting_ties(plan, got, want, nblocks)
-    print("threshold ties: %d of %d channels" % (len(flips), len(plan)), flips)
+    import conftest
+    conftest.note_ties("test_cfg5_geometry_full_spectrum_with_n0[%s]" % variant, flips, len(plan))
     assert len(flips) <= 1, flips
     _n0_ties_are_ties(plan, g, iq, nblocks, flips, 0.001)
 

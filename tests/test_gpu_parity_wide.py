@@ -42,7 +42,8 @@ def test_channels_at_bench_geometry(gpu, name, mode, n0, nchan):
     # within one float rounding of compute_n0's 2 x mean cut (radio.c:414-420) moves n0 by one bin's worth (0.2 %) in
     # a few channels per thousand; everything else of such a channel still has to agree
     flips = _compare_counting_ties(plan, got, want, nblocks, check_n0=n0)
-    print("threshold ties: %d of %d channels" % (len(flips), len(plan)), flips)
+    import conftest
+    conftest.note_ties("test_channels_at_bench_geometry[%s-%s-%s-%d]" % (name, mode, n0, nchan), flips, len(plan))
     big = g["L"] + g["M"] - 1 > 16384
     # N = 65536: the float32 oracle sums its first pass over 62 000 bins in sequence and lands 1e-4 below the exact mean
     # (at 16384 bins: 3e-5), so a bin within 1e-4 of the cut is decided differently: 2 - 3 % of the channels.  Each of them
@@ -55,6 +56,13 @@ def test_channels_at_bench_geometry(gpu, name, mode, n0, nchan):
     worst_if = max(abs(got[c]["status"][b]["if_power"] / want[c][1][b]["if_power"] - 1) for c in range(len(plan))
                    for b in range(nblocks))
     assert worst_if < 1e-4, worst_if      # the reference sums 8192 floats in sequence; the kernel sums them as a tree
+    # ... and against float64 arithmetic on the same samples (radio.c:123,143-145: E <- (E + sum |s|^2) / 2, if_power = E / L)
+    # the kernel's figure holds to 2e-6: the 1e-4 above is the float32 oracle's sequential sum
+    E, L = 0.0, g["L"]
+    for b in range(nblocks):
+        x = iq[b * L:(b + 1) * L].astype(np.complex128)
+        E = 0.5 * (E + float(np.sum(x.real ** 2 + x.imag ** 2)))
+        np.testing.assert_allclose(got[0]["status"][b]["if_power"], E / L, rtol=2e-6)
 
 
 def test_decision_flips_stay_within_budget(gpu):
@@ -83,4 +91,6 @@ def test_decision_flips_stay_within_budget(gpu):
                     assert filt < FILT_TOL and same_counts, ("not a threshold tie", seed, mode, c, p, str(e)[:300])
                     flips.append((seed, mode, c, p["demod"], str(e)[:120]))
     assert len(flips) <= FLIP_BUDGET * total, (len(flips), total, flips)
-    print("decision flips: %d of %d randomised channels" % (len(flips), total), flips)
+    import conftest
+    conftest.TIES.append(("test_decision_flips_stay_within_budget", len(flips), total,
+                          "; ".join("seed %d %s ch %d %s" % f[:4] for f in flips[:6])))

@@ -25,6 +25,18 @@ extern "C" int send_stereo_output(struct demod *, const float *, int) __attribut
 
 namespace {
 
+// struct demod is shared with the host program's other threads the way the reference shares it -- plain fields, no lock
+// (display.c:161 writes filter.low / high, set_mode writes terminate, radio.c:336): the fields those threads write are
+// read here with relaxed atomic loads, and the slave pointer they pick up is published with a release store, so that the
+// protocol is defined behaviour (and clean under ThreadSanitizer, tests/tsan) without changing the layout.
+template <class T>
+inline T shared_load(const T &v) {
+  T t;
+  __atomic_load(const_cast<T *>(&v), &t, __ATOMIC_RELAXED);
+  return t;
+}
+inline void publish_slave(struct demod *demod, struct filter_out *s) { __atomic_store_n(&demod->filter.out, s, __ATOMIC_RELEASE); }
+
 struct Session {
   struct demod *demod = nullptr;
   struct filter_out *slave = nullptr;
@@ -53,7 +65,7 @@ struct Session {
 
 void fail(struct demod *demod, const char *what) {
   fprintf(stderr, "ka9q_hip: demodulator thread: %s (%s)\n", what, kq_last_error());
-  demod->filter.out = NULL;
+  publish_slave(demod, NULL);
 }
 
 // Prologue common to the three threads: slave (for the caller-visible state) + bank of one
@@ -74,8 +86,9 @@ bool start(Session &s, struct demod *demod, int demod_type, enum filtertype out_
     fail(demod, "create_filter_output failed");
     return false;
   }
-  demod->filter.out = s.slave;
-  set_filter(s.slave, edge_scale * demod->filter.low, edge_scale * demod->filter.high, demod->filter.kaiser_beta);
+  publish_slave(demod, s.slave);
+  float const low0 = shared_load(demod->filter.low), high0 = shared_load(demod->filter.high), beta0 = shared_load(demod->filter.kaiser_beta);
+  set_filter(s.slave, edge_scale * low0, edge_scale * high0, beta0);
   s.olen = s.slave->olen;
   s.dev = kq::compat_master_device();
 
@@ -106,9 +119,9 @@ bool start(Session &s, struct demod *demod, int demod_type, enum filtertype out_
   cc.flat = demod->opt.flat;
   cc.isb = demod_type == KQ_LINEAR_DEMOD ? demod->filter.isb : 0;
   cc.channels = demod->output.channels == 2 ? 2 : 1;
-  cc.low = demod->filter.low;
-  cc.high = demod->filter.high;
-  cc.kaiser_beta = demod->filter.kaiser_beta;
+  cc.low = low0;  // (an edge the user interface moves from here on is picked up by next_block's comparison)
+  cc.high = high0;
+  cc.kaiser_beta = beta0;
   cc.headroom = demod->agc.headroom;
   cc.hangtime = demod->agc.hangtime;
   cc.recovery_rate = demod->agc.recovery_rate;
@@ -145,10 +158,11 @@ bool start(Session &s, struct demod *demod, int demod_type, enum filtertype out_
 bool next_block(Session &s, kq_chan_status *st, std::vector<float> &audio, size_t *nout) {
   struct demod *demod = s.demod;
   // filter edges may change under us (display.c:163, 950 call set_filter on demod->filter.out after updating these)
-  if (demod->filter.low != s.low || demod->filter.high != s.high || demod->filter.kaiser_beta != s.beta) {
-    s.low = demod->filter.low;
-    s.high = demod->filter.high;
-    s.beta = demod->filter.kaiser_beta;
+  float const low = shared_load(demod->filter.low), high = shared_load(demod->filter.high), beta = shared_load(demod->filter.kaiser_beta);
+  if (low != s.low || high != s.high || beta != s.beta) {
+    s.low = low;
+    s.high = high;
+    s.beta = beta;
     if (kq_bank_set_filter(s.bank, 0, s.low, s.high, s.beta)) return false;
   }
   // The master does not wait for its consumers (filter.c:146-172): by the time this thread wakes it may have queued the
@@ -157,7 +171,7 @@ bool next_block(Session &s, kq_chan_status *st, std::vector<float> &audio, size_
   // blocks, as the reference's equality test on blocknum does, filter.c:195-199.)
   for (;;) {
     if (execute_filter_output(s.slave)) return false;  // blocks until the master has a new block; refreshes output.c
-    if (demod->terminate) return false;
+    if (shared_load(demod->terminate)) return false;
     unsigned blk = 0;
     if (kq::compat_snapshot_window(demod->filter.in, s.d_window, &blk) < 0) return false;
     if (s.have_block && blk == s.last_block) continue;
@@ -172,7 +186,7 @@ bool next_block(Session &s, kq_chan_status *st, std::vector<float> &audio, size_
   if (s.host_n0) {
     // radio.c:383-425 on the master's resident spectrum, then the demodulator's smoothing (fm.c:78-82: 0.01;
     // am.c:46-49, linear.c:123-126: 0.001; the first value is taken as it comes)
-    float const raw = kq_compat_compute_n0(demod->filter.in, demod->input.samprate, demod->filter.low, demod->filter.high);
+    float const raw = kq_compat_compute_n0(demod->filter.in, demod->input.samprate, s.low, s.high);
     float const k = s.type == KQ_FM_DEMOD ? 0.01f : 0.001f;
     st->n0 = std::isnan(demod->sig.n0) ? raw : demod->sig.n0 + k * (raw - demod->sig.n0);
   }
@@ -181,7 +195,7 @@ bool next_block(Session &s, kq_chan_status *st, std::vector<float> &audio, size_
 
 void finish(Session &s) {
   struct demod *demod = s.demod;
-  demod->filter.out = NULL;  // fm.c:182, am.c:81, linear.c:320 (the Session's destructor deletes the slave)
+  publish_slave(demod, NULL);  // fm.c:182, am.c:81, linear.c:320 (the Session's destructor deletes the slave)
 }
 
 }  // namespace
@@ -201,9 +215,9 @@ void *demod_fm(void *arg) {
   std::vector<float> audio;
   kq_chan_status st;
   size_t n = 0;
-  while (!demod->terminate) {
+  while (!shared_load(demod->terminate)) {
     if (!next_block(s, &st, audio, &n)) {
-      fail(demod, "block failed");
+      if (!shared_load(demod->terminate)) fail(demod, "block failed");  // (told to stop while waiting: not a failure)
       break;
     }
     demod->sig.n0 = st.n0;  // fm.c:78-82 (smoothed on the device with the same recurrence)
@@ -232,9 +246,9 @@ void *demod_am(void *arg) {
   std::vector<float> audio;
   kq_chan_status st;
   size_t n = 0;
-  while (!demod->terminate) {
+  while (!shared_load(demod->terminate)) {
     if (!next_block(s, &st, audio, &n)) {
-      fail(demod, "block failed");
+      if (!shared_load(demod->terminate)) fail(demod, "block failed");  // (told to stop while waiting: not a failure)
       break;
     }
     demod->sig.n0 = st.n0;  // am.c:46-49
@@ -259,7 +273,7 @@ void *demod_linear(void *arg) {
   std::vector<float> audio;
   kq_chan_status st;
   size_t n = 0;
-  while (!demod->terminate) {
+  while (!shared_load(demod->terminate)) {
     // linear.c:117-120: the ISB flag is copied to the slave before every block; output.channels is read after it
     int const isb = demod->filter.isb != 0, channels = demod->output.channels == 2 ? 2 : 1;
     if (isb != s.isb || channels != s.channels) {
@@ -279,7 +293,7 @@ void *demod_linear(void *arg) {
       }
     }
     if (!next_block(s, &st, audio, &n)) {
-      fail(demod, "block failed");
+      if (!shared_load(demod->terminate)) fail(demod, "block failed");  // (told to stop while waiting: not a failure)
       break;
     }
     demod->sig.n0 = st.n0;  // linear.c:123-126

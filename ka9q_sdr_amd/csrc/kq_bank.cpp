@@ -533,7 +533,10 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   chd.hist_freq = chd.lo_phase + 6 * Cmax;
   chd.hist_rate = chd.lo_phase + 7 * Cmax;
   // this parity's hand-over planes were last read by the demodulators two calls ago
-  if (b->stream2 != b->stream) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[pp], 0));
+  // (asked of the host first: a wait on another stream's event costs the stream a barrier packet, several microseconds
+  // of idle device even when the event fired long ago -- and two calls later it always has)
+  if (b->stream2 != b->stream && hipEventQuery(b->ev_demod_done[pp]) != hipSuccess)
+    HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[pp], 0));
   int slot = 0, nret = 0;
   if (stage_call_params(b, b->n_abs - (g.M - 1), update_host, nblocks, &slot, &nret)) return -1;
   size_t const ret_off = 8 * Cmax * sizeof(double) + ((b->cfg.max_blocks + 7) & ~7u);
@@ -845,11 +848,12 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     rc |= dev_alloc(&b->osc_dev2[k], 8 * C + (B + sizeof(double) - 1) / sizeof(double) + (C * sizeof(int) + 7) / 8);
   b->chd.lo_phase = b->chd.lo_freq = b->chd.lo_rate = b->chd.sh_phase = b->chd.sh_freq = nullptr;  // set per call
   b->chd.hist_phase = b->chd.hist_freq = b->chd.hist_rate = nullptr;
-  // Overlap is opt-in (KQ_DEMOD_OVERLAP=1): measured on MI355X the single-wave demodulator workgroups squat on
-  // CUs between filter workgroups (236-VGPR waves cannot co-reside with them) and the step gets slower, so by
-  // default the demodulators simply follow the filter on the main stream.
+  // The demodulators of call k run on a second stream under the filter pass of call k+1 (KQ_DEMOD_OVERLAP=0 puts them
+  // back on the main stream).  Round 2 measured this a loss next to the 236-VGPR pruned kernel and a 1.9 % gain at +2 % on
+  // the full-spectrum kernel; with this round's kernels the filter kernel's own time is unchanged (1.353 ms either way)
+  // and the step drops 1.3 % (1.433 -> 1.414 ms, A/B on one box), so it is the default now.
   const char *ov = getenv("KQ_DEMOD_OVERLAP");
-  bool const overlap = ov && atoi(ov) != 0;
+  bool const overlap = !ov || atoi(ov) != 0;
   if (!overlap) b->stream2 = b->stream;
   if ((overlap && hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess) ||
       hipEventCreateWithFlags(&b->ev_filter_done, hipEventDisableTiming) != hipSuccess ||

@@ -223,10 +223,13 @@ const void *kq_fanout_acquire(kq_fanout *f, int slot, void *consumer_stream, siz
     return nullptr;
   }
   kq::DeviceScope scope(f->device);
-  if (hipError_t e = hipStreamWaitEvent((hipStream_t)consumer_stream, f->ready[slot], 0); e != hipSuccess) {
-    fail("kq_fanout_acquire: hipStreamWaitEvent", e);
-    return nullptr;
-  }
+  // a batch that has already landed needs no wait on the device (a cross-stream wait is a barrier packet: microseconds
+  // of idle consumer stream even for an event that fired long ago)
+  if (hipEventQuery(f->ready[slot]) != hipSuccess)
+    if (hipError_t e = hipStreamWaitEvent((hipStream_t)consumer_stream, f->ready[slot], 0); e != hipSuccess) {
+      fail("kq_fanout_acquire: hipStreamWaitEvent", e);
+      return nullptr;
+    }
   if (nsamples) *nsamples = f->count[slot];
   return f->buf[slot];
 }

@@ -188,7 +188,10 @@ __device__ __forceinline__ void sibling_exchange(unsigned long long *slots, int 
 // loads can be issued before anything else (with that path in the kernel they cost it 24 spilled registers).
 // BIG: 0 = N 16384; 1 = N 65536 (four sibling workgroups per channel-block, blockIdx.x = 4 * channel + r); 2 = the same,
 // PLAIN launch with swept channels
-template <bool N0, bool DUMP, bool PLAIN, bool PAIRED, int BIG>
+// EPI: which slave epilogue the instance carries -- 1: N/D = 64 only (one wave, registers); 2: N/D = 128 .. 512 only (N/D / 64
+// waves); 0: all of them, chosen at run time (other N/D, the DUMP instances, N = 65536 which has none).  The headline
+// instance is EPI = 1: with the other epilogues compiled in it took 4 registers more and ran 0.4 % slower.
+template <bool N0, bool DUMP, bool PLAIN, bool PAIRED, int BIG, int EPI>
 __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,
                                                        const float2 *__restrict__ tw, const float2 *__restrict__ tab,
                                                        float2 *__restrict__ spec_dump, int spec_ch,
@@ -541,12 +544,29 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   const float2 *H = ch.resp + (size_t)c * Ndec;
   bool const isb = (ch.flags[c] & FLAG_ISB) != 0;
   v2f epi_h = {0.f, 0.f}, epi_h2 = {0.f, 0.f}, epi_w[5] = {};
-  if (BIG == 0 && Ndec == 64 && t < 64) {
+  bool const epi64 = BIG == 0 && (EPI == 1 || (EPI == 0 && Ndec == 64));
+  if (epi64 && t < 64) {
     int const q = (int)(__brev((unsigned)t) >> 26);
     epi_h = ld2(H + q);
     if (isb) epi_h2 = ld2(H + ((64 - q) & 63));
 #pragma unroll
     for (int st = 0; st < 5; st++) epi_w[st] = buf_ld2(tabr, (unsigned)t * 8u, (unsigned)(kTabEpi + st * 64) * 8u);
+  }
+  // N/D = 128, 256, 512 (cfg 2: 256): R = N_dec / 64 waves share the inverse transform (below); each fetches its
+  // response bins, the lane-exchange twiddles and its output twiddle here, under compute_n0
+  int const epiR = (BIG == 0 && (EPI == 2 || (EPI == 0 && Ndec >= 128 && Ndec <= 512))) ? Ndec >> 6 : 0;
+  v2f epi_post = {1.f, 0.f};
+  if (epiR && t < 64 * epiR) {
+    int const r = t >> 6, l = t & 63;
+    int const q = (int)(__brev((unsigned)l) >> 26);
+    int const k = epiR * q + r;  // this lane's bin, and its CROSS_CONJ partner N_dec - k
+    epi_h = ld2(H + k);
+    if (isb) epi_h2 = ld2(H + ((Ndec - k) & (Ndec - 1)));
+#pragma unroll
+    for (int st = 0; st < 5; st++) epi_w[st] = buf_ld2(tabr, (unsigned)l * 8u, (unsigned)(kTabEpi + st * 64) * 8u);
+    float sn, cs;
+    sincospif(2.f * (float)(r * l) / (float)Ndec, &sn, &cs);  // exp(+2 pi i r m / N_dec) for output m = lane
+    epi_post = (v2f){cs, sn};
   }
 
   // ---------------- compute_n0 (radio.c:383-425), status only.  pp[k3] = (|X[ka + 1024 k3]|^2, |X[kb + 1024 k3]|^2)
@@ -719,7 +739,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     }
   }
   if constexpr (BIG != 0) return;  // response multiply and inverse transform: k_epilogue64k
-  if (Ndec == 64) {
+  if (epi64) {
     // cfg 3 / 4: one wave multiplies and runs the 64-point inverse transform in its registers (lane exchanges, no
     // barriers); the other seven are done.  Its response bins and stage twiddles were fetched before compute_n0
     // (epi_*), so nothing here waits for memory: the workgroup's slot on the CU is held by this tail alone.
@@ -749,6 +769,73 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     KQ_STAMP(9);
     return;
   }
+  if (epiR) {
+    // N_dec = 64 R.  With k = R q + r and n = m + 64 j:
+    //   y[m + 64 j] = sum_r e^{2 pi i r j / R} [ e^{2 pi i r m / N_dec} sum_q G[R q + r] e^{2 pi i q m / 64} ]
+    // wave r runs the 64-point inverse transform of its bins across its lanes exactly as the N/D = 64 epilogue does
+    // (registers and lane exchanges, no barrier), twiddles it and leaves Z_r[m] in LDS; one barrier; then lane m of wave 0
+    // finishes with the R-point transform over r in its registers.  The shared LDS transform this replaces ran its passes on
+    // one wave, behind a barrier each, with 64 threads busy: 4200 cycles of a 30 000-cycle workgroup at cfg 2
+    // (tools/timeline.py) where this takes a third of that.
+    float2 *Z = G;  // [R][64], behind the bins
+    if (t < 64 * epiR) {
+      int const r = t >> 6, l = t & 63;
+      int const q = (int)(__brev((unsigned)l) >> 26);
+      int const k = epiR * q + r;
+      v2f z = pk_cmul(epi_h, ld2(Xs + k));
+      if (isb && k != 0 && 2 * k != Ndec) {  // filter.c:242-248
+        v2f const other = pk_cmul(epi_h2, ld2(Xs + Ndec - k));
+        v2f const oc = (v2f){other.x, -other.y};
+        z = 2 * k < Ndec ? z + oc : z - oc;
+      }
+      auto stage = [&](auto mm, v2f w, bool first) {
+        constexpr int half = decltype(mm)::value;
+        v2f const v = first ? z : pk_cmul(z, w);
+        v2f const rr = (v2f){lane_xor<half>(v.x, l), lane_xor<half>(v.y, l)};
+        float const sg = __int_as_float(0x3f800000 | ((l & half) ? 0x80000000 : 0));
+        z = rfft::pk_fma(v, (v2f){sg, sg}, rr);
+      };
+      stage(std::integral_constant<int, 1>{}, z, true);
+      stage(std::integral_constant<int, 2>{}, epi_w[0], false);
+      stage(std::integral_constant<int, 4>{}, epi_w[1], false);
+      stage(std::integral_constant<int, 8>{}, epi_w[2], false);
+      stage(std::integral_constant<int, 16>{}, epi_w[3], false);
+      stage(std::integral_constant<int, 32>{}, epi_w[4], false);
+      z = pk_cmul(z, epi_post);
+      Z[64 * r + l] = make_float2(z.x, z.y);
+    }
+    __syncthreads();
+    if (t >= 64) return;
+    // lane m: the R-point inverse transform over r of Z_r[m] in registers (conjugate in, forward transform, conjugate
+    // out), then the samples the slave keeps (filter.c:131): n = m + 64 j >= N_dec - olen
+    float2 *o = pl.filt + ((size_t)c * g.max_blocks + b) * g.olen;
+    int const first = Ndec - g.olen;
+    auto combine = [&](auto rc) {
+      constexpr int R = decltype(rc)::value;
+      constexpr int bits = R == 2 ? 1 : R == 4 ? 2 : 3;
+      float2 v[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        float2 const zz = Z[64 * r + t];
+        v[(int)(__brev((unsigned)r) >> (32 - bits))] = make_float2(zz.x, -zz.y);
+      }
+      rfft::fft_dit<R>(v);
+#pragma unroll
+      for (int j = 0; j < R; j++) {
+        int const i = t + 64 * j - first;
+        if (i >= 0 && i < g.olen) o[i] = make_float2(v[j].x, -v[j].y);
+      }
+    };
+    if (epiR == 2)
+      combine(std::integral_constant<int, 2>{});
+    else if (epiR == 4)
+      combine(std::integral_constant<int, 4>{});
+    else
+      combine(std::integral_constant<int, 8>{});
+    KQ_STAMP(9);
+    return;
+  }
+  if constexpr (EPI != 0) return;  // (not reached: the host picks the instance by N/D)
   for (int p = t; p <= Ndec / 2; p += kT) {
     float2 gp = cmul(H[p], Xs[p]);
     if (p > 0 && p < Ndec / 2) {
@@ -767,6 +854,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
 
   float2 *o = pl.filt + ((size_t)c * g.max_blocks + b) * g.olen;
   for (int i = t; i < g.olen; i += kT) o[i] = G[Ndec - g.olen + i];  // filter.c:131
+  KQ_STAMP(9);
 }
 
 // N = 65536: what is left of a channel-block once its four sibling workgroups are done -- the response multiply,
@@ -871,12 +959,26 @@ void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
     hipLaunchKernelGGL(kernel, dim3(nchan, nblocks), dim3(kT), lds_bytes, s, g, ch, pl, paired ? window_paired : window, tw, tab,
                        spec_dump, spec_ch, chan_list, big);
   };
-  auto pick = [&](auto n0c, auto dumpc) {
+  int const epi = dump ? 0 : g.Ndec == 64 ? 1 : (g.Ndec >= 128 && g.Ndec <= 512) ? 2 : 0;
+  auto pick3 = [&](auto n0c, auto dumpc, auto epic) {
     constexpr bool kN0 = decltype(n0c)::value, kDump = decltype(dumpc)::value;
+    constexpr int kEpi = decltype(epic)::value;
     if (paired)
-      go(k_filter_full16k<kN0, kDump, true, true, 0>);
+      go(k_filter_full16k<kN0, kDump, true, true, 0, kEpi>);
     else
-      plain ? go(k_filter_full16k<kN0, kDump, true, false, 0>) : go(k_filter_full16k<kN0, kDump, false, false, 0>);
+      plain ? go(k_filter_full16k<kN0, kDump, true, false, 0, kEpi>) : go(k_filter_full16k<kN0, kDump, false, false, 0, kEpi>);
+  };
+  auto pick = [&](auto n0c, auto dumpc) {
+    if constexpr (decltype(dumpc)::value) {
+      pick3(n0c, dumpc, std::integral_constant<int, 0>{});
+    } else {
+      if (epi == 1)
+        pick3(n0c, dumpc, std::integral_constant<int, 1>{});
+      else if (epi == 2)
+        pick3(n0c, dumpc, std::integral_constant<int, 2>{});
+      else
+        pick3(n0c, dumpc, std::integral_constant<int, 0>{});
+    }
   };
   using T = std::true_type;
   using F = std::false_type;
@@ -905,11 +1007,11 @@ void launch_filter_full64k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
   auto pick = [&](auto n0c, auto dumpc) {
     constexpr bool kN0 = decltype(n0c)::value, kDump = decltype(dumpc)::value;
     if (!plain)
-      go(k_filter_full16k<kN0, kDump, false, false, 1>);
+      go(k_filter_full16k<kN0, kDump, false, false, 1, 0>);
     else if (paired)
-      swept ? go(k_filter_full16k<kN0, kDump, true, true, 2>) : go(k_filter_full16k<kN0, kDump, true, true, 1>);
+      swept ? go(k_filter_full16k<kN0, kDump, true, true, 2, 0>) : go(k_filter_full16k<kN0, kDump, true, true, 1, 0>);
     else
-      swept ? go(k_filter_full16k<kN0, kDump, true, false, 2>) : go(k_filter_full16k<kN0, kDump, true, false, 1>);
+      swept ? go(k_filter_full16k<kN0, kDump, true, false, 2, 0>) : go(k_filter_full16k<kN0, kDump, true, false, 1, 0>);
   };
   using T = std::true_type;
   using F = std::false_type;

@@ -99,7 +99,8 @@ def test_c_fanout_wrapper_stats_and_rccl_view(gpu):
         fan.post(i)
     st = fan.stats()
     assert st["world"] == 1 and st["rccl_ranks"] == 1 and st["rccl_version"] > 0, st
-    assert st["broadcasts"] >= 6 and st["broadcast_ms"] > 0, st
+    # (a broadcast still in flight when its slot is posted again is not timed: at least the last two are)
+    assert 2 <= st["broadcasts"] <= 8 and st["broadcast_ms"] > 0, st
     # the slot holds what the root put there
     back = torch.empty(2 * n, dtype=torch.float32, device="cuda")
     import ctypes

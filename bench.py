@@ -111,6 +111,55 @@ def cpu_baseline(name, geom, plan, iq_host, target_s, compute_n0=0):
                       (nchan, timed, name, "compute_n0 every block" if compute_n0 else "no compute_n0", cores, visible, cores, t)}
 
 
+class GpuState:
+    """Shader clock and socket power while the timed steps run, sampled from the amdgpu hwmon files every 20 ms: the same
+    build differs by a few per cent from one box of the pool to the next, and this says whether the clock or the power
+    cap is behind it.  One sampler per process; the card is the one whose clock is highest under load."""
+
+    def __init__(self):
+        import glob
+        self.dirs = [os.path.dirname(f) for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")]
+        self.samples = {d: [] for d in self.dirs}
+        self.stop = False
+        self.thread = None
+
+    @staticmethod
+    def _read(path):
+        try:
+            return float(open(path).read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self.stop:
+            for d in self.dirs:
+                f, p = self._read(d + "/freq1_input"), self._read(d + "/power1_input")
+                if f is not None:
+                    self.samples[d].append((f / 1e6, (p or 0.0) / 1e6))
+            time.sleep(0.02)
+
+    def start(self):
+        import threading
+        if self.dirs:
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+
+    def finish(self):
+        self.stop = True
+        if self.thread:
+            self.thread.join()
+        best = max(self.dirs, key=lambda d: max([s[0] for s in self.samples[d]] or [0]), default=None)
+        if not best or not self.samples[best]:
+            return None
+        f = [s[0] for s in self.samples[best]]
+        w = [s[1] for s in self.samples[best]]
+        cap = self._read(best + "/power1_cap")
+        return {"sclk_mhz": {"min": round(min(f)), "mean": round(sum(f) / len(f)), "max": round(max(f))},
+                "power_w": {"min": round(min(w)), "mean": round(sum(w) / len(w)), "max": round(max(w))},
+                "power_cap_w": round(cap / 1e6) if cap else None, "samples": len(f),
+                "source": "amdgpu hwmon freq1_input / power1_input, 20 ms apart over the timed steps"}
+
+
 def pmc_traffic(config, channels, blocks, fwd):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 read correction: tools/pmc_summary.py).  PMC collection
@@ -262,6 +311,9 @@ def main():
         dist.barrier()
     bank.enable_timing(1)      # HIP events around the filter kernel only: two stream operations per step
     bank.timing(reset=True)
+    gpu_state = GpuState() if rank == 0 else None
+    if gpu_state:
+        gpu_state.start()
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(spin + a.warmup + k)
@@ -269,6 +321,7 @@ def main():
     if dist:
         dist.barrier()
     t1 = time.perf_counter()
+    gpu_state = gpu_state.finish() if gpu_state else None
     elapsed = t1 - t0
     rank_ms = [elapsed / a.steps * 1e3] * 2      # fastest / slowest rank
     if dist:
@@ -419,6 +472,7 @@ def main():
             },
             "roofline": roofline(k_ms, bool(a.n0), fwd_used, tm2["demod_ms"] / max(1, tm2["filter_launches"])),
             "cold_first_steps_ms": cold,
+            "gpu_state": gpu_state,
             "ms_per_step_ranks": {"min": round(rank_ms[0], 4), "max": round(rank_ms[1], 4)},
             "fanout": "kq_fanout (C ABI, ncclBroadcast on the library's side stream)" if use_c else
                       "torch.distributed.broadcast (%s)" % a.backend,

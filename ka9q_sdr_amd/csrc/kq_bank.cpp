@@ -588,7 +588,11 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
         kq::launch_pruned_tables(b->stream, g, chd, b->chan_tw, C);
         b->chan_tw_dirty = false;
       }
-      kq::launch_filter_pruned(b->stream, g, chd, pl, window, b->chan_tw, C, (int)nblocks, swept);
+      {  // slots emptied by remove_channel are skipped: the launch goes over the list of active channels then
+        bool const holes = !b->list_active_host.empty();
+        kq::launch_filter_pruned(b->stream, g, chd, pl, window, b->chan_tw, holes ? (int)b->list_active_host.size() : C,
+                                 (int)nblocks, swept, holes ? b->list_active_dev : nullptr);
+      }
       // The pruned kernels assume one oscillator over the whole window.  For the first block after a retune the
       // history half still carries the old one: redo just those channel-blocks on the per-sample path.
       if (nret > 0) {
@@ -656,7 +660,11 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
                          b->pll_rings, b->pll_side, (int)nblocks, b->cfg.compute_n0);
   if (g.pl_n > 0 && !b->list_host[0].empty())
     kq::launch_pl_track(b->stream2, g, chd, pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), (int)nblocks);
-  if (b->pcm_on) kq::launch_pcm(b->stream2, g, pl, b->pcm, b->pcm_mask, C, (int)nblocks);
+  if (b->pcm_on) {
+    bool const holes = !b->list_active_host.empty();
+    kq::launch_pcm(b->stream2, g, pl, b->pcm, b->pcm_mask, holes ? (int)b->list_active_host.size() : C, (int)nblocks,
+                   holes ? b->list_active_dev : nullptr);
+  }
   if (b->stream2 != b->stream) HIP_TRY(hipEventRecord(b->ev_demod_done[pp], b->stream2));
   LAUNCH_CHECK("PLL / PL tone / PCM stage");
   b->pl = pl;  // what the pull functions read

@@ -158,7 +158,7 @@ void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const 
                          const float2 *tw, int nchan, int nblocks, const int *chan_list);
 bool pruned_supported(const Geom &g);
 void launch_filter_pruned(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
-                          const float2 *chan_tw, int nchan, int nblocks, bool swept);
+                          const float2 *chan_tw, int nchan, int nblocks, bool swept, const int *chan_list);
 void launch_pruned_tables(hipStream_t s, const Geom &g, const ChanDev &ch, float2 *chan_tw, int nchan);
 size_t demod_fm_lds_bytes(const Geom &g);
 void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw,
@@ -170,7 +170,9 @@ void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Plane
                     const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0);
 void launch_demod_pll(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_pll,
                       int n_pll, PllState *state, float2 *rings, float2 *side, int nblocks, int compute_n0);
-void launch_pcm(hipStream_t s, const Geom &g, const Planes &pl, short *pcm, unsigned *mask, int nchan, int nblocks);
+// chan_list (both): the active channels when kq_bank_remove_channel has left holes (nchan = its length), else null
+void launch_pcm(hipStream_t s, const Geom &g, const Planes &pl, short *pcm, unsigned *mask, int nchan, int nblocks,
+                const int *chan_list);
 void launch_pl_track(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_fm,
                      int n_fm, int nblocks);
 // single transforms for the compat surface

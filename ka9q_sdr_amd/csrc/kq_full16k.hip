@@ -50,7 +50,8 @@ __device__ unsigned long long kq_timeline[64][8][12];
 #define KQ_STAMP(i)                                                                        \
   do {                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                     \
-    if (blockIdx.y == 40 && (blockIdx.x & 15) == 0 && (threadIdx.x & 63) == 0)            \
+    if (blockIdx.y == (gridDim.y > 40 ? 40 : gridDim.y / 2) && (blockIdx.x & 15) == 0 && (blockIdx.x >> 4) < 64 &&      \
+        (threadIdx.x & 63) == 0)                                                           \
       kq_timeline[blockIdx.x >> 4][threadIdx.x >> 6][i] = clock64();                       \
     __builtin_amdgcn_sched_barrier(0);                                                     \
   } while (0)

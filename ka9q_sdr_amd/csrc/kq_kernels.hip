@@ -963,8 +963,9 @@ void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes
 // ---------------------------------------------------------------- PCM output stage
 // float -> clipped int16 in network byte order (audio.c:22-28, htons at audio.c:48,98) and the all-zero test per
 // 480-word chunk that decides whether the reference sends the packet (audio.c:49,99,105).  One wave per channel-block.
-__global__ void __launch_bounds__(64) k_pcm(Geom g, Planes pl, short *__restrict__ pcm, unsigned *__restrict__ mask) {
-  int const c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+__global__ void __launch_bounds__(64) k_pcm(Geom g, Planes pl, short *__restrict__ pcm, unsigned *__restrict__ mask,
+                                            const int *__restrict__ chan_list) {
+  int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   size_t const cb = (size_t)c * g.max_blocks + b;
   int const nout = pl.status[cb].nout;
   const float *a = pl.audio + cb * 2 * (size_t)g.olen;
@@ -993,8 +994,9 @@ __global__ void __launch_bounds__(64) k_pcm(Geom g, Planes pl, short *__restrict
   if (lane == 0) mask[cb] = m;
 }
 
-void launch_pcm(hipStream_t s, const Geom &g, const Planes &pl, short *pcm, unsigned *mask, int nchan, int nblocks) {
-  hipLaunchKernelGGL(k_pcm, dim3(nchan, nblocks), dim3(64), 0, s, g, pl, pcm, mask);
+void launch_pcm(hipStream_t s, const Geom &g, const Planes &pl, short *pcm, unsigned *mask, int nchan, int nblocks,
+                const int *chan_list) {
+  hipLaunchKernelGGL(k_pcm, dim3(nchan, nblocks), dim3(64), 0, s, g, pl, pcm, mask, chan_list);
 }
 
 // ---------------------------------------------------------------- single transforms (compat surface)

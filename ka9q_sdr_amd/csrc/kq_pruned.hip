@@ -540,7 +540,8 @@ __global__ void k_pruned_tables(Geom g, ChanDev ch, float *__restrict__ tab, int
 template <int NWAVES, int CPW, int R, bool SWEPT>
 __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident(Geom g, ChanDev ch, Planes pl,
                                                                  const float2 *__restrict__ window,
-                                                                 const float *__restrict__ tab, int nchan) {
+                                                                 const float *__restrict__ tab, int nchan,
+                                                                 const int *__restrict__ chan_list) {
   constexpr int ND = 64;
   constexpr int N = ND * R;  // compile time, so that LDS offsets are immediates
   constexpr int groups = R / 64;
@@ -565,8 +566,9 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident(Geom g, ChanDev
   double const m0 = (double)blk * g.L;
 
   for (int ci = 0; ci < CPW; ci++) {
-    int const c = __builtin_amdgcn_readfirstlane((blockIdx.x * NWAVES + wave) * CPW + ci);
-    if (c >= nchan) break;
+    int const idx = __builtin_amdgcn_readfirstlane((blockIdx.x * NWAVES + wave) * CPW + ci);
+    if (idx >= nchan) break;
+    int const c = chan_list ? __builtin_amdgcn_readfirstlane(chan_list[idx]) : idx;  // slots emptied by remove_channel are skipped
     const float *tc = tab + (size_t)c * Tab<ND>::kFloats;
     const float2 *tL = reinterpret_cast<const float2 *>(tc + Tab<ND>::kA + Tab<ND>::kT);
     double const f0 = ch.lo_freq[c], r = SWEPT ? ch.lo_rate[c] : 0.0;
@@ -662,7 +664,8 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident(Geom g, ChanDev
 template <int NWAVES, int R, bool SWEPT>
 __global__ void __launch_bounds__(NWAVES * 64) k_pruned_stream(Geom g, ChanDev ch, Planes pl,
                                                                const float2 *__restrict__ window,
-                                                               const float *__restrict__ tab, int nchan) {
+                                                               const float *__restrict__ tab, int nchan,
+                                                                 const int *__restrict__ chan_list) {
   constexpr int ND = 128, P = 4;
   constexpr int N = ND * R;
   constexpr int groups = R / 64;
@@ -677,7 +680,8 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_stream(Geom g, ChanDev c
   const float2 *win = window + (size_t)blk * g.L;
   double const m0 = (double)blk * g.L;
 
-  int const c = __builtin_amdgcn_readfirstlane(min((int)(blockIdx.x * NWAVES + wave), nchan - 1));
+  int const idx = __builtin_amdgcn_readfirstlane(min((int)(blockIdx.x * NWAVES + wave), nchan - 1));
+  int const c = chan_list ? __builtin_amdgcn_readfirstlane(chan_list[idx]) : idx;
   bool const live = (int)(blockIdx.x * NWAVES + wave) < nchan;  // idle waves still help loading the slices
   const float *tc = tab + (size_t)c * Tab<ND>::kFloats;
   const float2 *tL = reinterpret_cast<const float2 *>(tc + Tab<ND>::kA + Tab<ND>::kT);
@@ -752,7 +756,8 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_stream(Geom g, ChanDev c
 template <int NWAVES, int CPW>
 __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident256(Geom g, ChanDev ch, Planes pl,
                                                                     const float2 *__restrict__ window,
-                                                                    const float *__restrict__ tab, int nchan) {
+                                                                    const float *__restrict__ tab, int nchan,
+                                                                 const int *__restrict__ chan_list) {
   constexpr int ND = 256, P = 8, R = 64;
   constexpr int N = ND * R;
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -774,8 +779,9 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident256(Geom g, Chan
   for (int i = 0; i < 6; i++) th[i] = make_float2(1.f, 0.f);
 
   for (int ci = 0; ci < CPW; ci++) {
-    int const c = __builtin_amdgcn_readfirstlane((blockIdx.x * NWAVES + wave) * CPW + ci);
-    if (c >= nchan) break;
+    int const idx = __builtin_amdgcn_readfirstlane((blockIdx.x * NWAVES + wave) * CPW + ci);
+    if (idx >= nchan) break;
+    int const c = chan_list ? __builtin_amdgcn_readfirstlane(chan_list[idx]) : idx;  // slots emptied by remove_channel are skipped
     const float *tc = tab + (size_t)c * Tab<ND>::kFloats;
     const float2 *tL = reinterpret_cast<const float2 *>(tc + Tab<ND>::kA + Tab<ND>::kT);
     const float2 *H = ch.resp + (size_t)c * ND;
@@ -848,58 +854,58 @@ void launch_pruned_tables(hipStream_t s, const Geom &g, const ChanDev &ch, float
 namespace {
 template <int R, bool SWEPT>
 void launch_resident(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window, const float *tab,
-                     int nchan, int nblocks) {
+                     int nchan, int nblocks, const int *chan_list) {
   constexpr int NWAVES = 8, CPW = 4;
   size_t const lds_bytes = (size_t)64 * R * sizeof(float2) + (size_t)NWAVES * Tab<64>::kWaveF4 * sizeof(float4) +
                            32 * sizeof(float2);  // window, wave slots, inverse-transform twiddles
   ensure_dynamic_lds((const void *)k_pruned_resident<NWAVES, CPW, R, SWEPT>, (size_t)(lds_bytes));
   int const per_wg = NWAVES * CPW;
   hipLaunchKernelGGL((k_pruned_resident<NWAVES, CPW, R, SWEPT>), dim3((nchan + per_wg - 1) / per_wg, nblocks),
-                     dim3(NWAVES * 64), lds_bytes, s, g, ch, pl, window, tab, nchan);
+                     dim3(NWAVES * 64), lds_bytes, s, g, ch, pl, window, tab, nchan, chan_list);
 }
 
 void launch_resident256(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
-                        const float *tab, int nchan, int nblocks) {
+                        const float *tab, int nchan, int nblocks, const int *chan_list) {
   constexpr int NWAVES = 8, CPW = 4;
   size_t const lds_bytes = (size_t)16384 * sizeof(float2) + (size_t)NWAVES * 256 * sizeof(float2);
   ensure_dynamic_lds((const void *)k_pruned_resident256<NWAVES, CPW>, (size_t)(lds_bytes));
   int const per_wg = NWAVES * CPW;
   hipLaunchKernelGGL((k_pruned_resident256<NWAVES, CPW>), dim3((nchan + per_wg - 1) / per_wg, nblocks),
-                     dim3(NWAVES * 64), lds_bytes, s, g, ch, pl, window, tab, nchan);
+                     dim3(NWAVES * 64), lds_bytes, s, g, ch, pl, window, tab, nchan, chan_list);
 }
 
 template <bool SWEPT>
 void launch_stream(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window, const float *tab,
-                   int nchan, int nblocks) {
+                   int nchan, int nblocks, const int *chan_list) {
   constexpr int NWAVES = 8, R = 512;
   size_t const lds_bytes = (size_t)2 * 128 * 64 * sizeof(float2) + (size_t)NWAVES * (Tab<128>::kWaveF4 + 64) * sizeof(float4) +
                            128 * sizeof(float2);
   ensure_dynamic_lds((const void *)k_pruned_stream<NWAVES, R, SWEPT>, (size_t)(lds_bytes));
   hipLaunchKernelGGL((k_pruned_stream<NWAVES, R, SWEPT>), dim3((nchan + NWAVES - 1) / NWAVES, nblocks), dim3(NWAVES * 64),
-                     lds_bytes, s, g, ch, pl, window, tab, nchan);
+                     lds_bytes, s, g, ch, pl, window, tab, nchan, chan_list);
 }
 }  // namespace
 
 void launch_filter_pruned(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
-                          const float2 *chan_tw, int nchan, int nblocks, bool swept) {
+                          const float2 *chan_tw, int nchan, int nblocks, bool swept, const int *chan_list) {
   const float *tab = reinterpret_cast<const float *>(chan_tw);
   if (g.Ndec == 256) {  // unswept only (the host routes swept channels at this geometry to the full path)
-    launch_resident256(s, g, ch, pl, window, tab, nchan, nblocks);
+    launch_resident256(s, g, ch, pl, window, tab, nchan, nblocks, chan_list);
     return;
   }
   if (g.Ndec == 128) {
     if (swept)
-      launch_stream<true>(s, g, ch, pl, window, tab, nchan, nblocks);
+      launch_stream<true>(s, g, ch, pl, window, tab, nchan, nblocks, chan_list);
     else
-      launch_stream<false>(s, g, ch, pl, window, tab, nchan, nblocks);
+      launch_stream<false>(s, g, ch, pl, window, tab, nchan, nblocks, chan_list);
     return;
   }
 #define KQ_RES(RR)                                                           \
   if (g.D == RR) {                                                           \
     if (swept)                                                               \
-      launch_resident<RR, true>(s, g, ch, pl, window, tab, nchan, nblocks);  \
+      launch_resident<RR, true>(s, g, ch, pl, window, tab, nchan, nblocks, chan_list);  \
     else                                                                     \
-      launch_resident<RR, false>(s, g, ch, pl, window, tab, nchan, nblocks); \
+      launch_resident<RR, false>(s, g, ch, pl, window, tab, nchan, nblocks, chan_list); \
     return;                                                                  \
   }
   KQ_RES(256)

@@ -472,6 +472,51 @@ def test_channels_come_and_go(gpu):
     bank.close()
 
 
+@pytest.mark.parametrize("name", ["cfg4", "cfg5", "cfg2"])
+def test_holes_are_skipped_on_the_pruned_paths_and_in_the_pcm_stage(gpu, name):
+    """kq_bank_remove_channel on the pruned forward kernels (N/D = 64 resident, 128 streamed, 256 resident) with the PCM
+    stage on: the launches go over the list of active channels, the survivors keep their slots, state and output."""
+    import kq_oracle as ko
+    from common import oracle_cfg
+    g = wl.GEOMETRY[name]
+    fs, L, M = g["samprate"], g["L"], g["M"]
+    plan = wl.channel_plan(name, 11)
+    for p in plan:                       # unswept: cfg 2's N/D = 256 pruned kernel takes no sweep
+        p["second_lo"] -= p["doppler"]
+        p["doppler"] = p["doppler_rate"] = 0.0
+    per, ncalls = 2, 3
+    iq = wl.make_iq(fs, per * ncalls * L, seed=37)
+    chans = {c: ko.Channel(oracle_cfg(p, fs, L, M, g["D"])) for c, p in enumerate(plan)}
+    bank = kq.Bank(fs, L, M, g["D"], len(plan), per, fwd_mode=kq.KQ_FWD_PRUNED)
+    for p in plan:
+        bank.add_channel(bank_cfg(p))
+    bank.enable_pcm(True)
+    for call in range(ncalls):
+        if call == 1:
+            for c in (0, 4, 9):
+                bank.remove_channel(c)
+                chans.pop(c).close()
+        if call == 2:
+            bank.remove_channel(10)
+            chans.pop(10).close()
+        bank.push_iq(iq[call * per * L:(call + 1) * per * L])
+        assert bank.process() == per
+        for b in range(per):
+            x = iq[(call * per + b) * L:(call * per + b + 1) * L]
+            for c, ch in chans.items():
+                wa, ws, wf, _ = ch.block(x, want_filt=True)
+                assert rel_rms(bank.filter_output(c, b), wf) < FILT_TOL, (call, b, c)
+                ga = bank.audio(c, b)
+                if not (plan[c]["demod"] == "linear" and call == 0 and b == 0):
+                    assert rel_rms(ga, wa) < AUDIO_TOL, (call, b, c)
+                words, silent = bank.pcm(c, b)
+                want_words, want_silent, _ = ko.pcm_block(ga)
+                assert np.array_equal(words, want_words) and silent == want_silent, (call, b, c)
+    bank.close()
+    for ch in chans.values():
+        ch.close()
+
+
 def _random_plan(rng, fs, n):
     """Channels tuned on emitters of the synthetic band with randomised mode, filter, AGC and tuning details"""
     plan = []

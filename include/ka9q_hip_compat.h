@@ -11,7 +11,8 @@
  *   - `fwd_plan` / `rev_plan` are opaque device contexts (void *), not fftwf_plan.
  *   - response arrays handed to create_filter_output() must come from malloc()/calloc()
  *     (the reference frees them with fftwf_free, filter.c:271; here it is free()).
- *   - N = L+M-1 and N/decimate must be powers of two, N <= 16384.
+ *   - N = L+M-1 and N/decimate must be powers of two, 4 <= N <= 2^22 (past 16384 points the master's transform runs
+ *     in two passes through device memory), 4 <= N/decimate <= 16384.
  *   - This surface moves one block over PCIe per call; it exists for drop-in correctness.  The
  *     throughput path is the channel bank in ka9q_hip.h.
  */

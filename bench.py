@@ -253,6 +253,7 @@ def main():
     # Front-end fan-out (the reference's UDP multicast, multicast.c:143-237): rank 0 -> all over RCCL,
     # double buffered on a side stream so batch k+1 travels while batch k is processed
     use_c = a.fanout == "c" and (world == 1 or a.backend == "nccl")
+    fan_error = None
     if use_c:
         import ctypes
         from ka9q_sdr_amd.shard import CFanout, share_unique_id
@@ -264,8 +265,24 @@ def main():
                 raise RuntimeError("kq_fanout_unique_id: " + (lib.kq_last_error() or b"").decode())
             return buf.raw
 
-        ident = share_unique_id(make_id, rank, 0, dist, dev) if world > 1 else None
-        fan = CFanout(lib, dev_index, rank, world, nwin, ident)         # collective: every rank is here
+        fan, fan_error = None, None
+        try:
+            ident = share_unique_id(make_id, rank, 0, dist, dev) if world > 1 else None
+            fan = CFanout(lib, dev_index, rank, world, nwin, ident)     # collective: every rank is here
+        except Exception as e:                                            # e.g. librccl refusing the topology
+            fan_error = "%s: %s" % (type(e).__name__, e)
+        if world > 1:      # all ranks take the same road: one failure sends everybody to the torch twin (said in the line)
+            flag = torch.tensor([1 if fan is None else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                if fan is not None:
+                    fan.close()
+                    fan = None
+                fan_error = fan_error or "another rank's kq_fanout_create failed"
+        elif fan is None:
+            raise RuntimeError(fan_error)
+        use_c = fan is not None
+    if use_c:
         for i in range(2):                                                # the batch goes into both slots once
             fan.fill(i, bufs[0].data_ptr() if rank == 0 else None)
         cs = stream.cuda_stream
@@ -475,7 +492,7 @@ def main():
             "gpu_state": gpu_state,
             "ms_per_step_ranks": {"min": round(rank_ms[0], 4), "max": round(rank_ms[1], 4)},
             "fanout": "kq_fanout (C ABI, ncclBroadcast on the library's side stream)" if use_c else
-                      "torch.distributed.broadcast (%s)" % a.backend,
+                      "torch.distributed.broadcast (%s)%s" % (a.backend, ("; kq_fanout unavailable: " + fan_error) if fan_error else ""),
         }
         if fan_stats is not None:
             out["rccl"] = {"ranks": fan_stats["rccl_ranks"], "world": world, "version": fan_stats["rccl_version"],

@@ -1455,7 +1455,17 @@ int kq_bank_pull_planes_async(kq_bank *b, float *audio, kq_chan_status *status) 
   // of every channel-block's 2 * olen floats only the status.nout that hold samples travel (mono: half): the kernel
   // moves 16 bytes per lane, so olen must be a multiple of 4 for it -- other geometries take the plain copy
   size_t const sbytes = n * sizeof(kq_chan_status), s16 = sbytes & ~(size_t)15;
-  bool const rows_ok = b->g.olen % 4 == 0;
+  // (hipHostMalloc'ed memory is page aligned; anything less than 16 bytes takes the plain copies)
+  bool const aligned = (reinterpret_cast<uintptr_t>(audio) & 15) == 0 && (reinterpret_cast<uintptr_t>(status) & 15) == 0;
+  bool const rows_ok = b->g.olen % 4 == 0 && aligned;
+  if (!aligned) {
+    if (audio)
+      HIP_TRY(hipMemcpyAsync(audio, b->pl.audio, n * 2 * (size_t)b->g.olen * sizeof(float), hipMemcpyDeviceToHost, b->copy_out));
+    if (status) HIP_TRY(hipMemcpyAsync(status, b->pl.status, sbytes, hipMemcpyDeviceToHost, b->copy_out));
+    HIP_TRY(hipEventRecord(b->out_done, b->copy_out));
+    b->out_pending = true;
+    return 0;
+  }
   kq::launch_copy_to_host(b->copy_out, b->pl.audio, rows_ok ? audio : nullptr, 2 * b->g.olen, b->pl.status, status, n);
   LAUNCH_CHECK("plane copy");
   if (audio && !rows_ok)

@@ -211,13 +211,15 @@ def test_fm_hand_overs_across_many_blocks(gpu, per_call, D):
     assert seen_closed > 20 and seen_blanked > 20           # the case exercises what it is meant to
 
 
-@pytest.mark.parametrize("L,D,pruned", [(512, 16, 0), (512, 4, 0), (8192, 256, 0), (8192, 256, 1)])
+@pytest.mark.parametrize("L,D,pruned", [(512, 16, 0), (512, 4, 0), (8192, 256, 0), (8192, 256, 1), (32768, 512, 0)])
 def test_nan_sample_propagates_like_the_reference(gpu, L, D, pruned):
     """One NaN sample in the input: every comparison in the chain that the reference makes with a NaN operand (squelch
     `snr > 2`, blanking threshold, AGC `isnan(gain)` and `gain*level > headroom`, compute_n0's `< 2*mean`, the AM
     carrier filter that never recovers) has to fall the same way.  Outputs must be NaN in the same places, equal
     where finite, and the integer state identical.  N = 1024 with D = 16 runs the wave-per-channel demodulators, D = 4 the
-    generic ones; N = 16384 the register-resident full-spectrum kernel and the pruned kernel."""
+    generic ones; N = 16384 the register-resident full-spectrum kernel and the pruned kernel; N = 65536 the four sibling
+    workgroups per channel-block, whose compute_n0 then takes the spelled-out loops with two more exchanges between the
+    siblings (sum and count of the first pass)."""
     g = dict(samprate=192000 if L == 512 else 10000000, L=L, M=L + 1, D=D)
     fs = g["samprate"]
     nb = 9
@@ -353,3 +355,28 @@ def test_n0_smoothing_continues_from_a_seeded_value(gpu):
         assert abs(seeded.status(c, 2)["n0"] / seed - 1) < 30 * rate + 0.01 and abs(fresh.status(c, 2)["n0"] / raw0 - 1) < 0.5
     fresh.close()
     seeded.close()
+
+
+def test_digital_silence_at_65536_points(gpu):
+    """All-zero input at N = 65536 with compute_n0: the threshold is 0, so the four sibling workgroups take the
+    spelled-out loops (and their extra exchanges); n0 is 0/0 = NaN in the reference and here, then recovers."""
+    g = wl.GEOMETRY["cfg5"]
+    fs, L = g["samprate"], g["L"]
+    plan = wl.channel_plan("cfg5", 3)
+    nb = 4
+    iq = wl.make_iq(fs, nb * L, seed=9).copy()
+    iq[:2 * L] = 0
+    want = run_oracle(plan, g, iq, nb, compute_n0=1)
+    bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), nb, compute_n0=True)
+    for p in plan:
+        bank.add_channel(bank_cfg(p))
+    bank.push_iq(iq)
+    assert bank.process() == nb and bank.fwd_mode == kq.KQ_FWD_FULL
+    for c in range(len(plan)):
+        for b in range(nb):
+            gs, ws = bank.status(c, b), want[c][1][b]
+            assert np.isnan(gs["n0"]) == np.isnan(ws["n0"]), (c, b, gs["n0"], ws["n0"])
+            assert gs["nout"] == ws["nout"]
+            if b < 2:
+                assert not np.any(bank.filter_output(c, b)) and np.isnan(ws["n0"])
+    bank.close()

@@ -133,23 +133,16 @@ __device__ __forceinline__ void filter3(const Taps3 &t, float2 &r0, float2 &r1) 
 template <bool HB15, class Emit>
 __device__ __forceinline__ void run_stage(Level src, int n_prod, const GroupArgs &a, Emit emit) {
   int const npairs = (n_prod + 1) >> 1;
-  for (int p = threadIdx.x; p < npairs; p += 2 * kThreads) {
-    int const p2 = p + kThreads;
-    bool const has2 = p2 < npairs;
-    float2 r0, r1, q0, q1;
+  for (int p = threadIdx.x; p < npairs; p += kThreads) {
+    float2 r0, r1;
     if constexpr (HB15) {
       Taps15 const ta = read15(src, p);
-      Taps15 const tb = read15(src, has2 ? p2 : p);
       filter15(ta, a, r0, r1);
-      filter15(tb, a, q0, q1);
     } else {
       Taps3 const ta = read3(src, p);
-      Taps3 const tb = read3(src, has2 ? p2 : p);
       filter3(ta, r0, r1);
-      filter3(tb, q0, q1);
     }
     emit(p, r0, r1);
-    if (has2) emit(p2, q0, q1);
   }
 }
 

@@ -283,6 +283,7 @@ def main():
             raise RuntimeError(fan_error)
         use_c = fan is not None
     if use_c:
+        torch.cuda.synchronize()                                          # the batch is in bufs[0] before another stream reads it
         for i in range(2):                                                # the batch goes into both slots once
             fan.fill(i, bufs[0].data_ptr() if rank == 0 else None)
         cs = stream.cuda_stream

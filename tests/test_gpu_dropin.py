@@ -39,10 +39,11 @@ def harness(gpu):
     os.unlink(exe)
 
 
-def _signal(kind, seed):
+def _signal(kind, seed, geom=None):
     rng = np.random.default_rng(seed)
-    n = NB * L
-    t = np.arange(n) / FS
+    fs_, l_ = (geom or (FS, L, M, D))[:2]
+    n = NB * l_
+    t = np.arange(n) / fs_
     fc = 20000.0
     if kind == "am":
         env = 0.1 * (1 + 0.5 * np.cos(2 * np.pi * 1000 * t))
@@ -55,11 +56,12 @@ def _signal(kind, seed):
     return s.astype(np.complex64)
 
 
-def _run(exe, mode, iq, low, high, extra=()):
+def _run(exe, mode, iq, low, high, extra=(), geom=None):
+    fs_, l_, m_, d_ = geom or (FS, L, M, D)
     with tempfile.TemporaryDirectory() as d:
         fin, fout = os.path.join(d, "in.cf32"), os.path.join(d, "out.bin")
         iq.tofile(fin)
-        cmd = [exe, mode, str(FS), str(L), str(M), str(D), str(low), str(high), str(NB), fin, fout, "--lo", "-20000"]
+        cmd = [exe, mode, str(fs_), str(l_), str(m_), str(d_), str(low), str(high), str(NB), fin, fout, "--lo", "-20000"]
         r = subprocess.run(cmd + list(extra), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
         blob = open(fout, "rb").read()
@@ -79,9 +81,10 @@ def _run(exe, mode, iq, low, high, extra=()):
     return recs[:NB], tail
 
 
-def _oracle(p, iq):
-    cfg = oracle_cfg(p, FS, L, M, D, compute_n0=1)
-    return ko.run_chain(cfg, iq.reshape(NB, L), want_filt=False)
+def _oracle(p, iq, geom=None):
+    fs_, l_, m_, d_ = geom or (FS, L, M, D)
+    cfg = oracle_cfg(p, fs_, l_, m_, d_, compute_n0=1)
+    return ko.run_chain(cfg, iq.reshape(NB, l_), want_filt=False)
 
 
 AM = dict(demod="am", low=-5000.0, high=5000.0, second_lo=-20000.0, hangtime=0.0, recovery_rate=50.0)
@@ -141,3 +144,17 @@ def test_library_demod_linear_thread(harness, stereo):
     assert rel_rms(np.concatenate([a for a, _ in recs[1:]]), np.concatenate(auds[1:])) < 1e-5
     for b in range(1, NB):
         assert abs(recs[b][1]["gain"] / sts[b]["agc_gain"] - 1) < 2e-5
+
+
+def test_linear_thread_at_65536_points(harness):
+    """The cfg-5 geometry through the reference's own shell: master of 65536 points (the compat surface's two-pass
+    transform), demod_linear as radio.c starts it, compute_n0 from the bank's N = 65536 full-spectrum kernel
+    (linear.c:123-126) -- not from the host-side single-spectrum kernel the threads used past 16384 points until round 3."""
+    geom = (20000000, 32768, 32769, 512)
+    iq = _signal("usb", 6, geom)
+    recs, _ = _run(harness, "linear", iq, USB["low"], USB["high"], ["--hang", "1.1", "--recovery", "6"], geom)
+    auds, sts, _ = _oracle(USB, iq, geom)
+    assert all(len(a) == geom[1] // geom[3] for a, _ in recs)
+    assert rel_rms(np.concatenate([a for a, _ in recs][1:]), np.concatenate(auds[1:])) < 1e-5
+    for b in range(NB):
+        assert abs(recs[b][1]["n0"] / sts[b]["n0"] - 1) < 5e-3, (b, recs[b][1]["n0"], sts[b]["n0"])   # (a tie moves it 1e-3)

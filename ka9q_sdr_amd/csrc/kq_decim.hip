@@ -7,8 +7,8 @@
 //
 // Every stage is a FIR, so instead of the reference's per-stage shift registers the carried state is the tail of
 // each kernel's INPUT (zero at start, exactly like the zeroed states of hackrf.c:211-216): a workgroup re-derives
-// the few intermediate samples it needs from that halo.  Up to three stages (decimate by 8) are fused in one
-// kernel, staged through LDS, so HBM sees the input once plus 1/8 + 1/8 of it between kernels.  The arithmetic
+// the few intermediate samples it needs from that halo.  Up to four stages (decimate by 16) are fused in one
+// kernel, staged through LDS, so HBM sees the input once plus 1/16 + 1/16 of it between kernels.  The arithmetic
 // keeps the reference's operand order with FMA contraction switched off, so the
 // result is bit-identical to a scalar C evaluation of decimate.c.
 #include <hip/hip_runtime.h>
@@ -31,8 +31,10 @@ namespace {
 __device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
 __device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
 
-constexpr int kMaxFuse = 3;       // stages per kernel
-constexpr int kTileOut = 512;     // outputs of a fused group per workgroup
+constexpr int kMaxFuse = 4;       // stages per kernel
+// outputs of a fused group per workgroup: the level-0 tile is 4096 samples (+ halo) either way, i.e. 50 KB of LDS with
+// level 1 and three workgroups per CU
+__host__ __device__ constexpr int tile_out(int nstages) { return nstages >= 4 ? 256 : 512; }
 constexpr int kThreads = 512;     // (256 until round 3: the same 50 KB tile shared by eight waves instead of four -- 16 waves per CU
                                   //  instead of 12, 102 instead of 131 registers -- is 4 % faster; 1024 threads 9 % slower)
 
@@ -41,7 +43,10 @@ struct GroupArgs {
   const float2 *hist;  // the `halo` samples preceding in[0]
   float2 *out;         // n_out complex samples (scaled by `scale` when final)
   int16_t *out16;      // final group only, may be null: interleaved I,Q int16
-  float *partial;      // final group only: per-tile energy
+  unsigned long long *partial;  // final group only: per-tile energy, tagged: epoch << 32 | float bits
+  float *energy_out;   // final group only, may be null: the call's output energy, added up by the edge workgroup
+  int *err;            // pinned host word, set when a tile's energy never arrived
+  unsigned epoch;      // this call's tag
   long long n_out;
   int nstages;
   unsigned hb15_mask;  // bit s set: stage s of this group is the 15-tap filter, else 1-2-1
@@ -49,10 +54,26 @@ struct GroupArgs {
   int rot_step;        // Fs/4 rotation (first group only): phase(i) = (rot_phase0 + i*rot_step) & 3
   int rot_phase0;
   int rotate;
+  int in_once;         // `in` is the caller's buffer, read once: nontemporal loads
   int final;
   float scale;
   float c0, c1, c2, c3;
 };
+
+// The caller's samples are read once (plus a tile's 98-sample halo): nontemporal loads, which leave the cache to the
+// lines the stores are being merged in.  Measured on the byte mix of the first group (tools/hb_probe.hip): 6.35 against
+// 5.4 TB/s.  The later groups read what the group before them has just written (an eighth of the size, normally still in
+// the Infinity Cache) with plain loads: nontemporal there was 2 % slower on the whole call.
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef float vf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 load_once(const float4 *p) {
+  vf4 const w = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(p));
+  return make_float4(w.x, w.y, w.z, w.w);
+}
+__device__ __forceinline__ float2 load_once(const float2 *p) {
+  vf2 const w = __builtin_nontemporal_load(reinterpret_cast<const vf2 *>(p));
+  return make_float2(w.x, w.y);
+}
 
 __device__ __forceinline__ float2 rot90(float2 v, int phase) {
   // hackrf.c:272-289: multiply by j^phase -- an exact swap and sign flip, done without branches
@@ -155,12 +176,13 @@ using ic = std::integral_constant<int, N>;
 
 // Persistent workgroups: each walks tiles blockIdx.x, +gridDim.x, ... and issues the global loads of its next tile
 // (held in registers) before it starts filtering the current one, so HBM requests stay in flight during the LDS phases.
-// G = stages in this group; FINAL = last group (Filter_atten, int16, energy); PAIR = the group's halo is even, so a
-// thread can load two neighbouring samples (16 bytes) that land on the same element of the two planes; ROT = Fs/4
-// rotation on the way in.
+// G = stages in this group; FINAL = last group (Filter_atten, int16, energy); ROT = Fs/4 rotation on the way in.
+// A thread loads two neighbouring samples (16 bytes) that land on the same element of the two planes.  That needs an
+// even number of history samples in front of the tile: when the group's halo is odd (its first stage is then the 1-2-1
+// filter) the tile starts one sample earlier, which swaps the roles of the planes for stage 0 (`pad` below).
 // EDGE = this workgroup takes the tiles that need care -- the first (history buffer) and a ragged last one -- with
 // clamped indices and a pointer select; the other workgroups share the full tiles in between and need neither.
-template <int G, bool FINAL, bool PAIR, bool ROT, bool EDGE>
+template <int G, bool FINAL, bool ROT, bool EDGE>
 __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
   // halo_s: history (in level-s samples) that level s must hold ahead of a tile's first output
   int halo[G + 1];
@@ -168,43 +190,50 @@ __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
 #pragma unroll
   for (int s = G - 1; s >= 0; s--) halo[s] = 2 * halo[s + 1] + ((a.hb15_mask >> s) & 1 ? 14 : 1);
 
-  int const cap0 = plane_cap((kTileOut << G) + halo[0]);
+  constexpr int kTileOut = tile_out(G);
+  int const pad = halo[0] & 1;
+  int const cap0 = plane_cap((kTileOut << G) + halo[0] + pad);
   int const cap1 = G > 1 ? plane_cap((kTileOut << (G - 1)) + halo[G > 1 ? 1 : 0]) : 0;
-  Level const lvA{lds, lds + cap0};                        // level 0 (and level 2)
-  Level const lvB{lds + 2 * cap0, lds + 2 * cap0 + cap1};  // level 1
+  Level const lvA{lds, lds + cap0};                        // level 0 as loaded (and level 2)
+  Level const lvB{lds + 2 * cap0, lds + 2 * cap0 + cap1};  // level 1 (and level 3)
+  // level 0 as stage 0 sees it, local sample 0 = the first history sample it needs: with the pad sample in front, the
+  // even samples sit in the odd plane and the odd ones in the even plane, one element up
+  Level const lv0 = pad ? Level{lvA.odd, lvA.even + 1} : lvA;
 
   long long const ntiles = (a.n_out + kTileOut - 1) / kTileOut;
   constexpr int kMaxLen0 = (kTileOut << G) + 14 * ((1 << G) - 1);
-  constexpr int kPer = PAIR ? 2 : 1;
+  constexpr int kPer = 2;
   constexpr int kLoadIters = (kMaxLen0 + kPer * kThreads - 1) / (kPer * kThreads);
   constexpr int kFullIters = (kTileOut << G) / (kPer * kThreads);  // always inside a full tile, whatever the halo
-  using LoadT = std::conditional_t<PAIR, float4, float2>;
+  using LoadT = float4;
   LoadT v[kLoadIters];
   int const tid = threadIdx.x;
 
-  // Level 0 of tile t: global input index = t * kTileOut * 2^G - halo[0] + i, i < (tile << G) + halo[0].  All loads of a
-  // thread are issued back to back.
+  // Level 0 of tile t as loaded: global input index = t * kTileOut * 2^G - halo[0] - pad + i, i < (tile << G) + halo[0]
+  // + pad (an even count from an even index).  All loads of a thread are issued back to back.
   auto fetch = [&](long long t) {
     long long const first_out = t * kTileOut;
-    long long const lo0 = (first_out << G) - halo[0];
+    long long const lo0 = (first_out << G) - halo[0] - pad;
     if constexpr (!EDGE) {
-      int const len0 = (kTileOut << G) + halo[0];
+      int const len0 = (kTileOut << G) + halo[0] + pad;
       const LoadT *src = reinterpret_cast<const LoadT *>(a.in + lo0) + tid;
 #pragma unroll
       for (int it = 0; it < kLoadIters; it++) {
         if (it < kFullIters)
-          v[it] = src[it * kThreads];
-        else
-          v[it] = *reinterpret_cast<const LoadT *>(a.in + lo0 + min((it * kThreads + tid) * kPer, len0 - kPer));
+          v[it] = a.in_once ? load_once(src + it * kThreads) : src[it * kThreads];
+        else {
+          const LoadT *q = reinterpret_cast<const LoadT *>(a.in + lo0 + min((it * kThreads + tid) * kPer, len0 - kPer));
+          v[it] = a.in_once ? load_once(q) : *q;
+        }
       }
     } else {
       int const tile = (int)min((long long)kTileOut, a.n_out - first_out);
-      int const len0 = (tile << G) + halo[0];
+      int const len0 = (tile << G) + halo[0] + pad;
 #pragma unroll
       for (int it = 0; it < kLoadIters; it++) {
         int const i = min((it * kThreads + tid) * kPer, len0 - kPer);
         long long const gi = lo0 + i;
-        const float2 *src = gi >= 0 ? a.in + gi : a.hist + (a.halo + gi);
+        const float2 *src = gi >= 0 ? a.in + gi : a.hist + (a.halo + gi);  // hist[-1] exists (the pad sample, unused)
         v[it] = *reinterpret_cast<const LoadT *>(src);
       }
     }
@@ -223,28 +252,21 @@ __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
     int len[G + 1];
 #pragma unroll
     for (int s = 0; s <= G; s++) len[s] = (tile << (G - s)) + halo[s];
-    long long const lo0 = (first_out << G) - halo[0];
+    long long const lo0 = (first_out << G) - halo[0] - pad;
     // rotation phase of this thread's first sample; later iterations are a multiple of 4 samples further on
     int const ph = a.rot_phase0 + (int)((lo0 + tid * kPer) & 3) * a.rot_step;
     bool const full = !EDGE;
 #pragma unroll
     for (int it = 0; it < kLoadIters; it++) {
       int const i = (it * kThreads + tid) * kPer;
-      if ((it < kFullIters && full) || i < len[0]) {
-        if constexpr (PAIR) {
-          float2 w0 = make_float2(v[it].x, v[it].y), w1 = make_float2(v[it].z, v[it].w);
-          if constexpr (ROT) {
-            w0 = rot90(w0, ph);
-            w1 = rot90(w1, ph + a.rot_step);
-          }
-          lvA.even[it * kThreads + tid] = w0;
-          lvA.odd[it * kThreads + tid] = w1;
-        } else {
-          float2 w = v[it];
-          if constexpr (ROT) w = rot90(w, ph);
-          // kThreads is even, so a thread's samples all have the parity of its first one
-          ((tid & 1) ? lvA.odd : lvA.even)[(it * kThreads + tid) >> 1] = w;
+      if ((it < kFullIters && full) || i < len[0] + pad) {
+        float2 w0 = make_float2(v[it].x, v[it].y), w1 = make_float2(v[it].z, v[it].w);
+        if constexpr (ROT) {
+          w0 = rot90(w0, ph);
+          w1 = rot90(w1, ph + a.rot_step);
         }
+        lvA.even[it * kThreads + tid] = w0;
+        lvA.odd[it * kThreads + tid] = w1;
       }
     }
     __syncthreads();
@@ -255,7 +277,7 @@ __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
       constexpr int s = decltype(sc)::value;
       if constexpr (s < G) {
         constexpr bool last = s == G - 1;
-        Level const src = (s & 1) ? lvB : lvA;
+        Level const src = s == 0 ? lv0 : (s & 1) ? lvB : lvA;
         Level const dst = (s & 1) ? lvA : lvB;
         int const n_prod = len[s + 1];
         auto emit = [&](int p, float2 r0, float2 r1) {
@@ -301,6 +323,7 @@ __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
     do_stage(ic<0>{});
     do_stage(ic<1>{});
     do_stage(ic<2>{});
+    do_stage(ic<3>{});
 
     if constexpr (FINAL) {
       // fixed-order reduction: lanes by xor-shuffle, then waves in order
@@ -311,7 +334,10 @@ __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
       if (threadIdx.x == 0) {
         float e = 0;
         for (int w = 0; w < kThreads / 64; w++) e += wsum[w];
-        a.partial[t] = e;
+        // value and "this call's" in one word, so that the edge workgroup can take it without a release fence here (which
+        // would write back the L2 under every workgroup's output stores) and without a launch boundary
+        __hip_atomic_store(a.partial + t, ((unsigned long long)a.epoch << 32) | __float_as_uint(e), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -327,66 +353,75 @@ __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
     }
     __syncthreads();
     if (tid < a.halo) const_cast<float2 *>(a.hist)[tid] = hv;
+
+    if constexpr (FINAL) {
+      // Output energy (hackrf.c:308,325): the per-tile partials in a fixed order, whichever workgroup produced them and
+      // whenever.  Nobody waits for this workgroup, so the others finish regardless and the wait below ends; the bound
+      // only guards against a workgroup that died (a kernel cannot run longer than HBM lasts: 60 ms).
+      if (a.energy_out) {
+        __shared__ double dsum[kThreads / 64];
+        double acc = 0;
+        bool lost = false;
+        for (long long i = tid; i < ntiles; i += kThreads) {
+          unsigned long long w;
+          int polls = 0;
+          for (;;) {
+            w = __hip_atomic_load(a.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w >> 32) == a.epoch || ++polls > (1 << 20)) break;
+            __builtin_amdgcn_s_sleep(8);
+          }
+          if ((unsigned)(w >> 32) != a.epoch) {
+            lost = true;
+            w = 0x7fc00000u;  // NaN
+          }
+          acc += (double)__uint_as_float((unsigned)w);
+        }
+        if (lost) *a.err = 1;
+        for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+        if ((tid & 63) == 0) dsum[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+          double e = 0;
+          for (int w = 0; w < kThreads / 64; w++) e += dsum[w];
+          *a.energy_out = (float)e;
+        }
+      }
+    }
   }
 }
 
-// Output energy (hackrf.c:308,325): the per-tile partials added in a fixed order.  (Doing this in the group kernel
-// behind a "last workgroup" counter was measured slower: the release fence it needs writes back the L2 under every
-// workgroup's output stores.)
-__global__ __launch_bounds__(kThreads) void k_hb_energy(const float *__restrict__ partial, int n, float *out) {
-  __shared__ double dsum[kThreads / 64];
-  int const tid = threadIdx.x;
-  double acc = 0;
-  for (int i = tid; i < n; i += kThreads) acc += partial[i];
-  for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
-  if ((tid & 63) == 0) dsum[tid >> 6] = acc;
-  __syncthreads();
-  if (tid == 0) {
-    double e = 0;
-    for (int w = 0; w < kThreads / 64; w++) e += dsum[w];
-    *out = (float)e;
-  }
-}
-
-template <int G, bool FINAL, bool PAIR, bool ROT>
+template <int G, bool FINAL, bool ROT>
 __global__ __launch_bounds__(kThreads) void k_hb_group(GroupArgs a) {
   extern __shared__ float4 lds4[];
   float2 *lds = reinterpret_cast<float2 *>(lds4);
   if (blockIdx.x == 0)
-    hb_group_body<G, FINAL, PAIR, ROT, true>(a, lds);
+    hb_group_body<G, FINAL, ROT, true>(a, lds);
   else
-    hb_group_body<G, FINAL, PAIR, ROT, false>(a, lds);
+    hb_group_body<G, FINAL, ROT, false>(a, lds);
 }
 
-template <int G, bool FINAL, bool PAIR>
+template <int G, bool FINAL>
 void launch_group_r(const GroupArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st) {
   if (a.rotate)
-    hipLaunchKernelGGL((k_hb_group<G, FINAL, PAIR, true>), dim3(grid), dim3(kThreads), lds_bytes, st, a);
+    hipLaunchKernelGGL((k_hb_group<G, FINAL, true>), dim3(grid), dim3(kThreads), lds_bytes, st, a);
   else
-    hipLaunchKernelGGL((k_hb_group<G, FINAL, PAIR, false>), dim3(grid), dim3(kThreads), lds_bytes, st, a);
+    hipLaunchKernelGGL((k_hb_group<G, FINAL, false>), dim3(grid), dim3(kThreads), lds_bytes, st, a);
 }
 
 template <int G>
 void launch_group_g(const GroupArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st) {
-  bool const pair = (a.halo & 1) == 0;
-  if (a.final) {
-    if (pair)
-      launch_group_r<G, true, true>(a, grid, lds_bytes, st);
-    else
-      launch_group_r<G, true, false>(a, grid, lds_bytes, st);
-  } else {
-    if (pair)
-      launch_group_r<G, false, true>(a, grid, lds_bytes, st);
-    else
-      launch_group_r<G, false, false>(a, grid, lds_bytes, st);
-  }
+  if (a.final)
+    launch_group_r<G, true>(a, grid, lds_bytes, st);
+  else
+    launch_group_r<G, false>(a, grid, lds_bytes, st);
 }
 
 void launch_group(const GroupArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st) {
   switch (a.nstages) {
     case 1: launch_group_g<1>(a, grid, lds_bytes, st); break;
     case 2: launch_group_g<2>(a, grid, lds_bytes, st); break;
-    default: launch_group_g<3>(a, grid, lds_bytes, st); break;
+    case 3: launch_group_g<3>(a, grid, lds_bytes, st); break;
+    default: launch_group_g<4>(a, grid, lds_bytes, st); break;
   }
 }
 
@@ -395,7 +430,7 @@ struct Group {
   unsigned mask = 0;
   int halo = 0;
   int shift_in = 0;  // log2(input rate / final output rate)
-  float2 *hist = nullptr;  // the `halo` input samples preceding the next call
+  float2 *hist = nullptr;  // the `halo` input samples preceding the next call; hist[-2], hist[-1] are allocated (pad)
   float2 *out = nullptr;  // intermediate buffer (null for the last group)
 };
 
@@ -412,10 +447,13 @@ struct kq_decimator {
   float2 *in_dev = nullptr;   // staging for host-resident input
   float2 *out_dev = nullptr;  // staging for host-resident output
   int16_t *out16_dev = nullptr;
-  float *partial = nullptr;
+  unsigned long long *partial = nullptr;  // tagged per-tile energies of the last group
   float *energy_dev = nullptr;
+  int *err = nullptr;  // pinned host word the kernel sets when a tile's energy never arrived
+  unsigned epoch = 0;
   size_t n_partial = 0;
   unsigned num_cus = 256;
+  int max_fuse = kMaxFuse;
 };
 
 void kq_internal_set_error(const char *fmt, ...);
@@ -447,8 +485,9 @@ static int decim_alloc(kq_decimator *d) {
   int const S = c.log_decimate;
   int done = 0;
   while (done < S) {
-    Group g;
-    g.nstages = std::min(kMaxFuse, S - done);
+    d->groups.emplace_back();  // in the list before it owns anything, so that a failure below still frees it
+    Group &g = d->groups.back();
+    g.nstages = std::min(d->max_fuse, S - done);
     g.shift_in = S - done;
     for (int s = 0; s < g.nstages; s++) {
       int const j = S - 1 - (done + s);
@@ -458,16 +497,28 @@ static int decim_alloc(kq_decimator *d) {
     for (int s = g.nstages - 1; s >= 0; s--) need = 2 * need + ((g.mask >> s) & 1 ? 14 : 1);
     g.halo = need;
     done += g.nstages;
-    DEC_TRY(hipMalloc(&g.hist, sizeof(float2) * need));
-    DEC_TRY(hipMemsetAsync(g.hist, 0, sizeof(float2) * need, d->stream));
+    float2 *h = nullptr;
+    DEC_TRY(hipMalloc(&h, sizeof(float2) * (need + 2)));
+    g.hist = h + 2;
+    DEC_TRY(hipMemsetAsync(h, 0, sizeof(float2) * (need + 2), d->stream));
     if (done < S) DEC_TRY(hipMalloc(&g.out, sizeof(float2) * (c.max_out << (S - done))));
-    d->groups.push_back(g);
   }
-  d->n_partial = (c.max_out + kTileOut - 1) / kTileOut;
-  DEC_TRY(hipMalloc(&d->partial, sizeof(float) * d->n_partial));
+  d->n_partial = (c.max_out + tile_out(kMaxFuse) - 1) / tile_out(kMaxFuse);  // the smallest tile
+  DEC_TRY(hipMalloc(&d->partial, sizeof(unsigned long long) * d->n_partial));
+  DEC_TRY(hipMemsetAsync(d->partial, 0, sizeof(unsigned long long) * d->n_partial, d->stream));  // epoch 0 = never written
+  DEC_TRY(hipHostMalloc((void **)&d->err, sizeof(int), hipHostMallocDefault));
+  *d->err = 0;
   DEC_TRY(hipMalloc(&d->energy_dev, sizeof(float)));
   DEC_TRY(hipStreamSynchronize(d->stream));
   return 0;
+}
+
+// after a synchronisation: did the edge workgroup of some call give up waiting for a tile's energy?
+static bool decim_lost(kq_decimator *d) {
+  if (!d->err || !*d->err) return false;
+  *d->err = 0;
+  kq_internal_set_error("kq_decim: a workgroup's output energy never arrived (device fault?); the energy of that call is NaN");
+  return true;
 }
 
 extern "C" {
@@ -485,6 +536,7 @@ kq_decimator *kq_decim_create(const kq_decim_config *cfg) {
   d->coeffs[2] = -116. / 802;
   d->coeffs[1] = 33. / 802;
   d->coeffs[0] = -6. / 802;
+  if (const char *e = getenv("KQ_DECIM_FUSE")) d->max_fuse = std::max(1, std::min(kMaxFuse, atoi(e)));  // diagnostic
   if (decim_alloc(d) != 0) {
     kq_decim_destroy(d);
     return nullptr;
@@ -497,7 +549,7 @@ int kq_decim_destroy(kq_decimator *d) {
   if (!d) return -1;
   if (d->stream) (void)hipStreamSynchronize(d->stream);
   for (Group &g : d->groups) {
-    (void)hipFree(g.hist);
+    if (g.hist) (void)hipFree(g.hist - 2);
     (void)hipFree(g.out);
   }
   (void)hipFree(d->in_dev);
@@ -505,6 +557,7 @@ int kq_decim_destroy(kq_decimator *d) {
   (void)hipFree(d->out16_dev);
   (void)hipFree(d->partial);
   (void)hipFree(d->energy_dev);
+  if (d->err) (void)hipHostFree(d->err);
   if (d->own_stream) (void)hipStreamDestroy(d->stream);
   delete d;
   return 0;
@@ -545,6 +598,7 @@ int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t 
     final_out = d->out_dev;
     final16 = out_s16 ? d->out16_dev : nullptr;
   }
+  d->epoch++;
   size_t n_g_in = n_in;
   for (size_t gi = 0; gi < d->groups.size(); gi++) {
     Group &g = d->groups[gi];
@@ -555,6 +609,9 @@ int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t 
     a.out = last ? final_out : g.out;
     a.out16 = last ? final16 : nullptr;
     a.partial = last ? d->partial : nullptr;
+    a.energy_out = last && out_energy ? (on_device ? out_energy : d->energy_dev) : nullptr;
+    a.err = d->err;
+    a.epoch = d->epoch;
     a.n_out = (long long)(n_g_in >> g.nstages);
     a.nstages = g.nstages;
     a.hb15_mask = g.mask;
@@ -562,16 +619,18 @@ int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t 
     a.rotate = gi == 0 && (d->cfg.offset & 3) != 0;
     a.rot_step = d->cfg.offset & 3;
     a.rot_phase0 = d->rot_phase;
+    a.in_once = gi == 0;
     a.final = last;
     a.scale = d->atten;
     a.c0 = d->coeffs[0];
     a.c1 = d->coeffs[1];
     a.c2 = d->coeffs[2];
     a.c3 = d->coeffs[3];
+    int const kTileOut = tile_out(g.nstages);
     unsigned const ntiles = (unsigned)((a.n_out + kTileOut - 1) / kTileOut);
     // two planes each for level 0 and level 1
     int const h1 = (g.halo - ((g.mask & 1) ? 14 : 1)) / 2;
-    size_t const lds_elems = 2 * (size_t)plane_cap((kTileOut << g.nstages) + g.halo) +
+    size_t const lds_elems = 2 * (size_t)plane_cap((kTileOut << g.nstages) + g.halo + (g.halo & 1)) +
                              (g.nstages > 1 ? 2 * (size_t)plane_cap((kTileOut << (g.nstages - 1)) + h1) : 0);
     unsigned const resident = std::max(1u, std::min(16u, (unsigned)(160 * 1024 / (sizeof(float2) * lds_elems + 64))));
     unsigned const grid = std::min(ntiles, d->num_cus * resident) + 1;  // + the edge workgroup
@@ -581,19 +640,14 @@ int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t 
   }
   DEC_TRY(hipGetLastError());
   d->rot_phase = (int)((d->rot_phase + (long long)(n_in & 3) * (d->cfg.offset & 3)) & 3);
-  if (out_energy) {
-    unsigned const np = (unsigned)((n_out + kTileOut - 1) / kTileOut);
-    hipLaunchKernelGGL(k_hb_energy, dim3(1), dim3(kThreads), 0, d->stream, d->partial, (int)np, d->energy_dev);
-    if (on_device)
-      DEC_TRY(hipMemcpyAsync(out_energy, d->energy_dev, sizeof(float), hipMemcpyDeviceToDevice, d->stream));
-    else
-      DEC_TRY(hipMemcpyAsync(out_energy, d->energy_dev, sizeof(float), hipMemcpyDeviceToHost, d->stream));
-  }
+  if (out_energy && !on_device)
+    DEC_TRY(hipMemcpyAsync(out_energy, d->energy_dev, sizeof(float), hipMemcpyDeviceToHost, d->stream));
   if (!on_device) {
     DEC_TRY(hipMemcpyAsync(out_cf32, d->out_dev, sizeof(float2) * n_out, hipMemcpyDeviceToHost, d->stream));
     if (out_s16)
       DEC_TRY(hipMemcpyAsync(out_s16, d->out16_dev, sizeof(int16_t) * 2 * n_out, hipMemcpyDeviceToHost, d->stream));
     DEC_TRY(hipStreamSynchronize(d->stream));
+    if (decim_lost(d)) return -1;
   }
   return 0;
 }
@@ -602,7 +656,7 @@ int kq_decim_sync(kq_decimator *d) {
   kq::DeviceScope dev_scope_(d ? d->cfg.device : -1);
   if (!d) return -1;
   DEC_TRY(hipStreamSynchronize(d->stream));
-  return 0;
+  return decim_lost(d) ? -1 : 0;
 }
 
 int kq_decim_reset(kq_decimator *d) {

@@ -121,3 +121,31 @@ def test_random_cascades_bit_exact(gpu):
             assert np.array_equal(s16[ok, 0], ws16[ok, 0])
             np.testing.assert_allclose(e, we, rtol=5e-6)
         dec.close()
+
+
+@pytest.mark.parametrize("log_dec", [4, 6])
+def test_many_tiles_energy_on_device(gpu, log_dec):
+    """More tiles than resident workgroups, outputs and energy left on the device, three calls of different sizes: the
+    edge workgroup adds up the tagged per-tile energies of THIS call (a stale tile of the longer call before must not
+    count), and the outputs stay bit-exact whichever workgroup took which tile."""
+    import torch
+    from ka9q_sdr_amd import Decimator
+    max_out = 300_000 if log_dec == 4 else 80_000
+    dec = Decimator(log_dec, 8, 1, max_out=max_out, stream=torch.cuda.current_stream().cuda_stream)
+    fe = ko.FrontEndDecimator(log_dec, 8, 1)
+    y = torch.empty(max_out, 2, device="cuda", dtype=torch.float32)
+    s16 = torch.empty(max_out, 2, device="cuda", dtype=torch.int16)
+    e = torch.full((1,), -1.0, device="cuda", dtype=torch.float32)
+    for call, n_out in enumerate([max_out, max_out // 3 + 5, max_out - 255]):
+        x = _iq(n_out << log_dec, 40 + call)
+        xd = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).cuda()
+        dec.process_device(xd.data_ptr(), n_out, y.data_ptr(), s16.data_ptr(), e.data_ptr())
+        dec.sync()
+        wy, ws16, we = fe.process(x)
+        got = y[:n_out].cpu().numpy().view(np.complex64).ravel()
+        assert np.array_equal(got.view(np.uint32), wy.view(np.uint32)), call
+        assert np.array_equal(s16[:n_out].cpu().numpy(), ws16)
+        exact = float(np.sum(np.abs(wy.astype(np.complex128)) ** 2))
+        np.testing.assert_allclose(float(e.item()), exact, rtol=1e-6)
+        np.testing.assert_allclose(float(e.item()), we, rtol=2e-5)  # the oracle's own sum is sequential float32
+    dec.close()

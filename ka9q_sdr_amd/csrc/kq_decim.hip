@@ -43,9 +43,9 @@ struct GroupArgs {
   const float2 *hist;  // the `halo` samples preceding in[0]
   float2 *out;         // n_out complex samples (scaled by `scale` when final)
   int16_t *out16;      // final group only, may be null: interleaved I,Q int16
-  unsigned long long *partial;  // final group only: per-tile energy, tagged: epoch << 32 | float bits
+  unsigned long long *partial;  // final group only: per-workgroup energy, tagged: epoch << 32 | float bits
   float *energy_out;   // final group only, may be null: the call's output energy, added up by the edge workgroup
-  int *err;            // pinned host word, set when a tile's energy never arrived
+  int *err;            // pinned host word, set when a workgroup's energy never arrived
   unsigned epoch;      // this call's tag
   long long n_out;
   int nstages;
@@ -246,6 +246,7 @@ __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
   long long const end = EDGE ? ntiles : nfull;
   long long t = first;
   if (t < end) fetch(t);
+  float energy = 0.f;  // FINAL: this thread's share over all of the workgroup's tiles
   for (; t < end; t += step) {
     long long const first_out = t * kTileOut;
     int const tile = (int)min((long long)kTileOut, a.n_out - first_out);
@@ -272,7 +273,6 @@ __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
     __syncthreads();
     if (t + step < end) fetch(t + step);
 
-    float energy = 0.f;
     auto do_stage = [&](auto sc) {
       constexpr int s = decltype(sc)::value;
       if constexpr (s < G) {
@@ -324,21 +324,23 @@ __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
     do_stage(ic<1>{});
     do_stage(ic<2>{});
     do_stage(ic<3>{});
+  }
 
-    if constexpr (FINAL) {
-      // fixed-order reduction: lanes by xor-shuffle, then waves in order
-      __shared__ float wsum[kThreads / 64];
-      for (int off = 32; off; off >>= 1) energy += __shfl_xor(energy, off);
-      if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = energy;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        float e = 0;
-        for (int w = 0; w < kThreads / 64; w++) e += wsum[w];
-        // value and "this call's" in one word, so that the edge workgroup can take it without a release fence here (which
-        // would write back the L2 under every workgroup's output stores) and without a launch boundary
-        __hip_atomic_store(a.partial + t, ((unsigned long long)a.epoch << 32) | __float_as_uint(e), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
+  if constexpr (FINAL) {
+    // The workgroup's output energy, once per launch (per tile it was one more barrier on every tile's critical path):
+    // lanes by xor-shuffle, then waves in order.  Which tiles a workgroup takes depends only on the grid, so the sum is
+    // reproducible on a given device.  Value and "this call's" go out in one word, so that the edge workgroup can take it
+    // without a release fence here (which would write back the L2 under every workgroup's output stores) and without a
+    // launch boundary.  Every workgroup publishes, also one that found no tile.
+    __shared__ float wsum[kThreads / 64];
+    for (int off = 32; off; off >>= 1) energy += __shfl_xor(energy, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = energy;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float e = 0;
+      for (int w = 0; w < kThreads / 64; w++) e += wsum[w];
+      __hip_atomic_store(a.partial + blockIdx.x, ((unsigned long long)a.epoch << 32) | __float_as_uint(e), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
@@ -355,14 +357,13 @@ __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
     if (tid < a.halo) const_cast<float2 *>(a.hist)[tid] = hv;
 
     if constexpr (FINAL) {
-      // Output energy (hackrf.c:308,325): the per-tile partials in a fixed order, whichever workgroup produced them and
-      // whenever.  Nobody waits for this workgroup, so the others finish regardless and the wait below ends; the bound
+      // Output energy (hackrf.c:308,325): the workgroups' partials in a fixed order, whenever they arrive.  Nobody waits for this workgroup, so the others finish regardless and the wait below ends; the bound
       // only guards against a workgroup that died (a kernel cannot run longer than HBM lasts: 60 ms).
       if (a.energy_out) {
         __shared__ double dsum[kThreads / 64];
         double acc = 0;
         bool lost = false;
-        for (long long i = tid; i < ntiles; i += kThreads) {
+        for (int i = tid; i < (int)gridDim.x; i += kThreads) {
           unsigned long long w;
           int polls = 0;
           for (;;) {
@@ -390,8 +391,10 @@ __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
   }
 }
 
+// six waves per SIMD = three workgroups per CU, which is what the 50 KB tile allows: the FINAL instances otherwise take
+// 86-91 registers and run two (log_decimate 3 and 4: -5 % and -10 %)
 template <int G, bool FINAL, bool ROT>
-__global__ __launch_bounds__(kThreads) void k_hb_group(GroupArgs a) {
+__global__ __launch_bounds__(kThreads, 6) void k_hb_group(GroupArgs a) {
   extern __shared__ float4 lds4[];
   float2 *lds = reinterpret_cast<float2 *>(lds4);
   if (blockIdx.x == 0)
@@ -400,28 +403,20 @@ __global__ __launch_bounds__(kThreads) void k_hb_group(GroupArgs a) {
     hb_group_body<G, FINAL, ROT, false>(a, lds);
 }
 
-template <int G, bool FINAL>
-void launch_group_r(const GroupArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st) {
-  if (a.rotate)
-    hipLaunchKernelGGL((k_hb_group<G, FINAL, true>), dim3(grid), dim3(kThreads), lds_bytes, st, a);
-  else
-    hipLaunchKernelGGL((k_hb_group<G, FINAL, false>), dim3(grid), dim3(kThreads), lds_bytes, st, a);
-}
+using GroupKernel = void (*)(GroupArgs);
 
 template <int G>
-void launch_group_g(const GroupArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st) {
-  if (a.final)
-    launch_group_r<G, true>(a, grid, lds_bytes, st);
-  else
-    launch_group_r<G, false>(a, grid, lds_bytes, st);
+GroupKernel group_kernel_g(bool final, bool rotate) {
+  if (final) return rotate ? k_hb_group<G, true, true> : k_hb_group<G, true, false>;
+  return rotate ? k_hb_group<G, false, true> : k_hb_group<G, false, false>;
 }
 
-void launch_group(const GroupArgs &a, unsigned grid, size_t lds_bytes, hipStream_t st) {
-  switch (a.nstages) {
-    case 1: launch_group_g<1>(a, grid, lds_bytes, st); break;
-    case 2: launch_group_g<2>(a, grid, lds_bytes, st); break;
-    case 3: launch_group_g<3>(a, grid, lds_bytes, st); break;
-    default: launch_group_g<4>(a, grid, lds_bytes, st); break;
+GroupKernel group_kernel(int nstages, bool final, bool rotate) {
+  switch (nstages) {
+    case 1: return group_kernel_g<1>(final, rotate);
+    case 2: return group_kernel_g<2>(final, rotate);
+    case 3: return group_kernel_g<3>(final, rotate);
+    default: return group_kernel_g<4>(final, rotate);
   }
 }
 
@@ -432,6 +427,8 @@ struct Group {
   int shift_in = 0;  // log2(input rate / final output rate)
   float2 *hist = nullptr;  // the `halo` input samples preceding the next call; hist[-2], hist[-1] are allocated (pad)
   float2 *out = nullptr;  // intermediate buffer (null for the last group)
+  unsigned resident = 0;  // workgroups of this group's kernel that fit on a CU (for resident_for bytes of LDS)
+  size_t resident_for = 0;
 };
 
 }  // namespace
@@ -447,7 +444,7 @@ struct kq_decimator {
   float2 *in_dev = nullptr;   // staging for host-resident input
   float2 *out_dev = nullptr;  // staging for host-resident output
   int16_t *out16_dev = nullptr;
-  unsigned long long *partial = nullptr;  // tagged per-tile energies of the last group
+  unsigned long long *partial = nullptr;  // tagged per-workgroup energies of the last group's launch
   float *energy_dev = nullptr;
   int *err = nullptr;  // pinned host word the kernel sets when a tile's energy never arrived
   unsigned epoch = 0;
@@ -503,7 +500,7 @@ static int decim_alloc(kq_decimator *d) {
     DEC_TRY(hipMemsetAsync(h, 0, sizeof(float2) * (need + 2), d->stream));
     if (done < S) DEC_TRY(hipMalloc(&g.out, sizeof(float2) * (c.max_out << (S - done))));
   }
-  d->n_partial = (c.max_out + tile_out(kMaxFuse) - 1) / tile_out(kMaxFuse);  // the smallest tile
+  d->n_partial = (size_t)d->num_cus * 16 + 1;  // one per workgroup of the last launch
   DEC_TRY(hipMalloc(&d->partial, sizeof(unsigned long long) * d->n_partial));
   DEC_TRY(hipMemsetAsync(d->partial, 0, sizeof(unsigned long long) * d->n_partial, d->stream));  // epoch 0 = never written
   DEC_TRY(hipHostMalloc((void **)&d->err, sizeof(int), hipHostMallocDefault));
@@ -632,9 +629,18 @@ int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t 
     int const h1 = (g.halo - ((g.mask & 1) ? 14 : 1)) / 2;
     size_t const lds_elems = 2 * (size_t)plane_cap((kTileOut << g.nstages) + g.halo + (g.halo & 1)) +
                              (g.nstages > 1 ? 2 * (size_t)plane_cap((kTileOut << (g.nstages - 1)) + h1) : 0);
-    unsigned const resident = std::max(1u, std::min(16u, (unsigned)(160 * 1024 / (sizeof(float2) * lds_elems + 64))));
-    unsigned const grid = std::min(ntiles, d->num_cus * resident) + 1;  // + the edge workgroup
-    launch_group(a, grid, sizeof(float2) * lds_elems, d->stream);
+    // persistent workgroups: exactly as many as fit on the device at once (registers, wave slots and LDS all count -- an
+    // estimate from the LDS alone once launched half as many again as could run, and the stragglers ran alone)
+    GroupKernel const kern = group_kernel(g.nstages, last, a.rotate != 0);
+    size_t const lds_bytes = sizeof(float2) * lds_elems;
+    if (g.resident_for != lds_bytes) {
+      int nb = 0;
+      DEC_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, kThreads, lds_bytes));
+      g.resident = (unsigned)std::max(1, nb);
+      g.resident_for = lds_bytes;
+    }
+    unsigned const grid = std::min(ntiles, d->num_cus * g.resident) + 1;  // + the edge workgroup
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds_bytes, d->stream, a);
     src = g.out;
     n_g_in >>= g.nstages;
   }

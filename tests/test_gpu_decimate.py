@@ -126,7 +126,7 @@ def test_random_cascades_bit_exact(gpu):
 @pytest.mark.parametrize("log_dec", [4, 6])
 def test_many_tiles_energy_on_device(gpu, log_dec):
     """More tiles than resident workgroups, outputs and energy left on the device, three calls of different sizes: the
-    edge workgroup adds up the tagged per-tile energies of THIS call (a stale tile of the longer call before must not
+    edge workgroup adds up the tagged per-workgroup energies of THIS call (a stale word of the call before must not
     count), and the outputs stay bit-exact whichever workgroup took which tile."""
     import torch
     from ka9q_sdr_amd import Decimator

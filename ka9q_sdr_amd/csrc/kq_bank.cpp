@@ -132,7 +132,6 @@ struct kq_bank {
   bool rtp_retry = false;          // the last datagram was sent back with -2: the same one comes again
   uint16_t rtp_retry_seq = 0;
   uint32_t rtp_retry_ts = 0;
-  hipEvent_t ev_filter_done = nullptr;
   hipEvent_t ev_demod_done[2] = {nullptr, nullptr};
   kq::Planes pl2[2];
   double *osc_dev2[2] = {nullptr, nullptr};
@@ -177,7 +176,13 @@ struct kq_bank {
   // pinned staging slots so kq_bank_process never has to synchronise the stream
   static constexpr int kSlots = 4;
   unsigned char *stage_host[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+  // One marker per call on the main stream, recorded behind the filter launch(es) of the call that used the slot: the
+  // demodulator stream waits for it, the host waits for it before it refills the slot four calls later, and with
+  // kq_bank_enable_timing it closes the filter's time interval, which stage_t0 opened (a marker costs the stream ~5 us
+  // behind a long kernel, tools/marker_probe.hip; there were four per call)
   hipEvent_t stage_ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t stage_t0[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+  bool stage_timed[kSlots] = {false, false, false, false};
   int stage_next = 0;
   size_t stage_bytes = 0;
   float2 *spec_dump = nullptr;
@@ -375,8 +380,20 @@ int sync_all(kq_bank *b) {
   return 0;
 }
 
+// the filter interval of the call that last used the slot (its closing marker has completed)
+int harvest_slot(kq_bank *b, int slot) {
+  if (!b->stage_timed[slot]) return 0;
+  b->stage_timed[slot] = false;
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, b->stage_t0[slot], b->stage_ev[slot]));
+  b->acc.filter_ms += ms;
+  return 0;
+}
+
 int drain_timing(kq_bank *b) {
   if (sync_all(b)) return -1;
+  for (int k = 0; k < kq_bank::kSlots; k++)
+    if (harvest_slot(b, k)) return -1;
   std::vector<EventPair> *sets[3] = {&b->ev_filter, &b->ev_demod, &b->ev_ingest};
   double *dst[3] = {&b->acc.filter_ms, &b->acc.demod_ms, &b->acc.ingest_ms};
   for (int k = 0; k < 3; k++) {
@@ -415,7 +432,8 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
   size_t const C = b->chans.size(), Cmax = b->cfg.max_channels;
   int const slot = b->stage_next;
   b->stage_next = (slot + 1) % kq_bank::kSlots;
-  HIP_TRY(hipEventSynchronize(b->stage_ev[slot]));  // the kernel that last read this slot has completed
+  HIP_TRY(hipEventSynchronize(b->stage_ev[slot]));  // the call that last read this slot has got past its filter
+  if (harvest_slot(b, slot)) return -1;
   double *pl = reinterpret_cast<double *>(b->stage_host[slot]);
   double *ph = pl, *fr = pl + Cmax, *rt = pl + 2 * Cmax, *sp = pl + 3 * Cmax, *sf = pl + 4 * Cmax;
   double *hph = pl + 5 * Cmax, *hfr = pl + 6 * Cmax, *hrt = pl + 7 * Cmax;
@@ -564,15 +582,17 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   float2 *const paired = ((use16k || b->use64k) && plain && b->win_paired && b->fwd_mode != KQ_FWD_PRUNED) ? b->win_paired : nullptr;
   {
     Scope t(b, 2, b->stream);
-    kq::launch_block_energy(b->stream, window + (g.M - 1), g.L, (int)nblocks,
-                            reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power,
-                            b->stage_host[slot], b->osc_dev2[pp], nret ? ret_off + nret * sizeof(int) : 8 * Cmax * sizeof(double) + nblocks,
-                            paired, (int)(g.M - 1));
+    // the partial sums live behind the plane's max_blocks if_power values
+    kq::launch_block_energy_sum(b->stream, window + (g.M - 1), g.L, (int)nblocks, pl.if_power + b->cfg.max_blocks,
+                                b->stage_host[slot], b->osc_dev2[pp],
+                                nret ? ret_off + nret * sizeof(int) : 8 * Cmax * sizeof(double) + nblocks, paired, (int)(g.M - 1));
   }
-  HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
   LAUNCH_CHECK("IF power");
+  if (b->timing) {
+    HIP_TRY(hipEventRecord(b->stage_t0[slot], b->stream));
+    b->stage_timed[slot] = true;
+  }
   {
-    Scope t(b, 0, b->stream);
     // `redo`: the list names channels retuned since the last call, which need the general variant
     auto const full_launch = [&](hipStream_t st, const kq::Geom &gg, const kq::ChanDev &cd, const kq::Planes &pp, const float2 *win,
                                  const float2 *twp, int nch, int nbl, int n0, float2 *dump, int dump_ch, const int *list,
@@ -628,14 +648,16 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     b->acc.filter_launches++;
     b->acc.channel_blocks += (uint64_t)C * nblocks;
   }
-  if (b->stream2 != b->stream) {  // one stream: program order already is the dependency
-    HIP_TRY(hipEventRecord(b->ev_filter_done, b->stream));
-    HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_filter_done, 0));
-  }
+  HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
+  if (b->stream2 != b->stream) HIP_TRY(hipStreamWaitEvent(b->stream2, b->stage_ev[slot], 0));  // one stream: program order is the dependency
   if (b->out_pending) {  // kq_bank_pull_planes_async is still reading the audio / status planes of the last call
     HIP_TRY(hipStreamWaitEvent(b->stream2, b->out_done, 0));
     b->out_pending = false;
   }
+  // the IF-power recurrence over the call's blocks: one wave, consumed by the demodulators only, so it runs with them
+  // (under the next call's filter) and not in front of this call's
+  kq::launch_block_energy_iir(b->stream2, pl.if_power + b->cfg.max_blocks, g.L, (int)nblocks,
+                              reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power);
   {
     Scope t(b, 1, b->stream2);
     int const nfm = (int)b->list_host[0].size(), nam = (int)b->list_host[1].size(), nlin = (int)b->list_host[2].size();
@@ -864,7 +886,6 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   bool const overlap = !ov || atoi(ov) != 0;
   if (!overlap) b->stream2 = b->stream;
   if ((overlap && hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess) ||
-      hipEventCreateWithFlags(&b->ev_filter_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&b->ev_demod_done[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&b->ev_demod_done[1], hipEventDisableTiming) != hipSuccess) {
     set_err("second stream / event creation failed");
@@ -873,7 +894,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   b->stage_bytes = 8 * C * sizeof(double) + ((B + 7) & ~(size_t)7) + ((C * sizeof(int) + 7) & ~(size_t)7);  // copied in 8-byte words
   for (int k = 0; k < kq_bank::kSlots && !rc; k++) {
     if (hipHostMalloc((void **)&b->stage_host[k], b->stage_bytes, hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&b->stage_ev[k], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreate(&b->stage_ev[k]) != hipSuccess || hipEventCreate(&b->stage_t0[k]) != hipSuccess) {
       set_err("pinned staging allocation failed");
       rc = -1;
     }
@@ -908,7 +929,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     b->pl2[k].status = b->pl.status;
     rc |= dev_alloc(&b->pl2[k].filt, C * B * g.olen);
     rc |= dev_alloc(&b->pl2[k].n0raw, C * B);
-    rc |= dev_alloc(&b->pl2[k].if_power, B);
+    rc |= dev_alloc(&b->pl2[k].if_power, B * (1 + kq::kEnergySplitMax));  // + the partial sums of k_block_energy_sum
     b->pl2[k].plout = nullptr;
     if (g.pl_n > 0) rc |= dev_alloc(&b->pl2[k].plout, C * B * g.pl_l);
   }
@@ -995,8 +1016,8 @@ int kq_bank_destroy(kq_bank *b) {
   for (int k = 0; k < kq_bank::kSlots; k++) {
     if (b->stage_host[k]) (void)hipHostFree(b->stage_host[k]);
     if (b->stage_ev[k]) (void)hipEventDestroy(b->stage_ev[k]);
+    if (b->stage_t0[k]) (void)hipEventDestroy(b->stage_t0[k]);
   }
-  if (b->ev_filter_done) (void)hipEventDestroy(b->ev_filter_done);
   for (int k = 0; k < 2; k++)
     if (b->ev_demod_done[k]) (void)hipEventDestroy(b->ev_demod_done[k]);
   if (b->stream2 && b->stream2 != b->stream) (void)hipStreamDestroy(b->stream2);

@@ -317,7 +317,9 @@ __device__ __forceinline__ void hb_group_body(const GroupArgs &a, float2 *lds) {
           run_stage<true>(src, n_prod, a, emit);
         else
           run_stage<false>(src, n_prod, a, emit);
-        __syncthreads();
+        // the last stage of an even group reads level G-1 in lvB and writes to memory: the next tile's level 0 (lvA) can
+        // go in beside it, and the barrier behind that comes before anything writes lvB again
+        if constexpr (!last || (s & 1) == 0) __syncthreads();
       }
     };
     do_stage(ic<0>{});

@@ -116,11 +116,16 @@ void ensure_dynamic_lds(const void *kernel, size_t bytes);
 void launch_copy_to_host(hipStream_t s, const float *audio, float *haudio, int row, const kq_chan_status *status, void *hstatus,
                          size_t rows);
 void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size_t nsamples, float scale);
-// `update` points into the device copy of the parameter block that the first kernel makes from `params_host`
-// (pinned, device-visible) into `params_dev`
-void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nblocks, const unsigned char *update,
-                         float *energy_state, float *if_power, const void *params_host, void *params_dev,
-                         size_t params_bytes, float2 *paired, int hist);
+// IF power in two launches.  _sum (in front of the filter, whose row-paired samples it also writes): per-block partial
+// sums of |s|^2 into sums[nblocks * block_energy_split(L)], and the call's parameter block from `params_host` (pinned,
+// device-visible) into `params_dev`.  _iir (wherever the demodulators run, behind _sum): the recurrence over the blocks;
+// `update` points into the device copy of the parameter block.
+constexpr int kEnergySplitMax = 16;
+int block_energy_split(int L);
+void launch_block_energy_sum(hipStream_t s, const float2 *newsamples, int L, int nblocks, float *sums, const void *params_host,
+                             void *params_dev, size_t params_bytes, float2 *paired, int hist);
+void launch_block_energy_iir(hipStream_t s, const float *sums, int L, int nblocks, const unsigned char *update, float *energy_state,
+                             float *if_power);
 void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                         const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
                         const int *chan_list);
@@ -140,7 +145,7 @@ bool full16k_supported(const Geom &g);
 constexpr int kFull16kHalf = 16;
 constexpr int full16k_bin(int t) { return (t >> 5) + 32 * (t & 31); }
 // plain: no channel of the launch has a sweep rate or a retune pending (a leaner kernel variant serves that case);
-// window_paired: the same samples with their 512-sample rows interleaved in pairs (launch_block_energy writes it), which
+// window_paired: the same samples with their 512-sample rows interleaved in pairs (launch_block_energy_sum writes it), which
 // the plain variant loads 16 bytes at a time; null: it reads `window`
 void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,

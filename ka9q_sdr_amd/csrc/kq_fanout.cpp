@@ -66,6 +66,8 @@ struct kq_fanout {
   float2 *buf[2] = {nullptr, nullptr};
   hipEvent_t ready[2] = {nullptr, nullptr}, freed[2] = {nullptr, nullptr};
   size_t count[2] = {0, 0};
+  hipStream_t release_stream[2] = {nullptr, nullptr};  // no communicator: a release whose marker has not been recorded yet
+  bool release_pending[2] = {false, false};
   // broadcast timing: events around ncclBroadcast on the side stream, read back when the slot is posted again
   hipEvent_t t0[2] = {nullptr, nullptr}, t1[2] = {nullptr, nullptr};
   bool timed[2] = {false, false};
@@ -194,13 +196,22 @@ int kq_fanout_post(kq_fanout *f, int slot, const void *src, size_t nsamples, int
   }
   kq::DeviceScope scope(f->device);
   harvest(f, slot);
+  bool const copies = f->rank == f->root && src != f->buf[slot];
+  if (!f->comm && !copies) {  // a world of one refilling its slot in place: nothing moves, nothing to order
+    f->count[slot] = nsamples;
+    return 0;
+  }
   // the slot's previous consumer (kq_fanout_release) must be done before it is overwritten
+  if (f->release_pending[slot]) {  // (a world of one puts its marker on the consumer's stream only now that it is needed)
+    f->release_pending[slot] = false;
+    if (hipError_t e = hipEventRecord(f->freed[slot], f->release_stream[slot]); e != hipSuccess)
+      return fail("kq_fanout_post: hipEventRecord", e);
+  }
   if (hipError_t e = hipStreamWaitEvent(f->side, f->freed[slot], 0); e != hipSuccess) return fail("kq_fanout_post: hipStreamWaitEvent", e);
-  if (f->rank == f->root) {
+  if (copies) {
     hipMemcpyKind const kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    if (src != f->buf[slot])
-      if (hipError_t e = hipMemcpyAsync(f->buf[slot], src, nsamples * sizeof(float2), kind, f->side); e != hipSuccess)
-        return fail("kq_fanout_post: copy into the slot", e);
+    if (hipError_t e = hipMemcpyAsync(f->buf[slot], src, nsamples * sizeof(float2), kind, f->side); e != hipSuccess)
+      return fail("kq_fanout_post: copy into the slot", e);
   }
   if (f->comm) {
     (void)hipEventRecord(f->t0[slot], f->side);
@@ -237,6 +248,14 @@ const void *kq_fanout_acquire(kq_fanout *f, int slot, void *consumer_stream, siz
 int kq_fanout_release(kq_fanout *f, int slot, void *consumer_stream) {
   if (!f || slot < 0 || slot > 1) return -1;
   kq::DeviceScope scope(f->device);
+  if (!f->comm) {
+    // Without a communicator the slot is only ever overwritten by a copy the same host thread posts: the marker (~5 us of
+    // the consumer's stream behind a long kernel, tools/marker_probe.hip) is left until such a post needs it.  It then
+    // lands behind whatever else the consumer stream has been given meanwhile, which only waits longer.
+    f->release_stream[slot] = (hipStream_t)consumer_stream;
+    f->release_pending[slot] = true;
+    return 0;
+  }
   if (hipError_t e = hipEventRecord(f->freed[slot], (hipStream_t)consumer_stream); e != hipSuccess)
     return fail("kq_fanout_release: hipEventRecord", e);
   return 0;

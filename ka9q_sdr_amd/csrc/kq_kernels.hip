@@ -59,43 +59,48 @@ void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size
   hipLaunchKernelGGL(k_ingest, dim3((unsigned)blocks), dim3(threads), 0, s, src, format, dst, nsamples, gain);
 }
 
-// Sum |s|^2 over the L new samples of each block (radio.c:123).  The workgroups behind the nblocks summing ones carry
+// Sum |s|^2 over the L new samples of each block (radio.c:123), `split` workgroups per block (a block alone is 15 trips
+// of one workgroup at cfg 4: latency, with 32 of 256 CUs busy), each taking every split-th trip of 1024 samples and
+// leaving its partial sum in sums[block * split + part].  The workgroups behind the summing ones carry
 // the call's parameter block (oscillator planes + update flags) from the pinned host staging slot into device
 // memory, 8 bytes per thread straight over the bus: a hipMemcpyAsync in front of this kernel cost ~25 us of idle
 // stream per call (copy-engine start-up), this costs nothing.
-// Workgroups 0 .. nblocks-1: energy of one block's new samples; then the copy of the call's staged parameters; then
+// Workgroups 0 .. nblocks*split-1: energy; then the copy of the call's staged parameters; then
 // (paired != null) the window's history rows.  `paired`: the samples written out once more with their 512-sample rows
 // interleaved in pairs, for k_filter_full16k's 16-byte loads (kq_full16k.hip: out[1024 r + 2 c + e] = in[512 (2 r + e)
 // + c]) -- the kernel reads every new sample anyway.  L and hist are multiples of 1024 then.
-__global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *__restrict__ sums, int nblocks,
+__global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *__restrict__ sums, int nblocks, int split,
                                    const unsigned long long *__restrict__ params_host,
                                    unsigned long long *__restrict__ params_dev, unsigned nwords, int copy_wgs,
                                    float2 *__restrict__ paired, int hist) {
   int const pcol = 2 * (threadIdx.x & 511) + (threadIdx.x >> 9);  // place of sample (row parity, column) within its pair of rows
-  if ((int)blockIdx.x >= nblocks + copy_wgs) {  // history: copy only, 8192 samples per workgroup
-    int const base = ((int)blockIdx.x - nblocks - copy_wgs) * 8192;
+  int const nsum = nblocks * split;
+  if ((int)blockIdx.x >= nsum + copy_wgs) {  // history: copy only, 8192 samples per workgroup
+    int const base = ((int)blockIdx.x - nsum - copy_wgs) * 8192;
     for (int j = 0; j < 8 && base + 1024 * j < hist; j++) paired[base + 1024 * j + pcol] = (x - hist)[base + 1024 * j + threadIdx.x];
     return;
   }
-  if ((int)blockIdx.x >= nblocks) {
-    unsigned const i = (blockIdx.x - nblocks) * blockDim.x + threadIdx.x;
+  if ((int)blockIdx.x >= nsum) {
+    unsigned const i = (blockIdx.x - nsum) * blockDim.x + threadIdx.x;
     if (i < nwords) params_dev[i] = params_host[i];
     return;
   }
   __shared__ float red_f[16];
   __shared__ int red_i[16];
-  const float2 *p = x + (size_t)blockIdx.x * L;
+  int const blk = (int)blockIdx.x / split, part = (int)blockIdx.x % split;
+  const float2 *p = x + (size_t)blk * L;
   float acc = 0;
   int dummy = 0;
+  int const first = part * (int)blockDim.x + (int)threadIdx.x, stride = split * (int)blockDim.x;
   if (paired) {
-    float2 *o = paired + hist + (size_t)blockIdx.x * L;
-    for (int i = threadIdx.x; i < L; i += blockDim.x) {  // blockDim.x = 1024 = one pair of rows per trip
+    float2 *o = paired + hist + (size_t)blk * L;
+    for (int i = first; i < L; i += stride) {  // blockDim.x = 1024 = one pair of rows per trip
       float2 const v = p[i];
       acc += cnrm(v);
       o[(i - (int)threadIdx.x) + pcol] = v;
     }
   } else {
-    for (int i = threadIdx.x; i < L; i += blockDim.x) acc += cnrm(p[i]);
+    for (int i = first; i < L; i += stride) acc += cnrm(p[i]);
   }
   block_sum_fi(acc, dummy, red_f, red_i);
   if (threadIdx.x == 0) sums[blockIdx.x] = acc;
@@ -103,27 +108,36 @@ __global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *_
 // E <- 0.5*(E + sum); if_power = E / L  (the accumulator is halved, never cleared: radio.c:143-145).
 // A block whose last sample came from the lost-packet zero fill completes inside radio.c:94-98,
 // which runs the filter but leaves block_energy and if_power alone: update[b] == 0 marks those.
-__global__ void k_block_energy_iir(const float *sums, const unsigned char *__restrict__ update, int nblocks, int L,
-                                   float *__restrict__ state, float *if_power) {
-  // one wave: fetch 64 sums/flags at a time in parallel, then run the (inherently serial) recurrence out of
-  // registers via readlane
+__global__ void k_block_energy_iir(const float *__restrict__ sums, int split, const unsigned char *__restrict__ update,
+                                   int nblocks, int L, float *__restrict__ state, float *__restrict__ if_power) {
+  // one wave: fetch 64 blocks' sums and flags at a time in parallel, run the (inherently serial) recurrence out of
+  // registers via readlane -- two additions' worth per block -- and divide once, in parallel, at the end
   int const lane = threadIdx.x;
   float e = state[0], last = state[1];
   for (int base = 0; base < nblocks; base += 64) {
     int const i = base + lane;
-    float const sm = i < nblocks ? sums[i] : 0.f;
+    float sm = 0.f;
+    if (i < nblocks)
+      for (int k = 0; k < split; k++) sm += sums[i * split + k];  // the parts in order
     int const up = i < nblocks ? update[i] : 0;
-    float mine = 0.f;
+    float e_upd = 0.f, mine_e = 0.f;  // the accumulator as the last updating block left it; the same as of this lane's block
+    bool any = false, mine_any = false;
     int const cnt = min(64, nblocks - base);
     for (int k = 0; k < cnt; k++) {  // k is wave-uniform: v_readlane, not a trip through the LDS crossbar
       e += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), k));
       if (__builtin_amdgcn_readlane(up, k)) {
         e *= 0.5f;
-        last = e / L;
+        e_upd = e;
+        any = true;
       }
-      if (lane == k) mine = last;
+      if (lane == k) {
+        mine_e = e_upd;
+        mine_any = any;
+      }
     }
+    float const mine = mine_any ? mine_e / L : last;  // blocks before the chunk's first update keep what came before
     if (i < nblocks) if_power[i] = mine;
+    if (any) last = e_upd / L;
   }
   if (lane == 0) {
     state[0] = e;
@@ -131,17 +145,26 @@ __global__ void k_block_energy_iir(const float *sums, const unsigned char *__res
   }
 }
 
-void launch_block_energy(hipStream_t s, const float2 *newsamples, int L, int nblocks, const unsigned char *update,
-                         float *energy_state, float *if_power, const void *params_host, void *params_dev,
-                         size_t params_bytes, float2 *paired, int hist) {
-  // if_power doubles as scratch for the per-block sums: the IIR pass reads sums[b] before writing if_power[b]
+int block_energy_split(int L) {
+  int const trips = (L + 1023) / 1024;
+  return std::max(1, std::min(kEnergySplitMax, (trips + 2) / 3));
+}
+
+void launch_block_energy_sum(hipStream_t s, const float2 *newsamples, int L, int nblocks, float *sums, const void *params_host,
+                             void *params_dev, size_t params_bytes, float2 *paired, int hist) {
   unsigned const nwords = (unsigned)((params_bytes + 7) / 8);
   int const copy_wgs = (int)((nwords + 1023) / 1024);
   int const hist_wgs = paired ? (hist + 8191) / 8192 : 0;
-  hipLaunchKernelGGL(k_block_energy_sum, dim3(nblocks + copy_wgs + hist_wgs), dim3(1024), 0, s, newsamples, L, if_power, nblocks,
-                     static_cast<const unsigned long long *>(params_host), static_cast<unsigned long long *>(params_dev),
+  int const split = block_energy_split(L);
+  hipLaunchKernelGGL(k_block_energy_sum, dim3(nblocks * split + copy_wgs + hist_wgs), dim3(1024), 0, s, newsamples, L, sums, nblocks,
+                     split, static_cast<const unsigned long long *>(params_host), static_cast<unsigned long long *>(params_dev),
                      nwords, copy_wgs, paired, hist);
-  hipLaunchKernelGGL(k_block_energy_iir, dim3(1), dim3(64), 0, s, if_power, update, nblocks, L, energy_state, if_power);
+}
+
+void launch_block_energy_iir(hipStream_t s, const float *sums, int L, int nblocks, const unsigned char *update, float *energy_state,
+                             float *if_power) {
+  hipLaunchKernelGGL(k_block_energy_iir, dim3(1), dim3(64), 0, s, sums, block_energy_split(L), update, nblocks, L, energy_state,
+                     if_power);
 }
 
 // Device planes -> pinned host memory, 16 bytes per thread and trip, by a handful of workgroups that stay resident

@@ -125,7 +125,10 @@ struct kq_bank {
   int fwd_mode = KQ_FWD_FULL;
   // The demodulators are latency-bound and independent of the next batch's filter pass, so they run on a
   // second stream: filter(k+1) overlaps demod(k).  Planes the two stages hand over are double buffered.
-  hipStream_t stream2 = nullptr;
+  hipStream_t stream2 = nullptr;   // demodulators of a call that overlaps the next call's filter pass (== stream: never)
+  int overlap_mode = -1;           // KQ_DEMOD_OVERLAP: 0 never, 1 always, unset (-1) per call, see run_blocks
+  bool demod_overlapped[2] = {false, false};  // by call parity: ev_demod_done[parity] was recorded on stream2
+  bool pulled_since_call = false;  // kq_bank_pull_planes_async since the last call: the host streams planes out
   // front-end packet bookkeeping (struct rtp_state + demod->input.samples)
   kq_rtp_counters rtp{};
   bool rtp_init = false;
@@ -553,7 +556,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   // this parity's hand-over planes were last read by the demodulators two calls ago
   // (asked of the host first: a wait on another stream's event costs the stream a barrier packet, several microseconds
   // of idle device even when the event fired long ago -- and two calls later it always has)
-  if (b->stream2 != b->stream && hipEventQuery(b->ev_demod_done[pp]) != hipSuccess)
+  if (b->demod_overlapped[pp] && hipEventQuery(b->ev_demod_done[pp]) != hipSuccess)
     HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[pp], 0));
   int slot = 0, nret = 0;
   if (stage_call_params(b, b->n_abs - (g.M - 1), update_host, nblocks, &slot, &nret)) return -1;
@@ -649,45 +652,63 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     b->acc.channel_blocks += (uint64_t)C * nblocks;
   }
   HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
-  if (b->stream2 != b->stream) HIP_TRY(hipStreamWaitEvent(b->stream2, b->stage_ev[slot], 0));  // one stream: program order is the dependency
+  // Where the demodulators of this call run.  On a second stream they overlap the next call's filter pass -- but that
+  // kernel leaves no room beside it (500 of a SIMD's 512 registers), so what they take it loses, and at N = 65536 a
+  // displaced sibling workgroup stalls the three that wait for it.  Measured on one box (tools/ab_env_rows.sh,
+  // tools/ab_hostio.sh; ms per step overlapped / not): cfg 4 1.432 / 1.432-1.439, pruned 0.821 / 0.819, cfg 2 0.475 /
+  // 0.469, cfg 5 1.31 / 1.15 -- but cfg 3 1.464 / 1.488 (the AGC recurrence of an AM or SSB channel is one long thin wave)
+  // and, with the planes streamed to the host after every call, 1.54 / 1.60-1.76 (the copy kernel then has the whole next
+  // filter pass to hide under).  KQ_DEMOD_OVERLAP=0 / 1 forces either.
+  bool const agc_channels = !b->list_host[1].empty() || !b->list_host[2].empty();
+  bool const overlap = b->stream2 != b->stream &&
+                       (b->overlap_mode == 1 || (b->overlap_mode < 0 && !b->use64k && (b->pulled_since_call || agc_channels)));
+  b->pulled_since_call = false;
+  hipStream_t const ds = overlap ? b->stream2 : b->stream;
+  int const prev = pp ^ 1;
+  if (overlap)
+    HIP_TRY(hipStreamWaitEvent(ds, b->stage_ev[slot], 0));  // behind this call's filter, hence behind the last call's demodulators if they ran on the main stream
+  else if (b->calls > 0 && b->demod_overlapped[prev])
+    HIP_TRY(hipStreamWaitEvent(ds, b->ev_demod_done[prev], 0));  // the channel state they carry
   if (b->out_pending) {  // kq_bank_pull_planes_async is still reading the audio / status planes of the last call
-    HIP_TRY(hipStreamWaitEvent(b->stream2, b->out_done, 0));
+    HIP_TRY(hipStreamWaitEvent(ds, b->out_done, 0));
     b->out_pending = false;
   }
-  // the IF-power recurrence over the call's blocks: one wave, consumed by the demodulators only, so it runs with them
-  // (under the next call's filter) and not in front of this call's
-  kq::launch_block_energy_iir(b->stream2, pl.if_power + b->cfg.max_blocks, g.L, (int)nblocks,
+  // the IF-power recurrence over the call's blocks: one wave, consumed by the demodulators only, so it runs with them and
+  // not in front of the filter (folded into the sum's launch -- its last workgroup taking tagged partial sums as they
+  // arrive -- it saved nothing measurable: 1.422 against 1.421 ms per step)
+  kq::launch_block_energy_iir(ds, pl.if_power + b->cfg.max_blocks, g.L, (int)nblocks,
                               reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power);
   {
-    Scope t(b, 1, b->stream2);
+    Scope t(b, 1, ds);
     int const nfm = (int)b->list_host[0].size(), nam = (int)b->list_host[1].size(), nlin = (int)b->list_host[2].size();
     if (kq::demod64_supported(g)) {
-      kq::launch_demod64(b->stream2, g, chd, pl, b->list_dev[0], nfm, b->list_dev[1], nam, b->list_dev[2], nlin, (int)nblocks,
+      kq::launch_demod64(ds, g, chd, pl, b->list_dev[0], nfm, b->list_dev[1], nam, b->list_dev[2], nlin, (int)nblocks,
                          b->cfg.compute_n0);
     } else if (kq::demod_agc_wave_supported(g)) {  // wave-per-channel AM / linear, generic FM
-      kq::launch_demod64(b->stream2, g, chd, pl, b->list_dev[0], 0, b->list_dev[1], nam, b->list_dev[2], nlin, (int)nblocks,
+      kq::launch_demod64(ds, g, chd, pl, b->list_dev[0], 0, b->list_dev[1], nam, b->list_dev[2], nlin, (int)nblocks,
                          b->cfg.compute_n0);
-      kq::launch_demods(b->stream2, g, chd, pl, b->tw, b->list_dev[0], nfm, b->list_dev[1], 0, b->list_dev[2], 0, (int)nblocks,
+      kq::launch_demods(ds, g, chd, pl, b->tw, b->list_dev[0], nfm, b->list_dev[1], 0, b->list_dev[2], 0, (int)nblocks,
                         b->cfg.compute_n0, b->fmout, b->fm_hist[b->fm_hist_cur], b->fm_hist[b->fm_hist_cur ^ 1]);
       if (nfm > 0) b->fm_hist_cur ^= 1;
     } else {
-      kq::launch_demods(b->stream2, g, chd, pl, b->tw, b->list_dev[0], nfm, b->list_dev[1], nam, b->list_dev[2], nlin,
+      kq::launch_demods(ds, g, chd, pl, b->tw, b->list_dev[0], nfm, b->list_dev[1], nam, b->list_dev[2], nlin,
                         (int)nblocks, b->cfg.compute_n0, b->fmout, b->fm_hist[b->fm_hist_cur], b->fm_hist[b->fm_hist_cur ^ 1]);
       if (nfm > 0) b->fm_hist_cur ^= 1;
     }
   }
   LAUNCH_CHECK("demodulators");
   if (!b->list_pll_host.empty())
-    kq::launch_demod_pll(b->stream2, g, chd, pl, b->tw, b->list_pll_dev, (int)b->list_pll_host.size(), b->pll_state,
+    kq::launch_demod_pll(ds, g, chd, pl, b->tw, b->list_pll_dev, (int)b->list_pll_host.size(), b->pll_state,
                          b->pll_rings, b->pll_side, (int)nblocks, b->cfg.compute_n0);
   if (g.pl_n > 0 && !b->list_host[0].empty())
-    kq::launch_pl_track(b->stream2, g, chd, pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), (int)nblocks);
+    kq::launch_pl_track(ds, g, chd, pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), (int)nblocks);
   if (b->pcm_on) {
     bool const holes = !b->list_active_host.empty();
-    kq::launch_pcm(b->stream2, g, pl, b->pcm, b->pcm_mask, holes ? (int)b->list_active_host.size() : C, (int)nblocks,
+    kq::launch_pcm(ds, g, pl, b->pcm, b->pcm_mask, holes ? (int)b->list_active_host.size() : C, (int)nblocks,
                    holes ? b->list_active_dev : nullptr);
   }
-  if (b->stream2 != b->stream) HIP_TRY(hipEventRecord(b->ev_demod_done[pp], b->stream2));
+  if (overlap) HIP_TRY(hipEventRecord(b->ev_demod_done[pp], ds));
+  b->demod_overlapped[pp] = overlap;
   LAUNCH_CHECK("PLL / PL tone / PCM stage");
   b->pl = pl;  // what the pull functions read
   b->calls++;
@@ -878,12 +899,10 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     rc |= dev_alloc(&b->osc_dev2[k], 8 * C + (B + sizeof(double) - 1) / sizeof(double) + (C * sizeof(int) + 7) / 8);
   b->chd.lo_phase = b->chd.lo_freq = b->chd.lo_rate = b->chd.sh_phase = b->chd.sh_freq = nullptr;  // set per call
   b->chd.hist_phase = b->chd.hist_freq = b->chd.hist_rate = nullptr;
-  // The demodulators of call k run on a second stream under the filter pass of call k+1 (KQ_DEMOD_OVERLAP=0 puts them
-  // back on the main stream).  Round 2 measured this a loss next to the 236-VGPR pruned kernel and a 1.9 % gain at +2 % on
-  // the full-spectrum kernel; with this round's kernels the filter kernel's own time is unchanged (1.353 ms either way)
-  // and the step drops 1.3 % (1.433 -> 1.414 ms, A/B on one box), so it is the default now.
+  // the demodulators' own stream (run_blocks says when it is used); KQ_DEMOD_OVERLAP=0 leaves it out
   const char *ov = getenv("KQ_DEMOD_OVERLAP");
-  bool const overlap = !ov || atoi(ov) != 0;
+  b->overlap_mode = ov ? (atoi(ov) != 0 ? 1 : 0) : -1;
+  bool const overlap = b->overlap_mode != 0;
   if (!overlap) b->stream2 = b->stream;
   if ((overlap && hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess) ||
       hipEventCreateWithFlags(&b->ev_demod_done[0], hipEventDisableTiming) != hipSuccess ||
@@ -1471,8 +1490,15 @@ int kq_bank_pull_planes_async(kq_bank *b, float *audio, kq_chan_status *status) 
   }
   if (host_io_setup(b)) return -1;
   size_t const n = b->chans.size() * (size_t)b->g.max_blocks;
-  HIP_TRY(hipEventRecord(b->out_ready, b->stream2));  // behind the last call's demodulators
-  HIP_TRY(hipStreamWaitEvent(b->copy_out, b->out_ready, 0));
+  // behind the last call's demodulators: their own marker when they ran on their own stream, else one on the main stream
+  int const last = (int)((b->calls - 1) & 1);
+  if (b->demod_overlapped[last]) {
+    HIP_TRY(hipStreamWaitEvent(b->copy_out, b->ev_demod_done[last], 0));
+  } else {
+    HIP_TRY(hipEventRecord(b->out_ready, b->stream));
+    HIP_TRY(hipStreamWaitEvent(b->copy_out, b->out_ready, 0));
+  }
+  b->pulled_since_call = true;
   // of every channel-block's 2 * olen floats only the status.nout that hold samples travel (mono: half): the kernel
   // moves 16 bytes per lane, so olen must be a multiple of 4 for it -- other geometries take the plain copy
   size_t const sbytes = n * sizeof(kq_chan_status), s16 = sbytes & ~(size_t)15;
@@ -1707,7 +1733,8 @@ int kq_bank_join(kq_bank *b) {
   kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return -1;
   if (b->calls == 0) return 0;
-  if (b->stream2 != b->stream) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[(b->calls - 1) & 1], 0));
+  int const last = (int)((b->calls - 1) & 1);
+  if (b->demod_overlapped[last]) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[last], 0));
   return 0;
 }
 

@@ -148,3 +148,57 @@ def test_streaming_host_io_equals_the_blocking_calls(gpu):
                 assert st[c, b]["bb_power"] == np.float32(ws["bb_power"]) and st[c, b]["n0"] == np.float32(ws["n0"])
     ref.close()
     bank.close()
+
+
+def test_demodulator_stream_changes_from_call_to_call(gpu, monkeypatch):
+    """The bank decides per call where the demodulators run: on the main stream, or (when the planes of the last call were
+    pulled asynchronously, or the plan has AGC channels) on their own stream under the next filter pass.  FM-only plan,
+    pulls on some calls and not on others, so that consecutive calls alternate between the two; every call's audio and
+    status equal those of a bank that never overlaps (KQ_DEMOD_OVERLAP=0) and of one that always does (=1)."""
+    g = dict(samprate=192000, L=512, M=513, D=4)
+    fs, L, M = g["samprate"], g["L"], g["M"]
+    plan = wl.channel_plan("cfg1", 4)
+    nblocks, ncalls = 4, 9
+    iq = wl.make_iq(fs, ncalls * nblocks * L, seed=93)
+    olen = L // g["D"]
+    banks = {}
+    for name, env in (("auto", None), ("never", "0"), ("always", "1")):
+        if env is None:
+            monkeypatch.delenv("KQ_DEMOD_OVERLAP", raising=False)
+        else:
+            monkeypatch.setenv("KQ_DEMOD_OVERLAP", env)
+        banks[name] = kq.Bank(fs, L, M, g["D"], len(plan), nblocks, compute_n0=True)
+        for p in plan:
+            banks[name].add_channel(bank_cfg(p))
+    monkeypatch.delenv("KQ_DEMOD_OVERLAP", raising=False)
+    pinned = torch.from_numpy(iq.copy()).pin_memory()
+    audio = torch.zeros(len(plan) * nblocks * 2 * olen, dtype=torch.float32).pin_memory()
+    status = torch.zeros(len(plan) * nblocks * C.sizeof(kq.ChanStatus), dtype=torch.uint8).pin_memory()
+    pull_after = {1, 2, 4, 7}          # calls 2, 3, 5 and 8 then run overlapped in the "auto" bank, the others do not
+    for k in range(ncalls):
+        chunk = iq[k * nblocks * L:(k + 1) * nblocks * L]
+        for name, bank in banks.items():
+            if name == "auto":
+                bank.push_iq_async(pinned.data_ptr() + 8 * k * nblocks * L, nblocks * L)
+            else:
+                bank.push_iq(chunk)
+            assert bank.process() == nblocks
+        pulled = None
+        if k in pull_after:
+            banks["auto"].pull_planes_async(audio.data_ptr(), status.data_ptr())
+            banks["auto"].host_io_wait()
+            pulled = audio.numpy().reshape(len(plan), nblocks, 2 * olen).copy()
+        for c in range(len(plan)):
+            for b in range(nblocks):
+                want = banks["never"].audio(c, b)
+                assert np.array_equal(banks["always"].audio(c, b), want), (k, c, b)
+                assert np.array_equal(banks["auto"].audio(c, b), want), (k, c, b)
+                if pulled is not None:
+                    assert np.array_equal(pulled[c, b, :len(want)], want), (k, c, b)
+                ws = banks["never"].status(c, b)
+                for other in ("auto", "always"):
+                    st = banks[other].status(c, b)
+                    assert st["nout"] == ws["nout"] and st["squelch_count"] == ws["squelch_count"]
+                    assert np.float32(st["bb_power"]) == np.float32(ws["bb_power"]) and np.float32(st["if_power"]) == np.float32(ws["if_power"])
+    for bank in banks.values():
+        bank.close()

@@ -199,7 +199,13 @@ __global__ void __launch_bounds__(256) k_copy_to_host(const float *__restrict__ 
 }
 void launch_copy_to_host(hipStream_t s, const float *audio, float *haudio, int row, const kq_chan_status *status, void *hstatus,
                          size_t rows) {
-  hipLaunchKernelGGL(k_copy_to_host, dim3(32), dim3(256), 0, s, audio, haudio, row, status, (u32x4 *)hstatus, rows,
+  // As few workgroups as the transfer needs: one pushes ~4.4 GB/s over the link whatever it has in flight, and every wave
+  // of this kernel displaces a workgroup of the filter pass running beside it (with_host_io at cfg 4, 12.6 MB per call:
+  // 1.59 ms per step with 32 workgroups, 1.48 with 4-8, 1.64 with 2, which no longer finish inside the step).  One per
+  // 2 MiB is 26 GB/s at cfg 4.
+  size_t const bytes = rows * ((haudio ? (size_t)row * sizeof(float) : 0) + (hstatus ? sizeof(kq_chan_status) : 0));
+  unsigned const wgs = (unsigned)std::min<size_t>(64, std::max<size_t>(4, (bytes + (2u << 20) - 1) >> 21));
+  hipLaunchKernelGGL(k_copy_to_host, dim3(wgs), dim3(256), 0, s, audio, haudio, row, status, (u32x4 *)hstatus, rows,
                      rows * sizeof(kq_chan_status) / 16);
 }
 

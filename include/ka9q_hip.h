@@ -294,7 +294,9 @@ int kq_bank_fwd_mode(const kq_bank *bank);
  *                 p = kq_fanout_acquire(f, slot, bank_stream, &n)                  bank_stream waits for the batch
  *                 kq_bank_process_resident(bank, p, nblocks)                       (window layout: M-1 history + blocks)
  *                 kq_fanout_release(f, slot, bank_stream)                          the slot may be overwritten after this
- * `bank_stream` is the hipStream_t the bank was created on (kq_bank_config.stream). */
+ * `bank_stream` is the hipStream_t the bank was created on (kq_bank_config.stream); it must outlive the fan-out's next
+ * kq_fanout_post of that slot (a world of one without a communicator records the release on it only then, and only if
+ * that post copies something into the slot). */
 #define KQ_FANOUT_ID_BYTES 128
 typedef struct kq_fanout kq_fanout;
 /* contiguous, balanced range of `rank`: the first total % world ranks hold one channel more */
@@ -338,8 +340,11 @@ int kq_decim_destroy(kq_decimator *d);
 int kq_decim_set_coeffs(kq_decimator *d, const float coeffs[4]);
 /* iq_in: n_out << log_decimate interleaved complex float samples.  out_cf32: n_out complex samples after
  * Filter_atten; out_s16 (may be NULL): the same as (short)round(32767*s), interleaved I,Q; out_energy (may be
- * NULL): sum of s*s over the call (hackrf.c:308,325 output_energy).  on_device != 0: every pointer is device
- * memory and the call is asynchronous on the handle's stream; otherwise host memory, synchronous. */
+ * NULL): sum of s*s over the call (hackrf.c:308,325 output_energy), added up inside the last kernel of the call in an
+ * order fixed by the device (same input, same device: same bits).  on_device != 0: every pointer is device
+ * memory and the call is asynchronous on the handle's stream; otherwise host memory, synchronous.
+ * kq_decim_sync (and a host-memory call) returns -1 if a workgroup's share of the energy never arrived (a device fault;
+ * that call's energy is NaN, its samples are unaffected). */
 int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t n_out, float *out_cf32,
                      int16_t *out_s16, float *out_energy);
 int kq_decim_sync(kq_decimator *d);

@@ -198,8 +198,9 @@ int kq_bank_process(kq_bank *bank);
 /* Convenience for resident-input benchmarks: process `nblocks` blocks reading the window
  * [M-1 history | nblocks*L] straight from `iq_dev` (device, complex float), no ring copy. */
 int kq_bank_process_resident(kq_bank *bank, const void *iq_dev, unsigned nblocks);
-/* The demodulators of a call run on a second internal stream, overlapping the next call's filter pass.
- * kq_bank_join makes the bank's main stream wait (on the device) for the last call's demodulators;
+/* The demodulators of a call may run on a second internal stream, overlapping the next call's filter pass (the bank
+ * decides per call: after kq_bank_pull_planes_async, or with AM / SSB channels; KQ_DEMOD_OVERLAP=0 / 1 forces it).
+ * kq_bank_join makes the bank's main stream wait (on the device) for the last call's demodulators wherever they ran;
  * kq_bank_sync blocks the host until everything issued so far has finished. */
 int kq_bank_join(kq_bank *bank);
 int kq_bank_sync(kq_bank *bank);

@@ -10,12 +10,12 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INST
   rocprofv3 --pmc $grp -d $OUT/p$i -o p$i --output-format csv -- python3 $R/tools/bench_decim.py --steps 2 --warmup 1 "$@" > $OUT/p$i.log 2>&1
 done
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "k_hb_group" in r["Kernel_Name"]:
-            agg[r["Kernel_Name"].split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[re.search(r"k_hb_group<[^>]*>", r["Kernel_Name"]).group(0)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k)
     for c, v in sorted(d.items()):

@@ -54,6 +54,8 @@ def parse():
                     help="front-end fan-out: c = the library's kq_fanout_* (ncclBroadcast, the product path); torch = "
                          "ka9q_sdr_amd/shard.py's torch.distributed twin (always used with --backend gloo)")
     ap.add_argument("--no-host-io", action="store_true", help="skip the with_host_io measurement")
+    ap.add_argument("--gpu-state", action="store_true",
+                    help="sample shader clock and power at 50 Hz over the spin-up steps (disturbs the timed steps by about 1 %%)")
     return ap.parse_args()
 
 
@@ -116,9 +118,18 @@ class GpuState:
     build differs by a few per cent from one box of the pool to the next, and this says whether the clock or the power
     cap is behind it.  One sampler per process; the card is the one whose clock is highest under load."""
 
-    def __init__(self):
+    def __init__(self, pci_bus=None):
+        """pci_bus: bus number of the device in use (torch's pci_bus_id).  A box of the pool holds eight GPUs, the others
+        busy with somebody else's work: only the cards whose sysfs path goes through that bus are read -- when there are
+        any; otherwise all, and the one drawing most power is reported.  (Until late in round 3 the card with the
+        highest clock was reported, which was a neighbour's: 2404 MHz at 290 W, while this workload runs its own GPU
+        at 2.2-2.4 GHz and 1.1-1.4 kW against a 1.4 kW cap.)"""
         import glob
         self.dirs = [os.path.dirname(f) for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")]
+        if pci_bus is not None:
+            mine = [d for d in self.dirs if (":%02x:" % pci_bus) in os.path.realpath(os.path.join(d, "..", ".."))]
+            if mine:
+                self.dirs = mine
         self.samples = {d: [] for d in self.dirs}
         self.stop = False
         self.thread = None
@@ -138,6 +149,22 @@ class GpuState:
                     self.samples[d].append((f / 1e6, (p or 0.0) / 1e6))
             time.sleep(0.02)
 
+    @classmethod
+    def once(cls, pci_bus=None):
+        """one reading of the card(s) on the device's bus (or of every card), the one drawing most power reported"""
+        g = cls(pci_bus)
+        best = None
+        for d in g.dirs:
+            f, p = cls._read(d + "/freq1_input"), cls._read(d + "/power1_input")
+            if f is not None and (best is None or (p or 0) > best[1]):
+                best = (f / 1e6, (p or 0.0) / 1e6, d)
+        if not best:
+            return None
+        cap = cls._read(best[2] + "/power1_cap")
+        return {"sclk_mhz": round(best[0]), "power_w": round(best[1]), "power_cap_w": round(cap / 1e6) if cap else None,
+                "samples": 1, "source": "amdgpu hwmon freq1_input / power1_input of the card drawing most power, read once "
+                                        "while the last timed steps were queued (--gpu-state samples at 50 Hz over the spin-up)"}
+
     def start(self):
         import threading
         if self.dirs:
@@ -148,7 +175,7 @@ class GpuState:
         self.stop = True
         if self.thread:
             self.thread.join()
-        best = max(self.dirs, key=lambda d: max([s[0] for s in self.samples[d]] or [0]), default=None)
+        best = max(self.dirs, key=lambda d: max([s[1] for s in self.samples[d]] or [0]), default=None)   # most power
         if not best or not self.samples[best]:
             return None
         f = [s[0] for s in self.samples[best]]
@@ -157,7 +184,7 @@ class GpuState:
         return {"sclk_mhz": {"min": round(min(f)), "mean": round(sum(f) / len(f)), "max": round(max(f))},
                 "power_w": {"min": round(min(w)), "mean": round(sum(w) / len(w)), "max": round(max(w))},
                 "power_cap_w": round(cap / 1e6) if cap else None, "samples": len(f),
-                "source": "amdgpu hwmon freq1_input / power1_input, 20 ms apart over the timed steps"}
+                "source": "amdgpu hwmon freq1_input / power1_input, 20 ms apart over the untimed spin-up and warm-up steps"}
 
 
 def pmc_traffic(config, channels, blocks, fwd):
@@ -318,6 +345,14 @@ def main():
     # Spin-up, then the W warm-up steps, then the K timed steps: one continuous sequence of identical steps.  The
     # spin-up count is even so that the double buffers are at the same parity whatever its length.
     spin = 2 * (max(0, a.spinup) // 2)
+    # Clocks and power: by default ONE reading, taken while the last timed steps are still queued on the device.  Every read of the hwmon files is a query to
+    # the SMU, and sampling disturbs what it looks at (tools/gs_probe.sh): a 50 Hz sampler over the timed steps cost them
+    # 0.5 %, the same sampler over the spin-up steps only, stopped before the clock starts, 0.5-1.6 %.  --gpu-state
+    # asks for that sampler (over spin-up and warm-up) all the same.
+    pci_bus = getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)
+    gpu_state = GpuState(pci_bus) if rank == 0 and a.gpu_state else None
+    if gpu_state:
+        gpu_state.start()
     for k in range(spin):
         step(4 + k)
     spin_reported = spin
@@ -325,21 +360,20 @@ def main():
     for k in range(a.warmup):
         step(spin + k)
     torch.cuda.synchronize()
+    gpu_state = gpu_state.finish() if gpu_state else None
     if dist:
         dist.barrier()
     bank.enable_timing(1)      # HIP events around the filter kernel only: two stream operations per step
     bank.timing(reset=True)
-    gpu_state = GpuState() if rank == 0 else None
-    if gpu_state:
-        gpu_state.start()
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(spin + a.warmup + k)
+    if rank == 0 and not a.gpu_state:
+        gpu_state = GpuState.once(pci_bus)     # the last steps are still queued on the device: it is read under load
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     t1 = time.perf_counter()
-    gpu_state = gpu_state.finish() if gpu_state else None
     elapsed = t1 - t0
     rank_ms = [elapsed / a.steps * 1e3] * 2      # fastest / slowest rank
     if dist:

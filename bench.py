@@ -163,7 +163,7 @@ class GpuState:
         cap = cls._read(best[2] + "/power1_cap")
         return {"sclk_mhz": round(best[0]), "power_w": round(best[1]), "power_cap_w": round(cap / 1e6) if cap else None,
                 "samples": 1, "source": "amdgpu hwmon freq1_input / power1_input of the card drawing most power, read once "
-                                        "while the last timed steps were queued (--gpu-state samples at 50 Hz over the spin-up)"}
+                                        "during the last quarter of the timed steps (--gpu-state samples at 50 Hz over the spin-up)"}
 
     def start(self):
         import threading
@@ -345,7 +345,7 @@ def main():
     # Spin-up, then the W warm-up steps, then the K timed steps: one continuous sequence of identical steps.  The
     # spin-up count is even so that the double buffers are at the same parity whatever its length.
     spin = 2 * (max(0, a.spinup) // 2)
-    # Clocks and power: by default ONE reading, taken while the last timed steps are still queued on the device.  Every read of the hwmon files is a query to
+    # Clocks and power: by default ONE reading, taken by a side thread during the last quarter of the timed steps.  Every read of the hwmon files is a query to
     # the SMU, and sampling disturbs what it looks at (tools/gs_probe.sh): a 50 Hz sampler over the timed steps cost them
     # 0.5 %, the same sampler over the spin-up steps only, stopped before the clock starts, 0.5-1.6 %.  --gpu-state
     # asks for that sampler (over spin-up and warm-up) all the same.
@@ -366,14 +366,22 @@ def main():
     bank.enable_timing(1)      # HIP events around the filter kernel only: two stream operations per step
     bank.timing(reset=True)
     t0 = time.perf_counter()
+    reader, reading = None, {}
     for k in range(a.steps):
+        if rank == 0 and not a.gpu_state and k == max(0, a.steps - max(8, a.steps // 4)):
+            # one reading under load, from a thread of its own: the files take a millisecond or two to read, and the host
+            # is never more than four steps ahead of the device
+            import threading
+            reader = threading.Thread(target=lambda: reading.update(state=GpuState.once(pci_bus)), daemon=True)
+            reader.start()
         step(spin + a.warmup + k)
-    if rank == 0 and not a.gpu_state:
-        gpu_state = GpuState.once(pci_bus)     # the last steps are still queued on the device: it is read under load
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     t1 = time.perf_counter()
+    if reader:
+        reader.join()
+        gpu_state = reading.get("state")
     elapsed = t1 - t0
     rank_ms = [elapsed / a.steps * 1e3] * 2      # fastest / slowest rank
     if dist:

@@ -36,9 +36,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--spinup", type=int, default=300,
-                    help="untimed steps run before the warm-up steps so that the GPU is at its sustained clocks when the "
-                         "timed region starts (an idle MI355X needs ~35 ms of load to get there)")
+    ap.add_argument("--spinup", type=int, default=-1,
+                    help="untimed steps run before the warm-up steps so that the GPU is in its sustained state when the "
+                         "timed region starts; -1 (default): as many as fill --spinup-seconds")
+    ap.add_argument("--spinup-seconds", type=float, default=15.0,
+                    help="length of the default spin-up: after an idle pause the power management lets the same step get "
+                         "faster for about 15 s (tools/cold_spinup.sh: 1.462 ms after 0.4 s, 1.444 after 4 s, 1.428 after "
+                         "14 s of load), and a receiver streams for hours")
     ap.add_argument("--config", default="cfg4", help="workload: cfg2|cfg3|cfg4|cfg5 (ka9q_sdr_amd/workload.py)")
     ap.add_argument("--channels", type=int, default=None, help="channels per GPU (default: the config's)")
     ap.add_argument("--blocks", type=int, default=64, help="overlap-save blocks per step")
@@ -344,7 +348,15 @@ def main():
         cold.append(round((time.perf_counter() - tc) * 1e3, 4))
     # Spin-up, then the W warm-up steps, then the K timed steps: one continuous sequence of identical steps.  The
     # spin-up count is even so that the double buffers are at the same parity whatever its length.
-    spin = 2 * (max(0, a.spinup) // 2)
+    if a.spinup >= 0:
+        spin = 2 * (a.spinup // 2)
+    else:   # by time, from the cold steps just measured; every rank runs the same count (the steps post collectives)
+        est_ms = max(1e-3, min(cold[1:]))
+        spin = 2 * int(min(400000, a.spinup_seconds * 1e3 / est_ms) // 2)
+        if dist:
+            cnt = torch.tensor([spin], device=dev, dtype=torch.int64)
+            dist.broadcast(cnt, src=0)
+            spin = int(cnt.item())
     # Clocks and power: by default ONE reading, taken by a side thread during the last quarter of the timed steps.  Every read of the hwmon files is a query to
     # the SMU, and sampling disturbs what it looks at (tools/gs_probe.sh): a 50 Hz sampler over the timed steps cost them
     # 0.5 %, the same sampler over the spin-up steps only, stopped before the clock starts, 0.5-1.6 %.  --gpu-state

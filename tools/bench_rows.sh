@@ -6,7 +6,8 @@ row() {
 import json, sys
 d = json.loads(sys.stdin.readline())
 r = d["roofline"]
-print("%-28s step %.4f ms  kernel %.4f ms  frac %.4f  valu_frac %.3f  demod %.4f ms  value %.0f" % (" ".join(sys.argv[1:]), d["ms_per_step"], r["kernel_ms"], r["frac"], r["valu_frac"], r.get("demod_ms", 0), d["value"]))' "$@"
+g = d.get("gpu_state") or {}
+print("%-28s step %.4f ms  kernel %.4f ms  frac %.4f  valu_frac %.3f  demod %.4f ms  value %.0f  (%s MHz, %s W)" % (" ".join(sys.argv[1:]), d["ms_per_step"], r["kernel_ms"], r["frac"], r["valu_frac"], r.get("demod_ms", 0), d["value"], g.get("sclk_mhz"), g.get("power_w")))' "$@"
 }
 row --config cfg4
 row --config cfg3

@@ -21,6 +21,8 @@
  *   - written: filter.out (a slave created with create_filter_output, its output.c refreshed every block),
  *     output.channels (FM, AM: 1), agc.gain, sig.{bb_power,n0,snr,foffset,pdeviation,plfreq,cphase,pll_lock,lock_timer};
  *     sig.if_power stays with proc_samples (radio.c:143-145);
+ *   - terminate is read with acquire semantics and the thread deletes its slave (filter.out) once it has seen it set: set
+ *     it after the last set_filter / noise_gain on that slave (radio.c:336-338 does, followed by pthread_join);
  *   - audio_master (FM) stays NULL: the post-detection filter lives on the device;
  *   - linear: filter.out->output.c holds the filter output before AGC (the reference scales it in place,
  *     linear.c:280); the audio handed to send_*_output is the scaled, shifted signal as in the reference.

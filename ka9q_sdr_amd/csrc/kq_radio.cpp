@@ -28,13 +28,16 @@ namespace {
 // struct demod is shared with the host program's other threads the way the reference shares it -- plain fields, no lock
 // (display.c:161 writes filter.low / high, set_mode writes terminate, radio.c:336): the fields those threads write are
 // read here with relaxed atomic loads, and the slave pointer they pick up is published with a release store, so that the
-// protocol is defined behaviour (and clean under ThreadSanitizer, tests/tsan) without changing the layout.
+// protocol is defined behaviour (and clean under ThreadSanitizer, tests/tsan) without changing the layout.  `terminate`
+// is read with acquire: the thread frees its slave once it has seen the flag, and whatever the thread that set the flag
+// did to that slave before (set_filter, noise_gain) must be over by then -- which a release store of the flag hands on.
 template <class T>
 inline T shared_load(const T &v) {
   T t;
   __atomic_load(const_cast<T *>(&v), &t, __ATOMIC_RELAXED);
   return t;
 }
+inline int told_to_stop(const struct demod *demod) { return __atomic_load_n(const_cast<int *>(&demod->terminate), __ATOMIC_ACQUIRE); }
 inline void publish_slave(struct demod *demod, struct filter_out *s) { __atomic_store_n(&demod->filter.out, s, __ATOMIC_RELEASE); }
 
 struct Session {
@@ -171,7 +174,7 @@ bool next_block(Session &s, kq_chan_status *st, std::vector<float> &audio, size_
   // blocks, as the reference's equality test on blocknum does, filter.c:195-199.)
   for (;;) {
     if (execute_filter_output(s.slave)) return false;  // blocks until the master has a new block; refreshes output.c
-    if (shared_load(demod->terminate)) return false;
+    if (told_to_stop(demod)) return false;
     unsigned blk = 0;
     if (kq::compat_snapshot_window(demod->filter.in, s.d_window, &blk) < 0) return false;
     if (s.have_block && blk == s.last_block) continue;
@@ -215,9 +218,9 @@ void *demod_fm(void *arg) {
   std::vector<float> audio;
   kq_chan_status st;
   size_t n = 0;
-  while (!shared_load(demod->terminate)) {
+  while (!told_to_stop(demod)) {
     if (!next_block(s, &st, audio, &n)) {
-      if (!shared_load(demod->terminate)) fail(demod, "block failed");  // (told to stop while waiting: not a failure)
+      if (!told_to_stop(demod)) fail(demod, "block failed");  // (told to stop while waiting: not a failure)
       break;
     }
     demod->sig.n0 = st.n0;  // fm.c:78-82 (smoothed on the device with the same recurrence)
@@ -246,9 +249,9 @@ void *demod_am(void *arg) {
   std::vector<float> audio;
   kq_chan_status st;
   size_t n = 0;
-  while (!shared_load(demod->terminate)) {
+  while (!told_to_stop(demod)) {
     if (!next_block(s, &st, audio, &n)) {
-      if (!shared_load(demod->terminate)) fail(demod, "block failed");  // (told to stop while waiting: not a failure)
+      if (!told_to_stop(demod)) fail(demod, "block failed");  // (told to stop while waiting: not a failure)
       break;
     }
     demod->sig.n0 = st.n0;  // am.c:46-49
@@ -273,7 +276,7 @@ void *demod_linear(void *arg) {
   std::vector<float> audio;
   kq_chan_status st;
   size_t n = 0;
-  while (!shared_load(demod->terminate)) {
+  while (!told_to_stop(demod)) {
     // linear.c:117-120: the ISB flag is copied to the slave before every block; output.channels is read after it
     int const isb = demod->filter.isb != 0, channels = demod->output.channels == 2 ? 2 : 1;
     if (isb != s.isb || channels != s.channels) {
@@ -293,7 +296,7 @@ void *demod_linear(void *arg) {
       }
     }
     if (!next_block(s, &st, audio, &n)) {
-      if (!shared_load(demod->terminate)) fail(demod, "block failed");  // (told to stop while waiting: not a failure)
+      if (!told_to_stop(demod)) fail(demod, "block failed");  // (told to stop while waiting: not a failure)
       break;
     }
     demod->sig.n0 = st.n0;  // linear.c:123-126

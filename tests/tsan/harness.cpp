@@ -203,7 +203,7 @@ int main() {
   pthread_join(ui, nullptr);
   for (int k = 0; k < 3; k++) {
     int one = 1;
-    __atomic_store(&dm[k].terminate, &one, __ATOMIC_RELAXED);  // set_mode, radio.c:336-338
+    __atomic_store(&dm[k].terminate, &one, __ATOMIC_RELEASE);  // set_mode, radio.c:336-338 (after the last touch of the slave)
   }
   while (g_running.load() > 0) {  // the threads look at terminate once per block: keep the blocks coming
     for (unsigned i = 0; i < L; i++) master->input.c[i] = 0;

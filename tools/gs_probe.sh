@@ -1,3 +1,5 @@
+#!/bin/bash
+# The headline step without and with the 50 Hz clock / power sampler (--gpu-state):  gpurun -- 'bash tools/gs_probe.sh'
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for rep in 1 2 3; do
 for v in 0 1; do

@@ -92,15 +92,20 @@ __global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *_
   float acc = 0;
   int dummy = 0;
   int const first = part * (int)blockDim.x + (int)threadIdx.x, stride = split * (int)blockDim.x;
-  if (paired) {
-    float2 *o = paired + hist + (size_t)blk * L;
-    for (int i = first; i < L; i += stride) {  // blockDim.x = 1024 = one pair of rows per trip
-      float2 const v = p[i];
-      acc += cnrm(v);
-      o[(i - (int)threadIdx.x) + pcol] = v;
+  // four trips' loads in flight at a time (a workgroup has three or four trips in all: one memory latency, not one each)
+  float2 *o = paired ? paired + hist + (size_t)blk * L : nullptr;
+  for (int i0 = first; i0 < L; i0 += 4 * stride) {  // blockDim.x = 1024 = one pair of rows per trip
+    float2 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = i0 + j * stride < L ? p[i0 + j * stride] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int const i = i0 + j * stride;
+      if (i < L) {
+        acc += cnrm(v[j]);
+        if (o) o[(i - (int)threadIdx.x) + pcol] = v[j];
+      }
     }
-  } else {
-    for (int i = first; i < L; i += stride) acc += cnrm(p[i]);
   }
   block_sum_fi(acc, dummy, red_f, red_i);
   if (threadIdx.x == 0) sums[blockIdx.x] = acc;

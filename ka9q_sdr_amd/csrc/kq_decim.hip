@@ -35,8 +35,8 @@ constexpr int kMaxFuse = 4;       // stages per kernel
 // outputs of a fused group per workgroup: the level-0 tile is 4096 samples (+ halo) either way, i.e. 50 KB of LDS with
 // level 1 and three workgroups per CU
 __host__ __device__ constexpr int tile_out(int nstages) { return nstages >= 4 ? 256 : 512; }
-constexpr int kThreads = 512;     // (256 until round 3: the same 50 KB tile shared by eight waves instead of four -- 16 waves per CU
-                                  //  instead of 12, 102 instead of 131 registers -- is 4 % faster; 1024 threads 9 % slower)
+constexpr int kThreads = 512;     // (256 until round 3: the same 50 KB tile shared by eight waves instead of four, at most
+                                  //  80 registers each so that three workgroups fit a CU, is 4 % faster; 1024 threads 9 % slower)
 
 struct GroupArgs {
   const float2 *in;    // n_in = n_out << nstages complex samples

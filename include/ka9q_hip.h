@@ -288,7 +288,10 @@ int kq_bank_fwd_mode(const kq_bank *bank);
  *   every rank:   f = kq_fanout_create(device, rank, world, root, id, samples_per_batch);
  *                 COLLECTIVE: ncclCommInitRank inside returns only once all `world` ranks have called it with the same
  *                 id -- one thread or process per rank, all calling concurrently (one thread creating the fan-outs of
- *                 several ranks one after the other would wait on itself for ever)
+ *                 several ranks one after the other would wait on itself for ever).  A rank whose own set-up fails
+ *                 (memory, stream) still enters the communicator, and the ranks then agree through a one-word
+ *                 ncclAllReduce: either every rank gets its fan-out or every rank gets NULL (kq_last_error says which
+ *                 side it was on).  KQ_RCCL_LIB in the environment names the librccl to dlopen.
  *                 kq_shard_range(total_channels, world, rank, &first, &count) -> add channels first .. first+count-1
  *   per batch k:  slot = k & 1
  *                 kq_fanout_post(f, slot, iq, n, is_device)      queue the broadcast (iq: read on the root rank only)
@@ -316,8 +319,16 @@ typedef struct kq_fanout_info {
   int rccl_ranks, rccl_version;
   unsigned long long broadcasts;
   double broadcast_ms;
+  /* consumer side: kq_fanout_acquire calls so far; of those, the ones that found their batch not yet landed while
+   * kq_fanout_enable_timing was on (`waits`), and the time the consumer stream then stood still for it (`wait_ms`, HIP
+   * events on that stream around the wait: a stalled step shows here, a slow broadcast that still arrives in time does not) */
+  unsigned long long acquires, waits;
+  double wait_ms;
 } kq_fanout_info;
 int kq_fanout_stats(kq_fanout *f, kq_fanout_info *out);
+/* on != 0: time the consumer's waits (two event records on the consumer stream per acquire that has to wait, ~5 us each
+ * behind a long kernel -- a diagnostic, off by default). */
+int kq_fanout_enable_timing(kq_fanout *f, int on);
 
 /* --- front-end half-band decimator cascade ---------------------------------------------------
  * What hackrf.c:260-330 does to every block of raw A/D samples before they reach the channel filter: rotate by

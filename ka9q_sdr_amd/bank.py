@@ -165,6 +165,7 @@ def load_library():
     L.kq_fanout_release.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.kq_fanout_destroy.argtypes = [C.c_void_p]
     L.kq_fanout_stats.argtypes = [C.c_void_p, C.POINTER(FanoutInfo)]
+    L.kq_fanout_enable_timing.argtypes = [C.c_void_p, C.c_int]
     _lib = L
     return L
 
@@ -172,7 +173,8 @@ def load_library():
 class FanoutInfo(C.Structure):
     """kq_fanout_info (include/ka9q_hip.h)"""
     _fields_ = [("world", C.c_int), ("rank", C.c_int), ("rccl_ranks", C.c_int), ("rccl_version", C.c_int),
-                ("broadcasts", C.c_ulonglong), ("broadcast_ms", C.c_double)]
+                ("broadcasts", C.c_ulonglong), ("broadcast_ms", C.c_double),
+                ("acquires", C.c_ulonglong), ("waits", C.c_ulonglong), ("wait_ms", C.c_double)]
 
 
 def device_count():

@@ -200,6 +200,7 @@ struct kq_bank {
   hipStream_t copy_in = nullptr, copy_out = nullptr;
   void *in_stage[2] = {nullptr, nullptr};
   size_t in_stage_cap[2] = {0, 0};
+  bool in_used[2] = {false, false};  // in_ready[k] has been recorded at least once
   hipEvent_t in_ready[2] = {nullptr, nullptr}, in_free[2] = {nullptr, nullptr};
   int in_next = 0;
   hipEvent_t out_ready = nullptr, out_done = nullptr;
@@ -377,9 +378,23 @@ int ensure_events(std::vector<EventPair> &v, size_t need) {
   return 0;
 }
 
+// the N = 65536 kernel's "a sibling never showed up" flag (pinned host memory): reported once, by whichever of
+// kq_bank_sync / kq_bank_host_io_wait the host uses to wait -- a streaming host never calls the former
+int report_lost_sibling(kq_bank *b) {
+  if (b->big.err && *b->big.err) {
+    *b->big.err = 0;
+    set_err("N = 65536 filter: a sibling workgroup's compute_n0 sum never arrived (n0 of that call is NaN)");
+    return -1;
+  }
+  return 0;
+}
+
 int sync_all(kq_bank *b) {
   HIP_TRY(hipStreamSynchronize(b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream2));
+  // the streaming copies too: "everything issued so far" (kq_bank_sync) includes a plane copy still in flight
+  if (b->copy_in) HIP_TRY(hipStreamSynchronize(b->copy_in));
+  if (b->copy_out) HIP_TRY(hipStreamSynchronize(b->copy_out));
   return 0;
 }
 
@@ -1003,6 +1018,8 @@ int kq_bank_destroy(kq_bank *b) {
   if (!b) return 0;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->stream2 && b->stream2 != b->stream) (void)hipStreamSynchronize(b->stream2);
+  for (hipStream_t st : {b->copy_in, b->copy_out})  // before any plane they read or write is freed
+    if (st) (void)hipStreamSynchronize(st);
   void *ptrs[] = {b->ring[0], b->ring[1], b->tw, b->chan_tw, b->chd.mode, b->chd.flags, b->chd.low, b->chd.high, b->chd.resp,
                   b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.n0lane, b->chd.n0meta, b->fmout, b->fm_hist[0], b->fm_hist[1],
                   b->osc_dev2[0], b->osc_dev2[1], b->chd.fm_state,
@@ -1047,11 +1064,11 @@ int kq_bank_destroy(kq_bank *b) {
 }
 
 namespace {
-bool is_pll(const kq_channel_config &c) { return c.demod_type == KQ_LINEAR_DEMOD && c.pll; }
+static bool is_pll(const kq_channel_config &c) { return c.demod_type == KQ_LINEAR_DEMOD && c.pll; }
 
 // PLL channels own the slot equal to their rank among the PLL channels (upload_lists): when a channel enters or
 // leaves that set the carried state of the channels behind it moves by one slot
-int move_pll_slot(kq_bank *b, int from, int to) {
+static int move_pll_slot(kq_bank *b, int from, int to) {
   HIP_TRY(hipMemcpy(b->pll_state + to, b->pll_state + from, sizeof(kq::PllState), hipMemcpyDeviceToDevice));
   HIP_TRY(hipMemcpy(b->pll_rings + (size_t)to * 65536, b->pll_rings + (size_t)from * 65536, sizeof(float2) * 65536,
                     hipMemcpyDeviceToDevice));
@@ -1059,7 +1076,7 @@ int move_pll_slot(kq_bank *b, int from, int to) {
 }
 
 // slot channel `ch` has or would have among the PLL channels, and how many others there are
-void pll_rank(const kq_bank *b, int ch, int &rank, int &npll) {
+static void pll_rank(const kq_bank *b, int ch, int &rank, int &npll) {
   rank = npll = 0;
   for (int c = 0; c < (int)b->chans.size(); c++)
     if (c != ch && b->chans[c].active && is_pll(b->chans[c].cfg)) {
@@ -1070,7 +1087,7 @@ void pll_rank(const kq_bank *b, int ch, int &rank, int &npll) {
 
 // checks and lazy allocations before a channel becomes a PLL channel (linear.c:51-56: the carrier search window is
 // +-300 Hz, x2 when squaring, in bins of the 65536-point transform)
-int pll_admit(kq_bank *b, const kq_channel_config &m, int npll) {
+static int pll_admit(kq_bank *b, const kq_channel_config &m, int npll) {
   if (npll >= kq_bank::kMaxPll) {
     set_err("at most %d carrier-tracking (pll) channels per bank", kq_bank::kMaxPll);
     return -1;
@@ -1092,14 +1109,14 @@ int pll_admit(kq_bank *b, const kq_channel_config &m, int npll) {
 }
 
 // open slot `rank` for a fresh loop (linear.c:97-112) / close it; both streams are idle
-int pll_enter(kq_bank *b, int rank, int npll) {
+static int pll_enter(kq_bank *b, int rank, int npll) {
   for (int s = npll; s > rank; s--)
     if (move_pll_slot(b, s - 1, s)) return -1;
   HIP_TRY(hipMemset(b->pll_state + rank, 0, sizeof(kq::PllState)));
   HIP_TRY(hipMemset(b->pll_rings + (size_t)rank * 65536, 0, sizeof(float2) * 65536));
   return 0;
 }
-int pll_leave(kq_bank *b, int rank, int npll) {
+static int pll_leave(kq_bank *b, int rank, int npll) {
   for (int s = rank; s < npll; s++)
     if (move_pll_slot(b, s + 1, s)) return -1;
   return 0;
@@ -1408,7 +1425,7 @@ int kq_bank_push_iq(kq_bank *b, const void *iq, size_t nsamples, int format, int
 }
 
 namespace {
-int host_io_setup(kq_bank *b) {
+static int host_io_setup(kq_bank *b) {
   if (b->copy_in) return 0;
   // Streams share a handful of hardware queues, handed out in creation order, and a queue runs in order: the two copy
   // streams can land on one queue.  Then an input copy queued BEHIND an output copy waits with it for that call's
@@ -1427,7 +1444,7 @@ int host_io_setup(kq_bank *b) {
   return 0;
 }
 // block completion bookkeeping for the IF-power rule (radio.c:140-146 against radio.c:94-98)
-void note_pushed(kq_bank *b, size_t nsamples, unsigned char zero) {
+static void note_pushed(kq_bank *b, size_t nsamples, unsigned char zero) {
   size_t fill = b->pending % b->g.L, left = nsamples;
   while (left) {
     size_t const take = std::min(left, (size_t)b->g.L - fill);
@@ -1470,6 +1487,11 @@ int kq_bank_push_iq_async(kq_bank *b, const void *iq, size_t nsamples, int forma
     b->in_stage_cap[k] = nsamples * bps;
     HIP_TRY(hipMalloc(&b->in_stage[k], b->in_stage_cap[k]));
   }
+  // The header's promise -- `iq` may be reused once two more pushes have been queued -- is kept here: the push two
+  // back used this staging index, and its host-to-device copy must have READ the caller's buffer before this call
+  // returns (a device-side wait alone would let the host run ahead of the copy engine).  Normally long done.
+  if (b->in_used[k]) HIP_TRY(hipEventSynchronize(b->in_ready[k]));
+  b->in_used[k] = true;
   HIP_TRY(hipStreamWaitEvent(b->copy_in, b->in_free[k], 0));  // the conversion kernel that last read this buffer
   HIP_TRY(hipMemcpyAsync(b->in_stage[k], iq, nsamples * bps, hipMemcpyHostToDevice, b->copy_in));
   HIP_TRY(hipEventRecord(b->in_ready[k], b->copy_in));
@@ -1530,7 +1552,7 @@ int kq_bank_host_io_wait(kq_bank *b) {
   if (!b) return -1;
   if (b->copy_in) HIP_TRY(hipStreamSynchronize(b->copy_in));
   if (b->copy_out) HIP_TRY(hipStreamSynchronize(b->copy_out));
-  return 0;
+  return report_lost_sibling(b);  // the planes just landed come from kernels that have finished
 }
 
 int kq_bank_push_zeros(kq_bank *b, size_t nsamples) {
@@ -1743,12 +1765,7 @@ int kq_bank_sync(kq_bank *b) {
   kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return -1;
   if (sync_all(b)) return -1;
-  if (b->big.err && *b->big.err) {
-    *b->big.err = 0;
-    set_err("N = 65536 filter: a sibling workgroup's compute_n0 sum never arrived (n0 of that call is NaN)");
-    return -1;
-  }
-  return 0;
+  return report_lost_sibling(b);
 }
 
 unsigned kq_bank_olen(const kq_bank *b) { return b ? (unsigned)b->g.olen : 0; }

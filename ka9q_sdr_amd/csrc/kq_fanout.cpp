@@ -6,13 +6,15 @@
 // double buffered: batch k+1 travels while batch k is processed.  Channels are independent, so this is the only
 // exchange on the path.  Same protocol as ka9q_sdr_amd/shard.py (which bench.py drives through torch.distributed).
 //
-// librccl is loaded on first use (dlopen), so that a single-GPU host never maps it.
+// librccl is loaded on first use (dlopen), so that a single-GPU host never maps it; KQ_RCCL_LIB names another build of
+// it (a path for dlopen) -- tests/tsan/ runs this file, unchanged, against a thread-based stand-in that way.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -29,6 +31,7 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   ncclResult_t (*GetVersion)(int *) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
@@ -39,19 +42,24 @@ Rccl &rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (r.handle) break;
+    if (const char *named = getenv("KQ_RCCL_LIB"); named && *named) {
+      r.handle = dlopen(named, RTLD_NOW | RTLD_GLOBAL);  // and nothing else: a misspelt path must not fall back silently
+    } else {
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+      }
     }
     if (!r.handle) return;
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
     r.Broadcast = (decltype(r.Broadcast))dlsym(r.handle, "ncclBroadcast");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
     r.GetVersion = (decltype(r.GetVersion))dlsym(r.handle, "ncclGetVersion");
     r.CommCount = (decltype(r.CommCount))dlsym(r.handle, "ncclCommCount");
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Broadcast && r.GetErrorString;
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Broadcast && r.AllReduce && r.GetErrorString;
   });
   return r;
 }
@@ -73,6 +81,12 @@ struct kq_fanout {
   bool timed[2] = {false, false};
   double bcast_ms = 0;
   unsigned long long bcasts = 0;
+  // consumer-side wait (kq_fanout_enable_timing): events on the consumer's stream around the wait for `ready`
+  bool time_waits = false;
+  hipEvent_t w0[2] = {nullptr, nullptr}, w1[2] = {nullptr, nullptr};
+  bool waited[2] = {false, false};
+  double wait_ms = 0;
+  unsigned long long waits = 0, acquires = 0;
 };
 
 namespace {
@@ -89,6 +103,16 @@ void harvest(kq_fanout *f, int slot) {
     f->bcasts++;
   }
   f->timed[slot] = false;
+}
+// the same for the slot's last timed wait of the consumer
+void harvest_wait(kq_fanout *f, int slot) {
+  if (!f->waited[slot]) return;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, f->w0[slot], f->w1[slot]) == hipSuccess) {
+    f->wait_ms += ms;
+    f->waits++;
+  }
+  f->waited[slot] = false;
 }
 }  // namespace
 
@@ -148,20 +172,39 @@ kq_fanout *kq_fanout_create(int device, int rank, int world, int root, const voi
   }
   bool ok = e == hipSuccess;
   if (!ok) fail(step, e);
-  if (ok && (world > 1 || id128 != nullptr)) {  // with an id even a world of one goes through RCCL (tests)
+  if (world > 1 || id128 != nullptr) {  // with an id even a world of one goes through RCCL (tests)
+    // The communicator is entered even when this rank's own set-up has already failed: ncclCommInitRank is collective,
+    // and the other ranks would wait in theirs for ever.  Then the ranks AGREE: a one-word all-reduce (minimum of "my
+    // set-up worked") tells every rank whether every rank made it; if one did not, all of them give the communicator
+    // back and return NULL -- nobody is left holding a fan-out whose first broadcast can never complete.
     Rccl &r = rccl();
     if (!r.ok) {
-      kq_internal_set_error("kq_fanout_create: librccl not available");
-      ok = false;
+      if (ok) kq_internal_set_error("kq_fanout_create: librccl not available%s", getenv("KQ_RCCL_LIB") ? " (KQ_RCCL_LIB)" : "");
+      ok = false;  // (every rank of the world loads the same library: they all fail here, nobody waits)
     } else {
       ncclUniqueId id;
       memcpy(&id, id128, sizeof id);
-      // collective: returns once every rank of the world has called it with the same id
       ncclResult_t const ne = r.CommInitRank(&f->comm, world, id, rank);
       if (ne != ncclSuccess) {
-        kq_internal_set_error("kq_fanout_create: ncclCommInitRank(rank %d of %d): %s", rank, world, r.GetErrorString(ne));
+        if (ok) kq_internal_set_error("kq_fanout_create: ncclCommInitRank(rank %d of %d): %s", rank, world, r.GetErrorString(ne));
         f->comm = nullptr;
         ok = false;
+      } else {
+        int *flag = nullptr;  // device memory: the all-reduce runs in place on it
+        int mine = ok ? 1 : 0, all = 0;
+        bool agreed = hipMalloc((void **)&flag, sizeof(int)) == hipSuccess &&
+                      hipMemcpyAsync(flag, &mine, sizeof(int), hipMemcpyHostToDevice, f->side) == hipSuccess &&
+                      r.AllReduce(flag, flag, 1, ncclInt32, ncclMin, f->comm, f->side) == ncclSuccess &&
+                      hipMemcpyAsync(&all, flag, sizeof(int), hipMemcpyDeviceToHost, f->side) == hipSuccess &&
+                      hipStreamSynchronize(f->side) == hipSuccess;
+        if (flag) (void)hipFree(flag);
+        if (!agreed) {
+          if (ok) kq_internal_set_error("kq_fanout_create: the ranks' agreement (ncclAllReduce) failed on rank %d", rank);
+          ok = false;
+        } else if (!all) {
+          if (ok) kq_internal_set_error("kq_fanout_create: another rank's set-up failed; every rank gives up (rank %d)", rank);
+          ok = false;
+        }
       }
     }
   }
@@ -183,6 +226,8 @@ int kq_fanout_destroy(kq_fanout *f) {
     if (f->freed[i]) (void)hipEventDestroy(f->freed[i]);
     if (f->t0[i]) (void)hipEventDestroy(f->t0[i]);
     if (f->t1[i]) (void)hipEventDestroy(f->t1[i]);
+    if (f->w0[i]) (void)hipEventDestroy(f->w0[i]);
+    if (f->w1[i]) (void)hipEventDestroy(f->w1[i]);
   }
   if (f->side) (void)hipStreamDestroy(f->side);
   delete f;
@@ -236,11 +281,20 @@ const void *kq_fanout_acquire(kq_fanout *f, int slot, void *consumer_stream, siz
   kq::DeviceScope scope(f->device);
   // a batch that has already landed needs no wait on the device (a cross-stream wait is a barrier packet: microseconds
   // of idle consumer stream even for an event that fired long ago)
-  if (hipEventQuery(f->ready[slot]) != hipSuccess)
-    if (hipError_t e = hipStreamWaitEvent((hipStream_t)consumer_stream, f->ready[slot], 0); e != hipSuccess) {
+  f->acquires++;
+  if (hipEventQuery(f->ready[slot]) != hipSuccess) {
+    hipStream_t const cs = (hipStream_t)consumer_stream;
+    bool const timed = f->time_waits && f->w0[slot] && f->w1[slot];
+    if (timed) {
+      harvest_wait(f, slot);
+      (void)hipEventRecord(f->w0[slot], cs);
+    }
+    if (hipError_t e = hipStreamWaitEvent(cs, f->ready[slot], 0); e != hipSuccess) {
       fail("kq_fanout_acquire: hipStreamWaitEvent", e);
       return nullptr;
     }
+    if (timed) f->waited[slot] = hipEventRecord(f->w1[slot], cs) == hipSuccess;
+  }
   if (nsamples) *nsamples = f->count[slot];
   return f->buf[slot];
 }
@@ -278,6 +332,23 @@ int kq_fanout_stats(kq_fanout *f, kq_fanout_info *out) {
   }
   out->broadcasts = f->bcasts;
   out->broadcast_ms = f->bcast_ms;
+  // (a wait still in flight on the consumer's stream is left for the next call: this one never waits for that stream)
+  for (int i = 0; i < 2; i++)
+    if (f->waited[i] && hipEventQuery(f->w1[i]) == hipSuccess) harvest_wait(f, i);
+  out->acquires = f->acquires;
+  out->waits = f->waits;
+  out->wait_ms = f->wait_ms;
+  return 0;
+}
+
+int kq_fanout_enable_timing(kq_fanout *f, int on) {
+  if (!f) return -1;
+  kq::DeviceScope scope(f->device);
+  for (int i = 0; i < 2 && on; i++) {
+    if (!f->w0[i] && hipEventCreate(&f->w0[i]) != hipSuccess) return fail("kq_fanout_enable_timing: hipEventCreate", hipGetLastError());
+    if (!f->w1[i] && hipEventCreate(&f->w1[i]) != hipSuccess) return fail("kq_fanout_enable_timing: hipEventCreate", hipGetLastError());
+  }
+  f->time_waits = on != 0;
   return 0;
 }
 

@@ -77,6 +77,10 @@ class CFanout:
         self._chk(self.lib.kq_fanout_stats(self.h, C.byref(info)), "kq_fanout_stats")
         return {k: getattr(info, k) for k, _ in info._fields_}
 
+    def enable_timing(self, on=True):
+        """time the consumer stream's waits for a batch (kq_fanout_stats: waits, wait_ms)"""
+        self._chk(self.lib.kq_fanout_enable_timing(self.h, 1 if on else 0), "kq_fanout_enable_timing")
+
     def close(self):
         if self.h:
             self.lib.kq_fanout_destroy(self.h)

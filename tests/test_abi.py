@@ -64,6 +64,29 @@ def test_radio_thread_entry_points_exported(lib):
     assert lib.demod_am(None) is None
 
 
+def test_library_exports_exactly_its_headers(lib):
+    """A library linked under an 18 kLoC C program with a flat namespace exports its headers' names and nothing else
+    (csrc/exports.map): the kq_* surface of ka9q_hip.h, the reference names of filter.h:81-105, osc.h:21-24,
+    dsp.h:20-31 and radio.h:235-237, and the one global of filter.c:279."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", kq.library_path()], capture_output=True, text=True,
+                         check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    declared = set()
+    for h in ("ka9q_hip.h", "ka9q_hip_compat.h", "ka9q_hip_radio.h"):
+        declared |= _declared(h)
+    declared |= {"Kaiser_beta"}
+    declared -= {"send_mono_output", "send_stereo_output"}       # the host program's (weak references here)
+    declared = {n for n in declared if not n.isupper()}           # macros with arguments
+    stray = exported - declared
+    assert not stray, "exported but declared by no header: %s" % sorted(stray)
+    missing = {n for n in declared if n.startswith("kq_") or n in exported} - exported
+    assert not missing, sorted(missing)
+    # every function the headers declare is there (macros such as notch_delete aside)
+    for n in sorted(declared - exported):
+        assert n in ("notch_delete", "free", "kq_cfloat", "kq_cdouble"), "declared but not exported: %s" % n
+
+
 def test_version_and_errors(lib):
     assert b"gfx950" in lib.kq_version()
     # argument validation happens before any device work

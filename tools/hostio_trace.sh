@@ -2,7 +2,7 @@
 # Kernel / copy timeline of bench.py's with_host_io row: rocprofv3 --kernel-trace --memory-copy-trace, then the last steps in
 # start order.   gpurun -- 'bash tools/hostio_trace.sh'
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/hio
 rm -rf $OUT
 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $OUT -o hio --output-format csv -- python3 $R/bench.py --steps 10 --spinup 20 --no-cpu-baseline --no-second-row "$@" > /dev/null 2>&1

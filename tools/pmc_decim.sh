@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counters for the half-band decimator kernel, one small pass per counter group (no trace domains with --pmc).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_decim
 mkdir -p $OUT
 i=0

@@ -3,7 +3,7 @@
 # note in MI355X_MICROARCH.md) next to their algorithmic bytes, then the SQ counters of tools/pmc_decim.sh.
 #   gpurun -- 'bash tools/pmc_decim_traffic.sh > gpurun_out/pmc_decim.txt'
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=/tmp/pmc_decim_t
 rm -rf $OUT; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do

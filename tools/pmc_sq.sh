@@ -1,8 +1,8 @@
 #!/bin/bash
 # SQ counters of one kernel (substring match), one small pass per counter group (no trace domains with --pmc).
-#   bash tools/pmc_sq.sh k_pruned_resident bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-second-row
+#   bash tools/pmc_sq.sh k_pruned_resident bench.py --steps 2 --warmup 1 --spinup 0 --no-host-io --no-cpu-baseline --no-second-row
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 K=$1; shift
 PROG=$1; shift
 OUT=$R/gpurun_out/pmc_sq_$K

@@ -4,7 +4,7 @@
 # Usage on the GPU box: bash tools/profile_round.sh r01     (writes gpurun_out/profiles_<tag>/; copy into profiles/<tag>/)
 TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 run_stats() {  # name, program args...

@@ -2,7 +2,7 @@
 # Kernel timeline of the headline step: rocprofv3 --kernel-trace of a short bench run, the last kernels in start order with
 # the idle time in front of each.   gpurun -- 'bash tools/step_trace.sh [bench args]'   (KQ_DEMOD_OVERLAP etc. pass through)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/steptrace
 rm -rf $OUT
 rocprofv3 --kernel-trace -d $OUT -o st --output-format csv -- python3 $R/bench.py --steps 20 --spinup 40 --no-cpu-baseline --no-second-row --no-host-io "$@" > /dev/null 2>&1

@@ -58,6 +58,9 @@ def parse():
                     help="front-end fan-out: c = the library's kq_fanout_* (ncclBroadcast, the product path); torch = "
                          "ka9q_sdr_amd/shard.py's torch.distributed twin (always used with --backend gloo)")
     ap.add_argument("--no-host-io", action="store_true", help="skip the with_host_io measurement")
+    ap.add_argument("--no-rows", action="store_true",
+                    help="skip the `rows` object: BASELINE.json's other single-GPU shapes (cfg2, cfg3, cfg5 per-GPU share), each "
+                         "with 2 s of spin-up and 20 timed steps (only measured at N = 1 on the default workload)")
     ap.add_argument("--gpu-state", action="store_true",
                     help="sample shader clock and power at 50 Hz over the spin-up steps (disturbs the timed steps by about 1 %%)")
     return ap.parse_args()
@@ -209,6 +212,87 @@ def pmc_traffic(config, channels, blocks, fwd):
     return best if best else (None, None)
 
 
+def roofline_of(wl, config, geom, plan, C, B, k_ms, n0, fwd_name, demod_ms=None):
+    """SURVEY 8d's HBM figure (algorithmic bytes / kernel time; the shared input makes it exceed what crosses the
+    memory side) and, beside it, the bounds that do bind: vector-ALU rate against the 157.3 TFLOP/s FP32 peak,
+    and the HBM traffic the PMC counters measured."""
+    abytes = sum(wl.algorithmic_bytes(geom, p["demod"], p.get("channels", 1) == 2) for p in plan) * B
+    fl = sum(wl.algorithmic_flops(geom, p["demod"], bool(p.get("doppler", 0.0)), n0, fwd_name == "pruned") for p in plan) * B
+    traffic, src = pmc_traffic(config, C, B, fwd_name)
+    ach = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    r = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+         "traffic": traffic, "traffic_source": src,
+         "kernel": "pre-detection filter (NCO mix + forward FFT%s + response + IFFT), %s path" %
+                   (" + compute_n0" if n0 else "", fwd_name),
+         "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": abytes,
+         "algorithmic_flops_per_launch": int(fl),
+         "valu_tflops": round(fl / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else 0.0,
+         "valu_peak_tflops": 157.3,
+         "valu_frac": round(fl / (k_ms * 1e-3) / 157.3e12, 4) if k_ms > 0 else 0.0,
+         "hbm_frac_measured": round(traffic / (k_ms * 1e-3) / 8e12, 4) if (traffic and k_ms > 0) else None,
+         "note": "frac = algorithmic bytes (SURVEY 8d: the N-sample window counted once per channel) / kernel time / "
+                 "8 TB/s; every channel reads the one shared input through L2, so the bytes that cross the memory "
+                 "side (hbm_frac_measured, from the FETCH_SIZE / WRITE_SIZE passes in profiles/) are ~1 % of peak and "
+                 "HBM is not what limits the kernel; valu_frac prices the same launch against the FP32 vector peak."}
+    if demod_ms is not None:
+        r["demod_ms"] = round(demod_ms, 4)
+    return r
+
+
+def measure_row(torch, kq, wl, config, blocks, dev_index, stream, pci_bus, spin_seconds=2.0, steps=20):
+    """One more single-GPU shape of BASELINE.json on the driver's own line: its per-GPU channel count,
+    compute_n0 on, input resident in HBM, `spin_seconds` of untimed identical steps, then `steps` timed ones."""
+    geom = dict(wl.GEOMETRY[config])
+    L, M, D, fs, C = geom["L"], geom["M"], geom["D"], geom["samprate"], geom["channels"]
+    plan = wl.channel_plan(config, C)
+    bank = kq.Bank(fs, L, M, D, C, blocks, device=dev_index, compute_n0=True, fwd_mode=kq.KQ_FWD_AUTO, stream=stream.cuda_stream)
+    for p in plan:
+        bank.add_channel(wl.bank_channel_config(p))
+    nwin = (M - 1) + blocks * L
+    iq = torch.from_numpy(wl.make_iq(fs, nwin, seed=0x6B613971 ^ int(config[3:]))).to(torch.device("cuda", dev_index))
+    for _ in range(4):
+        bank.process_resident(iq.data_ptr(), blocks)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        bank.process_resident(iq.data_ptr(), blocks)
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - t0) / 8
+    nspin = int(min(100000, spin_seconds / max(est, 1e-6)))
+    for _ in range(nspin):
+        bank.process_resident(iq.data_ptr(), blocks)
+    torch.cuda.synchronize()
+    bank.enable_timing(1)
+    bank.timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bank.process_resident(iq.data_ptr(), blocks)
+    state = GpuState.once(pci_bus)       # the queue is still several steps deep when the files are read
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tm = bank.timing(reset=True)
+    bank.enable_timing(2)
+    for _ in range(3):
+        bank.process_resident(iq.data_ptr(), blocks)
+    torch.cuda.synchronize()
+    tm2 = bank.timing(reset=True)
+    fwd_used = {1: "full", 2: "pruned"}[bank.fwd_mode]
+    bank.close()
+    k_ms = tm["filter_ms"] / max(1, tm["filter_launches"])
+    r = roofline_of(wl, config, geom, plan, C, blocks, k_ms, True, fwd_used, tm2["demod_ms"] / max(1, tm2["filter_launches"]))
+    per_kind = {}
+    for p in plan:
+        per_kind[p["demod"]] = per_kind.get(p["demod"], 0) + 1
+    return {"workload": "%s: %d channels (%s), N=%d, decimate %d, %.3g MS/s, %d blocks/step, fwd=%s, compute_n0=1" %
+                        (config, C, "+".join("%d %s" % (v, k) for k, v in sorted(per_kind.items())), L + M - 1, D, fs / 1e6,
+                         blocks, fwd_used),
+            "value": round(C * blocks * L / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 4), "steps": steps,
+            "spinup_steps": nspin, "kernel_ms": r["kernel_ms"], "demod_ms": r.get("demod_ms"),
+            "frac": r["frac"], "valu_frac": r["valu_frac"],
+            "step_frac": round(r["algorithmic_bytes_per_launch"] / dt / 8e12, 4),
+            "realtime_factor": round(blocks * L / dt / fs, 2), "gpu_state": state}
+
+
 def self_launch(a):
     """`bench.py --gpus N` started as a plain process: start the N ranks ourselves (one child per GPU through
     torch.distributed.run) BEFORE anything here touches the GPU, pass rank 0's JSON line through, exit with its code."""
@@ -348,6 +432,9 @@ def main():
         cold.append(round((time.perf_counter() - tc) * 1e3, 4))
     # Spin-up, then the W warm-up steps, then the K timed steps: one continuous sequence of identical steps.  The
     # spin-up count is even so that the double buffers are at the same parity whatever its length.
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    if a.spinup < 0 and under_profiler:
+        a.spinup = 300      # a trace or counter pass of ten thousand serialised launches takes minutes and gigabytes
     if a.spinup >= 0:
         spin = 2 * (a.spinup // 2)
     else:   # by time, from the cold steps just measured; every rank runs the same count (the steps post collectives)
@@ -365,8 +452,12 @@ def main():
     gpu_state = GpuState(pci_bus) if rank == 0 and a.gpu_state else None
     if gpu_state:
         gpu_state.start()
+    torch.cuda.synchronize()
+    ts0 = time.perf_counter()
     for k in range(spin):
         step(4 + k)
+    torch.cuda.synchronize()     # one wait at its end: the spin-up's own average sits inside the driver's clock around this run
+    spin_ms = (time.perf_counter() - ts0) / max(1, spin) * 1e3
     spin_reported = spin
     spin += 4       # the four cold steps kept the slot parity
     for k in range(a.warmup):
@@ -395,6 +486,7 @@ def main():
         reader.join()
         gpu_state = reading.get("state")
     elapsed = t1 - t0
+    elapsed_local = elapsed
     rank_ms = [elapsed / a.steps * 1e3] * 2      # fastest / slowest rank
     if dist:
         tdev = dev if a.backend == "nccl" else "cpu"
@@ -406,10 +498,34 @@ def main():
         rank_ms = [float(tmin.item()) / a.steps * 1e3, elapsed / a.steps * 1e3]
     fan_stats = fan.stats() if use_c else None
     tm = bank.timing(reset=True)
+    # Per-rank diagnostics (a sub-linear scaling result must be readable from the one line): a few more untimed steps with
+    # the consumer stream's waits for its batch timed (two event records per acquire that has to wait), then every rank's
+    # step time, filter-kernel time, broadcast time and stall time travel to rank 0.
+    per_rank = None
+    if use_c and world > 1:
+        fan.enable_timing(True)
+        nd = 40
+        for k in range(nd):
+            step(spin + a.warmup + a.steps + k)
+        torch.cuda.synchronize()
+        fan.enable_timing(False)
+        fs2 = fan.stats()
+        mine = torch.tensor([elapsed_local / a.steps * 1e3, tm["filter_ms"] / max(1, tm["filter_launches"]),
+                             fs2["broadcast_ms"] / max(1, fs2["broadcasts"]), float(fs2["broadcasts"]),
+                             fs2["wait_ms"] / nd, float(fs2["waits"]), float(nd)], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "ms_per_step": round(float(v[0]), 4), "kernel_ms": round(float(v[1]), 4),
+                     "bcast_ms": round(float(v[2]), 4), "bcasts_timed": int(v[3]),
+                     "wait_ms_per_step": round(float(v[4]), 4), "waits": int(v[5]), "diag_steps": int(v[6])}
+                    for r, v in enumerate(allr)]
+        a_steps_done = a.steps + nd
+    else:
+        a_steps_done = a.steps
     # the demodulator kernels' time comes from a few extra, untimed steps with the full set of events
     bank.enable_timing(2)
-    for k in range(3):
-        step(spin + a.warmup + a.steps + k)
+    for k in range(4):       # (an even count: the slots keep their parity)
+        step(spin + a.warmup + a_steps_done + k)
     torch.cuda.synchronize()
     tm2 = bank.timing(reset=True)
     bank.enable_timing(0)
@@ -484,6 +600,13 @@ def main():
                   "unit": "Msamples/s (channel-samples)", "ms_per_step": round(dt * 1e3, 4), "steps": n2,
                   "kernel_ms": round(tm_b["filter_ms"] / max(1, tm_b["filter_launches"]), 4)}
 
+    # BASELINE.json's other single-GPU shapes, each measured the same way on this box in this run
+    rows = None
+    if world == 1 and not a.no_rows and a.config == "cfg4" and not under_profiler:
+        rows = {}
+        for name, blocks in (("cfg2", 64), ("cfg3", 64), ("cfg5", 16)):
+            rows[name] = measure_row(torch, kq, wl, name, blocks, dev_index, stream, pci_bus)
+
     if rank == 0:
         total_ch = C * world
         chan_samples = total_ch * B * L * a.steps
@@ -492,35 +615,8 @@ def main():
         per_kind = {}
         for p in plan:
             per_kind[p["demod"]] = per_kind.get(p["demod"], 0) + 1
-        abytes = sum(wl.algorithmic_bytes(geom, p["demod"], p.get("channels", 1) == 2) for p in plan) * B
-
-        def flops(n0, pruned):
-            return sum(wl.algorithmic_flops(geom, p["demod"], bool(p.get("doppler", 0.0)), n0, pruned) for p in plan) * B
-
         def roofline(k_ms, n0, fwd_name, demod_ms=None):
-            """SURVEY 8d's HBM figure (algorithmic bytes / kernel time; the shared input makes it exceed what crosses the
-            memory side) and, beside it, the bounds that do bind: vector-ALU rate against the 157.3 TFLOP/s FP32 peak,
-            and the HBM traffic the PMC counters measured."""
-            traffic, src = pmc_traffic(a.config, C, B, fwd_name)
-            ach = abytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-            fl = flops(n0, fwd_name == "pruned")
-            r = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                 "traffic": traffic, "traffic_source": src,
-                 "kernel": "pre-detection filter (NCO mix + forward FFT%s + response + IFFT), %s path" %
-                           (" + compute_n0" if n0 else "", fwd_name),
-                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": abytes,
-                 "algorithmic_flops_per_launch": int(fl),
-                 "valu_tflops": round(fl / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else 0.0,
-                 "valu_peak_tflops": 157.3,
-                 "valu_frac": round(fl / (k_ms * 1e-3) / 157.3e12, 4) if k_ms > 0 else 0.0,
-                 "hbm_frac_measured": round(traffic / (k_ms * 1e-3) / 8e12, 4) if (traffic and k_ms > 0) else None,
-                 "note": "frac = algorithmic bytes (SURVEY 8d: the N-sample window counted once per channel) / kernel time / "
-                         "8 TB/s; every channel reads the one shared input through L2, so the bytes that cross the memory "
-                         "side (hbm_frac_measured, from the FETCH_SIZE / WRITE_SIZE passes in profiles/) are ~1 % of peak and "
-                         "HBM is not what limits the kernel; valu_frac prices the same launch against the FP32 vector peak."}
-            if demod_ms is not None:
-                r["demod_ms"] = round(demod_ms, 4)
-            return r
+            return roofline_of(wl, a.config, geom, plan, C, B, k_ms, n0, fwd_name, demod_ms)
 
         k_ms = tm["filter_ms"] / max(1, tm["filter_launches"])
         out = {
@@ -528,6 +624,7 @@ def main():
             "value": round(value, 1),
             "unit": "Msamples/s (channel-samples: front-end input samples x channels, all GPUs)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "spinup_steps": spin_reported,
+            "spinup_ms_per_step": round(spin_ms, 4),
             "ms_per_step": round(elapsed / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -556,6 +653,11 @@ def main():
                            "bytes_per_broadcast": nwin * 8,
                            "note": "ranks = ncclCommCount of the fan-out's communicator (0: one rank, no communicator); "
                                    "bcast_ms = HIP events around ncclBroadcast on the side stream, rank 0"}
+        out["step_frac"] = round(out["roofline"]["algorithmic_bytes_per_launch"] / (elapsed / a.steps) / 8e12, 4)
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        if rows:
+            out["rows"] = rows
         if host_io:
             host_io["fraction_of_value"] = round(host_io["value"] / max(value, 1e-9), 4)
             out["with_host_io"] = host_io

@@ -204,6 +204,10 @@ int kq_bank_process_resident(kq_bank *bank, const void *iq_dev, unsigned nblocks
  * kq_bank_sync blocks the host until everything issued so far has finished. */
 int kq_bank_join(kq_bank *bank);
 int kq_bank_sync(kq_bank *bank);
+/* The hipStream_t the bank launches on, as void*: kq_bank_config.stream, or the bank's own stream when that was NULL.
+ * A C host without the HIP headers hands it to kq_fanout_acquire / kq_fanout_release as the consumer stream. */
+void *kq_bank_stream(kq_bank *bank);
+
 /* --- streaming host I/O ---
  * Both ends of the path are host buffers in the reference: a packet's samples in (radio.c:106-147), one float buffer
  * per block out (audio.c:82 send_mono_output(demod, samples, olen)).  These three move whole batches between PINNED host

@@ -1752,6 +1752,8 @@ int kq_bank_process_resident(kq_bank *b, const void *iq_dev, unsigned nblocks) {
   return run_blocks(b, (const float2 *)iq_dev, nblocks, upd.data());
 }
 
+void *kq_bank_stream(kq_bank *b) { return b ? (void *)b->stream : nullptr; }
+
 int kq_bank_join(kq_bank *b) {
   kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return -1;

@@ -25,3 +25,23 @@ def test_radio_bank_c_example_runs(gpu):
     lines = run.stdout.strip().splitlines()
     assert lines[-1] == "ok"
     assert sum(1 for ln in lines if ln.startswith("block ")) == 4
+
+
+def test_radio_fanout_c_example_runs_with_a_world_of_one(gpu):
+    """examples/radio_fanout.c (the plain-C host for several GPUs, one thread per GPU) on the one GPU of the test box:
+    world = 1, the bank's own stream from kq_bank_stream as the fan-out's consumer stream, batches posted from host
+    memory; the FM channel on the first carrier must measure its 3 kHz deviation.  (World = 8 runs on the CPU against
+    the mock RCCL: tests/test_tsan_compat.py.)"""
+    lib = os.path.join(ROOT, "ka9q_sdr_amd", "lib")
+    out = os.path.join(tempfile.gettempdir(), "kq_radio_fanout_example_%d" % os.getpid())
+    r = subprocess.run(["gcc", "-std=gnu11", "-O2", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "radio_fanout.c"), "-L", lib, "-lka9q_hip", "-Wl,-rpath," + lib,
+                        "-lm", "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    try:
+        run = subprocess.run([out, "1", "5"], capture_output=True, text=True, timeout=300)
+    finally:
+        os.unlink(out)
+    assert run.returncode == 0, run.stdout + run.stderr
+    lines = run.stdout.strip().splitlines()
+    assert lines[-1] == "ok" and lines[0].startswith("rank 0: channels 0..26  rccl ranks 0")

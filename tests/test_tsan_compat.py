@@ -49,3 +49,20 @@ def test_fanout_protocol_with_a_world_of_eight_is_race_free():
         r = subprocess.run(["make", "-C", os.path.join(HERE, "tsan"), "fanout", "WORLD=%d" % w, "STEPS=400"],
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "fan-out protocol: ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_c_host_for_several_gpus_runs_with_a_world_of_eight():
+    """examples/radio_fanout.c -- one thread per GPU, plain C -- compiled unchanged by gcc and run with a world of 8 under
+    ThreadSanitizer against kq_fanout.cpp (unchanged), the mock streams, the mock librccl and a stand-in bank: every rank
+    must have seen bit-identical front-end samples (IF power of every block equal to rank 0's)."""
+    if not shutil.which("g++") or not shutil.which("make"):
+        pytest.skip("no g++ / make")
+    probe = subprocess.run("echo 'int main(){}' | g++ -x c++ -fsanitize=thread - -o /dev/null", shell=True, capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("this g++ has no ThreadSanitizer runtime")
+    r = subprocess.run(["make", "-C", os.path.join(HERE, "tsan"), "example", "WORLD=8"], capture_output=True, text=True,
+                       timeout=900)
+    out = r.stdout + r.stderr
+    assert "ThreadSanitizer" not in out, out[-4000:]
+    assert r.returncode == 0, out[-4000:]
+    assert out.count("rccl ranks 8") == 8 and "\nok\n" in out

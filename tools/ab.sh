@@ -8,7 +8,7 @@ cp $LIB /tmp/libka9q_hip.keep
 for f in $R/ab/*.so; do
   cp $f $LIB
   for rep in 1 2; do
-    python $R/bench.py --steps 50 --no-cpu-baseline --no-second-row "$@" 2>/dev/null | grep -o -E '"(kernel_ms|ms_per_step)": [0-9.]*' | head -2 | tr '\n' ' '
+    python $R/bench.py --steps 50 --no-cpu-baseline --no-second-row --no-rows "$@" 2>/dev/null | grep -o -E '"(kernel_ms|ms_per_step)": [0-9.]*' | head -2 | tr '\n' ' '
   done
   echo " $(basename $f .so)"
 done

@@ -8,7 +8,7 @@ while [ $# -gt 0 ] && [ "$1" != "--" ]; do vals+=("$1"); shift; done
 for rep in 1 2; do
   for v in "${vals[@]}"; do
     if [ "$v" == "unset" ]; then unset $var; else export $var=$v; fi
-    python $R/bench.py --steps 50 --no-cpu-baseline --no-second-row "$@" 2>/dev/null | grep -o -E '"(kernel_ms|ms_per_step)": [0-9.]*' | head -2 | tr '\n' ' '
+    python $R/bench.py --steps 50 --no-cpu-baseline --no-second-row --no-rows "$@" 2>/dev/null | grep -o -E '"(kernel_ms|ms_per_step)": [0-9.]*' | head -2 | tr '\n' ' '
     echo " $var=$v"
   done
 done

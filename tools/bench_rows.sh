@@ -2,7 +2,7 @@
 # One line per bench configuration: step, kernel, roofline fraction.   gpurun -- 'bash tools/bench_rows.sh'
 R=${GRAFT_REPO_ROOT:-/root/repo}
 row() {
-  python $R/bench.py "$@" --steps 50 --no-cpu-baseline --no-second-row --no-host-io 2>/dev/null | python -c '
+  python $R/bench.py "$@" --steps 50 --no-cpu-baseline --no-second-row --no-rows --no-host-io 2>/dev/null | python -c '
 import json, sys
 d = json.loads(sys.stdin.readline())
 r = d["roofline"]

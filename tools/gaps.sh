@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/gaps
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace -d $OUT/raw -o t --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --spinup 300 --no-host-io --no-cpu-baseline --no-second-row > $OUT/bench.json 2> $OUT/err.log
+rocprofv3 --kernel-trace -d $OUT/raw -o t --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --spinup 300 --no-host-io --no-cpu-baseline --no-second-row --no-rows > $OUT/bench.json 2> $OUT/err.log
 F=$(find $OUT/raw -name "*kernel_trace.csv" | head -1)
 python3 - <<PY
 import csv

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/hio
 rm -rf $OUT
-rocprofv3 --kernel-trace --memory-copy-trace --stats -d $OUT -o hio --output-format csv -- python3 $R/bench.py --steps 10 --spinup 20 --no-cpu-baseline --no-second-row "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --stats -d $OUT -o hio --output-format csv -- python3 $R/bench.py --steps 10 --spinup 20 --no-cpu-baseline --no-second-row --no-rows "$@" > /dev/null 2>&1
 python3 - <<PY
 import csv
 rows=[]

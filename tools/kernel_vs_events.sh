@@ -5,10 +5,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for ov in 1 0; do
   export KQ_DEMOD_OVERLAP=$ov
-  python3 $R/bench.py --steps 50 --spinup 300 --no-cpu-baseline --no-second-row --no-host-io 2>/dev/null | grep -o -E '"(kernel_ms|ms_per_step)": [0-9.]*' | head -2 | tr '\n' ' '
+  python3 $R/bench.py --steps 50 --spinup 300 --no-cpu-baseline --no-second-row --no-rows --no-host-io 2>/dev/null | grep -o -E '"(kernel_ms|ms_per_step)": [0-9.]*' | head -2 | tr '\n' ' '
   echo " unprofiled, overlap=$ov"
   rm -rf /tmp/kve
-  rocprofv3 --kernel-trace --stats -d /tmp/kve -o k --output-format csv -- python3 $R/bench.py --steps 50 --spinup 300 --no-cpu-baseline --no-second-row --no-host-io 2>/dev/null | grep -o -E '"(kernel_ms|ms_per_step)": [0-9.]*' | head -2 | tr '\n' ' '
+  rocprofv3 --kernel-trace --stats -d /tmp/kve -o k --output-format csv -- python3 $R/bench.py --steps 50 --spinup 300 --no-cpu-baseline --no-second-row --no-rows --no-host-io 2>/dev/null | grep -o -E '"(kernel_ms|ms_per_step)": [0-9.]*' | head -2 | tr '\n' ' '
   echo " under rocprofv3, overlap=$ov"
   python3 - <<'PY'
 import csv, glob

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of one kernel (substring match), one small pass per counter group (no trace domains with --pmc).
-#   bash tools/pmc_sq.sh k_pruned_resident bench.py --steps 2 --warmup 1 --spinup 0 --no-host-io --no-cpu-baseline --no-second-row
+#   bash tools/pmc_sq.sh k_pruned_resident bench.py --steps 2 --warmup 1 --spinup 0 --no-host-io --no-cpu-baseline --no-second-row --no-rows
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 K=$1; shift

@@ -13,7 +13,7 @@ run_stats() {  # name, program args...
   local f=$(find $OUT/raw_$name -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/${name}_kernel_stats.csv
 }
-Q="--no-cpu-baseline --no-second-row --no-host-io --spinup 300"
+Q="--no-cpu-baseline --no-second-row --no-rows --no-host-io --spinup 300"
 run_stats full_n0_cfg4 $R/bench.py --steps 10 --spinup 300 --cpu-seconds 4
 run_stats pruned_cfg4 $R/bench.py --steps 10 --n0 0 $Q
 run_stats full_n0_cfg2 $R/bench.py --steps 10 --config cfg2 $Q

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/steptrace
 rm -rf $OUT
-rocprofv3 --kernel-trace -d $OUT -o st --output-format csv -- python3 $R/bench.py --steps 20 --spinup 40 --no-cpu-baseline --no-second-row --no-host-io "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace -d $OUT -o st --output-format csv -- python3 $R/bench.py --steps 20 --spinup 40 --no-cpu-baseline --no-second-row --no-rows --no-host-io "$@" > /dev/null 2>&1
 python3 - <<PY
 import csv
 rows=[]

@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--spinup", "100", "--no-cpu-baseline", "--no-second-row", "--no-host-io"] + sys.argv[1:]
+sys.argv = ["bench.py", "--steps", "3", "--warmup", "1", "--spinup", "100", "--no-cpu-baseline", "--no-second-row", "--no-rows", "--no-host-io"] + sys.argv[1:]
 try:
     runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
 except SystemExit:

@@ -198,6 +198,14 @@ int kq_bank_process(kq_bank *bank);
 /* Convenience for resident-input benchmarks: process `nblocks` blocks reading the window
  * [M-1 history | nblocks*L] straight from `iq_dev` (device, complex float), no ring copy. */
 int kq_bank_process_resident(kq_bank *bank, const void *iq_dev, unsigned nblocks);
+/* The part of the path that follows the master (what a demodulator thread of the reference does with
+ * filter.in->fdomain): `spectrum_dev` = nblocks x N complex float bins in device memory, the master's forward
+ * transform of each block (execute_filter_input, filter.c:151) -- execute_filter_output (filter.c:206-250),
+ * compute_n0 (radio.c:383-425) and the demodulators run on it; nothing is mixed or transformed forward.  Channels must
+ * have no second LO / Doppler set (that mix sits in front of the master, radio.c:132-139); status.if_power is left 0
+ * (radio.c:143-145 belongs to whoever fed the master).  The demodulator thread entry points use this on the compat
+ * master's resident spectrum. */
+int kq_bank_process_spectrum(kq_bank *bank, const void *spectrum_dev, unsigned nblocks);
 /* The demodulators of a call may run on a second internal stream, overlapping the next call's filter pass (the bank
  * decides per call: after kq_bank_pull_planes_async, or with AM / SSB channels; KQ_DEMOD_OVERLAP=0 / 1 forces it).
  * kq_bank_join makes the bank's main stream wait (on the device) for the last call's demodulators wherever they ran;

@@ -527,7 +527,10 @@ int upload_lists(kq_bank *b) {
 }
 
 // The kernels of one call over `nblocks` blocks whose first window starts at `window`
-int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigned char *update_host) {
+// `spectrum` != null: the master's transform has been done elsewhere (execute_filter_input of the compat surface) and
+// `spectrum` holds its N bins per block -- slave, compute_n0 and demodulators only (kq_bank_process_spectrum)
+int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigned char *update_host,
+               const float2 *spectrum = nullptr) {
   kq::Geom const &g = b->g;
   int const C = (int)b->chans.size();
   bool any = false;
@@ -602,9 +605,11 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   {
     Scope t(b, 2, b->stream);
     // the partial sums live behind the plane's max_blocks if_power values
-    kq::launch_block_energy_sum(b->stream, window + (g.M - 1), g.L, (int)nblocks, pl.if_power + b->cfg.max_blocks,
+    // (spectrum mode: no samples to sum -- the launch only carries the call's parameter block to the device)
+    kq::launch_block_energy_sum(b->stream, window + (g.M - 1), g.L, spectrum ? 0 : (int)nblocks, pl.if_power + b->cfg.max_blocks,
                                 b->stage_host[slot], b->osc_dev2[pp],
-                                nret ? ret_off + nret * sizeof(int) : 8 * Cmax * sizeof(double) + nblocks, paired, (int)(g.M - 1));
+                                nret ? ret_off + nret * sizeof(int) : 8 * Cmax * sizeof(double) + nblocks,
+                                spectrum ? nullptr : paired, (int)(g.M - 1));
   }
   LAUNCH_CHECK("IF power");
   if (b->timing) {
@@ -622,7 +627,22 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
       else
         kq::launch_filter_full(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list);
     };
-    if (b->fwd_mode == KQ_FWD_PRUNED) {
+    if (spectrum) {
+      // execute_filter_output (filter.c:206-250) and compute_n0 (radio.c:383-425) on the spectrum handed in: one small
+      // launch each per channel-block (this is the one-channel, one-block path of the demodulator thread entry points)
+      for (int c = 0; c < C; c++) {
+        if (!b->chans[c].active) continue;
+        bool const isb = b->chans[c].cfg.demod_type == KQ_LINEAR_DEMOD && b->chans[c].cfg.isb;
+        for (unsigned k = 0; k < nblocks; k++) {
+          const float2 *X = spectrum + (size_t)k * g.N;
+          size_t const cb = (size_t)c * g.max_blocks + k;
+          if (b->cfg.compute_n0)
+            kq::launch_n0_single(b->stream, X, g.N, g.samprate, b->chans[c].cfg.low, b->chans[c].cfg.high, pl.n0raw + cb);
+          kq::launch_slave_bank(b->stream, X, chd.resp + (size_t)c * g.Ndec, pl.filt + cb * g.olen, g.N, g.Ndec, g.olen, isb ? 2 : 1,
+                                b->tw, g.tw_log2);
+        }
+      }
+    } else if (b->fwd_mode == KQ_FWD_PRUNED) {
       if (b->chan_tw_dirty) {  // the tables depend only on each channel's LO step: rebuild after a retune
         kq::launch_pruned_tables(b->stream, g, chd, b->chan_tw, C);
         b->chan_tw_dirty = false;
@@ -692,8 +712,9 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   // the IF-power recurrence over the call's blocks: one wave, consumed by the demodulators only, so it runs with them and
   // not in front of the filter (folded into the sum's launch -- its last workgroup taking tagged partial sums as they
   // arrive -- it saved nothing measurable: 1.422 against 1.421 ms per step)
-  kq::launch_block_energy_iir(ds, pl.if_power + b->cfg.max_blocks, g.L, (int)nblocks,
-                              reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power);
+  if (!spectrum)  // (spectrum mode: the IF power belongs to whoever fed the master, radio.c:123,143-145; status.if_power stays 0)
+    kq::launch_block_energy_iir(ds, pl.if_power + b->cfg.max_blocks, g.L, (int)nblocks,
+                                reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power);
   {
     Scope t(b, 1, ds);
     int const nfm = (int)b->list_host[0].size(), nam = (int)b->list_host[1].size(), nlin = (int)b->list_host[2].size();
@@ -1752,7 +1773,30 @@ int kq_bank_process_resident(kq_bank *b, const void *iq_dev, unsigned nblocks) {
   return run_blocks(b, (const float2 *)iq_dev, nblocks, upd.data());
 }
 
+int kq_bank_process_spectrum(kq_bank *b, const void *spectrum_dev, unsigned nblocks) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  if (!b || !spectrum_dev) {
+    set_err("NULL argument");
+    return -1;
+  }
+  if (nblocks == 0 || nblocks > b->cfg.max_blocks) {
+    set_err("nblocks %u out of range 1..%u", nblocks, b->cfg.max_blocks);
+    return -1;
+  }
+  for (HostChan const &h : b->chans) {
+    if (!h.active) continue;
+    // the spectrum is what it is: a channel that still has an oscillator to apply cannot be served from it
+    if (h.lo2.set_f != 0 || h.dop.set_f != 0) {
+      set_err("kq_bank_process_spectrum: a channel has a second LO or Doppler set; the mix belongs in front of the master");
+      return -1;
+    }
+  }
+  std::vector<unsigned char> upd(nblocks, 0);
+  return run_blocks(b, nullptr, nblocks, upd.data(), (const float2 *)spectrum_dev);
+}
+
 void *kq_bank_stream(kq_bank *b) { return b ? (void *)b->stream : nullptr; }
+
 
 int kq_bank_join(kq_bank *b) {
   kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);

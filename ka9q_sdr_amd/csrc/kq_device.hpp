@@ -188,6 +188,8 @@ void launch_fft_large(hipStream_t s, const float2 *in, float2 *out, float2 *tmp,
 void launch_n0_single(hipStream_t s, const float2 *fdomain, int N, int samprate, float low, float high, float *out);
 void launch_slave_single(hipStream_t s, const float2 *fdomain, const float2 *resp, float2 *out, int N, int Ndec,
                          int in_real, int out_type, const float2 *tw, int tw_log2);
+void launch_slave_bank(hipStream_t s, const float2 *fdomain, const float2 *resp, float2 *out, int N, int Ndec, int olen,
+                       int out_type, const float2 *tw, int tw_log2);
 size_t pruned_table_elems(const Geom &g);
 
 
@@ -196,6 +198,8 @@ size_t pruned_table_elems(const Geom &g);
 // `dst` (device), ordered behind that transform on the compat stream, and waits for it.  Returns N, or -1.
 // *block: the master's block number the copied window belongs to (the master may be one block ahead of its consumers)
 int compat_snapshot_window(struct filter_in *master, float2 *dst, unsigned *block);
+// the same for the master's device-resident SPECTRUM (N bins) of the block last transformed
+int compat_snapshot_spectrum(struct filter_in *master, float2 *dst, unsigned *block);
 int compat_master_device(void);  // device the compat surface runs on (the calling thread's current device at first use)
 
 }  // namespace kq

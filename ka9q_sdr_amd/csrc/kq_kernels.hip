@@ -1168,6 +1168,40 @@ __global__ void k_slave_single(const float2 *__restrict__ X, const float2 *__res
   }
 }
 
+// The bank's slave on a spectrum handed in from outside (kq_bank_process_spectrum): COMPLEX in, COMPLEX or CROSS_CONJ out,
+// the last `olen` of the N_dec outputs (filter.c:131) to `out`.
+__global__ void k_slave_bank(const float2 *__restrict__ X, const float2 *__restrict__ H, float2 *__restrict__ out, int N, int Ndec,
+                             int log2Ndec, int olen, int out_type, const float2 *__restrict__ tw, int tw_log2) {
+  extern __shared__ __attribute__((aligned(16))) float2 G[];
+  for (int p = threadIdx.x; p <= Ndec / 2; p += blockDim.x) {
+    float2 gp = cmul(H[p], X[p]);
+    if (p > 0 && p < Ndec / 2) {
+      int const k = Ndec - p;
+      float2 gn = cmul(H[k], X[N - p]);  // filter.c:225-227
+      if (out_type == 2) {               // CROSS_CONJ, filter.c:239-249
+        float2 const pos = gp, neg = gn;
+        gp = cadd(pos, cconj(neg));
+        gn = csub(neg, cconj(pos));
+      }
+      G[bitrev((unsigned)k, log2Ndec)] = gn;
+    }
+    G[bitrev((unsigned)p, log2Ndec)] = gp;
+  }
+  lds_fft<+1>(G, log2Ndec, tw, tw_log2);
+  for (int i = threadIdx.x; i < olen; i += blockDim.x) out[i] = G[Ndec - olen + i];
+}
+
+void launch_slave_bank(hipStream_t s, const float2 *fdomain, const float2 *resp, float2 *out, int N, int Ndec, int olen,
+                       int out_type, const float2 *tw, int tw_log2) {
+  int log2Ndec = 0;
+  while ((1 << log2Ndec) < Ndec) log2Ndec++;
+  size_t const lds_bytes = sizeof(float2) * (size_t)Ndec;
+  ensure_dynamic_lds((const void *)k_slave_bank, lds_bytes);
+  int const threads = Ndec >= 4096 ? 1024 : 256;
+  hipLaunchKernelGGL(k_slave_bank, dim3(1), dim3(threads), lds_bytes, s, fdomain, resp, out, N, Ndec, log2Ndec, olen, out_type, tw,
+                     tw_log2);
+}
+
 void launch_slave_single(hipStream_t s, const float2 *fdomain, const float2 *resp, float2 *out, int N, int Ndec, int in_real,
                          int out_type, const float2 *tw, int tw_log2) {
   int log2Ndec = 0;

@@ -15,7 +15,12 @@
  *   gcc -std=gnu11 -O2 -Iinclude examples/radio_threads.c -Lka9q_sdr_amd/lib -lka9q_hip \
  *       -Wl,-rpath,$PWD/ka9q_sdr_amd/lib -rdynamic -ldl -lpthread -lm -o radio_threads
  *   radio_threads am 192000 3840 3841 4 -5000 5000 6 in.cf32 out.bin [--lo HZ] [--ref libref_am.so]
- *              [--stereo] [--isb] [--flat] [--shift HZ] [--hang S] [--recovery DBPS]
+ *              [--stereo] [--isb] [--flat] [--shift HZ] [--hang S] [--recovery DBPS] [--time]
+ *
+ * --time prints, per block (mean over the run, the first four blocks left out): the host's mix loop, execute_filter_input
+ * (upload, N-point transform on the GPU, spectrum back to filter.in->fdomain), the demodulator thread's block (from
+ * execute_filter_input's return to the hand-off: slave, compute_n0, demodulator, audio back) and the real-time factor
+ * block duration / their sum.
  *
  * out.bin, per block: int32 n, float audio[n], then 8 floats read at the hand-off: bb_power, n0, snr, foffset,
  * pdeviation, agc.gain, plfreq, noise_gain.  (FM sets its status before the hand-off, AM and linear after it:
@@ -30,8 +35,15 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "ka9q_hip_radio.h"
+
+static double now_us(void){
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
 
 static FILE *Out;
 static sem_t Block_done;
@@ -74,7 +86,7 @@ int main(int argc, char **argv){
   const char *in_path = argv[9], *out_path = argv[10], *ref = NULL;
   double lo = 0, shift = 0;
   float hang = 0, recovery = 0;
-  int stereo = 0, isb = 0, flat = 0;
+  int stereo = 0, isb = 0, flat = 0, timing = 0;
   for(int i = 11; i < argc; i++){
     if(!strcmp(argv[i], "--lo") && i + 1 < argc) lo = atof(argv[++i]);
     else if(!strcmp(argv[i], "--ref") && i + 1 < argc) ref = argv[++i];
@@ -84,6 +96,7 @@ int main(int argc, char **argv){
     else if(!strcmp(argv[i], "--stereo")) stereo = 1;
     else if(!strcmp(argv[i], "--isb")) isb = 1;
     else if(!strcmp(argv[i], "--flat")) flat = 1;
+    else if(!strcmp(argv[i], "--time")) timing = 1;
     else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
   }
   void *(*entry)(void *) = !strcmp(mode, "fm") ? demod_fm : !strcmp(mode, "am") ? demod_am : demod_linear;
@@ -129,6 +142,8 @@ int main(int argc, char **argv){
 
   float complex *blk = malloc(L * sizeof *blk);
   int rc = 0;
+  double t_mix = 0, t_master = 0, t_thread = 0;
+  int timed = 0;
   for(int b = 0; b <= nblocks; b++){
     if(b == nblocks){
       demod->terminate = 1;                 /* radio.c:335: the thread leaves after one more block */
@@ -138,11 +153,14 @@ int main(int argc, char **argv){
       rc = 1;
       break;
     }
+    double const t0 = now_us();
     for(unsigned i = 0; i < L; i++){        /* radio.c:132-139: the product is formed in double */
       double complex const s = (double complex)blk[i] * step_osc(&demod->second_LO);
       demod->filter.in->input.c[i] = (float complex)s;
     }
+    double const t1 = now_us();
     execute_filter_input(demod->filter.in);
+    double const t2 = now_us();
     if(b < nblocks){
       struct timespec ts;
       clock_gettime(CLOCK_REALTIME, &ts);
@@ -153,7 +171,19 @@ int main(int argc, char **argv){
         demod->terminate = 1;
         break;
       }
+      if(b >= 4){
+        t_mix += t1 - t0;
+        t_master += t2 - t1;
+        t_thread += now_us() - t2;
+        timed++;
+      }
     }
+  }
+  if(timing && timed > 0){
+    double const block_us = 1e6 * L / samprate, sum = (t_mix + t_master + t_thread) / timed;
+    printf("timing: N %u D %d: mix %.1f us, execute_filter_input %.1f us, demodulator thread %.1f us per block of %.1f us: "
+           "%.1f x real time (%d blocks)\n", L + M - 1, D, t_mix / timed, t_master / timed, t_thread / timed, block_us,
+           block_us / sum, timed);
   }
   if(rc == 0)
     pthread_join(demod->demod_thread, NULL);

@@ -113,6 +113,22 @@ int compat_snapshot_window(struct filter_in *m, float2 *dst, unsigned *block) {
   return d->N;
 }
 
+// The master's spectrum of the block last transformed (N bins, complex input): what execute_filter_output and
+// compute_n0 read in the reference (filter.c:206-227, radio.c:396), copied so that the master may go on to its next block.
+int compat_snapshot_spectrum(struct filter_in *m, float2 *dst, unsigned *block) {
+  if (!m || !m->fwd_plan || !dst || m->in_type != COMPLEX) return -1;
+  kq::DeviceScope dev_scope_(ctx().ok ? ctx().device : -1);
+  MasterDev *d = (MasterDev *)m->fwd_plan;
+  hipStream_t s = ctx().stream;
+  {
+    std::lock_guard<std::mutex> lk(d->in_mu);
+    if (hipMemcpyAsync(dst, d->d_fdomain, (size_t)d->N * sizeof(float2), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+    if (block) *block = d->in_block;
+  }
+  if (hipStreamSynchronize(s) != hipSuccess) return -1;
+  return d->N;
+}
+
 }  // namespace kq
 
 extern "C" {
@@ -193,14 +209,16 @@ int execute_filter_input(struct filter_in *m) {
     src = m->input_buffer.c;
   }
   {
+    // upload and transform are queued under one lock: a consumer's snapshot (queued under the same lock) then finds
+    // window, spectrum and block number of ONE block, whichever side of this pair it lands on
     std::lock_guard<std::mutex> lk(d->in_mu);
     if (hipMemcpyAsync(d->d_in, src, N * sizeof(float2), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
     d->in_block = m->blocknum + 1;  // only this thread moves blocknum (below, once the transform is done)
+    if (N > 16384)
+      kq::launch_fft_large(s, d->d_in, d->d_fdomain, d->d_tmp, d->log2N, -1, d->tw, d->log2N);
+    else
+      kq::launch_fft_single(s, d->d_in, d->d_fdomain, d->log2N, -1, d->tw, d->log2N);
   }
-  if (N > 16384)
-    kq::launch_fft_large(s, d->d_in, d->d_fdomain, d->d_tmp, d->log2N, -1, d->tw, d->log2N);
-  else
-    kq::launch_fft_single(s, d->d_in, d->d_fdomain, d->log2N, -1, d->tw, d->log2N);
   size_t const bins = (m->in_type == REAL) ? N / 2 + 1 : N;
   if (hipMemcpyAsync(m->fdomain, d->d_fdomain, bins * sizeof(float2), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
   if (hipStreamSynchronize(s) != hipSuccess) return -1;

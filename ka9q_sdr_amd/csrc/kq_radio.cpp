@@ -44,7 +44,7 @@ struct Session {
   struct demod *demod = nullptr;
   struct filter_out *slave = nullptr;
   kq_bank *bank = nullptr;
-  float2 *d_window = nullptr;
+  float2 *d_spectrum = nullptr;
   int dev = -1;
   unsigned olen = 0;
   // what the bank channel was last told
@@ -58,9 +58,9 @@ struct Session {
 
   ~Session() {
     if (bank) kq_bank_destroy(bank);
-    if (d_window) {
+    if (d_spectrum) {
       kq::DeviceScope scope(dev);
-      (void)hipFree(d_window);
+      (void)hipFree(d_spectrum);
     }
     if (slave) delete_filter_output(slave);
   }
@@ -150,7 +150,7 @@ bool start(Session &s, struct demod *demod, int demod_type, enum filtertype out_
   s.channels = cc.channels;
   kq::DeviceScope scope(s.dev);
   size_t const N = (size_t)m->ilen + m->impulse_length - 1;
-  if (hipMalloc((void **)&s.d_window, N * sizeof(float2)) != hipSuccess) {
+  if (hipMalloc((void **)&s.d_spectrum, N * sizeof(float2)) != hipSuccess) {
     fail(demod, "device allocation failed");
     return false;
   }
@@ -169,20 +169,22 @@ bool next_block(Session &s, kq_chan_status *st, std::vector<float> &audio, size_
     if (kq_bank_set_filter(s.bank, 0, s.low, s.high, s.beta)) return false;
   }
   // The master does not wait for its consumers (filter.c:146-172): by the time this thread wakes it may have queued the
-  // next block already, and the window copied here is then that one.  A window is demodulated once: when the copy
+  // next block already, and the spectrum copied here is then that one.  A block is demodulated once: when the copy
   // turns out to be the block done last time round, wait for the next.  (A thread that falls further behind skips
   // blocks, as the reference's equality test on blocknum does, filter.c:195-199.)
   for (;;) {
     if (execute_filter_output(s.slave)) return false;  // blocks until the master has a new block; refreshes output.c
     if (told_to_stop(demod)) return false;
     unsigned blk = 0;
-    if (kq::compat_snapshot_window(demod->filter.in, s.d_window, &blk) < 0) return false;
+    if (kq::compat_snapshot_spectrum(demod->filter.in, s.d_spectrum, &blk) < 0) return false;
     if (s.have_block && blk == s.last_block) continue;
     s.have_block = true;
     s.last_block = blk;
     break;
   }
-  if (kq_bank_process_resident(s.bank, s.d_window, 1) != 1) return false;
+  // slave, compute_n0 and demodulator on the master's own transform (filter.c:206-250, radio.c:383-425): the forward
+  // transform is done once, by execute_filter_input, as in the reference
+  if (kq_bank_process_spectrum(s.bank, s.d_spectrum, 1) != 1) return false;
   audio.resize(2 * (size_t)s.olen);
   if (kq_bank_pull_audio(s.bank, 0, 0, audio.data(), audio.size(), nout)) return false;
   if (kq_bank_pull_status(s.bank, 0, 0, st)) return false;

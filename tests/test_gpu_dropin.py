@@ -148,8 +148,8 @@ def test_library_demod_linear_thread(harness, stereo):
 
 def test_linear_thread_at_65536_points(harness):
     """The cfg-5 geometry through the reference's own shell: master of 65536 points (the compat surface's two-pass
-    transform), demod_linear as radio.c starts it, compute_n0 from the bank's N = 65536 full-spectrum kernel
-    (linear.c:123-126) -- not from the host-side single-spectrum kernel the threads used past 16384 points until round 3."""
+    transform), demod_linear as radio.c starts it; slave, compute_n0 (linear.c:123-126) and the demodulator run on the
+    master's resident spectrum (kq_bank_process_spectrum): one forward transform per block, the master's."""
     geom = (20000000, 32768, 32769, 512)
     iq = _signal("usb", 6, geom)
     recs, _ = _run(harness, "linear", iq, USB["low"], USB["high"], ["--hang", "1.1", "--recovery", "6"], geom)
@@ -158,3 +158,48 @@ def test_linear_thread_at_65536_points(harness):
     assert rel_rms(np.concatenate([a for a, _ in recs][1:]), np.concatenate(auds[1:])) < 1e-5
     for b in range(NB):
         assert abs(recs[b][1]["n0"] / sts[b]["n0"] - 1) < 5e-3, (b, recs[b][1]["n0"], sts[b]["n0"])   # (a tie moves it 1e-3)
+
+
+def _timed_run(exe, mode, geom, nblocks, low, high, extra=()):
+    fs_, l_, m_, d_ = geom
+    rng = np.random.default_rng(11)
+    n = nblocks * l_
+    t = np.arange(n) / fs_
+    iq = (0.1 * np.exp(1j * (2 * np.pi * 20000.0 * t + 3.0 * np.sin(2 * np.pi * 1000 * t))) +
+          1e-3 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.cf32"), os.path.join(d, "out.bin")
+        iq.tofile(fin)
+        cmd = [exe, mode, str(fs_), str(l_), str(m_), str(d_), str(low), str(high), str(nblocks), fin, fout, "--lo", "-20000",
+               "--time"] + list(extra)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("timing:")][0]
+    import re
+    f = [float(x) for x in re.findall(r"([0-9.]+) us", line)]
+    factor = float(re.search(r"([0-9.]+) x real time", line).group(1))
+    return dict(mix_us=f[0], master_us=f[1], thread_us=f[2], block_us=f[3], factor=factor, line=line), iq
+
+
+def test_drop_in_surface_speed(harness, capsys):
+    """The drop-in surface measured: one channel through the reference's own shell -- host mix with step_osc,
+    execute_filter_input, the library's demod_fm thread -- at BASELINE.json's cfg 1 geometry (192 kHz, N = 16384, D = 4;
+    23.4 blocks/s in real time) must run at 20 x real time or better; beside it the oracle's chain (the reference's
+    structure: per-sample NCO, N-point transform, slave, compute_n0, FM demodulator) on one host core, and the same
+    shell at N = 65536 (cfg 5's geometry, demod_linear).  The figures go to INTEGRATION.md section A2."""
+    import time
+    g1 = (192000, 8192, 8193, 4)
+    r1, iq1 = _timed_run(harness, "fm", g1, 44, FM["low"], FM["high"])
+    cfg = oracle_cfg(FM, *g1, compute_n0=1)
+    blocks = iq1.reshape(-1, g1[1])
+    t0 = time.perf_counter()
+    ko.run_chain(cfg, blocks, want_filt=False)
+    oracle_us = (time.perf_counter() - t0) / len(blocks) * 1e6
+    g5 = (20000000, 32768, 32769, 512)
+    r5, _ = _timed_run(harness, "linear", g5, 24, USB["low"], USB["high"], ["--hang", "1.1", "--recovery", "6"])
+    with capsys.disabled():
+        print("\n  cfg 1 shell: " + r1["line"])
+        print("  cfg 1 oracle chain on one host core: %.0f us per block = %.1f x real time" % (oracle_us, r1["block_us"] / oracle_us))
+        print("  cfg 5 shell: " + r5["line"])
+    assert r1["factor"] >= 20.0, r1["line"]
+    assert r5["factor"] >= 1.0, r5["line"]

@@ -90,6 +90,15 @@ int kq_bank_process_resident(kq_bank *b, const void *iq, unsigned nblocks) {
   b->acc = a;
   return (int)nblocks;
 }
+int kq_bank_process_spectrum(kq_bank *b, const void *spec, unsigned nblocks) {
+  std::lock_guard<std::mutex> lk(mock_stream_mutex());
+  const float2 *x = static_cast<const float2 *>(spec);
+  unsigned const N = b->cfg.L + b->cfg.M - 1;
+  float a = 0;
+  for (unsigned i = 0; i < N; i++) a += x[i].x;
+  b->acc = a;
+  return (int)nblocks;
+}
 int kq_bank_pull_audio(kq_bank *b, int, unsigned, float *dst, size_t cap, size_t *n) {
   size_t const olen = b->cfg.L / b->cfg.decimate;
   for (size_t i = 0; i < cap; i++) dst[i] = b->acc;

@@ -67,6 +67,7 @@ int kq_bank_process_resident(kq_bank *b, const void *iq, unsigned nblocks) {
       memset(&st, 0, sizeof st);
       st.if_power = b->energy / (float)L;
       st.pdeviation = 3000.f;
+      st.snr = 100.f;
       st.nout = (int)(L / b->cfg.decimate);
       b->status[k] = st;
     }

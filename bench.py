@@ -245,7 +245,8 @@ def measure_row(torch, kq, wl, config, blocks, dev_index, stream, pci_bus, spin_
     geom = dict(wl.GEOMETRY[config])
     L, M, D, fs, C = geom["L"], geom["M"], geom["D"], geom["samprate"], geom["channels"]
     plan = wl.channel_plan(config, C)
-    bank = kq.Bank(fs, L, M, D, C, blocks, device=dev_index, compute_n0=True, fwd_mode=kq.KQ_FWD_AUTO, stream=stream.cuda_stream)
+    bank = kq.Bank(fs, L, M, D, C, blocks, device=dev_index, compute_n0=True, fwd_mode=kq.KQ_FWD_AUTO, stream=stream.cuda_stream,
+                   pl_tone=False)     # the synthetic configs 2-5 run without pltask
     for p in plan:
         bank.add_channel(wl.bank_channel_config(p))
     nwin = (M - 1) + blocks * L
@@ -283,7 +284,7 @@ def measure_row(torch, kq, wl, config, blocks, dev_index, stream, pci_bus, spin_
     per_kind = {}
     for p in plan:
         per_kind[p["demod"]] = per_kind.get(p["demod"], 0) + 1
-    return {"workload": "%s: %d channels (%s), N=%d, decimate %d, %.3g MS/s, %d blocks/step, fwd=%s, compute_n0=1" %
+    return {"workload": "%s: %d channels (%s), N=%d, decimate %d, %.3g MS/s, %d blocks/step, fwd=%s, compute_n0=1, pltask off" %
                         (config, C, "+".join("%d %s" % (v, k) for k, v in sorted(per_kind.items())), L + M - 1, D, fs / 1e6,
                          blocks, fwd_used),
             "value": round(C * blocks * L / dt / 1e6, 1), "ms_per_step": round(dt * 1e3, 4), "steps": steps,
@@ -352,8 +353,10 @@ def main():
     fwd = {"auto": kq.KQ_FWD_AUTO, "full": kq.KQ_FWD_FULL, "pruned": kq.KQ_FWD_PRUNED}[a.fwd]
     stream = torch.cuda.Stream(device=dev)     # an explicit (non-null) HIP stream handed to the library
     torch.cuda.set_stream(stream)
+    # pltask (fm.c:189-285) is part of cfg 1 only; the synthetic configs 2-5 are measured without it
+    pl_tone = a.config == "cfg1"
     bank = kq.Bank(fs, L, M, D, C, B, device=dev_index, compute_n0=bool(a.n0), fwd_mode=fwd,
-                   stream=stream.cuda_stream)
+                   stream=stream.cuda_stream, pl_tone=pl_tone)
     for p in plan:
         bank.add_channel(wl.bank_channel_config(p))
 
@@ -580,7 +583,7 @@ def main():
     if world == 1 and not a.no_second_row and a.fwd == "auto":
         bank.close()
         bank = kq.Bank(fs, L, M, D, C, B, device=dev_index, compute_n0=not a.n0, fwd_mode=kq.KQ_FWD_AUTO,
-                       stream=stream.cuda_stream)
+                       stream=stream.cuda_stream, pl_tone=pl_tone)
         for p in plan:
             bank.add_channel(wl.bank_channel_config(p))
         fwd2 = {1: "full", 2: "pruned"}[bank.fwd_mode]
@@ -630,9 +633,9 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": "%s: %d channels/GPU (%s), N=%d (L=%d, M=%d), decimate %d, %.3g MS/s synthetic complex-float "
-                            "I/Q, %d blocks/step, fwd=%s, compute_n0=%d" %
+                            "I/Q, %d blocks/step, fwd=%s, compute_n0=%d, pltask %s" %
                             (a.config, C, "+".join("%d %s" % (v, k) for k, v in sorted(per_kind.items())), L + M - 1, L, M, D,
-                             fs / 1e6, B, fwd_used, a.n0),
+                             fs / 1e6, B, fwd_used, a.n0, "on" if pl_tone else "off (SURVEY 8d)"),
                 "channels_total": total_ch,
                 "front_end_Msamples_per_s": round(front_end_msps, 2),
                 "realtime_factor": round(front_end_msps * 1e6 / fs, 2),

@@ -61,6 +61,9 @@ typedef struct kq_bank_config {
   int compute_n0;          /* run the status-only compute_n0 (radio.c:383-425) every block */
   int fwd_mode;            /* enum kq_fwd_mode */
   void *stream;            /* hipStream_t to launch on, or NULL for the bank's own stream */
+  int pl_tone_off;         /* 0 (default): pltask's PL / CTCSS tone measurement (fm.c:189-285) runs for every FM channel whenever
+                            * its slave has a usable size (N/D >= 128), as every demod_fm of the reference starts it;
+                            * 1: never (status.plfreq = NaN) -- SURVEY 8d measures the synthetic configs 2-5 without it */
 } kq_bank_config;
 
 /* One receiver channel: the fields of struct demod / struct modetab that the path reads

@@ -28,7 +28,7 @@ class BankConfig(C.Structure):
         ("device", C.c_int), ("samprate", C.c_int), ("L", C.c_uint), ("M", C.c_uint),
         ("decimate", C.c_uint), ("max_channels", C.c_uint), ("max_blocks", C.c_uint),
         ("gain_factor", C.c_float), ("compute_n0", C.c_int), ("fwd_mode", C.c_int),
-        ("stream", C.c_void_p),
+        ("stream", C.c_void_p), ("pl_tone_off", C.c_int),
     ]
 
 
@@ -202,10 +202,10 @@ class Bank:
     """A bank of receiver channels sharing one front-end I/Q stream on one GPU."""
 
     def __init__(self, samprate, L, M, decimate, max_channels, max_blocks, device=0, gain_factor=1.0,
-                 compute_n0=False, fwd_mode=KQ_FWD_AUTO, stream=None):
+                 compute_n0=False, fwd_mode=KQ_FWD_AUTO, stream=None, pl_tone=True):
         self.lib = load_library()
         cfg = BankConfig(device, samprate, L, M, decimate, max_channels, max_blocks, gain_factor,
-                         int(compute_n0), fwd_mode, stream)
+                         int(compute_n0), fwd_mode, stream, 0 if pl_tone else 1)
         self.h = self.lib.kq_bank_create(C.byref(cfg))
         if not self.h:
             raise KqError("kq_bank_create: " + _err(self.lib))

@@ -846,7 +846,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   {
     // pltask geometry (fm.c:201-205): decimate 32 from the audio master; needs a usable transform size
     int const pn = g.Ndec / 32, plen = g.olen / 32;
-    bool const ok = pn >= 4 && plen >= 1 && (pn & (pn - 1)) == 0;
+    bool const ok = pn >= 4 && plen >= 1 && (pn & (pn - 1)) == 0 && !cfg->pl_tone_off;
     g.pl_n = ok ? pn : 0;
     g.pl_l = ok ? plen : 0;
   }

@@ -761,6 +761,120 @@ __global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, 
   for (int n = lane; n < AL; n += 64) aud[n] = F[AN - AL + n].x * gain;  // fm.c:169-170
 }
 
+// The same de-emphasis overlap-save for AN = 256 (AL = 128, AM = 129: BASELINE cfg 2's geometry) with the PL measurement off:
+// one wave per PAIR of blocks, registers and lane exchanges only (k_demod64's scheme for 64 points, four values per lane).
+// The two real windows [b-1 | b] and [b | b+1] are the real and imaginary part of ONE complex 256-point sequence z; both are
+// filtered by the same response, so Y0 + i Y1 = HAf . (W0 + i W1) = HAf . Z with HAf the response's Hermitian extension
+// (real at DC and Nyquist, whose imaginary parts the c2r transform ignores, filter.c:250) -- no separation of the two
+// spectra is needed -- and one inverse transform returns block b's audio as its real part, block b+1's as its imaginary part.
+// 256 = 4 x 64: i = m + 64 a, k = 4 q + r (lane m, register a or r).  Forward, decimation in frequency: in-lane radix-4
+// over a, twiddle W_256^{m r}, then four 64-point transforms across the lanes (natural in, bit-reversed out: lane l holds
+// q = bitrev6(l)); inverse the other way round (bit-reversed in, natural out).  fm.c:162-171, filter.c:151,206-208,250.
+__global__ void __launch_bounds__(64) k_fm_audio256(Geom g, ChanDev ch, Planes pl, const float *__restrict__ fmout,
+                                                    const float *__restrict__ hist_in, float *__restrict__ hist_out,
+                                                    const int *__restrict__ list, int nblocks) {
+  constexpr int AL = 128, AN = 256;
+  int const c = list[blockIdx.x], b0 = 2 * (int)blockIdx.y, lane = threadIdx.x;
+  bool const have1 = b0 + 1 < nblocks;
+  const float *stream = fmout + (size_t)c * g.max_blocks * AL;  // detected samples of this call, block after block
+  const float *pm = b0 > 0 ? stream + (size_t)(b0 - 1) * AL : hist_in + (size_t)c * AL;  // AM - 1 = 128: exactly one block
+  float const p0 = pm[lane], p1 = pm[lane + 64];
+  float const c0 = stream[(size_t)b0 * AL + lane], c1 = stream[(size_t)b0 * AL + lane + 64];
+  float const n0 = have1 ? stream[(size_t)(b0 + 1) * AL + lane] : 0.f, n1 = have1 ? stream[(size_t)(b0 + 1) * AL + lane + 64] : 0.f;
+  if (b0 + 2 >= nblocks) {  // the call's last block precedes the next call (filter.c:164)
+    float *ho = hist_out + (size_t)c * AL;
+    ho[lane] = have1 ? n0 : c0;
+    ho[lane + 64] = have1 ? n1 : c1;
+  }
+  float *aud0 = pl.audio + ((size_t)c * g.max_blocks + b0) * (2 * (size_t)AL);
+  float *aud1 = aud0 + 2 * AL;
+  if (ch.flags[c] & FLAG_FLAT) {  // fm.c:164-172: no filter, no gain
+    aud0[lane] = c0;
+    aud0[lane + 64] = c1;
+    if (have1) {
+      aud1[lane] = n0;
+      aud1[lane + 64] = n1;
+    }
+    return;
+  }
+  // response on this lane's four bins k = 4 bitrev6(lane) + r, Hermitian-extended
+  const float2 *HA = ch.aresp + (size_t)c * (AN / 2 + 1);
+  int const q = (int)(__brev((unsigned)lane) >> 26);
+  float2 hf[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    int const k = 4 * q + r;
+    float2 const t = HA[k <= AN / 2 ? k : AN - k];
+    hf[r] = k <= AN / 2 ? t : cconj(t);
+    if (k == 0 || k == AN / 2) hf[r].y = 0.f;
+  }
+  // lane-exchange twiddles of the 64-point transforms and the radix-4 twiddles W_256^{lane r}
+  float2 wf[6], wi[6], w4[3];
+#pragma unroll
+  for (int s = 0; s < 6; s++) {
+    int const half = 1 << s;
+    float sn, cs;
+    sincospif((float)(lane & (half - 1)) / (float)half, &sn, &cs);
+    wf[s] = make_float2(cs, -sn);
+    wi[s] = make_float2(cs, sn);
+  }
+#pragma unroll
+  for (int r = 1; r < 4; r++) {
+    float sn, cs;
+    sincospif((float)(lane * r) / 128.f, &sn, &cs);
+    w4[r - 1] = make_float2(cs, -sn);
+  }
+  auto xor_pow = [&](float2 v, int s) {
+    switch (s) {
+      case 0: return make_float2(lane_xor<1>(v.x, lane), lane_xor<1>(v.y, lane));
+      case 1: return make_float2(lane_xor<2>(v.x, lane), lane_xor<2>(v.y, lane));
+      case 2: return make_float2(lane_xor<4>(v.x, lane), lane_xor<4>(v.y, lane));
+      case 3: return make_float2(lane_xor<8>(v.x, lane), lane_xor<8>(v.y, lane));
+      case 4: return make_float2(lane_xor<16>(v.x, lane), lane_xor<16>(v.y, lane));
+      default: return make_float2(lane_xor<32>(v.x, lane), lane_xor<32>(v.y, lane));
+    }
+  };
+  auto muli = [](float2 a) { return make_float2(-a.y, a.x); };  // i a
+  // z[m + 64 a]: real part the window [b0-1 | b0], imaginary part [b0 | b0+1]
+  float2 const z0 = make_float2(p0, c0), z1 = make_float2(p1, c1), z2 = make_float2(c0, n0), z3 = make_float2(c1, n1);
+  float2 u[4];
+  {
+    float2 const t0 = cadd(z0, z2), t1 = csub(z0, z2), t2 = cadd(z1, z3), t3 = csub(z1, z3);
+    u[0] = cadd(t0, t2);
+    u[2] = cmul(csub(t0, t2), w4[1]);
+    u[1] = cmul(csub(t1, muli(t3)), w4[0]);
+    u[3] = cmul(cadd(t1, muli(t3)), w4[2]);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    float2 z = u[r];
+#pragma unroll
+    for (int s = 5; s >= 0; s--) {  // forward, decimation in frequency: natural in, bit-reversed out
+      float2 const o = xor_pow(z, s);
+      z = ((lane >> s) & 1) ? cmul(csub(o, z), wf[s]) : cadd(z, o);
+    }
+    z = cmul(hf[r], z);  // filter.c:206-208 on both windows at once
+#pragma unroll
+    for (int s = 0; s < 6; s++) {  // backward, decimation in time: bit-reversed in, natural out
+      int const bit = (lane >> s) & 1;
+      float2 const v = bit ? cmul(z, wi[s]) : z;
+      float2 const o = xor_pow(v, s);
+      z = bit ? csub(o, v) : cadd(v, o);
+    }
+    u[r] = r ? cmul(z, cconj(w4[r - 1])) : z;
+  }
+  // inverse radix-4 over r, outputs i = 128 + m (a = 2) and 192 + m (a = 3) only: the samples the slave keeps (filter.c:140)
+  float2 const y2 = csub(cadd(u[0], u[2]), cadd(u[1], u[3]));
+  float2 const y3 = csub(csub(u[0], u[2]), muli(csub(u[1], u[3])));
+  float const gain = ch.fm_gain[c];
+  aud0[lane] = y2.x * gain;  // fm.c:169-170
+  aud0[lane + 64] = y3.x * gain;
+  if (have1) {
+    aud1[lane] = y2.y * gain;
+    aud1[lane + 64] = y3.y * gain;
+  }
+}
+
 // AM: envelope, carrier removal, hang AGC -- a strictly sequential recurrence per channel
 // (am.c:55-75), so one lane per channel and channels across lanes.
 __global__ void k_demod_am(Geom g, ChanDev ch, Planes pl, const int *__restrict__ list, int nchan, int nblocks,
@@ -984,8 +1098,12 @@ void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes
     ensure_dynamic_lds((const void *)k_demod_fm, lds_a);
     ensure_dynamic_lds((const void *)k_fm_audio, lds_b);
     hipLaunchKernelGGL(k_demod_fm, dim3(n_fm), dim3(64 * waves), lds_a, s, g, ch, pl, fmout, list_fm, nblocks, compute_n0);
-    hipLaunchKernelGGL(k_fm_audio, dim3(n_fm, nblocks), dim3(64), lds_b, s, g, ch, pl, tw, fmout, fm_hist_in, fm_hist_out,
-                       list_fm, nblocks);
+    if (g.Ndec == 256 && g.olen == 128 && g.Mdec == 129 && g.pl_n == 0)  // cfg 2's geometry without the PL measurement: registers only
+      hipLaunchKernelGGL(k_fm_audio256, dim3(n_fm, (nblocks + 1) / 2), dim3(64), 0, s, g, ch, pl, fmout, fm_hist_in, fm_hist_out,
+                         list_fm, nblocks);
+    else
+      hipLaunchKernelGGL(k_fm_audio, dim3(n_fm, nblocks), dim3(64), lds_b, s, g, ch, pl, tw, fmout, fm_hist_in, fm_hist_out,
+                         list_fm, nblocks);
   }
   if (n_am > 0)
     hipLaunchKernelGGL(k_demod_am, dim3((n_am + 63) / 64), dim3(64), 0, s, g, ch, pl, list_am, n_am, nblocks, compute_n0);

@@ -19,10 +19,10 @@ FIRST_LINEAR_TOL = 2e-3   # audio of a linear channel's first block (AGC start-u
 EXACT_TOL = 2e-6          # status sums against float64 arithmetic on the kernel's own samples
 
 
-def _run_bank(plan, geom, iq, nblocks, fwd_mode, compute_n0=False, per_call=None):
+def _run_bank(plan, geom, iq, nblocks, fwd_mode, compute_n0=False, per_call=None, pl_tone=True):
     per_call = per_call or nblocks
     bank = kq.Bank(geom["samprate"], geom["L"], geom["M"], geom["D"], len(plan), per_call,
-                   compute_n0=compute_n0, fwd_mode=fwd_mode)
+                   compute_n0=compute_n0, fwd_mode=fwd_mode, pl_tone=pl_tone)
     for p in plan:
         bank.add_channel(bank_cfg(p))
     L = geom["L"]
@@ -579,6 +579,29 @@ def test_random_channel_plans_generic_demodulators(gpu, seed):
     got, used = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_AUTO, compute_n0=True, per_call=4)
     assert used == kq.KQ_FWD_FULL
     _compare(plan, got, want, check_n0=True)
+
+
+@pytest.mark.parametrize("seed,per_call", [(5, 4), (6, 5), (7, 11), (8, 1)])
+def test_cfg2_geometry_without_the_pl_measurement(gpu, seed, per_call):
+    """cfg 2 as SURVEY 8d measures it (pltask off): the de-emphasis overlap-save then runs in k_fm_audio256 -- one wave per
+    pair of blocks, both real windows through one 256-point lane-exchange transform pair -- instead of the LDS kernel.
+    Eleven blocks (an odd count: the last wave has one block only) in calls of 4, 5, 11 and 1, so that the history hand-over
+    between calls is met at even and odd block counts; FM with and without de-emphasis among randomised plans."""
+    g = wl.GEOMETRY["cfg2"]
+    rng = np.random.default_rng(3000 + seed)
+    plan = _random_plan(rng, g["samprate"], 14)
+    fs = g["samprate"]
+    plan += [dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-(wl.emitter_freq(0, fs) + 3.0)),
+             dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-(wl.emitter_freq(1, fs) - 7.0), flat=1),
+             dict(demod="fm", low=-6000.0, high=9000.0, second_lo=-(wl.emitter_freq(4, fs) + 11.0), kaiser_beta=5.0)]
+    nblocks = 11
+    iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=300 + seed)
+    want = run_oracle(plan, g, iq, nblocks, compute_n0=1)
+    got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_AUTO, compute_n0=True, per_call=per_call, pl_tone=False)
+    _compare(plan, got, want, check_n0=True)
+    for c, p in enumerate(plan):
+        if p["demod"] == "fm":
+            assert all(np.isnan(st["plfreq"]) for st in got[c]["status"])
 
 
 def test_long_run_phase_continuity(gpu):

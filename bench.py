@@ -294,6 +294,15 @@ def measure_row(torch, kq, wl, config, blocks, dev_index, stream, pci_bus, spin_
             "realtime_factor": round(blocks * L / dt / fs, 2), "gpu_state": state}
 
 
+# The fan-out's broadcast is 4.3 MB per step on a side stream beside the filter kernel.  What an RCCL-shaped kernel there costs
+# the step was measured with a stand-in on one GPU (tools/bcast_probe.py, profiles/r04/bcast_side_kernel_probe.txt): 1 to 64
+# workgroups of 256 threads, resident for up to 400 us, cost 0.2-2.5 % (cfg 4) and 2-3.5 % (cfg 5), of which ~1 % is the two
+# stream markers -- far inside the 25 % the 6 x target leaves.  So the cap is not needed for the step; eight channels are
+# plenty for 4.3 MB (a channel moves >= 10 GB/s) and leave RCCL the fewest workgroups to place.  Read by RCCL at
+# communicator creation: set before any rank initialises it (an explicit NCCL_MAX_NCHANNELS in the environment wins).
+RCCL_CHANNEL_CAP = "8"
+
+
 def self_launch(a):
     """`bench.py --gpus N` started as a plain process: start the N ranks ourselves (one child per GPU through
     torch.distributed.run) BEFORE anything here touches the GPU, pass rank 0's JSON line through, exit with its code."""
@@ -306,6 +315,7 @@ def self_launch(a):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("NCCL_MAX_NCHANNELS", RCCL_CHANNEL_CAP)
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
@@ -313,6 +323,8 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)
+    if a.gpus > 1:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", RCCL_CHANNEL_CAP)   # (started by torch.distributed.run: same default)
     import torch
     import ka9q_sdr_amd as kq
     from ka9q_sdr_amd import workload as wl
@@ -653,7 +665,7 @@ def main():
             out["rccl"] = {"ranks": fan_stats["rccl_ranks"], "world": world, "version": fan_stats["rccl_version"],
                            "broadcasts": fan_stats["broadcasts"],
                            "bcast_ms": round(fan_stats["broadcast_ms"] / max(1, fan_stats["broadcasts"]), 4),
-                           "bytes_per_broadcast": nwin * 8,
+                           "bytes_per_broadcast": nwin * 8, "max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
                            "note": "ranks = ncclCommCount of the fan-out's communicator (0: one rank, no communicator); "
                                    "bcast_ms = HIP events around ncclBroadcast on the side stream, rank 0"}
         out["step_frac"] = round(out["roofline"]["algorithmic_bytes_per_launch"] / (elapsed / a.steps) / 8e12, 4)

@@ -163,7 +163,8 @@ struct kq_bank {
   static constexpr int kMaxPll = 64;
   int *list_pll_dev = nullptr;
   int *list_active_dev = nullptr;      // the active channels, for the filter launch, when remove_channel has left holes
-  std::vector<int> list_active_host;   // empty: no holes, the launch covers slots 0 .. chans.size() - 1
+  std::vector<int> list_active_host;   // empty: no holes, the launch covers slots 0 .. chans.size() - 1 (a bank whose channels
+                                       // have ALL been removed never launches: run_blocks refuses it up front)
   std::vector<int> list_pll_host;
   kq::PllState *pll_state = nullptr;
   float2 *pll_rings = nullptr, *pll_side = nullptr;

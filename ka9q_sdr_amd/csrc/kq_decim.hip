@@ -598,6 +598,7 @@ int kq_decim_process(kq_decimator *d, const float *iq_in, int on_device, size_t 
     final16 = out_s16 ? d->out16_dev : nullptr;
   }
   d->epoch++;
+  if (d->epoch == 0) d->epoch = 1;  // 0 is what a never-written word holds (the bank's tags skip it the same way)
   size_t n_g_in = n_in;
   for (size_t gi = 0; gi < d->groups.size(); gi++) {
     Group &g = d->groups[gi];

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [os.path.join(HERE, ".."), os.path.join(HERE, "..", "oracle"), HERE]
+sys.path[:0] = [os.path.join(HERE, "..", ".."), os.path.join(HERE, "..", "..", "oracle"), os.path.join(HERE, "..")]
 from common import rel_rms, run_oracle  # noqa: E402
 import ka9q_sdr_amd as kq  # noqa: E402
 from ka9q_sdr_amd import workload as wl  # noqa: E402

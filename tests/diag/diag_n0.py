@@ -5,7 +5,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [os.path.join(HERE, ".."), os.path.join(HERE, "..", "oracle"), HERE]
+sys.path[:0] = [os.path.join(HERE, "..", ".."), os.path.join(HERE, "..", "..", "oracle"), os.path.join(HERE, "..")]
 import test_gpu_parity as T  # noqa: E402
 from common import rel_rms, run_oracle  # noqa: E402
 import ka9q_sdr_amd as kq  # noqa: E402

@@ -1,8 +1,8 @@
-"""Diagnostic (not a test): per-channel parity margins HIP vs oracle at the cfg5 geometry.  Lives under tests/ because\nit drives the oracle.  Run on the GPU box: python tests/parity_margins.py"""
+"""Diagnostic (not a test): per-channel parity margins HIP vs oracle at the cfg5 geometry.  Lives under tests/ because\nit drives the oracle.  Run on the GPU box: python tests/diag/parity_margins.py"""
 import sys
 import os
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [os.path.join(HERE, '..'), os.path.join(HERE, '..', 'oracle'), HERE]
+sys.path[:0] = [os.path.join(HERE, '..', '..'), os.path.join(HERE, '..', '..', 'oracle'), os.path.join(HERE, '..')]
 import numpy as np
 import ka9q_sdr_amd as kq
 from ka9q_sdr_amd import workload as wl

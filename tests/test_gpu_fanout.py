@@ -202,3 +202,50 @@ def test_demodulator_stream_changes_from_call_to_call(gpu, monkeypatch):
                     assert np.float32(st["bb_power"]) == np.float32(ws["bb_power"]) and np.float32(st["if_power"]) == np.float32(ws["if_power"])
     for bank in banks.values():
         bank.close()
+
+
+def test_65536_points_with_forced_demodulator_overlap_and_streamed_planes(gpu, monkeypatch):
+    """the four sibling workgroups of an N = 65536 channel-block wait for each other (bounded spin) and rely on
+    being resident together; here they run with the last call's demodulators forced onto the second stream beside them
+    (KQ_DEMOD_OVERLAP=1, which the bank itself never chooses at this size) and with the planes streamed out
+    (kq_bank_pull_planes_async), six calls in a row without a host wait between the kernels.  Audio, n0 and the integer
+    status must equal a bank that never overlaps, and kq_bank_host_io_wait must not report a lost sibling."""
+    g = wl.GEOMETRY["cfg5"]
+    fs, L, M, D = g["samprate"], g["L"], g["M"], g["D"]
+    plan = wl.channel_plan("cfg5", 96)      # 384 sibling workgroups per block: most of the device's 512 slots
+    nblocks, ncalls = 4, 6
+    iq = wl.make_iq(fs, ncalls * nblocks * L, seed=93)
+    olen = L // D
+    monkeypatch.setenv("KQ_DEMOD_OVERLAP", "0")
+    ref = kq.Bank(fs, L, M, D, len(plan), nblocks, compute_n0=True)
+    monkeypatch.setenv("KQ_DEMOD_OVERLAP", "1")
+    bank = kq.Bank(fs, L, M, D, len(plan), nblocks, compute_n0=True)
+    monkeypatch.delenv("KQ_DEMOD_OVERLAP")
+    for p in plan:
+        ref.add_channel(bank_cfg(p))
+        bank.add_channel(bank_cfg(p))
+    pinned = torch.from_numpy(iq.copy()).pin_memory()
+    audio = [torch.zeros(len(plan) * nblocks * 2 * olen, dtype=torch.float32).pin_memory() for _ in range(ncalls)]
+    status = [torch.zeros(len(plan) * nblocks * C.sizeof(kq.ChanStatus), dtype=torch.uint8).pin_memory() for _ in range(ncalls)]
+    bank.push_iq_async(pinned.data_ptr(), nblocks * L)
+    for k in range(ncalls):      # the call order the header asks for: process k, push k + 1, pull k
+        assert bank.process() == nblocks
+        if k + 1 < ncalls:
+            bank.push_iq_async(pinned.data_ptr() + 8 * (k + 1) * nblocks * L, nblocks * L)
+        bank.pull_planes_async(audio[k].data_ptr(), status[k].data_ptr())
+    bank.host_io_wait()          # raises if a sibling's word never arrived
+    bank.sync()
+    for k in range(ncalls):
+        ref.push_iq(iq[k * nblocks * L:(k + 1) * nblocks * L])
+        assert ref.process() == nblocks
+        a = audio[k].numpy().reshape(len(plan), nblocks, 2 * olen)
+        st = np.frombuffer(status[k].numpy().tobytes(), dtype=np.dtype(kq.ChanStatus)).reshape(len(plan), nblocks)
+        for c in range(0, len(plan), 5):
+            for b in range(nblocks):
+                want = ref.audio(c, b)
+                ws = ref.status(c, b)
+                assert np.array_equal(a[c, b, :len(want)], want), (k, c, b)
+                assert st[c, b]["nout"] == ws["nout"] and st[c, b]["hangcount"] == ws["hangcount"]
+                assert st[c, b]["n0"] == np.float32(ws["n0"]) and not np.isnan(st[c, b]["n0"]), (k, c, b)
+    ref.close()
+    bank.close()

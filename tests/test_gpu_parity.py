@@ -43,7 +43,17 @@ def _run_bank(plan, geom, iq, nblocks, fwd_mode, compute_n0=False, per_call=None
     return res, mode
 
 
-def _compare(plan, got, want, skip_blocks=0, check_n0=False):
+def _fm_readings_float64(prev, cur, dsr):
+    """foffset and pdeviation (fm.c:125-154) of a fully open block without blanked samples, in float64 on the filter output
+    the kernel itself produced: y_n = arg(s_n conj(s_{n-1})), the block's first sample against the last one of the block
+    before; foffset = dsr mean(y) / 2 pi, pdeviation = dsr max(y_max - mean, mean - y_min) / 2 pi."""
+    s = np.concatenate([prev[-1:], cur]).astype(np.complex128)
+    y = np.angle(s[1:] * np.conj(s[:-1]))
+    avg = y.mean()
+    return dsr * avg / (2 * np.pi), dsr * max(y.max() - avg, avg - y.min()) / (2 * np.pi)
+
+
+def _compare(plan, got, want, skip_blocks=0, check_n0=False, geom=None):
     for c, p in enumerate(plan):
         auds, sts, filts = want[c]
         nb = len(auds)
@@ -92,6 +102,14 @@ def _compare(plan, got, want, skip_blocks=0, check_n0=False):
                 np.testing.assert_allclose(1.0 / (1.0 + sg["snr"]), 1.0 / (1.0 + sw["snr"]), rtol=2e-4, atol=2e-5)
                 np.testing.assert_allclose(sg["foffset"], sw["foffset"], rtol=1e-4, atol=1e-2)
                 np.testing.assert_allclose(sg["pdeviation"], sw["pdeviation"], rtol=1e-4, atol=1e-2)
+                # ... and, where the block and the one before it are fully open with no sample blanked (so that the hold
+                # rule of fm.c:128-144 is not involved), against float64 arithmetic on the kernel's own filter output:
+                # what is left is atan2f's rounding, 2e-5 of the deviation and 2e-3 Hz on the offset (which may be near 0)
+                if geom is not None and b > 0 and all(g["status"][k]["squelch_count"] == 0 and g["status"][k]["blanked"] == 0
+                                                      for k in (b - 1, b)):
+                    fo, pd = _fm_readings_float64(g["filt"][b - 1], g["filt"][b], geom["samprate"] / geom["D"])
+                    np.testing.assert_allclose(sg["foffset"], fo, rtol=2e-5, atol=2e-3, err_msg="foffset vs float64 (%d, %d)" % (c, b))
+                    np.testing.assert_allclose(sg["pdeviation"], pd, rtol=2e-5, atol=2e-3, err_msg="pdeviation vs float64 (%d, %d)" % (c, b))
             else:
                 if b > 0 or p["demod"] == "am":
                     np.testing.assert_allclose(sg["agc_gain"], sw["agc_gain"], rtol=2e-5)
@@ -213,7 +231,7 @@ def test_config_geometry_full(gpu, name, nchan):
     # pins the wrapped passband mask of the full-spectrum kernel
     want = run_oracle(plan, g, iq, nblocks, compute_n0=1)
     got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_FULL, compute_n0=True, per_call=4)
-    _compare(plan, got, want, check_n0=True)
+    _compare(plan, got, want, check_n0=True, geom=g)
 
 
 def test_full_size_pruned_and_full_spectrum_agree_on_every_channel(gpu):
@@ -306,7 +324,7 @@ def test_geometry_sweep(gpu, N, L, M, D, fs, mode, n0):
     got, used = _run_bank(plan, g, iq, nblocks, fwd, compute_n0=n0, per_call=3)
     if mode != "auto":
         assert used == fwd
-    _compare(plan, got, want, check_n0=n0)
+    _compare(plan, got, want, check_n0=n0, geom=g)
 
 
 def test_filter_and_shift_changed_while_running(gpu):
@@ -598,7 +616,7 @@ def test_cfg2_geometry_without_the_pl_measurement(gpu, seed, per_call):
     iq = wl.make_iq(g["samprate"], nblocks * g["L"], seed=300 + seed)
     want = run_oracle(plan, g, iq, nblocks, compute_n0=1)
     got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_AUTO, compute_n0=True, per_call=per_call, pl_tone=False)
-    _compare(plan, got, want, check_n0=True)
+    _compare(plan, got, want, check_n0=True, geom=g)
     for c, p in enumerate(plan):
         if p["demod"] == "fm":
             assert all(np.isnan(st["plfreq"]) for st in got[c]["status"])
@@ -718,7 +736,7 @@ def test_cfg5_geometry_full_spectrum_with_n0(gpu, variant):
     got, mode = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_AUTO, compute_n0=True, per_call=2)
     assert mode == kq.KQ_FWD_FULL
     # (one of these nine channels has a bin 5e-5 below the cut in its first block -- checked in float64 on the kernel's
-    # own spectrum, tests/diag_n0_64k.py: the kernel keeps it, the oracle's sequential float sum, 1.3e-4 low, drops it)
+    # own spectrum, tests/diag/diag_n0_64k.py: the kernel keeps it, the oracle's sequential float sum, 1.3e-4 low, drops it)
     flips = _compare_counting_ties(plan, got, want, nblocks)
     import conftest
     conftest.note_ties("test_cfg5_geometry_full_spectrum_with_n0[%s]" % variant, flips, len(plan))

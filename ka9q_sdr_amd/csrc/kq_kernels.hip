@@ -9,6 +9,7 @@
 //
 // The pruned forward path lives in kq_pruned.hip.
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -209,7 +210,9 @@ void launch_copy_to_host(hipStream_t s, const float *audio, float *haudio, int r
   // 1.59 ms per step with 32 workgroups, 1.48 with 4-8, 1.64 with 2, which no longer finish inside the step).  One per
   // 2 MiB is 26 GB/s at cfg 4.
   size_t const bytes = rows * ((haudio ? (size_t)row * sizeof(float) : 0) + (hstatus ? sizeof(kq_chan_status) : 0));
-  unsigned const wgs = (unsigned)std::min<size_t>(64, std::max<size_t>(4, (bytes + (2u << 20) - 1) >> 21));
+  unsigned wgs = (unsigned)std::min<size_t>(64, std::max<size_t>(4, (bytes + (2u << 20) - 1) >> 21));
+  static int const forced = getenv("KQ_COPY_WGS") ? atoi(getenv("KQ_COPY_WGS")) : 0;  // diagnostic (tools/ab_env_hostio.sh)
+  if (forced > 0) wgs = (unsigned)forced;
   hipLaunchKernelGGL(k_copy_to_host, dim3(wgs), dim3(256), 0, s, audio, haudio, row, status, (u32x4 *)hstatus, rows,
                      rows * sizeof(kq_chan_status) / 16);
 }

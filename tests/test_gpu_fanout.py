@@ -101,6 +101,19 @@ def test_c_fanout_wrapper_stats_and_rccl_view(gpu):
     assert st["world"] == 1 and st["rccl_ranks"] == 1 and st["rccl_version"] > 0, st
     # (a broadcast still in flight when its slot is posted again is not timed: at least the last two are)
     assert 2 <= st["broadcasts"] <= 8 and st["broadcast_ms"] > 0, st
+    assert st["acquires"] == 6 and st["waits"] == 0 and st["wait_ms"] == 0, st      # waits are only timed on request
+    # kq_fanout_enable_timing: an acquire that finds its batch still travelling records two events on the consumer's stream
+    fan.enable_timing(True)
+    for k in range(6, 12):
+        i = k & 1
+        assert fan.acquire(i, stream.cuda_stream)
+        fan.release(i, stream.cuda_stream)
+        fan.post(i)
+    torch.cuda.synchronize()
+    st = fan.stats()
+    assert st["acquires"] == 12 and 0 <= st["waits"] <= 6 and st["wait_ms"] >= 0, st
+    assert (st["waits"] == 0) == (st["wait_ms"] == 0), st
+    fan.enable_timing(False)
     # the slot holds what the root put there
     back = torch.empty(2 * n, dtype=torch.float32, device="cuda")
     import ctypes
@@ -248,4 +261,24 @@ def test_65536_points_with_forced_demodulator_overlap_and_streamed_planes(gpu, m
                 assert st[c, b]["nout"] == ws["nout"] and st[c, b]["hangcount"] == ws["hangcount"]
                 assert st[c, b]["n0"] == np.float32(ws["n0"]) and not np.isnan(st[c, b]["n0"]), (k, c, b)
     ref.close()
+    bank.close()
+
+
+def test_process_spectrum_refuses_a_channel_with_its_own_oscillator(gpu):
+    """kq_bank_process_spectrum serves what follows the master: a channel that still has a second LO to apply cannot be
+    demodulated from a spectrum transformed elsewhere (radio.c:132-139 mixes in front of the master)."""
+    g = dict(samprate=192000, L=512, M=513, D=4)
+    bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], 1, 1, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL)
+    bank.add_channel(bank_cfg(dict(demod="am", low=-5000.0, high=5000.0, second_lo=-20000.0, recovery_rate=50.0)))
+    spec = torch.zeros(g["L"] + g["M"] - 1, dtype=torch.complex64, device="cuda")
+    lib = kq.load_library()
+    lib.kq_bank_process_spectrum.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    assert lib.kq_bank_process_spectrum(bank.h, C.c_void_p(spec.data_ptr()), 1) == -1
+    assert b"second LO" in lib.kq_last_error()
+    bank.close()
+    # without one it runs: an all-zero spectrum gives all-zero audio
+    bank = kq.Bank(g["samprate"], g["L"], g["M"], g["D"], 1, 1, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL)
+    bank.add_channel(bank_cfg(dict(demod="linear", low=100.0, high=3000.0, second_lo=0.0, hangtime=1.1, recovery_rate=6.0)))
+    assert lib.kq_bank_process_spectrum(bank.h, C.c_void_p(spec.data_ptr()), 1) == 1, lib.kq_last_error()
+    assert not np.any(bank.audio(0, 0)) and bank.status(0, 0)["nout"] == g["L"] // g["D"]
     bank.close()

@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--fanout", default="c", choices=["c", "torch"],
                     help="front-end fan-out: c = the library's kq_fanout_* (ncclBroadcast, the product path); torch = "
                          "ka9q_sdr_amd/shard.py's torch.distributed twin (always used with --backend gloo)")
+    ap.add_argument("--rccl-max-channels", type=int, default=0,
+                    help="N > 0: export NCCL_MAX_NCHANNELS=N before RCCL initialises (default 0: RCCL's own choice; the "
+                         "broadcast's footprint costs the step <= 2.5 %% at any count, profiles/r04/bcast_side_kernel_probe.txt)")
     ap.add_argument("--no-host-io", action="store_true", help="skip the with_host_io measurement")
     ap.add_argument("--no-rows", action="store_true",
                     help="skip the `rows` object: BASELINE.json's other single-GPU shapes (cfg2, cfg3, cfg5 per-GPU share), each "
@@ -297,10 +300,9 @@ def measure_row(torch, kq, wl, config, blocks, dev_index, stream, pci_bus, spin_
 # The fan-out's broadcast is 4.3 MB per step on a side stream beside the filter kernel.  What an RCCL-shaped kernel there costs
 # the step was measured with a stand-in on one GPU (tools/bcast_probe.py, profiles/r04/bcast_side_kernel_probe.txt): 1 to 64
 # workgroups of 256 threads, resident for up to 400 us, cost 0.2-2.5 % (cfg 4) and 2-3.5 % (cfg 5), of which ~1 % is the two
-# stream markers -- far inside the 25 % the 6 x target leaves.  So the cap is not needed for the step; eight channels are
-# plenty for 4.3 MB (a channel moves >= 10 GB/s) and leave RCCL the fewest workgroups to place.  Read by RCCL at
-# communicator creation: set before any rank initialises it (an explicit NCCL_MAX_NCHANNELS in the environment wins).
-RCCL_CHANNEL_CAP = "8"
+# stream markers -- far inside the 25 % the 6 x target leaves at ANY channel count.  So RCCL keeps its own choice (the
+# configuration it is tested in); --rccl-max-channels N exports NCCL_MAX_NCHANNELS=N before any rank creates a communicator
+# for whoever wants fewer workgroups beside the filter launch (an NCCL_MAX_NCHANNELS already in the environment wins).
 
 
 def self_launch(a):
@@ -315,7 +317,8 @@ def self_launch(a):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("NCCL_MAX_NCHANNELS", RCCL_CHANNEL_CAP)
+    if a.rccl_max_channels > 0:
+        env.setdefault("NCCL_MAX_NCHANNELS", str(a.rccl_max_channels))
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
@@ -323,8 +326,8 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)
-    if a.gpus > 1:
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", RCCL_CHANNEL_CAP)   # (started by torch.distributed.run: same default)
+    if a.gpus > 1 and a.rccl_max_channels > 0:     # (started by torch.distributed.run: set here, before torch or RCCL load)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(a.rccl_max_channels))
     import torch
     import ka9q_sdr_amd as kq
     from ka9q_sdr_amd import workload as wl

@@ -607,7 +607,8 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
     Scope t(b, 2, b->stream);
     // the partial sums live behind the plane's max_blocks if_power values
     // (spectrum mode: no samples to sum -- the launch only carries the call's parameter block to the device)
-    kq::launch_block_energy_sum(b->stream, window + (g.M - 1), g.L, spectrum ? 0 : (int)nblocks, pl.if_power + b->cfg.max_blocks,
+    kq::launch_block_energy_sum(b->stream, spectrum ? nullptr : window + (g.M - 1), g.L, spectrum ? 0 : (int)nblocks,
+                                pl.if_power + b->cfg.max_blocks,
                                 b->stage_host[slot], b->osc_dev2[pp],
                                 nret ? ret_off + nret * sizeof(int) : 8 * Cmax * sizeof(double) + nblocks,
                                 spectrum ? nullptr : paired, (int)(g.M - 1));

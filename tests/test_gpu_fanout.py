@@ -282,3 +282,40 @@ def test_process_spectrum_refuses_a_channel_with_its_own_oscillator(gpu):
     assert lib.kq_bank_process_spectrum(bank.h, C.c_void_p(spec.data_ptr()), 1) == 1, lib.kq_last_error()
     assert not np.any(bank.audio(0, 0)) and bank.status(0, 0)["nout"] == g["L"] // g["D"]
     bank.close()
+
+
+def test_push_iq_async_buffer_may_be_reused_after_two_more_pushes(gpu):
+    """include/ka9q_hip.h's promise for kq_bank_push_iq_async: `iq` must stay unchanged until two more pushes have
+    been queued -- so a host that rotates three pinned buffers and scribbles over the oldest as soon as the third push has
+    returned must get the same audio as the blocking path.  Small blocks, many calls, no host wait in between: the host runs
+    as far ahead of the device as the library lets it."""
+    g = dict(samprate=192000, L=512, M=513, D=4)
+    fs, L, M = g["samprate"], g["L"], g["M"]
+    plan = wl.channel_plan("cfg1", 2)
+    nblocks, ncalls = 4, 40
+    iq = wl.make_iq(fs, ncalls * nblocks * L, seed=97)
+    ref = kq.Bank(fs, L, M, g["D"], len(plan), nblocks, compute_n0=True)
+    bank = kq.Bank(fs, L, M, g["D"], len(plan), nblocks, compute_n0=True)
+    for p in plan:
+        ref.add_channel(bank_cfg(p))
+        bank.add_channel(bank_cfg(p))
+    n = nblocks * L
+    bufs = [torch.zeros(n, dtype=torch.complex64).pin_memory() for _ in range(3)]
+    junk = torch.full((n,), 1e3 + 1e3j, dtype=torch.complex64)
+    got = []
+    for k in range(ncalls):
+        bufs[k % 3].copy_(torch.from_numpy(iq[k * n:(k + 1) * n]))
+        bank.push_iq_async(bufs[k % 3].data_ptr(), n)
+        if k >= 2:
+            bufs[(k - 2) % 3].copy_(junk)        # two more pushes have been queued since push k - 2: its buffer is ours again
+        assert bank.process() == nblocks
+        got.append([bank.audio(c, nblocks - 1).copy() for c in range(len(plan))] if k % 8 == 7 else None)
+    bank.host_io_wait()
+    for k in range(ncalls):
+        ref.push_iq(iq[k * n:(k + 1) * n])
+        assert ref.process() == nblocks
+        if got[k] is not None:
+            for c in range(len(plan)):
+                assert np.array_equal(got[k][c], ref.audio(c, nblocks - 1)), (k, c)
+    ref.close()
+    bank.close()

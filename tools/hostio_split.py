@@ -31,6 +31,9 @@ iq_dev = torch.from_numpy(iq).to(dev)
 olen = L // D
 audio_pin = torch.zeros(C * B * 2 * olen, dtype=torch.float32).pin_memory()
 status_pin = torch.empty(C * B * ctypes.sizeof(kq.ChanStatus), dtype=torch.uint8).pin_memory()
+# the same copy kernel with DEVICE memory as its destination: its workgroups and loads without the link
+audio_dev = torch.zeros(C * B * 2 * olen, dtype=torch.float32, device=dev)
+status_dev = torch.empty(C * B * ctypes.sizeof(kq.ChanStatus), dtype=torch.uint8, device=dev)
 
 
 def run(push, pull, steps=400):
@@ -47,7 +50,9 @@ def run(push, pull, steps=400):
     def step():
         assert bank.process() == B
         feed()
-        if pull:
+        if pull == "dev":
+            bank.pull_planes_async(audio_dev.data_ptr(), status_dev.data_ptr())
+        elif pull:
             bank.pull_planes_async(audio_pin.data_ptr(), status_pin.data_ptr())
 
     feed()
@@ -66,5 +71,6 @@ def run(push, pull, steps=400):
 
 
 for push in ("device", "host"):
-    for pull in (False, True):
-        print("%s: input from %-6s memory, planes %-22s %.4f ms/step" % (a.config, push, "to pinned host memory" if pull else "left on the device", run(push, pull)))
+    for pull in (False, "dev", True):
+        what = {False: "left on the device", "dev": "copied to device memory", True: "to pinned host memory"}[pull]
+        print("%s: input from %-6s memory, planes %-24s %.4f ms/step" % (a.config, push, what, run(push, pull)))

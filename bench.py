@@ -268,12 +268,18 @@ def measure_row(torch, kq, wl, config, blocks, dev_index, stream, pci_bus, spin_
     torch.cuda.synchronize()
     bank.enable_timing(1)
     bank.timing(reset=True)
+    import threading
+    reading = {}
+    reader = threading.Thread(target=lambda: reading.update(state=GpuState.once(pci_bus)), daemon=True)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for k in range(steps):
+        if k == steps // 2:       # clock and power under the load, read by a side thread (the files take a millisecond or two:
+            reader.start()        # read from this thread they would let the four-step queue of a 0.4 ms step run dry)
         bank.process_resident(iq.data_ptr(), blocks)
-    state = GpuState.once(pci_bus)       # the queue is still several steps deep when the files are read
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    reader.join()
+    state = reading.get("state")
     tm = bank.timing(reset=True)
     bank.enable_timing(2)
     for _ in range(3):

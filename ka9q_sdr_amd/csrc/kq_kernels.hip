@@ -791,14 +791,16 @@ __global__ void __launch_bounds__(64) k_fm_audio256(Geom g, ChanDev ch, Planes p
   }
   float *aud0 = pl.audio + ((size_t)c * g.max_blocks + b0) * (2 * (size_t)AL);
   float *aud1 = aud0 + 2 * AL;
-  if (ch.flags[c] & FLAG_FLAT) {  // fm.c:164-172: no filter, no gain
+  bool const pl_on = g.pl_n == 8 && pl.plout != nullptr;  // the PL slave (fm.c:201-234) reads bins 0..4 of the same transform
+  bool const flat = (ch.flags[c] & FLAG_FLAT) != 0;
+  if (flat) {  // fm.c:164-172: no filter, no gain
     aud0[lane] = c0;
     aud0[lane + 64] = c1;
     if (have1) {
       aud1[lane] = n0;
       aud1[lane + 64] = n1;
     }
-    return;
+    if (!pl_on) return;
   }
   // response on this lane's four bins k = 4 bitrev6(lane) + r, Hermitian-extended
   const float2 *HA = ch.aresp + (size_t)c * (AN / 2 + 1);
@@ -840,7 +842,7 @@ __global__ void __launch_bounds__(64) k_fm_audio256(Geom g, ChanDev ch, Planes p
   auto muli = [](float2 a) { return make_float2(-a.y, a.x); };  // i a
   // z[m + 64 a]: real part the window [b0-1 | b0], imaginary part [b0 | b0+1]
   float2 const z0 = make_float2(p0, c0), z1 = make_float2(p1, c1), z2 = make_float2(c0, n0), z3 = make_float2(c1, n1);
-  float2 u[4];
+  float2 u[4], xf[4];
   {
     float2 const t0 = cadd(z0, z2), t1 = csub(z0, z2), t2 = cadd(z1, z3), t3 = csub(z1, z3);
     u[0] = cadd(t0, t2);
@@ -856,6 +858,7 @@ __global__ void __launch_bounds__(64) k_fm_audio256(Geom g, ChanDev ch, Planes p
       float2 const o = xor_pow(z, s);
       z = ((lane >> s) & 1) ? cmul(csub(o, z), wf[s]) : cadd(z, o);
     }
+    xf[r] = z;           // X[4 bitrev6(lane) + r] of the pair's packed transform (the PL slave reads a few of them)
     z = cmul(hf[r], z);  // filter.c:206-208 on both windows at once
 #pragma unroll
     for (int s = 0; s < 6; s++) {  // backward, decimation in time: bit-reversed in, natural out
@@ -865,6 +868,35 @@ __global__ void __launch_bounds__(64) k_fm_audio256(Geom g, ChanDev ch, Planes p
       z = bit ? csub(o, v) : cadd(v, o);
     }
     u[r] = r ? cmul(z, cconj(w4[r - 1])) : z;
+  }
+  if (pl_on) {
+    // PL slave of both blocks (fm.c:219,234: REAL -> REAL, decimate 32, 8 points, the last 4 kept): it needs bins 0..4 of each
+    // window's own transform, W0[k] = (X[k] + conj X[256 - k]) / 2 and W1[k] = (X[k] - conj X[256 - k]) / 2i -- nine values
+    // of the packed transform, held by lanes 0 (bins 0..3), 32 (bin 4) and 63 (bins 252..255).  Lane j < 8 forms output
+    // n = 4 + (j & 3) of window j >> 2: y[n] = G0 + (-1)^n G4 + 2 Re sum_{k=1..3} G[k] e^{2 pi i k n / 8}, G = plresp . W.
+    auto rd = [&](float2 v, int src) { return make_float2(__shfl(v.x, src, 64), __shfl(v.y, src, 64)); };
+    float2 const X0 = rd(xf[0], 0), X1 = rd(xf[1], 0), X2 = rd(xf[2], 0), X3 = rd(xf[3], 0), X4 = rd(xf[0], 32);
+    float2 const Xm1 = rd(xf[3], 63), Xm2 = rd(xf[2], 63), Xm3 = rd(xf[1], 63), Xm4 = rd(xf[0], 63);
+    float2 const Xk[5] = {X0, X1, X2, X3, X4}, Xn[5] = {X0, Xm1, Xm2, Xm3, Xm4};
+    int const w = (lane >> 2) & 1, n = 4 + (lane & 3);
+    float y = 0.f;
+#pragma unroll
+    for (int k = 0; k <= 4; k++) {
+      float2 const a = Xk[k], bc = cconj(Xn[k]);
+      // window 0: (a + b) / 2; window 1: (a - b) / 2i = -i (a - b) / 2
+      float2 const d = csub(a, bc);
+      float2 const W = w ? make_float2(0.5f * d.y, -0.5f * d.x) : make_float2(0.5f * (a.x + bc.x), 0.5f * (a.y + bc.y));
+      float2 gk = cmul(ch.plresp[k], W);
+      if (k == 0 || k == 4) {
+        y += (k == 4 && (n & 1)) ? -gk.x : gk.x;  // the c2r transform ignores the imaginary parts of DC and Nyquist
+      } else {
+        float sn, cs;
+        sincospif((float)(k * n) * 0.25f, &sn, &cs);
+        y += 2.f * (gk.x * cs - gk.y * sn);
+      }
+    }
+    if (lane < 8 && (w == 0 || have1)) pl.plout[((size_t)c * g.max_blocks + b0 + w) * g.pl_l + (lane & 3)] = y;  // filter.c:140
+    if (flat) return;
   }
   // inverse radix-4 over r, outputs i = 128 + m (a = 2) and 192 + m (a = 3) only: the samples the slave keeps (filter.c:140)
   float2 const y2 = csub(cadd(u[0], u[2]), cadd(u[1], u[3]));
@@ -1007,11 +1039,17 @@ __global__ void __launch_bounds__(1024) k_pl_track(Geom g, ChanDev ch, Planes pl
   int ptr = ch.pl_ptr[c], last = ch.pl_last[c];
   float plfreq = ch.plfreq[c];
   float const pl_samprate = g.dsamprate / 32.f;
-  for (int b = 0; b < nblocks; b++) {
+  // The blocks between two transforms are taken together: their PL samples (contiguous in plout) go into the ring in one
+  // sweep and their status records in another -- block by block this was a chain of 64 tiny dependent steps per call.
+  for (int b = 0; b < nblocks;) {
+    int need = (512 - last + g.pl_l - 1) / g.pl_l;  // blocks until fm.c:251's count is reached
+    if (need < 1) need = 1;
+    int const nb = min(need, nblocks - b);
     const float *src = pl.plout + ((size_t)c * g.max_blocks + b) * g.pl_l;
-    for (int i = threadIdx.x; i < g.pl_l; i += blockDim.x) ring[(ptr + i) & (FS - 1)] = src[i];
-    ptr = (ptr + g.pl_l) & (FS - 1);
-    last += g.pl_l;
+    for (int i = threadIdx.x; i < nb * g.pl_l; i += blockDim.x) ring[(ptr + i) & (FS - 1)] = src[i];
+    ptr = (ptr + nb * g.pl_l) & (FS - 1);
+    last += nb * g.pl_l;
+    float const before = plfreq;  // what the blocks in front of the one that completes the count report
     if (last >= 512) {  // fm.c:251
       last = 0;
       __syncthreads();
@@ -1063,7 +1101,9 @@ __global__ void __launch_bounds__(1024) k_pl_track(Geom g, ChanDev ch, Planes pl
       }
       __syncthreads();
     }
-    if (threadIdx.x == 0) pl.status[(size_t)c * g.max_blocks + b].plfreq = plfreq;
+    for (int j = threadIdx.x; j < nb; j += blockDim.x)
+      pl.status[(size_t)c * g.max_blocks + b + j].plfreq = j == nb - 1 ? plfreq : before;
+    b += nb;
   }
   if (threadIdx.x == 0) {
     ch.pl_ptr[c] = ptr;
@@ -1101,7 +1141,7 @@ void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes
     ensure_dynamic_lds((const void *)k_demod_fm, lds_a);
     ensure_dynamic_lds((const void *)k_fm_audio, lds_b);
     hipLaunchKernelGGL(k_demod_fm, dim3(n_fm), dim3(64 * waves), lds_a, s, g, ch, pl, fmout, list_fm, nblocks, compute_n0);
-    if (g.Ndec == 256 && g.olen == 128 && g.Mdec == 129 && g.pl_n == 0)  // cfg 2's geometry without the PL measurement: registers only
+    if (g.Ndec == 256 && g.olen == 128 && g.Mdec == 129 && (g.pl_n == 0 || (g.pl_n == 8 && g.pl_l == 4)))  // cfg 2's geometry: registers only
       hipLaunchKernelGGL(k_fm_audio256, dim3(n_fm, (nblocks + 1) / 2), dim3(64), 0, s, g, ch, pl, fmout, fm_hist_in, fm_hist_out,
                          list_fm, nblocks);
     else

@@ -822,6 +822,34 @@ def test_pl_tone_measurement_cfg1_geometry(gpu):
     assert np.isnan(tones[0]) and abs(tones[-1] - 100.0) < 0.2
 
 
+def test_pl_tone_measurement_cfg2_geometry(gpu):
+    """The same measurement at cfg 2's geometry (N/D = 256: a PL slave of 8 points, 4 samples per block), where the
+    de-emphasis filter and the PL slave of a PAIR of blocks come out of one packed 256-point transform in registers
+    (k_fm_audio256: the slave's bins 0..4 of each window are separated from the packed spectrum by Hermitian symmetry).
+    512 PL samples = 128 blocks until the first ring transform (fm.c:251): 280 blocks in calls of 37 (an odd count, so
+    pairs straddle the calls) see two of them; the tone -- and with it the peak bin, fm.c:260-267 -- must equal the
+    oracle's in every block, for a de-emphasised and a flat channel."""
+    g = wl.GEOMETRY["cfg2"]
+    fs, L = g["samprate"], g["L"]
+    nblocks = 280
+    t = np.arange(nblocks * L) / fs
+    ph = 2 * np.pi * 100000.0 * t + 3.0 * np.sin(2 * np.pi * 1000.0 * t) + 6.0 * np.sin(2 * np.pi * 100.0 * t)
+    rng = np.random.default_rng(33)
+    # (30 dB of in-channel SNR: with less noise the envelope's variance, fm.c:101, is float rounding of either sign and the
+    # squelch counter with it)
+    sigma = 0.1 * 10 ** (-30 / 20) / np.sqrt(2 * 16000.0 / fs)
+    iq = (0.1 * np.exp(1j * ph) + sigma / np.sqrt(2) * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    plan = [dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-100000.0),
+            dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-100000.0, flat=1)]
+    want = run_oracle(plan, g, iq, nblocks)
+    got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_FULL, per_call=37)
+    _compare(plan, got, want)
+    for c in range(2):
+        tones = [s["plfreq"] for s in got[c]["status"]]
+        assert np.isnan(tones[0]) and np.isnan(tones[126]) and abs(tones[-1] - 100.0) < 0.5, (tones[0], tones[126], tones[-1])
+        assert sum(1 for a, b in zip(tones[:-1], tones[1:]) if not (a == b or (np.isnan(a) and np.isnan(b)))) >= 1
+
+
 def test_pcm_output_stage(gpu):
     """scaleclip + network byte order + per-480-word silence flags (audio.c:22-28, 45-50, 95-100),
     bit exact against the oracle applied to the same device audio; includes clipping and an all-zero (squelched) block."""

@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--rccl-max-channels", type=int, default=0,
                     help="N > 0: export NCCL_MAX_NCHANNELS=N before RCCL initialises (default 0: RCCL's own choice; the "
                          "broadcast's footprint costs the step <= 2.5 %% at any count, profiles/r04/bcast_side_kernel_probe.txt)")
+    ap.add_argument("--per-rank", action="store_true",
+                    help="emit the per_rank diagnostics (step, kernel, broadcast and stall time of every rank) at N = 1 too; "
+                         "with --gpus N > 1 they are always on the line")
     ap.add_argument("--no-host-io", action="store_true", help="skip the with_host_io measurement")
     ap.add_argument("--no-rows", action="store_true",
                     help="skip the `rows` object: BASELINE.json's other single-GPU shapes (cfg2, cfg3, cfg5 per-GPU share), each "
@@ -526,7 +529,7 @@ def main():
     # the consumer stream's waits for its batch timed (two event records per acquire that has to wait), then every rank's
     # step time, filter-kernel time, broadcast time and stall time travel to rank 0.
     per_rank = None
-    if use_c and world > 1:
+    if use_c and (world > 1 or a.per_rank):
         fan.enable_timing(True)
         nd = 40
         for k in range(nd):
@@ -538,7 +541,10 @@ def main():
                              fs2["broadcast_ms"] / max(1, fs2["broadcasts"]), float(fs2["broadcasts"]),
                              fs2["wait_ms"] / nd, float(fs2["waits"]), float(nd)], device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
+        if dist:
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
         per_rank = [{"rank": r, "ms_per_step": round(float(v[0]), 4), "kernel_ms": round(float(v[1]), 4),
                      "bcast_ms": round(float(v[2]), 4), "bcasts_timed": int(v[3]),
                      "wait_ms_per_step": round(float(v[4]), 4), "waits": int(v[5]), "diag_steps": int(v[6])}

@@ -66,3 +66,41 @@ def test_c_host_for_several_gpus_runs_with_a_world_of_eight():
     assert "ThreadSanitizer" not in out, out[-4000:]
     assert r.returncode == 0, out[-4000:]
     assert out.count("rccl ranks 8") == 8 and "\nok\n" in out
+
+
+@pytest.mark.parametrize("what,old,new", [
+    ("the producer's wait for the slot's release",
+     'if (hipError_t e = hipStreamWaitEvent(f->side, f->freed[slot], 0); e != hipSuccess) return fail("kq_fanout_post: hipStreamWaitEvent", e);',
+     "/* mutated: no wait for the consumer's release */"),
+    ("the consumer's wait for the batch",
+     "if (hipEventQuery(f->ready[slot]) != hipSuccess) {",
+     "if (false) {  /* mutated: the consumer never waits */"),
+])
+def test_fanout_harness_catches_a_missing_wait(what, old, new, tmp_path):
+    """The world-of-eight run means something only if it fails when the protocol is broken: kq_fanout.cpp with ONE of its two
+    cross-stream waits taken out must be reported by ThreadSanitizer (a slot overwritten before its release / read before
+    its batch has landed is a data race on plain memory under the mock streams)."""
+    if not shutil.which("g++") or not shutil.which("make"):
+        pytest.skip("no g++ / make")
+    probe = subprocess.run("echo 'int main(){}' | g++ -x c++ -fsanitize=thread - -o /dev/null", shell=True, capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("this g++ has no ThreadSanitizer runtime")
+    tsan = os.path.join(HERE, "tsan")
+    r = subprocess.run(["make", "-C", tsan, "_build/librccl_mock.so"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    src = open(os.path.join(HERE, "..", "ka9q_sdr_amd", "csrc", "kq_fanout.cpp")).read()
+    assert src.count(old) == 1, "kq_fanout.cpp no longer holds the statement this test takes out: " + what
+    mutated = tmp_path / "kq_fanout_mutated.cpp"
+    mutated.write_text(src.replace(old, new).replace('#include "../../include/ka9q_hip.h"', '#include "ka9q_hip.h"'))
+    exe = tmp_path / "harness"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I" + os.path.join(tsan, "mock_async"),
+           "-I" + os.path.join(HERE, "..", "include"), "-I" + os.path.join(HERE, "..", "ka9q_sdr_amd", "csrc"),
+           "-Wno-unknown-pragmas", os.path.join(tsan, "fanout_harness.cpp"), str(mutated), "-o", str(exe),
+           "-L" + os.path.join(tsan, "_build"), "-lrccl_mock", "-Wl,-rpath," + os.path.join(tsan, "_build"), "-ldl", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ, KQ_RCCL_LIB=os.path.join(tsan, "_build", "librccl_mock.so"), TSAN_OPTIONS="halt_on_error=1")
+    run = subprocess.run([str(exe), "8", "400"], capture_output=True, text=True, timeout=600, env=env)
+    out = run.stdout + run.stderr
+    assert run.returncode != 0 and ("ThreadSanitizer: data race" in out or "failures" in out), \
+        "the run did not notice " + what + ":\n" + out[-2000:]

@@ -129,6 +129,11 @@ int kq_bank_destroy(kq_bank *bank);                               /* filter.c:25
  *     am.c:21-41, linear.c:29-81): creates the slave, designs its response, arms the demodulator.
  *     Returns the channel index (>= 0) or -1. --- */
 int kq_bank_add_channel(kq_bank *bank, const kq_channel_config *cfg);
+/* n channels at once -- the same result as n calls of kq_bank_add_channel, but every distinct response is designed once
+ * (one launch for all), every distinct compute_n0 mask is built once and every per-channel plane is uploaded with one copy:
+ * a bank of tens of thousands of channels is set up in a second instead of a minute.  indices (may be NULL) receives the
+ * channel numbers.  All or nothing: returns n, or -1 with no channel added. */
+int kq_bank_add_channels(kq_bank *bank, const kq_channel_config *cfgs, unsigned n, int *indices);
 /* The demodulator thread's epilogue once demod->terminate is set and it has been joined (fm.c:177-182, am.c:80,
  * linear.c:319: delete_filter_output on its slaves).  The other channels keep their numbers; the slot is a hole that
  * the next kq_bank_add_channel reuses (lowest hole first, with prologue state), and holes at the end are dropped.
@@ -232,12 +237,23 @@ void *kq_bank_stream(kq_bank *bank);
  *                             (of each channel-block the first status.nout floats are written, the rest of its row is
  *                             left as it was) and status [channels][max_blocks] (either may be NULL) -- on the output copy stream;
  *                             the next call's demodulators wait for it on the device before they overwrite the planes.
+ *  kq_bank_pull_pcm_planes_async: the same delivery in the reference's own output format (audio.c:22-28, 45-50, 95-100):
+ *                             pcm [channels][max_blocks][2 * olen] clipped int16 in network byte order (status.nout words
+ *                             per channel-block), silent_mask [channels][max_blocks] (may be NULL; bit i set: the i-th
+ *                             480-word chunk is all zero, the packet send_mono_output would not send) and the status
+ *                             plane -- half the bytes of the float plane; the conversion rides in the copy kernel and
+ *                             does not need kq_bank_enable_pcm.  olen a multiple of 8.
+ *  kq_bank_pull_wait:         blocks until the delivery queued `lag` deliveries before the newest one has landed (0: the
+ *                             newest; at most 7) -- a streaming host takes the planes of call k-2 in hand while calls
+ *                             k-1 and k are in flight.
  *  kq_bank_host_io_wait:      blocks until every queued copy has landed.
  * Call order for full overlap: process batch k, push batch k+1, then pull the planes of batch k --
  *     push(0); for k: { process(); push(k + 1); pull_planes(k); }
  * an input copy queued behind an output copy may share its hardware queue and then waits with it for the demodulators. */
 int kq_bank_push_iq_async(kq_bank *bank, const void *iq_pinned, size_t nsamples, int format);
 int kq_bank_pull_planes_async(kq_bank *bank, float *audio_pinned, kq_chan_status *status_pinned);
+int kq_bank_pull_pcm_planes_async(kq_bank *bank, int16_t *pcm_pinned, uint32_t *silent_mask_pinned, kq_chan_status *status_pinned);
+int kq_bank_pull_wait(kq_bank *bank, unsigned lag);
 int kq_bank_host_io_wait(kq_bank *bank);
 
 /* --- results of the last kq_bank_process call (replace send_mono_output/send_stereo_output,
@@ -289,6 +305,17 @@ void *kq_bank_status_device_ptr(kq_bank *bank);
  * IF-power and demodulator kernels as well */
 int kq_bank_enable_timing(kq_bank *bank, int on);
 int kq_bank_get_timing(kq_bank *bank, kq_timing *t, int reset);
+/* The HOST's own time inside kq_bank_process / _resident / _spectrum since the last reset -- what scales with the number of
+ * channels on the host side of a call (the kernels are only queued there).  A receiver at 1.0 x real time with tens of
+ * thousands of channels and a batch of a few blocks has about a millisecond per call: this is the figure to watch.
+ * No reference analogue (each `radio` process steps its own oscillators per sample, radio.c:132-136). */
+typedef struct kq_host_timing {
+  double call_ms;          /* wall time inside the process calls, everything included */
+  double stage_ms;         /* of that: evaluating and staging the per-channel oscillator parameters of the call */
+  double slot_wait_ms;     /* of that: blocked because the device was four calls behind (back-pressure, not work) */
+  uint64_t calls;
+} kq_host_timing;
+int kq_bank_get_host_timing(kq_bank *bank, kq_host_timing *t, int reset);
 /* Which forward path the bank resolved to (enum kq_fwd_mode, never AUTO) */
 int kq_bank_fwd_mode(const kq_bank *bank);
 

@@ -67,6 +67,11 @@ class RtpCounters(C.Structure):
                 ("packets", C.c_int64), ("drops", C.c_int64), ("dupes", C.c_int64), ("samples", C.c_int64)]
 
 
+class HostTiming(C.Structure):
+    """kq_host_timing: the host's own time inside the process calls"""
+    _fields_ = [("call_ms", C.c_double), ("stage_ms", C.c_double), ("slot_wait_ms", C.c_double), ("calls", C.c_uint64)]
+
+
 class Timing(C.Structure):
     _fields_ = [("filter_ms", C.c_double), ("demod_ms", C.c_double), ("ingest_ms", C.c_double),
                 ("filter_launches", C.c_uint64), ("channel_blocks", C.c_uint64)]
@@ -109,6 +114,7 @@ def load_library():
     L.kq_bank_create.argtypes = [C.POINTER(BankConfig)]
     L.kq_bank_destroy.argtypes = [C.c_void_p]
     L.kq_bank_add_channel.argtypes = [C.c_void_p, C.POINTER(ChannelConfig)]
+    L.kq_bank_add_channels.argtypes = [C.c_void_p, C.POINTER(ChannelConfig), C.c_uint, C.POINTER(C.c_int)]
     L.kq_bank_set_mode.argtypes = [C.c_void_p, C.c_int, C.POINTER(ChannelConfig)]
     L.kq_bank_remove_channel.argtypes = [C.c_void_p, C.c_int]
     L.kq_bank_channel_active.argtypes = [C.c_void_p, C.c_int]
@@ -155,6 +161,9 @@ def load_library():
     L.kq_bank_push_iq_async.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.kq_bank_pull_planes_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.kq_bank_host_io_wait.argtypes = [C.c_void_p]
+    L.kq_bank_pull_pcm_planes_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kq_bank_pull_wait.argtypes = [C.c_void_p, C.c_uint]
+    L.kq_bank_get_host_timing.argtypes = [C.c_void_p, C.POINTER(HostTiming), C.c_int]
     L.kq_shard_range.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     L.kq_fanout_unique_id.argtypes = [C.c_void_p]
     L.kq_fanout_create.restype = C.c_void_p
@@ -231,6 +240,15 @@ class Bank:
     def add_channel(self, cfg):
         return self._chk(self.lib.kq_bank_add_channel(self.h, C.byref(cfg)), "kq_bank_add_channel")
 
+    def add_channels(self, cfgs):
+        """kq_bank_add_channels: a list of ChannelConfig in one call (responses designed once per distinct filter,
+        planes uploaded in one piece); returns the channel numbers"""
+        n = len(cfgs)
+        arr = (ChannelConfig * n)(*cfgs)
+        idx = (C.c_int * n)()
+        self._chk(self.lib.kq_bank_add_channels(self.h, arr, n, idx), "kq_bank_add_channels")
+        return list(idx)
+
     def remove_channel(self, ch):
         """fm.c:177-182 / am.c:80 / linear.c:319: end channel `ch`; its number is reused by a later add_channel"""
         self._chk(self.lib.kq_bank_remove_channel(self.h, ch), "kq_bank_remove_channel")
@@ -285,6 +303,20 @@ class Bank:
     def pull_planes_async(self, audio_ptr, status_ptr):
         """queues the copy of the last call's audio [C][max_blocks][2 olen] / status [C][max_blocks] planes to pinned host memory"""
         self._chk(self.lib.kq_bank_pull_planes_async(self.h, audio_ptr, status_ptr), "kq_bank_pull_planes_async")
+
+    def pull_pcm_planes_async(self, pcm_ptr, mask_ptr, status_ptr):
+        """the last call's audio as clipped big-endian int16 words [C][max_blocks][2 olen], the silent-chunk masks
+        [C][max_blocks] and the status plane to pinned host memory (kq_bank_pull_pcm_planes_async)"""
+        self._chk(self.lib.kq_bank_pull_pcm_planes_async(self.h, pcm_ptr, mask_ptr, status_ptr), "kq_bank_pull_pcm_planes_async")
+
+    def pull_wait(self, lag=0):
+        """block until the plane delivery queued `lag` deliveries before the newest has landed"""
+        self._chk(self.lib.kq_bank_pull_wait(self.h, lag), "kq_bank_pull_wait")
+
+    def host_timing(self, reset=True):
+        t = HostTiming()
+        self._chk(self.lib.kq_bank_get_host_timing(self.h, C.byref(t), int(reset)), "kq_bank_get_host_timing")
+        return {n: getattr(t, n) for n, _ in t._fields_}
 
     def host_io_wait(self):
         self._chk(self.lib.kq_bank_host_io_wait(self.h), "kq_bank_host_io_wait")

@@ -8,11 +8,13 @@
 //   * ring management and kernel sequencing
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -204,15 +206,28 @@ struct kq_bank {
   bool in_used[2] = {false, false};  // in_ready[k] has been recorded at least once
   hipEvent_t in_ready[2] = {nullptr, nullptr}, in_free[2] = {nullptr, nullptr};
   int in_next = 0;
-  hipEvent_t out_ready = nullptr, out_done = nullptr;
+  hipEvent_t out_ready = nullptr;
+  // one marker per queued plane copy, a ring of them: the next call's demodulators wait for the newest on the device, and a
+  // streaming host waits for the one `lag` deliveries back (kq_bank_pull_wait) while newer calls are in flight
+  static constexpr int kPullRing = 8;
+  hipEvent_t pull_done[kPullRing] = {};
+  uint64_t pulls = 0;        // plane copies queued so far; the newest one's marker is pull_done[(pulls - 1) % kPullRing]
   bool out_pending = false;  // a plane copy is queued that the next call's demodulators must wait for
 
   std::vector<HostChan> chans;
+  // Steady state of the oscillators: nothing has been set, added or removed since the call before, so the per-call planes
+  // follow from that call's on the device (k_block_energy_sum) and the host touches no per-channel state at all.
+  // osc_dirty = false promises: the planes of the call before are valid for its window start (planes_n_w, planes_out_abs),
+  // no channel has `retuned` set, and the cached launch decisions below still hold.
+  bool osc_dirty = true;
+  int64_t planes_n_w = 0, planes_out_abs = 0, rebased_at = 0;
+  bool cache_any = false, cache_plain = true, cache_swept64k = false, cache_swept_pruned = false;
   int64_t n_abs = 0;        // absolute index of the first new (not yet processed) sample
   int64_t out_abs = 0;      // absolute index of the next output sample
   unsigned last_blocks = 0;
 
   int timing = 0;  // 0 off, 1 filter kernel only, >= 2 every scope
+  kq_host_timing host_acc = {};  // the host's own time inside the process calls (always on: three clock reads per call)
   std::vector<EventPair> ev_filter, ev_demod, ev_ingest;
   size_t ev_used[3] = {0, 0, 0};
   kq_timing acc = {};
@@ -243,13 +258,11 @@ int upload(kq_bank *b, void *dst, const void *src, size_t bytes) {
 // compute_n0's passband exclusion (radio.c:405-411) depends only on the channel's filter edges: one bit per bin, as
 // 64-bit lane masks in the order k_filter_full16k holds the bins (kq_device.hpp ChanDev::n0lane).  Same arithmetic as
 // the reference, int wrap of k * samprate included (radio.c:407,409).  N = 65536: sub-transform r holds bins 4 q + r.
-int upload_n0mask(kq_bank *b, int c) {
-  if (!b->chd.n0lane) return 0;
+void build_n0mask(const kq_bank *b, float low, float high, std::vector<unsigned long long> &m, std::vector<unsigned> &meta) {
   kq::Geom const &g = b->g;
-  float const low = b->chans[c].cfg.low, high = b->chans[c].cfg.high;
   int const nsub = b->use64k ? 4 : 1;
-  std::vector<unsigned long long> m((size_t)nsub * 256, 0ull);
-  std::vector<unsigned> meta(nsub, 0u);
+  m.assign((size_t)nsub * 256, 0ull);
+  meta.assign(nsub, 0u);
   for (int r = 0; r < nsub; r++)
     for (int t = 0; t < 512; t++) {
       int const ka = kq::full16k_bin(t);
@@ -265,10 +278,40 @@ int upload_n0mask(kq_bank *b, int c) {
           }
         }
     }
+}
+
+int upload_n0mask(kq_bank *b, int c) {
+  if (!b->chd.n0lane) return 0;
+  int const nsub = b->use64k ? 4 : 1;
+  std::vector<unsigned long long> m;
+  std::vector<unsigned> meta;
+  build_n0mask(b, b->chans[c].cfg.low, b->chans[c].cfg.high, m, meta);
   if (upload(b, b->chd.n0lane + (size_t)c * nsub * 256, m.data(), m.size() * sizeof(m[0]))) return -1;
   if (upload(b, b->chd.n0meta + (size_t)c * nsub, meta.data(), meta.size() * sizeof(unsigned))) return -1;
   HIP_TRY(hipStreamSynchronize(b->stream));  // the vectors are about to die
   return 0;
+}
+
+// The constants each demodulator thread derives in its prologue (fm.c:86; am.c:21-30; linear.c:29-39)
+struct Derived {
+  int mode, flags, hangmax;
+  float fm_gain, recovery, init_gain;
+};
+Derived derive(const kq::Geom &g, const kq_channel_config &k) {
+  Derived d;
+  d.mode = k.demod_type;
+  d.flags = 0;
+  if (k.flat) d.flags |= kq::FLAG_FLAT;
+  if (k.isb && d.mode == KQ_LINEAR_DEMOD) d.flags |= kq::FLAG_ISB;
+  if (k.channels == 2 && d.mode == KQ_LINEAR_DEMOD) d.flags |= kq::FLAG_STEREO;
+  if (k.square && d.mode == KQ_LINEAR_DEMOD) d.flags |= kq::FLAG_SQUARE;
+  float const samptime = (float)g.D / (float)g.samprate;  // am.c:21, linear.c:29
+  float const rec_db = k.recovery_rate * samptime;
+  d.recovery = powf(10.f, (float)((double)rec_db / 20.));  // dB2voltage, dsp.h:38
+  d.hangmax = (int)(k.hangtime / samptime);                  // am.c:29, linear.c:38
+  d.fm_gain = (float)((k.headroom * M_1_PI * g.dsamprate) / fabsf(k.low - k.high));  // fm.c:86
+  d.init_gain = (d.mode == KQ_AM_DEMOD) ? powf(10.f, (float)(80. / 20.)) : powf(10.f, (float)(100.0 / 20.));
+  return d;
 }
 
 // Derived per-channel constants, as each demod thread computes them in its prologue
@@ -279,18 +322,9 @@ int upload_channel(kq_bank *b, int c, bool fresh = true) {
   HostChan &h = b->chans[c];
   kq::Geom const &g = b->g;
   kq_channel_config const &k = h.cfg;
-  int const mode = k.demod_type;
-  int flags = 0;
-  if (k.flat) flags |= kq::FLAG_FLAT;
-  if (k.isb && mode == KQ_LINEAR_DEMOD) flags |= kq::FLAG_ISB;
-  if (k.channels == 2 && mode == KQ_LINEAR_DEMOD) flags |= kq::FLAG_STEREO;
-  if (k.square && mode == KQ_LINEAR_DEMOD) flags |= kq::FLAG_SQUARE;
-  float const samptime = (float)g.D / (float)g.samprate;  // am.c:21, linear.c:29
-  float const rec_db = k.recovery_rate * samptime;
-  float const recovery = powf(10.f, (float)((double)rec_db / 20.));  // dB2voltage, dsp.h:38
-  int const hangmax = (int)(k.hangtime / samptime);                  // am.c:29, linear.c:38
-  float const fm_gain = (float)((k.headroom * M_1_PI * g.dsamprate) / fabsf(k.low - k.high));  // fm.c:86
-  float const init_gain = (mode == KQ_AM_DEMOD) ? powf(10.f, (float)(80. / 20.)) : powf(10.f, (float)(100.0 / 20.));
+  Derived const dv = derive(g, k);
+  int const mode = dv.mode, flags = dv.flags, hangmax = dv.hangmax;
+  float const recovery = dv.recovery, fm_gain = dv.fm_gain, init_gain = dv.init_gain;
   float const nan = NAN;
   float2 const one = make_float2(1.f, 0.f);  // fm.c:26
 
@@ -448,15 +482,26 @@ struct Scope {
 // Per-call parameters: oscillator phase/step/sweep for a call whose first window starts at absolute
 // sample n_w, the shift oscillator at the first output sample, and the IF-power update flags.
 // Filled into the next pinned staging slot (returned in *slot_out); the first kernel of the call copies it to the device.
-int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsigned nblocks, int *slot_out, int *nret_out) {
+int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsigned nblocks, int *slot_out, int *nret_out,
+                      bool steady) {
   size_t const C = b->chans.size(), Cmax = b->cfg.max_channels;
   int const slot = b->stage_next;
   b->stage_next = (slot + 1) % kq_bank::kSlots;
+  auto const tw0 = std::chrono::steady_clock::now();
   HIP_TRY(hipEventSynchronize(b->stage_ev[slot]));  // the call that last read this slot has got past its filter
+  auto const tw1 = std::chrono::steady_clock::now();
+  b->host_acc.slot_wait_ms += std::chrono::duration<double, std::milli>(tw1 - tw0).count();
   if (harvest_slot(b, slot)) return -1;
   double *pl = reinterpret_cast<double *>(b->stage_host[slot]);
   double *ph = pl, *fr = pl + Cmax, *rt = pl + 2 * Cmax, *sp = pl + 3 * Cmax, *sf = pl + 4 * Cmax;
   double *hph = pl + 5 * Cmax, *hfr = pl + 6 * Cmax, *hrt = pl + 7 * Cmax;
+  if (steady) {  // the planes are advanced on the device from the call before; only the flags travel
+    memcpy(b->stage_host[slot] + 8 * Cmax * sizeof(double), update, nblocks);
+    *nret_out = 0;
+    *slot_out = slot;
+    b->host_acc.stage_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count();
+    return 0;
+  }
   for (size_t c = 0; c < C; c++) {
     HostChan const &h = b->chans[c];
     double p = h.lo2.phase_at(n_w), f = h.lo2.step_at(n_w), r = h.lo2.sweep();
@@ -497,6 +542,7 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
     if (b->chans[c].active && b->chans[c].retuned) ret[nret++] = (int)c;
   *nret_out = nret;
   *slot_out = slot;
+  b->host_acc.stage_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count();
   return 0;
 }
 
@@ -530,36 +576,60 @@ int upload_lists(kq_bank *b) {
 // The kernels of one call over `nblocks` blocks whose first window starts at `window`
 // `spectrum` != null: the master's transform has been done elsewhere (execute_filter_input of the compat surface) and
 // `spectrum` holds its N bins per block -- slave, compute_n0 and demodulators only (kq_bank_process_spectrum)
+int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const unsigned char *update_host,
+                     const float2 *spectrum);
+
+// kq_bank_get_host_timing: the host's wall time inside one call, kernels only queued (call_ms includes slot_wait_ms)
 int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigned char *update_host,
                const float2 *spectrum = nullptr) {
+  auto const t0 = std::chrono::steady_clock::now();
+  int const rc = run_blocks_timed(b, window, nblocks, update_host, spectrum);
+  b->host_acc.call_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  b->host_acc.calls++;
+  return rc;
+}
+
+int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const unsigned char *update_host,
+                     const float2 *spectrum) {
   kq::Geom const &g = b->g;
   int const C = (int)b->chans.size();
-  bool any = false;
-  for (HostChan const &h : b->chans) any = any || h.active;
-  if (!any) {
+  // Per-channel decisions are taken afresh only when something about the channels or their oscillators has changed since
+  // the call before (osc_dirty); a steady call walks no per-channel state on the host.
+  static bool const steady_off = getenv("KQ_STEADY") && atoi(getenv("KQ_STEADY")) == 0;  // A/B switch: stage every call on the host
+  bool const steady = !b->osc_dirty && !spectrum && b->calls > 0 && !steady_off;
+  if (!steady) {
+    bool any = false;
+    for (HostChan const &h : b->chans) any = any || h.active;
+    b->cache_any = any;
+  }
+  if (!b->cache_any) {
     set_err("no channels in bank");
     return -1;
   }
   if (b->lists_dirty && upload_lists(b)) return -1;
-  bool swept = false;
-  if (b->fwd_mode == KQ_FWD_PRUNED)
-    for (HostChan const &h : b->chans) {
-      if (!h.active) continue;
-      double const r = h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0);
-      if (r == 0) continue;
-      swept = true;
-      // The pruned kernels take the sweep's cross term r*R*a*b to first order and drop its b^2 part:
-      // both must stay far below the 1e-5 parity budget over one window.
-      double const cross = 2 * M_PI * std::fabs(r) * (double)g.N * g.D, quad = std::fabs(r) * (double)g.D * g.D * 0.5;
-      if (g.Ndec == 256) {
-        set_err("swept NCO at N/D = 256 is only available on the full forward path: use KQ_FWD_FULL");
-        return -1;
+  if (!steady) {
+    bool swept = false;
+    if (b->fwd_mode == KQ_FWD_PRUNED)
+      for (HostChan const &h : b->chans) {
+        if (!h.active) continue;
+        double const r = h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0);
+        if (r == 0) continue;
+        swept = true;
+        // The pruned kernels take the sweep's cross term r*R*a*b to first order and drop its b^2 part:
+        // both must stay far below the 1e-5 parity budget over one window.
+        double const cross = 2 * M_PI * std::fabs(r) * (double)g.N * g.D, quad = std::fabs(r) * (double)g.D * g.D * 0.5;
+        if (g.Ndec == 256) {
+          set_err("swept NCO at N/D = 256 is only available on the full forward path: use KQ_FWD_FULL");
+          return -1;
+        }
+        if (cross > 3e-4 || quad > 2e-7) {
+          set_err("sweep rate too large for the pruned forward path (cross term %.3g rad): use KQ_FWD_FULL", cross);
+          return -1;
+        }
       }
-      if (cross > 3e-4 || quad > 2e-7) {
-        set_err("sweep rate too large for the pruned forward path (cross term %.3g rad): use KQ_FWD_FULL", cross);
-        return -1;
-      }
-    }
+    b->cache_swept_pruned = swept;
+  }
+  bool const swept = b->cache_swept_pruned;
   if (swept) b->chan_tw_dirty = true;  // the step changes from call to call
   int const pp = (int)(b->calls & 1);
   size_t const Cmax = b->cfg.max_channels;
@@ -579,7 +649,8 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   if (b->demod_overlapped[pp] && hipEventQuery(b->ev_demod_done[pp]) != hipSuccess)
     HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[pp], 0));
   int slot = 0, nret = 0;
-  if (stage_call_params(b, b->n_abs - (g.M - 1), update_host, nblocks, &slot, &nret)) return -1;
+  int64_t const n_w = b->n_abs - (g.M - 1);
+  if (stage_call_params(b, n_w, update_host, nblocks, &slot, &nret, steady)) return -1;
   size_t const ret_off = 8 * Cmax * sizeof(double) + ((b->cfg.max_blocks + 7) & ~7u);
   const int *retune_list = reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(b->osc_dev2[pp]) + ret_off);
   // full-spectrum path: the register-resident N = 16384 kernel where it applies (KQ_FULL_LDS=1 forces the LDS one)
@@ -588,18 +659,23 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   // No sweep anywhere: the register-resident kernel runs without its per-sample oscillator path; the first block of
   // a channel retuned since the last call (history still on the old oscillator) is then redone below with the
   // general variant, as the pruned path does.
-  bool plain = true;
-  bool swept64k = false;  // N = 65536: the steady-state variant takes sweeps up to full64k_sweep_limit() itself
-  for (HostChan const &h : b->chans) {
-    if (!h.active) continue;
-    double const r = h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0);
-    if (b->use64k) {
-      if (r != 0) swept64k = true;
-      if (std::fabs(r) > kq::full64k_sweep_limit()) plain = false;
-    } else if (r != 0) {
-      plain = false;
+  if (!steady) {
+    bool plain = true;
+    bool swept64k = false;  // N = 65536: the steady-state variant takes sweeps up to full64k_sweep_limit() itself
+    for (HostChan const &h : b->chans) {
+      if (!h.active) continue;
+      double const r = h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0);
+      if (b->use64k) {
+        if (r != 0) swept64k = true;
+        if (std::fabs(r) > kq::full64k_sweep_limit()) plain = false;
+      } else if (r != 0) {
+        plain = false;
+      }
     }
+    b->cache_plain = plain;
+    b->cache_swept64k = swept64k;
   }
+  bool const plain = b->cache_plain, swept64k = b->cache_swept64k;
   // That steady-state variant loads its samples 16 bytes at a time from a copy of the call's samples whose 512-sample
   // rows are interleaved in pairs; the IF-power kernel, which reads every new sample anyway, writes it
   float2 *const paired = ((use16k || b->use64k) && plain && b->win_paired && b->fwd_mode != KQ_FWD_PRUNED) ? b->win_paired : nullptr;
@@ -611,7 +687,8 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
                                 pl.if_power + b->cfg.max_blocks,
                                 b->stage_host[slot], b->osc_dev2[pp],
                                 nret ? ret_off + nret * sizeof(int) : 8 * Cmax * sizeof(double) + nblocks,
-                                spectrum ? nullptr : paired, (int)(g.M - 1));
+                                spectrum ? nullptr : paired, (int)(g.M - 1), steady ? b->osc_dev2[pp ^ 1] : nullptr, (unsigned)C,
+                                (unsigned)Cmax, (double)(n_w - b->planes_n_w), (double)(b->out_abs - b->planes_out_abs));
   }
   LAUNCH_CHECK("IF power");
   if (b->timing) {
@@ -708,7 +785,7 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   else if (b->calls > 0 && b->demod_overlapped[prev])
     HIP_TRY(hipStreamWaitEvent(ds, b->ev_demod_done[prev], 0));  // the channel state they carry
   if (b->out_pending) {  // kq_bank_pull_planes_async is still reading the audio / status planes of the last call
-    HIP_TRY(hipStreamWaitEvent(ds, b->out_done, 0));
+    HIP_TRY(hipStreamWaitEvent(ds, b->pull_done[(b->pulls - 1) % kq_bank::kPullRing], 0));
     b->out_pending = false;
   }
   // the IF-power recurrence over the call's blocks: one wave, consumed by the demodulators only, so it runs with them and
@@ -751,13 +828,23 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
   LAUNCH_CHECK("PLL / PL tone / PCM stage");
   b->pl = pl;  // what the pull functions read
   b->calls++;
+  b->planes_n_w = n_w;  // what this parity's planes on the device describe
+  b->planes_out_abs = b->out_abs;
   b->n_abs += (int64_t)nblocks * g.L;
   b->out_abs += (int64_t)nblocks * g.olen;
-  for (HostChan &h : b->chans) {
-    h.retuned = false;
-    h.lo2.rebase(b->n_abs);
-    h.dop.rebase(b->n_abs);
-    h.shift.rebase(b->out_abs);
+  if (!steady) {
+    for (HostChan &h : b->chans) {
+      h.retuned = false;
+      h.lo2.rebase(b->n_abs);
+      h.dop.rebase(b->n_abs);
+      h.shift.rebase(b->out_abs);
+    }
+    b->rebased_at = b->n_abs;
+    b->osc_dirty = spectrum != nullptr;  // (a spectrum call stages no oscillators the next call could advance)
+  } else if (b->n_abs - b->rebased_at > ((int64_t)1 << 24)) {
+    // the host's closed forms are referred to the sample of the last full staging: move them up before f k loses digits
+    // (2^24 samples: 1e-9 turns) -- the next call stages afresh from the host's own oscillators
+    b->osc_dirty = true;
   }
   b->last_blocks = nblocks;
   return (int)nblocks;
@@ -1074,7 +1161,8 @@ int kq_bank_destroy(kq_bank *b) {
     if (b->in_free[k]) (void)hipEventDestroy(b->in_free[k]);
   }
   if (b->out_ready) (void)hipEventDestroy(b->out_ready);
-  if (b->out_done) (void)hipEventDestroy(b->out_done);
+  for (hipEvent_t e : b->pull_done)
+    if (e) (void)hipEventDestroy(e);
   for (int k = 0; k < kq_bank::kSlots; k++) {
     if (b->stage_host[k]) (void)hipHostFree(b->stage_host[k]);
     if (b->stage_ev[k]) (void)hipEventDestroy(b->stage_ev[k]);
@@ -1211,8 +1299,216 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
     return -1;
   }
   b->lists_dirty = true;
+  b->osc_dirty = true;
   b->chan_tw_dirty = true;
   return c;
+}
+
+// Many channels at once (a receiver bank of tens of thousands of channels is set up in one go): the same result as
+// kq_bank_add_channel called n times, but every distinct response is designed once (one launch for all of them), every
+// distinct compute_n0 mask is built once, and each per-channel plane is uploaded with one copy instead of n.
+int kq_bank_add_channels(kq_bank *b, const kq_channel_config *cfgs, unsigned n, int *indices) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  if (!b || (!cfgs && n)) {
+    set_err("NULL argument");
+    return -1;
+  }
+  if (n == 0) return 0;
+  bool holes = false, any_pll = false;
+  for (HostChan const &h : b->chans) holes = holes || !h.active;
+  for (unsigned i = 0; i < n; i++) any_pll = any_pll || is_pll(cfgs[i]);
+  if (holes || any_pll || n < 4) {  // slot reuse and carrier-loop slots: one by one; all or nothing
+    std::vector<int> got;
+    for (unsigned i = 0; i < n; i++) {
+      int const c = kq_bank_add_channel(b, &cfgs[i]);
+      if (c < 0) {
+        std::string const why = g_err;
+        for (size_t k = got.size(); k-- > 0;) (void)kq_bank_remove_channel(b, got[k]);
+        g_err = why;
+        return -1;
+      }
+      got.push_back(c);
+      if (indices) indices[i] = c;
+    }
+    return (int)n;
+  }
+  kq::Geom const &g = b->g;
+  size_t const c0 = b->chans.size();
+  if (c0 + n > b->cfg.max_channels) {
+    set_err("bank is full (%u channels): %zu present, %u more asked for", b->cfg.max_channels, c0, n);
+    return -1;
+  }
+  for (unsigned i = 0; i < n; i++) {
+    kq_channel_config const &k = cfgs[i];
+    if (k.demod_type < KQ_LINEAR_DEMOD || k.demod_type > KQ_FM_DEMOD) {
+      set_err("unknown demod_type %d (entry %u)", k.demod_type, i);
+      return -1;
+    }
+    if (std::isnan(k.low) || std::isnan(k.high)) {  // filter.c:504-505
+      set_err("NaN filter edge (entry %u)", i);
+      return -1;
+    }
+    if (k.demod_type == KQ_FM_DEMOD && !kq::demod64_supported(g) && kq::demod_fm_lds_bytes(g) > 160 * 1024) {
+      set_err("FM working set of %zu bytes exceeds the 160 KiB of LDS at this geometry", kq::demod_fm_lds_bytes(g));
+      return -1;
+    }
+  }
+  // responses: every distinct (out_type, edges, beta) once, one launch per out_type
+  std::vector<HostChan> hs(n);
+  double const fs = g.samprate;
+  struct Key {
+    float lo, hi, beta;
+    bool operator<(Key const &o) const { return lo != o.lo ? lo < o.lo : hi != o.hi ? hi < o.hi : beta < o.beta; }
+  };
+  for (int ot : {(int)kq::FT_COMPLEX, (int)kq::FT_CROSS_CONJ}) {
+    std::map<Key, int> job;
+    std::vector<kq::BandEdges> edges;
+    std::vector<int> which(n, -1);
+    for (unsigned i = 0; i < n; i++) {
+      kq_channel_config const &k = cfgs[i];
+      int const out_type = (k.demod_type == KQ_LINEAR_DEMOD && k.isb) ? kq::FT_CROSS_CONJ : kq::FT_COMPLEX;
+      if (out_type != ot) continue;
+      float lo_n, hi_n;  // as design_channel: fm.c:35 divides by the output rate, am.c:41 / linear.c:81 multiply by samptime
+      if (k.demod_type == KQ_FM_DEMOD) {
+        lo_n = k.low / g.dsamprate;
+        hi_n = k.high / g.dsamprate;
+      } else {
+        float const samptime = (float)g.D / (float)g.samprate;
+        lo_n = samptime * k.low;
+        hi_n = samptime * k.high;
+      }
+      Key const key{lo_n, hi_n, k.kaiser_beta};
+      auto it = job.find(key);
+      if (it == job.end()) {
+        it = job.emplace(key, (int)edges.size()).first;
+        edges.push_back(kq::BandEdges{lo_n, hi_n, k.kaiser_beta});
+      }
+      which[i] = it->second;
+    }
+    if (edges.empty()) continue;
+    std::vector<kq::cfloat> resp;
+    std::vector<float> ng;
+    if (kq::design_responses(g.N, g.olen, g.Mdec, ot, edges, resp, ng) || resp.size() != edges.size() * (size_t)g.Ndec) {
+      set_err("response design failed");
+      return -1;
+    }
+    for (unsigned i = 0; i < n; i++)
+      if (which[i] >= 0) {
+        hs[i].out_type = ot;
+        hs[i].resp.assign(resp.begin() + (size_t)which[i] * g.Ndec, resp.begin() + (size_t)(which[i] + 1) * g.Ndec);
+        hs[i].noise_gain = ng[which[i]];
+      }
+  }
+  std::map<float, std::vector<kq::cfloat>> aresp_by_beta;  // fm.c:54-66 depends on the geometry and beta only
+  for (unsigned i = 0; i < n; i++) {
+    kq_channel_config const &k = cfgs[i];
+    HostChan &h = hs[i];
+    h.cfg = k;
+    // oscillator setter scalings: radio.c:299, radio.c:182, radio.c:309
+    h.lo2.set(k.second_lo == 0 ? 0.0 : k.second_lo / fs, 0.0, b->n_abs);
+    h.dop.set(-k.doppler / fs, -k.doppler_rate / (fs * fs), b->n_abs);
+    h.shift.set(k.shift == 0 ? 0.0 : k.shift * g.D / fs, 0.0, b->out_abs);
+    if (k.demod_type == KQ_FM_DEMOD && !k.flat) {
+      auto it = aresp_by_beta.find(k.kaiser_beta);
+      if (it == aresp_by_beta.end()) {
+        std::vector<kq::cfloat> a = kq::design_fm_audio_response(g.olen, g.Mdec, g.dsamprate, k.kaiser_beta);
+        if (a.empty()) {
+          set_err("FM audio response design failed");
+          return -1;
+        }
+        it = aresp_by_beta.emplace(k.kaiser_beta, std::move(a)).first;
+      }
+      h.aresp = it->second;
+    }
+  }
+  if (sync_all(b)) return -1;
+  // per-channel planes of the new range, one copy each
+  auto put = [&](auto *dst, auto const &v) -> int {
+    HIP_TRY(hipMemcpy(dst + c0, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
+    return 0;
+  };
+  {
+    std::vector<int> mode(n), flags(n), hangmax(n);
+    std::vector<float> low(n), high(n), fm_gain(n), headroom(n), recovery(n), gain(n), ngain(n), nanv(n, NAN);
+    std::vector<float2> one(n, make_float2(1.f, 0.f));  // fm.c:26
+    for (unsigned i = 0; i < n; i++) {
+      Derived const d = derive(g, cfgs[i]);
+      mode[i] = d.mode;
+      flags[i] = d.flags;
+      hangmax[i] = d.hangmax;
+      low[i] = cfgs[i].low;
+      high[i] = cfgs[i].high;
+      fm_gain[i] = d.fm_gain;
+      headroom[i] = cfgs[i].headroom;
+      recovery[i] = d.recovery;
+      gain[i] = d.init_gain;
+      ngain[i] = hs[i].noise_gain;
+    }
+    if (put(b->chd.mode, mode) || put(b->chd.flags, flags) || put(b->chd.hangmax, hangmax) || put(b->chd.low, low) ||
+        put(b->chd.high, high) || put(b->chd.fm_gain, fm_gain) || put(b->chd.headroom, headroom) ||
+        put(b->chd.recovery, recovery) || put(b->chd.gain, gain) || put(b->chd.noise_gain, ngain) || put(b->chd.n0, nanv) ||
+        put(b->chd.plfreq, nanv) || put(b->chd.fm_state, one))
+      return -1;
+  }
+  // demodulator state at its prologue values (fm.c:26,68-69; am.c:26,33; linear.c:33)
+  HIP_TRY(hipMemset(b->chd.lastaudio + c0, 0, n * sizeof(float)));
+  HIP_TRY(hipMemset(b->chd.sq_count + c0, 0, n * sizeof(int)));
+  HIP_TRY(hipMemset(b->chd.hang + c0, 0, n * sizeof(int)));
+  HIP_TRY(hipMemset(b->chd.dc + c0, 0, n * sizeof(float)));
+  HIP_TRY(hipMemset(b->chd.foffset + c0, 0, n * sizeof(float)));
+  HIP_TRY(hipMemset(b->chd.pdev + c0, 0, n * sizeof(float)));
+  if (g.Mdec > 1) {
+    size_t const w = (size_t)(g.Mdec - 1);
+    HIP_TRY(hipMemset(b->chd.ahist + c0 * w, 0, n * w * sizeof(float)));
+    for (int k = 0; k < 2; k++)
+      if (b->fm_hist[k]) HIP_TRY(hipMemset(b->fm_hist[k] + c0 * w, 0, n * w * sizeof(float)));
+  }
+  if (g.pl_n > 0) {
+    HIP_TRY(hipMemset(b->chd.plring + c0 * 16384, 0, (size_t)n * 16384 * sizeof(float)));
+    HIP_TRY(hipMemset(b->chd.pl_ptr + c0, 0, n * sizeof(*b->chd.pl_ptr)));
+    HIP_TRY(hipMemset(b->chd.pl_last + c0, 0, n * sizeof(*b->chd.pl_last)));
+  }
+  {  // responses
+    std::vector<float2> resp((size_t)n * g.Ndec);
+    for (unsigned i = 0; i < n; i++) memcpy(&resp[(size_t)i * g.Ndec], hs[i].resp.data(), sizeof(float2) * g.Ndec);
+    HIP_TRY(hipMemcpy(b->chd.resp + c0 * g.Ndec, resp.data(), resp.size() * sizeof(float2), hipMemcpyHostToDevice));
+    size_t const na = (size_t)g.Ndec / 2 + 1;
+    std::vector<float2> ar((size_t)n * na, make_float2(0.f, 0.f));
+    bool any = false;
+    for (unsigned i = 0; i < n; i++)
+      if (!hs[i].aresp.empty()) {
+        memcpy(&ar[(size_t)i * na], hs[i].aresp.data(), sizeof(float2) * na);
+        any = true;
+      }
+    if (any) HIP_TRY(hipMemcpy(b->chd.aresp + c0 * na, ar.data(), ar.size() * sizeof(float2), hipMemcpyHostToDevice));
+  }
+  if (b->chd.n0lane) {  // compute_n0's lane masks: one per distinct pair of edges
+    int const nsub = b->use64k ? 4 : 1;
+    size_t const per = (size_t)nsub * 256;
+    std::map<std::pair<float, float>, std::pair<std::vector<unsigned long long>, std::vector<unsigned>>> cache;
+    std::vector<unsigned long long> m((size_t)n * per);
+    std::vector<unsigned> meta((size_t)n * nsub);
+    for (unsigned i = 0; i < n; i++) {
+      auto key = std::make_pair(cfgs[i].low, cfgs[i].high);
+      auto it = cache.find(key);
+      if (it == cache.end()) {
+        it = cache.emplace(key, std::make_pair(std::vector<unsigned long long>(), std::vector<unsigned>())).first;
+        build_n0mask(b, cfgs[i].low, cfgs[i].high, it->second.first, it->second.second);
+      }
+      memcpy(&m[(size_t)i * per], it->second.first.data(), per * sizeof(unsigned long long));
+      memcpy(&meta[(size_t)i * nsub], it->second.second.data(), nsub * sizeof(unsigned));
+    }
+    HIP_TRY(hipMemcpy(b->chd.n0lane + c0 * per, m.data(), m.size() * sizeof(m[0]), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->chd.n0meta + c0 * nsub, meta.data(), meta.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+  }
+  for (unsigned i = 0; i < n; i++) {
+    b->chans.push_back(std::move(hs[i]));
+    if (indices) indices[i] = (int)(c0 + i);
+  }
+  b->lists_dirty = true;
+  b->osc_dirty = true;
+  b->chan_tw_dirty = true;
+  return (int)n;
 }
 
 // close_chan equivalent: the demodulator thread is joined and its struct demod freed (radio.c:335-337 does the join
@@ -1236,6 +1532,7 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
   h.out_rtp = kq_out_rtp_state{};
   while (!b->chans.empty() && !b->chans.back().active) b->chans.pop_back();  // holes at the end just go
   b->lists_dirty = true;
+  b->osc_dirty = true;
   return 0;
 }
 
@@ -1288,6 +1585,7 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
   if (design_channel(b, h)) return -1;
   if (upload_channel(b, ch, false) || upload_response(b, ch)) return -1;
   b->lists_dirty = true;
+  b->osc_dirty = true;
   return 0;
 }
 
@@ -1334,6 +1632,7 @@ int kq_bank_set_second_lo(kq_bank *b, int ch, double hz) {
   b->chans[ch].cfg.second_lo = hz;
   b->chans[ch].lo2.set(hz == 0 ? 0.0 : hz / b->g.samprate, 0.0, b->n_abs);
   b->chan_tw_dirty = true;
+  b->osc_dirty = true;
   return 0;
 }
 
@@ -1353,6 +1652,7 @@ int kq_bank_set_doppler(kq_bank *b, int ch, double hz, double hz_per_s) {
   b->chans[ch].cfg.doppler_rate = hz_per_s;
   b->chans[ch].dop.set(-hz / fs, -hz_per_s / (fs * fs), b->n_abs);
   b->chan_tw_dirty = true;
+  b->osc_dirty = true;
   return 0;
 }
 
@@ -1364,6 +1664,7 @@ int kq_bank_set_shift(kq_bank *b, int ch, double hz) {
   }
   b->chans[ch].cfg.shift = hz;
   b->chans[ch].shift.set(hz == 0 ? 0.0 : hz * b->g.D / (double)b->g.samprate, 0.0, b->out_abs);
+  b->osc_dirty = true;
   return 0;
 }
 
@@ -1465,7 +1766,7 @@ static int host_io_setup(kq_bank *b) {
     HIP_TRY(hipEventCreateWithFlags(&b->in_free[k], hipEventDisableTiming));
   }
   HIP_TRY(hipEventCreateWithFlags(&b->out_ready, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&b->out_done, hipEventDisableTiming));
+  for (int k = 0; k < kq_bank::kPullRing; k++) HIP_TRY(hipEventCreateWithFlags(&b->pull_done[k], hipEventDisableTiming));
   return 0;
 }
 // block completion bookkeeping for the IF-power rule (radio.c:140-146 against radio.c:94-98)
@@ -1530,15 +1831,15 @@ int kq_bank_push_iq_async(kq_bank *b, const void *iq, size_t nsamples, int forma
   return 0;
 }
 
-int kq_bank_pull_planes_async(kq_bank *b, float *audio, kq_chan_status *status) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+namespace {
+// the copy stream gets behind the last call's demodulators: their own marker when they ran on their own stream, else one
+// on the main stream
+static int pull_prologue(kq_bank *b) {
   if (!b || b->calls == 0) {
     set_err("nothing processed yet");
     return -1;
   }
   if (host_io_setup(b)) return -1;
-  size_t const n = b->chans.size() * (size_t)b->g.max_blocks;
-  // behind the last call's demodulators: their own marker when they ran on their own stream, else one on the main stream
   int const last = (int)((b->calls - 1) & 1);
   if (b->demod_overlapped[last]) {
     HIP_TRY(hipStreamWaitEvent(b->copy_out, b->ev_demod_done[last], 0));
@@ -1547,6 +1848,20 @@ int kq_bank_pull_planes_async(kq_bank *b, float *audio, kq_chan_status *status) 
     HIP_TRY(hipStreamWaitEvent(b->copy_out, b->out_ready, 0));
   }
   b->pulled_since_call = true;
+  return 0;
+}
+static int pull_epilogue(kq_bank *b) {
+  HIP_TRY(hipEventRecord(b->pull_done[b->pulls % kq_bank::kPullRing], b->copy_out));
+  b->pulls++;
+  b->out_pending = true;
+  return 0;
+}
+}  // namespace
+
+int kq_bank_pull_planes_async(kq_bank *b, float *audio, kq_chan_status *status) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  if (pull_prologue(b)) return -1;
+  size_t const n = b->chans.size() * (size_t)b->g.max_blocks;
   // of every channel-block's 2 * olen floats only the status.nout that hold samples travel (mono: half): the kernel
   // moves 16 bytes per lane, so olen must be a multiple of 4 for it -- other geometries take the plain copy
   size_t const sbytes = n * sizeof(kq_chan_status), s16 = sbytes & ~(size_t)15;
@@ -1557,9 +1872,7 @@ int kq_bank_pull_planes_async(kq_bank *b, float *audio, kq_chan_status *status) 
     if (audio)
       HIP_TRY(hipMemcpyAsync(audio, b->pl.audio, n * 2 * (size_t)b->g.olen * sizeof(float), hipMemcpyDeviceToHost, b->copy_out));
     if (status) HIP_TRY(hipMemcpyAsync(status, b->pl.status, sbytes, hipMemcpyDeviceToHost, b->copy_out));
-    HIP_TRY(hipEventRecord(b->out_done, b->copy_out));
-    b->out_pending = true;
-    return 0;
+    return pull_epilogue(b);
   }
   kq::launch_copy_to_host(b->copy_out, b->pl.audio, rows_ok ? audio : nullptr, 2 * b->g.olen, b->pl.status, status, n);
   LAUNCH_CHECK("plane copy");
@@ -1567,9 +1880,44 @@ int kq_bank_pull_planes_async(kq_bank *b, float *audio, kq_chan_status *status) 
     HIP_TRY(hipMemcpyAsync(audio, b->pl.audio, n * 2 * (size_t)b->g.olen * sizeof(float), hipMemcpyDeviceToHost, b->copy_out));
   if (status && sbytes > s16)
     HIP_TRY(hipMemcpyAsync((char *)status + s16, (const char *)b->pl.status + s16, sbytes - s16, hipMemcpyDeviceToHost, b->copy_out));
-  HIP_TRY(hipEventRecord(b->out_done, b->copy_out));
-  b->out_pending = true;
-  return 0;
+  return pull_epilogue(b);
+}
+
+// The reference's real output format (audio.c:22-28, 45-50, 95-100): clipped int16 in network byte order, half the bytes
+// of the float plane.  The conversion runs inside the copy kernel (the same arithmetic as k_pcm, the stage behind
+// kq_bank_enable_pcm, which this call does not need).
+int kq_bank_pull_pcm_planes_async(kq_bank *b, int16_t *pcm, uint32_t *silent_mask, kq_chan_status *status) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  if (!pcm) {
+    set_err("NULL pcm plane");
+    return -1;
+  }
+  bool const aligned = (reinterpret_cast<uintptr_t>(pcm) & 15) == 0 && (reinterpret_cast<uintptr_t>(status) & 15) == 0 &&
+                       (reinterpret_cast<uintptr_t>(silent_mask) & 3) == 0;
+  if (b && (b->g.olen % 8 != 0 || !aligned || 2 * (size_t)b->g.olen > 32 * 480)) {
+    set_err("kq_bank_pull_pcm_planes_async: olen must be a multiple of 8 and at most 7680, the planes 16-byte aligned");
+    return -1;
+  }
+  if (pull_prologue(b)) return -1;
+  size_t const n = b->chans.size() * (size_t)b->g.max_blocks;
+  size_t const sbytes = n * sizeof(kq_chan_status), s16 = sbytes & ~(size_t)15;
+  kq::launch_copy_pcm_to_host(b->copy_out, b->pl.audio, pcm, silent_mask, 2 * b->g.olen, b->pl.status, status, n);
+  LAUNCH_CHECK("PCM plane copy");
+  if (status && sbytes > s16)
+    HIP_TRY(hipMemcpyAsync((char *)status + s16, (const char *)b->pl.status + s16, sbytes - s16, hipMemcpyDeviceToHost, b->copy_out));
+  return pull_epilogue(b);
+}
+
+int kq_bank_pull_wait(kq_bank *b, unsigned lag) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  if (!b) return -1;
+  if (lag >= (unsigned)kq_bank::kPullRing) {
+    set_err("kq_bank_pull_wait: lag %u, at most %d deliveries are remembered", lag, kq_bank::kPullRing - 1);
+    return -1;
+  }
+  if (b->pulls <= lag) return 0;  // nothing that far back was ever queued
+  HIP_TRY(hipEventSynchronize(b->pull_done[(b->pulls - 1 - lag) % kq_bank::kPullRing]));
+  return report_lost_sibling(b);
 }
 
 int kq_bank_host_io_wait(kq_bank *b) {
@@ -2042,6 +2390,13 @@ int kq_bank_get_timing(kq_bank *b, kq_timing *t, int reset) {
   if (drain_timing(b)) return -1;
   *t = b->acc;
   if (reset) b->acc = kq_timing{};
+  return 0;
+}
+
+int kq_bank_get_host_timing(kq_bank *b, kq_host_timing *t, int reset) {
+  if (!b || !t) return -1;
+  *t = b->host_acc;
+  if (reset) b->host_acc = kq_host_timing{};
   return 0;
 }
 

@@ -832,8 +832,13 @@ void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Plane
   if (g.olen == 32) {
     int const wgs = n_fm + n_am + n_lin;
     if (wgs == 0) return;
-    // KQ_DEMOD_ONE_WAVE=1: the one-wave forms of the FM and AM demodulators (A/B switch)
-    static bool const one_wave = getenv("KQ_DEMOD_ONE_WAVE") && atoi(getenv("KQ_DEMOD_ONE_WAVE")) != 0;
+    // KQ_DEMOD_ONE_WAVE=1 / 0: the one-wave forms of the FM and AM demodulators always / never (A/B switch).  Otherwise by
+    // the number of channels: the multi-wave pipelines exist to fill a device that has one wave per SIMD to run (1024
+    // channels); with more than two waves' worth of channels per SIMD the one-wave forms do the same work in fewer
+    // instructions, without the LDS hand-overs and the pipeline's fill and drain (rocprofv3, 32768 channels x 2 blocks:
+    // 82 us against 157; 8192 x 8: 46 against 61; 1024 x 64: 79 against 47)
+    static int const forced = getenv("KQ_DEMOD_ONE_WAVE") ? atoi(getenv("KQ_DEMOD_ONE_WAVE")) : -1;
+    bool const one_wave = forced >= 0 ? forced != 0 : wgs > 2048;
     if (n_fm + n_am > 0 && !one_wave)
       hipLaunchKernelGGL((k_demod64<32, 256>), dim3(wgs), dim3(256), 0, s, g, ch, pl, list_fm, n_fm, list_am, n_am, list_lin,
                          n_lin, nblocks, compute_n0);

@@ -115,6 +115,8 @@ void ensure_dynamic_lds(const void *kernel, size_t bytes);
 // first status.nout, and the status plane up to its last whole 16 bytes
 void launch_copy_to_host(hipStream_t s, const float *audio, float *haudio, int row, const kq_chan_status *status, void *hstatus,
                          size_t rows);
+void launch_copy_pcm_to_host(hipStream_t s, const float *audio, short *hpcm, unsigned *hmask, int row,
+                             const kq_chan_status *status, void *hstatus, size_t rows);
 void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size_t nsamples, float scale);
 // IF power in two launches.  _sum (in front of the filter, whose row-paired samples it also writes): per-block partial
 // sums of |s|^2 into sums[nblocks * block_energy_split(L)], and the call's parameter block from `params_host` (pinned,
@@ -123,7 +125,8 @@ void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size
 constexpr int kEnergySplitMax = 16;
 int block_energy_split(int L);
 void launch_block_energy_sum(hipStream_t s, const float2 *newsamples, int L, int nblocks, float *sums, const void *params_host,
-                             void *params_dev, size_t params_bytes, float2 *paired, int hist);
+                             void *params_dev, size_t params_bytes, float2 *paired, int hist, const double *prev_planes = nullptr,
+                             unsigned nchan = 0, unsigned cmax = 0, double adv = 0, double adv_out = 0);
 void launch_block_energy_iir(hipStream_t s, const float *sums, int L, int nblocks, const unsigned char *update, float *energy_state,
                              float *if_power);
 void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,

@@ -70,10 +70,23 @@ void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size
 // (paired != null) the window's history rows.  `paired`: the samples written out once more with their 512-sample rows
 // interleaved in pairs, for k_filter_full16k's 16-byte loads (kq_full16k.hip: out[1024 r + 2 c + e] = in[512 (2 r + e)
 // + c]) -- the kernel reads every new sample anyway.  L and hist are multiples of 1024 then.
+// `prev` != null, the steady state (no oscillator has been set, no channel has come or gone since the call before): the
+// eight oscillator planes are not carried over the bus at all but ADVANCED on the device from the planes of the call
+// before -- phase(n + adv) = phase + f adv + r adv (adv - 1) / 2, f + r adv (osc.c:39-51 in closed form, as the host's
+// Osc::rebase does it), the history's oscillator = the current one, the shift oscillator advanced by adv_out output
+// samples -- and only the per-block flag bytes come from the host.  At 32768 channels the planes are 2 MiB per call and
+// took 144 us of the call's 1.6 ms to fetch over the link, 8 bytes per thread.
+__device__ __forceinline__ double frac_turns(double ph, double f, double n) {
+  // ph + f n modulo one turn: the product split exactly (hi + lo = f n to 106 bits), its whole turns dropped before the sum
+  double const hi = f * n, lo = __fma_rn(f, n, -hi);
+  double const p = ph + ((hi - floor(hi)) + lo);
+  return p - floor(p);
+}
 __global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *__restrict__ sums, int nblocks, int split,
                                    const unsigned long long *__restrict__ params_host,
                                    unsigned long long *__restrict__ params_dev, unsigned nwords, int copy_wgs,
-                                   float2 *__restrict__ paired, int hist) {
+                                   float2 *__restrict__ paired, int hist, const double *__restrict__ prev, unsigned nchan,
+                                   unsigned cmax, double adv, double adv_out) {
   int const pcol = 2 * (threadIdx.x & 511) + (threadIdx.x >> 9);  // place of sample (row parity, column) within its pair of rows
   int const nsum = nblocks * split;
   if ((int)blockIdx.x >= nsum + copy_wgs) {  // history: copy only, 8192 samples per workgroup
@@ -83,7 +96,31 @@ __global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *_
   }
   if ((int)blockIdx.x >= nsum) {
     unsigned const i = (blockIdx.x - nsum) * blockDim.x + threadIdx.x;
-    if (i < nwords) params_dev[i] = params_host[i];
+    if (!prev) {
+      if (i < nwords) params_dev[i] = params_host[i];
+      return;
+    }
+    if (i < nchan) {
+      double *out = reinterpret_cast<double *>(params_dev);
+      double const ph = prev[i], f = prev[cmax + i], r = prev[2 * (size_t)cmax + i];
+      double const sp = prev[3 * (size_t)cmax + i], sf = prev[4 * (size_t)cmax + i];
+      double p = frac_turns(ph, f, adv);
+      if (r != 0.0) {
+        p += r * (0.5 * adv * (adv - 1.0));
+        p -= floor(p);
+      }
+      double const f2 = f + r * adv;
+      out[i] = p;
+      out[cmax + i] = f2;
+      out[2 * (size_t)cmax + i] = r;
+      out[3 * (size_t)cmax + i] = frac_turns(sp, sf, adv_out);
+      out[4 * (size_t)cmax + i] = sf;
+      out[5 * (size_t)cmax + i] = p;
+      out[6 * (size_t)cmax + i] = f2;
+      out[7 * (size_t)cmax + i] = r;
+    } else if (i - nchan < nwords - 8 * cmax) {  // the per-block flags behind the planes
+      params_dev[8 * (size_t)cmax + (i - nchan)] = params_host[8 * (size_t)cmax + (i - nchan)];
+    }
     return;
   }
   __shared__ float red_f[16];
@@ -157,14 +194,17 @@ int block_energy_split(int L) {
 }
 
 void launch_block_energy_sum(hipStream_t s, const float2 *newsamples, int L, int nblocks, float *sums, const void *params_host,
-                             void *params_dev, size_t params_bytes, float2 *paired, int hist) {
+                             void *params_dev, size_t params_bytes, float2 *paired, int hist, const double *prev_planes,
+                             unsigned nchan, unsigned cmax, double adv, double adv_out) {
   unsigned const nwords = (unsigned)((params_bytes + 7) / 8);
-  int const copy_wgs = (int)((nwords + 1023) / 1024);
+  // steady state: one thread per channel advances its planes, then the flag words behind the planes are copied
+  unsigned const work = prev_planes ? nchan + (nwords - 8 * cmax) : nwords;
+  int const copy_wgs = (int)((work + 1023) / 1024);
   int const hist_wgs = paired ? (hist + 8191) / 8192 : 0;
   int const split = block_energy_split(L);
   hipLaunchKernelGGL(k_block_energy_sum, dim3(nblocks * split + copy_wgs + hist_wgs), dim3(1024), 0, s, newsamples, L, sums, nblocks,
                      split, static_cast<const unsigned long long *>(params_host), static_cast<unsigned long long *>(params_dev),
-                     nwords, copy_wgs, paired, hist);
+                     nwords, copy_wgs, paired, hist, prev_planes, nchan, cmax, adv, adv_out);
 }
 
 void launch_block_energy_iir(hipStream_t s, const float *sums, int L, int nblocks, const unsigned char *update, float *energy_state,
@@ -214,6 +254,65 @@ void launch_copy_to_host(hipStream_t s, const float *audio, float *haudio, int r
   static int const forced = getenv("KQ_COPY_WGS") ? atoi(getenv("KQ_COPY_WGS")) : 0;  // diagnostic (tools/ab_env_hostio.sh)
   if (forced > 0) wgs = (unsigned)forced;
   hipLaunchKernelGGL(k_copy_to_host, dim3(wgs), dim3(256), 0, s, audio, haudio, row, status, (u32x4 *)hstatus, rows,
+                     rows * sizeof(kq_chan_status) / 16);
+}
+
+// The same delivery in the reference's own output format: float -> clipped int16 in network byte order (scaleclip,
+// audio.c:22-28; htons at audio.c:48,98 -- the arithmetic of k_pcm below) on the way out, half the bytes over the link.
+// 16 lanes take one row, 8 words (two 16-byte loads, one 16-byte store) per lane and trip; 480 = 60 x 8, so a lane's 8
+// words never straddle one of the 480-word chunks whose all-zero test decides whether the reference sends the packet
+// (audio.c:49,99,105): mask bit k = chunk k of the row is all zero.
+__device__ __forceinline__ unsigned pcm_word_be(float x) {
+  int v;
+  if (x >= 1.0f)
+    v = 32767;
+  else if (x <= -1.0f)
+    v = -32768;
+  else
+    v = (int)(32767.f * x);  // truncation, as the (short) cast of audio.c:27
+  unsigned const h = (unsigned)v & 0xffffu;
+  return ((h << 8) | (h >> 8)) & 0xffffu;
+}
+__global__ void __launch_bounds__(256) k_copy_pcm_to_host(const float *__restrict__ audio, short *__restrict__ hpcm,
+                                                          unsigned *__restrict__ hmask, int row,
+                                                          const kq_chan_status *__restrict__ status, u32x4 *__restrict__ hstatus,
+                                                          size_t rows, size_t status16) {
+  size_t const stride = (size_t)gridDim.x * blockDim.x;
+  size_t const tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int const sub = (int)(tid & 15);
+  for (size_t r = tid >> 4; r < rows; r += stride >> 4) {
+    int const n = min(status[r].nout, row);
+    const float *src = audio + r * row;
+    short *dst = hpcm + r * row;
+    unsigned nonzero = 0;  // bit k: this lane saw a non-zero word in chunk k
+    for (int i = 8 * sub; i < n; i += 128) {  // row and nout are multiples of 8 here (the caller checks)
+      float4 const a = *reinterpret_cast<const float4 *>(src + i), c = *reinterpret_cast<const float4 *>(src + i + 4);
+      u32x4 v;
+      v.x = pcm_word_be(a.x) | (pcm_word_be(a.y) << 16);
+      v.y = pcm_word_be(a.z) | (pcm_word_be(a.w) << 16);
+      v.z = pcm_word_be(c.x) | (pcm_word_be(c.y) << 16);
+      v.w = pcm_word_be(c.z) | (pcm_word_be(c.w) << 16);
+      if ((v.x | v.y | v.z | v.w) != 0) nonzero |= 1u << (i / 480);
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst + i));
+    }
+    // (the 16 lanes of a row run the same number of trips +-1 and meet again here: rows are handed out 16 lanes at a time)
+    for (int m = 1; m < 16; m <<= 1) nonzero |= __shfl_xor(nonzero, m, 16);
+    if (sub == 0 && hmask) {
+      int const chunks = (n + 479) / 480;
+      hmask[r] = ~nonzero & (chunks >= 32 ? 0xffffffffu : ((1u << chunks) - 1u));
+    }
+  }
+  const u32x4 *sp = reinterpret_cast<const u32x4 *>(status);
+  if (hstatus)
+    for (size_t i = tid; i < status16; i += stride) __builtin_nontemporal_store(sp[i], hstatus + i);
+}
+void launch_copy_pcm_to_host(hipStream_t s, const float *audio, short *hpcm, unsigned *hmask, int row,
+                             const kq_chan_status *status, void *hstatus, size_t rows) {
+  size_t const bytes = rows * ((size_t)row * sizeof(short) + 4 + (hstatus ? sizeof(kq_chan_status) : 0));
+  unsigned wgs = (unsigned)std::min<size_t>(64, std::max<size_t>(4, (bytes + (2u << 20) - 1) >> 21));
+  static int const forced = getenv("KQ_COPY_WGS") ? atoi(getenv("KQ_COPY_WGS")) : 0;
+  if (forced > 0) wgs = (unsigned)forced;
+  hipLaunchKernelGGL(k_copy_pcm_to_host, dim3(wgs), dim3(256), 0, s, audio, hpcm, hmask, row, status, (u32x4 *)hstatus, rows,
                      rows * sizeof(kq_chan_status) / 16);
 }
 

@@ -1,0 +1,118 @@
+"""Channels at 1.0 x real time on one GPU, MEASURED (BASELINE.json's "channels @ real-time").
+
+The reference's operating point is one `radio` process per channel, each at the front end's rate (main.c:105,
+README.md:470-477).  Here: C channels of one bank, a small batch of B blocks per call (B = 2 at cfg 4's geometry: 1.64 ms
+of signal), every batch fed from pinned host memory and every channel's audio + status handed back to pinned host memory
+after every call.  What scales with C rather than with C x B is exercised here and nowhere else: the per-call oscillator
+parameters of every channel, the demodulator grid, the status plane, several GB/s of audio leaving the GPU.
+
+Used by bench.py (the `realtime` object of the N = 1 line), tools/realtime_probe.py and tests/test_gpu_realtime.py.
+"""
+import ctypes
+import time
+
+import numpy as np
+
+
+def build_bank(kq, wl, config, C, B, dev_index, stream, compute_n0=True):
+    """A bank of C channels of `config`'s plan with room for B blocks per call; returns (bank, plan, set-up seconds)."""
+    geom = dict(wl.GEOMETRY[config])
+    L, M, D, fs = geom["L"], geom["M"], geom["D"], geom["samprate"]
+    plan = wl.channel_plan(config, C)
+    t0 = time.perf_counter()
+    bank = kq.Bank(fs, L, M, D, C, B, device=dev_index, compute_n0=compute_n0, fwd_mode=kq.KQ_FWD_AUTO,
+                   stream=stream.cuda_stream if stream is not None else None, pl_tone=False)
+    bank.add_channels([wl.bank_channel_config(p) for p in plan])
+    bank.sync()
+    return bank, plan, time.perf_counter() - t0
+
+
+def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.0, host_io=True, pcm=False, warm_calls=50):
+    """C channels, B blocks per call, for `seconds` of wall time.  host_io: input from pinned host memory, audio (float, or
+    the int16 PCM words when pcm) + status planes to pinned host memory after every call into one of three buffer sets; the
+    host waits for the planes of call k-2 once it has queued call k (it never runs more than two deliveries ahead of what it
+    has in hand, so a buffer set is never overwritten before it has landed)."""
+    geom = dict(wl.GEOMETRY[config])
+    L, M, D, fs = geom["L"], geom["M"], geom["D"], geom["samprate"]
+    olen = L // D
+    bank, plan, setup_s = build_bank(kq, wl, config, C, B, dev_index, stream)
+    dev = torch.device("cuda", dev_index)
+    nwin = (M - 1) + B * L
+    iq_host = wl.make_iq(fs, nwin, seed=0x6B613971)
+    out_bytes = 0
+    if host_io:
+        iq_pin = torch.from_numpy(np.ascontiguousarray(iq_host[M - 1:])).pin_memory()
+        nbuf = 3
+        if pcm:
+            outs = [torch.zeros(C * B * 2 * olen, dtype=torch.int16).pin_memory() for _ in range(nbuf)]
+            masks = [torch.zeros(C * B, dtype=torch.int32).pin_memory() for _ in range(nbuf)]
+        else:
+            outs = [torch.zeros(C * B * 2 * olen, dtype=torch.float32).pin_memory() for _ in range(nbuf)]
+        stats = [torch.zeros(C * B * ctypes.sizeof(kq.ChanStatus), dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
+        nout_words = sum((2 if p.get("channels", 1) == 2 else 1) * olen for p in plan) * B
+        out_bytes = nout_words * (2 if pcm else 4) + stats[0].numel() + (4 * C * B if pcm else 0)
+
+        def call(k):
+            assert bank.process() == B
+            bank.push_iq_async(iq_pin.data_ptr(), B * L)
+            j = k % nbuf
+            if pcm:
+                bank.pull_pcm_planes_async(outs[j].data_ptr(), masks[j].data_ptr(), stats[j].data_ptr())
+            else:
+                bank.pull_planes_async(outs[j].data_ptr(), stats[j].data_ptr())
+            bank.pull_wait(2)     # the planes of call k-2 are in host memory now; calls k-1 and k are in flight
+
+        bank.push_iq_async(iq_pin.data_ptr(), B * L)
+    else:
+        iq_dev = torch.from_numpy(iq_host).to(dev)
+
+        def call(k):
+            bank.process_resident(iq_dev.data_ptr(), B)
+
+    def run(ncalls, k0):
+        for k in range(k0, k0 + ncalls):
+            call(k)
+
+    run(warm_calls, 0)
+    if host_io:
+        bank.host_io_wait()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(8, warm_calls)
+    if host_io:
+        bank.host_io_wait()
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - t0) / 8
+    ncalls = int(max(16, min(400000, seconds / max(est, 1e-6))))
+    bank.host_timing(reset=True)
+    bank.enable_timing(1)
+    bank.timing(reset=True)
+    t0 = time.perf_counter()
+    run(ncalls, warm_calls + 8)
+    if host_io:
+        bank.host_io_wait()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / ncalls
+    ht = bank.host_timing(reset=True)
+    tm = bank.timing(reset=True)
+    bank.enable_timing(0)
+    checksum = None
+    if host_io:
+        j = (warm_calls + 8 + ncalls - 1) % nbuf
+        st = np.frombuffer(stats[j].numpy().tobytes(), dtype=kq.bank.STATUS_DTYPE).reshape(C, B)
+        a = outs[j].numpy().reshape(C, B, 2 * olen)
+        checksum = {"nout_sum": int(st["nout"].sum()), "squelch_open": int((st["squelch_count"] < 2).sum()),
+                    "audio_abs_sum": float(np.abs(a[::max(1, C // 997), :, :olen].astype(np.float64)).sum())}
+    bank.close()
+    signal_s = B * L / fs
+    return {"config": config, "channels": C, "blocks_per_call": B, "signal_ms_per_call": round(signal_s * 1e3, 4),
+            "ms_per_call": round(dt * 1e3, 4), "realtime_factor": round(signal_s / dt, 4), "calls": ncalls,
+            "wall_s": round(dt * ncalls, 2),
+            "filter_kernel_ms": round(tm["filter_ms"] / max(1, tm["filter_launches"]), 4),
+            "host_ms_per_call": round(ht["call_ms"] / max(1, ht["calls"]), 4),
+            "host_stage_ms_per_call": round(ht["stage_ms"] / max(1, ht["calls"]), 4),
+            "host_slot_wait_ms_per_call": round(ht["slot_wait_ms"] / max(1, ht["calls"]), 4),
+            "host_io": ("pcm int16 + status" if pcm else "float audio + status") if host_io else None,
+            "d2h_bytes_per_call": out_bytes, "d2h_GBps": round(out_bytes / dt / 1e9, 3),
+            "h2d_bytes_per_call": B * L * 8 if host_io else 0,
+            "setup_s": round(setup_s, 2), "check": checksum}

@@ -1,0 +1,277 @@
+"""The reference's operating point -- every channel at 1.0 x the front end's rate (main.c:105, README.md:470-477) -- as one
+bank of tens of thousands of channels fed in small batches: what scales with the number of channels rather than with
+channels x blocks.
+
+* 32768 channels of cfg 4's geometry, two blocks per call, three calls through the streaming host I/O; every 64th channel
+  against the oracle, sample counts and squelch state of ALL channels exact.
+* kq_bank_add_channels against kq_bank_add_channel, channel by channel: bit-identical.
+* the steady-state path (per-call oscillator planes advanced on the device) against per-call staging on the host, with
+  sweeps, shifts and a retune on the way.
+* kq_bank_pull_pcm_planes_async against the PCM stage of kq_bank_enable_pcm / the oracle's scaleclip.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch   # before the HIP library is loaded: both then share one HIP runtime (as tests/test_gpu_fanout.py)
+
+import ka9q_sdr_amd as kq
+from common import bank_cfg, rel_rms, run_oracle
+from ka9q_sdr_amd import workload as wl
+from ka9q_sdr_amd.bank import STATUS_DTYPE
+from test_gpu_parity import AUDIO_TOL, FILT_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _pinned(n, dtype):
+    return torch.zeros(n, dtype=dtype).pin_memory()
+
+
+def test_32768_channels_two_blocks_per_call_against_the_oracle(gpu):
+    g = wl.GEOMETRY["cfg4"]
+    fs, L, M, D = g["samprate"], g["L"], g["M"], g["D"]
+    olen = L // D
+    C, B, ncalls, every = 32768, 2, 3, 64
+    plan = wl.channel_plan("cfg4", C)
+    iq = wl.make_iq(fs, ncalls * B * L, seed=0x6B62)
+    sampled = list(range(0, C, every))
+    want = run_oracle([plan[c] for c in sampled], g, iq, ncalls * B, compute_n0=1)
+
+    bank = kq.Bank(fs, L, M, D, C, B, compute_n0=True, fwd_mode=kq.KQ_FWD_AUTO, pl_tone=False)
+    idx = bank.add_channels([bank_cfg(p) for p in plan])
+    assert idx == list(range(C)) and bank.num_channels == C
+    iq_pin = torch.from_numpy(iq.copy()).pin_memory()
+    audio = [_pinned(C * B * 2 * olen, torch.float32) for _ in range(ncalls)]
+    stat = [_pinned(C * B * ctypes.sizeof(kq.ChanStatus), torch.uint8) for _ in range(ncalls)]
+    filt = {c: [] for c in sampled}
+    bank.push_iq_async(iq_pin.data_ptr(), B * L)
+    for k in range(ncalls):
+        assert bank.process() == B
+        if k + 1 < ncalls:
+            bank.push_iq_async(iq_pin.data_ptr() + 8 * (k + 1) * B * L, B * L)
+        bank.pull_planes_async(audio[k].data_ptr(), stat[k].data_ptr())
+        bank.pull_wait(0)
+        for c in sampled[::8]:          # the filter output of a few of them (a synchronous pull each)
+            for b in range(B):
+                filt[c].append(bank.filter_output(c, b))
+    bank.host_io_wait()
+    ht = bank.host_timing()
+    assert ht["calls"] == ncalls
+    bank.close()
+
+    st = [np.frombuffer(s.numpy().tobytes(), dtype=STATUS_DTYPE).reshape(C, B) for s in stat]
+    au = [a.numpy().reshape(C, B, 2 * olen) for a in audio]
+    # counts / indices on ALL channels: every block delivers olen samples; the squelch state is the one the oracle finds
+    # on the sampled channels (all of them listen to an emitter 45 dB above the noise: one value per block)
+    for k in range(ncalls):
+        assert np.all(st[k]["nout"] == olen)
+        for b in range(B):
+            sq = {want[i][1][k * B + b]["squelch_count"] for i in range(len(sampled))}
+            assert len(sq) == 1, sq
+            assert np.all(st[k]["squelch_count"][:, b] == sq.pop()), (k, b)
+            assert np.all(np.isfinite(st[k]["n0"][:, b])) and np.all(st[k]["n0"][:, b] > 0)
+            assert np.all(st[k]["if_power"][:, b] == st[k]["if_power"][0, b])     # one front end: one IF power
+    # every 64th channel against the oracle
+    worst_a = worst_f = worst_n0 = 0.0
+    ties = []
+    for i, c in enumerate(sampled):
+        auds, sts, filts = want[i]
+        got = np.concatenate([au[k][c, b, :olen] for k in range(ncalls) for b in range(B)])
+        ea = rel_rms(got, np.concatenate(auds))
+        worst_a = max(worst_a, ea)
+        assert ea < AUDIO_TOL, ("audio", c, ea)
+        for k in range(ncalls):
+            for b in range(B):
+                s, w = st[k][c, b], sts[k * B + b]
+                assert s["blanked"] == w["blanked"] and s["squelch_count"] == w["squelch_count"], (c, k, b)
+                np.testing.assert_allclose(s["bb_power"], w["bb_power"], rtol=1e-5)
+                np.testing.assert_allclose(s["if_power"], w["if_power"], rtol=1e-4)
+                dn0 = abs(s["n0"] / w["n0"] - 1)
+                if dn0 > 2e-4:           # a bin at compute_n0's 2 x mean cut (radio.c:414-420): counted, bounded
+                    assert dn0 < 5e-3, ("n0", c, k, b, dn0)
+                    ties.append((c, "n0", dn0))
+                else:
+                    worst_n0 = max(worst_n0, dn0)
+        if filt[c]:
+            ef = rel_rms(np.concatenate(filt[c]), np.concatenate(filts))
+            worst_f = max(worst_f, ef)
+            assert ef < FILT_TOL, ("filter", c, ef)
+    assert len({t[0] for t in ties}) <= max(2, 0.01 * len(sampled)), ties
+    import conftest
+    conftest.note_ties("test_32768_channels_two_blocks_per_call_against_the_oracle", ties, len(sampled))
+    print("worst audio %.2g filter %.2g n0 %.2g over %d channels" % (worst_a, worst_f, worst_n0, len(sampled)))
+
+
+def _mixed_plan(fs, n):
+    rng = np.random.default_rng(77)
+    plan = []
+    for c in range(n):
+        e = int(rng.integers(24, 40))
+        p = dict(wl._mode_params(wl.emitter_kind(e), e))
+        p.update(second_lo=-(wl.emitter_freq(e, fs) + float(rng.uniform(-40, 40))), kaiser_beta=float(rng.choice([2.0, 3.0])),
+                 headroom=wl.HEADROOM, channels=1, flat=0, isb=0, shift=0.0, doppler=0.0, doppler_rate=0.0)
+        if p["demod"] == "fm" and c % 3 == 0:
+            p["flat"] = 1
+        if p["demod"] == "linear":
+            if c % 2:
+                p.update(isb=1, channels=2, low=-3000.0, high=3000.0)
+            if c % 5 == 0:
+                p["shift"] = 300.0
+        plan.append(p)
+    return plan
+
+
+def _pull_all(bank, C, nb):
+    return ([[bank.audio(c, b) for b in range(nb)] for c in range(C)], [[bank.status(c, b) for b in range(nb)] for c in range(C)])
+
+
+def test_batched_add_is_the_same_as_adding_one_by_one(gpu):
+    g = dict(samprate=192000, L=512, M=513, D=4)
+    fs, L = g["samprate"], g["L"]
+    plan = _mixed_plan(fs, 40)
+    nb = 4
+    iq = wl.make_iq(fs, 2 * nb * L, seed=5, emitters=range(24, 40))
+    res = []
+    for batched in (False, True):
+        bank = kq.Bank(fs, L, g["M"], g["D"], len(plan) + 3, nb, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL)
+        if batched:
+            assert bank.add_channels([bank_cfg(p) for p in plan[:5]]) == list(range(5))
+            assert bank.add_channels([bank_cfg(p) for p in plan[5:]]) == list(range(5, len(plan)))   # appended behind the first lot
+        else:
+            for p in plan:
+                bank.add_channel(bank_cfg(p))
+        out = []
+        for k in range(2):
+            bank.push_iq(iq[k * nb * L:(k + 1) * nb * L])
+            assert bank.process() == nb
+            out.append(_pull_all(bank, len(plan), nb))
+        resp = [bank.response(c) for c in range(len(plan))]
+        res.append((out, resp))
+        if batched:     # all or nothing: a bad entry adds none, a batch beyond the capacity adds none
+            bad = [bank_cfg(plan[0]), bank_cfg(plan[1]), bank_cfg(plan[2]), bank_cfg(plan[3])]
+            bad[2].low = float("nan")
+            with pytest.raises(kq.KqError):
+                bank.add_channels(bad)
+            with pytest.raises(kq.KqError):
+                bank.add_channels([bank_cfg(plan[0])] * 4)
+            assert bank.num_channels == len(plan)
+            bank.remove_channel(7)          # with a hole the batch goes one by one and reuses it
+            assert bank.add_channels([bank_cfg(plan[7]), bank_cfg(plan[8])]) == [7, len(plan)]
+        bank.close()
+    (a, ra), (b, rb) = res
+    for c in range(len(plan)):
+        assert np.array_equal(ra[c], rb[c]), c
+        for k in range(2):
+            for blk in range(nb):
+                assert np.array_equal(a[k][0][c][blk], b[k][0][c][blk]), (c, k, blk)
+                sa, sb = a[k][1][c][blk], b[k][1][c][blk]
+                for key in sa:
+                    assert sa[key] == sb[key] or (np.isnan(sa[key]) and np.isnan(sb[key])), (c, k, blk, key)
+
+
+@pytest.mark.parametrize("geom", ["n1024", "cfg4", "cfg5"])
+def test_steady_state_planes_advanced_on_the_device(gpu, geom):
+    """A call that follows a call with nothing set in between takes its oscillator planes from the device (advanced in
+    closed form by k_block_energy_sum) instead of from the host.  Same audio as a bank whose every call is staged by the
+    host (forced by re-setting one channel's shift to the value it has), through sweeps, shifts, a retune and a channel
+    leaving; integer state identical."""
+    if geom == "n1024":
+        g = dict(samprate=192000, L=512, M=513, D=4)
+        plan = _mixed_plan(g["samprate"], 12)
+        emit = range(24, 40)
+    else:
+        g = wl.GEOMETRY[geom]
+        plan = wl.channel_plan(geom, 24)
+        emit = None
+    fs, L = g["samprate"], g["L"]
+    for c, p in enumerate(plan):                  # sweeps on a third of them (per-sample variant of the kernels)
+        if geom != "cfg5" and c % 3 == 1:
+            p.update(doppler=1500.0 + 10 * c, doppler_rate=-300.0 * (c + 1))
+            p["second_lo"] += p["doppler"]
+    nb, ncalls = 2, 9
+    iq = wl.make_iq(fs, ncalls * nb * L, seed=9, emitters=emit)
+    outs = []
+    for forced in (False, True):
+        bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), nb, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL, pl_tone=False)
+        bank.add_channels([bank_cfg(p) for p in plan])
+        got = []
+        for k in range(ncalls):
+            if forced:
+                bank.set_shift(0, plan[0].get("shift", 0.0))       # no change of any sequence: the phase is kept (osc.c:24-27)
+            if k == 4:
+                bank.set_second_lo(2, plan[2]["second_lo"] + 750.0)  # a retune on the way: its first block keeps the old LO in the history
+            if k == 6:
+                bank.remove_channel(5)
+            bank.push_iq(iq[k * nb * L:(k + 1) * nb * L])
+            assert bank.process() == nb
+            live = [c for c in range(len(plan)) if bank.channel_active(c)]
+            got.append({c: ([bank.audio(c, b) for b in range(nb)], [bank.status(c, b) for b in range(nb)]) for c in live})
+        ht = bank.host_timing()
+        outs.append((got, ht))
+        bank.close()
+    (a, ha), (b, hb) = outs
+    assert ha["calls"] == hb["calls"] == ncalls
+    for k in range(ncalls):
+        assert a[k].keys() == b[k].keys()
+        for c in a[k]:
+            for blk in range(nb):
+                x, y = a[k][c][0][blk], b[k][c][0][blk]
+                assert len(x) == len(y)
+                if np.abs(y).max() > 0:
+                    # a linear channel's first block divides by numerically-zero start-up samples (linear.c:271-272)
+                    tol = 2e-3 if (k == 0 and blk == 0 and plan[c]["demod"] == "linear") else 2e-6
+                    assert rel_rms(x, y) < tol, (k, c, blk, rel_rms(x, y))
+                sa, sb = a[k][c][1][blk], b[k][c][1][blk]
+                for key in ("nout", "squelch_count", "hangcount", "blanked"):
+                    assert sa[key] == sb[key], (k, c, blk, key)
+
+
+def test_pcm_planes_straight_to_the_host(gpu):
+    """kq_bank_pull_pcm_planes_async: the words and silent-chunk masks of the PCM stage (audio.c:22-28, 45-50, 95-100)
+    formed inside the copy kernel -- equal to kq_bank_pull_pcm's (the k_pcm stage) and to the oracle's scaleclip on the
+    same device audio; a loud channel that clips, a stereo channel, a channel that squelches."""
+    import kq_oracle as ko
+    g = dict(samprate=192000, L=2048, M=2049, D=4)        # olen = 512: chunks of 480 + 32 (mono), 480 + 480 + 64 (stereo)
+    fs, L = g["samprate"], g["L"]
+    olen = L // g["D"]
+    nb = 8
+    t = np.arange(nb * L) / fs
+    sig = 0.2 * np.exp(1j * (2 * np.pi * 20000.0 * t + 3.0 * np.sin(2 * np.pi * 1000.0 * t)))
+    sig[4 * L:] = 0                                         # the carrier drops: squelch closes, audio becomes exact zeros
+    rng = np.random.default_rng(8)
+    iq = (sig + 1e-4 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    plan = [dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-20000.0, headroom=30.0),   # loud: clips
+            dict(demod="linear", low=-5000.0, high=5000.0, second_lo=-20000.0, hangtime=1.1, recovery_rate=6.0, channels=2),
+            dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-20000.0)]
+    C = len(plan)
+    bank = kq.Bank(fs, L, g["M"], g["D"], C, nb, fwd_mode=kq.KQ_FWD_FULL)
+    bank.enable_pcm(True)
+    for p in plan:
+        bank.add_channel(bank_cfg(p))
+    bank.push_iq(iq)
+    assert bank.process() == nb
+    pcm = _pinned(C * nb * 2 * olen, torch.int16)
+    mask = _pinned(C * nb, torch.int32)
+    stat = _pinned(C * nb * ctypes.sizeof(kq.ChanStatus), torch.uint8)
+    bank.pull_pcm_planes_async(pcm.data_ptr(), mask.data_ptr(), stat.data_ptr())
+    bank.pull_wait(0)
+    words = pcm.numpy().reshape(C, nb, 2 * olen)
+    masks = mask.numpy().view(np.uint32).reshape(C, nb)
+    st = np.frombuffer(stat.numpy().tobytes(), dtype=STATUS_DTYPE).reshape(C, nb)
+    clipped = silent = 0
+    for c in range(C):
+        for b in range(nb):
+            a = bank.audio(c, b)
+            stage, smask = bank.pcm(c, b)
+            want, wmask, _ = ko.pcm_block(a)
+            n = len(a)
+            assert st[c, b]["nout"] == n
+            assert np.array_equal(words[c, b, :n], want) and np.array_equal(stage, want), (c, b)
+            assert int(masks[c, b]) == wmask == smask, (c, b, masks[c, b], wmask)
+            clipped += int(np.sum(np.abs(a) >= 1.0))
+            silent += bin(wmask).count("1")
+    assert clipped > 0 and silent > 0
+    with pytest.raises(kq.KqError):
+        bank.pull_wait(8)               # only the last eight deliveries are remembered
+    bank.close()

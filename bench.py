@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--no-rows", action="store_true",
                     help="skip the `rows` object: BASELINE.json's other single-GPU shapes (cfg2, cfg3, cfg5 per-GPU share), each "
                          "with 2 s of spin-up and 20 timed steps (only measured at N = 1 on the default workload)")
+    ap.add_argument("--no-realtime", action="store_true",
+                    help="skip the `realtime` object: the largest channel count one GPU carries at 1.0 x real time, measured "
+                         "(cfg 4 geometry, 2 blocks per call, host I/O every call; about 25 s)")
+    ap.add_argument("--realtime-seconds", type=float, default=10.0, help="length of the run that has to hold real time")
     ap.add_argument("--gpu-state", action="store_true",
                     help="sample shader clock and power at 50 Hz over the spin-up steps (disturbs the timed steps by about 1 %%)")
     return ap.parse_args()
@@ -306,6 +310,42 @@ def measure_row(torch, kq, wl, config, blocks, dev_index, stream, pci_bus, spin_
             "realtime_factor": round(blocks * L / dt / fs, 2), "gpu_state": state}
 
 
+def measure_channels_at_realtime(torch, kq, wl, dev_index, stream, seconds):
+    """BASELINE.json's "channels @ real-time", measured instead of extrapolated: the reference's operating
+    point is every channel at 1.0 x the front end's rate (one `radio` per channel, main.c:105, README.md:470-477).  cfg 4's
+    geometry (N = 16384, D = 256, 10 MS/s, FM, compute_n0 on), ONE bank of C channels on this GPU, two blocks per call
+    (1.64 ms of signal), the batch from pinned host memory and every channel's audio + status to pinned host memory after
+    every call (kq_bank_push_iq_async / kq_bank_pull_planes_async / kq_bank_pull_wait: the host never runs more than two
+    deliveries ahead).  A first short run at 32768 channels places the candidate; the candidate then has to hold
+    realtime_factor >= 1.0 over `seconds` of wall time (else it is lowered by 2 % and tried again).  Then the same C with
+    the int16 PCM plane (the reference's real output format, audio.c:22-28) instead of float audio, and with four blocks
+    per call."""
+    from ka9q_sdr_amd.realtime import measure_realtime
+    trials = []
+    probe = measure_realtime(torch, kq, wl, "cfg4", 32768, 2, dev_index, stream, seconds=1.5)
+    trials.append(probe)
+    C = int(32768 * probe["realtime_factor"] * 0.995) // 256 * 256
+    best = None
+    for _ in range(4):
+        r = measure_realtime(torch, kq, wl, "cfg4", C, 2, dev_index, stream, seconds=seconds)
+        trials.append(r)
+        if r["realtime_factor"] >= 1.0:
+            best = r
+            break
+        C = int(C * min(0.98, r["realtime_factor"] * 0.995)) // 256 * 256
+    out = {"definition": "largest channel count of ONE bank on one GPU whose measured realtime_factor (signal time / wall time) "
+                         "stayed >= 1.0 over the run: cfg4 geometry (N=16384, decimate 256, 10 MS/s, FM, compute_n0=1), 2 blocks "
+                         "(1.64 ms of signal) per call, input from pinned host memory, audio + status of every channel to pinned "
+                         "host memory every call",
+           "channels": best["channels"] if best else 0, "held_seconds": best["wall_s"] if best else 0.0,
+           "float_audio": best, "trials": [{k: t[k] for k in ("channels", "blocks_per_call", "realtime_factor", "wall_s")} for t in trials]}
+    if best:
+        out["pcm_int16"] = measure_realtime(torch, kq, wl, "cfg4", best["channels"], 2, dev_index, stream, seconds=min(4.0, seconds), pcm=True)
+        out["four_blocks_per_call"] = measure_realtime(torch, kq, wl, "cfg4", best["channels"], 4, dev_index, stream,
+                                                       seconds=min(4.0, seconds))
+    return out
+
+
 # The fan-out's broadcast is 4.3 MB per step on a side stream beside the filter kernel.  What an RCCL-shaped kernel there costs
 # the step was measured with a stand-in on one GPU (tools/bcast_probe.py, profiles/r04/bcast_side_kernel_probe.txt): 1 to 64
 # workgroups of 256 threads, resident for up to 400 us, cost 0.2-2.5 % (cfg 4) and 2-3.5 % (cfg 5), of which ~1 % is the two
@@ -394,7 +434,11 @@ def main():
         bufs[1].copy_(bufs[0])
     # Front-end fan-out (the reference's UDP multicast, multicast.c:143-237): rank 0 -> all over RCCL,
     # double buffered on a side stream so batch k+1 travels while batch k is processed
-    use_c = a.fanout == "c" and (world == 1 or a.backend == "nccl")
+    # The C fan-out holds its own RCCL communicator, whatever backend torch.distributed runs on: the process group only
+    # carries the 128-byte identifier and the ranks' agreement.  (Two ranks sharing one GPU -- `--backend gloo` on a one-GPU
+    # box -- are refused by RCCL inside kq_fanout_create, on every rank: that run exercises the fall-back to the torch twin.)
+    use_c = a.fanout == "c"
+    tdev = dev if a.backend == "nccl" else torch.device("cpu")     # where the process group wants its tensors
     fan_error = None
     if use_c:
         import ctypes
@@ -409,12 +453,12 @@ def main():
 
         fan, fan_error = None, None
         try:
-            ident = share_unique_id(make_id, rank, 0, dist, dev) if world > 1 else None
+            ident = share_unique_id(make_id, rank, 0, dist, tdev) if world > 1 else None
             fan = CFanout(lib, dev_index, rank, world, nwin, ident)     # collective: every rank is here
         except Exception as e:                                            # e.g. librccl refusing the topology
             fan_error = "%s: %s" % (type(e).__name__, e)
         if world > 1:      # all ranks take the same road: one failure sends everybody to the torch twin (said in the line)
-            flag = torch.tensor([1 if fan is None else 0], device=dev, dtype=torch.int32)
+            flag = torch.tensor([1 if fan is None else 0], device=tdev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             if int(flag.item()):
                 if fan is not None:
@@ -468,7 +512,7 @@ def main():
         est_ms = max(1e-3, min(cold[1:]))
         spin = 2 * int(min(400000, a.spinup_seconds * 1e3 / est_ms) // 2)
         if dist:
-            cnt = torch.tensor([spin], device=dev, dtype=torch.int64)
+            cnt = torch.tensor([spin], device=tdev, dtype=torch.int64)
             dist.broadcast(cnt, src=0)
             spin = int(cnt.item())
     # Clocks and power: by default ONE reading, taken by a side thread during the last quarter of the timed steps.  Every read of the hwmon files is a query to
@@ -516,7 +560,6 @@ def main():
     elapsed_local = elapsed
     rank_ms = [elapsed / a.steps * 1e3] * 2      # fastest / slowest rank
     if dist:
-        tdev = dev if a.backend == "nccl" else "cpu"
         tt = torch.tensor([elapsed], device=tdev, dtype=torch.float64)
         tmin = tt.clone()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -529,25 +572,35 @@ def main():
     # the consumer stream's waits for its batch timed (two event records per acquire that has to wait), then every rank's
     # step time, filter-kernel time, broadcast time and stall time travel to rank 0.
     per_rank = None
-    if use_c and (world > 1 or a.per_rank):
-        fan.enable_timing(True)
+    if world > 1 or a.per_rank:
         nd = 40
+        if use_c:
+            fan.enable_timing(True)
         for k in range(nd):
             step(spin + a.warmup + a.steps + k)
         torch.cuda.synchronize()
-        fan.enable_timing(False)
-        fs2 = fan.stats()
+        if use_c:
+            fan.enable_timing(False)
+            fs2 = fan.stats()
+        else:      # the torch twin keeps no times of its own: step and kernel time only
+            fs2 = {"broadcast_ms": float("nan"), "broadcasts": 0, "wait_ms": float("nan"), "waits": 0, "waits_dropped": 0}
         mine = torch.tensor([elapsed_local / a.steps * 1e3, tm["filter_ms"] / max(1, tm["filter_launches"]),
                              fs2["broadcast_ms"] / max(1, fs2["broadcasts"]), float(fs2["broadcasts"]),
-                             fs2["wait_ms"] / nd, float(fs2["waits"]), float(nd)], device=dev, dtype=torch.float64)
+                             fs2["wait_ms"] / nd, float(fs2["waits"]), float(nd), float(fs2["waits_dropped"])],
+                            device=tdev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         if dist:
             dist.all_gather(allr, mine)
         else:
             allr = [mine]
-        per_rank = [{"rank": r, "ms_per_step": round(float(v[0]), 4), "kernel_ms": round(float(v[1]), 4),
-                     "bcast_ms": round(float(v[2]), 4), "bcasts_timed": int(v[3]),
-                     "wait_ms_per_step": round(float(v[4]), 4), "waits": int(v[5]), "diag_steps": int(v[6])}
+
+        def num(x, digits=4):
+            x = float(x)
+            return None if x != x else round(x, digits)
+
+        per_rank = [{"rank": r, "ms_per_step": num(v[0]), "kernel_ms": num(v[1]),
+                     "bcast_ms": num(v[2]), "bcasts_timed": int(v[3]),
+                     "wait_ms_per_step": num(v[4]), "waits": int(v[5]), "diag_steps": int(v[6]), "waits_untimed": int(v[7])}
                     for r, v in enumerate(allr)]
         a_steps_done = a.steps + nd
     else:
@@ -637,6 +690,12 @@ def main():
         for name, blocks in (("cfg2", 64), ("cfg3", 64), ("cfg5", 16)):
             rows[name] = measure_row(torch, kq, wl, name, blocks, dev_index, stream, pci_bus)
 
+    # "channels @ real-time", the second half of BASELINE.json's metric, measured (1 GPU, default workload only)
+    realtime = None
+    if world == 1 and not a.no_realtime and a.config == "cfg4" and not under_profiler:
+        bank.close()
+        realtime = measure_channels_at_realtime(torch, kq, wl, dev_index, stream, a.realtime_seconds)
+
     if rank == 0:
         total_ch = C * world
         chan_samples = total_ch * B * L * a.steps
@@ -667,6 +726,8 @@ def main():
                 "front_end_Msamples_per_s": round(front_end_msps, 2),
                 "realtime_factor": round(front_end_msps * 1e6 / fs, 2),
                 "channels_at_realtime": int(total_ch * front_end_msps * 1e6 / fs),
+                "channels_at_realtime_note": "extrapolated: channels_total x realtime_factor of this 64-blocks-per-step, HBM-resident "
+                                             "run; the MEASURED figure (one bank, 2 blocks per call, host I/O) is realtime.channels",
                 "parallelism": "channels sharded x%d, front-end I/Q broadcast over RCCL" % world if world > 1 else "1 GPU",
             },
             "roofline": roofline(k_ms, bool(a.n0), fwd_used, tm2["demod_ms"] / max(1, tm2["filter_launches"])),
@@ -681,11 +742,15 @@ def main():
                            "broadcasts": fan_stats["broadcasts"],
                            "bcast_ms": round(fan_stats["broadcast_ms"] / max(1, fan_stats["broadcasts"]), 4),
                            "bytes_per_broadcast": nwin * 8, "max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
+                           "library": (lib.kq_fanout_rccl_path() or b"").decode(),
+                           "libraries_mapped": sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln}),
                            "note": "ranks = ncclCommCount of the fan-out's communicator (0: one rank, no communicator); "
                                    "bcast_ms = HIP events around ncclBroadcast on the side stream, rank 0"}
         out["step_frac"] = round(out["roofline"]["algorithmic_bytes_per_launch"] / (elapsed / a.steps) / 8e12, 4)
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if realtime:
+            out["realtime"] = realtime
         if rows:
             out["rows"] = rows
         if host_io:

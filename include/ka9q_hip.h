@@ -118,6 +118,11 @@ typedef struct kq_timing {
 
 const char *kq_last_error(void);
 const char *kq_version(void);
+/* The structs of this header carry no size fields; the library counts their revisions instead.  A host built against
+ * this header checks kq_abi_version() == KQ_ABI_VERSION once at start-up: a mismatch means a struct (kq_bank_config,
+ * kq_fanout_info ...) has gained a field since the host was compiled. */
+#define KQ_ABI_VERSION 5
+int kq_abi_version(void);
 /* Number of visible HIP devices, or -1 when the HIP runtime cannot be initialised */
 int kq_device_count(void);
 
@@ -332,8 +337,11 @@ int kq_bank_fwd_mode(const kq_bank *bank);
  *                 id -- one thread or process per rank, all calling concurrently (one thread creating the fan-outs of
  *                 several ranks one after the other would wait on itself for ever).  A rank whose own set-up fails
  *                 (memory, stream) still enters the communicator, and the ranks then agree through a one-word
- *                 ncclAllReduce: either every rank gets its fan-out or every rank gets NULL (kq_last_error says which
- *                 side it was on).  KQ_RCCL_LIB in the environment names the librccl to dlopen.
+ *                 ncclAllReduce, issued by every rank that holds a communicator whatever else went wrong on it: either
+ *                 every rank gets its fan-out or every rank gets NULL (kq_last_error says which side it was on).
+ *                 What this cannot cover: ncclCommInitRank itself failing, or librccl missing, on a SUBSET of the ranks --
+ *                 the others then wait inside RCCL, and only the caller's own timeout ends that.
+ *                 KQ_RCCL_LIB in the environment names the librccl to dlopen.
  *                 kq_shard_range(total_channels, world, rank, &first, &count) -> add channels first .. first+count-1
  *   per batch k:  slot = k & 1
  *                 kq_fanout_post(f, slot, iq, n, is_device)      queue the broadcast (iq: read on the root rank only)
@@ -366,8 +374,15 @@ typedef struct kq_fanout_info {
    * events on that stream around the wait: a stalled step shows here, a slow broadcast that still arrives in time does not) */
   unsigned long long acquires, waits;
   double wait_ms;
+  /* acquires that had to wait but went untimed because the slot's previous timed wait was still in flight (the host several
+   * steps ahead of a stalled device): wait_ms / waits describe the timed ones only */
+  unsigned long long waits_dropped;
 } kq_fanout_info;
 int kq_fanout_stats(kq_fanout *f, kq_fanout_info *out);
+/* Path of the shared object ncclBroadcast was bound from (dladdr), "" before librccl has been loaded or when it could not
+ * be: a process that also holds torch has torch's own copy of librccl mapped, and the dynamic loader hands this library
+ * whichever `librccl.so.1` it finds first -- one line of a bench or log says which one carried the broadcasts. */
+const char *kq_fanout_rccl_path(void);
 /* on != 0: time the consumer's waits (two event records on the consumer stream per acquire that has to wait, ~5 us each
  * behind a long kernel -- a diagnostic, off by default). */
 int kq_fanout_enable_timing(kq_fanout *f, int on);

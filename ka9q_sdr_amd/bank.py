@@ -17,6 +17,7 @@ _lib = None
 KQ_LINEAR_DEMOD, KQ_AM_DEMOD, KQ_FM_DEMOD = 0, 1, 2
 KQ_IQ_CF32, KQ_IQ_S16, KQ_IQ_S8 = 0, 1, 2
 KQ_FWD_AUTO, KQ_FWD_FULL, KQ_FWD_PRUNED = 0, 1, 2
+KQ_ABI_VERSION = 5        # include/ka9q_hip.h
 
 
 class KqError(RuntimeError):
@@ -175,6 +176,10 @@ def load_library():
     L.kq_fanout_destroy.argtypes = [C.c_void_p]
     L.kq_fanout_stats.argtypes = [C.c_void_p, C.POINTER(FanoutInfo)]
     L.kq_fanout_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    L.kq_fanout_rccl_path.restype = C.c_char_p
+    L.kq_abi_version.restype = C.c_int
+    if L.kq_abi_version() != KQ_ABI_VERSION:
+        raise KqError("libka9q_hip.so has ABI revision %d, this mirror was written for %d" % (L.kq_abi_version(), KQ_ABI_VERSION))
     _lib = L
     return L
 
@@ -183,7 +188,8 @@ class FanoutInfo(C.Structure):
     """kq_fanout_info (include/ka9q_hip.h)"""
     _fields_ = [("world", C.c_int), ("rank", C.c_int), ("rccl_ranks", C.c_int), ("rccl_version", C.c_int),
                 ("broadcasts", C.c_ulonglong), ("broadcast_ms", C.c_double),
-                ("acquires", C.c_ulonglong), ("waits", C.c_ulonglong), ("wait_ms", C.c_double)]
+                ("acquires", C.c_ulonglong), ("waits", C.c_ulonglong), ("wait_ms", C.c_double),
+                ("waits_dropped", C.c_ulonglong)]
 
 
 def device_count():

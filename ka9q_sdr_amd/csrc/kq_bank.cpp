@@ -111,6 +111,7 @@ struct HostChan {
   int out_type;
   std::vector<kq::cfloat> resp, aresp;
   float noise_gain;
+  int n0slot = -1;  // which of the bank's compute_n0 mask sets this channel uses (shared by all channels with its edges)
 };
 
 struct EventPair {
@@ -214,6 +215,12 @@ struct kq_bank {
   uint64_t pulls = 0;        // plane copies queued so far; the newest one's marker is pull_done[(pulls - 1) % kPullRing]
   bool out_pending = false;  // a plane copy is queued that the next call's demodulators must wait for
 
+  // compute_n0's lane masks depend on a channel's filter edges only, and a receiver's channels mostly share a handful
+  // of filters: one mask set (2 KiB; N = 65536: 8 KiB) per distinct pair of edges, counted references, so that the masks
+  // of tens of thousands of channels stay in the L2 instead of streaming 70 MB per block from memory
+  std::map<std::pair<float, float>, int> n0slot_of;
+  std::vector<int> n0slot_refs;                       // per slot; 0 = free
+  std::vector<std::pair<float, float>> n0slot_key;    // per slot
   std::vector<HostChan> chans;
   // Steady state of the oscillators: nothing has been set, added or removed since the call before, so the per-call planes
   // follow from that call's on the device (k_block_energy_sum) and the host touches no per-channel state at all.
@@ -280,14 +287,54 @@ void build_n0mask(const kq_bank *b, float low, float high, std::vector<unsigned 
     }
 }
 
+// the mask set for these edges: an existing one, or a free slot filled now (*fresh).  Takes a reference.
+int acquire_n0slot(kq_bank *b, float low, float high, bool *fresh) {
+  auto const key = std::make_pair(low, high);
+  auto it = b->n0slot_of.find(key);
+  *fresh = it == b->n0slot_of.end();
+  int slot;
+  if (!*fresh) {
+    slot = it->second;
+  } else {
+    slot = -1;
+    for (size_t k = 0; k < b->n0slot_refs.size(); k++)
+      if (b->n0slot_refs[k] == 0) {
+        slot = (int)k;
+        break;
+      }
+    if (slot < 0) {  // (never more slots than channels: every reference belongs to a channel)
+      slot = (int)b->n0slot_refs.size();
+      b->n0slot_refs.push_back(0);
+      b->n0slot_key.push_back(key);
+    }
+    b->n0slot_key[slot] = key;
+    b->n0slot_of[key] = slot;
+  }
+  b->n0slot_refs[slot]++;
+  return slot;
+}
+void release_n0slot(kq_bank *b, int slot) {
+  if (slot < 0 || (size_t)slot >= b->n0slot_refs.size() || b->n0slot_refs[slot] <= 0) return;
+  if (--b->n0slot_refs[slot] == 0) b->n0slot_of.erase(b->n0slot_key[slot]);
+}
+
 int upload_n0mask(kq_bank *b, int c) {
   if (!b->chd.n0lane) return 0;
   int const nsub = b->use64k ? 4 : 1;
+  bool fresh = false;
+  int const old = b->chans[c].n0slot;
+  int const slot = acquire_n0slot(b, b->chans[c].cfg.low, b->chans[c].cfg.high, &fresh);
+  release_n0slot(b, old);  // (after the acquire: unchanged edges keep their slot)
+  b->chans[c].n0slot = slot;
+  // on the bank's stream: behind whatever call in flight still reads a slot its last user has just given back
   std::vector<unsigned long long> m;
   std::vector<unsigned> meta;
-  build_n0mask(b, b->chans[c].cfg.low, b->chans[c].cfg.high, m, meta);
-  if (upload(b, b->chd.n0lane + (size_t)c * nsub * 256, m.data(), m.size() * sizeof(m[0]))) return -1;
-  if (upload(b, b->chd.n0meta + (size_t)c * nsub, meta.data(), meta.size() * sizeof(unsigned))) return -1;
+  if (fresh) {
+    build_n0mask(b, b->chans[c].cfg.low, b->chans[c].cfg.high, m, meta);
+    if (upload(b, b->chd.n0lane + (size_t)slot * nsub * 256, m.data(), m.size() * sizeof(m[0]))) return -1;
+    if (upload(b, b->chd.n0meta + (size_t)slot * nsub, meta.data(), meta.size() * sizeof(unsigned))) return -1;
+  }
+  if (upload(b, b->chd.n0slot + c, &slot, sizeof(int))) return -1;
   HIP_TRY(hipStreamSynchronize(b->stream));  // the vectors are about to die
   return 0;
 }
@@ -791,7 +838,10 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   // the IF-power recurrence over the call's blocks: one wave, consumed by the demodulators only, so it runs with them and
   // not in front of the filter (folded into the sum's launch -- its last workgroup taking tagged partial sums as they
   // arrive -- it saved nothing measurable: 1.422 against 1.421 ms per step)
-  if (!spectrum)  // (spectrum mode: the IF power belongs to whoever fed the master, radio.c:123,143-145; status.if_power stays 0)
+  if (spectrum)  // the IF power belongs to whoever fed the master (radio.c:123,143-145): status.if_power = 0, not what a
+                 // normal call two calls back left in this parity's plane
+    HIP_TRY(hipMemsetAsync(pl.if_power, 0, nblocks * sizeof(float), ds));
+  else
     kq::launch_block_energy_iir(ds, pl.if_power + b->cfg.max_blocks, g.L, (int)nblocks,
                                 reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power);
   {
@@ -868,6 +918,7 @@ extern "C" {
 
 const char *kq_last_error(void) { return g_err.c_str(); }
 const char *kq_version(void) { return "ka9q_hip 0.1 (gfx950)"; }
+int kq_abi_version(void) { return KQ_ABI_VERSION; }
 
 int kq_device_count(void) {
   int n = 0;
@@ -1000,14 +1051,17 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.noise_gain, C);
   b->chd.n0lane = nullptr;
   b->chd.n0meta = nullptr;
+  b->chd.n0slot = nullptr;
   if (b->cfg.compute_n0 && kq::full16k_supported(g)) {
     rc |= dev_alloc(&b->chd.n0lane, C * 256);
     rc |= dev_alloc(&b->chd.n0meta, C);
+    rc |= dev_alloc(&b->chd.n0slot, C);
   }
   if (b->use64k) {
     if (b->cfg.compute_n0) {
       rc |= dev_alloc(&b->chd.n0lane, C * 4 * 256);
       rc |= dev_alloc(&b->chd.n0meta, C * 4);
+      rc |= dev_alloc(&b->chd.n0slot, C);
     }
     rc |= dev_alloc(&b->big.sync, C * cfg->max_blocks * 12);
     rc |= dev_alloc(&b->big.n0part, C * cfg->max_blocks * 4);
@@ -1133,7 +1187,7 @@ int kq_bank_destroy(kq_bank *b) {
   for (hipStream_t st : {b->copy_in, b->copy_out})  // before any plane they read or write is freed
     if (st) (void)hipStreamSynchronize(st);
   void *ptrs[] = {b->ring[0], b->ring[1], b->tw, b->chan_tw, b->chd.mode, b->chd.flags, b->chd.low, b->chd.high, b->chd.resp,
-                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.n0lane, b->chd.n0meta, b->fmout, b->fm_hist[0], b->fm_hist[1],
+                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.n0lane, b->chd.n0meta, b->chd.n0slot, b->fmout, b->fm_hist[0], b->fm_hist[1],
                   b->osc_dev2[0], b->osc_dev2[1], b->chd.fm_state,
                   b->chd.lastaudio, b->chd.sq_count, b->chd.ahist, b->chd.foffset, b->chd.pdev, b->chd.gain, b->chd.hang,
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
@@ -1482,24 +1536,22 @@ int kq_bank_add_channels(kq_bank *b, const kq_channel_config *cfgs, unsigned n, 
       }
     if (any) HIP_TRY(hipMemcpy(b->chd.aresp + c0 * na, ar.data(), ar.size() * sizeof(float2), hipMemcpyHostToDevice));
   }
-  if (b->chd.n0lane) {  // compute_n0's lane masks: one per distinct pair of edges
+  if (b->chd.n0lane) {  // compute_n0's lane masks: one set per distinct pair of edges, shared
     int const nsub = b->use64k ? 4 : 1;
-    size_t const per = (size_t)nsub * 256;
-    std::map<std::pair<float, float>, std::pair<std::vector<unsigned long long>, std::vector<unsigned>>> cache;
-    std::vector<unsigned long long> m((size_t)n * per);
-    std::vector<unsigned> meta((size_t)n * nsub);
+    std::vector<int> slots(n);
     for (unsigned i = 0; i < n; i++) {
-      auto key = std::make_pair(cfgs[i].low, cfgs[i].high);
-      auto it = cache.find(key);
-      if (it == cache.end()) {
-        it = cache.emplace(key, std::make_pair(std::vector<unsigned long long>(), std::vector<unsigned>())).first;
-        build_n0mask(b, cfgs[i].low, cfgs[i].high, it->second.first, it->second.second);
+      bool fresh = false;
+      int const slot = acquire_n0slot(b, cfgs[i].low, cfgs[i].high, &fresh);
+      hs[i].n0slot = slots[i] = slot;
+      if (fresh) {
+        std::vector<unsigned long long> m;
+        std::vector<unsigned> meta;
+        build_n0mask(b, cfgs[i].low, cfgs[i].high, m, meta);
+        HIP_TRY(hipMemcpy(b->chd.n0lane + (size_t)slot * nsub * 256, m.data(), m.size() * sizeof(m[0]), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->chd.n0meta + (size_t)slot * nsub, meta.data(), meta.size() * sizeof(unsigned), hipMemcpyHostToDevice));
       }
-      memcpy(&m[(size_t)i * per], it->second.first.data(), per * sizeof(unsigned long long));
-      memcpy(&meta[(size_t)i * nsub], it->second.second.data(), nsub * sizeof(unsigned));
     }
-    HIP_TRY(hipMemcpy(b->chd.n0lane + c0 * per, m.data(), m.size() * sizeof(m[0]), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b->chd.n0meta + c0 * nsub, meta.data(), meta.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->chd.n0slot + c0, slots.data(), n * sizeof(int), hipMemcpyHostToDevice));
   }
   for (unsigned i = 0; i < n; i++) {
     b->chans.push_back(std::move(hs[i]));
@@ -1528,6 +1580,8 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
   }
   h.active = false;
   h.retuned = false;
+  release_n0slot(b, h.n0slot);
+  h.n0slot = -1;
   h.lo2 = h.dop = h.shift = h.lo2_old = h.dop_old = Osc{};
   h.out_rtp = kq_out_rtp_state{};
   while (!b->chans.empty() && !b->chans.back().active) b->chans.pop_back();  // holes at the end just go

@@ -55,7 +55,8 @@ struct ChanDev {
   // 64-bit lane mask, bit l set = thread t = 64 w + l's bin full16k_bin(t) + kFull16kHalf half + 1024 k3 lies OUTSIDE the
   // passband.  [C][8][32]; N = 65536: [C][4][8][32], one set per sub-transform (bins 4 q + r)
   unsigned long long *n0lane;
-  unsigned *n0meta;     // [C] number of bins outside the passband (N = 65536: [C][4], per sub-transform)
+  unsigned *n0meta;     // [slot] number of bins outside the passband (N = 65536: [slot][4], per sub-transform)
+  int *n0slot;          // [C] the channel's mask set in n0lane / n0meta (channels with the same filter edges share one)
   // oscillator phase (turns), step (cycles/sample) and sweep (cycles/sample^2) at sample 0 of the
   // first window of the call; second LO and Doppler already summed (they multiply, so phases add)
   double *lo_phase, *lo_freq, *lo_rate;

@@ -36,6 +36,7 @@ struct Rccl {
   ncclResult_t (*GetVersion)(int *) = nullptr;
   ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
   bool ok = false;
+  char path[512] = "";  // the shared object ncclBroadcast was bound from (dladdr), for kq_fanout_rccl_path
 };
 
 Rccl &rccl() {
@@ -60,6 +61,8 @@ Rccl &rccl() {
     r.GetVersion = (decltype(r.GetVersion))dlsym(r.handle, "ncclGetVersion");
     r.CommCount = (decltype(r.CommCount))dlsym(r.handle, "ncclCommCount");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Broadcast && r.AllReduce && r.GetErrorString;
+    Dl_info info;
+    if (r.Broadcast && dladdr((void *)r.Broadcast, &info) && info.dli_fname) snprintf(r.path, sizeof r.path, "%s", info.dli_fname);
   });
   return r;
 }
@@ -86,7 +89,7 @@ struct kq_fanout {
   hipEvent_t w0[2] = {nullptr, nullptr}, w1[2] = {nullptr, nullptr};
   bool waited[2] = {false, false};
   double wait_ms = 0;
-  unsigned long long waits = 0, acquires = 0;
+  unsigned long long waits = 0, acquires = 0, waits_dropped = 0;
 };
 
 namespace {
@@ -178,9 +181,15 @@ kq_fanout *kq_fanout_create(int device, int rank, int world, int root, const voi
     // set-up worked") tells every rank whether every rank made it; if one did not, all of them give the communicator
     // back and return NULL -- nobody is left holding a fan-out whose first broadcast can never complete.
     Rccl &r = rccl();
+    // the word the ranks agree through, made BEFORE the collective set-up: once the communicator exists the all-reduce is
+    // issued whatever else has failed (a rank that skipped it left the others waiting in theirs).  Slot 0 of
+    // the fan-out is not in use yet and serves when it could be allocated; else four bytes of their own.
+    int *flag = f->buf[0] ? reinterpret_cast<int *>(f->buf[0]) : nullptr, *own_flag = nullptr;
+    if (!flag && hipMalloc((void **)&own_flag, sizeof(int)) == hipSuccess) flag = own_flag;
     if (!r.ok) {
       if (ok) kq_internal_set_error("kq_fanout_create: librccl not available%s", getenv("KQ_RCCL_LIB") ? " (KQ_RCCL_LIB)" : "");
-      ok = false;  // (every rank of the world loads the same library: they all fail here, nobody waits)
+      ok = false;  // (no communicator can exist on this rank: a world whose other ranks do load librccl waits in its
+                   //  ncclCommInitRank for this one -- see the header, a subset failing there needs the caller's timeout)
     } else {
       ncclUniqueId id;
       memcpy(&id, id128, sizeof id);
@@ -190,14 +199,14 @@ kq_fanout *kq_fanout_create(int device, int rank, int world, int root, const voi
         f->comm = nullptr;
         ok = false;
       } else {
-        int *flag = nullptr;  // device memory: the all-reduce runs in place on it
-        int mine = ok ? 1 : 0, all = 0;
-        bool agreed = hipMalloc((void **)&flag, sizeof(int)) == hipSuccess &&
-                      hipMemcpyAsync(flag, &mine, sizeof(int), hipMemcpyHostToDevice, f->side) == hipSuccess &&
-                      r.AllReduce(flag, flag, 1, ncclInt32, ncclMin, f->comm, f->side) == ncclSuccess &&
-                      hipMemcpyAsync(&all, flag, sizeof(int), hipMemcpyDeviceToHost, f->side) == hipSuccess &&
-                      hipStreamSynchronize(f->side) == hipSuccess;
-        if (flag) (void)hipFree(flag);
+        int all = 0;
+        // a flag that could not be allocated or set counts as "my set-up failed", but the collective is still entered
+        // whenever there is memory to run it on
+        bool set = flag && hipMemsetD32Async((hipDeviceptr_t)flag, ok ? 1 : 0, 1, f->side) == hipSuccess;
+        if (flag && !set) set = hipMemsetD32Async((hipDeviceptr_t)flag, 0, 1, f->side) == hipSuccess;
+        bool const agreed = flag && r.AllReduce(flag, flag, 1, ncclInt32, ncclMin, f->comm, f->side) == ncclSuccess &&
+                            hipMemcpyAsync(&all, flag, sizeof(int), hipMemcpyDeviceToHost, f->side) == hipSuccess &&
+                            hipStreamSynchronize(f->side) == hipSuccess;
         if (!agreed) {
           if (ok) kq_internal_set_error("kq_fanout_create: the ranks' agreement (ncclAllReduce) failed on rank %d", rank);
           ok = false;
@@ -207,6 +216,7 @@ kq_fanout *kq_fanout_create(int device, int rank, int world, int root, const voi
         }
       }
     }
+    if (own_flag) (void)hipFree(own_flag);
   }
   if (!ok) {
     kq_fanout_destroy(f);
@@ -284,10 +294,18 @@ const void *kq_fanout_acquire(kq_fanout *f, int slot, void *consumer_stream, siz
   f->acquires++;
   if (hipEventQuery(f->ready[slot]) != hipSuccess) {
     hipStream_t const cs = (hipStream_t)consumer_stream;
-    bool const timed = f->time_waits && f->w0[slot] && f->w1[slot];
+    bool timed = f->time_waits && f->w0[slot] && f->w1[slot];
     if (timed) {
-      harvest_wait(f, slot);
-      (void)hipEventRecord(f->w0[slot], cs);
+      // the slot's event pair may still be in flight (the host runs several steps ahead of a stalled device -- exactly the
+      // case this diagnostic exists for): re-recording it would lose that sample, so this acquire goes untimed instead
+      // and is counted
+      if (f->waited[slot] && hipEventQuery(f->w1[slot]) != hipSuccess) {
+        f->waits_dropped++;
+        timed = false;
+      } else {
+        harvest_wait(f, slot);
+        (void)hipEventRecord(f->w0[slot], cs);
+      }
     }
     if (hipError_t e = hipStreamWaitEvent(cs, f->ready[slot], 0); e != hipSuccess) {
       fail("kq_fanout_acquire: hipStreamWaitEvent", e);
@@ -338,7 +356,13 @@ int kq_fanout_stats(kq_fanout *f, kq_fanout_info *out) {
   out->acquires = f->acquires;
   out->waits = f->waits;
   out->wait_ms = f->wait_ms;
+  out->waits_dropped = f->waits_dropped;
   return 0;
+}
+
+const char *kq_fanout_rccl_path(void) {
+  Rccl &r = rccl();
+  return r.handle ? r.path : "";
 }
 
 int kq_fanout_enable_timing(kq_fanout *f, int on) {

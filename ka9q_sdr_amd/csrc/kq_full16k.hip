@@ -578,8 +578,9 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     // (read through the constant address space: nothing writes the masks while a kernel runs, and only then may the
     // compiler fetch them with scalar loads this late in the kernel, behind global stores it cannot tell apart from them)
     typedef const unsigned long long __attribute__((address_space(4))) *lane_masks;
+    int const ns = __builtin_amdgcn_readfirstlane(ch.n0slot[c]);  // channels with the same filter edges share one mask set
     lane_masks const lm = (lane_masks)(
-        ch.n0lane + ((size_t)(c * (BIG ? 4 : 1) + r4) * (kT / 64) + __builtin_amdgcn_readfirstlane(t >> 6)) * 32);
+        ch.n0lane + ((size_t)(ns * (BIG ? 4 : 1) + r4) * (kT / 64) + __builtin_amdgcn_readfirstlane(t >> 6)) * 32);
 #pragma unroll
     for (int k3 = 0; k3 < 16; k3++) {
       // spelled out (given `x*x + y*y` on both halves the compiler pairs the additions into one v_pk_add_f32 behind three
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
       asm("v_cndmask_b32_e64 %0, 0, %0, %1" : "+v"(p1) : "s"(lm[16 + k3]));
       pp[k3] = (v2f){p0, p1};
     }
-    outside = (int)ch.n0meta[c * (BIG ? 4 : 1) + r4];
+    outside = (int)ch.n0meta[ns * (BIG ? 4 : 1) + r4];
     // First pass: avg_n = inf, so `s < avg_n * 2` keeps every finite bin.  Sum them all (the passband's count as 0); when
     // the total comes out finite no bin was inf or NaN (powers are >= 0, nothing cancels) and the count is the
     // precomputed one.
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
       // the mean runs over the bins of all four sub-transforms: same four numbers, same order in every sibling
       sibling_exchange(slots, r4, __float_as_uint(total), big.epoch, sib_f, big.err);
       total = (sib_f[0] + sib_f[1]) + (sib_f[2] + sib_f[3]);
-      const unsigned *const mt = ch.n0meta + c * 4;
+      const unsigned *const mt = ch.n0meta + ns * 4;
       bins1 = (int)(mt[0] + mt[1] + mt[2] + mt[3]);
     }
     float const thr = (total / bins1) * 2;

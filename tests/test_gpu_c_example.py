@@ -39,9 +39,14 @@ def test_radio_fanout_c_example_runs_with_a_world_of_one(gpu):
                         "-lm", "-o", out], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     try:
-        run = subprocess.run([out, "1", "5"], capture_output=True, text=True, timeout=300)
+        run = subprocess.run([out, "1", "5", "0", "30"], capture_output=True, text=True, timeout=300)
     finally:
         os.unlink(out)
     assert run.returncode == 0, run.stdout + run.stderr
     lines = run.stdout.strip().splitlines()
     assert lines[-1] == "ok" and lines[0].startswith("rank 0: channels 0..26  rccl ranks 0")
+    # the per-rank table of the timed phase (what bench.py --gpus N carries as per_rank)
+    head = [i for i, ln in enumerate(lines) if ln.startswith("rank  ms_per_step")]
+    assert len(head) == 1, run.stdout
+    row = lines[head[0] + 1].split()
+    assert row[0] == "0" and float(row[1]) > 0 and float(row[2]) > 0 and float(row[1]) >= float(row[2]), row

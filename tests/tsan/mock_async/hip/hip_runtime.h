@@ -160,6 +160,14 @@ inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind
   st->enqueue([=] { memcpy(d, s, n); });
   return hipSuccess;
 }
+typedef void *hipDeviceptr_t;
+inline hipError_t hipMemsetD32Async(hipDeviceptr_t p, int v, size_t count, hipStream_t st) {
+  if (!st) return hipErrorInvalidValue;
+  st->enqueue([=] {
+    for (size_t i = 0; i < count; i++) static_cast<int *>(p)[i] = v;
+  });
+  return hipSuccess;
+}
 inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags) {
   *e = new mock_event_t();
   (*e)->timing = !(flags & hipEventDisableTiming);

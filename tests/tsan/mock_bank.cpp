@@ -74,6 +74,12 @@ int kq_bank_process_resident(kq_bank *b, const void *iq, unsigned nblocks) {
   });
   return (int)nblocks;
 }
+int kq_abi_version(void) { return KQ_ABI_VERSION; }
+int kq_bank_enable_timing(kq_bank *, int) { return 0; }
+int kq_bank_get_timing(kq_bank *, kq_timing *t, int) {
+  memset(t, 0, sizeof *t);
+  return 0;
+}
 int kq_bank_sync(kq_bank *b) {
   hipStreamSynchronize(b->stream);
   return 0;

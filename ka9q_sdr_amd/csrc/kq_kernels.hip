@@ -1009,6 +1009,376 @@ __global__ void __launch_bounds__(64) k_fm_audio256(Geom g, ChanDev ch, Planes p
   }
 }
 
+// The whole FM demodulator of one channel in ONE launch for N/D = 256 (cfg 2's geometry: 128 samples per block, de-emphasis
+// filter of 129 taps) without the PL measurement: k_demod_fm's four phases and k_fm_audio256's overlap-save on the same
+// 16-wave workgroup, the call's blocks held in LDS from the first load to the audio store.  What the two-kernel form pays
+// and this does not: the second launch, the detected samples' round trip through memory (8 MB per call at cfg 2), and one
+// exposed memory latency per block and phase -- a wave asks for all its blocks' samples at once here, and phase C finds
+// them in LDS.  Per-block expressions and reduction orders are those of k_demod_fm / k_fm_audio256 (and so of the
+// sequential loop of fm.c:91-171): the results are theirs bit for bit.
+// Static LDS: S[64][128] float2 (64 KiB) | FO[65][128] float (row 0 = the block before the chunk) | Y[16][128] float.
+namespace {
+struct Audio256 {  // k_fm_audio256's transform pair, set up once per wave
+  float2 hf[4], wf[6], wi[6], w4[3];
+  int lane;
+  __device__ __forceinline__ void init(int lane_, const float2 *HA) {
+    lane = lane_;
+    int const q = (int)(__brev((unsigned)lane) >> 26);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      int const k = 4 * q + r;
+      float2 const t = HA[k <= 128 ? k : 256 - k];
+      hf[r] = k <= 128 ? t : cconj(t);
+      if (k == 0 || k == 128) hf[r].y = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+      int const half = 1 << s;
+      float sn, cs;
+      sincospif((float)(lane & (half - 1)) / (float)half, &sn, &cs);
+      wf[s] = make_float2(cs, -sn);
+      wi[s] = make_float2(cs, sn);
+    }
+#pragma unroll
+    for (int r = 1; r < 4; r++) {
+      float sn, cs;
+      sincospif((float)(lane * r) / 128.f, &sn, &cs);
+      w4[r - 1] = make_float2(cs, -sn);
+    }
+  }
+  __device__ __forceinline__ float2 xor_pow(float2 v, int s) const {
+    switch (s) {
+      case 0: return make_float2(lane_xor<1>(v.x, lane), lane_xor<1>(v.y, lane));
+      case 1: return make_float2(lane_xor<2>(v.x, lane), lane_xor<2>(v.y, lane));
+      case 2: return make_float2(lane_xor<4>(v.x, lane), lane_xor<4>(v.y, lane));
+      case 3: return make_float2(lane_xor<8>(v.x, lane), lane_xor<8>(v.y, lane));
+      case 4: return make_float2(lane_xor<16>(v.x, lane), lane_xor<16>(v.y, lane));
+      default: return make_float2(lane_xor<32>(v.x, lane), lane_xor<32>(v.y, lane));
+    }
+  }
+  // z[m + 64 a] = (window [b-1 | b], window [b | b+1]) -> the filtered samples 128 + m and 192 + m of both (real / imaginary part)
+  __device__ __forceinline__ void run(float2 z0, float2 z1, float2 z2, float2 z3, float2 &y2, float2 &y3) const {
+    auto muli = [](float2 a) { return make_float2(-a.y, a.x); };  // i a
+    float2 u[4];
+    {
+      float2 const t0 = cadd(z0, z2), t1 = csub(z0, z2), t2 = cadd(z1, z3), t3 = csub(z1, z3);
+      u[0] = cadd(t0, t2);
+      u[2] = cmul(csub(t0, t2), w4[1]);
+      u[1] = cmul(csub(t1, muli(t3)), w4[0]);
+      u[3] = cmul(cadd(t1, muli(t3)), w4[2]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float2 z = u[r];
+#pragma unroll
+      for (int s = 5; s >= 0; s--) {
+        float2 const o = xor_pow(z, s);
+        z = ((lane >> s) & 1) ? cmul(csub(o, z), wf[s]) : cadd(z, o);
+      }
+      z = cmul(hf[r], z);
+#pragma unroll
+      for (int s = 0; s < 6; s++) {
+        int const bit = (lane >> s) & 1;
+        float2 const v = bit ? cmul(z, wi[s]) : z;
+        float2 const o = xor_pow(v, s);
+        z = bit ? csub(o, v) : cadd(v, o);
+      }
+      u[r] = r ? cmul(z, cconj(w4[r - 1])) : z;
+    }
+    y2 = csub(cadd(u[0], u[2]), cadd(u[1], u[3]));
+    y3 = csub(csub(u[0], u[2]), muli(csub(u[1], u[3])));
+  }
+};
+}  // namespace
+
+__global__ void __launch_bounds__(512) k_demod_fm256(Geom g, ChanDev ch, Planes pl, const float *__restrict__ hist_in,
+                                                      float *__restrict__ hist_out, const int *__restrict__ list, int nblocks,
+                                                      int compute_n0) {
+  constexpr int olen = 128, W = 8;  // (16 waves leave 128 registers per lane: the audio transform then spills 112 of them)
+  __shared__ __attribute__((aligned(16))) float2 S[64 * olen];
+  __shared__ __attribute__((aligned(16))) float FO[65 * olen];
+  __shared__ float Yall[W * olen];
+  __shared__ float r_bb[64], r_snr[64], r_amp[64], r_la_out[64], r_la_in[64], r_foff[64], r_pdev[64];
+  __shared__ int r_carry[64], r_pvc[64], r_sq[64], r_blanked[64];
+  __shared__ float2 r_sc[64], r_sp[64], r_st_out[64], r_st_in[64];
+  int const c = list[blockIdx.x];
+  int const lane = threadIdx.x & 63;
+  int const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float *Y = Yall + wave * olen;
+  float2 c_state = ch.fm_state[c];
+  float c_la = ch.lastaudio[c];
+  int c_sq = ch.sq_count[c];
+  float c_foff = ch.foffset[c], c_pdev = ch.pdev[c];
+  float c_n0 = ch.n0[c];
+  float const noise_gain = ch.noise_gain[c];
+  bool const flat = (ch.flags[c] & FLAG_FLAT) != 0;
+  float const gain = ch.fm_gain[c];
+  if (threadIdx.x < olen) FO[threadIdx.x] = hist_in[(size_t)c * olen + threadIdx.x];  // the block before the call (AM - 1 = 128)
+
+  for (int b0 = 0; b0 < nblocks; b0 += 64) {
+    int const nb = min(64, nblocks - b0);
+    // ---- A: all of this wave's blocks asked for at once, then statistics block by block (fm.c:91-103)
+    constexpr int kPer = 64 / W;
+    float2 va[kPer], vb[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; i++) {
+      int const k = wave + W * i;
+      if (k < nb) {
+        const float2 *in = pl.filt + ((size_t)c * g.max_blocks + b0 + k) * olen;
+        va[i] = in[lane];
+        vb[i] = in[lane + 64];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; i++) {
+      int const k = wave + W * i;
+      if (k >= nb) break;
+      float2 *Sk = S + k * olen;
+      Sk[lane] = va[i];
+      Sk[lane + 64] = vb[i];
+      float sum_t = 0, sum_a = 0;
+      {  // (n = lane, then n = lane + 64: the accumulation order of k_demod_fm's loop)
+        float const t0 = cnrm(va[i]);
+        sum_t += t0;
+        sum_a += sqrtf(t0);
+        float const t1 = cnrm(vb[i]);
+        sum_t += t1;
+        sum_a += sqrtf(t1);
+      }
+      sum_t = wave_sum(sum_t);
+      sum_a = wave_sum(sum_a);
+      float const bb = sum_t / (2 * olen);
+      float const amp = (float)((double)sum_a / (M_SQRT2 * olen));
+      float const variance = bb - amp * amp;
+      float snr = amp * amp / (2 * variance) - 1;
+      snr = (0.0f > snr) ? 0.0f : snr;  // misc.h max(): NaN propagates
+      float const thr = (float)(0.55 * 0.55 * amp * amp);  // fm.c:121
+      int carry = -1, pvc = -1;  // last strong sample and the one before it
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        bool const valid = cnrm(h ? vb[i] : va[i]) > thr;
+        unsigned long long const m = __ballot(valid);
+        if (m) {
+          int const top = top_bit(m);
+          unsigned long long const rest = m & ~(1ull << top);
+          pvc = rest ? 64 * h + top_bit(rest) : carry;
+          carry = 64 * h + top;
+        }
+      }
+      wave_sync();
+      if (lane == 0) {
+        r_bb[k] = bb;
+        r_snr[k] = snr;
+        r_amp[k] = amp;
+        r_carry[k] = carry;
+        r_pvc[k] = pvc;
+        r_sc[k] = carry >= 0 ? Sk[carry] : make_float2(0.f, 0.f);
+        r_sp[k] = pvc >= 0 ? Sk[pvc] : make_float2(0.f, 0.f);
+      }
+    }
+    __syncthreads();
+    // ---- B: squelch counters and what every block starts from (k_demod_fm's phase B)
+    if (wave == 0) {
+      bool const act = lane < nb;
+      bool const reset = act && r_snr[lane] > 2;  // fm.c:108-114
+      unsigned long long const rm = __ballot(reset), rl = rm & bits_upto(lane);
+      int const sq = rl ? lane - top_bit(rl) : min(c_sq + lane + 1, 1000);
+      bool const open = sq < 2;
+      int const carry = act ? r_carry[lane] : -1;
+      bool const def = act && (!open || carry >= 0);
+      float2 const sc = r_sc[lane];
+      r_st_out[lane] = open ? cconj(sc) : make_float2(0.f, 0.f);
+      unsigned long long const dm = __ballot(def), dl = dm & bits_below(lane);
+      int const j = dl ? top_bit(dl) : -1;
+      wave_sync();
+      float2 const st_in = j >= 0 ? r_st_out[j] : c_state;
+      float ylast = 0;
+      if (open && carry >= 0) {  // the discriminator output at the block's last strong sample (fm.c:130-132)
+        float2 const st = r_pvc[lane] >= 0 ? cconj(r_sp[lane]) : st_in;
+        float2 const pr = cmul(sc, st);
+        ylast = atan2f(pr.y, pr.x);
+      }
+      r_la_out[lane] = ylast;
+      wave_sync();
+      r_la_in[lane] = j >= 0 ? r_la_out[j] : c_la;
+      r_st_in[lane] = st_in;
+      r_sq[lane] = sq;
+      if (dm) {
+        int const jl = top_bit(dm);
+        c_state = r_st_out[jl];
+        c_la = r_la_out[jl];
+      }
+      c_sq = __shfl(sq, nb - 1, 64);
+    }
+    __syncthreads();
+    // ---- C: discriminator and hold rule (fm.c:116-160), samples from LDS, detected samples into FO[k + 1]
+    for (int k = wave; k < nb; k += W) {
+      const float2 *Sk = S + k * olen;
+      float *fo = FO + (k + 1) * olen;
+      int const sq = r_sq[k];
+      int blanked = 0;
+      float foff = 0, pdev = 0;
+      if (sq < 2) {
+        float const amp = r_amp[k];
+        float const thr = (float)(0.55 * 0.55 * amp * amp);
+        float2 const st_in = r_st_in[k];
+        float const la_in = r_la_in[k];
+        int carry = -1;
+        for (int cb = 0; cb < olen; cb += 64) {
+          int const n = cb + lane;
+          float2 const v = Sk[n];
+          bool const valid = cnrm(v) > thr;
+          unsigned long long const m = __ballot(valid), ml = m & bits_below(lane);
+          if (valid) {  // arg(s_n * conj(previous strong sample)), fm.c:130-132
+            int const pv = ml ? cb + top_bit(ml) : carry;
+            float2 const st = pv >= 0 ? cconj(Sk[pv]) : st_in;
+            float2 const pr = cmul(v, st);
+            Y[n] = atan2f(pr.y, pr.x);
+          }
+          if (m) carry = cb + top_bit(m);
+        }
+        wave_sync();
+        float sum_y = 0, vmax = -INFINITY, vmin = INFINITY;
+        bool first_valid = false;
+        carry = -1;
+        for (int cb = 0; cb < olen; cb += 64) {
+          int const n = cb + lane;
+          bool const valid = cnrm(Sk[n]) > thr;
+          unsigned long long const m = __ballot(valid), mu = m & bits_upto(lane);
+          if (cb == 0) first_valid = (m & 1ull) != 0;
+          int const lv = mu ? cb + top_bit(mu) : carry;
+          float const y = lv >= 0 ? Y[lv] : la_in;  // weak samples repeat the last good audio value (fm.c:141)
+          fo[n] = y;
+          sum_y += y;
+          if (valid) {
+            if (n > 0) {
+              vmax = fmaxf(vmax, y);
+              vmin = fminf(vmin, y);
+            }
+          } else {
+            blanked++;
+          }
+          if (m) carry = cb + top_bit(m);
+        }
+        sum_y = wave_sum(sum_y);
+        vmax = wave_max(vmax);
+        vmin = wave_min(vmin);
+        blanked = wave_sum_i(blanked);
+        float const seed = first_valid ? Y[0] : 0.0f;  // fm.c:125-139
+        float pdev_pos = fmaxf(seed, vmax), pdev_neg = fminf(seed, vmin);
+        float const avg_f = sum_y / olen;
+        if (sq < 1) {  // fm.c:146-154
+          foff = (float)(g.dsamprate * avg_f * (0.5 * M_1_PI));
+          pdev_pos -= avg_f;
+          pdev_neg -= avg_f;
+          float const mx = (pdev_pos > -pdev_neg) ? pdev_pos : -pdev_neg;
+          pdev = (float)(g.dsamprate * mx * (0.5 * M_1_PI));
+        }
+        wave_sync();  // Y is reused by this wave's next block
+      } else {
+        fo[lane] = 0;  // fm.c:156-160
+        fo[lane + 64] = 0;
+      }
+      if (lane == 0) {
+        r_blanked[k] = blanked;
+        r_foff[k] = foff;
+        r_pdev[k] = pdev;
+      }
+    }
+    __syncthreads();
+    // ---- D (wave 0): carried readings and the status records; the other waves start on the audio filter meanwhile
+    if (wave == 0) {
+      bool const act = lane < nb;
+      int const sq = r_sq[lane];
+      bool const own = act && sq < 1;
+      unsigned long long const om = __ballot(own), ol = om & bits_upto(lane);
+      int const jo = ol ? top_bit(ol) : -1;
+      float const foffset = jo >= 0 ? r_foff[jo] : c_foff;
+      float const pdev = jo >= 0 ? r_pdev[jo] : c_pdev;
+      if (om) {
+        int const jl = top_bit(om);
+        c_foff = r_foff[jl];
+        c_pdev = r_pdev[jl];
+      }
+      float n0_mine = NAN;
+      if (compute_n0) {  // fm.c:79-82: a chain in double through the blocks
+        float const fresh_v = act ? pl.n0raw[(size_t)c * g.max_blocks + b0 + lane] : 0.f;
+        for (int k = 0; k < nb; k++) {
+          float const fresh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fresh_v), k));
+          c_n0 = isnan(c_n0) ? fresh : (float)((double)c_n0 + .01 * (double)(fresh - c_n0));
+          if (lane == k) n0_mine = c_n0;
+        }
+      }
+      if (act) {
+        kq_chan_status st;
+        st.if_power = pl.if_power[b0 + lane];
+        st.noise_gain = noise_gain;
+        st.plfreq = NAN;
+        st.cphase = 0;
+        st.pll_lock = 0;
+        st.lock_count = 0;
+        st.n0 = n0_mine;
+        st.bb_power = r_bb[lane];
+        st.snr = r_snr[lane];
+        st.foffset = foffset;
+        st.pdeviation = pdev;
+        st.agc_gain = 0;
+        st.squelch_count = sq;
+        st.hangcount = 0;
+        st.blanked = r_blanked[lane];
+        st.nout = olen;
+        pl.status[(size_t)c * g.max_blocks + b0 + lane] = st;
+      }
+    }
+    // ---- audio: REAL -> REAL de-emphasis overlap-save on pairs of blocks (fm.c:162-171), FO row k + 1 = block b0 + k
+    // (the transform's constants are formed here and not at the top: held across phases A - C they spill)
+    Audio256 af;
+    if (!flat) af.init(lane, ch.aresp + (size_t)c * 129);
+    for (int pr = (wave + W - 1) % W; pr < (nb + 1) / 2; pr += W) {  // (wave 1 takes pair 0: wave 0 is busy with phase D)
+      int const k = 2 * pr;
+      bool const have1 = k + 1 < nb;
+      const float *pm = FO + k * olen, *cm = pm + olen, *nm = cm + olen;
+      float const p0 = pm[lane], p1 = pm[lane + 64], c0 = cm[lane], c1 = cm[lane + 64];
+      float const n0 = have1 ? nm[lane] : 0.f, n1 = have1 ? nm[lane + 64] : 0.f;
+      float *aud0 = pl.audio + ((size_t)c * g.max_blocks + b0 + k) * (2 * (size_t)olen);
+      float *aud1 = aud0 + 2 * olen;
+      if (flat) {  // fm.c:164-172: no filter, no gain
+        aud0[lane] = c0;
+        aud0[lane + 64] = c1;
+        if (have1) {
+          aud1[lane] = n0;
+          aud1[lane + 64] = n1;
+        }
+        continue;
+      }
+      float2 y2, y3;
+      af.run(make_float2(p0, c0), make_float2(p1, c1), make_float2(c0, n0), make_float2(c1, n1), y2, y3);
+      aud0[lane] = y2.x * gain;  // fm.c:169-170
+      aud0[lane + 64] = y3.x * gain;
+      if (have1) {
+        aud1[lane] = y2.y * gain;
+        aud1[lane + 64] = y3.y * gain;
+      }
+    }
+    __syncthreads();
+    // the chunk's last block precedes the next chunk (and, after the last chunk, the next call: filter.c:164)
+    if (threadIdx.x < olen) {
+      float const v = FO[nb * olen + threadIdx.x];
+      FO[threadIdx.x] = v;
+      if (b0 + 64 >= nblocks) hist_out[(size_t)c * olen + threadIdx.x] = v;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    ch.n0[c] = c_n0;
+    ch.fm_state[c] = c_state;
+    ch.lastaudio[c] = c_la;
+    ch.sq_count[c] = c_sq;
+    ch.foffset[c] = c_foff;
+    ch.pdev[c] = c_pdev;
+  }
+}
+
 // AM: envelope, carrier removal, hang AGC -- a strictly sequential recurrence per channel
 // (am.c:55-75), so one lane per channel and channels across lanes.
 __global__ void k_demod_am(Geom g, ChanDev ch, Planes pl, const int *__restrict__ list, int nchan, int nblocks,
@@ -1234,7 +1604,13 @@ size_t demod_fm_lds_bytes(const Geom &g) { return std::max(fm_disc_lds_bytes(g),
 void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_fm,
                    int n_fm, const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0,
                    float *fmout, const float *fm_hist_in, float *fm_hist_out) {
-  if (n_fm > 0) {
+  // cfg 2's geometry without the PL measurement: one fused launch (KQ_FM_FUSED=0: the two-kernel form, A/B switch)
+  static bool const fused_off = getenv("KQ_FM_FUSED") && atoi(getenv("KQ_FM_FUSED")) == 0;
+  bool const fused = g.Ndec == 256 && g.olen == 128 && g.Mdec == 129 && g.pl_n == 0 && !fused_off;
+  if (n_fm > 0 && fused) {
+    hipLaunchKernelGGL(k_demod_fm256, dim3(n_fm), dim3(512), 0, s, g, ch, pl, fm_hist_in, fm_hist_out, list_fm, nblocks,
+                       compute_n0);
+  } else if (n_fm > 0) {
     int const waves = fm_disc_waves(g, nblocks);
     size_t const lds_a = fm_disc_lds_bytes(g, waves), lds_b = fm_audio_lds_bytes(g);
     ensure_dynamic_lds((const void *)k_demod_fm, lds_a);

@@ -157,14 +157,17 @@ def test_handles_release_their_device_memory(gpu):
     assert before - after < 8 << 20, (before, after)
 
 
-@pytest.mark.parametrize("per_call,D", [(150, 4), (64, 4), (7, 4), (150, 16), (7, 16)])
-def test_fm_hand_overs_across_many_blocks(gpu, per_call, D):
+@pytest.mark.parametrize("per_call,D,pl_tone", [(150, 4, True), (64, 4, True), (7, 4, True), (150, 16, True), (7, 16, True),
+                                                (150, 4, False), (64, 4, False), (7, 4, False), (1, 4, False)])
+def test_fm_hand_overs_across_many_blocks(gpu, per_call, D, pl_tone):
     """The generic FM demodulator takes 64 blocks of a channel at a time and resolves what each block inherits from
     the ones before it (squelch counter, last strong sample, last audio value, offset / deviation readings) by a
     scan.  A signal that comes and goes, fades below the blanking threshold, and a stretch of exact zeros (an open
     block without a single strong sample, then a squelched one) against the oracle's sequential loop; 150 blocks in
     one call span three chunks, 7 per call leave every chunk ragged.  D = 16 (N/D = 64) runs the same signal through
-    the wave-per-channel demodulator, which pairs blocks instead."""
+    the wave-per-channel demodulator, which pairs blocks instead.  pl_tone = False at D = 4 is cfg 2's geometry as SURVEY 8d
+    measures it: the whole demodulator then runs in the one fused launch k_demod_fm256 (blocks held in LDS, the audio filter
+    on pairs of them; 150 blocks = three chunks with the history handed from chunk to chunk inside the kernel)."""
     g = dict(samprate=192000, L=512, M=513, D=D)            # D = 4: N/D = 256, 128 samples per block
     fs, L = g["samprate"], g["L"]
     nb = 150
@@ -182,7 +185,7 @@ def test_fm_hand_overs_across_many_blocks(gpu, per_call, D):
     plan = [dict(demod="fm", low=-w, high=w, second_lo=-30000.0 - 13.0),
             dict(demod="fm", low=-0.75 * w, high=w, second_lo=-30000.0 + 7.0, flat=1)]
     want = run_oracle(plan, g, iq, nb, compute_n0=1)
-    bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), per_call, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL)
+    bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), per_call, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL, pl_tone=pl_tone)
     for p in plan:
         bank.add_channel(bank_cfg(p))
     got = [[] for _ in plan]

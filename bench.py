@@ -617,42 +617,62 @@ def main():
     # host float buffer per block (audio.c:82).  Same step, but the batch comes from pinned host memory
     # (kq_bank_push_iq_async -> ring -> kq_bank_process) and audio + status of every step go back to pinned host memory
     # (kq_bank_pull_planes_async); the copies ride on the bank's copy streams under the kernels.  Beside `value`, never it.
-    host_io = None
+    host_io = host_io_pcm = None
     if world == 1 and not a.no_host_io:
         import ctypes
         olen = L // D
         iq_pin = torch.from_numpy(np.ascontiguousarray(iq_host[M - 1:M - 1 + B * L])).pin_memory()
-        audio_pin = torch.zeros(C * B * 2 * olen, dtype=torch.float32).pin_memory()
         status_pin = torch.empty(C * B * ctypes.sizeof(kq.ChanStatus), dtype=torch.uint8).pin_memory()
 
-        def io_step():     # the call order include/ka9q_hip.h asks for: the next batch is on its way before this one's planes leave
-            assert bank.process() == B
-            bank.push_iq_async(iq_pin.data_ptr(), B * L)
-            bank.pull_planes_async(audio_pin.data_ptr(), status_pin.data_ptr())
+        def host_io_row(pcm):
+            """pcm: the int16 PCM plane (the reference's own output format, audio.c:22-28: clipped, network byte order)
+            + silent-chunk masks instead of float audio -- half the bytes over the link"""
+            if pcm:
+                out_pin = torch.zeros(C * B * 2 * olen, dtype=torch.int16).pin_memory()
+                mask_pin = torch.zeros(C * B, dtype=torch.int32).pin_memory()
+            else:
+                out_pin = torch.zeros(C * B * 2 * olen, dtype=torch.float32).pin_memory()
 
-        n_io = max(2, min(50, a.steps))
-        bank.push_iq_async(iq_pin.data_ptr(), B * L)
-        for k in range(20):
-            io_step()
-        bank.host_io_wait()
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        for k in range(n_io):
-            io_step()
-        bank.host_io_wait()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t3) / n_io
-        # of each channel-block's 2 olen floats the nout that hold samples travel (mono olen, stereo 2 olen), plus the status plane
-        h2d = iq_pin.numel() * 8
-        d2h = sum((2 if p.get("channels", 1) == 2 else 1) * olen * 4 for p in plan) * B + status_pin.numel()
-        host_io = {"value": round(C * B * L / dt / 1e6, 1), "unit": "Msamples/s (channel-samples)",
-                   "ms_per_step": round(dt * 1e3, 4), "steps": n_io,
-                   "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": d2h,
-                   "h2d_GBps": round(h2d / dt / 1e9, 2), "d2h_GBps": round(d2h / dt / 1e9, 2),
-                   "audio_checksum": float(audio_pin[:C * B * 2 * olen:997].abs().sum()),
-                   "note": "input from pinned host memory (kq_bank_push_iq_async + kq_bank_process, ring path with its "
-                           "history copy), audio (nout floats per channel-block) + status [C][B] planes to pinned host memory "
-                           "every step (kq_bank_pull_planes_async); copies on the bank's copy streams, overlapped with the kernels"}
+            def io_step():     # the call order include/ka9q_hip.h asks for: the next batch is on its way before this one's planes leave
+                assert bank.process() == B
+                bank.push_iq_async(iq_pin.data_ptr(), B * L)
+                if pcm:
+                    bank.pull_pcm_planes_async(out_pin.data_ptr(), mask_pin.data_ptr(), status_pin.data_ptr())
+                else:
+                    bank.pull_planes_async(out_pin.data_ptr(), status_pin.data_ptr())
+
+            n_io = max(2, min(50, a.steps))
+            bank.push_iq_async(iq_pin.data_ptr(), B * L)
+            for k in range(20):
+                io_step()
+            bank.host_io_wait()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for k in range(n_io):
+                io_step()
+            bank.host_io_wait()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t3) / n_io
+            bank.process()      # (the batch the last step pushed: the ring is empty for whoever comes next)
+            torch.cuda.synchronize()
+            # of each channel-block's 2 olen words the nout that hold samples travel (mono olen, stereo 2 olen), plus the status plane
+            h2d = iq_pin.numel() * 8
+            words = sum((2 if p.get("channels", 1) == 2 else 1) * olen for p in plan) * B
+            d2h = words * (2 if pcm else 4) + status_pin.numel() + (4 * C * B if pcm else 0)
+            return {"value": round(C * B * L / dt / 1e6, 1), "unit": "Msamples/s (channel-samples)",
+                    "ms_per_step": round(dt * 1e3, 4), "steps": n_io,
+                    "h2d_bytes_per_step": h2d, "d2h_bytes_per_step": d2h,
+                    "h2d_GBps": round(h2d / dt / 1e9, 2), "d2h_GBps": round(d2h / dt / 1e9, 2),
+                    "audio_checksum": float(out_pin[:C * B * 2 * olen:997].to(torch.float64).abs().sum()),
+                    "note": "input from pinned host memory (kq_bank_push_iq_async + kq_bank_process, ring path with its "
+                            "history copy), %s + status [C][B] planes to pinned host memory every step (%s); copies on the "
+                            "bank's copy streams, overlapped with the kernels" %
+                            (("int16 PCM words (audio.c:22-28: clipped, network byte order; nout per channel-block) + silent-chunk masks",
+                              "kq_bank_pull_pcm_planes_async") if pcm else
+                             ("audio (nout floats per channel-block)", "kq_bank_pull_planes_async"))}
+
+        host_io = host_io_row(False)
+        host_io_pcm = host_io_row(True)
 
     # Secondary row (1 GPU only): the same workload with compute_n0 switched the other way.  The headline computes
     # the noise estimate of radio.c:383-425 on every channel-block, as the reference's demod threads do, which needs
@@ -756,6 +776,9 @@ def main():
         if host_io:
             host_io["fraction_of_value"] = round(host_io["value"] / max(value, 1e-9), 4)
             out["with_host_io"] = host_io
+        if host_io_pcm:
+            host_io_pcm["fraction_of_value"] = round(host_io_pcm["value"] / max(value, 1e-9), 4)
+            out["with_host_io_pcm"] = host_io_pcm
         if second:
             second["roofline"] = roofline(second["kernel_ms"], bool(second["compute_n0"]), second["fwd"])
             second["note"] = ("the same workload %s compute_n0 (radio.c:383-425, status only): the bank then runs its %s "

@@ -1,0 +1,178 @@
+/* radio_realtime.c -- tens of thousands of receiver channels on ONE GPU, every one of them at 1.0 x the front end's rate: the
+ * reference's operating point (one `radio` process per channel behind one multicast group, main.c:105, README.md:470-477) as
+ * one channel bank fed in small batches.  INTEGRATION.md section B2.
+ *
+ *   radio_realtime [channels [blocks_per_call [seconds [pcm]]]]      defaults 32768 2 3 1
+ *
+ * A 10 MS/s front end with FM carriers 140 kHz apart (rank 0 of radio_fanout.c's stream), N = 16384, decimate 256: a
+ * batch of 2 blocks is 1.64 ms of signal.  The host's loop is the one a live receiver runs --
+ *
+ *   process batch k;  push batch k + 1;  queue the delivery of batch k;  wait for the delivery of batch k - 2
+ *
+ * -- with the input in pinned host memory (what a socket reader fills) and every channel's audio handed back to pinned host
+ * memory after every call, as clipped big-endian int16 PCM words (audio.c:22-28: what send_mono_output puts on the wire) with
+ * the silent-packet masks, or as floats (pcm = 0), plus the status plane.  Set-up is one kq_bank_add_channels call.
+ * Prints the real-time factor (signal time / wall time; >= 1 means the bank keeps up), the host's own time per call and
+ * the delivery rate, and checks a delivered channel: squelch open, the 1 kHz tone's deviation seen.
+ *
+ *   gcc -std=gnu11 -O2 -Iinclude examples/radio_realtime.c -Lka9q_sdr_amd/lib -lka9q_hip \
+ *       -Wl,-rpath,$PWD/ka9q_sdr_amd/lib -L/opt/rocm/lib -lamdhip64 -lm -o radio_realtime
+ * (libamdhip64 only for hipHostMalloc / hipHostFree: pinned memory is the host program's to allocate.)
+ */
+#include <complex.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "ka9q_hip.h"
+
+/* the two HIP runtime calls a host needs for pinned buffers, declared here so that the example builds without the HIP headers */
+extern int hipHostMalloc(void **ptr, size_t size, unsigned flags);
+extern int hipHostFree(void *ptr);
+
+enum { L = 8192, M = 8193, D = 256, SAMPRATE = 10000000, OLEN = L / D };
+#define NEMIT 16
+#define DEVIATION 3000.0
+
+static double now_s(void){
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+static double emitter_freq(int e){ return (e - (NEMIT - 1) / 2.0) * 140000.0; }
+
+int main(int argc, char **argv){
+  unsigned const C = argc > 1 ? (unsigned)atoi(argv[1]) : 32768u;
+  unsigned const B = argc > 2 ? (unsigned)atoi(argv[2]) : 2u;
+  double const seconds = argc > 3 ? atof(argv[3]) : 3.0;
+  int const pcm = argc > 4 ? atoi(argv[4]) : 1;
+  if(C == 0 || B == 0 || B > 64)
+    return 2;
+  if(kq_abi_version() != KQ_ABI_VERSION || kq_device_count() <= 0){
+    fprintf(stderr, "library / device: %s\n", kq_last_error());
+    return 2;
+  }
+  /* ---- the bank and its channels: channel c listens to emitter c mod NEMIT, a few Hz off so that no two LOs are equal */
+  kq_bank_config bc = { .device = 0, .samprate = SAMPRATE, .L = L, .M = M, .decimate = D, .max_channels = C, .max_blocks = B,
+                        .gain_factor = 1.0f, .compute_n0 = 1, .fwd_mode = KQ_FWD_AUTO, .pl_tone_off = 1 };
+  double t0 = now_s();
+  kq_bank *bank = kq_bank_create(&bc);
+  if(!bank){
+    fprintf(stderr, "kq_bank_create: %s\n", kq_last_error());
+    return 1;
+  }
+  kq_channel_config *cc = calloc(C, sizeof *cc);
+  for(unsigned c = 0; c < C; c++)
+    cc[c] = (kq_channel_config){ .demod_type = KQ_FM_DEMOD, .channels = 1, .low = -8000, .high = 8000, .kaiser_beta = 3.0f,
+                                 .headroom = 0.1778f, .second_lo = -(emitter_freq(c % NEMIT) + (c / NEMIT) * 0.25) };
+  if(kq_bank_add_channels(bank, cc, C, NULL) != (int)C){
+    fprintf(stderr, "kq_bank_add_channels: %s\n", kq_last_error());
+    return 1;
+  }
+  free(cc);
+  printf("%u FM channels set up in %.2f s\n", C, now_s() - t0);
+
+  /* ---- pinned host memory: one batch of input (a live receiver has a ring of them), three sets of output planes */
+  size_t const nin = (size_t)B * L, rows = (size_t)C * B;
+  float complex *in = NULL;
+  void *out[3], *st[3];
+  uint32_t *mask[3];
+  size_t const out_bytes = rows * 2 * OLEN * (pcm ? sizeof(int16_t) : sizeof(float));
+  int bad = hipHostMalloc((void **)&in, nin * sizeof *in, 0);
+  for(int i = 0; i < 3; i++)
+    bad |= hipHostMalloc(&out[i], out_bytes, 0) | hipHostMalloc(&st[i], rows * sizeof(kq_chan_status), 0) |
+           hipHostMalloc((void **)&mask[i], rows * sizeof(uint32_t), 0);
+  if(bad){
+    fprintf(stderr, "hipHostMalloc failed\n");
+    return 1;
+  }
+  double phase[NEMIT] = {0};
+  unsigned lcg = 2024u;
+  for(size_t i = 0; i < nin; i++){
+    double const t = (double)i / SAMPRATE;
+    float complex s = 0;
+    for(int e = 0; e < NEMIT; e++){
+      phase[e] += 2 * M_PI * (emitter_freq(e) + DEVIATION * cos(2 * M_PI * 1000. * t)) / SAMPRATE;
+      s += 0.04f * ((float)cos(phase[e]) + (float)sin(phase[e]) * I);
+    }
+    lcg = lcg * 1664525u + 1013904223u;
+    float const nr = ((lcg >> 8) & 0xffff) / 65536.f - 0.5f;
+    lcg = lcg * 1664525u + 1013904223u;
+    float const ni = ((lcg >> 8) & 0xffff) / 65536.f - 0.5f;
+    in[i] = s + 2e-3f * (nr + ni * I);
+  }
+
+  /* ---- the receiver's loop (the same batch over and over: the stream is synthetic, the work is not) */
+  double const signal_s = (double)B * L / SAMPRATE;
+  long calls = 0, warm = 50;
+  kq_host_timing ht;
+  int rc = 0;
+  if(kq_bank_push_iq_async(bank, in, nin, KQ_IQ_CF32) != 0)
+    rc = 1;
+  for(long k = 0; rc == 0; k++){
+    if(k == warm){                      /* clocks up, every buffer touched once */
+      kq_bank_host_io_wait(bank);
+      kq_bank_get_host_timing(bank, &ht, 1);
+      t0 = now_s();
+    }
+    int const j = (int)(k % 3);
+    if(kq_bank_process(bank) != (int)B || kq_bank_push_iq_async(bank, in, nin, KQ_IQ_CF32) != 0)
+      rc = 1;
+    else if(pcm ? kq_bank_pull_pcm_planes_async(bank, out[j], mask[j], st[j]) : kq_bank_pull_planes_async(bank, out[j], st[j]))
+      rc = 1;
+    else if(kq_bank_pull_wait(bank, 2) != 0)      /* delivery k - 2 has landed: out[(k - 2) % 3] is the host's to read */
+      rc = 1;
+    if(k >= warm){
+      calls++;
+      if(now_s() - t0 >= seconds)
+        break;
+    }
+  }
+  if(rc != 0 || kq_bank_host_io_wait(bank) != 0){
+    fprintf(stderr, "receiver loop: %s\n", kq_last_error());
+    return 1;
+  }
+  double const wall = now_s() - t0;
+  kq_bank_get_host_timing(bank, &ht, 0);
+  double const per_call = wall / calls;
+  double const d2h = (double)rows * (OLEN * (pcm ? 2 : 4) + sizeof(kq_chan_status) + (pcm ? 4 : 0));
+  printf("%u channels x %u blocks per call (%.3f ms of signal): %.4f ms per call over %ld calls = %.3f x real time\n", C, B,
+         signal_s * 1e3, per_call * 1e3, calls, signal_s / per_call);
+  printf("host inside kq_bank_process: %.4f ms per call (per-channel staging %.4f); delivered %s + status: %.2f GB/s\n",
+         ht.call_ms / (double)ht.calls, ht.stage_ms / (double)ht.calls, pcm ? "int16 PCM" : "float audio", d2h / per_call / 1e9);
+
+  /* ---- a delivered plane: every channel reports olen samples per block; channel 5 sits on a carrier */
+  int const jl = (int)((warm + calls - 1 + 0) % 3);
+  const kq_chan_status *s = st[jl];
+  unsigned open = 0;
+  for(size_t r = 0; r < rows; r++){
+    if(s[r].nout != OLEN)
+      rc = 3;
+    open += s[r].squelch_count < 2;
+  }
+  kq_chan_status const *s5 = &s[(size_t)(5 % C) * B];
+  printf("last delivery: %u of %zu channel-blocks with the squelch open; channel %u: snr %.0f, pdeviation %.0f Hz, n0 %.3g\n",
+         open, rows, 5 % C, s5->snr, s5->pdeviation, s5->n0);
+  if(open != rows || !(s5->snr > 20.f) || !(s5->pdeviation > 0.3f * DEVIATION && s5->pdeviation < 2.f * DEVIATION))
+    rc = 4;
+  if(pcm){                                       /* the PCM words of an open FM channel are not silence */
+    const int16_t *w = (const int16_t *)out[jl] + (size_t)(5 % C) * B * 2 * OLEN;
+    int nz = 0;
+    for(int i = 0; i < OLEN; i++)
+      nz += w[i] != 0;
+    if(nz == 0 || mask[jl][(size_t)(5 % C) * B] != 0)
+      rc = 5;
+  }
+  kq_bank_destroy(bank);
+  hipHostFree(in);
+  for(int i = 0; i < 3; i++){
+    hipHostFree(out[i]);
+    hipHostFree(st[i]);
+    hipHostFree(mask[i]);
+  }
+  puts(rc == 0 ? "ok" : "unexpected result");
+  return rc;
+}

@@ -46,7 +46,15 @@ typedef struct kq_bank kq_bank;   /* opaque */
 
 /* Bank geometry: replaces the arguments of create_filter_input(L, M, COMPLEX) (filter.c:54,
  * called from main.c:232) plus demod->filter.decimate and demod->input.samprate
- * (radio_status.c:264-267), which the reference keeps per process. */
+ * (radio_status.c:264-267), which the reference keeps per process.
+ * Limits (deviations from the reference, which hands any L / M to FFTW -- main.c:160-170, filter.c:78,132):
+ *   - N = L + M - 1 and N / decimate must be powers of two (the reference's default, N = 8192, is one); decimate must
+ *     divide N, L and M - 1 (the reference only warns when it does not, filter.c:106-107);
+ *   - the full-spectrum forward path (compute_n0 = 1) serves N <= 16384 and N = 65536; N = 32768 only without compute_n0;
+ *   - at most 64 carrier-tracking channels (kq_channel_config.pll, linear.c:129-246) per bank -- each keeps a 65536-sample
+ *     search ring; kq_bank_add_channel / kq_bank_set_mode return -1 beyond that;
+ *   - FM channels need N / decimate <= 8192 (the post-detection filter lives in one CU's LDS).
+ * Nothing limits max_channels but memory (~3 KiB per channel + the planes): banks of 34560 channels run in the bench. */
 typedef struct kq_bank_config {
   int device;              /* HIP device ordinal.  A handle stays on its device: every call taking the handle runs
                             * there and restores the calling thread's current device, so one process can drive

@@ -383,3 +383,17 @@ def test_digital_silence_at_65536_points(gpu):
             if b < 2:
                 assert not np.any(bank.filter_output(c, b)) and np.isnan(ws["n0"])
     bank.close()
+
+
+def test_soak64k_smoke(gpu):
+    """tools/soak64k.py with 300 calls: N = 65536 banks with compute_n0 created and destroyed thirty times
+    without leaking device memory, one stepped 300 times with kq_bank_sync never reporting a lost sibling workgroup and
+    the same block giving the same output at the end as at the start, then the streaming host I/O over 200 steps queued
+    without a host wait and checked bit for bit against the blocking pulls.  A child process: its own HIP context."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak64k.py"), "300"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert r.stdout.strip().splitlines()[-1] == "soak ok", r.stdout[-2000:]

@@ -324,10 +324,10 @@ def measure_channels_at_realtime(torch, kq, wl, dev_index, stream, seconds):
     trials = []
     probe = measure_realtime(torch, kq, wl, "cfg4", 32768, 2, dev_index, stream, seconds=1.5)
     trials.append(probe)
-    C = int(32768 * probe["realtime_factor"] * 0.995) // 256 * 256
+    C = int(32768 * probe["realtime_factor"] * 0.985) // 256 * 256     # 1.5 % under the short run's rate: the long run has to HOLD it
     best = None
     for _ in range(4):
-        r = measure_realtime(torch, kq, wl, "cfg4", C, 2, dev_index, stream, seconds=seconds)
+        r = measure_realtime(torch, kq, wl, "cfg4", C, 2, dev_index, stream, seconds=1.05 * seconds)
         trials.append(r)
         if r["realtime_factor"] >= 1.0:
             best = r

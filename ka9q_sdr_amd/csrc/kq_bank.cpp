@@ -112,6 +112,8 @@ struct HostChan {
   std::vector<kq::cfloat> resp, aresp;
   float noise_gain;
   int n0slot = -1;  // which of the bank's compute_n0 mask sets this channel uses (shared by all channels with its edges)
+  bool patched = false;  // an oscillator of this channel has been set since the last call (it is on the bank's patch list)
+  double r_eff = 0;      // sweep of its input oscillators as the launch decisions last saw it (cycles / sample^2)
 };
 
 struct EventPair {
@@ -228,7 +230,17 @@ struct kq_bank {
   // no channel has `retuned` set, and the cached launch decisions below still hold.
   bool osc_dirty = true;
   int64_t planes_n_w = 0, planes_out_abs = 0, rebased_at = 0;
-  bool cache_any = false, cache_plain = true, cache_swept64k = false, cache_swept_pruned = false;
+  bool cache_any = false;
+  // Retunes (kq_bank_set_second_lo / _doppler / _shift) leave the steady state intact: the channels touched since the last
+  // call are on patch_list, and the next call advances everybody on the device as usual and then overwrites just those
+  // channels' planes from a few records staged by the host (k_patch_planes) -- a receiver that tracks Doppler on thousands
+  // of channels retunes some of them before almost every call, and staging all channels for that cost 55 us and 0.4 ms of
+  // host time per call at 32768 channels.  Beyond kMaxPatch channels per call the whole bank is staged as before.
+  static constexpr int kMaxPatch = 1024;
+  static constexpr size_t kPatchBytes = 72;  // one record: channel index (8 bytes), then the channel's eight plane values
+  std::vector<int> patch_list;
+  size_t patch_off = 0;                       // of the patch records inside a staging slot
+  int n_swept = 0, n_fast = 0;                // active channels with a sweep / with one beyond the N = 65536 table path's reach
   int64_t n_abs = 0;        // absolute index of the first new (not yet processed) sample
   int64_t out_abs = 0;      // absolute index of the next output sample
   unsigned last_blocks = 0;
@@ -529,8 +541,45 @@ struct Scope {
 // Per-call parameters: oscillator phase/step/sweep for a call whose first window starts at absolute
 // sample n_w, the shift oscillator at the first output sample, and the IF-power update flags.
 // Filled into the next pinned staging slot (returned in *slot_out); the first kernel of the call copies it to the device.
+// the eight plane values of one channel for a call whose first window starts at absolute sample n_w:
+// out = {phase, step, sweep, shift phase, shift step, history phase, history step, history sweep}
+void eval_planes(const kq_bank *b, const HostChan &h, int64_t n_w, double out[8]) {
+  double p = h.lo2.phase_at(n_w), f = h.lo2.step_at(n_w), r = h.lo2.sweep();
+  if (h.dop.set_f != 0) {  // radio.c:135: the Doppler NCO is applied only while its frequency is non-zero
+    p += h.dop.phase_at(n_w);
+    f += h.dop.step_at(n_w);
+    r += h.dop.sweep();
+  }
+  out[0] = p - std::floor(p);
+  out[1] = f;
+  out[2] = r;
+  double const q = h.shift.phase_at(b->out_abs);
+  out[3] = q - std::floor(q);
+  out[4] = h.shift.step_at(b->out_abs);
+  if (h.retuned) {  // history of the first block keeps the pre-retune oscillators
+    double q2 = h.lo2_old.phase_at(n_w), g2 = h.lo2_old.step_at(n_w), r2 = h.lo2_old.sweep();
+    if (h.dop_old.set_f != 0) {
+      q2 += h.dop_old.phase_at(n_w);
+      g2 += h.dop_old.step_at(n_w);
+      r2 += h.dop_old.sweep();
+    }
+    out[5] = q2 - std::floor(q2);
+    out[6] = g2;
+    out[7] = r2;
+  } else {
+    out[5] = out[0];
+    out[6] = f;
+    out[7] = r;
+  }
+}
+
+// Per-call parameters: oscillator phase/step/sweep for a call whose first window starts at absolute
+// sample n_w, the shift oscillator at the first output sample, and the IF-power update flags.
+// Filled into the next pinned staging slot (returned in *slot_out); the first kernel of the call copies it to the device.
+// steady: the planes are advanced on the device from the call before; only the flags, the retune list and the patch
+// records of the channels on b->patch_list travel (*npatch_out of them).
 int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsigned nblocks, int *slot_out, int *nret_out,
-                      bool steady) {
+                      bool steady, int *npatch_out) {
   size_t const C = b->chans.size(), Cmax = b->cfg.max_channels;
   int const slot = b->stage_next;
   b->stage_next = (slot + 1) % kq_bank::kSlots;
@@ -540,54 +589,37 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
   b->host_acc.slot_wait_ms += std::chrono::duration<double, std::milli>(tw1 - tw0).count();
   if (harvest_slot(b, slot)) return -1;
   double *pl = reinterpret_cast<double *>(b->stage_host[slot]);
-  double *ph = pl, *fr = pl + Cmax, *rt = pl + 2 * Cmax, *sp = pl + 3 * Cmax, *sf = pl + 4 * Cmax;
-  double *hph = pl + 5 * Cmax, *hfr = pl + 6 * Cmax, *hrt = pl + 7 * Cmax;
-  if (steady) {  // the planes are advanced on the device from the call before; only the flags travel
-    memcpy(b->stage_host[slot] + 8 * Cmax * sizeof(double), update, nblocks);
-    *nret_out = 0;
-    *slot_out = slot;
-    b->host_acc.stage_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count();
-    return 0;
-  }
-  for (size_t c = 0; c < C; c++) {
-    HostChan const &h = b->chans[c];
-    double p = h.lo2.phase_at(n_w), f = h.lo2.step_at(n_w), r = h.lo2.sweep();
-    if (h.dop.set_f != 0) {  // radio.c:135: the Doppler NCO is applied only while its frequency is non-zero
-      p += h.dop.phase_at(n_w);
-      f += h.dop.step_at(n_w);
-      r += h.dop.sweep();
-    }
-    ph[c] = p - std::floor(p);
-    fr[c] = f;
-    rt[c] = r;
-    if (h.retuned) {  // history of the first block keeps the pre-retune oscillators
-      double q = h.lo2_old.phase_at(n_w), g2 = h.lo2_old.step_at(n_w), r2 = h.lo2_old.sweep();
-      if (h.dop_old.set_f != 0) {
-        q += h.dop_old.phase_at(n_w);
-        g2 += h.dop_old.step_at(n_w);
-        r2 += h.dop_old.sweep();
-      }
-      hph[c] = q - std::floor(q);
-      hfr[c] = g2;
-      hrt[c] = r2;
-    } else {
-      hph[c] = ph[c];
-      hfr[c] = f;
-      hrt[c] = r;
-    }
-    double q = h.shift.phase_at(b->out_abs);
-    sp[c] = q - std::floor(q);
-    sf[c] = h.shift.step_at(b->out_abs);
-  }
   unsigned char *flags = b->stage_host[slot] + 8 * Cmax * sizeof(double);
   memcpy(flags, update, nblocks);
   // the per-block flags sit right behind the eight oscillator planes, in the staging slot and on the device; behind
   // them the channels retuned since the last call (their first block is redone on the per-sample path)
   int *ret = reinterpret_cast<int *>(flags + ((b->cfg.max_blocks + 7) & ~7u));
-  int nret = 0;
-  for (size_t c = 0; c < C; c++)
-    if (b->chans[c].active && b->chans[c].retuned) ret[nret++] = (int)c;
+  int nret = 0, npatch = 0;
+  if (steady) {
+    unsigned char *rec = b->stage_host[slot] + b->patch_off;
+    for (int c : b->patch_list) {
+      HostChan const &h = b->chans[c];
+      if (!h.active) continue;
+      long long const idx = c;
+      memcpy(rec, &idx, sizeof idx);
+      double v[8];
+      eval_planes(b, h, n_w, v);
+      memcpy(rec + 8, v, sizeof v);
+      rec += kq_bank::kPatchBytes;
+      npatch++;
+      if (h.retuned) ret[nret++] = c;
+    }
+  } else {
+    for (size_t c = 0; c < C; c++) {
+      double v[8];
+      eval_planes(b, b->chans[c], n_w, v);
+      for (int k = 0; k < 8; k++) pl[(size_t)k * Cmax + c] = v[k];
+    }
+    for (size_t c = 0; c < C; c++)
+      if (b->chans[c].active && b->chans[c].retuned) ret[nret++] = (int)c;
+  }
   *nret_out = nret;
+  *npatch_out = npatch;
   *slot_out = slot;
   b->host_acc.stage_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count();
   return 0;
@@ -642,7 +674,8 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   int const C = (int)b->chans.size();
   // Per-channel decisions are taken afresh only when something about the channels or their oscillators has changed since
   // the call before (osc_dirty); a steady call walks no per-channel state on the host.
-  static bool const steady_off = getenv("KQ_STEADY") && atoi(getenv("KQ_STEADY")) == 0;  // A/B switch: stage every call on the host
+  const char *const steady_env = getenv("KQ_STEADY");  // A/B switch, read per call: 0 = stage every call on the host
+  bool const steady_off = steady_env && atoi(steady_env) == 0;
   bool const steady = !b->osc_dirty && !spectrum && b->calls > 0 && !steady_off;
   if (!steady) {
     bool any = false;
@@ -654,29 +687,48 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     return -1;
   }
   if (b->lists_dirty && upload_lists(b)) return -1;
+  // Launch decisions that depend on the channels' sweeps: counted over all channels when the bank is staged afresh, kept up
+  // to date from the patch list otherwise.
+  auto const sweep_of = [](HostChan const &h) { return h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0); };
+  auto const sweep_ok = [&](double r) {  // the pruned forward path's limits on a swept oscillator
+    if (b->fwd_mode != KQ_FWD_PRUNED || r == 0) return true;
+    // The pruned kernels take the sweep's cross term r*R*a*b to first order and drop its b^2 part:
+    // both must stay far below the 1e-5 parity budget over one window.
+    double const cross = 2 * M_PI * std::fabs(r) * (double)g.N * g.D, quad = std::fabs(r) * (double)g.D * g.D * 0.5;
+    if (g.Ndec == 256) {
+      set_err("swept NCO at N/D = 256 is only available on the full forward path: use KQ_FWD_FULL");
+      return false;
+    }
+    if (cross > 3e-4 || quad > 2e-7) {
+      set_err("sweep rate too large for the pruned forward path (cross term %.3g rad): use KQ_FWD_FULL", cross);
+      return false;
+    }
+    return true;
+  };
   if (!steady) {
-    bool swept = false;
-    if (b->fwd_mode == KQ_FWD_PRUNED)
-      for (HostChan const &h : b->chans) {
-        if (!h.active) continue;
-        double const r = h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0);
-        if (r == 0) continue;
-        swept = true;
-        // The pruned kernels take the sweep's cross term r*R*a*b to first order and drop its b^2 part:
-        // both must stay far below the 1e-5 parity budget over one window.
-        double const cross = 2 * M_PI * std::fabs(r) * (double)g.N * g.D, quad = std::fabs(r) * (double)g.D * g.D * 0.5;
-        if (g.Ndec == 256) {
-          set_err("swept NCO at N/D = 256 is only available on the full forward path: use KQ_FWD_FULL");
-          return -1;
-        }
-        if (cross > 3e-4 || quad > 2e-7) {
-          set_err("sweep rate too large for the pruned forward path (cross term %.3g rad): use KQ_FWD_FULL", cross);
-          return -1;
-        }
-      }
-    b->cache_swept_pruned = swept;
+    int n_swept = 0, n_fast = 0;
+    for (HostChan &h : b->chans) {
+      if (!h.active) continue;
+      double const r = sweep_of(h);
+      if (!sweep_ok(r)) return -1;
+      h.r_eff = r;
+      n_swept += r != 0;
+      n_fast += std::fabs(r) > kq::full64k_sweep_limit();
+    }
+    b->n_swept = n_swept;
+    b->n_fast = n_fast;
+  } else {
+    for (int c : b->patch_list) {
+      HostChan &h = b->chans[c];
+      if (!h.active) continue;
+      double const r = sweep_of(h);
+      if (!sweep_ok(r)) return -1;
+      b->n_swept += (r != 0) - (h.r_eff != 0);
+      b->n_fast += (std::fabs(r) > kq::full64k_sweep_limit()) - (std::fabs(h.r_eff) > kq::full64k_sweep_limit());
+      h.r_eff = r;
+    }
   }
-  bool const swept = b->cache_swept_pruned;
+  bool const swept = b->fwd_mode == KQ_FWD_PRUNED && b->n_swept > 0;
   if (swept) b->chan_tw_dirty = true;  // the step changes from call to call
   int const pp = (int)(b->calls & 1);
   size_t const Cmax = b->cfg.max_channels;
@@ -695,9 +747,9 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   // of idle device even when the event fired long ago -- and two calls later it always has)
   if (b->demod_overlapped[pp] && hipEventQuery(b->ev_demod_done[pp]) != hipSuccess)
     HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[pp], 0));
-  int slot = 0, nret = 0;
+  int slot = 0, nret = 0, npatch = 0;
   int64_t const n_w = b->n_abs - (g.M - 1);
-  if (stage_call_params(b, n_w, update_host, nblocks, &slot, &nret, steady)) return -1;
+  if (stage_call_params(b, n_w, update_host, nblocks, &slot, &nret, steady, &npatch)) return -1;
   size_t const ret_off = 8 * Cmax * sizeof(double) + ((b->cfg.max_blocks + 7) & ~7u);
   const int *retune_list = reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(b->osc_dev2[pp]) + ret_off);
   // full-spectrum path: the register-resident N = 16384 kernel where it applies (KQ_FULL_LDS=1 forces the LDS one)
@@ -706,23 +758,9 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   // No sweep anywhere: the register-resident kernel runs without its per-sample oscillator path; the first block of
   // a channel retuned since the last call (history still on the old oscillator) is then redone below with the
   // general variant, as the pruned path does.
-  if (!steady) {
-    bool plain = true;
-    bool swept64k = false;  // N = 65536: the steady-state variant takes sweeps up to full64k_sweep_limit() itself
-    for (HostChan const &h : b->chans) {
-      if (!h.active) continue;
-      double const r = h.lo2.sweep() + (h.dop.set_f != 0 ? h.dop.sweep() : 0.0);
-      if (b->use64k) {
-        if (r != 0) swept64k = true;
-        if (std::fabs(r) > kq::full64k_sweep_limit()) plain = false;
-      } else if (r != 0) {
-        plain = false;
-      }
-    }
-    b->cache_plain = plain;
-    b->cache_swept64k = swept64k;
-  }
-  bool const plain = b->cache_plain, swept64k = b->cache_swept64k;
+  // (N = 65536: the steady-state variant takes sweeps up to full64k_sweep_limit() itself)
+  bool const plain = b->use64k ? b->n_fast == 0 : b->n_swept == 0;
+  bool const swept64k = b->use64k && b->n_swept > 0;
   // That steady-state variant loads its samples 16 bytes at a time from a copy of the call's samples whose 512-sample
   // rows are interleaved in pairs; the IF-power kernel, which reads every new sample anyway, writes it
   float2 *const paired = ((use16k || b->use64k) && plain && b->win_paired && b->fwd_mode != KQ_FWD_PRUNED) ? b->win_paired : nullptr;
@@ -737,6 +775,8 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
                                 spectrum ? nullptr : paired, (int)(g.M - 1), steady ? b->osc_dev2[pp ^ 1] : nullptr, (unsigned)C,
                                 (unsigned)Cmax, (double)(n_w - b->planes_n_w), (double)(b->out_abs - b->planes_out_abs));
   }
+  if (npatch > 0)  // the channels retuned since the last call: their planes, staged by the host, over the advanced ones
+    kq::launch_patch_planes(b->stream, b->stage_host[slot] + b->patch_off, b->osc_dev2[pp], npatch, (unsigned)Cmax);
   LAUNCH_CHECK("IF power");
   if (b->timing) {
     HIP_TRY(hipEventRecord(b->stage_t0[slot], b->stream));
@@ -882,6 +922,12 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   b->planes_out_abs = b->out_abs;
   b->n_abs += (int64_t)nblocks * g.L;
   b->out_abs += (int64_t)nblocks * g.olen;
+  for (int c : b->patch_list)
+    if ((size_t)c < b->chans.size()) {
+      b->chans[c].patched = false;
+      b->chans[c].retuned = false;
+    }
+  b->patch_list.clear();
   if (!steady) {
     for (HostChan &h : b->chans) {
       h.retuned = false;
@@ -1093,6 +1139,8 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     rc = -1;
   }
   b->stage_bytes = 8 * C * sizeof(double) + ((B + 7) & ~(size_t)7) + ((C * sizeof(int) + 7) & ~(size_t)7);  // copied in 8-byte words
+  b->patch_off = b->stage_bytes;               // the retune patches' records (never copied as a whole: k_patch_planes reads them)
+  b->stage_bytes += (size_t)kq_bank::kMaxPatch * kq_bank::kPatchBytes;
   for (int k = 0; k < kq_bank::kSlots && !rc; k++) {
     if (hipHostMalloc((void **)&b->stage_host[k], b->stage_bytes, hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&b->stage_ev[k]) != hipSuccess || hipEventCreate(&b->stage_t0[k]) != hipSuccess) {
@@ -1580,6 +1628,7 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
   }
   h.active = false;
   h.retuned = false;
+  h.patched = false;  // (its entry on the patch list, if any, is skipped: the next call stages the whole bank)
   release_n0slot(b, h.n0slot);
   h.n0slot = -1;
   h.lo2 = h.dop = h.shift = h.lo2_old = h.dop_old = Osc{};
@@ -1672,6 +1721,18 @@ int kq_bank_set_linear_options(kq_bank *b, int ch, int isb, int channels) {
   return 0;
 }
 
+// an oscillator of channel `ch` has been set: the next call patches its planes (or, with too many of them, stages the bank)
+static void note_patch(kq_bank *b, int ch) {
+  HostChan &h = b->chans[ch];
+  if (h.patched) return;
+  if ((int)b->patch_list.size() >= kq_bank::kMaxPatch) {
+    b->osc_dirty = true;
+    return;
+  }
+  h.patched = true;
+  b->patch_list.push_back(ch);
+}
+
 int kq_bank_set_second_lo(kq_bank *b, int ch, double hz) {
   kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!valid_ch(b, ch) || std::isnan(hz)) {
@@ -1686,7 +1747,7 @@ int kq_bank_set_second_lo(kq_bank *b, int ch, double hz) {
   b->chans[ch].cfg.second_lo = hz;
   b->chans[ch].lo2.set(hz == 0 ? 0.0 : hz / b->g.samprate, 0.0, b->n_abs);
   b->chan_tw_dirty = true;
-  b->osc_dirty = true;
+  note_patch(b, ch);
   return 0;
 }
 
@@ -1706,7 +1767,7 @@ int kq_bank_set_doppler(kq_bank *b, int ch, double hz, double hz_per_s) {
   b->chans[ch].cfg.doppler_rate = hz_per_s;
   b->chans[ch].dop.set(-hz / fs, -hz_per_s / (fs * fs), b->n_abs);
   b->chan_tw_dirty = true;
-  b->osc_dirty = true;
+  note_patch(b, ch);
   return 0;
 }
 
@@ -1718,7 +1779,7 @@ int kq_bank_set_shift(kq_bank *b, int ch, double hz) {
   }
   b->chans[ch].cfg.shift = hz;
   b->chans[ch].shift.set(hz == 0 ? 0.0 : hz * b->g.D / (double)b->g.samprate, 0.0, b->out_abs);
-  b->osc_dirty = true;
+  note_patch(b, ch);
   return 0;
 }
 

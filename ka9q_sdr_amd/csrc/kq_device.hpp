@@ -128,6 +128,7 @@ int block_energy_split(int L);
 void launch_block_energy_sum(hipStream_t s, const float2 *newsamples, int L, int nblocks, float *sums, const void *params_host,
                              void *params_dev, size_t params_bytes, float2 *paired, int hist, const double *prev_planes = nullptr,
                              unsigned nchan = 0, unsigned cmax = 0, double adv = 0, double adv_out = 0);
+void launch_patch_planes(hipStream_t s, const void *records_host, void *planes_dev, int npatch, unsigned cmax);
 void launch_block_energy_iir(hipStream_t s, const float *sums, int L, int nblocks, const unsigned char *update, float *energy_state,
                              float *if_power);
 void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,

@@ -207,6 +207,24 @@ void launch_block_energy_sum(hipStream_t s, const float2 *newsamples, int L, int
                      nwords, copy_wgs, paired, hist, prev_planes, nchan, cmax, adv, adv_out);
 }
 
+// The planes of the channels retuned since the last call (kq_bank.cpp: patch_list), staged by the host as records of
+// (channel index, eight values) in pinned memory, written over what k_block_energy_sum has just advanced.  One thread per
+// record; launched only for a call that follows a retune.
+__global__ void k_patch_planes(const unsigned long long *__restrict__ rec_host, double *__restrict__ planes, int npatch,
+                               unsigned cmax) {
+  int const j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= npatch) return;
+  const unsigned long long *r = rec_host + (size_t)j * 9;
+  unsigned const c = (unsigned)r[0];
+  if (c >= cmax) return;
+#pragma unroll
+  for (int k = 0; k < 8; k++) planes[(size_t)k * cmax + c] = __longlong_as_double((long long)r[1 + k]);
+}
+void launch_patch_planes(hipStream_t s, const void *records_host, void *planes_dev, int npatch, unsigned cmax) {
+  hipLaunchKernelGGL(k_patch_planes, dim3((npatch + 255) / 256), dim3(256), 0, s, static_cast<const unsigned long long *>(records_host),
+                     static_cast<double *>(planes_dev), npatch, cmax);
+}
+
 void launch_block_energy_iir(hipStream_t s, const float *sums, int L, int nblocks, const unsigned char *update, float *energy_state,
                              float *if_power) {
   hipLaunchKernelGGL(k_block_energy_iir, dim3(1), dim3(64), 0, s, sums, block_energy_split(L), update, nblocks, L, energy_state,

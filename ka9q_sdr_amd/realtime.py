@@ -27,11 +27,14 @@ def build_bank(kq, wl, config, C, B, dev_index, stream, compute_n0=True):
     return bank, plan, time.perf_counter() - t0
 
 
-def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.0, host_io=True, pcm=False, warm_calls=50):
+def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.0, host_io=True, pcm=False, warm_calls=50,
+                     retunes_per_call=0):
     """C channels, B blocks per call, for `seconds` of wall time.  host_io: input from pinned host memory, audio (float, or
     the int16 PCM words when pcm) + status planes to pinned host memory after every call into one of three buffer sets; the
     host waits for the planes of call k-2 once it has queued call k (it never runs more than two deliveries ahead of what it
-    has in hand, so a buffer set is never overwritten before it has landed)."""
+    has in hand, so a buffer set is never overwritten before it has landed).  retunes_per_call > 0: that many channels get
+    a new second LO before every call (kq_bank_set_second_lo, 1 Hz to and fro) -- every call then stages all channels'
+    oscillators on the host and carries them over the link, the path a call without retunes skips."""
     geom = dict(wl.GEOMETRY[config])
     L, M, D, fs = geom["L"], geom["M"], geom["D"], geom["samprate"]
     olen = L // D
@@ -53,6 +56,9 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
         out_bytes = nout_words * (2 if pcm else 4) + stats[0].numel() + (4 * C * B if pcm else 0)
 
         def call(k):
+            for i in range(retunes_per_call):
+                c = (k * 7919 + i * 104729) % C
+                bank.set_second_lo(c, plan[c]["second_lo"] + (1.0 if k & 1 else 0.0))
             assert bank.process() == B
             bank.push_iq_async(iq_pin.data_ptr(), B * L)
             j = k % nbuf
@@ -115,4 +121,4 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
             "host_io": ("pcm int16 + status" if pcm else "float audio + status") if host_io else None,
             "d2h_bytes_per_call": out_bytes, "d2h_GBps": round(out_bytes / dt / 1e9, 3),
             "h2d_bytes_per_call": B * L * 8 if host_io else 0,
-            "setup_s": round(setup_s, 2), "check": checksum}
+            "retunes_per_call": retunes_per_call, "setup_s": round(setup_s, 2), "check": checksum}

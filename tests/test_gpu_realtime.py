@@ -172,10 +172,12 @@ def test_batched_add_is_the_same_as_adding_one_by_one(gpu):
 
 @pytest.mark.parametrize("geom", ["n1024", "cfg4", "cfg5"])
 def test_steady_state_planes_advanced_on_the_device(gpu, geom):
-    """A call that follows a call with nothing set in between takes its oscillator planes from the device (advanced in
-    closed form by k_block_energy_sum) instead of from the host.  Same audio as a bank whose every call is staged by the
-    host (forced by re-setting one channel's shift to the value it has), through sweeps, shifts, a retune and a channel
-    leaving; integer state identical."""
+    """A call that follows a call with no channel added or removed takes its oscillator planes from the device (advanced in
+    closed form by k_block_energy_sum; the channels retuned in between are patched from a few records, k_patch_planes)
+    instead of from the host.  Same audio as a bank whose every call is staged by the host (KQ_STEADY=0, read per call),
+    through sweeps, shifts, retunes of the second LO, the Doppler and the shift oscillator, and a channel leaving; integer
+    state identical."""
+    import os
     if geom == "n1024":
         g = dict(samprate=192000, L=512, M=513, D=4)
         plan = _mixed_plan(g["samprate"], 12)
@@ -196,13 +198,20 @@ def test_steady_state_planes_advanced_on_the_device(gpu, geom):
         bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), nb, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL, pl_tone=False)
         bank.add_channels([bank_cfg(p) for p in plan])
         got = []
+        if forced:
+            os.environ["KQ_STEADY"] = "0"
         for k in range(ncalls):
-            if forced:
-                bank.set_shift(0, plan[0].get("shift", 0.0))       # no change of any sequence: the phase is kept (osc.c:24-27)
+            if k == 3:
+                bank.set_shift(4, 250.0)                             # patches: one channel's planes, the others advance on the device
             if k == 4:
                 bank.set_second_lo(2, plan[2]["second_lo"] + 750.0)  # a retune on the way: its first block keeps the old LO in the history
+                bank.set_second_lo(7, plan[7]["second_lo"] - 320.0)
+            if k == 5 and geom != "cfg5":
+                bank.set_doppler(3, 900.0, 0.0)                      # a Doppler oscillator that was off comes on (radio.c:135)
             if k == 6:
                 bank.remove_channel(5)
+            if k == 7:
+                bank.set_doppler(1, plan[1].get("doppler", 0.0) + 40.0, plan[1].get("doppler_rate", 0.0))
             bank.push_iq(iq[k * nb * L:(k + 1) * nb * L])
             assert bank.process() == nb
             live = [c for c in range(len(plan)) if bank.channel_active(c)]
@@ -210,6 +219,7 @@ def test_steady_state_planes_advanced_on_the_device(gpu, geom):
         ht = bank.host_timing()
         outs.append((got, ht))
         bank.close()
+        os.environ.pop("KQ_STEADY", None)
     (a, ha), (b, hb) = outs
     assert ha["calls"] == hb["calls"] == ncalls
     for k in range(ncalls):

@@ -241,6 +241,13 @@ struct kq_bank {
   std::vector<int> patch_list;
   size_t patch_off = 0;                       // of the patch records inside a staging slot
   int n_swept = 0, n_fast = 0;                // active channels with a sweep / with one beyond the N = 65536 table path's reach
+  int n_active = 0;
+  // N = 16384, some channels swept (satellite passes in a bank of fixed-frequency channels): the unswept ones still run the
+  // steady-state variant of the kernel (16-byte loads from the row-paired copy, no per-sample oscillator path), the swept
+  // ones the general variant, as two launches over two channel lists -- one swept channel used to cost the whole bank 6 %
+  int *list_unswept_dev = nullptr, *list_swept_dev = nullptr;
+  std::vector<int> list_unswept_host, list_swept_host;
+  bool sweep_lists_dirty = true;
   int64_t n_abs = 0;        // absolute index of the first new (not yet processed) sample
   int64_t out_abs = 0;      // absolute index of the next output sample
   unsigned last_blocks = 0;
@@ -706,23 +713,27 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     return true;
   };
   if (!steady) {
-    int n_swept = 0, n_fast = 0;
+    int n_swept = 0, n_fast = 0, n_active = 0;
     for (HostChan &h : b->chans) {
       if (!h.active) continue;
       double const r = sweep_of(h);
       if (!sweep_ok(r)) return -1;
       h.r_eff = r;
+      n_active++;
       n_swept += r != 0;
       n_fast += std::fabs(r) > kq::full64k_sweep_limit();
     }
     b->n_swept = n_swept;
     b->n_fast = n_fast;
+    b->n_active = n_active;
+    b->sweep_lists_dirty = true;
   } else {
     for (int c : b->patch_list) {
       HostChan &h = b->chans[c];
       if (!h.active) continue;
       double const r = sweep_of(h);
       if (!sweep_ok(r)) return -1;
+      if ((r != 0) != (h.r_eff != 0)) b->sweep_lists_dirty = true;
       b->n_swept += (r != 0) - (h.r_eff != 0);
       b->n_fast += (std::fabs(r) > kq::full64k_sweep_limit()) - (std::fabs(h.r_eff) > kq::full64k_sweep_limit());
       h.r_eff = r;
@@ -761,9 +772,21 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   // (N = 65536: the steady-state variant takes sweeps up to full64k_sweep_limit() itself)
   bool const plain = b->use64k ? b->n_fast == 0 : b->n_swept == 0;
   bool const swept64k = b->use64k && b->n_swept > 0;
+  // N = 16384 with swept and unswept channels side by side: two launches over two lists (see list_unswept_dev)
+  bool const mixed = use16k && !b->use64k && b->fwd_mode != KQ_FWD_PRUNED && !spectrum && b->n_swept > 0 && b->n_swept < b->n_active;
+  if (mixed && b->sweep_lists_dirty) {
+    b->list_unswept_host.clear();
+    b->list_swept_host.clear();
+    for (size_t c = 0; c < b->chans.size(); c++)
+      if (b->chans[c].active) (b->chans[c].r_eff != 0 ? b->list_swept_host : b->list_unswept_host).push_back((int)c);
+    // (pageable source: the copy is staged before the call returns; on the bank's stream, behind the launches that read the old lists)
+    if (upload(b, b->list_unswept_dev, b->list_unswept_host.data(), b->list_unswept_host.size() * sizeof(int))) return -1;
+    if (upload(b, b->list_swept_dev, b->list_swept_host.data(), b->list_swept_host.size() * sizeof(int))) return -1;
+    b->sweep_lists_dirty = false;
+  }
   // That steady-state variant loads its samples 16 bytes at a time from a copy of the call's samples whose 512-sample
   // rows are interleaved in pairs; the IF-power kernel, which reads every new sample anyway, writes it
-  float2 *const paired = ((use16k || b->use64k) && plain && b->win_paired && b->fwd_mode != KQ_FWD_PRUNED) ? b->win_paired : nullptr;
+  float2 *const paired = ((use16k || b->use64k) && (plain || mixed) && b->win_paired && b->fwd_mode != KQ_FWD_PRUNED) ? b->win_paired : nullptr;
   {
     Scope t(b, 2, b->stream);
     // the partial sums live behind the plane's max_blocks if_power values
@@ -784,12 +807,13 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   }
   {
     // `redo`: the list names channels retuned since the last call, which need the general variant
+    // (as_plain: the steady-state variant -- the host vouches that no channel of THIS launch sweeps)
     auto const full_launch = [&](hipStream_t st, const kq::Geom &gg, const kq::ChanDev &cd, const kq::Planes &pp, const float2 *win,
                                  const float2 *twp, int nch, int nbl, int n0, float2 *dump, int dump_ch, const int *list,
-                                 bool redo = true) {
+                                 bool redo = true, bool as_plain = false) {
+      bool const pv = !redo && (plain || as_plain);
       if (use16k)
-        kq::launch_filter_full16k(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list, plain && !redo,
-                                  redo ? nullptr : paired, b->big);
+        kq::launch_filter_full16k(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list, pv, pv ? paired : nullptr, b->big);
       else
         kq::launch_filter_full(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list);
     };
@@ -844,9 +868,16 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     } else {
       // slots emptied by remove_channel are skipped: the launch goes over the list of active channels then
       bool const holes = !b->list_active_host.empty();
-      full_launch(b->stream, g, chd, pl, window, b->tw, holes ? (int)b->list_active_host.size() : C, (int)nblocks,
-                  b->cfg.compute_n0, b->spec_dump, b->spec_ch, holes ? b->list_active_dev : nullptr, false);
-      if (use16k && plain && nret > 0)
+      if (mixed) {
+        full_launch(b->stream, g, chd, pl, window, b->tw, (int)b->list_unswept_host.size(), (int)nblocks, b->cfg.compute_n0,
+                    b->spec_dump, b->spec_ch, b->list_unswept_dev, false, true);
+        full_launch(b->stream, g, chd, pl, window, b->tw, (int)b->list_swept_host.size(), (int)nblocks, b->cfg.compute_n0,
+                    b->spec_dump, b->spec_ch, b->list_swept_dev, false, false);
+      } else {
+        full_launch(b->stream, g, chd, pl, window, b->tw, holes ? (int)b->list_active_host.size() : C, (int)nblocks,
+                    b->cfg.compute_n0, b->spec_dump, b->spec_ch, holes ? b->list_active_dev : nullptr, false);
+      }
+      if (use16k && (plain || mixed) && nret > 0)
         full_launch(b->stream, g, chd, pl, window, b->tw, nret, 1, b->cfg.compute_n0, b->spec_dump, b->spec_ch, retune_list);
     }
     LAUNCH_CHECK("pre-detection filter");
@@ -1187,6 +1218,8 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   if (kq::full16k_paired_supported(b->g)) rc |= dev_alloc(&b->win_paired, (size_t)(b->g.M - 1) + (size_t)B * b->g.L);
   for (int k = 0; k < 3; k++) rc |= dev_alloc(&b->list_dev[k], C);
   rc |= dev_alloc(&b->list_active_dev, C);
+  rc |= dev_alloc(&b->list_unswept_dev, C);
+  rc |= dev_alloc(&b->list_swept_dev, C);
   if (b->fwd_mode == KQ_FWD_PRUNED) rc |= dev_alloc(&b->chan_tw, C * kq::pruned_table_elems(g));
   if (rc) {
     kq_bank_destroy(b);
@@ -1242,7 +1275,7 @@ int kq_bank_destroy(kq_bank *b) {
                   b->pl2[0].plout, b->pl2[1].plout, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
                   b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state, b->win_paired,
                   b->big.sync, b->big.n0part, b->big.xs,
-                  b->list_dev[0], b->list_dev[1], b->list_dev[2], b->list_active_dev, b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->list_pll_dev, b->pll_state, b->pll_rings,
+                  b->list_dev[0], b->list_dev[1], b->list_dev[2], b->list_active_dev, b->list_unswept_dev, b->list_swept_dev, b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->list_pll_dev, b->pll_state, b->pll_rings,
                   b->pll_side};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);

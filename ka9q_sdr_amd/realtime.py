@@ -28,7 +28,7 @@ def build_bank(kq, wl, config, C, B, dev_index, stream, compute_n0=True):
 
 
 def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.0, host_io=True, pcm=False, warm_calls=50,
-                     retunes_per_call=0):
+                     retunes_per_call=0, swept_channels=0):
     """C channels, B blocks per call, for `seconds` of wall time.  host_io: input from pinned host memory, audio (float, or
     the int16 PCM words when pcm) + status planes to pinned host memory after every call into one of three buffer sets; the
     host waits for the planes of call k-2 once it has queued call k (it never runs more than two deliveries ahead of what it
@@ -39,6 +39,10 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
     L, M, D, fs = geom["L"], geom["M"], geom["D"], geom["samprate"]
     olen = L // D
     bank, plan, setup_s = build_bank(kq, wl, config, C, B, dev_index, stream)
+    for i in range(swept_channels):      # satellite passes: a Doppler offset with a rate (radio.c:180-184) on some channels
+        c = (i * 7919) % C
+        bank.set_doppler(c, 2000.0 + i, -40.0 - (i % 7))
+        bank.set_second_lo(c, plan[c]["second_lo"] + 2000.0 + i)
     dev = torch.device("cuda", dev_index)
     nwin = (M - 1) + B * L
     iq_host = wl.make_iq(fs, nwin, seed=0x6B613971)
@@ -121,4 +125,4 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
             "host_io": ("pcm int16 + status" if pcm else "float audio + status") if host_io else None,
             "d2h_bytes_per_call": out_bytes, "d2h_GBps": round(out_bytes / dt / 1e9, 3),
             "h2d_bytes_per_call": B * L * 8 if host_io else 0,
-            "retunes_per_call": retunes_per_call, "setup_s": round(setup_s, 2), "check": checksum}
+            "retunes_per_call": retunes_per_call, "swept_channels": swept_channels, "setup_s": round(setup_s, 2), "check": checksum}

@@ -223,6 +223,17 @@ struct kq_bank {
   std::map<std::pair<float, float>, int> n0slot_of;
   std::vector<int> n0slot_refs;                       // per slot; 0 = free
   std::vector<std::pair<float, float>> n0slot_key;    // per slot
+  // Control-plane uploads (per-channel parameters, responses, lists) travel through a pinned ring and are ordered on the
+  // bank's stream: behind the calls in flight, which keep the values they were queued with, and in front of the next call.
+  // The host does not wait for the device (it used to drain both streams around every change: 6 ms per kq_bank_set_filter
+  // on a bank with four 1.5 ms calls in flight, tools/churn_probe.py).  Two halves; entering a half waits for the copies
+  // queued from it the last time round -- long done unless the control plane outruns the device by half a megabyte.
+  static constexpr size_t kCtlRing = 1u << 20;
+  unsigned char *ctl_ring = nullptr;
+  size_t ctl_off = 0;  // next free byte within the current half
+  int ctl_half = 0;
+  hipEvent_t ctl_ev[2] = {nullptr, nullptr};
+  bool ctl_ev_set[2] = {false, false};
   std::vector<HostChan> chans;
   // Steady state of the oscillators: nothing has been set, added or removed since the call before, so the per-call planes
   // follow from that call's on the device (k_block_energy_sum) and the host touches no per-channel state at all.
@@ -277,7 +288,37 @@ int ilog2(unsigned v) {
 int sync_all(kq_bank *b);
 
 int upload(kq_bank *b, void *dst, const void *src, size_t bytes) {
-  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->stream));
+  if (bytes == 0) return 0;
+  if (!b->ctl_ring || bytes > kq_bank::kCtlRing / 2) {  // (a plane larger than half the ring: the plain way)
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+  }
+  size_t const half = kq_bank::kCtlRing / 2;
+  size_t pos = (b->ctl_off + 15) & ~(size_t)15;  // within the current half
+  if (pos + bytes > half) {
+    // into the other half: mark what was queued from the one we leave, wait for what was queued from the one we enter
+    HIP_TRY(hipEventRecord(b->ctl_ev[b->ctl_half], b->stream));
+    b->ctl_ev_set[b->ctl_half] = true;
+    b->ctl_half ^= 1;
+    if (b->ctl_ev_set[b->ctl_half]) HIP_TRY(hipEventSynchronize(b->ctl_ev[b->ctl_half]));
+    pos = 0;
+  }
+  size_t const off = (size_t)b->ctl_half * half + pos;
+  memcpy(b->ctl_ring + off, src, bytes);
+  HIP_TRY(hipMemcpyAsync(dst, b->ctl_ring + off, bytes, hipMemcpyHostToDevice, b->stream));
+  b->ctl_off = pos + bytes;
+  return 0;
+}
+
+// What the control plane changes on the device is ordered on the main stream.  The demodulators of the last call may be
+// running on their own stream and read (and, at their end, write) per-channel state: the main stream waits for them -- on
+// the device; the host goes on.
+int order_after_demods(kq_bank *b) {
+  if (b->calls == 0) return 0;
+  int const last = (int)((b->calls - 1) & 1);
+  if (b->demod_overlapped[last] && hipEventQuery(b->ev_demod_done[last]) != hipSuccess)
+    HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[last], 0));
   return 0;
 }
 
@@ -354,7 +395,6 @@ int upload_n0mask(kq_bank *b, int c) {
     if (upload(b, b->chd.n0meta + (size_t)slot * nsub, meta.data(), meta.size() * sizeof(unsigned))) return -1;
   }
   if (upload(b, b->chd.n0slot + c, &slot, sizeof(int))) return -1;
-  HIP_TRY(hipStreamSynchronize(b->stream));  // the vectors are about to die
   return 0;
 }
 
@@ -384,7 +424,9 @@ Derived derive(const kq::Geom &g, const kq_channel_config &k) {
 // fresh = false: a new demodulator thread on an existing channel (set_mode): what struct demod keeps (sig.n0,
 // sig.foffset, sig.pdeviation) is left alone
 int upload_channel(kq_bank *b, int c, bool fresh = true) {
-  if (sync_all(b)) return -1;  // quiesce both streams before touching per-channel state
+  // per-channel state is written on the main stream, behind the calls in flight (whose demodulators, wherever they run,
+  // read and at their end write it) and in front of the next call: nothing here waits on the host
+  if (order_after_demods(b)) return -1;
   HostChan &h = b->chans[c];
   kq::Geom const &g = b->g;
   kq_channel_config const &k = h.cfg;
@@ -427,19 +469,17 @@ int upload_channel(kq_bank *b, int c, bool fresh = true) {
   }
   if (upload(b, b->chd.plfreq + c, &nan, sizeof(float))) return -1;
   if (upload_n0mask(b, c)) return -1;
-  if (sync_all(b)) return -1;  // also: the demod stream may still be reading the old parameters
   return 0;
 }
 
 int upload_response(kq_bank *b, int c) {
-  if (sync_all(b)) return -1;
+  if (order_after_demods(b)) return -1;
   HostChan &h = b->chans[c];
   kq::Geom const &g = b->g;
   if (upload(b, b->chd.resp + (size_t)c * g.Ndec, h.resp.data(), sizeof(float2) * g.Ndec)) return -1;
   if (upload(b, b->chd.noise_gain + c, &h.noise_gain, sizeof(float))) return -1;
   if (!h.aresp.empty())
     if (upload(b, b->chd.aresp + (size_t)c * (g.Ndec / 2 + 1), h.aresp.data(), sizeof(float2) * (g.Ndec / 2 + 1))) return -1;
-  if (sync_all(b)) return -1;
   return 0;
 }
 
@@ -633,6 +673,7 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
 }
 
 int upload_lists(kq_bank *b) {
+  if (order_after_demods(b)) return -1;  // the last call's demodulators may still be walking the old lists
   for (int k = 0; k < 3; k++) b->list_host[k].clear();
   b->list_pll_host.clear();
   b->list_active_host.clear();
@@ -654,7 +695,6 @@ int upload_lists(kq_bank *b) {
   for (int k = 0; k < 3; k++)
     if (!b->list_host[k].empty())
       if (upload(b, b->list_dev[k], b->list_host[k].data(), b->list_host[k].size() * sizeof(int))) return -1;
-  HIP_TRY(hipStreamSynchronize(b->stream));
   b->lists_dirty = false;
   return 0;
 }
@@ -1217,6 +1257,12 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->energy_state, 2);
   if (kq::full16k_paired_supported(b->g)) rc |= dev_alloc(&b->win_paired, (size_t)(b->g.M - 1) + (size_t)B * b->g.L);
   for (int k = 0; k < 3; k++) rc |= dev_alloc(&b->list_dev[k], C);
+  if (hipHostMalloc((void **)&b->ctl_ring, kq_bank::kCtlRing, hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&b->ctl_ev[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&b->ctl_ev[1], hipEventDisableTiming) != hipSuccess) {
+    set_err("pinned control ring allocation failed");
+    rc = -1;
+  }
   rc |= dev_alloc(&b->list_active_dev, C);
   rc |= dev_alloc(&b->list_unswept_dev, C);
   rc |= dev_alloc(&b->list_swept_dev, C);
@@ -1285,6 +1331,9 @@ int kq_bank_destroy(kq_bank *b) {
       (void)hipEventDestroy(p.b);
     }
   if (b->big.err) (void)hipHostFree(b->big.err);
+  if (b->ctl_ring) (void)hipHostFree(b->ctl_ring);
+  for (hipEvent_t e : b->ctl_ev)
+    if (e) (void)hipEventDestroy(e);
   for (hipStream_t st : {b->copy_in, b->copy_out})
     if (st) {
       (void)hipStreamSynchronize(st);
@@ -1652,13 +1701,14 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
     set_err("bad channel");
     return -1;
   }
-  if (sync_all(b)) return -1;
   HostChan &h = b->chans[ch];
-  if (is_pll(h.cfg)) {
+  if (is_pll(h.cfg)) {  // carrier-loop slots move by synchronous copies: both streams idle first (at most 64 such channels)
+    if (sync_all(b)) return -1;
     int rank, npll;
     pll_rank(b, ch, rank, npll);
     if (pll_leave(b, rank, npll)) return -1;
   }
+  // (nothing on the device changes otherwise: the calls in flight still carry the channel, the next call's lists do not)
   h.active = false;
   h.retuned = false;
   h.patched = false;  // (its entry on the patch list, if any, is skipped: the next call stages the whole bank)
@@ -1694,9 +1744,11 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
     set_err("FM working set exceeds the LDS at this geometry");
     return -1;
   }
-  if (sync_all(b)) return -1;  // pthread_join of the old demodulator thread (radio.c:335-337)
+  // pthread_join of the old demodulator thread (radio.c:335-337): the new state is written on the main stream behind the
+  // last call's demodulators (upload_channel); only carrier-loop slots, moved by synchronous copies, need the device idle
   HostChan &h = b->chans[ch];
   bool const was = is_pll(h.cfg), now = is_pll(*m);
+  if ((was || now) && sync_all(b)) return -1;
   int rank, npll;
   pll_rank(b, ch, rank, npll);
   if (now && pll_admit(b, *m, npll)) return -1;
@@ -1740,7 +1792,7 @@ int kq_bank_set_linear_options(kq_bank *b, int ch, int isb, int channels) {
     return -1;
   }
   if ((h.cfg.isb != 0) == (isb != 0) && h.cfg.channels == channels) return 0;
-  if (sync_all(b)) return -1;
+  if (order_after_demods(b)) return -1;
   h.cfg.isb = isb != 0;
   h.cfg.channels = channels;
   h.out_type = h.cfg.isb ? kq::FT_CROSS_CONJ : kq::FT_COMPLEX;
@@ -1750,7 +1802,6 @@ int kq_bank_set_linear_options(kq_bank *b, int ch, int isb, int channels) {
   if (h.cfg.channels == 2) flags |= kq::FLAG_STEREO;
   if (h.cfg.square) flags |= kq::FLAG_SQUARE;
   if (upload(b, b->chd.flags + ch, &flags, sizeof(int))) return -1;
-  HIP_TRY(hipStreamSynchronize(b->stream));
   return 0;
 }
 
@@ -1822,8 +1873,8 @@ int kq_bank_set_n0(kq_bank *b, int ch, float n0) {
     set_err("bad channel");
     return -1;
   }
-  if (sync_all(b)) return -1;  // the demodulators of a call in flight own the state
-  HIP_TRY(hipMemcpy(b->chd.n0 + ch, &n0, sizeof n0, hipMemcpyHostToDevice));
+  if (order_after_demods(b)) return -1;  // the demodulators of a call in flight own the state: written behind them
+  if (upload(b, b->chd.n0 + ch, &n0, sizeof n0)) return -1;
   return 0;
 }
 
@@ -1843,6 +1894,9 @@ int kq_bank_set_filter(kq_bank *b, int ch, float low, float high, float beta) {
   h.cfg.kaiser_beta = beta;
   if (design_channel(b, h, true)) return -1;
   float const fm_gain = (float)((h.cfg.headroom * M_1_PI * b->g.dsamprate) / fabsf(low - high));
+  // the new response takes effect from the next call on (filter.c:538-543 swaps it under the mutex between two blocks):
+  // written on the main stream behind the calls in flight and their demodulators; the host does not wait
+  if (order_after_demods(b)) return -1;
   if (upload(b, b->chd.low + ch, &low, sizeof(float))) return -1;
   if (upload(b, b->chd.high + ch, &high, sizeof(float))) return -1;
   if (upload(b, b->chd.fm_gain + ch, &fm_gain, sizeof(float))) return -1;

@@ -147,22 +147,53 @@ const float2 *design_twiddles(int log2T) {
   return d;
 }
 
-struct DevBuf {
-  void *p = nullptr;
-  explicit DevBuf(size_t bytes) {
-    if (bytes && hipMalloc(&p, bytes) != hipSuccess) p = nullptr;
+// Workspace of the design kernels: per device, grown on demand, never freed, with a stream of its own.  (hipMalloc /
+// hipFree around every design -- round 1's form -- made each retune a device-wide synchronisation: hipFree waits for
+// everything in flight, so kq_bank_set_filter on a bank running at real time stalled the host for the four calls it had
+// queued, 6 ms at 32768 channels.  tools/churn_probe.py.)
+struct Workspace {
+  hipStream_t stream = nullptr;
+  void *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t cap[5] = {0, 0, 0, 0, 0};
+  void *host = nullptr;  // pinned: job list in, results out
+  size_t host_cap = 0;
+  bool reserve(int i, size_t bytes) {
+    if (bytes <= cap[i]) return true;
+    // growing frees the old buffer -- a synchronising call, but only until the largest batch has been seen once
+    if (buf[i]) (void)hipFree(buf[i]);
+    buf[i] = nullptr;
+    cap[i] = 0;
+    size_t const want = bytes < 4096 ? 4096 : bytes;
+    if (hipMalloc(&buf[i], want) != hipSuccess) return false;
+    cap[i] = want;
+    return true;
   }
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
+  bool reserve_host(size_t bytes) {
+    if (bytes <= host_cap) return true;
+    if (host) (void)hipHostFree(host);
+    host = nullptr;
+    host_cap = 0;
+    size_t const want = bytes < 65536 ? 65536 : bytes;
+    if (hipHostMalloc(&host, want, hipHostMallocDefault) != hipSuccess) return false;
+    host_cap = want;
+    return true;
   }
-  DevBuf(const DevBuf &) = delete;
-  DevBuf &operator=(const DevBuf &) = delete;
 };
+std::mutex g_design_mu;  // one design at a time per process (control plane)
+Workspace *workspace() {
+  static std::map<int, Workspace> ws;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  Workspace &w = ws[dev];
+  if (!w.stream && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  return &w;
+}
 
 }  // namespace
 
 // Designs jobs.size() responses of N = L + M - 1 points on the current device; `given`: jobs.size() * nbins target
 // bins (SPEC_GIVEN) or null.  Returns 0 and fills `out` (jobs.size() * nbins) and, when asked, the |H|^2 sums.
+// Runs on the workspace's own stream and waits for that stream only: whatever else the device is doing goes on.
 int design_batch(int L, int M, bool real_taps, int spec, const std::vector<DesignJob> &jobs, const cfloat *given,
                  std::vector<cfloat> &out, std::vector<float> *sumsq, int nsum) {
   int const N = L + M - 1;
@@ -179,30 +210,46 @@ int design_batch(int L, int M, bool real_taps, int spec, const std::vector<Desig
   }
   size_t const count = jobs.size(), nbins = real_taps ? (size_t)N / 2 + 1 : (size_t)N;
   const float2 *tw = design_twiddles(log2n);
-  DevBuf d_jobs(count * sizeof(DesignJob)), d_in(given ? count * nbins * sizeof(float2) : 0), d_out(count * nbins * sizeof(float2)),
-      d_scratch(count * (size_t)N * sizeof(float2)), d_sum(count * sizeof(float));
-  if (!tw || !d_jobs.p || !d_out.p || !d_scratch.p || !d_sum.p || (given && !d_in.p)) {
+  std::lock_guard<std::mutex> lk(g_design_mu);
+  Workspace *w = workspace();
+  size_t const b_jobs = count * sizeof(DesignJob), b_in = given ? count * nbins * sizeof(float2) : 0,
+               b_out = count * nbins * sizeof(float2), b_sum = count * sizeof(float);
+  // pinned host block: [jobs | given | out | sums], each part 16-byte aligned
+  auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  size_t const o_in = al(b_jobs), o_out = o_in + al(b_in), o_sum = o_out + al(b_out), h_total = o_sum + al(b_sum);
+  if (!tw || !w || !w->reserve(0, b_jobs) || !w->reserve(1, b_in) || !w->reserve(2, b_out) ||
+      !w->reserve(3, count * (size_t)N * sizeof(float2)) || !w->reserve(4, b_sum) || !w->reserve_host(h_total)) {
     kq_internal_set_error("response design: device allocation failed");
     return -1;
   }
-  bool ok = hipMemcpy(d_jobs.p, jobs.data(), count * sizeof(DesignJob), hipMemcpyHostToDevice) == hipSuccess;
-  if (ok && given) ok = hipMemcpy(d_in.p, given, count * nbins * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess;
+  char *hp = static_cast<char *>(w->host);
+  memcpy(hp, jobs.data(), b_jobs);
+  if (given) memcpy(hp + o_in, given, b_in);
+  hipStream_t const st = w->stream;
+  bool ok = hipMemcpyAsync(w->buf[0], hp, b_jobs, hipMemcpyHostToDevice, st) == hipSuccess;
+  if (ok && given) ok = hipMemcpyAsync(w->buf[1], hp + o_in, b_in, hipMemcpyHostToDevice, st) == hipSuccess;
   if (ok) {
     size_t const lds_bytes = (size_t)N * sizeof(float2);
     int const threads = N >= 1024 ? 256 : 64;
     auto go = [&](auto kernel) {
       ensure_dynamic_lds((const void *)kernel, lds_bytes);
-      hipLaunchKernelGGL(kernel, dim3((unsigned)count), dim3(threads), lds_bytes, 0, log2n, M, spec, (const DesignJob *)d_jobs.p,
-                         (const float2 *)d_in.p, (float2 *)d_out.p, (float2 *)d_scratch.p, (float *)d_sum.p, nsum, tw, log2n);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)count), dim3(threads), lds_bytes, st, log2n, M, spec, (const DesignJob *)w->buf[0],
+                         (const float2 *)(given ? w->buf[1] : nullptr), (float2 *)w->buf[2], (float2 *)w->buf[3], (float *)w->buf[4],
+                         nsum, tw, log2n);
     };
     real_taps ? go(k_design<true>) : go(k_design<false>);
     ok = hipGetLastError() == hipSuccess;
   }
+  if (ok) ok = hipMemcpyAsync(hp + o_out, w->buf[2], b_out, hipMemcpyDeviceToHost, st) == hipSuccess;
+  if (ok && sumsq) ok = hipMemcpyAsync(hp + o_sum, w->buf[4], b_sum, hipMemcpyDeviceToHost, st) == hipSuccess;
+  if (ok) ok = hipStreamSynchronize(st) == hipSuccess;
   out.resize(count * nbins);
-  if (ok) ok = hipMemcpy((void *)out.data(), d_out.p, count * nbins * sizeof(float2), hipMemcpyDeviceToHost) == hipSuccess;
-  if (ok && sumsq) {
-    sumsq->resize(count);
-    ok = hipMemcpy(sumsq->data(), d_sum.p, count * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+  if (ok) {
+    memcpy((void *)out.data(), hp + o_out, b_out);
+    if (sumsq) {
+      sumsq->resize(count);
+      memcpy(sumsq->data(), hp + o_sum, b_sum);
+    }
   }
   if (!ok) kq_internal_set_error("response design: %s", hipGetErrorString(hipGetLastError()));
   return ok ? 0 : -1;
@@ -210,10 +257,15 @@ int design_batch(int L, int M, bool real_taps, int spec, const std::vector<Desig
 
 int make_kaiser(float *window, unsigned M, float beta) {
   if (M == 0) return 0;
-  DevBuf d(M * sizeof(float));
-  if (!d.p) return -1;
-  hipLaunchKernelGGL(k_kaiser, dim3((M + 255) / 256), dim3(256), 0, 0, (float *)d.p, (int)M, beta);
-  return hipMemcpy(window, d.p, M * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+  std::lock_guard<std::mutex> lk(g_design_mu);
+  Workspace *w = workspace();
+  if (!w || !w->reserve(2, M * sizeof(float)) || !w->reserve_host(M * sizeof(float))) return -1;
+  hipLaunchKernelGGL(k_kaiser, dim3((M + 255) / 256), dim3(256), 0, w->stream, (float *)w->buf[2], (int)M, beta);
+  if (hipMemcpyAsync(w->host, w->buf[2], M * sizeof(float), hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+      hipStreamSynchronize(w->stream) != hipSuccess)
+    return -1;
+  memcpy(window, w->host, M * sizeof(float));
+  return 0;
 }
 
 int window_filter(int L, int M, std::vector<cfloat> &response, float beta) {

@@ -121,6 +121,7 @@ def load_library():
     L.kq_bank_channel_active.argtypes = [C.c_void_p, C.c_int]
     L.kq_bank_num_channels.argtypes = [C.c_void_p]
     L.kq_bank_num_channels.restype = C.c_uint
+    L.kq_bank_set_linear_options.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.kq_bank_set_second_lo.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.kq_bank_set_doppler.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
     L.kq_bank_set_shift.argtypes = [C.c_void_p, C.c_int, C.c_double]
@@ -273,6 +274,10 @@ class Bank:
     @property
     def fwd_mode(self):
         return self.lib.kq_bank_fwd_mode(self.h)
+
+    def set_linear_options(self, ch, isb, channels):
+        """linear.c:117-120, 291-300: demod->filter.isb / output.channels of a running linear channel"""
+        self._chk(self.lib.kq_bank_set_linear_options(self.h, ch, int(isb), int(channels)), "kq_bank_set_linear_options")
 
     def set_second_lo(self, ch, hz):
         self._chk(self.lib.kq_bank_set_second_lo(self.h, ch, hz), "kq_bank_set_second_lo")

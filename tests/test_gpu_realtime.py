@@ -321,3 +321,87 @@ def test_swept_and_fixed_channels_side_by_side_against_the_oracle(gpu):
                 got = bank.status(c, b)
                 assert got["squelch_count"] == st["squelch_count"] and got["blanked"] == st["blanked"], (k, b, c)
     bank.close()
+
+
+@pytest.mark.parametrize("geom", ["n1024", "cfg4"])
+def test_control_plane_between_calls_in_flight(gpu, geom):
+    """The control plane no longer waits for the device: kq_bank_set_filter / set_mode / add_channel / remove_channel /
+    set_n0 / set_linear_options write their parameters on the bank's stream, behind the calls in flight (which keep the
+    values they were queued with) and their demodulators (wherever those run), in front of the next call.  A host that
+    never waits -- twelve calls queued back to back with such changes between them, every call's planes streamed to their
+    own pinned buffers, the demodulators therefore on their second stream -- must get, bit for bit, what a host gets that
+    drains the device before every change and after every call."""
+    if geom == "n1024":
+        g = dict(samprate=192000, L=512, M=513, D=4)
+        plan = _mixed_plan(g["samprate"], 14)
+        emit = range(24, 40)
+    else:
+        g = wl.GEOMETRY["cfg4"]
+        plan = wl.channel_plan("cfg3", 14)           # FM, AM and SSB channels at cfg 4's geometry
+        emit = None
+    fs, L = g["samprate"], g["L"]
+    olen = L // g["D"]
+    nb, ncalls = 2, 12
+    iq = wl.make_iq(fs, ncalls * nb * L, seed=21, emitters=emit)
+    iq_pin = torch.from_numpy(iq.copy()).pin_memory()
+    am = dict(demod="am", low=-5000.0, high=5000.0, recovery_rate=50.0, hangtime=0.0, second_lo=plan[3]["second_lo"])
+    cmax = len(plan) + 2
+    results = []
+    for drained in (False, True):
+        bank = kq.Bank(fs, L, g["M"], g["D"], cmax, nb, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL, pl_tone=False)
+        bank.add_channels([bank_cfg(p) for p in plan])
+        audio = [_pinned(cmax * nb * 2 * olen, torch.float32) for _ in range(ncalls)]
+        stat = [_pinned(cmax * nb * ctypes.sizeof(kq.ChanStatus), torch.uint8) for _ in range(ncalls)]
+        live = []
+
+        def change(k):
+            if drained:
+                bank.sync()
+            if k == 2:
+                bank.set_filter(1, plan[1]["low"] * 0.8, plan[1]["high"] * 0.9, 4.0)
+            if k == 3:
+                bank.set_mode(3, bank_cfg(am))
+                bank.set_n0(3, 1e-9)
+            if k == 4:
+                bank.remove_channel(6)
+                bank.set_second_lo(2, plan[2]["second_lo"] + 410.0)
+            if k == 5:
+                assert bank.add_channel(bank_cfg(plan[9])) == 6          # the hole, while calls that still carry the old channel 6 run
+                assert bank.add_channel(bank_cfg(plan[4])) == len(plan)
+            if k == 7:
+                lin = [c for c, p in enumerate(plan) if p["demod"] == "linear" and c not in (3, 6)]
+                if lin:
+                    bank.set_linear_options(lin[0], 1, 2)
+                bank.set_filter(0, plan[0]["low"] * 0.5, plan[0]["high"] * 0.5, 2.0)
+                bank.set_filter(len(plan), plan[4]["low"], plan[4]["high"] * 0.7, 3.0)
+            if k == 9:
+                bank.remove_channel(len(plan))
+                bank.set_mode(3, bank_cfg(plan[3]))
+
+        bank.push_iq_async(iq_pin.data_ptr(), nb * L)
+        for k in range(ncalls):
+            change(k)
+            assert bank.process() == nb
+            if k + 1 < ncalls:
+                bank.push_iq_async(iq_pin.data_ptr() + 8 * (k + 1) * nb * L, nb * L)
+            bank.pull_planes_async(audio[k].data_ptr(), stat[k].data_ptr())
+            live.append([c for c in range(cmax) if bank.channel_active(c)])
+            if drained:
+                bank.sync()
+        bank.host_io_wait()
+        bank.sync()
+        bank.close()
+        st = [np.frombuffer(s.numpy().tobytes(), dtype=STATUS_DTYPE).reshape(cmax, nb) for s in stat]
+        au = [a.numpy().reshape(cmax, nb, 2 * olen).copy() for a in audio]
+        results.append((st, au, live))
+    (sa, aa, la), (sb, ab, lb) = results
+    assert la == lb
+    for k in range(ncalls):
+        for c in la[k]:
+            for b in range(nb):
+                n = int(sb[k][c, b]["nout"])
+                assert int(sa[k][c, b]["nout"]) == n and n in (olen, 2 * olen), (k, c, b)
+                assert np.array_equal(aa[k][c, b, :n], ab[k][c, b, :n]), (k, c, b)
+                for key in STATUS_DTYPE.names:
+                    x, y = sa[k][c, b][key], sb[k][c, b][key]
+                    assert x == y or (np.isnan(x) and np.isnan(y)), (k, c, b, key, x, y)

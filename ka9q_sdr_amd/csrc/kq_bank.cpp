@@ -645,6 +645,7 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
   if (steady) {
     unsigned char *rec = b->stage_host[slot] + b->patch_off;
     for (int c : b->patch_list) {
+      if ((size_t)c >= b->chans.size()) continue;  // (removed since, and dropped from the end)
       HostChan const &h = b->chans[c];
       if (!h.active) continue;
       long long const idx = c;
@@ -728,7 +729,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     bool any = false;
     for (HostChan const &h : b->chans) any = any || h.active;
     b->cache_any = any;
-  }
+  }  // (steady: kept up to date by kq_bank_add_channel / kq_bank_remove_channel)
   if (!b->cache_any) {
     set_err("no channels in bank");
     return -1;
@@ -769,6 +770,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     b->sweep_lists_dirty = true;
   } else {
     for (int c : b->patch_list) {
+      if ((size_t)c >= b->chans.size()) continue;
       HostChan &h = b->chans[c];
       if (!h.active) continue;
       double const r = sweep_of(h);
@@ -1018,6 +1020,19 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
 }
 
 bool valid_ch(const kq_bank *b, int ch) { return b && ch >= 0 && (size_t)ch < b->chans.size() && b->chans[ch].active; }
+
+// an oscillator of channel `ch` has been set (or the channel is new): the next call patches its planes -- or, with too
+// many of them, stages the whole bank
+void note_patch(kq_bank *b, int ch) {
+  HostChan &h = b->chans[ch];
+  if (h.patched) return;
+  if ((int)b->patch_list.size() >= kq_bank::kMaxPatch) {
+    b->osc_dirty = true;
+    return;
+  }
+  h.patched = true;
+  b->patch_list.push_back(ch);
+}
 
 }  // namespace
 
@@ -1483,8 +1498,13 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
     return -1;
   }
   b->lists_dirty = true;
-  b->osc_dirty = true;
   b->chan_tw_dirty = true;
+  // a channel more leaves the steady state of the others alone: its planes are patched in by the next call
+  b->chans[c].r_eff = 0;
+  b->n_active++;
+  b->cache_any = true;
+  b->sweep_lists_dirty = true;
+  note_patch(b, c);
   return c;
 }
 
@@ -1714,11 +1734,17 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
   h.patched = false;  // (its entry on the patch list, if any, is skipped: the next call stages the whole bank)
   release_n0slot(b, h.n0slot);
   h.n0slot = -1;
+  // (the others' steady state is untouched: the launch decisions' counters lose this channel, the lists are redone)
+  b->n_active--;
+  b->n_swept -= h.r_eff != 0;
+  b->n_fast -= std::fabs(h.r_eff) > kq::full64k_sweep_limit();
+  b->cache_any = b->n_active > 0;
+  b->sweep_lists_dirty = true;
+  h.r_eff = 0;
   h.lo2 = h.dop = h.shift = h.lo2_old = h.dop_old = Osc{};
   h.out_rtp = kq_out_rtp_state{};
   while (!b->chans.empty() && !b->chans.back().active) b->chans.pop_back();  // holes at the end just go
   b->lists_dirty = true;
-  b->osc_dirty = true;
   return 0;
 }
 
@@ -1773,7 +1799,7 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
   if (design_channel(b, h)) return -1;
   if (upload_channel(b, ch, false) || upload_response(b, ch)) return -1;
   b->lists_dirty = true;
-  b->osc_dirty = true;
+  note_patch(b, ch);  // the shift oscillator (radio.c:367)
   return 0;
 }
 
@@ -1803,18 +1829,6 @@ int kq_bank_set_linear_options(kq_bank *b, int ch, int isb, int channels) {
   if (h.cfg.square) flags |= kq::FLAG_SQUARE;
   if (upload(b, b->chd.flags + ch, &flags, sizeof(int))) return -1;
   return 0;
-}
-
-// an oscillator of channel `ch` has been set: the next call patches its planes (or, with too many of them, stages the bank)
-static void note_patch(kq_bank *b, int ch) {
-  HostChan &h = b->chans[ch];
-  if (h.patched) return;
-  if ((int)b->patch_list.size() >= kq_bank::kMaxPatch) {
-    b->osc_dirty = true;
-    return;
-  }
-  h.patched = true;
-  b->patch_list.push_back(ch);
 }
 
 int kq_bank_set_second_lo(kq_bank *b, int ch, double hz) {

@@ -304,6 +304,13 @@ typedef struct kq_out_rtp_state {
 } kq_out_rtp_state;
 int kq_bank_set_output_ssrc(kq_bank *bank, int ch, uint32_t ssrc);
 int kq_bank_pull_rtp_audio(kq_bank *bank, int ch, unsigned blk, unsigned char *dst, size_t cap, size_t *used);
+/* The same datagrams built from planes the host already holds -- pcm [channels][max_blocks][2 * olen] and status
+ * [channels][max_blocks] as kq_bank_pull_pcm_planes_async delivered them: host work only, no device access, no wait; the
+ * per-channel RTP state advances exactly as with kq_bank_pull_rtp_audio (call it once per channel-block, in order; do
+ * not mix the two on one channel-block).  Channels are independent: a host with tens of thousands of them spreads the
+ * channel range over its threads. */
+int kq_bank_rtp_from_planes(kq_bank *bank, int ch, unsigned blk, const int16_t *pcm_plane, const kq_chan_status *status_plane,
+                            unsigned char *dst, size_t cap, size_t *used);
 int kq_bank_output_rtp_state(const kq_bank *bank, int ch, kq_out_rtp_state *out);
 /* Pre-detection filter output (filter.out->output.c, olen complex) before demodulation */
 int kq_bank_pull_filter_output(kq_bank *bank, int ch, unsigned blk, float *dst_re_im, size_t cap_complex);

@@ -130,6 +130,8 @@ def load_library():
     L.kq_bank_push_zeros.argtypes = [C.c_void_p, C.c_size_t]
     L.kq_bank_set_output_ssrc.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
     L.kq_bank_pull_rtp_audio.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.kq_bank_rtp_from_planes.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t,
+                                          C.POINTER(C.c_size_t)]
     L.kq_bank_output_rtp_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(OutRtpState)]
     L.kq_bank_push_rtp.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.kq_bank_rtp_counters.argtypes = [C.c_void_p, C.POINTER(RtpCounters)]
@@ -343,6 +345,19 @@ class Bank:
         buf = C.create_string_buffer(8 * self.olen + 4096)
         used = C.c_size_t()
         self._chk(self.lib.kq_bank_pull_rtp_audio(self.h, ch, blk, buf, len(buf), C.byref(used)), "kq_bank_pull_rtp_audio")
+        blob, out, pos = buf.raw[:used.value], [], 0
+        while pos < len(blob):
+            ln = blob[pos] | (blob[pos + 1] << 8)
+            out.append(blob[pos + 2:pos + 2 + ln])
+            pos += 2 + ln
+        return out
+
+    def rtp_from_planes(self, ch, blk, pcm_ptr, status_ptr):
+        """the datagrams of one channel-block from PCM / status planes the host holds (kq_bank_rtp_from_planes)"""
+        buf = C.create_string_buffer(8 * self.olen + 4096)
+        used = C.c_size_t()
+        self._chk(self.lib.kq_bank_rtp_from_planes(self.h, ch, blk, pcm_ptr, status_ptr, buf, len(buf), C.byref(used)),
+                  "kq_bank_rtp_from_planes")
         blob, out, pos = buf.raw[:used.value], [], 0
         while pos < len(blob):
             ln = blob[pos] | (blob[pos + 1] << 8)

@@ -2468,18 +2468,12 @@ int kq_bank_output_rtp_state(const kq_bank *b, int ch, kq_out_rtp_state *out) {
   return 0;
 }
 
-int kq_bank_pull_rtp_audio(kq_bank *b, int ch, unsigned blk, unsigned char *dst, size_t cap, size_t *used) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
-  if (!valid_ch(b, ch) || !dst) {
-    set_err("bad channel or NULL buffer");
-    return -1;
-  }
-  std::vector<int16_t> words(2 * (size_t)b->g.olen);
-  size_t nwords = 0;
-  if (kq_bank_pull_pcm(b, ch, blk, words.data(), words.size(), &nwords, nullptr)) return -1;
-  bool const stereo = nwords == 2 * (size_t)b->g.olen;  // what the demodulator passed to send_stereo_output
-  kq_out_rtp_state &o = b->chans[ch].out_rtp;
-  const unsigned char *w = reinterpret_cast<const unsigned char *>(words.data());  // already network byte order
+namespace {
+// send_mono_output / send_stereo_output (audio.c:32-132) on the words of one channel-block: 480-word chunks, all-zero
+// chunks skipped while the timestamp still advances, marker bit on the first packet after silence, sequence numbers on
+// sent packets only.  `w`: nwords int16 in network byte order.  Packets back to back as [2-byte LE length][bytes].
+int packetize_block(kq_out_rtp_state &o, const unsigned char *w, size_t nwords, bool stereo, unsigned char *dst, size_t cap,
+                    size_t *used) {
   size_t pos = 0, left = nwords;
   int packets = 0;
   while (left > 0) {
@@ -2523,6 +2517,37 @@ int kq_bank_pull_rtp_audio(kq_bank *b, int ch, unsigned blk, unsigned char *dst,
   }
   if (used) *used = pos;
   return packets;
+}
+}  // namespace
+
+int kq_bank_pull_rtp_audio(kq_bank *b, int ch, unsigned blk, unsigned char *dst, size_t cap, size_t *used) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  if (!valid_ch(b, ch) || !dst) {
+    set_err("bad channel or NULL buffer");
+    return -1;
+  }
+  std::vector<int16_t> words(2 * (size_t)b->g.olen);
+  size_t nwords = 0;
+  if (kq_bank_pull_pcm(b, ch, blk, words.data(), words.size(), &nwords, nullptr)) return -1;
+  bool const stereo = nwords == 2 * (size_t)b->g.olen;  // what the demodulator passed to send_stereo_output
+  return packetize_block(b->chans[ch].out_rtp, reinterpret_cast<const unsigned char *>(words.data()), nwords, stereo, dst, cap, used);
+}
+
+// The same datagrams from planes the host already holds (kq_bank_pull_pcm_planes_async): no device access, no wait.
+int kq_bank_rtp_from_planes(kq_bank *b, int ch, unsigned blk, const int16_t *pcm_plane, const kq_chan_status *status_plane,
+                            unsigned char *dst, size_t cap, size_t *used) {
+  if (!valid_ch(b, ch) || !dst || !pcm_plane || !status_plane || blk >= (unsigned)b->g.max_blocks) {
+    set_err("bad channel / block or NULL plane");
+    return -1;
+  }
+  size_t const cb = (size_t)ch * b->g.max_blocks + blk;
+  int const nout = status_plane[cb].nout;
+  if (nout < 0 || nout > 2 * b->g.olen) {
+    set_err("status plane: nout %d out of range", nout);
+    return -1;
+  }
+  return packetize_block(b->chans[ch].out_rtp, reinterpret_cast<const unsigned char *>(pcm_plane + cb * 2 * (size_t)b->g.olen),
+                         (size_t)nout, nout == 2 * b->g.olen, dst, cap, used);
 }
 
 int kq_bank_pull_filter_output(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap) {

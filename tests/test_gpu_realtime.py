@@ -405,3 +405,56 @@ def test_control_plane_between_calls_in_flight(gpu, geom):
                 for key in STATUS_DTYPE.names:
                     x, y = sa[k][c, b][key], sb[k][c, b][key]
                     assert x == y or (np.isnan(x) and np.isnan(y)), (k, c, b, key, x, y)
+
+
+def test_rtp_datagrams_from_streamed_pcm_planes(gpu):
+    """kq_bank_rtp_from_planes: the datagrams of send_mono_output / send_stereo_output (audio.c:32-132) built on the host from
+    the PCM and status planes kq_bank_pull_pcm_planes_async delivered -- byte for byte the oracle packetiser's output on the
+    same audio, through a carrier that drops (silent packets skipped, timestamp advancing, marker on resume), for a mono FM
+    and a stereo linear channel, over two streamed calls."""
+    import kq_oracle as ko
+    g = dict(samprate=192000, L=2048, M=2049, D=4)        # olen = 512: chunks of 480 + 32 (mono), 480 + 480 + 64 (stereo)
+    fs, L = g["samprate"], g["L"]
+    olen = L // g["D"]
+    nb, ncalls = 4, 2
+    t = np.arange(ncalls * nb * L) / fs
+    sig = 0.2 * np.exp(1j * (2 * np.pi * 20000.0 * t + 3.0 * np.sin(2 * np.pi * 1000.0 * t)))
+    sig[3 * L:5 * L] = 0                                    # the carrier drops for two blocks, then comes back
+    rng = np.random.default_rng(18)
+    iq = (sig + 1e-4 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    plan = [dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-20000.0),
+            dict(demod="linear", low=-5000.0, high=5000.0, second_lo=-20000.0, hangtime=1.1, recovery_rate=6.0, channels=2)]
+    C = len(plan)
+    bank = kq.Bank(fs, L, g["M"], g["D"], C, nb, fwd_mode=kq.KQ_FWD_FULL)
+    ssrc = [0xCAFE0001, 0x7FFFFFF2]
+    ora = []
+    for c, p in enumerate(plan):
+        bank.add_channel(bank_cfg(p))
+        bank.set_output_ssrc(c, ssrc[c])
+        ora.append(ko.OutRtp(ssrc=ssrc[c]))
+    iq_pin = torch.from_numpy(iq.copy()).pin_memory()
+    pcm = [_pinned(C * nb * 2 * olen, torch.int16) for _ in range(ncalls)]
+    aud = [_pinned(C * nb * 2 * olen, torch.float32) for _ in range(ncalls)]
+    stat = [_pinned(C * nb * ctypes.sizeof(kq.ChanStatus), torch.uint8) for _ in range(ncalls)]
+    bank.push_iq_async(iq_pin.data_ptr(), nb * L)
+    sent = skipped = markers = 0
+    for k in range(ncalls):
+        assert bank.process() == nb
+        if k + 1 < ncalls:
+            bank.push_iq_async(iq_pin.data_ptr() + 8 * (k + 1) * nb * L, nb * L)
+        bank.pull_pcm_planes_async(pcm[k].data_ptr(), None, stat[k].data_ptr())
+        bank.pull_planes_async(aud[k].data_ptr(), None)     # the float audio of the same call, for the oracle
+        bank.pull_wait(0)
+        a = aud[k].numpy().reshape(C, nb, 2 * olen)
+        st = np.frombuffer(stat[k].numpy().tobytes(), dtype=STATUS_DTYPE).reshape(C, nb)
+        for c in range(C):
+            for b in range(nb):
+                n = int(st[c, b]["nout"])
+                got = bank.rtp_from_planes(c, b, pcm[k].data_ptr(), stat[k].data_ptr())
+                want = ora[c].packetize(a[c, b, :n], stereo=(c == 1))
+                assert got == want, (k, c, b)
+                sent += len(got)
+                skipped += (n + 479) // 480 - len(got)
+                markers += sum(1 for d in got if d[1] & 0x80)
+    assert sent > 0 and skipped > 0 and markers >= 1
+    bank.close()

@@ -343,6 +343,10 @@ def measure_channels_at_realtime(torch, kq, wl, dev_index, stream, seconds):
         out["pcm_int16"] = measure_realtime(torch, kq, wl, "cfg4", best["channels"], 2, dev_index, stream, seconds=min(4.0, seconds), pcm=True)
         out["four_blocks_per_call"] = measure_realtime(torch, kq, wl, "cfg4", best["channels"], 4, dev_index, stream,
                                                        seconds=min(4.0, seconds))
+        # both ends in the reference's own formats: RTP datagrams of int16 I/Q in (radio.c:110-122, main.c:318-341; one
+        # kq_bank_push_rtp per datagram), int16 PCM planes out
+        out["rtp_in_pcm_out"] = measure_realtime(torch, kq, wl, "cfg4", best["channels"], 2, dev_index, stream,
+                                                 seconds=min(4.0, seconds), pcm=True, rtp_samples=1024)
     return out
 
 

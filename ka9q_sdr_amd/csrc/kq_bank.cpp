@@ -209,6 +209,16 @@ struct kq_bank {
   bool in_used[2] = {false, false};  // in_ready[k] has been recorded at least once
   hipEvent_t in_ready[2] = {nullptr, nullptr}, in_free[2] = {nullptr, nullptr};
   int in_next = 0;
+  // kq_bank_push_rtp's payloads gather in pinned host memory and travel as ONE asynchronous copy + conversion per run of
+  // packets (flushed by kq_bank_process and by whatever else touches the ring): a datagram no longer costs a host wait
+  // for everything the stream has queued -- with process calls of 1.5 ms in flight that wait was the end of real time
+  unsigned char *acc_pin[2] = {nullptr, nullptr};
+  size_t acc_cap = 0;        // bytes, each buffer
+  int acc_cur = 0, acc_fmt = -1;
+  size_t acc_n = 0;          // samples gathered in acc_pin[acc_cur]
+  size_t acc_ring_off = 0;   // where in the ring (samples) the run starts
+  hipEvent_t acc_read[2] = {nullptr, nullptr};  // the copy engine has read the buffer
+  bool acc_read_set[2] = {false, false};
   hipEvent_t out_ready = nullptr;
   // one marker per queued plane copy, a ring of them: the next call's demodulators wait for the newest on the device, and a
   // streaming host waits for the one `lag` deliveries back (kq_bank_pull_wait) while newer calls are in flight
@@ -1360,6 +1370,10 @@ int kq_bank_destroy(kq_bank *b) {
     if (b->in_free[k]) (void)hipEventDestroy(b->in_free[k]);
   }
   if (b->out_ready) (void)hipEventDestroy(b->out_ready);
+  for (int k = 0; k < 2; k++) {
+    if (b->acc_pin[k]) (void)hipHostFree(b->acc_pin[k]);
+    if (b->acc_read[k]) (void)hipEventDestroy(b->acc_read[k]);
+  }
   for (hipEvent_t e : b->pull_done)
     if (e) (void)hipEventDestroy(e);
   for (int k = 0; k < kq_bank::kSlots; k++) {
@@ -1918,12 +1932,18 @@ int kq_bank_set_filter(kq_bank *b, int ch, float low, float high, float beta) {
   return upload_response(b, ch);
 }
 
+namespace {
+static int acc_flush(kq_bank *b);
+static int acc_append(kq_bank *b, const void *src, size_t nsamples, int format);
+}  // namespace
+
 int kq_bank_push_iq(kq_bank *b, const void *iq, size_t nsamples, int format, int is_device) {
   kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b || (!iq && nsamples)) {
     set_err("NULL argument");
     return -1;
   }
+  if (acc_flush(b)) return -1;  // packet payloads gathered by kq_bank_push_rtp go first
   if (format < KQ_IQ_CF32 || format > KQ_IQ_S8) {
     set_err("unknown I/Q format %d", format);
     return -1;
@@ -2001,23 +2021,10 @@ static void note_pushed(kq_bank *b, size_t nsamples, unsigned char zero) {
 }
 }  // namespace
 
-int kq_bank_push_iq_async(kq_bank *b, const void *iq, size_t nsamples, int format) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
-  if (!b || (!iq && nsamples)) {
-    set_err("NULL argument");
-    return -1;
-  }
-  if (format < KQ_IQ_CF32 || format > KQ_IQ_S8) {
-    set_err("unknown I/Q format %d", format);
-    return -1;
-  }
-  kq::Geom const &g = b->g;
-  size_t const used = (size_t)(g.M - 1) + b->pending;
-  if (used + nsamples > b->ring_cap) {
-    set_err("ring overflow: %zu pending + %zu pushed > %zu", b->pending, nsamples, b->ring_cap - (g.M - 1));
-    return -1;
-  }
-  if (nsamples == 0) return 0;
+namespace {
+// `nsamples` samples of `format` in pinned host memory -> staging buffer (copy stream) -> conversion kernel (bank's stream)
+// into the ring at sample offset `ring_off`.  Nothing waits on the host but the reuse of a staging buffer two copies later.
+static int queue_input_copy(kq_bank *b, const void *iq, size_t nsamples, int format, size_t ring_off) {
   if (host_io_setup(b)) return -1;
   size_t const bps = format == KQ_IQ_CF32 ? 8 : format == KQ_IQ_S16 ? 4 : 2;
   int const k = b->in_next;
@@ -2040,9 +2047,68 @@ int kq_bank_push_iq_async(kq_bank *b, const void *iq, size_t nsamples, int forma
   HIP_TRY(hipStreamWaitEvent(b->stream, b->in_ready[k], 0));
   {
     Scope t(b, 2, b->stream);
-    kq::launch_ingest(b->stream, b->in_stage[k], format, b->ring[b->cur] + used, nsamples, b->cfg.gain_factor);
+    kq::launch_ingest(b->stream, b->in_stage[k], format, b->ring[b->cur] + ring_off, nsamples, b->cfg.gain_factor);
   }
   HIP_TRY(hipEventRecord(b->in_free[k], b->stream));
+  return 0;
+}
+
+// the gathered run of packet payloads goes out (see acc_pin)
+static int acc_flush(kq_bank *b) {
+  if (b->acc_n == 0) return 0;
+  int const j = b->acc_cur;
+  if (queue_input_copy(b, b->acc_pin[j], b->acc_n, b->acc_fmt, b->acc_ring_off)) return -1;
+  HIP_TRY(hipEventRecord(b->acc_read[j], b->copy_in));
+  b->acc_read_set[j] = true;
+  b->acc_cur ^= 1;
+  b->acc_n = 0;
+  // the buffer gathered into next was handed to the copy engine two flushes ago
+  if (b->acc_read_set[b->acc_cur]) HIP_TRY(hipEventSynchronize(b->acc_read[b->acc_cur]));
+  return 0;
+}
+
+// one packet's payload (host memory, any alignment) joins the run; the bookkeeping of the ring moves at once
+static int acc_append(kq_bank *b, const void *src, size_t nsamples, int format) {
+  if (nsamples == 0) return 0;
+  size_t const bps = format == KQ_IQ_S16 ? 4 : format == KQ_IQ_S8 ? 2 : 8;
+  if (!b->acc_pin[0]) {
+    b->acc_cap = b->ring_cap * 8;  // the whole ring in the widest format
+    for (int k = 0; k < 2; k++) {
+      HIP_TRY(hipHostMalloc((void **)&b->acc_pin[k], b->acc_cap, hipHostMallocDefault));
+      HIP_TRY(hipEventCreateWithFlags(&b->acc_read[k], hipEventDisableTiming));
+    }
+  }
+  if (b->acc_n && (format != b->acc_fmt || (b->acc_n + nsamples) * bps > b->acc_cap) && acc_flush(b)) return -1;
+  if (b->acc_n == 0) {
+    b->acc_fmt = format;
+    b->acc_ring_off = (size_t)(b->g.M - 1) + b->pending;
+  }
+  memcpy(b->acc_pin[b->acc_cur] + b->acc_n * bps, src, nsamples * bps);
+  b->acc_n += nsamples;
+  note_pushed(b, nsamples, 0);
+  return 0;
+}
+}  // namespace
+
+int kq_bank_push_iq_async(kq_bank *b, const void *iq, size_t nsamples, int format) {
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  if (!b || (!iq && nsamples)) {
+    set_err("NULL argument");
+    return -1;
+  }
+  if (format < KQ_IQ_CF32 || format > KQ_IQ_S8) {
+    set_err("unknown I/Q format %d", format);
+    return -1;
+  }
+  kq::Geom const &g = b->g;
+  size_t const used = (size_t)(g.M - 1) + b->pending;
+  if (used + nsamples > b->ring_cap) {
+    set_err("ring overflow: %zu pending + %zu pushed > %zu", b->pending, nsamples, b->ring_cap - (g.M - 1));
+    return -1;
+  }
+  if (nsamples == 0) return 0;
+  if (acc_flush(b)) return -1;
+  if (queue_input_copy(b, iq, nsamples, format, used)) return -1;
   note_pushed(b, nsamples, 0);
   return 0;
 }
@@ -2156,6 +2222,7 @@ int kq_bank_push_zeros(kq_bank *b, size_t nsamples) {
     set_err("ring overflow");
     return -1;
   }
+  if (acc_flush(b)) return -1;
   HIP_TRY(hipMemsetAsync(b->ring[b->cur] + used, 0, nsamples * sizeof(float2), b->stream));
   size_t fill = b->pending % g.L;
   size_t left = nsamples;
@@ -2289,7 +2356,8 @@ int kq_bank_push_rtp(kq_bank *b, const void *datagram, size_t size) {
     r.samples += time_step;
   }
   r.samples += sampcount;
-  if (sampcount > 0 && kq_bank_push_iq(b, p + hdr, (size_t)sampcount, type == 97 ? KQ_IQ_S16 : KQ_IQ_S8, 0)) return -1;
+  // the payload joins the run gathered in pinned memory: one asynchronous copy and one conversion per run, not per packet
+  if (sampcount > 0 && acc_append(b, p + hdr, (size_t)sampcount, type == 97 ? KQ_IQ_S16 : KQ_IQ_S8)) return -1;
   return time_step + sampcount;
 }
 
@@ -2309,6 +2377,7 @@ int kq_bank_process(kq_bank *b) {
     return -1;
   }
   kq::Geom const &g = b->g;
+  if (acc_flush(b)) return -1;  // what kq_bank_push_rtp has gathered goes into the ring now
   unsigned nb = (unsigned)(b->pending / g.L);
   if (nb > b->cfg.max_blocks) nb = b->cfg.max_blocks;
   if (nb == 0) return 0;

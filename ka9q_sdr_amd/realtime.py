@@ -28,13 +28,15 @@ def build_bank(kq, wl, config, C, B, dev_index, stream, compute_n0=True):
 
 
 def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.0, host_io=True, pcm=False, warm_calls=50,
-                     retunes_per_call=0, swept_channels=0):
+                     retunes_per_call=0, swept_channels=0, rtp_samples=0):
     """C channels, B blocks per call, for `seconds` of wall time.  host_io: input from pinned host memory, audio (float, or
     the int16 PCM words when pcm) + status planes to pinned host memory after every call into one of three buffer sets; the
     host waits for the planes of call k-2 once it has queued call k (it never runs more than two deliveries ahead of what it
     has in hand, so a buffer set is never overwritten before it has landed).  retunes_per_call > 0: that many channels get
     a new second LO before every call (kq_bank_set_second_lo, 1 Hz to and fro) -- every call then stages all channels'
-    oscillators on the host and carries them over the link, the path a call without retunes skips."""
+    oscillators on the host and carries them over the link, the path a call without retunes skips.  rtp_samples > 0: the
+    input arrives as the reference's front end sends it -- RTP datagrams of that many int16 I/Q samples (payload type 97
+    behind the 24-byte status block, main.c:318-341), one kq_bank_push_rtp per datagram -- instead of a float batch."""
     geom = dict(wl.GEOMETRY[config])
     L, M, D, fs = geom["L"], geom["M"], geom["D"], geom["samprate"]
     olen = L // D
@@ -59,12 +61,33 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
         nout_words = sum((2 if p.get("channels", 1) == 2 else 1) * olen for p in plan) * B
         out_bytes = nout_words * (2 if pcm else 4) + stats[0].numel() + (4 * C * B if pcm else 0)
 
+        pkts = []
+        if rtp_samples:      # the batch as datagrams: header patched per call (sequence number, timestamp), payload fixed
+            import struct
+            scale = 0.9 * 32767.0 / float(np.abs(np.concatenate([iq_host.real, iq_host.imag])).max())
+            new = iq_host[M - 1:]
+            i16 = np.stack([np.round(new.real * scale), np.round(new.imag * scale)], axis=1).astype("<i2")
+            assert (B * L) % rtp_samples == 0
+            for j in range(B * L // rtp_samples):
+                body = i16[j * rtp_samples:(j + 1) * rtp_samples].tobytes()
+                pkts.append(bytearray(struct.pack(">BBHII", 2 << 6, 97, 0, 0, 0x6B61) + b"\0" * 24 + body))
+        seq = [0]
+
+        def push_batch():
+            if not rtp_samples:
+                bank.push_iq_async(iq_pin.data_ptr(), B * L)
+                return
+            for pk in pkts:
+                struct.pack_into(">HI", pk, 2, seq[0] & 0xFFFF, (seq[0] * rtp_samples) & 0xFFFFFFFF)
+                seq[0] += 1
+                assert bank.push_rtp(pk) == rtp_samples
+
         def call(k):
             for i in range(retunes_per_call):
                 c = (k * 7919 + i * 104729) % C
                 bank.set_second_lo(c, plan[c]["second_lo"] + (1.0 if k & 1 else 0.0))
             assert bank.process() == B
-            bank.push_iq_async(iq_pin.data_ptr(), B * L)
+            push_batch()
             j = k % nbuf
             if pcm:
                 bank.pull_pcm_planes_async(outs[j].data_ptr(), masks[j].data_ptr(), stats[j].data_ptr())
@@ -72,7 +95,7 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
                 bank.pull_planes_async(outs[j].data_ptr(), stats[j].data_ptr())
             bank.pull_wait(2)     # the planes of call k-2 are in host memory now; calls k-1 and k are in flight
 
-        bank.push_iq_async(iq_pin.data_ptr(), B * L)
+        push_batch()
     else:
         iq_dev = torch.from_numpy(iq_host).to(dev)
 
@@ -125,4 +148,6 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
             "host_io": ("pcm int16 + status" if pcm else "float audio + status") if host_io else None,
             "d2h_bytes_per_call": out_bytes, "d2h_GBps": round(out_bytes / dt / 1e9, 3),
             "h2d_bytes_per_call": B * L * 8 if host_io else 0,
+            "input": ("RTP datagrams of %d int16 I/Q samples (kq_bank_push_rtp)" % rtp_samples) if rtp_samples else
+                     ("float batch (kq_bank_push_iq_async)" if host_io else "resident"),
             "retunes_per_call": retunes_per_call, "swept_channels": swept_channels, "setup_s": round(setup_s, 2), "check": checksum}

@@ -203,7 +203,10 @@ int kq_bank_push_iq(kq_bank *bank, const void *iq, size_t nsamples, int format, 
  * none waiting the gap's zero fill (up to 192000 samples, radio.c:79-100) is itself larger than the ring: each call then
  * puts in as many zeros as fit and moves the timestamp past them before it returns -2, so every round brings the gap a
  * ring closer to its end, sample for sample as the reference fills it; the packet is counted once.  A payload larger
- * than the whole ring is an error (-1; its samples become a gap that the next packet fills with zeros). */
+ * than the whole ring is an error (-1; its samples become a gap that the next packet fills with zeros).
+ * The call does not wait for the device: payloads gather in pinned host memory and go to the ring as one asynchronous
+ * copy + conversion per run of packets, queued by the next kq_bank_process (or by any other call that touches the ring);
+ * kq_bank_blocks_ready counts them at once. */
 int kq_bank_push_rtp(kq_bank *bank, const void *datagram, size_t size);
 typedef struct kq_rtp_counters {   /* struct rtp_state (multicast.h:41-50) + demod->input.samples */
   uint32_t ssrc;

@@ -595,9 +595,6 @@ struct Scope {
   }
 };
 
-// Per-call parameters: oscillator phase/step/sweep for a call whose first window starts at absolute
-// sample n_w, the shift oscillator at the first output sample, and the IF-power update flags.
-// Filled into the next pinned staging slot (returned in *slot_out); the first kernel of the call copies it to the device.
 // the eight plane values of one channel for a call whose first window starts at absolute sample n_w:
 // out = {phase, step, sweep, shift phase, shift step, history phase, history step, history sweep}
 void eval_planes(const kq_bank *b, const HostChan &h, int64_t n_w, double out[8]) {

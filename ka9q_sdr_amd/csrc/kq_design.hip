@@ -147,12 +147,16 @@ const float2 *design_twiddles(int log2T) {
   return d;
 }
 
-// Workspace of the design kernels: per device, grown on demand, never freed, with a stream of its own.  (hipMalloc /
-// hipFree around every design -- round 1's form -- made each retune a device-wide synchronisation: hipFree waits for
-// everything in flight, so kq_bank_set_filter on a bank running at real time stalled the host for the four calls it had
-// queued, 6 ms at 32768 channels.  tools/churn_probe.py.)
+// Workspace of the design kernels: per device, grown on demand, never freed.  (hipMalloc / hipFree around every design --
+// round 1's form -- made each retune a device-wide synchronisation: hipFree waits for everything in flight, so
+// kq_bank_set_filter on a bank running at real time stalled the host for the four calls it had queued, 6 ms at 32768
+// channels.  tools/churn_probe.py.)  The kernels run on the NULL stream, as they always did, and wait for that stream only:
+// the bank's streams are non-blocking, so nothing of theirs is waited for.  (A stream of the workspace's own was tried first:
+// streams are dealt onto a handful of hardware queues in creation order, and one more stream created before the bank's copy
+// streams moved those onto queues they then shared with the kernels -- with_host_io went from 0.99 to 0.87 of the resident
+// step, found by bisecting the round's commits.)
 struct Workspace {
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;  // always the null stream
   void *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t cap[5] = {0, 0, 0, 0, 0};
   void *host = nullptr;  // pinned: job list in, results out
@@ -184,16 +188,14 @@ Workspace *workspace() {
   static std::map<int, Workspace> ws;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  Workspace &w = ws[dev];
-  if (!w.stream && hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-  return &w;
+  return &ws[dev];
 }
 
 }  // namespace
 
 // Designs jobs.size() responses of N = L + M - 1 points on the current device; `given`: jobs.size() * nbins target
 // bins (SPEC_GIVEN) or null.  Returns 0 and fills `out` (jobs.size() * nbins) and, when asked, the |H|^2 sums.
-// Runs on the workspace's own stream and waits for that stream only: whatever else the device is doing goes on.
+// Runs on the null stream and waits for that stream only: whatever the (non-blocking) streams of a bank are doing goes on.
 int design_batch(int L, int M, bool real_taps, int spec, const std::vector<DesignJob> &jobs, const cfloat *given,
                  std::vector<cfloat> &out, std::vector<float> *sumsq, int nsum) {
   int const N = L + M - 1;

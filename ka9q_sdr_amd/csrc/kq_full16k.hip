@@ -423,20 +423,31 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   // Half round A carries k1 < 16 (read by threads t < 256), half round B the rest.
   v2f u[32];
   tw2[(t >> 5) * kTw2Pitch + (t & 31)] = make_float2(tw2_mine.x, tw2_mine.y);  // read behind transpose 1's barriers
+#if defined(KQ_ABLATE) && (KQ_ABLATE & 1)
+  // ABLATION (tools/ablate.sh; results are garbage by design): transpose 1 without its LDS traffic and barriers -- what the
+  // kernel would cost if the exchange were free
+#pragma unroll
+  for (int n2 = 0; n2 < 32; n2++) u[n2] = v[n2];
+#else
   {
     int const rd = ((t >> 4) & 15) * kRow1 + (t & 15);
 #pragma unroll
     for (int half = 0; half < 2; half++) {
 #pragma unroll
       for (int k1 = 0; k1 < 16; k1++) xch[k1 * kRow1 + t] = make_float2(v[16 * half + k1].x, v[16 * half + k1].y);
+#if !(defined(KQ_ABLATE) && (KQ_ABLATE & 4))   // bit 2: the LDS traffic without the barriers (racy, timing only)
       __syncthreads();
+#endif
       if ((t >> 8) == half) {
 #pragma unroll
         for (int n2 = 0; n2 < 32; n2++) u[rfft::bitrev5(n2)] = ld2(xch + rd + 16 * n2);
       }
+#if !(defined(KQ_ABLATE) && (KQ_ABLATE & 4))
       __syncthreads();
+#endif
     }
   }
+#endif
 
   KQ_STAMP(3);
   // ---------------- pass 2: 32-point transforms over n2, twiddle W_512^{n3 k2} = W_N^{32 n3 k2}
@@ -459,6 +470,13 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   // the workgroup, which holds its LDS until its last wave is done, lives longer.)
   // Half round A is written by the threads holding k1 < 16 (t < 256) and yields ya, half round B yields yb.
   v2f ya[16], yb[16];
+#if defined(KQ_ABLATE) && (KQ_ABLATE & 2)
+#pragma unroll
+  for (int n3 = 0; n3 < 16; n3++) {  // ABLATION: transpose 2 without its LDS traffic and barriers
+    ya[n3] = u[n3];
+    yb[n3] = u[16 + n3];
+  }
+#else
   {
     int const wr = (t & 15) * kRow2 + ((t >> 4) & 15) * kCol2;
     int const rd = (t >> 5) * kCol2 + (t & 31);
@@ -468,12 +486,17 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
 #pragma unroll
         for (int k2 = 0; k2 < 32; k2++) xch[wr + k2] = make_float2(u[k2].x, u[k2].y);
       }
+#if !(defined(KQ_ABLATE) && (KQ_ABLATE & 4))
       __syncthreads();
+#endif
 #pragma unroll
       for (int n3 = 0; n3 < 16; n3++) (half ? yb : ya)[rfft::bitrev4(n3)] = ld2(xch + n3 * kRow2 + rd);
+#if !(defined(KQ_ABLATE) && (KQ_ABLATE & 4))
       __syncthreads();
+#endif
     }
   }
+#endif
 
   KQ_STAMP(5);
   // ---------------- pass 3: 16-point transforms over n3.  ya[k3] = X[ka + 1024 k3], yb[k3] = X[kb + 1024 k3]

@@ -458,3 +458,59 @@ def test_rtp_datagrams_from_streamed_pcm_planes(gpu):
                 markers += sum(1 for d in got if d[1] & 0x80)
     assert sent > 0 and skipped > 0 and markers >= 1
     bank.close()
+
+
+def test_8192_mixed_channels_two_blocks_per_call_against_the_oracle(gpu):
+    """cfg 3's mix (FM, AM, USB / LSB) at 8192 channels and two blocks per call: above 2048 channels the N/D = 64 demodulators
+    run their one-wave forms for every mode (AM and linear AGC recurrences included), and a batch of two blocks is one pair.
+    Every 64th channel against the oracle through four calls; hang counters, squelch state and sample counts exact."""
+    g = wl.GEOMETRY["cfg3"]
+    fs, L, M, D = g["samprate"], g["L"], g["M"], g["D"]
+    olen = L // D
+    C, B, ncalls, every = 8192, 2, 4, 64
+    plan = wl.channel_plan("cfg3", C)
+    # channel c listens to emitter c mod 64: sample with a stride that is odd in emitters so that every mode is met
+    sampled = list(range(0, C, every + 1))
+    iq = wl.make_iq(fs, ncalls * B * L, seed=0x6B64)
+    want = run_oracle([plan[c] for c in sampled], g, iq, ncalls * B, compute_n0=1)
+    bank = kq.Bank(fs, L, M, D, C, B, compute_n0=True, fwd_mode=kq.KQ_FWD_AUTO, pl_tone=False)
+    bank.add_channels([bank_cfg(p) for p in plan])
+    iq_pin = torch.from_numpy(iq.copy()).pin_memory()
+    audio = [_pinned(C * B * 2 * olen, torch.float32) for _ in range(ncalls)]
+    stat = [_pinned(C * B * ctypes.sizeof(kq.ChanStatus), torch.uint8) for _ in range(ncalls)]
+    bank.push_iq_async(iq_pin.data_ptr(), B * L)
+    for k in range(ncalls):
+        assert bank.process() == B
+        if k + 1 < ncalls:
+            bank.push_iq_async(iq_pin.data_ptr() + 8 * (k + 1) * B * L, B * L)
+        bank.pull_planes_async(audio[k].data_ptr(), stat[k].data_ptr())
+    bank.host_io_wait()
+    bank.close()
+    st = [np.frombuffer(s.numpy().tobytes(), dtype=STATUS_DTYPE).reshape(C, B) for s in stat]
+    au = [a.numpy().reshape(C, B, 2 * olen) for a in audio]
+    kinds = {}
+    ties = []
+    for i, c in enumerate(sampled):
+        auds, sts, _ = want[i]
+        p = plan[c]
+        kinds[p["demod"]] = kinds.get(p["demod"], 0) + 1
+        # (a linear channel's first block divides by numerically-zero start-up samples, linear.c:271-272: compared from block 1)
+        first = 1 if p["demod"] == "linear" else 0
+        got = np.concatenate([au[k][c, b, :olen] for k in range(ncalls) for b in range(B)][first:])
+        ref = np.concatenate(auds[first:])
+        err = rel_rms(got, ref)
+        for k in range(ncalls):
+            for b in range(B):
+                s, w = st[k][c, b], sts[k * B + b]
+                assert s["nout"] == w["nout"] and s["squelch_count"] == w["squelch_count"] and s["blanked"] == w["blanked"], (c, k, b)
+                if s["hangcount"] != w["hangcount"] or err >= AUDIO_TOL:
+                    # `gain * amplitude > headroom` with the gain riding at the limit (linear.c:271, am.c:66): a tie of the
+                    # reference's own comparison; the two gain tracks stay within 1e-5
+                    assert p["demod"] != "fm" and abs(s["agc_gain"] / w["agc_gain"] - 1) < 1e-4, (c, k, b, err, s["agc_gain"], w["agc_gain"])
+                    ties.append((c, "agc", float(abs(s["agc_gain"] / w["agc_gain"] - 1))))
+                np.testing.assert_allclose(s["bb_power"], w["bb_power"], rtol=2e-5)
+        assert err < (AUDIO_TOL if not any(t[0] == c for t in ties) else 1e-4), (c, p["demod"], err)
+    assert set(kinds) == {"fm", "am", "linear"}, kinds
+    assert len({t[0] for t in ties}) <= 2, ties
+    import conftest
+    conftest.note_ties("test_8192_mixed_channels_two_blocks_per_call_against_the_oracle", ties, len(sampled))

@@ -1502,6 +1502,8 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
       pll_rank(b, c, rank, npll);
       (void)pll_leave(b, rank, npll);
     }
+    release_n0slot(b, b->chans[c].n0slot);  // (the mask set it may have been given)
+    b->chans[c].n0slot = -1;
     if (appended)
       b->chans.pop_back();
     else
@@ -1700,19 +1702,28 @@ int kq_bank_add_channels(kq_bank *b, const kq_channel_config *cfgs, unsigned n, 
   if (b->chd.n0lane) {  // compute_n0's lane masks: one set per distinct pair of edges, shared
     int const nsub = b->use64k ? 4 : 1;
     std::vector<int> slots(n);
-    for (unsigned i = 0; i < n; i++) {
-      bool fresh = false;
-      int const slot = acquire_n0slot(b, cfgs[i].low, cfgs[i].high, &fresh);
-      hs[i].n0slot = slots[i] = slot;
-      if (fresh) {
-        std::vector<unsigned long long> m;
-        std::vector<unsigned> meta;
-        build_n0mask(b, cfgs[i].low, cfgs[i].high, m, meta);
-        HIP_TRY(hipMemcpy(b->chd.n0lane + (size_t)slot * nsub * 256, m.data(), m.size() * sizeof(m[0]), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(b->chd.n0meta + (size_t)slot * nsub, meta.data(), meta.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    unsigned taken = 0;
+    auto fill = [&]() -> int {
+      for (unsigned i = 0; i < n; i++) {
+        bool fresh = false;
+        int const slot = acquire_n0slot(b, cfgs[i].low, cfgs[i].high, &fresh);
+        hs[i].n0slot = slots[i] = slot;
+        taken = i + 1;
+        if (fresh) {
+          std::vector<unsigned long long> m;
+          std::vector<unsigned> meta;
+          build_n0mask(b, cfgs[i].low, cfgs[i].high, m, meta);
+          HIP_TRY(hipMemcpy(b->chd.n0lane + (size_t)slot * nsub * 256, m.data(), m.size() * sizeof(m[0]), hipMemcpyHostToDevice));
+          HIP_TRY(hipMemcpy(b->chd.n0meta + (size_t)slot * nsub, meta.data(), meta.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        }
       }
+      HIP_TRY(hipMemcpy(b->chd.n0slot + c0, slots.data(), n * sizeof(int), hipMemcpyHostToDevice));
+      return 0;
+    };
+    if (fill()) {  // all or nothing: the references taken so far go back
+      for (unsigned i = 0; i < taken; i++) release_n0slot(b, slots[i]);
+      return -1;
     }
-    HIP_TRY(hipMemcpy(b->chd.n0slot + c0, slots.data(), n * sizeof(int), hipMemcpyHostToDevice));
   }
   for (unsigned i = 0; i < n; i++) {
     b->chans.push_back(std::move(hs[i]));

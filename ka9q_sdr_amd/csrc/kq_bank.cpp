@@ -16,6 +16,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "kq_design.hpp"
@@ -168,6 +169,7 @@ struct kq_bank {
   static constexpr int kMaxPll = 64;
   int *list_pll_dev = nullptr;
   int *list_active_dev = nullptr;      // the active channels, for the filter launch, when remove_channel has left holes
+  int *list_active_ds_dev = nullptr;   // the same list as the PCM stage reads it, on the demodulators' stream
   std::vector<int> list_active_host;   // empty: no holes, the launch covers slots 0 .. chans.size() - 1 (a bank whose channels
                                        // have ALL been removed never launches: run_blocks refuses it up front)
   std::vector<int> list_pll_host;
@@ -233,17 +235,29 @@ struct kq_bank {
   std::map<std::pair<float, float>, int> n0slot_of;
   std::vector<int> n0slot_refs;                       // per slot; 0 = free
   std::vector<std::pair<float, float>> n0slot_key;    // per slot
-  // Control-plane uploads (per-channel parameters, responses, lists) travel through a pinned ring and are ordered on the
-  // bank's stream: behind the calls in flight, which keep the values they were queued with, and in front of the next call.
-  // The host does not wait for the device (it used to drain both streams around every change: 6 ms per kq_bank_set_filter
-  // on a bank with four 1.5 ms calls in flight, tools/churn_probe.py).  Two halves; entering a half waits for the copies
-  // queued from it the last time round -- long done unless the control plane outruns the device by half a megabyte.
-  static constexpr size_t kCtlRing = 1u << 20;
-  unsigned char *ctl_ring = nullptr;
-  size_t ctl_off = 0;  // next free byte within the current half
-  int ctl_half = 0;
-  hipEvent_t ctl_ev[2] = {nullptr, nullptr};
-  bool ctl_ev_set[2] = {false, false};
+  // Control-plane writes (per-channel parameters, responses, carried-state resets, channel lists) do not touch the device
+  // when they are made: they gather in pinned host memory, in two queues, and the next process call applies each queue with
+  // ONE small launch (k_ctl_apply) at the place in the stream order where its readers expect it --
+  //   FILTER side: what the filter kernels read (responses, compute_n0 masks, the ISB flag, the filter launch's lists):
+  //                on the main stream in front of the call's first kernel, behind the filter passes in flight;
+  //   DEMOD side:  what the demodulators read and carry (gains, flags, squelch / AGC / filter state, their lists): on
+  //                whichever stream the call's demodulators run, in front of them, behind the demodulators in flight.
+  // The calls in flight keep the values they were queued with, nothing waits on the host or across streams, and a
+  // change costs the device a few microseconds (as separate small copies on the stream each change cost 0.5-1 ms of
+  // pipeline time at 32768 channels, tools/soak_realtime.py --only filter).
+  struct CtlQueue {
+    static constexpr size_t kBytes = 1u << 20, kMaxRec = 4096;
+    unsigned char *buf[2] = {nullptr, nullptr};  // pinned; [records (32 B each, kMaxRec of them) | payloads]
+    hipEvent_t applied[2] = {nullptr, nullptr};
+    bool applied_set[2] = {false, false};
+    int cur = 0;
+    unsigned nrec = 0;
+    size_t used = 0;  // payload bytes
+    // The records of one launch are applied concurrently, one workgroup each: two writes to one place must not both be in
+    // it.  A later write to a destination already in the queue replaces the earlier one on the host (destination -> record).
+    std::unordered_map<unsigned long long, unsigned> at;
+  };
+  CtlQueue ctl[2];  // 0 filter side, 1 demod side
   std::vector<HostChan> chans;
   // Steady state of the oscillators: nothing has been set, added or removed since the call before, so the per-call planes
   // follow from that call's on the device (k_block_energy_sum) and the host touches no per-channel state at all.
@@ -297,38 +311,108 @@ int ilog2(unsigned v) {
 
 int sync_all(kq_bank *b);
 
-int upload(kq_bank *b, void *dst, const void *src, size_t bytes) {
-  if (bytes == 0) return 0;
-  if (!b->ctl_ring || bytes > kq_bank::kCtlRing / 2) {  // (a plane larger than half the ring: the plain way)
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
-    return 0;
+enum { CTL_FILTER = 0, CTL_DEMOD = 1 };
+struct CtlRecHost {  // kq_kernels.hip CtlRec
+  unsigned long long dst;
+  unsigned nbytes, fill, value, payload_off;
+  unsigned long long pad;
+};
+static_assert(sizeof(CtlRecHost) == 32, "control record layout");
+
+int ctl_flush(kq_bank *b, int side, hipStream_t st);
+int ctl_flush_now(kq_bank *b);
+
+// room for one more record with `bytes` of payload in queue `side`; a full queue is applied early, on the main stream
+// behind the demodulators in flight (never in practice: a megabyte of parameters between two calls)
+int ctl_room(kq_bank *b, int side, size_t bytes) {
+  kq_bank::CtlQueue &q = b->ctl[side];
+  size_t const payload_cap = kq_bank::CtlQueue::kBytes - kq_bank::CtlQueue::kMaxRec * sizeof(CtlRecHost);
+  if (bytes > payload_cap) {
+    set_err("control-plane write of %zu bytes exceeds the queue", bytes);
+    return -1;
   }
-  size_t const half = kq_bank::kCtlRing / 2;
-  size_t pos = (b->ctl_off + 15) & ~(size_t)15;  // within the current half
-  if (pos + bytes > half) {
-    // into the other half: mark what was queued from the one we leave, wait for what was queued from the one we enter
-    HIP_TRY(hipEventRecord(b->ctl_ev[b->ctl_half], b->stream));
-    b->ctl_ev_set[b->ctl_half] = true;
-    b->ctl_half ^= 1;
-    if (b->ctl_ev_set[b->ctl_half]) HIP_TRY(hipEventSynchronize(b->ctl_ev[b->ctl_half]));
-    pos = 0;
+  if (q.nrec >= kq_bank::CtlQueue::kMaxRec || q.used + bytes > payload_cap) {
+    if (b->calls > 0) {
+      int const last = (int)((b->calls - 1) & 1);
+      if (b->demod_overlapped[last]) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[last], 0));
+    }
+    if (ctl_flush(b, side, b->stream)) return -1;
   }
-  size_t const off = (size_t)b->ctl_half * half + pos;
-  memcpy(b->ctl_ring + off, src, bytes);
-  HIP_TRY(hipMemcpyAsync(dst, b->ctl_ring + off, bytes, hipMemcpyHostToDevice, b->stream));
-  b->ctl_off = pos + bytes;
   return 0;
 }
-
-// What the control plane changes on the device is ordered on the main stream.  The demodulators of the last call may be
-// running on their own stream and read (and, at their end, write) per-channel state: the main stream waits for them -- on
-// the device; the host goes on.
-int order_after_demods(kq_bank *b) {
-  if (b->calls == 0) return 0;
-  int const last = (int)((b->calls - 1) & 1);
-  if (b->demod_overlapped[last] && hipEventQuery(b->ev_demod_done[last]) != hipSuccess)
-    HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[last], 0));
+// queue a copy of `bytes` (a multiple of 4) from host memory to device memory / a 32-bit fill of device memory.
+// A destination that is already in the queue: the earlier record is rewritten in place (same or larger extent) or
+// cancelled and replaced (smaller extent) -- every field of the control plane has one destination and one extent, so a
+// partial overlap with a different start does not occur.
+int ctl_put(kq_bank *b, int side, void *dst, const void *src, size_t bytes) {
+  if (bytes == 0) return 0;
+  kq_bank::CtlQueue &q = b->ctl[side];
+  unsigned long long const key = (unsigned long long)(uintptr_t)dst;
+  auto it = q.at.find(key);
+  if (it != q.at.end()) {
+    CtlRecHost *old = reinterpret_cast<CtlRecHost *>(q.buf[q.cur]) + it->second;
+    if (!old->fill && old->nbytes >= bytes) {
+      memcpy(q.buf[q.cur] + old->payload_off, src, bytes);
+      return 0;
+    }
+    if (old->nbytes <= bytes) old->nbytes = 0;  // covered by the new record: cancelled
+    // (an earlier, LARGER fill under a smaller copy -- no caller does that -- stays in the launch beside the copy: avoided
+    //  by applying what has gathered first)
+    else if (ctl_flush_now(b)) return -1;
+  }
+  if (ctl_room(b, side, bytes)) return -1;
+  size_t const off = kq_bank::CtlQueue::kMaxRec * sizeof(CtlRecHost) + q.used;
+  memcpy(q.buf[q.cur] + off, src, bytes);
+  CtlRecHost const r{key, (unsigned)bytes, 0u, 0u, (unsigned)off, 0ull};
+  memcpy(q.buf[q.cur] + (size_t)q.nrec * sizeof r, &r, sizeof r);
+  q.at[key] = q.nrec;
+  q.nrec++;
+  q.used += (bytes + 15) & ~(size_t)15;
+  return 0;
+}
+int ctl_fill(kq_bank *b, int side, void *dst, unsigned value, size_t bytes) {
+  if (bytes == 0) return 0;
+  kq_bank::CtlQueue &q = b->ctl[side];
+  unsigned long long const key = (unsigned long long)(uintptr_t)dst;
+  auto it = q.at.find(key);
+  if (it != q.at.end()) {
+    CtlRecHost *old = reinterpret_cast<CtlRecHost *>(q.buf[q.cur]) + it->second;
+    if (old->nbytes <= bytes)
+      old->nbytes = 0;  // covered: cancelled
+    else if (ctl_flush_now(b))
+      return -1;
+  }
+  if (ctl_room(b, side, 0)) return -1;
+  CtlRecHost const r{key, (unsigned)bytes, 1u, value, 0u, 0ull};
+  memcpy(q.buf[q.cur] + (size_t)q.nrec * sizeof r, &r, sizeof r);
+  q.at[key] = q.nrec;
+  q.nrec++;
+  return 0;
+}
+// apply what has gathered in queue `side` with one launch on `st`
+int ctl_flush(kq_bank *b, int side, hipStream_t st) {
+  kq_bank::CtlQueue &q = b->ctl[side];
+  if (q.nrec == 0) return 0;
+  kq::launch_ctl_apply(st, q.buf[q.cur], (int)q.nrec);
+  HIP_TRY(hipEventRecord(q.applied[q.cur], st));
+  q.applied_set[q.cur] = true;
+  q.cur ^= 1;
+  q.nrec = 0;
+  q.used = 0;
+  q.at.clear();
+  // the buffer gathered into next was handed to the device two flushes ago: long applied
+  if (q.applied_set[q.cur]) HIP_TRY(hipEventSynchronize(q.applied[q.cur]));
+  return 0;
+}
+// both queues applied now, on the main stream behind the demodulators in flight (for the rare paths that go on to touch
+// the device synchronously: carrier-loop slots, batched channel set-up)
+int ctl_flush_now(kq_bank *b) {
+  if (b->ctl[0].nrec == 0 && b->ctl[1].nrec == 0) return 0;
+  if (b->calls > 0) {
+    int const last = (int)((b->calls - 1) & 1);
+    if (b->demod_overlapped[last]) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[last], 0));
+  }
+  if (ctl_flush(b, CTL_FILTER, b->stream) || ctl_flush(b, CTL_DEMOD, b->stream)) return -1;
   return 0;
 }
 
@@ -396,15 +480,15 @@ int upload_n0mask(kq_bank *b, int c) {
   int const slot = acquire_n0slot(b, b->chans[c].cfg.low, b->chans[c].cfg.high, &fresh);
   release_n0slot(b, old);  // (after the acquire: unchanged edges keep their slot)
   b->chans[c].n0slot = slot;
-  // on the bank's stream: behind whatever call in flight still reads a slot its last user has just given back
+  // filter side: applied behind whatever filter pass in flight still reads a slot its last user has just given back
   std::vector<unsigned long long> m;
   std::vector<unsigned> meta;
   if (fresh) {
     build_n0mask(b, b->chans[c].cfg.low, b->chans[c].cfg.high, m, meta);
-    if (upload(b, b->chd.n0lane + (size_t)slot * nsub * 256, m.data(), m.size() * sizeof(m[0]))) return -1;
-    if (upload(b, b->chd.n0meta + (size_t)slot * nsub, meta.data(), meta.size() * sizeof(unsigned))) return -1;
+    if (ctl_put(b, CTL_FILTER, b->chd.n0lane + (size_t)slot * nsub * 256, m.data(), m.size() * sizeof(m[0]))) return -1;
+    if (ctl_put(b, CTL_FILTER, b->chd.n0meta + (size_t)slot * nsub, meta.data(), meta.size() * sizeof(unsigned))) return -1;
   }
-  if (upload(b, b->chd.n0slot + c, &slot, sizeof(int))) return -1;
+  if (ctl_put(b, CTL_FILTER, b->chd.n0slot + c, &slot, sizeof(int))) return -1;
   return 0;
 }
 
@@ -434,9 +518,9 @@ Derived derive(const kq::Geom &g, const kq_channel_config &k) {
 // fresh = false: a new demodulator thread on an existing channel (set_mode): what struct demod keeps (sig.n0,
 // sig.foffset, sig.pdeviation) is left alone
 int upload_channel(kq_bank *b, int c, bool fresh = true) {
-  // per-channel state is written on the main stream, behind the calls in flight (whose demodulators, wherever they run,
-  // read and at their end write it) and in front of the next call: nothing here waits on the host
-  if (order_after_demods(b)) return -1;
+  // nothing here touches the device or waits: the writes gather in the control queues and the next call applies them --
+  // what the filter kernels read in front of its filter pass, what the demodulators read and carry in front of its
+  // demodulators, each behind the calls in flight
   HostChan &h = b->chans[c];
   kq::Geom const &g = b->g;
   kq_channel_config const &k = h.cfg;
@@ -445,51 +529,46 @@ int upload_channel(kq_bank *b, int c, bool fresh = true) {
   float const recovery = dv.recovery, fm_gain = dv.fm_gain, init_gain = dv.init_gain;
   float const nan = NAN;
   float2 const one = make_float2(1.f, 0.f);  // fm.c:26
+  auto const D = [&](void *dst, const void *src, size_t n) { return ctl_put(b, CTL_DEMOD, dst, src, n); };
+  auto const Z = [&](void *dst, size_t n) { return ctl_fill(b, CTL_DEMOD, dst, 0u, n); };
 
-  if (upload(b, b->chd.mode + c, &mode, sizeof(int))) return -1;
-  if (upload(b, b->chd.flags + c, &flags, sizeof(int))) return -1;
-  if (upload(b, b->chd.low + c, &k.low, sizeof(float))) return -1;
-  if (upload(b, b->chd.high + c, &k.high, sizeof(float))) return -1;
-  if (upload(b, b->chd.fm_gain + c, &fm_gain, sizeof(float))) return -1;
-  if (upload(b, b->chd.headroom + c, &k.headroom, sizeof(float))) return -1;
-  if (upload(b, b->chd.recovery + c, &recovery, sizeof(float))) return -1;
-  if (upload(b, b->chd.hangmax + c, &hangmax, sizeof(int))) return -1;
-  if (upload(b, b->chd.gain + c, &init_gain, sizeof(float))) return -1;
-  if (fresh && upload(b, b->chd.n0 + c, &nan, sizeof(float))) return -1;
-  if (upload(b, b->chd.fm_state + c, &one, sizeof(float2))) return -1;
+  if (ctl_put(b, CTL_FILTER, b->chd.fflags + c, &flags, sizeof(int))) return -1;
+  if (ctl_put(b, CTL_FILTER, b->chd.low + c, &k.low, sizeof(float))) return -1;
+  if (ctl_put(b, CTL_FILTER, b->chd.high + c, &k.high, sizeof(float))) return -1;
+  if (D(b->chd.mode + c, &mode, sizeof(int)) || D(b->chd.flags + c, &flags, sizeof(int)) ||
+      D(b->chd.fm_gain + c, &fm_gain, sizeof(float)) || D(b->chd.headroom + c, &k.headroom, sizeof(float)) ||
+      D(b->chd.recovery + c, &recovery, sizeof(float)) || D(b->chd.hangmax + c, &hangmax, sizeof(int)) ||
+      D(b->chd.gain + c, &init_gain, sizeof(float)) || (fresh && D(b->chd.n0 + c, &nan, sizeof(float))) ||
+      D(b->chd.fm_state + c, &one, sizeof(float2)))
+    return -1;
   // thread-local state of the demodulators at their prologue values (fm.c:26,68-69; am.c:26,33; linear.c:33)
-  HIP_TRY(hipMemsetAsync(b->chd.lastaudio + c, 0, sizeof(float), b->stream));
-  HIP_TRY(hipMemsetAsync(b->chd.sq_count + c, 0, sizeof(int), b->stream));
-  HIP_TRY(hipMemsetAsync(b->chd.hang + c, 0, sizeof(int), b->stream));
-  HIP_TRY(hipMemsetAsync(b->chd.dc + c, 0, sizeof(float), b->stream));
+  if (Z(b->chd.lastaudio + c, sizeof(float)) || Z(b->chd.sq_count + c, sizeof(int)) || Z(b->chd.hang + c, sizeof(int)) ||
+      Z(b->chd.dc + c, sizeof(float)))
+    return -1;
   if (g.Mdec > 1) {
-    HIP_TRY(hipMemsetAsync(b->chd.ahist + (size_t)c * (g.Mdec - 1), 0, sizeof(float) * (g.Mdec - 1), b->stream));
-    for (int k = 0; k < 2; k++)
-      if (b->fm_hist[k])
-        HIP_TRY(hipMemsetAsync(b->fm_hist[k] + (size_t)c * (g.Mdec - 1), 0, sizeof(float) * (g.Mdec - 1), b->stream));
+    if (Z(b->chd.ahist + (size_t)c * (g.Mdec - 1), sizeof(float) * (g.Mdec - 1))) return -1;
+    for (int kk = 0; kk < 2; kk++)
+      if (b->fm_hist[kk] && Z(b->fm_hist[kk] + (size_t)c * (g.Mdec - 1), sizeof(float) * (g.Mdec - 1))) return -1;
   }
-  if (fresh) {
-    HIP_TRY(hipMemsetAsync(b->chd.foffset + c, 0, sizeof(float), b->stream));
-    HIP_TRY(hipMemsetAsync(b->chd.pdev + c, 0, sizeof(float), b->stream));
-  }
+  if (fresh && (Z(b->chd.foffset + c, sizeof(float)) || Z(b->chd.pdev + c, sizeof(float)))) return -1;
   if (g.pl_n > 0) {
-    HIP_TRY(hipMemsetAsync(b->chd.plring + (size_t)c * 16384, 0, sizeof(float) * 16384, b->stream));
-    HIP_TRY(hipMemsetAsync(b->chd.pl_ptr + c, 0, sizeof(*b->chd.pl_ptr), b->stream));
-    HIP_TRY(hipMemsetAsync(b->chd.pl_last + c, 0, sizeof(*b->chd.pl_last), b->stream));
+    if (Z(b->chd.plring + (size_t)c * 16384, sizeof(float) * 16384) || Z(b->chd.pl_ptr + c, sizeof(*b->chd.pl_ptr)) ||
+        Z(b->chd.pl_last + c, sizeof(*b->chd.pl_last)))
+      return -1;
   }
-  if (upload(b, b->chd.plfreq + c, &nan, sizeof(float))) return -1;
+  if (D(b->chd.plfreq + c, &nan, sizeof(float))) return -1;
   if (upload_n0mask(b, c)) return -1;
   return 0;
 }
 
 int upload_response(kq_bank *b, int c) {
-  if (order_after_demods(b)) return -1;
   HostChan &h = b->chans[c];
   kq::Geom const &g = b->g;
-  if (upload(b, b->chd.resp + (size_t)c * g.Ndec, h.resp.data(), sizeof(float2) * g.Ndec)) return -1;
-  if (upload(b, b->chd.noise_gain + c, &h.noise_gain, sizeof(float))) return -1;
+  if (ctl_put(b, CTL_FILTER, b->chd.resp + (size_t)c * g.Ndec, h.resp.data(), sizeof(float2) * g.Ndec)) return -1;
+  if (ctl_put(b, CTL_DEMOD, b->chd.noise_gain + c, &h.noise_gain, sizeof(float))) return -1;
   if (!h.aresp.empty())
-    if (upload(b, b->chd.aresp + (size_t)c * (g.Ndec / 2 + 1), h.aresp.data(), sizeof(float2) * (g.Ndec / 2 + 1))) return -1;
+    if (ctl_put(b, CTL_DEMOD, b->chd.aresp + (size_t)c * (g.Ndec / 2 + 1), h.aresp.data(), sizeof(float2) * (g.Ndec / 2 + 1)))
+      return -1;
   return 0;
 }
 
@@ -681,7 +760,6 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
 }
 
 int upload_lists(kq_bank *b) {
-  if (order_after_demods(b)) return -1;  // the last call's demodulators may still be walking the old lists
   for (int k = 0; k < 3; k++) b->list_host[k].clear();
   b->list_pll_host.clear();
   b->list_active_host.clear();
@@ -694,15 +772,20 @@ int upload_lists(kq_bank *b) {
     else
       b->list_host[m == KQ_FM_DEMOD ? 0 : m == KQ_AM_DEMOD ? 1 : 2].push_back((int)c);
   }
-  if (b->list_active_host.size() == b->chans.size())
+  // the filter launch's list on the filter side; the demodulators' lists, and the PCM stage's copy of the active list,
+  // on the demodulator side (the last call's demodulators may still be walking the old ones)
+  if (b->list_active_host.size() == b->chans.size()) {
     b->list_active_host.clear();  // no holes
-  else if (upload(b, b->list_active_dev, b->list_active_host.data(), b->list_active_host.size() * sizeof(int)))
-    return -1;
+  } else {
+    size_t const n = b->list_active_host.size() * sizeof(int);
+    if (ctl_put(b, CTL_FILTER, b->list_active_dev, b->list_active_host.data(), n)) return -1;
+    if (ctl_put(b, CTL_DEMOD, b->list_active_ds_dev, b->list_active_host.data(), n)) return -1;
+  }
   if (!b->list_pll_host.empty())
-    if (upload(b, b->list_pll_dev, b->list_pll_host.data(), b->list_pll_host.size() * sizeof(int))) return -1;
+    if (ctl_put(b, CTL_DEMOD, b->list_pll_dev, b->list_pll_host.data(), b->list_pll_host.size() * sizeof(int))) return -1;
   for (int k = 0; k < 3; k++)
     if (!b->list_host[k].empty())
-      if (upload(b, b->list_dev[k], b->list_host[k].data(), b->list_host[k].size() * sizeof(int))) return -1;
+      if (ctl_put(b, CTL_DEMOD, b->list_dev[k], b->list_host[k].data(), b->list_host[k].size() * sizeof(int))) return -1;
   b->lists_dirty = false;
   return 0;
 }
@@ -828,14 +911,15 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     b->list_swept_host.clear();
     for (size_t c = 0; c < b->chans.size(); c++)
       if (b->chans[c].active) (b->chans[c].r_eff != 0 ? b->list_swept_host : b->list_unswept_host).push_back((int)c);
-    // (pageable source: the copy is staged before the call returns; on the bank's stream, behind the launches that read the old lists)
-    if (upload(b, b->list_unswept_dev, b->list_unswept_host.data(), b->list_unswept_host.size() * sizeof(int))) return -1;
-    if (upload(b, b->list_swept_dev, b->list_swept_host.data(), b->list_swept_host.size() * sizeof(int))) return -1;
+    if (ctl_put(b, CTL_FILTER, b->list_unswept_dev, b->list_unswept_host.data(), b->list_unswept_host.size() * sizeof(int))) return -1;
+    if (ctl_put(b, CTL_FILTER, b->list_swept_dev, b->list_swept_host.data(), b->list_swept_host.size() * sizeof(int))) return -1;
     b->sweep_lists_dirty = false;
   }
   // That steady-state variant loads its samples 16 bytes at a time from a copy of the call's samples whose 512-sample
   // rows are interleaved in pairs; the IF-power kernel, which reads every new sample anyway, writes it
   float2 *const paired = ((use16k || b->use64k) && (plain || mixed) && b->win_paired && b->fwd_mode != KQ_FWD_PRUNED) ? b->win_paired : nullptr;
+  // the control plane's filter-side writes since the last call, in front of this call's first kernel
+  if (ctl_flush(b, CTL_FILTER, b->stream)) return -1;
   {
     Scope t(b, 2, b->stream);
     // the partial sums live behind the plane's max_blocks if_power values
@@ -958,6 +1042,8 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   // the IF-power recurrence over the call's blocks: one wave, consumed by the demodulators only, so it runs with them and
   // not in front of the filter (folded into the sum's launch -- its last workgroup taking tagged partial sums as they
   // arrive -- it saved nothing measurable: 1.422 against 1.421 ms per step)
+  // the control plane's demodulator-side writes, on the stream this call's demodulators run on, in front of them
+  if (ctl_flush(b, CTL_DEMOD, ds)) return -1;
   if (spectrum)  // the IF power belongs to whoever fed the master (radio.c:123,143-145): status.if_power = 0, not what a
                  // normal call two calls back left in this parity's plane
     HIP_TRY(hipMemsetAsync(pl.if_power, 0, nblocks * sizeof(float), ds));
@@ -991,7 +1077,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   if (b->pcm_on) {
     bool const holes = !b->list_active_host.empty();
     kq::launch_pcm(ds, g, pl, b->pcm, b->pcm_mask, holes ? (int)b->list_active_host.size() : C, (int)nblocks,
-                   holes ? b->list_active_dev : nullptr);
+                   holes ? b->list_active_ds_dev : nullptr);
   }
   if (overlap) HIP_TRY(hipEventRecord(b->ev_demod_done[pp], ds));
   b->demod_overlapped[pp] = overlap;
@@ -1279,13 +1365,16 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->energy_state, 2);
   if (kq::full16k_paired_supported(b->g)) rc |= dev_alloc(&b->win_paired, (size_t)(b->g.M - 1) + (size_t)B * b->g.L);
   for (int k = 0; k < 3; k++) rc |= dev_alloc(&b->list_dev[k], C);
-  if (hipHostMalloc((void **)&b->ctl_ring, kq_bank::kCtlRing, hipHostMallocDefault) != hipSuccess ||
-      hipEventCreateWithFlags(&b->ctl_ev[0], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&b->ctl_ev[1], hipEventDisableTiming) != hipSuccess) {
-    set_err("pinned control ring allocation failed");
-    rc = -1;
-  }
+  for (kq_bank::CtlQueue &q : b->ctl)
+    for (int k = 0; k < 2; k++)
+      if (hipHostMalloc((void **)&q.buf[k], kq_bank::CtlQueue::kBytes, hipHostMallocDefault) != hipSuccess ||
+          hipEventCreateWithFlags(&q.applied[k], hipEventDisableTiming) != hipSuccess) {
+        set_err("pinned control queue allocation failed");
+        rc = -1;
+      }
   rc |= dev_alloc(&b->list_active_dev, C);
+  rc |= dev_alloc(&b->list_active_ds_dev, C);
+  rc |= dev_alloc(&b->chd.fflags, C);
   rc |= dev_alloc(&b->list_unswept_dev, C);
   rc |= dev_alloc(&b->list_swept_dev, C);
   if (b->fwd_mode == KQ_FWD_PRUNED) rc |= dev_alloc(&b->chan_tw, C * kq::pruned_table_elems(g));
@@ -1343,7 +1432,7 @@ int kq_bank_destroy(kq_bank *b) {
                   b->pl2[0].plout, b->pl2[1].plout, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
                   b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state, b->win_paired,
                   b->big.sync, b->big.n0part, b->big.xs,
-                  b->list_dev[0], b->list_dev[1], b->list_dev[2], b->list_active_dev, b->list_unswept_dev, b->list_swept_dev, b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->list_pll_dev, b->pll_state, b->pll_rings,
+                  b->list_dev[0], b->list_dev[1], b->list_dev[2], b->list_active_dev, b->list_active_ds_dev, b->chd.fflags, b->list_unswept_dev, b->list_swept_dev, b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->list_pll_dev, b->pll_state, b->pll_rings,
                   b->pll_side};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -1353,9 +1442,11 @@ int kq_bank_destroy(kq_bank *b) {
       (void)hipEventDestroy(p.b);
     }
   if (b->big.err) (void)hipHostFree(b->big.err);
-  if (b->ctl_ring) (void)hipHostFree(b->ctl_ring);
-  for (hipEvent_t e : b->ctl_ev)
-    if (e) (void)hipEventDestroy(e);
+  for (kq_bank::CtlQueue &q : b->ctl)
+    for (int k = 0; k < 2; k++) {
+      if (q.buf[k]) (void)hipHostFree(q.buf[k]);
+      if (q.applied[k]) (void)hipEventDestroy(q.applied[k]);
+    }
   for (hipStream_t st : {b->copy_in, b->copy_out})
     if (st) {
       (void)hipStreamSynchronize(st);
@@ -1423,7 +1514,7 @@ static int pll_admit(kq_bank *b, const kq_channel_config &m, int npll) {
     return -1;
   }
   if (!b->pll_state) {
-    if (sync_all(b)) return -1;
+    if (ctl_flush_now(b) || sync_all(b)) return -1;
     if (dev_alloc(&b->pll_state, kq_bank::kMaxPll) || dev_alloc(&b->pll_rings, (size_t)kq_bank::kMaxPll * 65536) ||
         dev_alloc(&b->pll_side, (size_t)kq_bank::kMaxPll * 4096) || dev_alloc(&b->list_pll_dev, kq_bank::kMaxPll))
       return -1;
@@ -1480,7 +1571,7 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
     int rank, npll;
     pll_rank(b, c, rank, npll);
     if (pll_admit(b, *cfg, npll)) return -1;
-    if (sync_all(b) || pll_enter(b, rank, npll)) return -1;
+    if (ctl_flush_now(b) || sync_all(b) || pll_enter(b, rank, npll)) return -1;
   }
   HostChan h;
   h.cfg = *cfg;
@@ -1638,7 +1729,7 @@ int kq_bank_add_channels(kq_bank *b, const kq_channel_config *cfgs, unsigned n, 
       h.aresp = it->second;
     }
   }
-  if (sync_all(b)) return -1;
+  if (ctl_flush_now(b) || sync_all(b)) return -1;  // (what the control plane has queued goes first: the copies below are immediate)
   // per-channel planes of the new range, one copy each
   auto put = [&](auto *dst, auto const &v) -> int {
     HIP_TRY(hipMemcpy(dst + c0, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
@@ -1661,7 +1752,7 @@ int kq_bank_add_channels(kq_bank *b, const kq_channel_config *cfgs, unsigned n, 
       gain[i] = d.init_gain;
       ngain[i] = hs[i].noise_gain;
     }
-    if (put(b->chd.mode, mode) || put(b->chd.flags, flags) || put(b->chd.hangmax, hangmax) || put(b->chd.low, low) ||
+    if (put(b->chd.mode, mode) || put(b->chd.flags, flags) || put(b->chd.fflags, flags) || put(b->chd.hangmax, hangmax) || put(b->chd.low, low) ||
         put(b->chd.high, high) || put(b->chd.fm_gain, fm_gain) || put(b->chd.headroom, headroom) ||
         put(b->chd.recovery, recovery) || put(b->chd.gain, gain) || put(b->chd.noise_gain, ngain) || put(b->chd.n0, nanv) ||
         put(b->chd.plfreq, nanv) || put(b->chd.fm_state, one))
@@ -1745,7 +1836,7 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
   }
   HostChan &h = b->chans[ch];
   if (is_pll(h.cfg)) {  // carrier-loop slots move by synchronous copies: both streams idle first (at most 64 such channels)
-    if (sync_all(b)) return -1;
+    if (ctl_flush_now(b) || sync_all(b)) return -1;
     int rank, npll;
     pll_rank(b, ch, rank, npll);
     if (pll_leave(b, rank, npll)) return -1;
@@ -1796,7 +1887,7 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
   // last call's demodulators (upload_channel); only carrier-loop slots, moved by synchronous copies, need the device idle
   HostChan &h = b->chans[ch];
   bool const was = is_pll(h.cfg), now = is_pll(*m);
-  if ((was || now) && sync_all(b)) return -1;
+  if ((was || now) && (ctl_flush_now(b) || sync_all(b))) return -1;
   int rank, npll;
   pll_rank(b, ch, rank, npll);
   if (now && pll_admit(b, *m, npll)) return -1;
@@ -1840,7 +1931,6 @@ int kq_bank_set_linear_options(kq_bank *b, int ch, int isb, int channels) {
     return -1;
   }
   if ((h.cfg.isb != 0) == (isb != 0) && h.cfg.channels == channels) return 0;
-  if (order_after_demods(b)) return -1;
   h.cfg.isb = isb != 0;
   h.cfg.channels = channels;
   h.out_type = h.cfg.isb ? kq::FT_CROSS_CONJ : kq::FT_COMPLEX;
@@ -1849,7 +1939,9 @@ int kq_bank_set_linear_options(kq_bank *b, int ch, int isb, int channels) {
   if (h.cfg.isb) flags |= kq::FLAG_ISB;
   if (h.cfg.channels == 2) flags |= kq::FLAG_STEREO;
   if (h.cfg.square) flags |= kq::FLAG_SQUARE;
-  if (upload(b, b->chd.flags + ch, &flags, sizeof(int))) return -1;
+  // (filter.out->out_type for the slave, demod->output.channels for the hand-off: each side from its next block on)
+  if (ctl_put(b, CTL_FILTER, b->chd.fflags + ch, &flags, sizeof(int))) return -1;
+  if (ctl_put(b, CTL_DEMOD, b->chd.flags + ch, &flags, sizeof(int))) return -1;
   return 0;
 }
 
@@ -1909,8 +2001,8 @@ int kq_bank_set_n0(kq_bank *b, int ch, float n0) {
     set_err("bad channel");
     return -1;
   }
-  if (order_after_demods(b)) return -1;  // the demodulators of a call in flight own the state: written behind them
-  if (upload(b, b->chd.n0 + ch, &n0, sizeof n0)) return -1;
+  // the demodulators of a call in flight own the state: written behind them, in front of the next call's
+  if (ctl_put(b, CTL_DEMOD, b->chd.n0 + ch, &n0, sizeof n0)) return -1;
   return 0;
 }
 
@@ -1931,11 +2023,10 @@ int kq_bank_set_filter(kq_bank *b, int ch, float low, float high, float beta) {
   if (design_channel(b, h, true)) return -1;
   float const fm_gain = (float)((h.cfg.headroom * M_1_PI * b->g.dsamprate) / fabsf(low - high));
   // the new response takes effect from the next call on (filter.c:538-543 swaps it under the mutex between two blocks):
-  // written on the main stream behind the calls in flight and their demodulators; the host does not wait
-  if (order_after_demods(b)) return -1;
-  if (upload(b, b->chd.low + ch, &low, sizeof(float))) return -1;
-  if (upload(b, b->chd.high + ch, &high, sizeof(float))) return -1;
-  if (upload(b, b->chd.fm_gain + ch, &fm_gain, sizeof(float))) return -1;
+  // queued for that call; the host does not wait
+  if (ctl_put(b, CTL_FILTER, b->chd.low + ch, &low, sizeof(float))) return -1;
+  if (ctl_put(b, CTL_FILTER, b->chd.high + ch, &high, sizeof(float))) return -1;
+  if (ctl_put(b, CTL_DEMOD, b->chd.fm_gain + ch, &fm_gain, sizeof(float))) return -1;
   if (upload_n0mask(b, ch)) return -1;
   return upload_response(b, ch);
 }

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   }
   // N/D = 64: the wave that will run the inverse transform fetches what it needs now, under compute_n0
   const float2 *H = ch.resp + (size_t)c * Ndec;
-  bool const isb = (ch.flags[c] & FLAG_ISB) != 0;
+  bool const isb = (ch.fflags[c] & FLAG_ISB) != 0;
   v2f epi_h = {0.f, 0.f}, epi_h2 = {0.f, 0.f}, epi_w[5] = {};
   bool const epi64 = BIG == 0 && (EPI == 1 || (EPI == 0 && Ndec == 64));
   if (epi64 && t < 64) {
@@ -900,7 +900,7 @@ __global__ void k_epilogue64k(Geom g, ChanDev ch, Planes pl, const float2 *__res
   }
   const float2 *Xs = big.xs + cb * Ndec;
   const float2 *H = ch.resp + (size_t)c * Ndec;
-  bool const isb = (ch.flags[c] & FLAG_ISB) != 0;
+  bool const isb = (ch.fflags[c] & FLAG_ISB) != 0;
   for (int p = t; p <= Ndec / 2; p += blockDim.x) {
     float2 gp = cmul(H[p], Xs[p]);
     if (p > 0 && p < Ndec / 2) {

@@ -207,6 +207,32 @@ void launch_block_energy_sum(hipStream_t s, const float2 *newsamples, int L, int
                      nwords, copy_wgs, paired, hist, prev_planes, nchan, cmax, adv, adv_out);
 }
 
+// Control-plane writes (kq_bank.cpp CtlQueue): what kq_bank_set_filter / add_channel / set_mode ... change on the device,
+// gathered by the host in pinned memory since the last call and applied here in ONE launch -- as separate small copies each
+// cost the stream 10-20 us of switching between kernel and copy packets (a kq_bank_set_filter came to 0.8 ms of pipeline
+// time on a bank at real time, tools/soak_realtime.py).  Record r (32 bytes at the front of the buffer): destination, byte
+// count (a multiple of 4), then either the offset of its payload in the buffer or a 32-bit fill value.
+struct CtlRec {
+  unsigned long long dst;
+  unsigned nbytes, fill, value, payload_off;
+  unsigned long long pad;
+};
+__global__ void __launch_bounds__(256) k_ctl_apply(const unsigned char *__restrict__ q) {
+  const CtlRec *r = reinterpret_cast<const CtlRec *>(q) + blockIdx.x;
+  unsigned *dst = reinterpret_cast<unsigned *>(r->dst);
+  unsigned const n = r->nbytes >> 2;
+  if (r->fill) {
+    unsigned const v = r->value;
+    for (unsigned i = threadIdx.x; i < n; i += 256) dst[i] = v;
+  } else {
+    const unsigned *src = reinterpret_cast<const unsigned *>(q + r->payload_off);
+    for (unsigned i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+  }
+}
+void launch_ctl_apply(hipStream_t s, const void *queue_host, int nrec) {
+  if (nrec > 0) hipLaunchKernelGGL(k_ctl_apply, dim3(nrec), dim3(256), 0, s, static_cast<const unsigned char *>(queue_host));
+}
+
 // The planes of the channels retuned since the last call (kq_bank.cpp: patch_list), staged by the host as records of
 // (channel index, eight values) in pinned memory, written over what k_block_energy_sum has just advanced.  One thread per
 // record; launched only for a call that follows a retune.
@@ -395,7 +421,7 @@ __global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__res
   // G goes to the unused middle of the spectrum buffer: bins N_dec/2+1 .. N-N_dec/2 are never read
   float2 *G = lds + (Ndec / 2 + 1);
   const float2 *H = ch.resp + (size_t)c * Ndec;
-  bool const isb = (ch.flags[c] & FLAG_ISB) != 0;
+  bool const isb = (ch.fflags[c] & FLAG_ISB) != 0;
   for (int p = threadIdx.x; p <= Ndec / 2; p += blockDim.x) {
     float2 gp = cmul(H[p], lds[p]);
     if (p > 0 && p < Ndec / 2) {
@@ -468,7 +494,7 @@ __global__ void k_filter_split(Geom g, ChanDev ch, Planes pl, const float2 *__re
   }
   __syncthreads();
   const float2 *H = ch.resp + (size_t)c * Ndec;
-  bool const isb = (ch.flags[c] & FLAG_ISB) != 0;
+  bool const isb = (ch.fflags[c] & FLAG_ISB) != 0;
   float2 *G = lds;
   for (int p = threadIdx.x; p <= Ndec / 2; p += blockDim.x) {
     float2 gp = cmul(H[p], side[p]);

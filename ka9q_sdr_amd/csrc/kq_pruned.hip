@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident(Geom g, ChanDev
       if (SWEPT) turns += r * (0.5 * m0 * (m0 - 1.0));
       y = cmul(y, unit(turns));
       y = cmul(y, ch.resp[(size_t)c * 64 + q]);
-      if (ch.flags[c] & FLAG_ISB) {
+      if (ch.fflags[c] & FLAG_ISB) {
         int const qp = (64 - q) & 63;
         int const partner = (int)(__brev((unsigned)qp) >> 26);
         float2 o;
@@ -743,7 +743,7 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_stream(Geom g, ChanDev c
   {
     double turns = ch.lo_phase[c] + f0 * m0;
     if (SWEPT) turns += r * (0.5 * m0 * (m0 - 1.0));
-    epilogue_lds<ND>(scratch, ypass, unit(turns), ch.resp + (size_t)c * ND, (ch.flags[c] & FLAG_ISB) != 0,
+    epilogue_lds<ND>(scratch, ypass, unit(turns), ch.resp + (size_t)c * ND, (ch.fflags[c] & FLAG_ISB) != 0,
                      pl.filt + ((size_t)c * g.max_blocks + blk) * g.olen, g.olen, lane);
   }
 }
@@ -826,7 +826,7 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident256(Geom g, Chan
       }
     }
     wave_lds_sync();
-    epilogue_from_scratch<ND>(scratch, (ch.flags[c] & FLAG_ISB) != 0, pl.filt + ((size_t)c * g.max_blocks + blk) * g.olen,
+    epilogue_from_scratch<ND>(scratch, (ch.fflags[c] & FLAG_ISB) != 0, pl.filt + ((size_t)c * g.max_blocks + blk) * g.olen,
                               g.olen, lane);
     wave_lds_sync();
   }

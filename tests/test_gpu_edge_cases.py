@@ -397,3 +397,17 @@ def test_soak64k_smoke(gpu):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak64k.py"), "300"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert r.stdout.strip().splitlines()[-1] == "soak ok", r.stdout[-2000:]
+
+
+def test_soak_realtime_smoke(gpu):
+    """tools/soak_realtime.py for a few seconds: 4096 FM / AM / SSB channels fed two blocks per call with PCM planes streamed
+    back, while a random script retunes, sweeps, shifts, refilters, restarts, removes and re-adds channels between the calls
+    (never waiting for the device); the first 200 calls bit for bit against a bank that is drained around every change."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_realtime.py"), "--channels", "4096", "--seconds", "3",
+                        "--check-calls", "200"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert r.stdout.strip().splitlines()[-1] == "soak ok", r.stdout[-2000:]

@@ -57,4 +57,24 @@ state = {}
 timed("add_channel", lambda: state.setdefault("ch", []).append(bank.add_channel(wl.bank_channel_config(plan[9]))))
 timed("remove_channel", lambda: bank.remove_channel(state["ch"].pop()))
 timed("set_mode", lambda: bank.set_mode(11, wl.bank_channel_config(dict(plan[11], demod="am", low=-5000.0, high=5000.0, recovery_rate=50.0))))
+
+
+def paced(name, fn, n=300):
+    """n calls back to back with fn() in front of each: what the operation costs the PIPELINE (the device's pace)"""
+    run(20)
+    bank.sync()
+    t0 = time.perf_counter()
+    for k in range(n):
+        fn(k)
+        bank.process_resident(iq.data_ptr(), B)
+    bank.sync()
+    print("%-28s %.4f ms per call with one in front of every call" % (name, (time.perf_counter() - t0) / n * 1e3))
+
+
+paced("nothing", lambda k: None)
+paced("set_second_lo", lambda k: bank.set_second_lo(5 + k % 100, plan[5 + k % 100]["second_lo"] + 3.0))
+paced("set_filter", lambda k: bank.set_filter(7 + k % 100, -7000.0 - k % 7, 7000.0, 3.0))
+paced("set_filter (same edges)", lambda k: bank.set_filter(7 + k % 100, -7000.0, 7000.0, 3.0))
+paced("set_n0", lambda k: bank.set_n0(7 + k % 100, 1e-9))
+paced("set_mode", lambda k: bank.set_mode(200 + k % 100, wl.bank_channel_config(plan[200 + k % 100])))
 bank.close()

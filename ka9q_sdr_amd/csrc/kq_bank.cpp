@@ -247,9 +247,10 @@ struct kq_bank {
   // pipeline time at 32768 channels, tools/soak_realtime.py --only filter).
   struct CtlQueue {
     static constexpr size_t kBytes = 1u << 20, kMaxRec = 4096;
-    unsigned char *buf[2] = {nullptr, nullptr};  // pinned; [records (32 B each, kMaxRec of them) | payloads]
-    hipEvent_t applied[2] = {nullptr, nullptr};
-    bool applied_set[2] = {false, false};
+    static constexpr int kDepth = 4;  // the host runs up to three calls ahead of the device (kq_bank_pull_wait's lag + 1)
+    unsigned char *buf[kDepth] = {};  // pinned; [records (32 B each, kMaxRec of them) | payloads]
+    hipEvent_t applied[kDepth] = {};
+    bool applied_set[kDepth] = {};
     int cur = 0;
     unsigned nrec = 0;
     size_t used = 0;  // payload bytes
@@ -258,6 +259,34 @@ struct kq_bank {
     std::unordered_map<unsigned long long, unsigned> at;
   };
   CtlQueue ctl[2];  // 0 filter side, 1 demod side
+  // Responses are designed where they are used: kq_bank_set_filter / add_channel / set_mode gather design jobs, and the
+  // next call launches ONE design kernel for them on the main stream in front of its filter pass, which writes each
+  // response into its channel's row (kq_design.hip design_launch).  No copy back, no wait: on a bank at real time the
+  // round trip of a design on a stream of its own came to 2.0-2.4 ms of host time per operation (its packets queue
+  // behind the copy kernels that share its hardware queue; tools/soak_realtime.py).  The noise gain a design yields is
+  // demodulator-side state: the kernel leaves it in ng_next[epoch parity][channel] and a device-to-device record of the
+  // DEMOD queue moves it over in front of the call's demodulators.  The host's copy of a response (kq_bank_get_response)
+  // is fetched when asked for.
+  struct DesignQueue {
+    static constexpr unsigned kMax = 1024;
+    static constexpr int kDepth = 4;
+    unsigned char *pin[kDepth] = {};  // pinned: [kMax jobs | kMax targets]
+    hipEvent_t read[kDepth] = {};     // the launch that read pin[k] is over
+    bool read_set[kDepth] = {};
+    int cur = 0;
+    std::vector<kq::DesignJob> jobs;
+    std::vector<kq::DesignTarget> targets;
+    std::unordered_map<int, unsigned> at;  // channel -> job: the later design of a channel replaces the earlier one
+    unsigned max_jobs = kMax;              // what the scratch holds
+    float2 *scratch = nullptr;             // max_jobs * Ndec
+    float *ng_next = nullptr;              // [2][max_channels]
+    hipEvent_t ng_moved[2] = {};           // the DEMOD-side records that read ng_next[p] have been applied
+    bool ng_moved_set[2] = {false, false};
+    int ng_to_record = -1;                 // parity whose records the next DEMOD flush applies
+    unsigned long long epoch = 0;
+  };
+  DesignQueue dq;
+  std::map<float, std::vector<kq::cfloat>> aresp_cache;  // FM audio response by Kaiser beta (fm.c:54-66: geometry fixed per bank)
   std::vector<HostChan> chans;
   // Steady state of the oscillators: nothing has been set, added or removed since the call before, so the per-call planes
   // follow from that call's on the device (k_block_energy_sum) and the host touches no per-channel state at all.
@@ -314,8 +343,8 @@ int sync_all(kq_bank *b);
 enum { CTL_FILTER = 0, CTL_DEMOD = 1 };
 struct CtlRecHost {  // kq_kernels.hip CtlRec
   unsigned long long dst;
-  unsigned nbytes, fill, value, payload_off;
-  unsigned long long pad;
+  unsigned nbytes, fill, value, payload_off;  // fill: 0 payload, 1 fill with `value`, 2 copy from device address `src`
+  unsigned long long src;
 };
 static_assert(sizeof(CtlRecHost) == 32, "control record layout");
 
@@ -331,13 +360,7 @@ int ctl_room(kq_bank *b, int side, size_t bytes) {
     set_err("control-plane write of %zu bytes exceeds the queue", bytes);
     return -1;
   }
-  if (q.nrec >= kq_bank::CtlQueue::kMaxRec || q.used + bytes > payload_cap) {
-    if (b->calls > 0) {
-      int const last = (int)((b->calls - 1) & 1);
-      if (b->demod_overlapped[last]) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[last], 0));
-    }
-    if (ctl_flush(b, side, b->stream)) return -1;
-  }
+  if (q.nrec >= kq_bank::CtlQueue::kMaxRec || q.used + bytes > payload_cap) return ctl_flush_now(b);
   return 0;
 }
 // queue a copy of `bytes` (a multiple of 4) from host memory to device memory / a 32-bit fill of device memory.
@@ -389,25 +412,89 @@ int ctl_fill(kq_bank *b, int side, void *dst, unsigned value, size_t bytes) {
   q.nrec++;
   return 0;
 }
+// queue a copy of `bytes` from device memory `src`, read when the queue is applied
+int ctl_copy_dev(kq_bank *b, int side, void *dst, const void *src, size_t bytes) {
+  kq_bank::CtlQueue &q = b->ctl[side];
+  unsigned long long const key = (unsigned long long)(uintptr_t)dst;
+  auto it = q.at.find(key);
+  if (it != q.at.end()) {
+    CtlRecHost *old = reinterpret_cast<CtlRecHost *>(q.buf[q.cur]) + it->second;
+    if (old->nbytes <= bytes)
+      old->nbytes = 0;
+    else if (ctl_flush_now(b))
+      return -1;
+  }
+  if (ctl_room(b, side, 0)) return -1;
+  CtlRecHost const r{key, (unsigned)bytes, 2u, 0u, 0u, (unsigned long long)(uintptr_t)src};
+  memcpy(q.buf[q.cur] + (size_t)q.nrec * sizeof r, &r, sizeof r);
+  q.at[key] = q.nrec;
+  q.nrec++;
+  return 0;
+}
+// withdraw a queued write to `dst` (something else is going to write there in front of the same call)
+void ctl_cancel(kq_bank *b, int side, void *dst) {
+  kq_bank::CtlQueue &q = b->ctl[side];
+  auto it = q.at.find((unsigned long long)(uintptr_t)dst);
+  if (it == q.at.end()) return;
+  (reinterpret_cast<CtlRecHost *>(q.buf[q.cur]) + it->second)->nbytes = 0;
+  q.at.erase(it);
+}
+
+// the design jobs gathered since the last call: one launch on the main stream
+int design_flush(kq_bank *b) {
+  kq_bank::DesignQueue &d = b->dq;
+  if (d.jobs.empty()) return 0;
+  int const p = (int)(d.epoch & 1);
+  unsigned const n = (unsigned)d.jobs.size();
+  if (d.read_set[d.cur]) HIP_TRY(hipEventSynchronize(d.read[d.cur]));  // (kDepth launches ago)
+  unsigned char *pin = d.pin[d.cur];
+  memcpy(pin, d.jobs.data(), n * sizeof(kq::DesignJob));
+  memcpy(pin + kq_bank::DesignQueue::kMax * sizeof(kq::DesignJob), d.targets.data(), n * sizeof(kq::DesignTarget));
+  // ng_next[p] was last written two design launches ago; the records that moved those values on ran on the demodulators' stream
+  if (d.ng_moved_set[p]) HIP_TRY(hipStreamWaitEvent(b->stream, d.ng_moved[p], 0));
+  if (kq::design_launch(b->stream, b->g.olen, b->g.Mdec, reinterpret_cast<const kq::DesignJob *>(pin),
+                        reinterpret_cast<const kq::DesignTarget *>(pin + kq_bank::DesignQueue::kMax * sizeof(kq::DesignJob)), n,
+                        d.scratch)) {
+    set_err("response design launch failed");
+    return -1;
+  }
+  HIP_TRY(hipEventRecord(d.read[d.cur], b->stream));
+  d.read_set[d.cur] = true;
+  d.cur = (d.cur + 1) % kq_bank::DesignQueue::kDepth;
+  d.ng_to_record = p;
+  d.epoch++;
+  d.jobs.clear();
+  d.targets.clear();
+  d.at.clear();
+  return 0;
+}
+
 // apply what has gathered in queue `side` with one launch on `st`
 int ctl_flush(kq_bank *b, int side, hipStream_t st) {
   kq_bank::CtlQueue &q = b->ctl[side];
+  if (side == CTL_FILTER && design_flush(b)) return -1;  // (the filter side is always applied on the main stream)
   if (q.nrec == 0) return 0;
   kq::launch_ctl_apply(st, q.buf[q.cur], (int)q.nrec);
   HIP_TRY(hipEventRecord(q.applied[q.cur], st));
   q.applied_set[q.cur] = true;
-  q.cur ^= 1;
+  if (side == CTL_DEMOD && b->dq.ng_to_record >= 0) {
+    int const p = b->dq.ng_to_record;
+    HIP_TRY(hipEventRecord(b->dq.ng_moved[p], st));
+    b->dq.ng_moved_set[p] = true;
+    b->dq.ng_to_record = -1;
+  }
+  q.cur = (q.cur + 1) % kq_bank::CtlQueue::kDepth;
   q.nrec = 0;
   q.used = 0;
   q.at.clear();
-  // the buffer gathered into next was handed to the device two flushes ago: long applied
+  // the buffer gathered into next was handed to the device kDepth flushes ago: long applied
   if (q.applied_set[q.cur]) HIP_TRY(hipEventSynchronize(q.applied[q.cur]));
   return 0;
 }
 // both queues applied now, on the main stream behind the demodulators in flight (for the rare paths that go on to touch
 // the device synchronously: carrier-loop slots, batched channel set-up)
 int ctl_flush_now(kq_bank *b) {
-  if (b->ctl[0].nrec == 0 && b->ctl[1].nrec == 0) return 0;
+  if (b->ctl[0].nrec == 0 && b->ctl[1].nrec == 0 && b->dq.jobs.empty()) return 0;
   if (b->calls > 0) {
     int const last = (int)((b->calls - 1) & 1);
     if (b->demod_overlapped[last]) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_demod_done[last], 0));
@@ -561,22 +648,20 @@ int upload_channel(kq_bank *b, int c, bool fresh = true) {
   return 0;
 }
 
-int upload_response(kq_bank *b, int c) {
-  HostChan &h = b->chans[c];
-  kq::Geom const &g = b->g;
-  if (ctl_put(b, CTL_FILTER, b->chd.resp + (size_t)c * g.Ndec, h.resp.data(), sizeof(float2) * g.Ndec)) return -1;
-  if (ctl_put(b, CTL_DEMOD, b->chd.noise_gain + c, &h.noise_gain, sizeof(float))) return -1;
-  if (!h.aresp.empty())
-    if (ctl_put(b, CTL_DEMOD, b->chd.aresp + (size_t)c * (g.Ndec / 2 + 1), h.aresp.data(), sizeof(float2) * (g.Ndec / 2 + 1)))
-      return -1;
-  return 0;
-}
-
 // Pre-detection response: set_filter with edges normalised to the output rate
 // (fm.c:35: low/dsamprate; am.c:41, linear.c:81: samptime*low)
 // `runtime`: a change made while running goes through display.c:161-177, which scales by samptime whatever the mode
-int design_channel(kq_bank *b, HostChan &h, bool runtime = false) {
+// The design is queued for the next call's design launch (kq_bank::DesignQueue); the FM audio response (designed once, in
+// the demodulator's prologue, fm.c:54-66) comes from the bank's cache by Kaiser beta -- designed, and waited for, the
+// first time a beta is seen.
+int queue_design(kq_bank *b, int c, bool runtime = false) {
+  HostChan &h = b->chans[c];
   kq::Geom const &g = b->g;
+  kq_bank::DesignQueue &d = b->dq;
+  if (g.Ndec > 16384) {
+    set_err("response design: N / decimate = %d exceeds 16384", g.Ndec);
+    return -1;
+  }
   float lo_n, hi_n;
   if (h.cfg.demod_type == KQ_FM_DEMOD && !runtime) {
     lo_n = h.cfg.low / g.dsamprate;
@@ -586,15 +671,51 @@ int design_channel(kq_bank *b, HostChan &h, bool runtime = false) {
     lo_n = samptime * h.cfg.low;
     hi_n = samptime * h.cfg.high;
   }
-  h.resp = kq::design_response(g.N, g.olen, g.Mdec, h.out_type, lo_n, hi_n, h.cfg.kaiser_beta, &h.noise_gain);
-  if (h.resp.empty()) return -1;
-  if (runtime) return 0;  // the FM audio response is designed once, in the demodulator's prologue (fm.c:54-66)
-  if (h.cfg.demod_type == KQ_FM_DEMOD && !h.cfg.flat) {
-    h.aresp = kq::design_fm_audio_response(g.olen, g.Mdec, g.dsamprate, h.cfg.kaiser_beta);
-    if (h.aresp.empty()) return -1;
-  } else {
-    h.aresp.clear();
+  if (!runtime) {
+    if (h.cfg.demod_type == KQ_FM_DEMOD && !h.cfg.flat) {
+      auto it = b->aresp_cache.find(h.cfg.kaiser_beta);
+      if (it == b->aresp_cache.end()) {
+        std::vector<kq::cfloat> a = kq::design_fm_audio_response(g.olen, g.Mdec, g.dsamprate, h.cfg.kaiser_beta);
+        if (a.empty()) return -1;
+        if (b->aresp_cache.size() >= 64) b->aresp_cache.clear();
+        it = b->aresp_cache.emplace(h.cfg.kaiser_beta, std::move(a)).first;
+      }
+      h.aresp = it->second;
+      if (ctl_put(b, CTL_DEMOD, b->chd.aresp + (size_t)c * (g.Ndec / 2 + 1), h.aresp.data(), sizeof(float2) * (g.Ndec / 2 + 1)))
+        return -1;
+    } else {
+      h.aresp.clear();
+    }
   }
+  auto at = d.at.find(c);
+  if (at == d.at.end() && d.jobs.size() >= d.max_jobs && ctl_flush_now(b)) return -1;  // (applies what has gathered, early)
+  int const p = (int)(d.epoch & 1);
+  float gain, ng_scale;
+  kq::design_scales(g.N, h.out_type, &gain, &ng_scale);
+  float2 *const row = b->chd.resp + (size_t)c * g.Ndec;
+  float *const ng = d.ng_next + (size_t)p * b->cfg.max_channels + c;
+  kq::DesignJob const job{lo_n, hi_n, h.cfg.kaiser_beta, gain};
+  kq::DesignTarget const target{row, ng, ng_scale, 0.f};
+  at = d.at.find(c);
+  if (at != d.at.end()) {
+    d.jobs[at->second] = job;
+    d.targets[at->second] = target;
+  } else {
+    d.at[c] = (unsigned)d.jobs.size();
+    d.jobs.push_back(job);
+    d.targets.push_back(target);
+  }
+  ctl_cancel(b, CTL_FILTER, row);  // a response queued from the host for this row: the design runs in front of the queue
+  h.resp.clear();                  // the host's copy: fetched when asked for
+  return ctl_copy_dev(b, CTL_DEMOD, b->chd.noise_gain + c, ng, sizeof(float));
+}
+// the host's copy of a channel's response
+int fetch_response(kq_bank *b, int c) {
+  HostChan &h = b->chans[c];
+  if (!h.resp.empty()) return 0;
+  if (ctl_flush_now(b) || sync_all(b)) return -1;
+  h.resp.resize(b->g.Ndec);
+  HIP_TRY(hipMemcpy((void *)h.resp.data(), b->chd.resp + (size_t)c * b->g.Ndec, sizeof(float2) * b->g.Ndec, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1366,12 +1487,27 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   if (kq::full16k_paired_supported(b->g)) rc |= dev_alloc(&b->win_paired, (size_t)(b->g.M - 1) + (size_t)B * b->g.L);
   for (int k = 0; k < 3; k++) rc |= dev_alloc(&b->list_dev[k], C);
   for (kq_bank::CtlQueue &q : b->ctl)
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < kq_bank::CtlQueue::kDepth; k++)
       if (hipHostMalloc((void **)&q.buf[k], kq_bank::CtlQueue::kBytes, hipHostMallocDefault) != hipSuccess ||
           hipEventCreateWithFlags(&q.applied[k], hipEventDisableTiming) != hipSuccess) {
         set_err("pinned control queue allocation failed");
         rc = -1;
       }
+  {
+    kq_bank::DesignQueue &d = b->dq;
+    size_t const per_job = (size_t)g.Ndec * sizeof(float2);
+    d.max_jobs = (unsigned)std::max<size_t>(1, std::min<size_t>(kq_bank::DesignQueue::kMax, ((size_t)64 << 20) / per_job));
+    rc |= dev_alloc(&d.scratch, (size_t)d.max_jobs * g.Ndec);
+    rc |= dev_alloc(&d.ng_next, 2 * C);
+    for (int k = 0; k < kq_bank::DesignQueue::kDepth; k++)
+      if (hipHostMalloc((void **)&d.pin[k], kq_bank::DesignQueue::kMax * (sizeof(kq::DesignJob) + sizeof(kq::DesignTarget)),
+                        hipHostMallocDefault) != hipSuccess ||
+          hipEventCreateWithFlags(&d.read[k], hipEventDisableTiming) != hipSuccess)
+        rc = -1;
+    for (int k = 0; k < 2; k++)
+      if (hipEventCreateWithFlags(&d.ng_moved[k], hipEventDisableTiming) != hipSuccess) rc = -1;
+    if (g.Ndec <= 16384 && kq::design_prepare(g.olen, g.Mdec)) rc = -1;  // (the twiddle table of the design kernel, built now)
+  }
   rc |= dev_alloc(&b->list_active_dev, C);
   rc |= dev_alloc(&b->list_active_ds_dev, C);
   rc |= dev_alloc(&b->chd.fflags, C);
@@ -1433,7 +1569,7 @@ int kq_bank_destroy(kq_bank *b) {
                   b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state, b->win_paired,
                   b->big.sync, b->big.n0part, b->big.xs,
                   b->list_dev[0], b->list_dev[1], b->list_dev[2], b->list_active_dev, b->list_active_ds_dev, b->chd.fflags, b->list_unswept_dev, b->list_swept_dev, b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->list_pll_dev, b->pll_state, b->pll_rings,
-                  b->pll_side};
+                  b->pll_side, b->dq.scratch, b->dq.ng_next};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (auto *v : {&b->ev_filter, &b->ev_demod, &b->ev_ingest})
@@ -1443,10 +1579,16 @@ int kq_bank_destroy(kq_bank *b) {
     }
   if (b->big.err) (void)hipHostFree(b->big.err);
   for (kq_bank::CtlQueue &q : b->ctl)
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < kq_bank::CtlQueue::kDepth; k++) {
       if (q.buf[k]) (void)hipHostFree(q.buf[k]);
       if (q.applied[k]) (void)hipEventDestroy(q.applied[k]);
     }
+  for (int k = 0; k < kq_bank::DesignQueue::kDepth; k++) {
+    if (b->dq.pin[k]) (void)hipHostFree(b->dq.pin[k]);
+    if (b->dq.read[k]) (void)hipEventDestroy(b->dq.read[k]);
+  }
+  for (int k = 0; k < 2; k++)
+    if (b->dq.ng_moved[k]) (void)hipEventDestroy(b->dq.ng_moved[k]);
   for (hipStream_t st : {b->copy_in, b->copy_out})
     if (st) {
       (void)hipStreamSynchronize(st);
@@ -1581,13 +1723,12 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
   h.lo2.set(cfg->second_lo == 0 ? 0.0 : cfg->second_lo / fs, 0.0, b->n_abs);
   h.dop.set(-cfg->doppler / fs, -cfg->doppler_rate / (fs * fs), b->n_abs);
   h.shift.set(cfg->shift == 0 ? 0.0 : cfg->shift * b->g.D / fs, 0.0, b->out_abs);
-  if (design_channel(b, h)) return -1;
   bool const appended = c == (int)b->chans.size();
   if (appended)
     b->chans.push_back(h);
   else
     b->chans[c] = h;
-  if (upload_channel(b, c) || upload_response(b, c)) {
+  if (upload_channel(b, c) || queue_design(b, c)) {
     if (is_pll(*cfg)) {  // give the slot back
       int rank, npll;
       pll_rank(b, c, rank, npll);
@@ -1676,7 +1817,7 @@ int kq_bank_add_channels(kq_bank *b, const kq_channel_config *cfgs, unsigned n, 
       kq_channel_config const &k = cfgs[i];
       int const out_type = (k.demod_type == KQ_LINEAR_DEMOD && k.isb) ? kq::FT_CROSS_CONJ : kq::FT_COMPLEX;
       if (out_type != ot) continue;
-      float lo_n, hi_n;  // as design_channel: fm.c:35 divides by the output rate, am.c:41 / linear.c:81 multiply by samptime
+      float lo_n, hi_n;  // as queue_design: fm.c:35 divides by the output rate, am.c:41 / linear.c:81 multiply by samptime
       if (k.demod_type == KQ_FM_DEMOD) {
         lo_n = k.low / g.dsamprate;
         hi_n = k.high / g.dsamprate;
@@ -1909,8 +2050,7 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
   h.cfg.shift = m->shift;
   h.out_type = (m->demod_type == KQ_LINEAR_DEMOD && m->isb) ? kq::FT_CROSS_CONJ : kq::FT_COMPLEX;
   h.shift.set(m->shift == 0 ? 0.0 : m->shift * b->g.D / (double)b->g.samprate, 0.0, b->out_abs);  // radio.c:367
-  if (design_channel(b, h)) return -1;
-  if (upload_channel(b, ch, false) || upload_response(b, ch)) return -1;
+  if (upload_channel(b, ch, false) || queue_design(b, ch)) return -1;
   b->lists_dirty = true;
   note_patch(b, ch);  // the shift oscillator (radio.c:367)
   return 0;
@@ -2020,7 +2160,6 @@ int kq_bank_set_filter(kq_bank *b, int ch, float low, float high, float beta) {
   h.cfg.low = low;
   h.cfg.high = high;
   h.cfg.kaiser_beta = beta;
-  if (design_channel(b, h, true)) return -1;
   float const fm_gain = (float)((h.cfg.headroom * M_1_PI * b->g.dsamprate) / fabsf(low - high));
   // the new response takes effect from the next call on (filter.c:538-543 swaps it under the mutex between two blocks):
   // queued for that call; the host does not wait
@@ -2028,7 +2167,7 @@ int kq_bank_set_filter(kq_bank *b, int ch, float low, float high, float beta) {
   if (ctl_put(b, CTL_FILTER, b->chd.high + ch, &high, sizeof(float))) return -1;
   if (ctl_put(b, CTL_DEMOD, b->chd.fm_gain + ch, &fm_gain, sizeof(float))) return -1;
   if (upload_n0mask(b, ch)) return -1;
-  return upload_response(b, ch);
+  return queue_design(b, ch, true);
 }
 
 namespace {
@@ -2763,6 +2902,7 @@ int kq_bank_get_response(kq_bank *b, int ch, float *dst, size_t cap) {
     set_err("bad channel/capacity");
     return -1;
   }
+  if (fetch_response(b, ch)) return -1;
   memcpy(dst, b->chans[ch].resp.data(), sizeof(float2) * b->g.Ndec);
   return 0;
 }

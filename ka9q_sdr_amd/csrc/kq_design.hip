@@ -61,14 +61,15 @@ __global__ void k_kaiser(float *__restrict__ w, int M, float beta) {
 template <bool REAL>
 __global__ void k_design(int log2n, int M, int spec, const DesignJob *__restrict__ jobs, const float2 *__restrict__ given,
                          float2 *__restrict__ out, float2 *__restrict__ scratch, float *__restrict__ sumsq, int nsum,
-                         const float2 *__restrict__ tw, int tw_log2) {
+                         const float2 *__restrict__ tw, int tw_log2, const DesignTarget *__restrict__ targets) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   __shared__ float red_f[16];
   __shared__ int red_i[16];
   int const N = 1 << log2n, nbins = REAL ? N / 2 + 1 : N;
   DesignJob const job = jobs[blockIdx.x];
   const float2 *in = given ? given + (size_t)blockIdx.x * nbins : nullptr;
-  float2 *res = out + (size_t)blockIdx.x * nbins;
+  float2 *res = targets ? static_cast<float2 *>(targets[blockIdx.x].resp) : out + (size_t)blockIdx.x * nbins;
+  if (!res) return;  // a job withdrawn after it was queued (the whole workgroup leaves)
   float2 *taps = scratch + (size_t)blockIdx.x * N;
 
   // ---- target spectrum, bin i of N (both halves: the inverse transform below is complex)
@@ -120,6 +121,7 @@ __global__ void k_design(int log2n, int M, int spec, const DesignJob *__restrict
   }
   block_sum_fi(acc, dummy, red_f, red_i);
   if (threadIdx.x == 0 && sumsq) sumsq[blockIdx.x] = acc;
+  if (threadIdx.x == 0 && targets && targets[blockIdx.x].noise_gain) *targets[blockIdx.x].noise_gain = targets[blockIdx.x].ng_scale * acc;
 }
 
 // twiddle tables exp(-2 pi i k / T), k < T/2, per device and size (built in double, rounded once)
@@ -237,7 +239,7 @@ int design_batch(int L, int M, bool real_taps, int spec, const std::vector<Desig
       ensure_dynamic_lds((const void *)kernel, lds_bytes);
       hipLaunchKernelGGL(kernel, dim3((unsigned)count), dim3(threads), lds_bytes, st, log2n, M, spec, (const DesignJob *)w->buf[0],
                          (const float2 *)(given ? w->buf[1] : nullptr), (float2 *)w->buf[2], (float2 *)w->buf[3], (float *)w->buf[4],
-                         nsum, tw, log2n);
+                         nsum, tw, log2n, (const DesignTarget *)nullptr);
     };
     real_taps ? go(k_design<true>) : go(k_design<false>);
     ok = hipGetLastError() == hipSuccess;
@@ -302,6 +304,39 @@ int design_responses(int N, int L_dec, int M_dec, int out_type, const std::vecto
   noise_gains.resize(sums.size());
   for (size_t i = 0; i < sums.size(); i++) noise_gains[i] = (two_sided ? 2.f : 1.f) * (float)N * sums[i];
   return 0;
+}
+
+// The same design, queued on a stream of the caller and left on the device: job i's response goes to targets[i].resp
+// and its noise gain to targets[i].noise_gain -- no copy back, nothing waits.  `jobs` and `targets` are read by the
+// kernel where they lie (pinned host memory the caller keeps until the launch is over), `scratch` is count * (L_dec +
+// M_dec - 1) float2 of device memory.  The twiddle table of this size must exist (design_prepare, which may block).
+int design_prepare(int L_dec, int M_dec) {
+  int const N = L_dec + M_dec - 1;
+  int log2n = 0;
+  while ((1 << log2n) < N) log2n++;
+  if (N < 2 || (1 << log2n) != N || N > 16384) return -1;
+  return design_twiddles(log2n) ? 0 : -1;
+}
+int design_launch(void *stream, int L_dec, int M_dec, const DesignJob *jobs, const DesignTarget *targets, unsigned count,
+                  void *scratch) {
+  int const N = L_dec + M_dec - 1;
+  int log2n = 0;
+  while ((1 << log2n) < N) log2n++;
+  hipStream_t const st = static_cast<hipStream_t>(stream);
+  const float2 *tw = design_twiddles(log2n);
+  if (!tw || count == 0) return tw ? 0 : -1;
+  size_t const lds_bytes = (size_t)N * sizeof(float2);
+  ensure_dynamic_lds((const void *)k_design<false>, lds_bytes);
+  hipLaunchKernelGGL(k_design<false>, dim3(count), dim3(N >= 1024 ? 256 : 64), lds_bytes, st, log2n, M_dec, (int)SPEC_BAND, jobs,
+                     (const float2 *)nullptr, (float2 *)nullptr, (float2 *)scratch, (float *)nullptr, N, tw, log2n, targets);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+// gain and noise-gain factor of a slave's design (what design_responses applies on the host)
+void design_scales(int N, int out_type, float *gain, float *ng_scale) {
+  bool const two_sided = out_type == FT_REAL || out_type == FT_CROSS_CONJ;
+  *gain = 1.0f / (float)N;
+  if (two_sided) *gain *= (float)M_SQRT1_2;
+  *ng_scale = (two_sided ? 2.f : 1.f) * (float)N;
 }
 
 std::vector<cfloat> design_response(int N, int L_dec, int M_dec, int out_type, float low, float high, float beta,

@@ -17,6 +17,12 @@ struct DesignJob {  // one response of a batch (device layout)
   float beta;       // Kaiser window shape
   float gain;       // passband value of the target spectrum
 };
+struct DesignTarget {  // where a response designed on a stream goes (design_launch); resp == null: the job is void
+  void *resp;          // (L_dec + M_dec - 1) complex bins, device memory
+  float *noise_gain;   // device memory, or null
+  float ng_scale;
+  float pad;
+};
 struct BandEdges {
   float low, high, beta;
 };
@@ -33,6 +39,11 @@ int design_responses(int N, int L_dec, int M_dec, int out_type, const std::vecto
 // one of them; empty on failure
 std::vector<cfloat> design_response(int N, int L_dec, int M_dec, int out_type, float low, float high, float beta,
                                     float *noise_gain_out = nullptr);
+
+// design_responses queued on a stream, results left on the device (kq_design.hip); hipStream_t passed as void *
+int design_prepare(int L_dec, int M_dec);
+int design_launch(void *stream, int L_dec, int M_dec, const DesignJob *jobs, const DesignTarget *targets, unsigned count, void *scratch);
+void design_scales(int N, int out_type, float *gain, float *ng_scale);
 
 // FM post-detection response (fm.c:42, 56-65): 300 Hz high-pass, -6 dB/octave to 6 kHz, Kaiser
 // windowed for a REAL->REAL filter of AL new samples and AM taps.  Returns AN/2+1 bins.

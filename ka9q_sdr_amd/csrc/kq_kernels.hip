@@ -211,19 +211,24 @@ void launch_block_energy_sum(hipStream_t s, const float2 *newsamples, int L, int
 // gathered by the host in pinned memory since the last call and applied here in ONE launch -- as separate small copies each
 // cost the stream 10-20 us of switching between kernel and copy packets (a kq_bank_set_filter came to 0.8 ms of pipeline
 // time on a bank at real time, tools/soak_realtime.py).  Record r (32 bytes at the front of the buffer): destination, byte
-// count (a multiple of 4), then either the offset of its payload in the buffer or a 32-bit fill value.
+// count (a multiple of 4), then the offset of its payload in the buffer (kind 0), a 32-bit fill value (kind 1) or the
+// device address to copy from (kind 2: a value an earlier kernel of the call left on the device -- the noise gain of a
+// response designed in front of the filter pass, kq_design.hip design_launch).
 struct CtlRec {
   unsigned long long dst;
-  unsigned nbytes, fill, value, payload_off;
-  unsigned long long pad;
+  unsigned nbytes, kind, value, payload_off;
+  unsigned long long src;
 };
 __global__ void __launch_bounds__(256) k_ctl_apply(const unsigned char *__restrict__ q) {
   const CtlRec *r = reinterpret_cast<const CtlRec *>(q) + blockIdx.x;
   unsigned *dst = reinterpret_cast<unsigned *>(r->dst);
   unsigned const n = r->nbytes >> 2;
-  if (r->fill) {
+  if (r->kind == 1) {
     unsigned const v = r->value;
     for (unsigned i = threadIdx.x; i < n; i += 256) dst[i] = v;
+  } else if (r->kind == 2) {
+    const unsigned *src = reinterpret_cast<const unsigned *>(r->src);
+    for (unsigned i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
   } else {
     const unsigned *src = reinterpret_cast<const unsigned *>(q + r->payload_off);
     for (unsigned i = threadIdx.x; i < n; i += 256) dst[i] = src[i];

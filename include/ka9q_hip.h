@@ -168,10 +168,12 @@ int kq_bank_set_mode(kq_bank *bank, int ch, const kq_channel_config *mode);
 
 /* --- tuning, all phase continuous and effective from the next block (osc.c:22-36) ---
  * None of the calls of this section, nor kq_bank_add_channel / remove_channel / set_mode / set_filter / set_n0, waits for
- * the device: what they change is written on the bank's stream, behind the process calls already queued (which keep the
- * values they were queued with) and in front of the next one.  A bank running at real time with several calls in flight is
- * not stalled by its control plane (0.05-0.2 ms of host time per call at 32768 channels; only carrier-tracking channels,
- * whose loop state moves between slots, still drain the device). */
+ * the device: what they change gathers in pinned queues and the next kq_bank_process applies it on the device, behind the
+ * calls already queued (which keep the values they were queued with) and in front of its own kernels -- a new filter
+ * response included, which is designed on the bank's stream where it is used (kq_bank_get_response then fetches it).  A
+ * bank running at real time with several calls in flight is not stalled by its control plane (0.001-0.05 ms of host time
+ * per operation at 32768 channels; only carrier-tracking channels, whose loop state moves between slots, still drain
+ * the device -- and kq_bank_get_response of a channel whose filter has just been set). */
 /* demod->filter.isb and demod->output.channels of a running linear channel (linear.c:117-120, 291-300): the slave's
  * out_type and the mono / stereo hand-off change from the next block on; AGC state and response are left alone. */
 int kq_bank_set_linear_options(kq_bank *bank, int ch, int isb, int channels);

@@ -1162,7 +1162,9 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   }
   // the IF-power recurrence over the call's blocks: one wave, consumed by the demodulators only, so it runs with them and
   // not in front of the filter (folded into the sum's launch -- its last workgroup taking tagged partial sums as they
-  // arrive -- it saved nothing measurable: 1.422 against 1.421 ms per step)
+  // arrive -- it saved nothing measurable: 1.422 against 1.421 ms per step; on the second stream beside the filter pass,
+  // with an event each way, it cost 7-9 us per step where the demodulators run on the main stream -- a wait on another
+  // queue's event is dearer than the 6.5 us kernel: cfg 2 0.4326 -> 0.4416, cfg 4 1.5050 -> 1.5124, tools/ab_env.sh)
   // the control plane's demodulator-side writes, on the stream this call's demodulators run on, in front of them
   if (ctl_flush(b, CTL_DEMOD, ds)) return -1;
   if (spectrum)  // the IF power belongs to whoever fed the master (radio.c:123,143-145): status.if_power = 0, not what a

@@ -369,6 +369,15 @@ int ctl_room(kq_bank *b, int side, size_t bytes) {
 // partial overlap with a different start does not occur.
 int ctl_put(kq_bank *b, int side, void *dst, const void *src, size_t bytes) {
   if (bytes == 0) return 0;
+  // a long payload (a channel list of a large bank: 128 KiB) as records of 4 KiB: a record is one workgroup's work, and its
+  // loads cross the link -- as ONE record a list took a workgroup ~0.25 ms, which the next call's kernels waited for
+  size_t const kChunk = 4096;
+  if (bytes > kChunk) {
+    for (size_t off = 0; off < bytes; off += kChunk)
+      if (ctl_put(b, side, static_cast<char *>(dst) + off, static_cast<const char *>(src) + off, std::min(kChunk, bytes - off)))
+        return -1;
+    return 0;
+  }
   kq_bank::CtlQueue &q = b->ctl[side];
   unsigned long long const key = (unsigned long long)(uintptr_t)dst;
   auto it = q.at.find(key);

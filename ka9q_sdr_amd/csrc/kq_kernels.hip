@@ -226,11 +226,16 @@ __global__ void __launch_bounds__(256) k_ctl_apply(const unsigned char *__restri
   if (r->kind == 1) {
     unsigned const v = r->value;
     for (unsigned i = threadIdx.x; i < n; i += 256) dst[i] = v;
-  } else if (r->kind == 2) {
-    const unsigned *src = reinterpret_cast<const unsigned *>(r->src);
-    for (unsigned i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    return;
+  }
+  // (a payload lies in host memory: every load is a trip over the link, so as few and as wide as the alignment allows --
+  //  the host cuts long payloads into records of 4 KiB, one trip per thread)
+  const unsigned *src = r->kind == 2 ? reinterpret_cast<const unsigned *>(r->src) : reinterpret_cast<const unsigned *>(q + r->payload_off);
+  if ((((unsigned long long)(uintptr_t)dst | (unsigned long long)(uintptr_t)src | r->nbytes) & 15ull) == 0) {
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+    for (unsigned i = threadIdx.x; i < (n >> 2); i += 256) d4[i] = s4[i];
   } else {
-    const unsigned *src = reinterpret_cast<const unsigned *>(q + r->payload_off);
     for (unsigned i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
   }
 }

@@ -2696,7 +2696,8 @@ int kq_bank_join(kq_bank *b) {
 int kq_bank_sync(kq_bank *b) {
   kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
   if (!b) return -1;
-  if (sync_all(b)) return -1;
+  // "everything issued so far" includes what the control plane has queued for the next call: applied now
+  if (ctl_flush_now(b) || sync_all(b)) return -1;
   return report_lost_sibling(b);
 }
 

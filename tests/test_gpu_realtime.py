@@ -514,3 +514,70 @@ def test_8192_mixed_channels_two_blocks_per_call_against_the_oracle(gpu):
     assert len({t[0] for t in ties}) <= 2, ties
     import conftest
     conftest.note_ties("test_8192_mixed_channels_two_blocks_per_call_against_the_oracle", ties, len(sampled))
+
+
+def test_many_filter_changes_between_two_calls(gpu):
+    """Responses are designed on the bank's stream in front of the call that uses them (kq_bank.cpp DesignQueue): 1300
+    kq_bank_set_filter calls between two calls in flight -- more than one design launch holds, so the queue is applied early
+    once -- then a second set_filter for some of those channels (the later design of a channel replaces the earlier one),
+    nothing drained.  Against a bank that is drained around every single change: responses (fetched from the device when
+    asked for), audio and every status word (noise_gain among them) bit for bit; and three of the responses against the oracle's
+    set_filter."""
+    import kq_oracle as ko
+    from common import oracle_cfg
+    g = dict(samprate=192000, L=512, M=513, D=4)
+    fs, L = g["samprate"], g["L"]
+    olen = L // g["D"]
+    C, nb, ncalls = 1300, 2, 4
+    base = _mixed_plan(fs, 13)
+    plan = [dict(base[c % 13]) for c in range(C)]
+    iq = wl.make_iq(fs, ncalls * nb * L, seed=8, emitters=range(24, 40))
+    iq_pin = torch.from_numpy(iq.copy()).pin_memory()
+
+    def edges(c, again):
+        p = plan[c]
+        f = 0.55 + 0.4 * ((c * 37) % 101) / 101.0
+        if again:
+            f *= 0.8
+        return p["low"] * f, p["high"] * (1.5 - f), 2.0 + (c % 4)
+
+    out = []
+    for drained in (False, True):
+        bank = kq.Bank(fs, L, g["M"], g["D"], C, nb, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL, pl_tone=False)
+        bank.add_channels([bank_cfg(p) for p in plan])
+        audio = [_pinned(C * nb * 2 * olen, torch.float32) for _ in range(ncalls)]
+        stat = [_pinned(C * nb * ctypes.sizeof(kq.ChanStatus), torch.uint8) for _ in range(ncalls)]
+        bank.push_iq_async(iq_pin.data_ptr(), nb * L)
+        for k in range(ncalls):
+            if k == 2:
+                for c in range(C):
+                    if drained:
+                        bank.sync()
+                    bank.set_filter(c, *edges(c, False))
+                for c in range(0, C, 7):
+                    if drained:
+                        bank.sync()
+                    bank.set_filter(c, *edges(c, True))
+            assert bank.process() == nb
+            if k + 1 < ncalls:
+                bank.push_iq_async(iq_pin.data_ptr() + 8 * (k + 1) * nb * L, nb * L)
+            bank.pull_planes_async(audio[k].data_ptr(), stat[k].data_ptr())
+            if drained:
+                bank.sync()
+        resp = np.stack([bank.response(c) for c in range(C)])      # (waits for what is in flight)
+        bank.host_io_wait()
+        bank.sync()
+        bank.close()
+        st = [np.frombuffer(s.numpy().tobytes(), dtype=STATUS_DTYPE).reshape(C, nb) for s in stat]
+        au = [a.numpy().reshape(C, nb, 2 * olen).copy() for a in audio]
+        out.append((st, au, resp))
+    (sa, aa, ra), (sb, ab, rb) = out
+    assert np.array_equal(ra, rb)
+    for k in range(ncalls):
+        assert np.array_equal(aa[k], ab[k]), k
+        assert sa[k].tobytes() == sb[k].tobytes(), k
+    assert not np.array_equal(sa[1]["noise_gain"], sa[2]["noise_gain"])     # the new responses' noise gains reached the status
+    for c in (0, 7, 1299):
+        ch = ko.Channel(oracle_cfg(plan[c], fs, L, g["M"], g["D"], compute_n0=1))
+        ch.set_filter(*edges(c, c % 7 == 0))
+        np.testing.assert_allclose(ra[c], ch.response(), rtol=0, atol=2e-9)

@@ -347,6 +347,10 @@ def measure_channels_at_realtime(torch, kq, wl, dev_index, stream, seconds):
         # kq_bank_push_rtp per datagram), int16 PCM planes out
         out["rtp_in_pcm_out"] = measure_realtime(torch, kq, wl, "cfg4", best["channels"], 2, dev_index, stream,
                                                  seconds=min(4.0, seconds), pcm=True, rtp_samples=1024)
+        # a busy control plane beside the stream: a filter change before every call, mode restarts, a channel leaving and
+        # returning (~1100 operations per second); none of them waits for the device or holds up the calls in flight
+        out["with_control_plane"] = measure_realtime(torch, kq, wl, "cfg4", best["channels"], 2, dev_index, stream,
+                                                     seconds=min(4.0, seconds), pcm=True, control_plane=True)
     return out
 
 

@@ -28,7 +28,7 @@ def build_bank(kq, wl, config, C, B, dev_index, stream, compute_n0=True):
 
 
 def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.0, host_io=True, pcm=False, warm_calls=50,
-                     retunes_per_call=0, swept_channels=0, rtp_samples=0):
+                     retunes_per_call=0, swept_channels=0, rtp_samples=0, control_plane=False):
     """C channels, B blocks per call, for `seconds` of wall time.  host_io: input from pinned host memory, audio (float, or
     the int16 PCM words when pcm) + status planes to pinned host memory after every call into one of three buffer sets; the
     host waits for the planes of call k-2 once it has queued call k (it never runs more than two deliveries ahead of what it
@@ -82,10 +82,36 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
                 seq[0] += 1
                 assert bank.push_rtp(pk) == rtp_samples
 
+        nops = [0]
+        gone = []
+
+        def operate(k):
+            c = (k * 7919) % C
+            if not gone or gone[0] != c:
+                f = 0.8 + 0.2 * ((k * 31) % 17) / 17.0
+                bank.set_filter(c, plan[c]["low"] * f, plan[c]["high"] * f, 3.0)
+                nops[0] += 1
+            if k % 3 == 0:
+                c = (k * 104729 + 11) % C
+                if not gone or gone[0] != c:
+                    bank.set_mode(c, wl.bank_channel_config(plan[c]))
+                    nops[0] += 1
+            if gone:
+                c = gone.pop()
+                assert bank.add_channel(wl.bank_channel_config(plan[c])) == c      # (the only hole)
+                nops[0] += 1
+            elif k % 2 == 0:
+                c = (k * 15485863 + 5) % C
+                bank.remove_channel(c)
+                gone.append(c)
+                nops[0] += 1
+
         def call(k):
             for i in range(retunes_per_call):
                 c = (k * 7919 + i * 104729) % C
                 bank.set_second_lo(c, plan[c]["second_lo"] + (1.0 if k & 1 else 0.0))
+            if control_plane:
+                operate(k)
             assert bank.process() == B
             push_batch()
             j = k % nbuf
@@ -120,6 +146,8 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
     bank.host_timing(reset=True)
     bank.enable_timing(1)
     bank.timing(reset=True)
+    if host_io:
+        nops[0] = 0
     t0 = time.perf_counter()
     run(ncalls, warm_calls + 8)
     if host_io:
@@ -134,6 +162,8 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
         j = (warm_calls + 8 + ncalls - 1) % nbuf
         st = np.frombuffer(stats[j].numpy().tobytes(), dtype=kq.bank.STATUS_DTYPE).reshape(C, B)
         a = outs[j].numpy().reshape(C, B, 2 * olen)
+        if gone:           # (the channel that is away right now still shows its last delivery: not counted)
+            st = np.delete(st, gone[0], axis=0)
         checksum = {"nout_sum": int(st["nout"].sum()), "squelch_open": int((st["squelch_count"] < 2).sum()),
                     "audio_abs_sum": float(np.abs(a[::max(1, C // 997), :, :olen].astype(np.float64)).sum())}
     bank.close()
@@ -150,4 +180,6 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
             "h2d_bytes_per_call": B * L * 8 if host_io else 0,
             "input": ("RTP datagrams of %d int16 I/Q samples (kq_bank_push_rtp)" % rtp_samples) if rtp_samples else
                      ("float batch (kq_bank_push_iq_async)" if host_io else "resident"),
-            "retunes_per_call": retunes_per_call, "swept_channels": swept_channels, "setup_s": round(setup_s, 2), "check": checksum}
+            "retunes_per_call": retunes_per_call, "swept_channels": swept_channels,
+            "control_plane_ops_per_s": round(nops[0] / (dt * ncalls), 1) if host_io and control_plane else 0,
+            "setup_s": round(setup_s, 2), "check": checksum}

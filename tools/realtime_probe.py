@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--retunes", type=int, default=0, help="channels retuned before every call (every call then stages on the host)")
     ap.add_argument("--swept", type=int, default=0, help="channels with a swept Doppler oscillator (rate != 0)")
     ap.add_argument("--rtp", type=int, default=0, help="input as RTP datagrams of this many int16 I/Q samples (kq_bank_push_rtp)")
+    ap.add_argument("--control-plane", action="store_true", help="filter / mode changes and a channel leaving and returning around every call")
     a = ap.parse_args()
     import torch
     import ka9q_sdr_amd as kq
@@ -46,7 +47,7 @@ def main():
     for C in [int(x) for x in a.channels.split(",")]:
         for B in [int(x) for x in a.blocks.split(",")]:
             r = measure_realtime(torch, kq, wl, a.config, C, B, 0, stream, seconds=a.seconds, host_io=not a.no_io, pcm=a.pcm,
-                                 retunes_per_call=a.retunes, swept_channels=a.swept, rtp_samples=a.rtp)
+                                 retunes_per_call=a.retunes, swept_channels=a.swept, rtp_samples=a.rtp, control_plane=a.control_plane)
             print(json.dumps(r), flush=True)
 
 

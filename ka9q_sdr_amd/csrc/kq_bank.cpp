@@ -1156,6 +1156,8 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   // and, with the planes streamed to the host after every call, 1.54 / 1.60-1.76 (the copy kernel then has the whole next
   // filter pass to hide under).  KQ_DEMOD_OVERLAP=0 / 1 forces either.
   bool const agc_channels = !b->list_host[1].empty() || !b->list_host[2].empty();
+  // (round 5, cfg 2 with its fused FM demodulator: overlapped 0.4175-0.4196 ms per step against 0.4194-0.4195 on one box,
+  //  0.4427 against 0.4475 on a slower one, with the filter launch itself 9 % longer -- left where it is)
   bool const overlap = b->stream2 != b->stream &&
                        (b->overlap_mode == 1 || (b->overlap_mode < 0 && !b->use64k && (b->pulled_since_call || agc_channels)));
   b->pulled_since_call = false;

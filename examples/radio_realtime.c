@@ -2,7 +2,7 @@
  * reference's operating point (one `radio` process per channel behind one multicast group, main.c:105, README.md:470-477) as
  * one channel bank fed in small batches.  INTEGRATION.md section B2.
  *
- *   radio_realtime [channels [blocks_per_call [seconds [pcm]]]]      defaults 32768 2 3 1
+ *   radio_realtime [channels [blocks_per_call [seconds [pcm [operator]]]]]      defaults 32768 2 3 1 0
  *
  * A 10 MS/s front end with FM carriers 140 kHz apart (rank 0 of radio_fanout.c's stream), N = 16384, decimate 256: a
  * batch of 2 blocks is 1.64 ms of signal.  The host's loop is the one a live receiver runs --
@@ -12,6 +12,10 @@
  * -- with the input in pinned host memory (what a socket reader fills) and every channel's audio handed back to pinned host
  * memory after every call, as clipped big-endian int16 PCM words (audio.c:22-28: what send_mono_output puts on the wire) with
  * the silent-packet masks, or as floats (pcm = 0), plus the status plane.  Set-up is one kq_bank_add_channels call.
+ * operator = 1: somebody works the receiver meanwhile -- before every call one channel's filter is changed
+ * (kq_bank_set_filter: display.c:161-177), before every other call a channel is dropped or the dropped one comes back
+ * (kq_bank_remove_channel / kq_bank_add_channel), before every fourth a channel is retuned (kq_bank_set_second_lo).  None of
+ * these waits for the device; the calls in flight keep the parameters they were queued with.
  * Prints the real-time factor (signal time / wall time; >= 1 means the bank keeps up), the host's own time per call and
  * the delivery rate, and checks a delivered channel: squelch open, the 1 kHz tone's deviation seen.
  *
@@ -49,6 +53,7 @@ int main(int argc, char **argv){
   unsigned const B = argc > 2 ? (unsigned)atoi(argv[2]) : 2u;
   double const seconds = argc > 3 ? atof(argv[3]) : 3.0;
   int const pcm = argc > 4 ? atoi(argv[4]) : 1;
+  int const operator_on = argc > 5 ? atoi(argv[5]) : 0;
   if(C == 0 || B == 0 || B > 64)
     return 2;
   if(kq_abi_version() != KQ_ABI_VERSION || kq_device_count() <= 0){
@@ -72,7 +77,6 @@ int main(int argc, char **argv){
     fprintf(stderr, "kq_bank_add_channels: %s\n", kq_last_error());
     return 1;
   }
-  free(cc);
   printf("%u FM channels set up in %.2f s\n", C, now_s() - t0);
 
   /* ---- pinned host memory: one batch of input (a live receiver has a ring of them), three sets of output planes */
@@ -107,7 +111,8 @@ int main(int argc, char **argv){
 
   /* ---- the receiver's loop (the same batch over and over: the stream is synthetic, the work is not) */
   double const signal_s = (double)B * L / SAMPRATE;
-  long calls = 0, warm = 50;
+  long calls = 0, warm = 50, ops = 0;
+  int away = -1;                        /* the channel that has been dropped and not yet come back */
   kq_host_timing ht;
   int rc = 0;
   if(kq_bank_push_iq_async(bank, in, nin, KQ_IQ_CF32) != 0)
@@ -119,6 +124,35 @@ int main(int argc, char **argv){
       t0 = now_s();
     }
     int const j = (int)(k % 3);
+    if(operator_on && C > 64){
+      unsigned const c = 64u + (unsigned)((k * 7919) % (C - 64));  /* (channels 0..63 are left alone: the check below reads channel 5) */
+      float const w = 6000.f + 125.f * (float)(k % 17);
+      if((int)c != away){
+        rc |= kq_bank_set_filter(bank, (int)c, -w, w, 3.0f) != 0;
+        ops++;
+      }
+      if(k % 2 == 0){
+        if(away < 0){
+          away = 64 + (int)((k * 104729 + 3) % (C - 64));
+          rc |= kq_bank_remove_channel(bank, away) != 0;
+        } else {
+          rc |= kq_bank_add_channel(bank, &cc[away]) != away;   /* the bank hands out the lowest hole: the only one */
+          away = -1;
+        }
+        ops++;
+      }
+      if(k % 4 == 1){
+        unsigned const r = 64u + (unsigned)((k * 15485863) % (C - 64));
+        if((int)r != away){
+          rc |= kq_bank_set_second_lo(bank, (int)r, cc[r].second_lo + (k & 4 ? 1.0 : 0.0)) != 0;
+          ops++;
+        }
+      }
+      if(rc){
+        fprintf(stderr, "operator: %s\n", kq_last_error());
+        break;
+      }
+    }
     if(kq_bank_process(bank) != (int)B || kq_bank_push_iq_async(bank, in, nin, KQ_IQ_CF32) != 0)
       rc = 1;
     else if(pcm ? kq_bank_pull_pcm_planes_async(bank, out[j], mask[j], st[j]) : kq_bank_pull_planes_async(bank, out[j], st[j]))
@@ -141,6 +175,8 @@ int main(int argc, char **argv){
   double const d2h = (double)rows * (OLEN * (pcm ? 2 : 4) + sizeof(kq_chan_status) + (pcm ? 4 : 0));
   printf("%u channels x %u blocks per call (%.3f ms of signal): %.4f ms per call over %ld calls = %.3f x real time\n", C, B,
          signal_s * 1e3, per_call * 1e3, calls, signal_s / per_call);
+  if(operator_on)
+    printf("operator: %ld changes (filter, channel dropped / back, retune) = %.0f per second beside the stream\n", ops, ops / wall);
   printf("host inside kq_bank_process: %.4f ms per call (per-channel staging %.4f); delivered %s + status: %.2f GB/s\n",
          ht.call_ms / (double)ht.calls, ht.stage_ms / (double)ht.calls, pcm ? "int16 PCM" : "float audio", d2h / per_call / 1e9);
 
@@ -148,15 +184,19 @@ int main(int argc, char **argv){
   int const jl = (int)((warm + calls - 1 + 0) % 3);
   const kq_chan_status *s = st[jl];
   unsigned open = 0;
+  size_t counted = 0;
   for(size_t r = 0; r < rows; r++){
+    if(operator_on && r / B >= 64)     /* a channel that has just come back or had its filter changed may still be settling */
+      continue;
+    counted++;
     if(s[r].nout != OLEN)
       rc = 3;
     open += s[r].squelch_count < 2;
   }
   kq_chan_status const *s5 = &s[(size_t)(5 % C) * B];
   printf("last delivery: %u of %zu channel-blocks with the squelch open; channel %u: snr %.0f, pdeviation %.0f Hz, n0 %.3g\n",
-         open, rows, 5 % C, s5->snr, s5->pdeviation, s5->n0);
-  if(open != rows || !(s5->snr > 20.f) || !(s5->pdeviation > 0.3f * DEVIATION && s5->pdeviation < 2.f * DEVIATION))
+         open, counted, 5 % C, s5->snr, s5->pdeviation, s5->n0);
+  if(open != counted || !(s5->snr > 20.f) || !(s5->pdeviation > 0.3f * DEVIATION && s5->pdeviation < 2.f * DEVIATION))
     rc = 4;
   if(pcm){                                       /* the PCM words of an open FM channel are not silence */
     const int16_t *w = (const int16_t *)out[jl] + (size_t)(5 % C) * B * 2 * OLEN;
@@ -167,6 +207,7 @@ int main(int argc, char **argv){
       rc = 5;
   }
   kq_bank_destroy(bank);
+  free(cc);
   hipHostFree(in);
   for(int i = 0; i < 3; i++){
     hipHostFree(out[i]);

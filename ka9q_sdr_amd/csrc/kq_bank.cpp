@@ -682,14 +682,19 @@ int queue_design(kq_bank *b, int c, bool runtime = false) {
   }
   if (!runtime) {
     if (h.cfg.demod_type == KQ_FM_DEMOD && !h.cfg.flat) {
-      auto it = b->aresp_cache.find(h.cfg.kaiser_beta);
-      if (it == b->aresp_cache.end()) {
-        std::vector<kq::cfloat> a = kq::design_fm_audio_response(g.olen, g.Mdec, g.dsamprate, h.cfg.kaiser_beta);
-        if (a.empty()) return -1;
-        if (b->aresp_cache.size() >= 64) b->aresp_cache.clear();
-        it = b->aresp_cache.emplace(h.cfg.kaiser_beta, std::move(a)).first;
+      if (std::isnan(h.cfg.kaiser_beta)) {  // (not a key an ordered map can hold; the design takes it as the reference's does)
+        h.aresp = kq::design_fm_audio_response(g.olen, g.Mdec, g.dsamprate, h.cfg.kaiser_beta);
+        if (h.aresp.empty()) return -1;
+      } else {
+        auto it = b->aresp_cache.find(h.cfg.kaiser_beta);
+        if (it == b->aresp_cache.end()) {
+          std::vector<kq::cfloat> a = kq::design_fm_audio_response(g.olen, g.Mdec, g.dsamprate, h.cfg.kaiser_beta);
+          if (a.empty()) return -1;
+          if (b->aresp_cache.size() >= 64) b->aresp_cache.clear();
+          it = b->aresp_cache.emplace(h.cfg.kaiser_beta, std::move(a)).first;
+        }
+        h.aresp = it->second;
       }
-      h.aresp = it->second;
       if (ctl_put(b, CTL_DEMOD, b->chd.aresp + (size_t)c * (g.Ndec / 2 + 1), h.aresp.data(), sizeof(float2) * (g.Ndec / 2 + 1)))
         return -1;
     } else {

@@ -43,6 +43,11 @@ enum kq_fwd_mode {
 };
 
 typedef struct kq_bank kq_bank;   /* opaque */
+/* Threads: a handle carries one lock, taken by every kq_bank_* entry point, so a receiver thread (process / push / pull) and
+ * an operator's thread (set_filter, set_mode, the frequency setters, add / remove -- display.c and radio_status.c beside the
+ * demodulator threads of the reference) may share a bank.  The entry points whose job is to wait for the device --
+ * kq_bank_pull_wait, kq_bank_host_io_wait, kq_bank_sync -- let go of the lock while they wait.  kq_last_error is per thread.
+ * kq_bank_destroy wants the handle to itself.  Buffers handed to the asynchronous pulls are the caller's to keep apart. */
 
 /* Bank geometry: replaces the arguments of create_filter_input(L, M, COMPLEX) (filter.c:54,
  * called from main.c:232) plus demod->filter.decimate and demod->input.samprate

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -124,6 +125,11 @@ struct EventPair {
 }  // namespace
 
 struct kq_bank {
+  // One lock per handle, taken by every entry point: a receiver thread in its process / push / pull loop and an operator's
+  // thread changing filters, modes and frequencies (display.c / radio_status.c beside the demodulator threads of the
+  // reference) may share a bank.  The entry points that wait for the device to catch up (kq_bank_pull_wait, _host_io_wait,
+  // _sync) let go of it while they wait.  Recursive: some entry points are built from others.
+  std::recursive_mutex mu;
   kq_bank_config cfg;
   kq::Geom g;
   hipStream_t stream = nullptr;
@@ -339,6 +345,27 @@ int ilog2(unsigned v) {
 }
 
 int sync_all(kq_bank *b);
+
+// every entry point taking a handle: the handle's device made current, the handle's lock held
+struct BankScope {
+  kq::DeviceScope dev;
+  std::unique_lock<std::recursive_mutex> lk;
+  explicit BankScope(kq_bank *b) : dev(b ? b->cfg.device : -1) {
+    if (b) lk = std::unique_lock<std::recursive_mutex>(b->mu);
+  }
+  explicit BankScope(const kq_bank *b) : BankScope(const_cast<kq_bank *>(b)) {}
+};
+// a wait for the device inside an entry point: the lock is let go for its duration (one level: an entry point called from
+// another keeps the outer one's)
+struct Unlocked {
+  std::unique_lock<std::recursive_mutex> &lk;
+  explicit Unlocked(BankScope &s) : lk(s.lk) {
+    if (lk.owns_lock()) lk.unlock();
+  }
+  ~Unlocked() {
+    if (lk.mutex() && !lk.owns_lock()) lk.lock();
+  }
+};
 
 enum { CTL_FILTER = 0, CTL_DEMOD = 1 };
 struct CtlRecHost {  // kq_kernels.hip CtlRec
@@ -1572,7 +1599,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
 }
 
 int kq_bank_destroy(kq_bank *b) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);  // (not the handle's lock: nobody else may be using a handle that is being destroyed)
   if (!b) return 0;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->stream2 && b->stream2 != b->stream) (void)hipStreamSynchronize(b->stream2);
@@ -1698,7 +1725,7 @@ static int pll_leave(kq_bank *b, int rank, int npll) {
 }  // namespace
 
 int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b || !cfg) {
     set_err("NULL argument");
     return -1;
@@ -1775,7 +1802,7 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
 // kq_bank_add_channel called n times, but every distinct response is designed once (one launch for all of them), every
 // distinct compute_n0 mask is built once, and each per-channel plane is uploaded with one copy instead of n.
 int kq_bank_add_channels(kq_bank *b, const kq_channel_config *cfgs, unsigned n, int *indices) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b || (!cfgs && n)) {
     set_err("NULL argument");
     return -1;
@@ -1988,7 +2015,7 @@ int kq_bank_add_channels(kq_bank *b, const kq_channel_config *cfgs, unsigned n, 
 // close_chan equivalent: the demodulator thread is joined and its struct demod freed (radio.c:335-337 does the join
 // for a mode change).  Channel numbers of the others do not change; the slot is a hole until an add reuses it.
 int kq_bank_remove_channel(kq_bank *b, int ch) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch)) {
     set_err("bad channel");
     return -1;
@@ -2020,12 +2047,20 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
   return 0;
 }
 
-int kq_bank_channel_active(const kq_bank *b, int ch) { return valid_ch(b, ch) ? 1 : 0; }
+int kq_bank_channel_active(const kq_bank *b, int ch) {
+  if (!b) return 0;
+  std::lock_guard<std::recursive_mutex> lk(const_cast<kq_bank *>(b)->mu);
+  return valid_ch(b, ch) ? 1 : 0;
+}
 
-unsigned kq_bank_num_channels(const kq_bank *b) { return b ? (unsigned)b->chans.size() : 0; }
+unsigned kq_bank_num_channels(const kq_bank *b) {
+  if (!b) return 0;
+  std::lock_guard<std::recursive_mutex> lk(const_cast<kq_bank *>(b)->mu);
+  return (unsigned)b->chans.size();
+}
 
 int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch) || !m) {
     set_err("bad channel or NULL mode");
     return -1;
@@ -2078,7 +2113,7 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
 // at demod->output.channels after it: both may change while the demodulator runs, without touching its AGC or the
 // response (which keeps the gain it was designed with until the next set_filter, as in the reference).
 int kq_bank_set_linear_options(kq_bank *b, int ch, int isb, int channels) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch) || (channels != 1 && channels != 2)) {
     set_err("bad channel, or channels not 1 or 2");
     return -1;
@@ -2104,7 +2139,7 @@ int kq_bank_set_linear_options(kq_bank *b, int ch, int isb, int channels) {
 }
 
 int kq_bank_set_second_lo(kq_bank *b, int ch, double hz) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch) || std::isnan(hz)) {
     set_err("bad channel or NaN");
     return -1;
@@ -2122,7 +2157,7 @@ int kq_bank_set_second_lo(kq_bank *b, int ch, double hz) {
 }
 
 int kq_bank_set_doppler(kq_bank *b, int ch, double hz, double hz_per_s) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch) || std::isnan(hz) || std::isnan(hz_per_s)) {
     set_err("bad channel or NaN");
     return -1;
@@ -2142,7 +2177,7 @@ int kq_bank_set_doppler(kq_bank *b, int ch, double hz, double hz_per_s) {
 }
 
 int kq_bank_set_shift(kq_bank *b, int ch, double hz) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch) || std::isnan(hz)) {
     set_err("bad channel or NaN");
     return -1;
@@ -2154,7 +2189,7 @@ int kq_bank_set_shift(kq_bank *b, int ch, double hz) {
 }
 
 int kq_bank_set_n0(kq_bank *b, int ch, float n0) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch)) {
     set_err("bad channel");
     return -1;
@@ -2165,7 +2200,7 @@ int kq_bank_set_n0(kq_bank *b, int ch, float n0) {
 }
 
 int kq_bank_set_filter(kq_bank *b, int ch, float low, float high, float beta) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch)) {
     set_err("bad channel");
     return -1;
@@ -2194,7 +2229,7 @@ static int acc_append(kq_bank *b, const void *src, size_t nsamples, int format);
 }  // namespace
 
 int kq_bank_push_iq(kq_bank *b, const void *iq, size_t nsamples, int format, int is_device) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b || (!iq && nsamples)) {
     set_err("NULL argument");
     return -1;
@@ -2347,7 +2382,7 @@ static int acc_append(kq_bank *b, const void *src, size_t nsamples, int format) 
 }  // namespace
 
 int kq_bank_push_iq_async(kq_bank *b, const void *iq, size_t nsamples, int format) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b || (!iq && nsamples)) {
     set_err("NULL argument");
     return -1;
@@ -2397,7 +2432,7 @@ static int pull_epilogue(kq_bank *b) {
 }  // namespace
 
 int kq_bank_pull_planes_async(kq_bank *b, float *audio, kq_chan_status *status) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (pull_prologue(b)) return -1;
   size_t const n = b->chans.size() * (size_t)b->g.max_blocks;
   // of every channel-block's 2 * olen floats only the status.nout that hold samples travel (mono: half): the kernel
@@ -2425,7 +2460,7 @@ int kq_bank_pull_planes_async(kq_bank *b, float *audio, kq_chan_status *status) 
 // of the float plane.  The conversion runs inside the copy kernel (the same arithmetic as k_pcm, the stage behind
 // kq_bank_enable_pcm, which this call does not need).
 int kq_bank_pull_pcm_planes_async(kq_bank *b, int16_t *pcm, uint32_t *silent_mask, kq_chan_status *status) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!pcm) {
     set_err("NULL pcm plane");
     return -1;
@@ -2447,27 +2482,34 @@ int kq_bank_pull_pcm_planes_async(kq_bank *b, int16_t *pcm, uint32_t *silent_mas
 }
 
 int kq_bank_pull_wait(kq_bank *b, unsigned lag) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b) return -1;
   if (lag >= (unsigned)kq_bank::kPullRing) {
     set_err("kq_bank_pull_wait: lag %u, at most %d deliveries are remembered", lag, kq_bank::kPullRing - 1);
     return -1;
   }
   if (b->pulls <= lag) return 0;  // nothing that far back was ever queued
-  HIP_TRY(hipEventSynchronize(b->pull_done[(b->pulls - 1 - lag) % kq_bank::kPullRing]));
+  hipEvent_t const ev = b->pull_done[(b->pulls - 1 - lag) % kq_bank::kPullRing];
+  {
+    Unlocked u(dev_scope_);  // (the ring holds kPullRing deliveries: the event is not recorded again before this one is long over)
+    HIP_TRY(hipEventSynchronize(ev));
+  }
   return report_lost_sibling(b);
 }
 
 int kq_bank_host_io_wait(kq_bank *b) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b) return -1;
-  if (b->copy_in) HIP_TRY(hipStreamSynchronize(b->copy_in));
-  if (b->copy_out) HIP_TRY(hipStreamSynchronize(b->copy_out));
+  {
+    Unlocked u(dev_scope_);
+    if (b->copy_in) HIP_TRY(hipStreamSynchronize(b->copy_in));
+    if (b->copy_out) HIP_TRY(hipStreamSynchronize(b->copy_out));
+  }
   return report_lost_sibling(b);  // the planes just landed come from kernels that have finished
 }
 
 int kq_bank_push_zeros(kq_bank *b, size_t nsamples) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b) {
     set_err("NULL bank");
     return -1;
@@ -2498,7 +2540,7 @@ int kq_bank_push_zeros(kq_bank *b, size_t nsamples) {
 static inline size_t g_M1(const kq_bank *b) { return (size_t)(b->g.M - 1); }
 
 int kq_bank_push_rtp(kq_bank *b, const void *datagram, size_t size) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b || !datagram) {
     set_err("NULL argument");
     return -1;
@@ -2618,16 +2660,20 @@ int kq_bank_push_rtp(kq_bank *b, const void *datagram, size_t size) {
 }
 
 int kq_bank_rtp_counters(const kq_bank *b, kq_rtp_counters *out) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b || !out) return -1;
   *out = b->rtp;
   return 0;
 }
 
-unsigned kq_bank_blocks_ready(const kq_bank *b) { return b ? (unsigned)(b->pending / b->g.L) : 0; }
+unsigned kq_bank_blocks_ready(const kq_bank *b) {
+  if (!b) return 0;
+  std::lock_guard<std::recursive_mutex> lk(const_cast<kq_bank *>(b)->mu);
+  return (unsigned)(b->pending / b->g.L);
+}
 
 int kq_bank_process(kq_bank *b) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b) {
     set_err("NULL bank");
     return -1;
@@ -2653,7 +2699,7 @@ int kq_bank_process(kq_bank *b) {
 }
 
 int kq_bank_process_resident(kq_bank *b, const void *iq_dev, unsigned nblocks) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b || !iq_dev) {
     set_err("NULL argument");
     return -1;
@@ -2667,7 +2713,7 @@ int kq_bank_process_resident(kq_bank *b, const void *iq_dev, unsigned nblocks) {
 }
 
 int kq_bank_process_spectrum(kq_bank *b, const void *spectrum_dev, unsigned nblocks) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b || !spectrum_dev) {
     set_err("NULL argument");
     return -1;
@@ -2692,7 +2738,7 @@ void *kq_bank_stream(kq_bank *b) { return b ? (void *)b->stream : nullptr; }
 
 
 int kq_bank_join(kq_bank *b) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b) return -1;
   if (b->calls == 0) return 0;
   int const last = (int)((b->calls - 1) & 1);
@@ -2701,10 +2747,14 @@ int kq_bank_join(kq_bank *b) {
 }
 
 int kq_bank_sync(kq_bank *b) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b) return -1;
   // "everything issued so far" includes what the control plane has queued for the next call: applied now
-  if (ctl_flush_now(b) || sync_all(b)) return -1;
+  if (ctl_flush_now(b)) return -1;
+  {
+    Unlocked u(dev_scope_);
+    if (sync_all(b)) return -1;
+  }
   return report_lost_sibling(b);
 }
 
@@ -2712,7 +2762,7 @@ unsigned kq_bank_olen(const kq_bank *b) { return b ? (unsigned)b->g.olen : 0; }
 unsigned kq_bank_last_blocks(const kq_bank *b) { return b ? b->last_blocks : 0; }
 
 int kq_bank_pull_status(kq_bank *b, int ch, unsigned blk, kq_chan_status *st) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch) || !st || blk >= b->last_blocks) {
     set_err("bad channel/block");
     return -1;
@@ -2723,7 +2773,7 @@ int kq_bank_pull_status(kq_bank *b, int ch, unsigned blk, kq_chan_status *st) {
 }
 
 int kq_bank_pull_audio(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap, size_t *n) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch) || !dst || blk >= b->last_blocks) {
     set_err("bad channel/block");
     return -1;
@@ -2741,7 +2791,7 @@ int kq_bank_pull_audio(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap,
 }
 
 int kq_bank_enable_pcm(kq_bank *b, int on) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b) return -1;
   if (on && 2 * (size_t)b->g.olen > 32 * 480) {
     // the silent-packet mask of kq_bank_pull_pcm is 32 bits: one per 480-word packet of a block
@@ -2757,7 +2807,7 @@ int kq_bank_enable_pcm(kq_bank *b, int on) {
 }
 
 int kq_bank_pull_pcm(kq_bank *b, int ch, unsigned blk, int16_t *dst, size_t cap, size_t *nwords, uint32_t *silent_mask) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch) || !dst || blk >= b->last_blocks || !b->pcm_on) {
     set_err("bad channel/block, or PCM stage not enabled");
     return -1;
@@ -2778,7 +2828,7 @@ int kq_bank_pull_pcm(kq_bank *b, int ch, unsigned blk, int16_t *dst, size_t cap,
 }
 
 int kq_bank_set_output_ssrc(kq_bank *b, int ch, uint32_t ssrc) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch)) {
     set_err("bad channel");
     return -1;
@@ -2788,7 +2838,7 @@ int kq_bank_set_output_ssrc(kq_bank *b, int ch, uint32_t ssrc) {
 }
 
 int kq_bank_output_rtp_state(const kq_bank *b, int ch, kq_out_rtp_state *out) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!out || !valid_ch(b, ch)) return -1;
   *out = b->chans[ch].out_rtp;
   return 0;
@@ -2847,7 +2897,7 @@ int packetize_block(kq_out_rtp_state &o, const unsigned char *w, size_t nwords, 
 }  // namespace
 
 int kq_bank_pull_rtp_audio(kq_bank *b, int ch, unsigned blk, unsigned char *dst, size_t cap, size_t *used) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch) || !dst) {
     set_err("bad channel or NULL buffer");
     return -1;
@@ -2862,6 +2912,11 @@ int kq_bank_pull_rtp_audio(kq_bank *b, int ch, unsigned blk, unsigned char *dst,
 // The same datagrams from planes the host already holds (kq_bank_pull_pcm_planes_async): no device access, no wait.
 int kq_bank_rtp_from_planes(kq_bank *b, int ch, unsigned blk, const int16_t *pcm_plane, const kq_chan_status *status_plane,
                             unsigned char *dst, size_t cap, size_t *used) {
+  if (!b) {
+    set_err("NULL bank");
+    return -1;
+  }
+  std::lock_guard<std::recursive_mutex> lk(b->mu);  // (the channel's RTP state; no device scope: nothing here touches the device)
   if (!valid_ch(b, ch) || !dst || !pcm_plane || !status_plane || blk >= (unsigned)b->g.max_blocks) {
     set_err("bad channel / block or NULL plane");
     return -1;
@@ -2877,7 +2932,7 @@ int kq_bank_rtp_from_planes(kq_bank *b, int ch, unsigned blk, const int16_t *pcm
 }
 
 int kq_bank_pull_filter_output(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch) || !dst || blk >= b->last_blocks || cap < (size_t)b->g.olen) {
     set_err("bad channel/block/capacity");
     return -1;
@@ -2889,7 +2944,7 @@ int kq_bank_pull_filter_output(kq_bank *b, int ch, unsigned blk, float *dst, siz
 }
 
 int kq_bank_pull_spectrum(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch) || !dst || cap < (size_t)b->g.N) {
     set_err("bad channel/capacity");
     return -1;
@@ -2916,7 +2971,7 @@ int kq_bank_pull_spectrum(kq_bank *b, int ch, unsigned blk, float *dst, size_t c
 }
 
 int kq_bank_get_response(kq_bank *b, int ch, float *dst, size_t cap) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch) || !dst || cap < (size_t)b->g.Ndec) {
     set_err("bad channel/capacity");
     return -1;
@@ -2927,7 +2982,7 @@ int kq_bank_get_response(kq_bank *b, int ch, float *dst, size_t cap) {
 }
 
 int kq_bank_get_audio_response(kq_bank *b, int ch, float *dst, size_t cap) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!valid_ch(b, ch) || !dst) {
     set_err("bad channel");
     return -1;
@@ -2945,7 +3000,7 @@ void *kq_bank_audio_device_ptr(kq_bank *b) { return b ? b->pl.audio : nullptr; }
 void *kq_bank_status_device_ptr(kq_bank *b) { return b ? b->pl.status : nullptr; }
 
 int kq_bank_enable_timing(kq_bank *b, int on) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b) return -1;
   if (!on && b->timing) drain_timing(b);
   b->timing = on;  // 0 off, 1 filter kernel only, >= 2 every scope
@@ -2953,7 +3008,7 @@ int kq_bank_enable_timing(kq_bank *b, int on) {
 }
 
 int kq_bank_get_timing(kq_bank *b, kq_timing *t, int reset) {
-  kq::DeviceScope dev_scope_(b ? b->cfg.device : -1);
+  BankScope dev_scope_(b);
   if (!b || !t) return -1;
   if (drain_timing(b)) return -1;
   *t = b->acc;
@@ -2963,6 +3018,7 @@ int kq_bank_get_timing(kq_bank *b, kq_timing *t, int reset) {
 
 int kq_bank_get_host_timing(kq_bank *b, kq_host_timing *t, int reset) {
   if (!b || !t) return -1;
+  std::lock_guard<std::recursive_mutex> lk(b->mu);
   *t = b->host_acc;
   if (reset) b->host_acc = kq_host_timing{};
   return 0;

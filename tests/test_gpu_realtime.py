@@ -581,3 +581,89 @@ def test_many_filter_changes_between_two_calls(gpu):
         ch = ko.Channel(oracle_cfg(plan[c], fs, L, g["M"], g["D"], compute_n0=1))
         ch.set_filter(*edges(c, c % 7 == 0))
         np.testing.assert_allclose(ra[c], ch.response(), rtol=0, atol=2e-9)
+
+
+def test_operator_thread_beside_the_receiver_thread(gpu):
+    """One bank, two threads, as the reference has them (display.c / radio_status.c beside the demodulator threads): the receiver's
+    loop -- process, push, queue the delivery, wait for the delivery two back -- and an operator who meanwhile changes filters and
+    modes, retunes, drops channels and brings them back, and reads the bank's bookkeeping.  Every entry point takes the handle's
+    lock; the ones that wait for the device let go of it while they wait, so the operator gets in between any two steps of the
+    loop.  No call may fail, every delivery of an untouched channel is whole, the operator gets its work done while the loop
+    runs, and the filters left at the end are the ones last asked for (against the oracle's set_filter)."""
+    import threading
+    import kq_oracle as ko
+    from common import oracle_cfg
+    g = wl.GEOMETRY["cfg4"]
+    fs, L, M, D = g["samprate"], g["L"], g["M"], g["D"]
+    olen = L // D
+    C, B, ncalls = 4096, 2, 400
+    plan = wl.channel_plan("cfg3", C)                 # FM, AM and SSB
+    bank = kq.Bank(fs, L, M, D, C, B, compute_n0=True, pl_tone=False)
+    bank.add_channels([bank_cfg(p) for p in plan])
+    iq_pin = torch.from_numpy(wl.make_iq(fs, B * L, seed=3).copy()).pin_memory()
+    pcm = [_pinned(C * B * 2 * olen, torch.int16) for _ in range(3)]
+    mask = [_pinned(C * B, torch.int32) for _ in range(3)]
+    stat = [_pinned(C * B * ctypes.sizeof(kq.ChanStatus), torch.uint8) for _ in range(3)]
+    quiet = np.arange(C) < 1024                       # the operator leaves the first 1024 channels alone
+    errors, done, ops = [], threading.Event(), [0]
+    last_filter = {}
+
+    def operator():
+        rng = np.random.default_rng(4)
+        away = None
+        try:
+            while not done.is_set():
+                c = int(rng.integers(1024, C))
+                what = int(rng.integers(0, 6))
+                if c == away:
+                    continue
+                if what == 0:
+                    f = float(rng.uniform(0.6, 1.0))
+                    last_filter[c] = (plan[c]["low"] * f, plan[c]["high"] * f, 3.0)
+                    bank.set_filter(c, *last_filter[c])
+                elif what == 1:
+                    bank.set_mode(c, bank_cfg(plan[c]))
+                    last_filter.pop(c, None)          # (set_mode designs the mode's own filter again)
+                elif what == 2:
+                    bank.set_second_lo(c, plan[c]["second_lo"] + float(rng.integers(-2, 3)))
+                elif what == 3 and away is None:
+                    bank.remove_channel(c)
+                    away = c
+                    last_filter.pop(c, None)
+                elif what == 4 and away is not None:
+                    assert bank.add_channel(bank_cfg(plan[away])) == away
+                    away = None
+                else:
+                    assert bank.num_channels == C and bank.channel_active(int(rng.integers(0, 1024)))
+                ops[0] += 1
+            if away is not None:
+                assert bank.add_channel(bank_cfg(plan[away])) == away
+        except Exception as e:                         # noqa: BLE001 -- handed to the main thread
+            errors.append(e)
+
+    th = threading.Thread(target=operator)
+    bank.push_iq_async(iq_pin.data_ptr(), B * L)
+    th.start()
+    try:
+        for k in range(ncalls):
+            assert bank.process() == B
+            bank.push_iq_async(iq_pin.data_ptr(), B * L)
+            j = k % 3
+            bank.pull_pcm_planes_async(pcm[j].data_ptr(), mask[j].data_ptr(), stat[j].data_ptr())
+            bank.pull_wait(2)
+            if k >= 2:
+                st = np.frombuffer(stat[(k - 2) % 3].numpy().tobytes(), dtype=STATUS_DTYPE).reshape(C, B)
+                assert np.all(st["nout"][quiet] >= olen), k
+                assert np.all(np.isfinite(st["bb_power"][quiet])), k
+    finally:
+        done.set()
+        th.join()
+    assert not errors, errors
+    assert ops[0] > ncalls // 4, ops        # the operator was not locked out by the loop
+    bank.host_io_wait()
+    bank.sync()
+    for c, args in list(last_filter.items())[:24]:
+        ch = ko.Channel(oracle_cfg(plan[c], fs, L, M, D, compute_n0=1))
+        ch.set_filter(*args)
+        np.testing.assert_allclose(bank.response(c), ch.response(), rtol=0, atol=2e-9)
+    bank.close()

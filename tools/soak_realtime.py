@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--channels", type=int, default=16384)
     ap.add_argument("--seconds", type=float, default=30.0)
     ap.add_argument("--check-calls", type=int, default=300)
+    ap.add_argument("--window", type=int, default=0, help="print the pace every this many calls")
     ap.add_argument("--only", default=None, choices=["retune", "filter", "mode", "churn", "none"])
     a = ap.parse_args()
     global ONLY
@@ -121,6 +122,8 @@ def main():
     fm_on = np.array([p["demod"] == "fm" for p in plan])
     t0 = time.perf_counter()
     k = nops = 0
+    swept = set()          # channels whose Doppler carries a rate right now (they run the filter kernel's per-sample oscillator variant)
+    t_win, k_win = time.perf_counter(), 0
     signal_s = B * L / fs
     while True:
         for i, bank in enumerate(banks):
@@ -129,9 +132,14 @@ def main():
             ops = script(rngs[i], plan, C, k, lives[i], holes[i], added[i])
             if i == 0:
                 nops += len(ops)
+                for name, args in ops:
+                    if name == "set_doppler":
+                        (swept.add if args[2] != 0.0 else swept.discard)(args[0])
+                    elif name in ("remove_channel", "add_channel", "set_mode"):
+                        swept.discard(args[0]) if name != "set_mode" else None
             if i == 1:
                 bank.sync()
-            apply(bank, plan, ops, clock=(i == 0 and k >= 200))
+            apply(bank, plan, ops, clock=(i == 0 and k >= max(200, a.check_calls)))
             assert bank.process() == B
             bank.push_iq_async(iq_pin.data_ptr(), B * L)
             j = k % nbuf
@@ -159,7 +167,11 @@ def main():
                 same = np.array_equal(st["nout"][both], s1["nout"][both]) and np.array_equal(w0[:, :, :olen], w1[:, :, :olen])
                 assert same, ("the soaked bank differs from the drained one at delivery", k - 2)
         k += 1
-        if k == 200:
+        if a.window and k % a.window == 0:
+            now = time.perf_counter()
+            print("  calls %6d-%6d: %.4f ms per call, %d swept channels" % (k_win, k, (now - t_win) / (k - k_win) * 1e3, len(swept)), flush=True)
+            t_win, k_win = now, k
+        if k == max(200, a.check_calls):      # the pace is taken once the twin bank and the host's comparisons are out of the loop
             torch.cuda.synchronize()
             free0 = torch.cuda.mem_get_info()[0]
             t0 = time.perf_counter()
@@ -167,7 +179,7 @@ def main():
             banks[0].host_timing(reset=True)
             banks[0].enable_timing(1)
             banks[0].timing(reset=True)
-        if k > 200 and time.perf_counter() - t0 > a.seconds:
+        if k > max(200, a.check_calls) and time.perf_counter() - t0 > a.seconds:
             break
     banks[0].host_io_wait()
     banks[0].sync()

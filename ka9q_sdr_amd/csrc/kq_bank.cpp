@@ -310,7 +310,8 @@ struct kq_bank {
   static constexpr size_t kPatchBytes = 72;  // one record: channel index (8 bytes), then the channel's eight plane values
   std::vector<int> patch_list;
   size_t patch_off = 0;                       // of the patch records inside a staging slot
-  int n_swept = 0, n_fast = 0;                // active channels with a sweep / with one beyond the N = 65536 table path's reach
+  int n_swept = 0, n_fast = 0;                // active channels with a sweep / with one beyond the table path's reach (N = 65536
+                                              // and N = 16384: full64k_sweep_limit / full16k_sweep_limit)
   int n_active = 0;
   // N = 16384, some channels swept (satellite passes in a bank of fixed-frequency channels): the unswept ones still run the
   // steady-state variant of the kernel (16-byte loads from the row-paired copy, no per-sample oscillator path), the swept
@@ -1005,6 +1006,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     }
     return true;
   };
+  double const fast_limit = b->use64k ? kq::full64k_sweep_limit() : kq::full16k_sweep_limit();
   if (!steady) {
     int n_swept = 0, n_fast = 0, n_active = 0;
     for (HostChan &h : b->chans) {
@@ -1014,7 +1016,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
       h.r_eff = r;
       n_active++;
       n_swept += r != 0;
-      n_fast += std::fabs(r) > kq::full64k_sweep_limit();
+      n_fast += std::fabs(r) > fast_limit;
     }
     b->n_swept = n_swept;
     b->n_fast = n_fast;
@@ -1029,7 +1031,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
       if (!sweep_ok(r)) return -1;
       if ((r != 0) != (h.r_eff != 0)) b->sweep_lists_dirty = true;
       b->n_swept += (r != 0) - (h.r_eff != 0);
-      b->n_fast += (std::fabs(r) > kq::full64k_sweep_limit()) - (std::fabs(h.r_eff) > kq::full64k_sweep_limit());
+      b->n_fast += (std::fabs(r) > fast_limit) - (std::fabs(h.r_eff) > fast_limit);
       h.r_eff = r;
     }
   }
@@ -1064,7 +1066,11 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   // a channel retuned since the last call (history still on the old oscillator) is then redone below with the
   // general variant, as the pruned path does.
   // (N = 65536: the steady-state variant takes sweeps up to full64k_sweep_limit() itself)
+  // (N = 16384: swept channels inside full16k_sweep_limit() have a steady-state variant of their own, `swept_steady`)
   bool const plain = b->use64k ? b->n_fast == 0 : b->n_swept == 0;
+  static bool const swept_steady_off = getenv("KQ_SWEPT_STEADY") && atoi(getenv("KQ_SWEPT_STEADY")) == 0;  // A/B switch
+  bool const swept_steady = use16k && !b->use64k && b->fwd_mode != KQ_FWD_PRUNED && !spectrum && b->n_swept > 0 && b->n_fast == 0 &&
+                            !swept_steady_off;
   bool const swept64k = b->use64k && b->n_swept > 0;
   // N = 16384 with swept and unswept channels side by side: two launches over two lists (see list_unswept_dev)
   bool const mixed = use16k && !b->use64k && b->fwd_mode != KQ_FWD_PRUNED && !spectrum && b->n_swept > 0 && b->n_swept < b->n_active;
@@ -1079,7 +1085,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   }
   // That steady-state variant loads its samples 16 bytes at a time from a copy of the call's samples whose 512-sample
   // rows are interleaved in pairs; the IF-power kernel, which reads every new sample anyway, writes it
-  float2 *const paired = ((use16k || b->use64k) && (plain || mixed) && b->win_paired && b->fwd_mode != KQ_FWD_PRUNED) ? b->win_paired : nullptr;
+  float2 *const paired = ((use16k || b->use64k) && (plain || mixed || swept_steady) && b->win_paired && b->fwd_mode != KQ_FWD_PRUNED) ? b->win_paired : nullptr;
   // the control plane's filter-side writes since the last call, in front of this call's first kernel
   if (ctl_flush(b, CTL_FILTER, b->stream)) return -1;
   {
@@ -1105,8 +1111,9 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     // (as_plain: the steady-state variant -- the host vouches that no channel of THIS launch sweeps)
     auto const full_launch = [&](hipStream_t st, const kq::Geom &gg, const kq::ChanDev &cd, const kq::Planes &pp, const float2 *win,
                                  const float2 *twp, int nch, int nbl, int n0, float2 *dump, int dump_ch, const int *list,
-                                 bool redo = true, bool as_plain = false) {
-      bool const pv = !redo && (plain || as_plain);
+                                 bool redo = true, bool as_plain = false, bool as_swept_steady = false) {
+      // 0: the general variant; 1: steady state, no channel of the launch sweeps; 2: steady state, every one does
+      int const pv = redo ? 0 : as_swept_steady ? 2 : (plain || as_plain) ? 1 : 0;
       if (use16k)
         kq::launch_filter_full16k(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list, pv, pv ? paired : nullptr, b->big);
       else
@@ -1167,12 +1174,12 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
         full_launch(b->stream, g, chd, pl, window, b->tw, (int)b->list_unswept_host.size(), (int)nblocks, b->cfg.compute_n0,
                     b->spec_dump, b->spec_ch, b->list_unswept_dev, false, true);
         full_launch(b->stream, g, chd, pl, window, b->tw, (int)b->list_swept_host.size(), (int)nblocks, b->cfg.compute_n0,
-                    b->spec_dump, b->spec_ch, b->list_swept_dev, false, false);
-      } else {
+                    b->spec_dump, b->spec_ch, b->list_swept_dev, false, false, swept_steady);
+      } else {  // (nobody sweeps, or everybody does)
         full_launch(b->stream, g, chd, pl, window, b->tw, holes ? (int)b->list_active_host.size() : C, (int)nblocks,
-                    b->cfg.compute_n0, b->spec_dump, b->spec_ch, holes ? b->list_active_dev : nullptr, false);
+                    b->cfg.compute_n0, b->spec_dump, b->spec_ch, holes ? b->list_active_dev : nullptr, false, false, swept_steady);
       }
-      if (use16k && (plain || mixed) && nret > 0)
+      if (use16k && (plain || mixed || swept_steady) && nret > 0)
         full_launch(b->stream, g, chd, pl, window, b->tw, nret, 1, b->cfg.compute_n0, b->spec_dump, b->spec_ch, retune_list);
     }
     LAUNCH_CHECK("pre-detection filter");
@@ -2036,7 +2043,7 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
   // (the others' steady state is untouched: the launch decisions' counters lose this channel, the lists are redone)
   b->n_active--;
   b->n_swept -= h.r_eff != 0;
-  b->n_fast -= std::fabs(h.r_eff) > kq::full64k_sweep_limit();
+  b->n_fast -= std::fabs(h.r_eff) > (b->use64k ? kq::full64k_sweep_limit() : kq::full16k_sweep_limit());
   b->cache_any = b->n_active > 0;
   b->sweep_lists_dirty = true;
   h.r_eff = 0;

@@ -158,7 +158,7 @@ constexpr int full16k_bin(int t) { return (t >> 5) + 32 * (t & 31); }
 // the plain variant loads 16 bytes at a time; null: it reads `window`
 void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
-                           const int *chan_list, bool plain, const float2 *window_paired, const Big64 &big);
+                           const int *chan_list, int plain, const float2 *window_paired, const Big64 &big);
 bool full16k_paired_supported(const Geom &g);
 bool full64k_supported(const Geom &g);
 // plain: no channel of the launch was retuned since the last call and every sweep rate is inside full64k_sweep_limit();
@@ -166,6 +166,7 @@ bool full64k_supported(const Geom &g);
 void launch_filter_full64k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
                            const int *chan_list, bool plain, bool swept, const float2 *window_paired, const Big64 &big);
+double full16k_sweep_limit();  // the same for the N = 16384 steady-state variant of swept channels (plain == 2)
 double full64k_sweep_limit();  // |rate| in cycles per sample^2 up to which the table path's first-order cross term holds
 bool split_supported(const Geom &g);
 void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,

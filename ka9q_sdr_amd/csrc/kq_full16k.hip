@@ -152,6 +152,9 @@ __device__ __forceinline__ v2f phasor2(double turns) {
 // N = 65536: largest sweep (cycles per sample^2) the table path takes.  The lane part of the cross term,
 // theta = 2 pi rate R lane with R <= 65024 and lane <= 63, is applied as 1 + i theta: its error theta^2 / 2 stays below 5e-8.
 constexpr double kSweepLimit64k = 1.1e-11;
+// N = 16384, the steady-state variant for swept channels (PLAIN == 2): theta = 2 pi rate (512 n1) lane, n1 <= 31, lane <= 63,
+// applied as 1 + i theta; up to 3e-4 rad (error 4.5e-8) -- 4.8 kHz/s at 10 MS/s, 190 Hz/s at 2 MS/s
+constexpr double kSweepLimit16k = 4.8e-11;
 
 // N = 65536: hands one 32-bit value to the three sibling workgroups of the channel-block and collects all four into
 // out[0..3] (LDS), in sub-transform order.  `slots` = this channel-block's four words of one exchange round; a word is
@@ -192,7 +195,7 @@ __device__ __forceinline__ void sibling_exchange(unsigned long long *slots, int 
 // EPI: which slave epilogue the instance carries -- 1: N/D = 64 only (one wave, registers); 2: N/D = 128 .. 512 only (N/D / 64
 // waves); 0: all of them, chosen at run time (other N/D, the DUMP instances, N = 65536 which has none).  The headline
 // instance is EPI = 1: with the other epilogues compiled in it took 4 registers more and ran 0.4 % slower.
-template <bool N0, bool DUMP, bool PLAIN, bool PAIRED, int BIG, int EPI>
+template <bool N0, bool DUMP, int PLAIN, bool PAIRED, int BIG, int EPI>
 __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,
                                                        const float2 *__restrict__ tw, const float2 *__restrict__ tab,
                                                        float2 *__restrict__ spec_dump, int spec_ch,
@@ -357,15 +360,31 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     // cannot run ahead of a load it cannot issue yet, so they cost nothing there (-1 % against parameters, table and
     // phasor behind the last load).  The phasor of sample 512 n1 + t is P_t S^{n1}, S = exp(j 2 pi 512 f0): lane n1 of
     // each wave evaluates S^{n1} from the double-precision phase into the wave's own LDS slot.
+    // PLAIN == 2: every channel of the launch sweeps (rate inside kSweepLimit16k), none was retuned since the last call.
+    // With u = A + R, A = b L + t and R = 512 n1, the phase ph0 + f0 u + rs u (u - 1) / 2 is
+    //   [ph0 + f0 A + rs A (A - 1) / 2]  +  [f0 R + rs R (R - 1) / 2 + rs R (b L + 64 w)]  +  rs R lane
+    // = P_t (rides on pass 1's twiddles as ever) + the wave's table entry n1 + a lane part that is applied to first order
+    // in the mix below (as the N = 65536 path does).
     double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c];
+    double const rs = PLAIN == 2 ? ch.lo_rate[c] : 0.0;
     load_rows(0, 12);
     __builtin_amdgcn_sched_barrier(0);
     float2 *const sw = stab + (t >> 6) * 32;
-    if ((t & 63) < 32) sw[t & 63] = phasor_turns(f0 * (double)(512 * (t & 63)));
+    if ((t & 63) < 32) {
+      double const R = (double)(512 * (t & 63));
+      double turns = f0 * R;
+      if constexpr (PLAIN == 2) turns += rs * (0.5 * R * (R - 1.0) + R * ((double)b * g.L + (double)(t & ~63)));
+      sw[t & 63] = phasor_turns(turns);
+    }
     __builtin_amdgcn_sched_barrier(0);
     load_rows(12, 22);
     __builtin_amdgcn_sched_barrier(0);
-    pt = phasor2(ph0 + f0 * ((double)b * g.L + t));
+    {
+      double const A = (double)b * g.L + t;
+      double turns = ph0 + f0 * A;
+      if constexpr (PLAIN == 2) turns += rs * (0.5 * A * (A - 1.0));
+      pt = phasor2(turns);
+    }
     __builtin_amdgcn_sched_barrier(0);
     load_rows(22, 32);
   }
@@ -394,8 +413,23 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if constexpr (PLAIN == 2) {
+        // y (1 + i theta), theta = kb n1: one packed add for theta, one packed fma with the operand swizzle of the N = 65536 path
+        float const kbf = (float)(2.0 * M_PI * 512.0 * r * (double)(t & 63));
+        v2f const kb = (v2f){kbf, kbf};
+        v2f th = (v2f){0.f, 0.f};
 #pragma unroll
-      for (int n1 = 1; n1 < 32; n1++) v[rfft::bitrev5(n1)] = pk_cmul(v[rfft::bitrev5(n1)], ld2(sw + n1));
+        for (int n1 = 1; n1 < 32; n1++) {
+          v2f const y = pk_cmul(v[rfft::bitrev5(n1)], ld2(sw + n1));
+          th = th + kb;
+          v2f z;
+          asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(z) : "v"(y), "v"(th), "v"(y));
+          v[rfft::bitrev5(n1)] = z;
+        }
+      } else {
+#pragma unroll
+        for (int n1 = 1; n1 < 32; n1++) v[rfft::bitrev5(n1)] = pk_cmul(v[rfft::bitrev5(n1)], ld2(sw + n1));
+      }
     } else if constexpr (!PLAIN) {
       // swept channels, and the first block after a retune (history still on the old oscillator): closed-form phase
       // per sample
@@ -966,10 +1000,11 @@ bool full16k_paired_supported(const Geom &g) {
 
 bool full64k_supported(const Geom &g) { return g.N == 4 * kN && g.Ndec >= 4 && g.Ndec <= 16384; }
 double full64k_sweep_limit() { return kSweepLimit64k; }
+double full16k_sweep_limit() { return kSweepLimit16k; }
 
 void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                            const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
-                           const int *chan_list, bool plain, const float2 *window_paired, const Big64 &big) {
+                           const int *chan_list, int plain, const float2 *window_paired, const Big64 &big) {
   size_t const lds_bytes = (size_t)kXchElems * sizeof(float2);
   const float2 *tab = twiddle_tables();
   if (!tab) {  // cannot happen short of an allocation failure: fall back to the LDS kernel rather than fail the block
@@ -988,10 +1023,12 @@ void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
   auto pick3 = [&](auto n0c, auto dumpc, auto epic) {
     constexpr bool kN0 = decltype(n0c)::value, kDump = decltype(dumpc)::value;
     constexpr int kEpi = decltype(epic)::value;
-    if (paired)
-      go(k_filter_full16k<kN0, kDump, true, true, 0, kEpi>);
+    if (plain == 2)  // steady state, every channel of the launch swept
+      paired ? go(k_filter_full16k<kN0, kDump, 2, true, 0, kEpi>) : go(k_filter_full16k<kN0, kDump, 2, false, 0, kEpi>);
+    else if (paired)
+      go(k_filter_full16k<kN0, kDump, 1, true, 0, kEpi>);
     else
-      plain ? go(k_filter_full16k<kN0, kDump, true, false, 0, kEpi>) : go(k_filter_full16k<kN0, kDump, false, false, 0, kEpi>);
+      plain ? go(k_filter_full16k<kN0, kDump, 1, false, 0, kEpi>) : go(k_filter_full16k<kN0, kDump, 0, false, 0, kEpi>);
   };
   auto pick = [&](auto n0c, auto dumpc) {
     if constexpr (decltype(dumpc)::value) {
@@ -1032,11 +1069,11 @@ void launch_filter_full64k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
   auto pick = [&](auto n0c, auto dumpc) {
     constexpr bool kN0 = decltype(n0c)::value, kDump = decltype(dumpc)::value;
     if (!plain)
-      go(k_filter_full16k<kN0, kDump, false, false, 1, 0>);
+      go(k_filter_full16k<kN0, kDump, 0, false, 1, 0>);
     else if (paired)
-      swept ? go(k_filter_full16k<kN0, kDump, true, true, 2, 0>) : go(k_filter_full16k<kN0, kDump, true, true, 1, 0>);
+      swept ? go(k_filter_full16k<kN0, kDump, 1, true, 2, 0>) : go(k_filter_full16k<kN0, kDump, 1, true, 1, 0>);
     else
-      swept ? go(k_filter_full16k<kN0, kDump, true, false, 2, 0>) : go(k_filter_full16k<kN0, kDump, true, false, 1, 0>);
+      swept ? go(k_filter_full16k<kN0, kDump, 1, false, 2, 0>) : go(k_filter_full16k<kN0, kDump, 1, false, 1, 0>);
   };
   using T = std::true_type;
   using F = std::false_type;

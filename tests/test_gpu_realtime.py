@@ -287,18 +287,22 @@ def test_pcm_planes_straight_to_the_host(gpu):
     bank.close()
 
 
-def test_swept_and_fixed_channels_side_by_side_against_the_oracle(gpu):
+@pytest.mark.parametrize("everybody", [False, True])
+def test_swept_and_fixed_channels_side_by_side_against_the_oracle(gpu, everybody):
     """A bank of fixed-frequency channels with a few satellite passes among them (Doppler offset with a rate, radio.c:180-184):
-    at N = 16384 the unswept channels run the steady-state variant of the filter kernel and the swept ones the general
-    variant, as two launches over two channel lists, and a channel changes list when its Doppler rate is set or cleared
-    while the bank runs.  Every channel against the oracle through four calls, with such changes in between."""
+    at N = 16384 the unswept channels run the steady-state variant of the filter kernel and the swept ones a steady-state
+    variant of their own (row phasors with the sweep in them, the lane part of the cross term to first order; rates up to
+    kq full16k_sweep_limit = 4.8 kHz/s at 10 MS/s), as two launches over two channel lists; a channel changes list when its
+    Doppler rate is set or cleared while the bank runs, and one rate beyond the limit sends the swept list back to the
+    per-sample variant.  everybody: all channels sweep (one launch).  Every channel against the oracle through five calls,
+    with such changes in between."""
     g = wl.GEOMETRY["cfg4"]
     fs, L = g["samprate"], g["L"]
     plan = wl.channel_plan("cfg4", 14)
-    for c in (2, 5, 11):
-        plan[c].update(doppler=1800.0 + 100 * c, doppler_rate=-250.0 * (c + 1))
+    for c in (range(14) if everybody else (2, 5, 11)):
+        plan[c].update(doppler=1800.0 + 100 * c, doppler_rate=-250.0 * (c + 1) if c % 2 else 330.0 * (c + 1))
         plan[c]["second_lo"] += plan[c]["doppler"]
-    nb, ncalls = 2, 4
+    nb, ncalls = 2, 5
     iq = wl.make_iq(fs, ncalls * nb * L, seed=0x6B63)
     import kq_oracle as ko
     from common import oracle_cfg
@@ -306,17 +310,23 @@ def test_swept_and_fixed_channels_side_by_side_against_the_oracle(gpu):
     bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), nb, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL, pl_tone=False)
     bank.add_channels([bank_cfg(p) for p in plan])
     for k in range(ncalls):
-        if k == 2:      # channel 7 starts to sweep, channel 5 stops (its offset stays): both change lists
-            for c, (d, r) in ((7, (900.0, -120.0)), (5, (plan[5]["doppler"], 0.0))):
-                bank.set_doppler(c, d, r)
-                chans[c].set_doppler(d, r)
+        changes = ()
+        if k == 2:      # channel 7 starts to sweep (or sweeps the other way), channel 5 stops (its offset stays): both change lists
+            changes = ((7, (900.0, -120.0)), (5, (plan[5]["doppler"], 0.0)))
+        if k == 3:      # 4.6 kHz/s: just inside the limit (theta up to 2.9e-4 rad)
+            changes = ((11, (2900.0, 4600.0)),)
+        if k == 4:      # 9 kHz/s: beyond it -- the swept channels of this call take the per-sample variant
+            changes = ((2, (2000.0, -9000.0)),)
+        for c, (d, r) in changes:
+            bank.set_doppler(c, d, r)
+            chans[c].set_doppler(d, r)
         bank.push_iq(iq[k * nb * L:(k + 1) * nb * L])
         assert bank.process() == nb
         for b in range(nb):
             blk = iq[(k * nb + b) * L:(k * nb + b + 1) * L]
             for c, ch in enumerate(chans):
                 aud, st, filt, _ = ch.block(blk, want_filt=True)
-                assert rel_rms(bank.filter_output(c, b), filt) < FILT_TOL, (k, b, c)
+                assert rel_rms(bank.filter_output(c, b), filt) < FILT_TOL, (k, b, c, rel_rms(bank.filter_output(c, b), filt))
                 assert rel_rms(bank.audio(c, b), aud) < AUDIO_TOL, (k, b, c)
                 got = bank.status(c, b)
                 assert got["squelch_count"] == st["squelch_count"] and got["blanked"] == st["blanked"], (k, b, c)

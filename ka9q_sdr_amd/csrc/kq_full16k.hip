@@ -189,7 +189,9 @@ __device__ __forceinline__ void sibling_exchange(unsigned long long *slots, int 
 // N0: compute_n0 on every block (needs ch.n0lane / ch.n0meta); DUMP: copy one channel's spectra out (tests); PLAIN: the
 // host vouches that no channel of the launch sweeps or was retuned since the last call -- the steady state of a
 // receiver -- so the per-sample oscillator path (2000 instructions of double arithmetic) is left out and the window
-// loads can be issued before anything else (with that path in the kernel they cost it 24 spilled registers).
+// loads can be issued before anything else (with that path in the kernel they cost it 24 spilled registers); PLAIN == 2
+// (N = 16384): the same promise about retunes, but EVERY channel of the launch sweeps, inside kSweepLimit16k -- the sweep
+// rides in the row phasors and in a first-order lane term (see the mix).
 // BIG: 0 = N 16384; 1 = N 65536 (four sibling workgroups per channel-block, blockIdx.x = 4 * channel + r); 2 = the same,
 // PLAIN launch with swept channels
 // EPI: which slave epilogue the instance carries -- 1: N/D = 64 only (one wave, registers); 2: N/D = 128 .. 512 only (N/D / 64

@@ -1483,7 +1483,10 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   bool const overlap = b->overlap_mode != 0;
   if (!overlap) b->stream2 = b->stream;
   // (its stream at high priority -- so that the demodulators' few workgroups are placed ahead of the next filter launch's --
-  // was measured in round 4: with_host_io 0.50 -> 0.78-1.25 ms at cfg 2, 1.45 -> 1.72 at cfg 4; default priority it is)
+  // was measured in round 4: with_host_io 0.50 -> 0.78-1.25 ms at cfg 2, 1.45 -> 1.72 at cfg 4; at the LOWEST priority --
+  // so that the next call's first kernels are not dispatched behind the demodulators' waiting workgroups -- round 5:
+  // 1.483 -> 1.692 ms per call at 32768 channels x 2 blocks, the demodulators starve until the filter pass ends and the
+  // call after next waits for them; default priority it is)
   if ((overlap && hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking) != hipSuccess) ||
       hipEventCreateWithFlags(&b->ev_demod_done[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&b->ev_demod_done[1], hipEventDisableTiming) != hipSuccess) {

@@ -22,6 +22,9 @@ run_stats full_n0_cfg3 $R/bench.py --steps 10 --config cfg3 $Q
 run_stats full_n0_cfg5 $R/bench.py --steps 10 --config cfg5 --blocks 16 $Q
 run_stats realtime_32768x2 $R/tools/realtime_probe.py --channels 32768 --blocks 2 --seconds 0.3
 run_stats realtime_32768x2_pcm $R/tools/realtime_probe.py --channels 32768 --blocks 2 --seconds 0.3 --pcm
+# the same with an operator at work (k_ctl_apply and k_design in front of the calls) and with 4096 swept channels (the PLAIN == 2 variant)
+run_stats realtime_32768x2_pcm_control_plane $R/tools/realtime_probe.py --channels 32768 --blocks 2 --seconds 0.3 --pcm --control-plane
+run_stats realtime_32768x2_pcm_swept4096 $R/tools/realtime_probe.py --channels 32768 --blocks 2 --seconds 0.3 --pcm --swept 4096
 pmc_pair() {  # tag, kernel substring, config, channels, blocks, fwd, bench args...
   local tag=$1 kern=$2 cfg=$3 ch=$4 bl=$5 fwd=$6; shift 6
   for c in FETCH_SIZE WRITE_SIZE; do

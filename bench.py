@@ -351,6 +351,17 @@ def measure_channels_at_realtime(torch, kq, wl, dev_index, stream, seconds):
         # returning (~1100 operations per second); none of them waits for the device or holds up the calls in flight
         out["with_control_plane"] = measure_realtime(torch, kq, wl, "cfg4", best["channels"], 2, dev_index, stream,
                                                      seconds=min(4.0, seconds), pcm=True, control_plane=True)
+        # for a host that does not read the noise estimate (status.n0 = NaN): without compute_n0 the bank runs its pruned forward
+        # path (the `without_compute_n0` row of this line at 1024 x 64) -- how many channels THAT holds at real time, PCM planes out
+        p2 = measure_realtime(torch, kq, wl, "cfg4", 49152, 2, dev_index, stream, seconds=1.5, pcm=True, compute_n0=False)
+        C2 = int(49152 * p2["realtime_factor"] * 0.985) // 256 * 256
+        for _ in range(2):
+            r2 = measure_realtime(torch, kq, wl, "cfg4", C2, 2, dev_index, stream, seconds=min(4.0, seconds), pcm=True, compute_n0=False)
+            if r2["realtime_factor"] >= 1.0:
+                break
+            C2 = int(C2 * min(0.98, r2["realtime_factor"] * 0.995)) // 256 * 256
+        out["without_compute_n0"] = dict(r2, note="secondary: the reference's demodulators run compute_n0 on every block; `channels` is "
+                                                  "the count tried last, it held real time iff realtime_factor >= 1")
     return out
 
 

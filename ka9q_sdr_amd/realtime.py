@@ -28,7 +28,7 @@ def build_bank(kq, wl, config, C, B, dev_index, stream, compute_n0=True):
 
 
 def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.0, host_io=True, pcm=False, warm_calls=50,
-                     retunes_per_call=0, swept_channels=0, rtp_samples=0, control_plane=False):
+                     retunes_per_call=0, swept_channels=0, rtp_samples=0, control_plane=False, compute_n0=True):
     """C channels, B blocks per call, for `seconds` of wall time.  host_io: input from pinned host memory, audio (float, or
     the int16 PCM words when pcm) + status planes to pinned host memory after every call into one of three buffer sets; the
     host waits for the planes of call k-2 once it has queued call k (it never runs more than two deliveries ahead of what it
@@ -40,7 +40,7 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
     geom = dict(wl.GEOMETRY[config])
     L, M, D, fs = geom["L"], geom["M"], geom["D"], geom["samprate"]
     olen = L // D
-    bank, plan, setup_s = build_bank(kq, wl, config, C, B, dev_index, stream)
+    bank, plan, setup_s = build_bank(kq, wl, config, C, B, dev_index, stream, compute_n0=compute_n0)
     for i in range(swept_channels):      # satellite passes: a Doppler offset with a rate (radio.c:180-184) on some channels
         c = (i * 7919) % C
         bank.set_doppler(c, 2000.0 + i, -40.0 - (i % 7))
@@ -168,7 +168,7 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
                     "audio_abs_sum": float(np.abs(a[::max(1, C // 997), :, :olen].astype(np.float64)).sum())}
     bank.close()
     signal_s = B * L / fs
-    return {"config": config, "channels": C, "blocks_per_call": B, "signal_ms_per_call": round(signal_s * 1e3, 4),
+    return {"config": config, "channels": C, "blocks_per_call": B, "compute_n0": int(bool(compute_n0)), "signal_ms_per_call": round(signal_s * 1e3, 4),
             "ms_per_call": round(dt * 1e3, 4), "realtime_factor": round(signal_s / dt, 4), "calls": ncalls,
             "wall_s": round(dt * ncalls, 2),
             "filter_kernel_ms": round(tm["filter_ms"] / max(1, tm["filter_launches"]), 4),

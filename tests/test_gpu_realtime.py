@@ -287,20 +287,21 @@ def test_pcm_planes_straight_to_the_host(gpu):
     bank.close()
 
 
-@pytest.mark.parametrize("everybody", [False, True])
-def test_swept_and_fixed_channels_side_by_side_against_the_oracle(gpu, everybody):
+@pytest.mark.parametrize("config,everybody", [("cfg4", False), ("cfg4", True), ("cfg2", False)])
+def test_swept_and_fixed_channels_side_by_side_against_the_oracle(gpu, config, everybody):
     """A bank of fixed-frequency channels with a few satellite passes among them (Doppler offset with a rate, radio.c:180-184):
     at N = 16384 the unswept channels run the steady-state variant of the filter kernel and the swept ones a steady-state
     variant of their own (row phasors with the sweep in them, the lane part of the cross term to first order; rates up to
-    kq full16k_sweep_limit = 4.8 kHz/s at 10 MS/s), as two launches over two channel lists; a channel changes list when its
-    Doppler rate is set or cleared while the bank runs, and one rate beyond the limit sends the swept list back to the
-    per-sample variant.  everybody: all channels sweep (one launch).  Every channel against the oracle through five calls,
-    with such changes in between."""
-    g = wl.GEOMETRY["cfg4"]
+    kq full16k_sweep_limit = 4.8e-11 cycles per sample^2: 4.8 kHz/s at cfg 4's 10 MS/s, 190 Hz/s at cfg 2's 2 MS/s), as two
+    launches over two channel lists; a channel changes list when its Doppler rate is set or cleared while the bank runs, and one
+    rate beyond the limit sends the swept list back to the per-sample variant.  everybody: all channels sweep (one launch).
+    Every channel against the oracle through five calls, with such changes in between."""
+    g = wl.GEOMETRY[config]
     fs, L = g["samprate"], g["L"]
-    plan = wl.channel_plan("cfg4", 14)
+    k_rate = (fs / 1e7) ** 2                 # the same rates in cycles per sample^2 at either sample rate
+    plan = wl.channel_plan(config, 14)
     for c in (range(14) if everybody else (2, 5, 11)):
-        plan[c].update(doppler=1800.0 + 100 * c, doppler_rate=-250.0 * (c + 1) if c % 2 else 330.0 * (c + 1))
+        plan[c].update(doppler=1800.0 + 100 * c, doppler_rate=k_rate * (-250.0 * (c + 1) if c % 2 else 330.0 * (c + 1)))
         plan[c]["second_lo"] += plan[c]["doppler"]
     nb, ncalls = 2, 5
     iq = wl.make_iq(fs, ncalls * nb * L, seed=0x6B63)
@@ -312,11 +313,11 @@ def test_swept_and_fixed_channels_side_by_side_against_the_oracle(gpu, everybody
     for k in range(ncalls):
         changes = ()
         if k == 2:      # channel 7 starts to sweep (or sweeps the other way), channel 5 stops (its offset stays): both change lists
-            changes = ((7, (900.0, -120.0)), (5, (plan[5]["doppler"], 0.0)))
-        if k == 3:      # 4.6 kHz/s: just inside the limit (theta up to 2.9e-4 rad)
-            changes = ((11, (2900.0, 4600.0)),)
+            changes = ((7, (900.0, -120.0 * k_rate)), (5, (plan[5]["doppler"], 0.0)))
+        if k == 3:      # 4.6 kHz/s at 10 MS/s: just inside the limit (theta up to 2.9e-4 rad)
+            changes = ((11, (2900.0, 4600.0 * k_rate)),)
         if k == 4:      # 9 kHz/s: beyond it -- the swept channels of this call take the per-sample variant
-            changes = ((2, (2000.0, -9000.0)),)
+            changes = ((2, (2000.0, -9000.0 * k_rate)),)
         for c, (d, r) in changes:
             bank.set_doppler(c, d, r)
             chans[c].set_doppler(d, r)

@@ -128,9 +128,12 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
         def call(k):
             bank.process_resident(iq_dev.data_ptr(), B)
 
+    stamps = []
+
     def run(ncalls, k0):
         for k in range(k0, k0 + ncalls):
             call(k)
+            stamps.append(time.perf_counter())     # (with host I/O: the moment delivery k - 2 was in hand)
 
     run(warm_calls, 0)
     if host_io:
@@ -148,12 +151,18 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
     bank.timing(reset=True)
     if host_io:
         nops[0] = 0
+    del stamps[:]
     t0 = time.perf_counter()
     run(ncalls, warm_calls + 8)
     if host_io:
         bank.host_io_wait()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / ncalls
+    # pacing as the host sees it: the intervals between consecutive deliveries (a receiver's output buffer has to ride out the
+    # longest of them)
+    iv = np.diff(np.array(stamps)) * 1e3 if len(stamps) > 2 else np.zeros(1)
+    pacing = {"p50": round(float(np.percentile(iv, 50)), 4), "p99": round(float(np.percentile(iv, 99)), 4),
+              "max": round(float(iv.max()), 4)}
     ht = bank.host_timing(reset=True)
     tm = bank.timing(reset=True)
     bank.enable_timing(0)
@@ -170,7 +179,7 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
     signal_s = B * L / fs
     return {"config": config, "channels": C, "blocks_per_call": B, "compute_n0": int(bool(compute_n0)), "signal_ms_per_call": round(signal_s * 1e3, 4),
             "ms_per_call": round(dt * 1e3, 4), "realtime_factor": round(signal_s / dt, 4), "calls": ncalls,
-            "wall_s": round(dt * ncalls, 2),
+            "wall_s": round(dt * ncalls, 2), "delivery_interval_ms": pacing,
             "filter_kernel_ms": round(tm["filter_ms"] / max(1, tm["filter_launches"]), 4),
             "host_ms_per_call": round(ht["call_ms"] / max(1, ht["calls"]), 4),
             "host_stage_ms_per_call": round(ht["stage_ms"] / max(1, ht["calls"]), 4),

@@ -114,6 +114,9 @@ struct HostChan {
   std::vector<kq::cfloat> resp, aresp;
   float noise_gain;
   int n0slot = -1;  // which of the bank's compute_n0 mask sets this channel uses (shared by all channels with its edges)
+  // where the channel stands in the bank's lists (kq_bank: list_host[lk][lpos], list_active_host[apos]); lk = 3: on the
+  // carrier-loop list, -1: on none
+  int lk = -1, lpos = -1, apos = -1;
   bool patched = false;  // an oscillator of this channel has been set since the last call (it is on the bank's patch list)
   double r_eff = 0;      // sweep of its input oscillators as the launch decisions last saw it (cycles / sample^2)
 };
@@ -176,8 +179,11 @@ struct kq_bank {
   int *list_pll_dev = nullptr;
   int *list_active_dev = nullptr;      // the active channels, for the filter launch, when remove_channel has left holes
   int *list_active_ds_dev = nullptr;   // the same list as the PCM stage reads it, on the demodulators' stream
-  std::vector<int> list_active_host;   // empty: no holes, the launch covers slots 0 .. chans.size() - 1 (a bank whose channels
-                                       // have ALL been removed never launches: run_blocks refuses it up front)
+  // Every active channel, in no particular order (the lists follow the channels' coming and going incrementally: a channel
+  // that leaves is replaced by the list's last entry, one that comes is appended -- one or two 4-byte writes to the device's
+  // copy instead of the list: at 32 768 channels a rebuilt list was 128 KiB over the link per change).  Used by the launches
+  // only while there are holes (fewer entries than slots); a bank whose channels have ALL been removed never launches.
+  std::vector<int> list_active_host;
   std::vector<int> list_pll_host;
   kq::PllState *pll_state = nullptr;
   float2 *pll_rings = nullptr, *pll_side = nullptr;
@@ -922,34 +928,103 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
   return 0;
 }
 
+int list_kind(const HostChan &h) {
+  int const m = h.cfg.demod_type;
+  if (m == KQ_LINEAR_DEMOD && h.cfg.pll) return 3;
+  return m == KQ_FM_DEMOD ? 0 : m == KQ_AM_DEMOD ? 1 : 2;
+}
+// the lists from scratch (set-up, batched adds, anything that touches the carrier-loop list): ascending channel order
 int upload_lists(kq_bank *b) {
   for (int k = 0; k < 3; k++) b->list_host[k].clear();
   b->list_pll_host.clear();
   b->list_active_host.clear();
   for (size_t c = 0; c < b->chans.size(); c++) {
-    if (!b->chans[c].active) continue;
+    HostChan &h = b->chans[c];
+    h.lk = h.lpos = h.apos = -1;
+    if (!h.active) continue;
+    h.apos = (int)b->list_active_host.size();
     b->list_active_host.push_back((int)c);
-    int const m = b->chans[c].cfg.demod_type;
-    if (m == KQ_LINEAR_DEMOD && b->chans[c].cfg.pll)
-      b->list_pll_host.push_back((int)c);  // slot = position in this list = order of creation
-    else
-      b->list_host[m == KQ_FM_DEMOD ? 0 : m == KQ_AM_DEMOD ? 1 : 2].push_back((int)c);
+    h.lk = list_kind(h);
+    std::vector<int> &l = h.lk == 3 ? b->list_pll_host : b->list_host[h.lk];  // (carrier loops: slot = position = order of creation)
+    h.lpos = (int)l.size();
+    l.push_back((int)c);
   }
   // the filter launch's list on the filter side; the demodulators' lists, and the PCM stage's copy of the active list,
   // on the demodulator side (the last call's demodulators may still be walking the old ones)
-  if (b->list_active_host.size() == b->chans.size()) {
-    b->list_active_host.clear();  // no holes
-  } else {
-    size_t const n = b->list_active_host.size() * sizeof(int);
-    if (ctl_put(b, CTL_FILTER, b->list_active_dev, b->list_active_host.data(), n)) return -1;
-    if (ctl_put(b, CTL_DEMOD, b->list_active_ds_dev, b->list_active_host.data(), n)) return -1;
-  }
+  size_t const n = b->list_active_host.size() * sizeof(int);
+  if (ctl_put(b, CTL_FILTER, b->list_active_dev, b->list_active_host.data(), n)) return -1;
+  if (ctl_put(b, CTL_DEMOD, b->list_active_ds_dev, b->list_active_host.data(), n)) return -1;
   if (!b->list_pll_host.empty())
     if (ctl_put(b, CTL_DEMOD, b->list_pll_dev, b->list_pll_host.data(), b->list_pll_host.size() * sizeof(int))) return -1;
   for (int k = 0; k < 3; k++)
     if (!b->list_host[k].empty())
       if (ctl_put(b, CTL_DEMOD, b->list_dev[k], b->list_host[k].data(), b->list_host[k].size() * sizeof(int))) return -1;
   b->lists_dirty = false;
+  return 0;
+}
+// one channel onto / off the lists as they stand (nothing to do while a rebuild is pending; a carrier-loop channel asks for one)
+int lists_add(kq_bank *b, int c) {
+  if (b->lists_dirty) return 0;
+  HostChan &h = b->chans[c];
+  int const k = list_kind(h);
+  if (k == 3) {
+    b->lists_dirty = true;
+    return 0;
+  }
+  h.apos = (int)b->list_active_host.size();
+  b->list_active_host.push_back(c);
+  if (ctl_put(b, CTL_FILTER, b->list_active_dev + h.apos, &c, sizeof(int))) return -1;
+  if (ctl_put(b, CTL_DEMOD, b->list_active_ds_dev + h.apos, &c, sizeof(int))) return -1;
+  h.lk = k;
+  h.lpos = (int)b->list_host[k].size();
+  b->list_host[k].push_back(c);
+  return ctl_put(b, CTL_DEMOD, b->list_dev[k] + h.lpos, &c, sizeof(int));
+}
+int lists_remove(kq_bank *b, int c, bool from_active);
+// after a mode change: onto the new mode's list if that is another one
+int lists_retype(kq_bank *b, int c) {
+  if (b->lists_dirty) return 0;
+  HostChan &h = b->chans[c];
+  int const k = list_kind(h);
+  if (k == 3 || h.lk == 3 || h.lk < 0) {
+    b->lists_dirty = true;
+    return 0;
+  }
+  if (k == h.lk) return 0;
+  if (lists_remove(b, c, false)) return -1;
+  h.lk = k;
+  h.lpos = (int)b->list_host[k].size();
+  b->list_host[k].push_back(c);
+  return ctl_put(b, CTL_DEMOD, b->list_dev[k] + h.lpos, &c, sizeof(int));
+}
+int lists_remove(kq_bank *b, int c, bool from_active = true) {
+  if (b->lists_dirty) return 0;
+  HostChan &h = b->chans[c];
+  if (h.lk == 3 || h.lk < 0 || h.lpos < 0 || h.apos < 0) {
+    b->lists_dirty = true;
+    return 0;
+  }
+  {
+    std::vector<int> &l = b->list_host[h.lk];
+    int const last = l.back();
+    l[h.lpos] = last;
+    b->chans[last].lpos = h.lpos;
+    l.pop_back();
+    if (last != c && ctl_put(b, CTL_DEMOD, b->list_dev[h.lk] + h.lpos, &last, sizeof(int))) return -1;
+  }
+  if (from_active) {
+    std::vector<int> &l = b->list_active_host;
+    int const last = l.back();
+    l[h.apos] = last;
+    b->chans[last].apos = h.apos;
+    l.pop_back();
+    if (last != c) {
+      if (ctl_put(b, CTL_FILTER, b->list_active_dev + h.apos, &last, sizeof(int))) return -1;
+      if (ctl_put(b, CTL_DEMOD, b->list_active_ds_dev + h.apos, &last, sizeof(int))) return -1;
+    }
+    h.apos = -1;
+  }
+  h.lk = h.lpos = -1;
   return 0;
 }
 
@@ -1140,7 +1215,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
         b->chan_tw_dirty = false;
       }
       {  // slots emptied by remove_channel are skipped: the launch goes over the list of active channels then
-        bool const holes = !b->list_active_host.empty();
+        bool const holes = b->list_active_host.size() != b->chans.size();
         kq::launch_filter_pruned(b->stream, g, chd, pl, window, b->chan_tw, holes ? (int)b->list_active_host.size() : C,
                                  (int)nblocks, swept, holes ? b->list_active_dev : nullptr);
       }
@@ -1153,7 +1228,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
           full_launch(b->stream, g, chd, pl, window, b->tw, nret, 1, 0, nullptr, -1, retune_list);
       }
     } else if (b->use64k) {
-      bool const holes = !b->list_active_host.empty();
+      bool const holes = b->list_active_host.size() != b->chans.size();
       auto const launch64k = [&](int nch, int nbl, const int *list, bool steady) {
         kq::Big64 big = b->big;
         big.epoch = ++b->big.epoch;  // never 0: the words start out zeroed
@@ -1169,7 +1244,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
       kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, nullptr);
     } else {
       // slots emptied by remove_channel are skipped: the launch goes over the list of active channels then
-      bool const holes = !b->list_active_host.empty();
+      bool const holes = b->list_active_host.size() != b->chans.size();
       if (mixed) {
         full_launch(b->stream, g, chd, pl, window, b->tw, (int)b->list_unswept_host.size(), (int)nblocks, b->cfg.compute_n0,
                     b->spec_dump, b->spec_ch, b->list_unswept_dev, false, true);
@@ -1248,7 +1323,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   if (g.pl_n > 0 && !b->list_host[0].empty())
     kq::launch_pl_track(ds, g, chd, pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), (int)nblocks);
   if (b->pcm_on) {
-    bool const holes = !b->list_active_host.empty();
+    bool const holes = b->list_active_host.size() != b->chans.size();
     kq::launch_pcm(ds, g, pl, b->pcm, b->pcm_mask, holes ? (int)b->list_active_host.size() : C, (int)nblocks,
                    holes ? b->list_active_ds_dev : nullptr);
   }
@@ -1797,7 +1872,7 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
       b->chans[c].active = false;
     return -1;
   }
-  b->lists_dirty = true;
+  if (lists_add(b, c)) return -1;
   b->chan_tw_dirty = true;
   // a channel more leaves the steady state of the others alone: its planes are patched in by the next call
   b->chans[c].r_eff = 0;
@@ -2038,6 +2113,7 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
     if (pll_leave(b, rank, npll)) return -1;
   }
   // (nothing on the device changes otherwise: the calls in flight still carry the channel, the next call's lists do not)
+  if (lists_remove(b, ch)) return -1;
   h.active = false;
   h.retuned = false;
   h.patched = false;  // (its entry on the patch list, if any, is skipped: the next call stages the whole bank)
@@ -2053,7 +2129,6 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
   h.lo2 = h.dop = h.shift = h.lo2_old = h.dop_old = Osc{};
   h.out_rtp = kq_out_rtp_state{};
   while (!b->chans.empty() && !b->chans.back().active) b->chans.pop_back();  // holes at the end just go
-  b->lists_dirty = true;
   return 0;
 }
 
@@ -2114,7 +2189,7 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
   h.out_type = (m->demod_type == KQ_LINEAR_DEMOD && m->isb) ? kq::FT_CROSS_CONJ : kq::FT_COMPLEX;
   h.shift.set(m->shift == 0 ? 0.0 : m->shift * b->g.D / (double)b->g.samprate, 0.0, b->out_abs);  // radio.c:367
   if (upload_channel(b, ch, false) || queue_design(b, ch)) return -1;
-  b->lists_dirty = true;
+  if (lists_retype(b, ch)) return -1;
   note_patch(b, ch);  // the shift oscillator (radio.c:367)
   return 0;
 }

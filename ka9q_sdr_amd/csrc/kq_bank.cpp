@@ -4,8 +4,14 @@
 //   * NCO bookkeeping in closed form.  The reference advances a complex-double phasor one sample at
 //     a time (osc.c:39-51); here each oscillator is (phase, step, sweep) at a reference sample index
 //     and the kernels evaluate phase(n) = phase + step*k + sweep*k*(k-1)/2 themselves.
-//   * response design (kq_design.cpp) and upload
-//   * ring management and kernel sequencing
+//     In the steady state (nothing set, added or removed since the call before) the device advances every channel's
+//     planes itself and the host touches no per-channel state; a retuned channel travels as one 72-byte patch record.
+//   * the control plane: set_filter / set_mode / add / remove / set_n0 ... never touch the device.  They gather write
+//     records (CtlQueue: filter side, demodulator side) and design jobs (DesignQueue) in pinned memory; the next call
+//     applies them with one launch each, in front of its own kernels, behind the calls in flight.  A new filter's
+//     response is designed on the bank's stream by kq_design.hip's kernel, straight into the channel's row.
+//   * ring management, kernel sequencing, streaming host I/O (copy streams, pinned planes), RTP in and out
+//   * one lock per handle (every entry point; let go of while an entry point waits for the device)
 #include <hip/hip_runtime.h>
 
 #include <chrono>

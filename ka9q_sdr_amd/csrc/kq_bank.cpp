@@ -1187,6 +1187,22 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     HIP_TRY(hipEventRecord(b->stage_t0[slot], b->stream));
     b->stage_timed[slot] = true;
   }
+  // The IF-power recurrence rides in the first full-spectrum launch of the call (one wave of its first workgroup,
+  // kq_full16k.hip) where there is one; KQ_IIR_IN_FILTER=0: as a launch of its own in front of the demodulators, as before
+  static bool const iir_in_filter_off = getenv("KQ_IIR_IN_FILTER") && atoi(getenv("KQ_IIR_IN_FILTER")) == 0;
+  bool iir_done = false;
+  auto const iir_arm = [&]() {  // before a launch of k_filter_full16k: hand it the job once per call
+    b->big.iir = kq::IirArgs{};
+    if (iir_done || iir_in_filter_off || spectrum) return;
+    b->big.iir.sums = pl.if_power + b->cfg.max_blocks;
+    b->big.iir.update = reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax);
+    b->big.iir.state = b->energy_state;
+    b->big.iir.if_power = pl.if_power;
+    b->big.iir.split = kq::block_energy_split(g.L);
+    b->big.iir.nblocks = (int)nblocks;
+    b->big.iir.L = g.L;
+    iir_done = true;
+  };
   {
     // `redo`: the list names channels retuned since the last call, which need the general variant
     // (as_plain: the steady-state variant -- the host vouches that no channel of THIS launch sweeps)
@@ -1195,6 +1211,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
                                  bool redo = true, bool as_plain = false, bool as_swept_steady = false) {
       // 0: the general variant; 1: steady state, no channel of the launch sweeps; 2: steady state, every one does
       int const pv = redo ? 0 : as_swept_steady ? 2 : (plain || as_plain) ? 1 : 0;
+      if (use16k && b->fwd_mode != KQ_FWD_PRUNED) iir_arm();  // (not the pruned path's redo launches: they come second)
       if (use16k)
         kq::launch_filter_full16k(st, gg, cd, pp, win, twp, nch, nbl, n0, dump, dump_ch, list, pv, pv ? paired : nullptr, b->big);
       else
@@ -1236,6 +1253,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     } else if (b->use64k) {
       bool const holes = b->list_active_host.size() != b->chans.size();
       auto const launch64k = [&](int nch, int nbl, const int *list, bool steady) {
+        iir_arm();
         kq::Big64 big = b->big;
         big.epoch = ++b->big.epoch;  // never 0: the words start out zeroed
         if (big.epoch == 0) big.epoch = ++b->big.epoch;
@@ -1291,7 +1309,9 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     HIP_TRY(hipStreamWaitEvent(ds, b->pull_done[(b->pulls - 1) % kq_bank::kPullRing], 0));
     b->out_pending = false;
   }
-  // the IF-power recurrence over the call's blocks: one wave, consumed by the demodulators only, so it runs with them and
+  // the IF-power recurrence over the call's blocks: one wave, consumed by the demodulators only.  Where the call has a
+  // full-spectrum launch it has ridden in that (iir_arm above: -5 us per step at cfg 4 and cfg 2, the filter kernel's own
+  // time unchanged; tools/ab_env.sh KQ_IIR_IN_FILTER); otherwise it runs here, with the demodulators and
   // not in front of the filter (folded into the sum's launch -- its last workgroup taking tagged partial sums as they
   // arrive -- it saved nothing measurable: 1.422 against 1.421 ms per step; on the second stream beside the filter pass,
   // with an event each way, it cost 7-9 us per step where the demodulators run on the main stream -- a wait on another
@@ -1301,7 +1321,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   if (spectrum)  // the IF power belongs to whoever fed the master (radio.c:123,143-145): status.if_power = 0, not what a
                  // normal call two calls back left in this parity's plane
     HIP_TRY(hipMemsetAsync(pl.if_power, 0, nblocks * sizeof(float), ds));
-  else
+  else if (!iir_done)
     kq::launch_block_energy_iir(ds, pl.if_power + b->cfg.max_blocks, g.L, (int)nblocks,
                                 reinterpret_cast<const unsigned char *>(b->osc_dev2[pp] + 8 * Cmax), b->energy_state, pl.if_power);
   {

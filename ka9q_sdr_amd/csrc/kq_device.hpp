@@ -9,6 +9,7 @@
 //   status    kq_chan_status [C][max_blocks]
 //   per-channel parameter / carried-state vectors (SoA, indexed by channel)
 #pragma once
+#include "kq_energy.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -140,12 +141,13 @@ void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const P
                         const int *chan_list);
 // N = 65536 on the same kernel: four sibling workgroups per channel-block, each the 16384-point transform of one residue
 // class of bins (k = 4 q + r); what they share travels through these planes (kq_full16k.hip)
-struct Big64 {
+struct Big64 {  // (N = 65536's hand-over places -- and, for every full-spectrum launch, what its side job needs: `iir`)
   unsigned long long *sync;  // [C][max_blocks][3][4] tagged words: first-pass sums of compute_n0 handed between the siblings
   float2 *n0part;            // [C][max_blocks][4] second pass: (sum, count) per sub-transform
   float2 *xs;                // [C][max_blocks][N_dec] the bins the slave reads, index k mod N_dec
   int *err;                  // set when a sibling's word never arrived
   unsigned epoch;            // tag of this launch
+  IirArgs iir;               // sums != null: the last wave of workgroup (0, 0) runs the call's IF-power recurrence first
 };
 // register-resident N = 16384 variant of the same (kq_full16k.hip)
 bool full16k_supported(const Geom &g);

@@ -15,6 +15,7 @@
 #include <utility>
 
 #include "kq_device.hpp"
+#include "kq_energy.hpp"
 #include "kq_ldsfft.hpp"
 
 namespace kq {
@@ -148,44 +149,10 @@ __global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *_
   block_sum_fi(acc, dummy, red_f, red_i);
   if (threadIdx.x == 0) sums[blockIdx.x] = acc;
 }
-// E <- 0.5*(E + sum); if_power = E / L  (the accumulator is halved, never cleared: radio.c:143-145).
-// A block whose last sample came from the lost-packet zero fill completes inside radio.c:94-98,
-// which runs the filter but leaves block_energy and if_power alone: update[b] == 0 marks those.
+// the IF-power recurrence as a launch of its own (kq_energy.hpp; the full-spectrum filter kernel runs it on the side instead)
 __global__ void k_block_energy_iir(const float *__restrict__ sums, int split, const unsigned char *__restrict__ update,
                                    int nblocks, int L, float *__restrict__ state, float *__restrict__ if_power) {
-  // one wave: fetch 64 blocks' sums and flags at a time in parallel, run the (inherently serial) recurrence out of
-  // registers via readlane -- two additions' worth per block -- and divide once, in parallel, at the end
-  int const lane = threadIdx.x;
-  float e = state[0], last = state[1];
-  for (int base = 0; base < nblocks; base += 64) {
-    int const i = base + lane;
-    float sm = 0.f;
-    if (i < nblocks)
-      for (int k = 0; k < split; k++) sm += sums[i * split + k];  // the parts in order
-    int const up = i < nblocks ? update[i] : 0;
-    float e_upd = 0.f, mine_e = 0.f;  // the accumulator as the last updating block left it; the same as of this lane's block
-    bool any = false, mine_any = false;
-    int const cnt = min(64, nblocks - base);
-    for (int k = 0; k < cnt; k++) {  // k is wave-uniform: v_readlane, not a trip through the LDS crossbar
-      e += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), k));
-      if (__builtin_amdgcn_readlane(up, k)) {
-        e *= 0.5f;
-        e_upd = e;
-        any = true;
-      }
-      if (lane == k) {
-        mine_e = e_upd;
-        mine_any = any;
-      }
-    }
-    float const mine = mine_any ? mine_e / L : last;  // blocks before the chunk's first update keep what came before
-    if (i < nblocks) if_power[i] = mine;
-    if (any) last = e_upd / L;
-  }
-  if (lane == 0) {
-    state[0] = e;
-    state[1] = last;
-  }
+  block_energy_iir_wave(sums, split, update, nblocks, L, state, if_power, (int)threadIdx.x);
 }
 
 int block_energy_split(int L) {

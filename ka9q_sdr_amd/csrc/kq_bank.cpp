@@ -1310,8 +1310,8 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     b->out_pending = false;
   }
   // the IF-power recurrence over the call's blocks: one wave, consumed by the demodulators only.  Where the call has a
-  // full-spectrum launch it has ridden in that (iir_arm above: -5 us per step at cfg 4 and cfg 2, the filter kernel's own
-  // time unchanged; tools/ab_env.sh KQ_IIR_IN_FILTER); otherwise it runs here, with the demodulators and
+  // full-spectrum launch it has ridden in that (iir_arm above: -5..6 us per step at cfg 4 and cfg 5, the filter kernel's own
+  // time unchanged; tools/ab_libs.sh against the commit before); otherwise it runs here, with the demodulators and
   // not in front of the filter (folded into the sum's launch -- its last workgroup taking tagged partial sums as they
   // arrive -- it saved nothing measurable: 1.422 against 1.421 ms per step; on the second stream beside the filter pass,
   // with an event each way, it cost 7-9 us per step where the demodulators run on the main stream -- a wait on another

@@ -214,12 +214,6 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
   __shared__ int red_i[2][kT / 64];
   int const t = threadIdx.x;
   int const Ndec = g.Ndec;
-  // Side job of ONE wave of the launch: the IF-power recurrence over the call's blocks (kq_energy.hpp), which the
-  // demodulators behind this launch read.  As a launch of its own it stood between every filter pass and its demodulators.
-  if (big.iir.sums != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && t >= kT - 64)
-    block_energy_iir_wave(big.iir.sums, big.iir.split, big.iir.update, big.iir.nblocks, big.iir.L, big.iir.state, big.iir.if_power,
-                          t & 63);
-
   // ---------------- load: samples n = 512 n1 + t into v[bitrev5(n1)].  The 32 window loads need nothing but the kernel
   // arguments, so they go out before the channel's parameters are even asked for: a workgroup's first microsecond is
   // otherwise two memory latencies in a row (parameters, then samples) with nothing to compute.
@@ -804,6 +798,13 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
       pl.n0raw[(size_t)c * g.max_blocks + b] = (float)(avg / (2.0 * kN * g.samprate));
     }
   }
+  // Side job of ONE wave of the launch: the IF-power recurrence over the call's blocks (kq_energy.hpp), which the
+  // demodulators behind this launch read.  As a launch of its own it stood between every filter pass and its demodulators.
+  // Here, behind compute_n0, the wave has nothing left to do in the one-wave and R-wave epilogues; in FRONT of the loads the
+  // same lines cost the kernel 4 % (the compiler's schedule of the whole load phase changed: 1.459 -> 1.518 ms, tools/ab_libs.sh).
+  if (big.iir.sums != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && t >= kT - 64)
+    block_energy_iir_wave(big.iir.sums, big.iir.split, big.iir.update, big.iir.nblocks, big.iir.L, big.iir.state, big.iir.if_power,
+                          t & 63);
   if constexpr (BIG != 0) return;  // response multiply and inverse transform: k_epilogue64k
   if (epi64) {
     // cfg 3 / 4: one wave multiplies and runs the 64-point inverse transform in its registers (lane exchanges, no

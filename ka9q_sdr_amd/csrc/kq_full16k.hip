@@ -1017,6 +1017,8 @@ void launch_filter_full16k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
   const float2 *tab = twiddle_tables();
   if (!tab) {  // cannot happen short of an allocation failure: fall back to the LDS kernel rather than fail the block
     launch_filter_full(s, g, ch, pl, window, tw, nchan, nblocks, compute_n0, spec_dump, spec_ch, chan_list);
+    if (big.iir.sums)  // the side job this launch was to carry
+      launch_block_energy_iir(s, big.iir.sums, big.iir.L, big.iir.nblocks, big.iir.update, big.iir.state, big.iir.if_power);
     return;
   }
   bool const n0 = compute_n0 && ch.n0lane && ch.n0meta;  // the bank uploads both whenever it was created with compute_n0

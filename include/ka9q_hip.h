@@ -245,7 +245,8 @@ int kq_bank_process_spectrum(kq_bank *bank, const void *spectrum_dev, unsigned n
 /* The demodulators of a call may run on a second internal stream, overlapping the next call's filter pass (the bank
  * decides per call: after kq_bank_pull_planes_async, or with AM / SSB channels; KQ_DEMOD_OVERLAP=0 / 1 forces it).
  * kq_bank_join makes the bank's main stream wait (on the device) for the last call's demodulators wherever they ran;
- * kq_bank_sync blocks the host until everything issued so far has finished. */
+ * kq_bank_sync applies what the control plane has queued since the last call and blocks the host until everything
+ * issued so far has finished. */
 int kq_bank_join(kq_bank *bank);
 int kq_bank_sync(kq_bank *bank);
 /* The hipStream_t the bank launches on, as void*: kq_bank_config.stream, or the bank's own stream when that was NULL.
@@ -326,7 +327,9 @@ int kq_bank_output_rtp_state(const kq_bank *bank, int ch, kq_out_rtp_state *out)
 int kq_bank_pull_filter_output(kq_bank *bank, int ch, unsigned blk, float *dst_re_im, size_t cap_complex);
 /* Master spectrum fdomain[N] of one channel/block (only in KQ_FWD_FULL mode; radio.c:396) */
 int kq_bank_pull_spectrum(kq_bank *bank, int ch, unsigned blk, float *dst_re_im, size_t cap_complex);
-/* Designed responses (filter.out->response, N/D complex; FM audio response N/D/2+1) */
+/* Designed responses (filter.out->response, N/D complex; FM audio response N/D/2+1).  The pre-detection response of a
+ * channel added or changed one at a time lives on the device (it is designed there, on the bank's stream): the first
+ * kq_bank_get_response after such a change applies what is queued, waits for the device and fetches it. */
 int kq_bank_get_response(kq_bank *bank, int ch, float *dst_re_im, size_t cap_complex);
 int kq_bank_get_audio_response(kq_bank *bank, int ch, float *dst_re_im, size_t cap_complex);
 /* Device-resident result planes for zero-copy consumers:

@@ -1239,8 +1239,10 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
       }
       {  // slots emptied by remove_channel are skipped: the launch goes over the list of active channels then
         bool const holes = b->list_active_host.size() != b->chans.size();
+        if (kq::pruned_carries_iir(g)) iir_arm();
         kq::launch_filter_pruned(b->stream, g, chd, pl, window, b->chan_tw, holes ? (int)b->list_active_host.size() : C,
-                                 (int)nblocks, swept, holes ? b->list_active_dev : nullptr);
+                                 (int)nblocks, swept, holes ? b->list_active_dev : nullptr, b->big.iir);
+        b->big.iir = kq::IirArgs{};
       }
       // The pruned kernels assume one oscillator over the whole window.  For the first block after a retune the
       // history half still carries the old one: redo just those channel-blocks on the per-sample path.

@@ -175,7 +175,9 @@ void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const 
                          const float2 *tw, int nchan, int nblocks, const int *chan_list);
 bool pruned_supported(const Geom &g);
 void launch_filter_pruned(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
-                          const float2 *chan_tw, int nchan, int nblocks, bool swept, const int *chan_list);
+                          const float2 *chan_tw, int nchan, int nblocks, bool swept, const int *chan_list, const IirArgs &iir = IirArgs{});
+// the geometries whose pruned kernel runs the IF-power recurrence handed to it in `iir` (the others ignore it)
+bool pruned_carries_iir(const Geom &g);
 void launch_pruned_tables(hipStream_t s, const Geom &g, const ChanDev &ch, float2 *chan_tw, int nchan);
 size_t demod_fm_lds_bytes(const Geom &g);
 void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw,

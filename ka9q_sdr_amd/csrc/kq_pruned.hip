@@ -541,7 +541,7 @@ template <int NWAVES, int CPW, int R, bool SWEPT>
 __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident(Geom g, ChanDev ch, Planes pl,
                                                                  const float2 *__restrict__ window,
                                                                  const float *__restrict__ tab, int nchan,
-                                                                 const int *__restrict__ chan_list) {
+                                                                 const int *__restrict__ chan_list, IirArgs iir) {
   constexpr int ND = 64;
   constexpr int N = ND * R;  // compile time, so that LDS offsets are immediates
   constexpr int groups = R / 64;
@@ -655,6 +655,10 @@ __global__ void __launch_bounds__(NWAVES * 64) k_pruned_resident(Geom g, ChanDev
     int const first = 64 - g.olen;  // the last olen samples are the output (filter.c:131)
     if (lane >= first) pl.filt[((size_t)c * g.max_blocks + blk) * g.olen + (lane - first)] = y;
   }
+  // side job of one wave of the launch, once its own channels are done: the call's IF-power recurrence (kq_energy.hpp; as
+  // in k_filter_full16k -- the launch of its own stood between the filter pass and the demodulators)
+  if (iir.sums != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && wave == NWAVES - 1)
+    block_energy_iir_wave(iir.sums, iir.split, iir.update, iir.nblocks, iir.L, iir.state, iir.if_power, lane);
 }
 
 // ------------------------------------------------------------------ N_dec = 128, window streamed in column slices
@@ -854,14 +858,14 @@ void launch_pruned_tables(hipStream_t s, const Geom &g, const ChanDev &ch, float
 namespace {
 template <int R, bool SWEPT>
 void launch_resident(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window, const float *tab,
-                     int nchan, int nblocks, const int *chan_list) {
+                     int nchan, int nblocks, const int *chan_list, const IirArgs &iir) {
   constexpr int NWAVES = 8, CPW = 4;
   size_t const lds_bytes = (size_t)64 * R * sizeof(float2) + (size_t)NWAVES * Tab<64>::kWaveF4 * sizeof(float4) +
                            32 * sizeof(float2);  // window, wave slots, inverse-transform twiddles
   ensure_dynamic_lds((const void *)k_pruned_resident<NWAVES, CPW, R, SWEPT>, (size_t)(lds_bytes));
   int const per_wg = NWAVES * CPW;
   hipLaunchKernelGGL((k_pruned_resident<NWAVES, CPW, R, SWEPT>), dim3((nchan + per_wg - 1) / per_wg, nblocks),
-                     dim3(NWAVES * 64), lds_bytes, s, g, ch, pl, window, tab, nchan, chan_list);
+                     dim3(NWAVES * 64), lds_bytes, s, g, ch, pl, window, tab, nchan, chan_list, iir);
 }
 
 void launch_resident256(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
@@ -886,8 +890,10 @@ void launch_stream(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes
 }
 }  // namespace
 
+bool pruned_carries_iir(const Geom &g) { return g.Ndec == 64 && (g.D == 256 || g.D == 128 || g.D == 64); }
+
 void launch_filter_pruned(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
-                          const float2 *chan_tw, int nchan, int nblocks, bool swept, const int *chan_list) {
+                          const float2 *chan_tw, int nchan, int nblocks, bool swept, const int *chan_list, const IirArgs &iir) {
   const float *tab = reinterpret_cast<const float *>(chan_tw);
   if (g.Ndec == 256) {  // unswept only (the host routes swept channels at this geometry to the full path)
     launch_resident256(s, g, ch, pl, window, tab, nchan, nblocks, chan_list);
@@ -903,9 +909,9 @@ void launch_filter_pruned(hipStream_t s, const Geom &g, const ChanDev &ch, const
 #define KQ_RES(RR)                                                           \
   if (g.D == RR) {                                                           \
     if (swept)                                                               \
-      launch_resident<RR, true>(s, g, ch, pl, window, tab, nchan, nblocks, chan_list);  \
+      launch_resident<RR, true>(s, g, ch, pl, window, tab, nchan, nblocks, chan_list, iir);  \
     else                                                                     \
-      launch_resident<RR, false>(s, g, ch, pl, window, tab, nchan, nblocks, chan_list); \
+      launch_resident<RR, false>(s, g, ch, pl, window, tab, nchan, nblocks, chan_list, iir); \
     return;                                                                  \
   }
   KQ_RES(256)

@@ -490,8 +490,10 @@ void ctl_cancel(kq_bank *b, int side, void *dst) {
 }
 
 // the design jobs gathered since the last call: one launch on the main stream
-int design_flush(kq_bank *b) {
+// `ctl_queue` != null: that many write records of the filter side's queue ride in the same launch (*took_records set)
+int design_flush(kq_bank *b, const void *ctl_queue = nullptr, unsigned ctl_records = 0, bool *took_records = nullptr) {
   kq_bank::DesignQueue &d = b->dq;
+  if (took_records) *took_records = false;
   if (d.jobs.empty()) return 0;
   int const p = (int)(d.epoch & 1);
   unsigned const n = (unsigned)d.jobs.size();
@@ -503,10 +505,11 @@ int design_flush(kq_bank *b) {
   if (d.ng_moved_set[p]) HIP_TRY(hipStreamWaitEvent(b->stream, d.ng_moved[p], 0));
   if (kq::design_launch(b->stream, b->g.olen, b->g.Mdec, reinterpret_cast<const kq::DesignJob *>(pin),
                         reinterpret_cast<const kq::DesignTarget *>(pin + kq_bank::DesignQueue::kMax * sizeof(kq::DesignJob)), n,
-                        d.scratch)) {
+                        d.scratch, ctl_queue, ctl_records)) {
     set_err("response design launch failed");
     return -1;
   }
+  if (took_records) *took_records = ctl_queue != nullptr && ctl_records > 0;
   HIP_TRY(hipEventRecord(d.read[d.cur], b->stream));
   d.read_set[d.cur] = true;
   d.cur = (d.cur + 1) % kq_bank::DesignQueue::kDepth;
@@ -521,9 +524,12 @@ int design_flush(kq_bank *b) {
 // apply what has gathered in queue `side` with one launch on `st`
 int ctl_flush(kq_bank *b, int side, hipStream_t st) {
   kq_bank::CtlQueue &q = b->ctl[side];
-  if (side == CTL_FILTER && design_flush(b)) return -1;  // (the filter side is always applied on the main stream)
+  // (the filter side is always applied on the main stream: with design jobs waiting, its records ride in their launch --
+  //  nothing a record writes is read or written by a design job, kq_bank::DesignQueue / ctl_cancel see to that)
+  bool applied = false;
+  if (side == CTL_FILTER && design_flush(b, q.nrec ? q.buf[q.cur] : nullptr, q.nrec, &applied)) return -1;
   if (q.nrec == 0) return 0;
-  kq::launch_ctl_apply(st, q.buf[q.cur], (int)q.nrec);
+  if (!applied) kq::launch_ctl_apply(st, q.buf[q.cur], (int)q.nrec);
   HIP_TRY(hipEventRecord(q.applied[q.cur], st));
   q.applied_set[q.cur] = true;
   if (side == CTL_DEMOD && b->dq.ng_to_record >= 0) {

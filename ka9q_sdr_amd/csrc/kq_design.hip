@@ -18,6 +18,7 @@
 #include "kq_design.hpp"
 #include "kq_device.hpp"
 #include "kq_ldsfft.hpp"
+#include "kq_ctl.hpp"
 
 void kq_internal_set_error(const char *fmt, ...);
 
@@ -61,7 +62,13 @@ __global__ void k_kaiser(float *__restrict__ w, int M, float beta) {
 template <bool REAL>
 __global__ void k_design(int log2n, int M, int spec, const DesignJob *__restrict__ jobs, const float2 *__restrict__ given,
                          float2 *__restrict__ out, float2 *__restrict__ scratch, float *__restrict__ sumsq, int nsum,
-                         const float2 *__restrict__ tw, int tw_log2, const DesignTarget *__restrict__ targets) {
+                         const float2 *__restrict__ tw, int tw_log2, const DesignTarget *__restrict__ targets,
+                         const unsigned char *__restrict__ ctlq, unsigned njobs) {
+  // a launch on a bank's stream may take the filter side's control records along: the workgroups behind the design jobs
+  if (ctlq != nullptr && blockIdx.x >= njobs) {
+    ctl_apply_record(ctlq, blockIdx.x - njobs, threadIdx.x, blockDim.x);
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   __shared__ float red_f[16];
   __shared__ int red_i[16];
@@ -239,7 +246,7 @@ int design_batch(int L, int M, bool real_taps, int spec, const std::vector<Desig
       ensure_dynamic_lds((const void *)kernel, lds_bytes);
       hipLaunchKernelGGL(kernel, dim3((unsigned)count), dim3(threads), lds_bytes, st, log2n, M, spec, (const DesignJob *)w->buf[0],
                          (const float2 *)(given ? w->buf[1] : nullptr), (float2 *)w->buf[2], (float2 *)w->buf[3], (float *)w->buf[4],
-                         nsum, tw, log2n, (const DesignTarget *)nullptr);
+                         nsum, tw, log2n, (const DesignTarget *)nullptr, (const unsigned char *)nullptr, (unsigned)count);
     };
     real_taps ? go(k_design<true>) : go(k_design<false>);
     ok = hipGetLastError() == hipSuccess;
@@ -318,7 +325,7 @@ int design_prepare(int L_dec, int M_dec) {
   return design_twiddles(log2n) ? 0 : -1;
 }
 int design_launch(void *stream, int L_dec, int M_dec, const DesignJob *jobs, const DesignTarget *targets, unsigned count,
-                  void *scratch) {
+                  void *scratch, const void *ctl_queue, unsigned ctl_records) {
   int const N = L_dec + M_dec - 1;
   int log2n = 0;
   while ((1 << log2n) < N) log2n++;
@@ -327,8 +334,10 @@ int design_launch(void *stream, int L_dec, int M_dec, const DesignJob *jobs, con
   if (!tw || count == 0) return tw ? 0 : -1;
   size_t const lds_bytes = (size_t)N * sizeof(float2);
   ensure_dynamic_lds((const void *)k_design<false>, lds_bytes);
-  hipLaunchKernelGGL(k_design<false>, dim3(count), dim3(N >= 1024 ? 256 : 64), lds_bytes, st, log2n, M_dec, (int)SPEC_BAND, jobs,
-                     (const float2 *)nullptr, (float2 *)nullptr, (float2 *)scratch, (float *)nullptr, N, tw, log2n, targets);
+  if (!ctl_queue) ctl_records = 0;
+  hipLaunchKernelGGL(k_design<false>, dim3(count + ctl_records), dim3(N >= 1024 ? 256 : 64), lds_bytes, st, log2n, M_dec, (int)SPEC_BAND,
+                     jobs, (const float2 *)nullptr, (float2 *)nullptr, (float2 *)scratch, (float *)nullptr, N, tw, log2n, targets,
+                     static_cast<const unsigned char *>(ctl_queue), count);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 // gain and noise-gain factor of a slave's design (what design_responses applies on the host)

@@ -42,7 +42,9 @@ std::vector<cfloat> design_response(int N, int L_dec, int M_dec, int out_type, f
 
 // design_responses queued on a stream, results left on the device (kq_design.hip); hipStream_t passed as void *
 int design_prepare(int L_dec, int M_dec);
-int design_launch(void *stream, int L_dec, int M_dec, const DesignJob *jobs, const DesignTarget *targets, unsigned count, void *scratch);
+// ctl_queue != null: `ctl_records` write records of a bank's control queue (kq_ctl.hpp) are applied by the same launch
+int design_launch(void *stream, int L_dec, int M_dec, const DesignJob *jobs, const DesignTarget *targets, unsigned count, void *scratch,
+                  const void *ctl_queue = nullptr, unsigned ctl_records = 0);
 void design_scales(int N, int out_type, float *gain, float *ng_scale);
 
 // FM post-detection response (fm.c:42, 56-65): 300 Hz high-pass, -6 dB/octave to 6 kHz, Kaiser

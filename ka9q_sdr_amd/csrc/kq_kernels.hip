@@ -15,6 +15,7 @@
 #include <utility>
 
 #include "kq_device.hpp"
+#include "kq_ctl.hpp"
 #include "kq_energy.hpp"
 #include "kq_ldsfft.hpp"
 
@@ -181,31 +182,7 @@ void launch_block_energy_sum(hipStream_t s, const float2 *newsamples, int L, int
 // count (a multiple of 4), then the offset of its payload in the buffer (kind 0), a 32-bit fill value (kind 1) or the
 // device address to copy from (kind 2: a value an earlier kernel of the call left on the device -- the noise gain of a
 // response designed in front of the filter pass, kq_design.hip design_launch).
-struct CtlRec {
-  unsigned long long dst;
-  unsigned nbytes, kind, value, payload_off;
-  unsigned long long src;
-};
-__global__ void __launch_bounds__(256) k_ctl_apply(const unsigned char *__restrict__ q) {
-  const CtlRec *r = reinterpret_cast<const CtlRec *>(q) + blockIdx.x;
-  unsigned *dst = reinterpret_cast<unsigned *>(r->dst);
-  unsigned const n = r->nbytes >> 2;
-  if (r->kind == 1) {
-    unsigned const v = r->value;
-    for (unsigned i = threadIdx.x; i < n; i += 256) dst[i] = v;
-    return;
-  }
-  // (a payload lies in host memory: every load is a trip over the link, so as few and as wide as the alignment allows --
-  //  the host cuts long payloads into records of 4 KiB, one trip per thread)
-  const unsigned *src = r->kind == 2 ? reinterpret_cast<const unsigned *>(r->src) : reinterpret_cast<const unsigned *>(q + r->payload_off);
-  if ((((unsigned long long)(uintptr_t)dst | (unsigned long long)(uintptr_t)src | r->nbytes) & 15ull) == 0) {
-    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
-    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
-    for (unsigned i = threadIdx.x; i < (n >> 2); i += 256) d4[i] = s4[i];
-  } else {
-    for (unsigned i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
-  }
-}
+__global__ void __launch_bounds__(256) k_ctl_apply(const unsigned char *__restrict__ q) { ctl_apply_record(q, blockIdx.x, threadIdx.x, 256); }
 void launch_ctl_apply(hipStream_t s, const void *queue_host, int nrec) {
   if (nrec > 0) hipLaunchKernelGGL(k_ctl_apply, dim3(nrec), dim3(256), 0, s, static_cast<const unsigned char *>(queue_host));
 }

@@ -150,7 +150,8 @@ int kq_bank_add_channel(kq_bank *bank, const kq_channel_config *cfg);
 /* n channels at once -- the same result as n calls of kq_bank_add_channel, but every distinct response is designed once
  * (one launch for all), every distinct compute_n0 mask is built once and every per-channel plane is uploaded with one copy:
  * a bank of tens of thousands of channels is set up in a second instead of a minute.  indices (may be NULL) receives the
- * channel numbers.  All or nothing: returns n, or -1 with no channel added. */
+ * channel numbers.  All or nothing: returns n, or -1 with no channel added.  Meant for set-up: its copies are immediate, so it
+ * waits for the calls in flight first -- on a running bank kq_bank_add_channel per channel does not (0.02 ms of host time each). */
 int kq_bank_add_channels(kq_bank *bank, const kq_channel_config *cfgs, unsigned n, int *indices);
 /* The demodulator thread's epilogue once demod->terminate is set and it has been joined (fm.c:177-182, am.c:80,
  * linear.c:319: delete_filter_output on its slaves).  The other channels keep their numbers; the slot is a hole that

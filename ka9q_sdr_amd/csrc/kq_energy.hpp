@@ -16,6 +16,7 @@ struct IirArgs {
   int split = 0, nblocks = 0, L = 0;
 };
 
+#ifdef __HIPCC__  // (the struct above is also seen by host-only builds: tests/tsan compiles kq_device.hpp with g++)
 // E <- 0.5*(E + sum); if_power = E / L  (the accumulator is halved, never cleared: radio.c:143-145).
 // A block whose last sample came from the lost-packet zero fill completes inside radio.c:94-98,
 // which runs the filter but leaves block_energy and if_power alone: update[b] == 0 marks those.
@@ -56,5 +57,6 @@ __device__ __forceinline__ void block_energy_iir_wave(const float *__restrict__ 
     state[1] = last;
   }
 }
+#endif  // __HIPCC__
 
 }  // namespace kq

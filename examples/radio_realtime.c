@@ -20,8 +20,8 @@
  * the delivery rate, and checks a delivered channel: squelch open, the 1 kHz tone's deviation seen.
  *
  *   gcc -std=gnu11 -O2 -Iinclude examples/radio_realtime.c -Lka9q_sdr_amd/lib -lka9q_hip \
- *       -Wl,-rpath,$PWD/ka9q_sdr_amd/lib -L/opt/rocm/lib -lamdhip64 -lm -o radio_realtime
- * (libamdhip64 only for hipHostMalloc / hipHostFree: pinned memory is the host program's to allocate.)
+ *       -Wl,-rpath,$PWD/ka9q_sdr_amd/lib -lm -o radio_realtime
+ * (nothing of HIP in the host program: the pinned buffers come from kq_host_alloc.)
  */
 #include <complex.h>
 #include <math.h>
@@ -32,10 +32,6 @@
 #include <time.h>
 
 #include "ka9q_hip.h"
-
-/* the two HIP runtime calls a host needs for pinned buffers, declared here so that the example builds without the HIP headers */
-extern int hipHostMalloc(void **ptr, size_t size, unsigned flags);
-extern int hipHostFree(void *ptr);
 
 enum { L = 8192, M = 8193, D = 256, SAMPRATE = 10000000, OLEN = L / D };
 #define NEMIT 16
@@ -85,12 +81,12 @@ int main(int argc, char **argv){
   void *out[3], *st[3];
   uint32_t *mask[3];
   size_t const out_bytes = rows * 2 * OLEN * (pcm ? sizeof(int16_t) : sizeof(float));
-  int bad = hipHostMalloc((void **)&in, nin * sizeof *in, 0);
+  int bad = (in = kq_host_alloc(nin * sizeof *in)) == NULL;
   for(int i = 0; i < 3; i++)
-    bad |= hipHostMalloc(&out[i], out_bytes, 0) | hipHostMalloc(&st[i], rows * sizeof(kq_chan_status), 0) |
-           hipHostMalloc((void **)&mask[i], rows * sizeof(uint32_t), 0);
+    bad |= (out[i] = kq_host_alloc(out_bytes)) == NULL || (st[i] = kq_host_alloc(rows * sizeof(kq_chan_status))) == NULL ||
+           (mask[i] = kq_host_alloc(rows * sizeof(uint32_t))) == NULL;
   if(bad){
-    fprintf(stderr, "hipHostMalloc failed\n");
+    fprintf(stderr, "kq_host_alloc: %s\n", kq_last_error());
     return 1;
   }
   double phase[NEMIT] = {0};
@@ -208,11 +204,11 @@ int main(int argc, char **argv){
   }
   kq_bank_destroy(bank);
   free(cc);
-  hipHostFree(in);
+  kq_host_free(in);
   for(int i = 0; i < 3; i++){
-    hipHostFree(out[i]);
-    hipHostFree(st[i]);
-    hipHostFree(mask[i]);
+    kq_host_free(out[i]);
+    kq_host_free(st[i]);
+    kq_host_free(mask[i]);
   }
   puts(rc == 0 ? "ok" : "unexpected result");
   return rc;

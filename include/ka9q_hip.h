@@ -138,6 +138,11 @@ const char *kq_version(void);
 int kq_abi_version(void);
 /* Number of visible HIP devices, or -1 when the HIP runtime cannot be initialised */
 int kq_device_count(void);
+/* Page-locked host memory for the streaming entry points (kq_bank_push_iq_async, kq_bank_pull_planes_async,
+ * kq_bank_pull_pcm_planes_async): what a host would otherwise take from hipHostMalloc, so that a C, cgo or JNI host links
+ * this library alone.  Usable with every device of the process.  NULL on failure (kq_last_error says why). */
+void *kq_host_alloc(size_t bytes);
+void kq_host_free(void *p);
 
 /* --- lifetime --- */
 kq_bank *kq_bank_create(const kq_bank_config *cfg);               /* main.c:232 create_filter_input */

@@ -1433,6 +1433,19 @@ int kq_device_count(void) {
   return n;
 }
 
+void *kq_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  hipError_t const e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);
+  if (e != hipSuccess) {
+    set_err("hipHostMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    return nullptr;
+  }
+  return p;
+}
+void kq_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
 kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   if (!cfg) {
     set_err("NULL config");

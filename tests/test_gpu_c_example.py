@@ -63,7 +63,7 @@ def test_radio_realtime_c_example(gpu, pcm, operator):
     out = os.path.join(tempfile.gettempdir(), "kq_radio_realtime_example_%d_%d_%d" % (os.getpid(), pcm, operator))
     r = subprocess.run(["gcc", "-std=gnu11", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "examples", "radio_realtime.c"), "-L", lib, "-lka9q_hip", "-Wl,-rpath," + lib,
-                        "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", out], capture_output=True, text=True)
+                        "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", out], capture_output=True, text=True)   # (no HIP library on the line)
     assert r.returncode == 0, r.stderr
     try:
         run = subprocess.run([out, "8192", "2", "1.5", str(pcm), str(operator)], capture_output=True, text=True, timeout=300)

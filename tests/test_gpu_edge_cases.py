@@ -411,3 +411,57 @@ def test_soak_realtime_smoke(gpu):
                         "--check-calls", "200"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert r.stdout.strip().splitlines()[-1] == "soak ok", r.stdout[-2000:]
+
+
+_IIR_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import ka9q_sdr_amd as kq
+from ka9q_sdr_amd import workload as wl
+bank_cfg = wl.bank_channel_config
+cfg, fwd = sys.argv[3], int(sys.argv[4])
+g = wl.GEOMETRY[cfg]
+fs, L = g["samprate"], g["L"]
+plan = wl.channel_plan(cfg, 6)
+nb = 5
+iq = wl.make_iq(fs, 3 * nb * L, seed=77)
+bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), nb, compute_n0=(fwd != kq.KQ_FWD_PRUNED), fwd_mode=fwd, pl_tone=False)
+bank.add_channels([bank_cfg(p) for p in plan])
+out = []
+for k in range(3):
+    if k == 1:
+        bank.push_zeros(2 * L + 100)        # a lost-packet gap: blocks completed inside it leave the IF power alone (radio.c:94-98)
+        bank.push_iq(iq[k * nb * L:(k + 1) * nb * L - (2 * L + 100)])
+    else:
+        bank.push_iq(iq[k * nb * L:(k + 1) * nb * L])
+    n = bank.process()
+    out.append([[bank.status(c, b)["if_power"] for b in range(n)] for c in range(len(plan))])
+bank.close()
+np.save(sys.argv[2], np.array(out, dtype=np.float32))
+"""
+
+
+@pytest.mark.parametrize("config,fwd", [("cfg4", "full"), ("cfg4", "pruned"), ("cfg5", "full")])
+def test_if_power_recurrence_in_the_filter_launch_is_the_stand_alone_one(gpu, config, fwd, tmp_path):
+    """The IF-power recurrence (radio.c:143-145) rides in the call's filter launch -- one wave of its first workgroup, behind
+    compute_n0 (k_filter_full16k, N = 16384 and 65536) or behind its channels (k_pruned_resident).  KQ_IIR_IN_FILTER=0 launches it
+    on its own as before: the status words must be the same bits either way, through three calls with a zero-filled gap in the
+    second (whose blocks must not update it)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fwd_mode = {"full": kq.KQ_FWD_FULL, "pruned": kq.KQ_FWD_PRUNED}[fwd]
+    res = []
+    for val in ("0", "1"):
+        path = str(tmp_path / ("ifp_%s.npy" % val))
+        env = dict(os.environ, KQ_IIR_IN_FILTER=val)
+        r = subprocess.run([sys.executable, "-c", _IIR_SCRIPT, root, path, config, str(fwd_mode)], capture_output=True, text=True,
+                           timeout=600, env=env)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        res.append(np.load(path))
+    a, b = res
+    assert a.shape == b.shape and a.size > 0
+    assert np.all(np.isfinite(a)) and np.all(a > 0)
+    assert a.tobytes() == b.tobytes()
+    assert np.all(a[:, 0, :] == a[:, 1, :])          # one front end: every channel reports the same IF power

@@ -24,6 +24,7 @@ from .bank import (  # noqa: F401
     build_library,
     channel_config,
     device_count,
+    HostBuffer,
     library_path,
     load_library,
 )

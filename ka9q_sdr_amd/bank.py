@@ -180,6 +180,9 @@ def load_library():
     L.kq_fanout_stats.argtypes = [C.c_void_p, C.POINTER(FanoutInfo)]
     L.kq_fanout_enable_timing.argtypes = [C.c_void_p, C.c_int]
     L.kq_fanout_rccl_path.restype = C.c_char_p
+    L.kq_host_alloc.restype = C.c_void_p
+    L.kq_host_alloc.argtypes = [C.c_size_t]
+    L.kq_host_free.argtypes = [C.c_void_p]
     L.kq_abi_version.restype = C.c_int
     if L.kq_abi_version() != KQ_ABI_VERSION:
         raise KqError("libka9q_hip.so has ABI revision %d, this mirror was written for %d" % (L.kq_abi_version(), KQ_ABI_VERSION))
@@ -193,6 +196,26 @@ class FanoutInfo(C.Structure):
                 ("broadcasts", C.c_ulonglong), ("broadcast_ms", C.c_double),
                 ("acquires", C.c_ulonglong), ("waits", C.c_ulonglong), ("wait_ms", C.c_double),
                 ("waits_dropped", C.c_ulonglong)]
+
+
+class HostBuffer:
+    """Page-locked host memory from the library (kq_host_alloc): .ptr for the streaming entry points, .array(dtype) a numpy view."""
+
+    def __init__(self, nbytes):
+        L = load_library()
+        self.nbytes = int(nbytes)
+        self.ptr = L.kq_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise KqError("kq_host_alloc: " + _err(L))
+
+    def array(self, dtype=np.uint8):
+        n = self.nbytes // np.dtype(dtype).itemsize
+        return np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self.ptr)).view(dtype)[:n]
+
+    def free(self):
+        if self.ptr:
+            load_library().kq_host_free(self.ptr)
+            self.ptr = None
 
 
 def device_count():

@@ -678,3 +678,44 @@ def test_operator_thread_beside_the_receiver_thread(gpu):
         ch.set_filter(*args)
         np.testing.assert_allclose(bank.response(c), ch.response(), rtol=0, atol=2e-9)
     bank.close()
+
+
+def test_streaming_through_the_library_s_own_pinned_buffers(gpu):
+    """kq_host_alloc / kq_host_free: the pinned buffers of the streaming entry points from the library itself (a host that
+    links nothing of HIP).  One call through kq_bank_push_iq_async / kq_bank_pull_pcm_planes_async with such buffers against the
+    same call through the synchronous entry points."""
+    g = dict(samprate=192000, L=512, M=513, D=4)
+    fs, L = g["samprate"], g["L"]
+    olen = L // g["D"]
+    plan = _mixed_plan(fs, 9)
+    C, nb = len(plan), 3
+    iq = wl.make_iq(fs, nb * L, seed=12, emitters=range(24, 40))
+    hin = kq.HostBuffer(nb * L * 8)
+    hpcm = kq.HostBuffer(C * nb * 2 * olen * 2)
+    hmask = kq.HostBuffer(C * nb * 4)
+    hst = kq.HostBuffer(C * nb * ctypes.sizeof(kq.ChanStatus))
+    hin.array(np.complex64)[:] = iq
+    got = []
+    for streamed in (True, False):
+        bank = kq.Bank(fs, L, g["M"], g["D"], C, nb, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL)
+        bank.add_channels([bank_cfg(p) for p in plan])
+        if streamed:
+            bank.push_iq_async(hin.ptr, nb * L)
+            assert bank.process() == nb
+            bank.pull_pcm_planes_async(hpcm.ptr, hmask.ptr, hst.ptr)
+            bank.pull_wait(0)
+            st = np.frombuffer(hst.array().tobytes(), dtype=STATUS_DTYPE).reshape(C, nb)
+            pcm = hpcm.array(np.int16).reshape(C, nb, 2 * olen).copy()
+            got.append(([[int(st[c, b]["nout"]) for b in range(nb)] for c in range(C)],
+                        [[pcm[c, b, :int(st[c, b]["nout"])].tobytes() for b in range(nb)] for c in range(C)]))
+        else:
+            bank.enable_pcm(True)
+            bank.push_iq(iq)
+            assert bank.process() == nb
+            nout = [[bank.status(c, b)["nout"] for b in range(nb)] for c in range(C)]
+            got.append((nout, [[bank.pcm(c, b)[0].tobytes() for b in range(nb)] for c in range(C)]))
+        bank.close()
+    assert got[0][0] == got[1][0]
+    assert got[0][1] == got[1][1]
+    for h in (hin, hpcm, hmask, hst):
+        h.free()

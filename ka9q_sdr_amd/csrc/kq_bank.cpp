@@ -315,13 +315,16 @@ struct kq_bank {
   bool cache_any = false;
   // Retunes (kq_bank_set_second_lo / _doppler / _shift) leave the steady state intact: the channels touched since the last
   // call are on patch_list, and the next call advances everybody on the device as usual and then overwrites just those
-  // channels' planes from a few records staged by the host (k_patch_planes) -- a receiver that tracks Doppler on thousands
+  // channels' planes from a few records staged by the host (the patch role of k_block_energy_sum) -- a receiver that tracks Doppler on thousands
   // of channels retunes some of them before almost every call, and staging all channels for that cost 55 us and 0.4 ms of
   // host time per call at 32768 channels.  Beyond kMaxPatch channels per call the whole bank is staged as before.
   static constexpr int kMaxPatch = 1024;
   static constexpr size_t kPatchBytes = 72;  // one record: channel index (8 bytes), then the channel's eight plane values
   std::vector<int> patch_list;
   size_t patch_off = 0;                       // of the patch records inside a staging slot
+  size_t bits_off = 0;                        // of the patched-channel bitmap (one bit per channel) behind them: the threads of
+                                              // k_block_energy_sum that advance the planes skip the channels its patch role writes
+  std::vector<unsigned> slot_bit_words[4];    // which words of a slot's bitmap are not zero (cleared when the slot comes round)
   int n_swept = 0, n_fast = 0;                // active channels with a sweep / with one beyond the table path's reach (N = 65536
                                               // and N = 16384: full64k_sweep_limit / full16k_sweep_limit)
   int n_active = 0;
@@ -909,8 +912,14 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
   // them the channels retuned since the last call (their first block is redone on the per-sample path)
   int *ret = reinterpret_cast<int *>(flags + ((b->cfg.max_blocks + 7) & ~7u));
   int nret = 0, npatch = 0;
+  {  // the bitmap of the slot's last use goes back to zero
+    unsigned long long *bits = reinterpret_cast<unsigned long long *>(b->stage_host[slot] + b->bits_off);
+    for (unsigned w : b->slot_bit_words[slot]) bits[w] = 0;
+    b->slot_bit_words[slot].clear();
+  }
   if (steady) {
     unsigned char *rec = b->stage_host[slot] + b->patch_off;
+    unsigned long long *bits = reinterpret_cast<unsigned long long *>(b->stage_host[slot] + b->bits_off);
     for (int c : b->patch_list) {
       if ((size_t)c >= b->chans.size()) continue;  // (removed since, and dropped from the end)
       HostChan const &h = b->chans[c];
@@ -922,6 +931,8 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
       memcpy(rec + 8, v, sizeof v);
       rec += kq_bank::kPatchBytes;
       npatch++;
+      bits[c >> 6] |= 1ull << (c & 63);
+      b->slot_bit_words[slot].push_back((unsigned)(c >> 6));
       if (h.retuned) ret[nret++] = c;
     }
   } else {
@@ -1184,10 +1195,11 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
                                 b->stage_host[slot], b->osc_dev2[pp],
                                 nret ? ret_off + nret * sizeof(int) : 8 * Cmax * sizeof(double) + nblocks,
                                 spectrum ? nullptr : paired, (int)(g.M - 1), steady ? b->osc_dev2[pp ^ 1] : nullptr, (unsigned)C,
-                                (unsigned)Cmax, (double)(n_w - b->planes_n_w), (double)(b->out_abs - b->planes_out_abs));
+                                (unsigned)Cmax, (double)(n_w - b->planes_n_w), (double)(b->out_abs - b->planes_out_abs),
+                                // the channels retuned since the last call: their planes, staged by the host, written by a
+                                // few more workgroups of the same launch (the advancing threads skip those channels)
+                                b->stage_host[slot] + b->patch_off, npatch, b->stage_host[slot] + b->bits_off);
   }
-  if (npatch > 0)  // the channels retuned since the last call: their planes, staged by the host, over the advanced ones
-    kq::launch_patch_planes(b->stream, b->stage_host[slot] + b->patch_off, b->osc_dev2[pp], npatch, (unsigned)Cmax);
   LAUNCH_CHECK("IF power");
   if (b->timing) {
     HIP_TRY(hipEventRecord(b->stage_t0[slot], b->stream));
@@ -1616,13 +1628,18 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     rc = -1;
   }
   b->stage_bytes = 8 * C * sizeof(double) + ((B + 7) & ~(size_t)7) + ((C * sizeof(int) + 7) & ~(size_t)7);  // copied in 8-byte words
-  b->patch_off = b->stage_bytes;               // the retune patches' records (never copied as a whole: k_patch_planes reads them)
+  b->patch_off = b->stage_bytes;               // the retune patches' records (never copied as a whole: the patch role of k_block_energy_sum reads them)
   b->stage_bytes += (size_t)kq_bank::kMaxPatch * kq_bank::kPatchBytes;
+  b->bits_off = b->stage_bytes;
+  b->stage_bytes += ((C + 63) / 64) * sizeof(unsigned long long);
+  static_assert(kq_bank::kSlots == 4, "slot_bit_words");
   for (int k = 0; k < kq_bank::kSlots && !rc; k++) {
     if (hipHostMalloc((void **)&b->stage_host[k], b->stage_bytes, hipHostMallocDefault) != hipSuccess ||
         hipEventCreate(&b->stage_ev[k]) != hipSuccess || hipEventCreate(&b->stage_t0[k]) != hipSuccess) {
       set_err("pinned staging allocation failed");
       rc = -1;
+    } else {
+      memset(b->stage_host[k] + b->bits_off, 0, b->stage_bytes - b->bits_off);
     }
   }
   rc |= dev_alloc(&b->chd.fm_state, C);

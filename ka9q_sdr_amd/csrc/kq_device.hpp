@@ -129,11 +129,11 @@ constexpr int kEnergySplitMax = 16;
 int block_energy_split(int L);
 void launch_block_energy_sum(hipStream_t s, const float2 *newsamples, int L, int nblocks, float *sums, const void *params_host,
                              void *params_dev, size_t params_bytes, float2 *paired, int hist, const double *prev_planes = nullptr,
-                             unsigned nchan = 0, unsigned cmax = 0, double adv = 0, double adv_out = 0);
+                             unsigned nchan = 0, unsigned cmax = 0, double adv = 0, double adv_out = 0, const void *patch_records_host = nullptr,
+                             int npatch = 0, const void *patch_bits_host = nullptr);
 // control-plane writes of a call, gathered by the host in pinned memory (kq_bank.cpp CtlQueue): nrec records {dst, nbytes,
 // payload offset | fill value}; one workgroup per record copies or fills 4-byte words
 void launch_ctl_apply(hipStream_t s, const void *queue_host, int nrec);
-void launch_patch_planes(hipStream_t s, const void *records_host, void *planes_dev, int npatch, unsigned cmax);
 void launch_block_energy_iir(hipStream_t s, const float *sums, int L, int nblocks, const unsigned char *update, float *energy_state,
                              float *if_power);
 void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,

@@ -88,9 +88,25 @@ __global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *_
                                    const unsigned long long *__restrict__ params_host,
                                    unsigned long long *__restrict__ params_dev, unsigned nwords, int copy_wgs,
                                    float2 *__restrict__ paired, int hist, const double *__restrict__ prev, unsigned nchan,
-                                   unsigned cmax, double adv, double adv_out) {
+                                   unsigned cmax, double adv, double adv_out, int hist_wgs,
+                                   const unsigned long long *__restrict__ patch_rec, int npatch,
+                                   const unsigned long long *__restrict__ patch_bits) {
   int const pcol = 2 * (threadIdx.x & 511) + (threadIdx.x >> 9);  // place of sample (row parity, column) within its pair of rows
   int const nsum = nblocks * split;
+  if ((int)blockIdx.x >= nsum + copy_wgs + hist_wgs) {
+    // the channels retuned since the last call (kq_bank.cpp: patch_list): their planes as the host staged them, records of
+    // (channel index, eight values) in pinned memory.  The advancing threads below leave exactly these channels alone
+    // (patch_bits: one bit per channel, staged with the records), so the two never write the same place.
+    int const j = ((int)blockIdx.x - nsum - copy_wgs - hist_wgs) * (int)blockDim.x + (int)threadIdx.x;
+    if (j >= npatch) return;
+    const unsigned long long *r = patch_rec + (size_t)j * 9;
+    unsigned const c = (unsigned)r[0];
+    if (c >= cmax) return;
+    double *planes = reinterpret_cast<double *>(params_dev);
+#pragma unroll
+    for (int k = 0; k < 8; k++) planes[(size_t)k * cmax + c] = __longlong_as_double((long long)r[1 + k]);
+    return;
+  }
   if ((int)blockIdx.x >= nsum + copy_wgs) {  // history: copy only, 8192 samples per workgroup
     int const base = ((int)blockIdx.x - nsum - copy_wgs) * 8192;
     for (int j = 0; j < 8 && base + 1024 * j < hist; j++) paired[base + 1024 * j + pcol] = (x - hist)[base + 1024 * j + threadIdx.x];
@@ -103,6 +119,7 @@ __global__ void k_block_energy_sum(const float2 *__restrict__ x, int L, float *_
       return;
     }
     if (i < nchan) {
+      if (patch_bits && ((patch_bits[i >> 6] >> (i & 63)) & 1ull)) return;  // a patched channel: the patch role writes its planes
       double *out = reinterpret_cast<double *>(params_dev);
       double const ph = prev[i], f = prev[cmax + i], r = prev[2 * (size_t)cmax + i];
       double const sp = prev[3 * (size_t)cmax + i], sf = prev[4 * (size_t)cmax + i];
@@ -163,16 +180,21 @@ int block_energy_split(int L) {
 
 void launch_block_energy_sum(hipStream_t s, const float2 *newsamples, int L, int nblocks, float *sums, const void *params_host,
                              void *params_dev, size_t params_bytes, float2 *paired, int hist, const double *prev_planes,
-                             unsigned nchan, unsigned cmax, double adv, double adv_out) {
+                             unsigned nchan, unsigned cmax, double adv, double adv_out, const void *patch_records_host, int npatch,
+                             const void *patch_bits_host) {
   unsigned const nwords = (unsigned)((params_bytes + 7) / 8);
   // steady state: one thread per channel advances its planes, then the flag words behind the planes are copied
   unsigned const work = prev_planes ? nchan + (nwords - 8 * cmax) : nwords;
   int const copy_wgs = (int)((work + 1023) / 1024);
   int const hist_wgs = paired ? (hist + 8191) / 8192 : 0;
   int const split = block_energy_split(L);
-  hipLaunchKernelGGL(k_block_energy_sum, dim3(nblocks * split + copy_wgs + hist_wgs), dim3(1024), 0, s, newsamples, L, sums, nblocks,
-                     split, static_cast<const unsigned long long *>(params_host), static_cast<unsigned long long *>(params_dev),
-                     nwords, copy_wgs, paired, hist, prev_planes, nchan, cmax, adv, adv_out);
+  if (!prev_planes || !patch_records_host || !patch_bits_host) npatch = 0;  // (patches exist in the steady state only)
+  int const patch_wgs = (npatch + 1023) / 1024;
+  hipLaunchKernelGGL(k_block_energy_sum, dim3(nblocks * split + copy_wgs + hist_wgs + patch_wgs), dim3(1024), 0, s, newsamples, L, sums,
+                     nblocks, split, static_cast<const unsigned long long *>(params_host),
+                     static_cast<unsigned long long *>(params_dev), nwords, copy_wgs, paired, hist, prev_planes, nchan, cmax, adv,
+                     adv_out, hist_wgs, static_cast<const unsigned long long *>(patch_records_host), npatch,
+                     npatch ? static_cast<const unsigned long long *>(patch_bits_host) : nullptr);
 }
 
 // Control-plane writes (kq_bank.cpp CtlQueue): what kq_bank_set_filter / add_channel / set_mode ... change on the device,
@@ -185,24 +207,6 @@ void launch_block_energy_sum(hipStream_t s, const float2 *newsamples, int L, int
 __global__ void __launch_bounds__(256) k_ctl_apply(const unsigned char *__restrict__ q) { ctl_apply_record(q, blockIdx.x, threadIdx.x, 256); }
 void launch_ctl_apply(hipStream_t s, const void *queue_host, int nrec) {
   if (nrec > 0) hipLaunchKernelGGL(k_ctl_apply, dim3(nrec), dim3(256), 0, s, static_cast<const unsigned char *>(queue_host));
-}
-
-// The planes of the channels retuned since the last call (kq_bank.cpp: patch_list), staged by the host as records of
-// (channel index, eight values) in pinned memory, written over what k_block_energy_sum has just advanced.  One thread per
-// record; launched only for a call that follows a retune.
-__global__ void k_patch_planes(const unsigned long long *__restrict__ rec_host, double *__restrict__ planes, int npatch,
-                               unsigned cmax) {
-  int const j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= npatch) return;
-  const unsigned long long *r = rec_host + (size_t)j * 9;
-  unsigned const c = (unsigned)r[0];
-  if (c >= cmax) return;
-#pragma unroll
-  for (int k = 0; k < 8; k++) planes[(size_t)k * cmax + c] = __longlong_as_double((long long)r[1 + k]);
-}
-void launch_patch_planes(hipStream_t s, const void *records_host, void *planes_dev, int npatch, unsigned cmax) {
-  hipLaunchKernelGGL(k_patch_planes, dim3((npatch + 255) / 256), dim3(256), 0, s, static_cast<const unsigned long long *>(records_host),
-                     static_cast<double *>(planes_dev), npatch, cmax);
 }
 
 void launch_block_energy_iir(hipStream_t s, const float *sums, int L, int nblocks, const unsigned char *update, float *energy_state,

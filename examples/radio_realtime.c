@@ -108,6 +108,7 @@ int main(int argc, char **argv){
   /* ---- the receiver's loop (the same batch over and over: the stream is synthetic, the work is not) */
   double const signal_s = (double)B * L / SAMPRATE;
   long calls = 0, warm = 50, ops = 0;
+  double op_worst = 0, op_total = 0;    /* host time inside the operator's calls */
   int away = -1;                        /* the channel that has been dropped and not yet come back */
   kq_host_timing ht;
   int rc = 0;
@@ -121,6 +122,7 @@ int main(int argc, char **argv){
     }
     int const j = (int)(k % 3);
     if(operator_on && C > 64){
+      double const op_t0 = now_s();
       unsigned const c = 64u + (unsigned)((k * 7919) % (C - 64));  /* (channels 0..63 are left alone: the check below reads channel 5) */
       float const w = 6000.f + 125.f * (float)(k % 17);
       if((int)c != away){
@@ -148,6 +150,10 @@ int main(int argc, char **argv){
         fprintf(stderr, "operator: %s\n", kq_last_error());
         break;
       }
+      double const op_dt = now_s() - op_t0;   /* this call's two or three operations together */
+      op_total += op_dt;
+      if(k >= warm && op_dt > op_worst)
+        op_worst = op_dt;
     }
     if(kq_bank_process(bank) != (int)B || kq_bank_push_iq_async(bank, in, nin, KQ_IQ_CF32) != 0)
       rc = 1;
@@ -172,7 +178,8 @@ int main(int argc, char **argv){
   printf("%u channels x %u blocks per call (%.3f ms of signal): %.4f ms per call over %ld calls = %.3f x real time\n", C, B,
          signal_s * 1e3, per_call * 1e3, calls, signal_s / per_call);
   if(operator_on)
-    printf("operator: %ld changes (filter, channel dropped / back, retune) = %.0f per second beside the stream\n", ops, ops / wall);
+    printf("operator: %ld changes (filter, channel dropped / back, retune) = %.0f per second beside the stream; host time inside them "
+           "%.4f ms per call, worst %.3f ms\n", ops, ops / wall, 1e3 * op_total / (double)(calls + warm), 1e3 * op_worst);
   printf("host inside kq_bank_process: %.4f ms per call (per-channel staging %.4f); delivered %s + status: %.2f GB/s\n",
          ht.call_ms / (double)ht.calls, ht.stage_ms / (double)ht.calls, pcm ? "int16 PCM" : "float audio", d2h / per_call / 1e9);
 

@@ -134,7 +134,7 @@ const char *kq_version(void);
 /* The structs of this header carry no size fields; the library counts their revisions instead.  A host built against
  * this header checks kq_abi_version() == KQ_ABI_VERSION once at start-up: a mismatch means a struct (kq_bank_config,
  * kq_fanout_info ...) has gained a field since the host was compiled. */
-#define KQ_ABI_VERSION 5
+#define KQ_ABI_VERSION 6
 int kq_abi_version(void);
 /* Number of visible HIP devices, or -1 when the HIP runtime cannot be initialised */
 int kq_device_count(void);
@@ -356,8 +356,14 @@ int kq_bank_get_timing(kq_bank *bank, kq_timing *t, int reset);
 typedef struct kq_host_timing {
   double call_ms;          /* wall time inside the process calls, everything included */
   double stage_ms;         /* of that: evaluating and staging the per-channel oscillator parameters of the call */
-  double slot_wait_ms;     /* of that: blocked because the device was four calls behind (back-pressure, not work) */
+  double slot_wait_ms;     /* of that: blocked because the device was four calls behind (back-pressure, not work); taken
+                              with the handle's lock let go, so control-plane calls from another thread run meanwhile */
   uint64_t calls;
+  /* The handle's lock between the receiver thread (the process calls) and whoever drives the control plane (set_* / add /
+   * remove from another thread; main.c's UI and status threads beside proc_samples): */
+  double lock_wait_ms;     /* total the process calls waited to get the lock (not part of call_ms) */
+  double lock_wait_max_ms; /* the worst single wait: what a control-plane call cost the stream at most */
+  double ctl_hold_max_ms;  /* the longest any OTHER entry point held the lock (device waits with the lock let go excluded) */
 } kq_host_timing;
 int kq_bank_get_host_timing(kq_bank *bank, kq_host_timing *t, int reset);
 /* Which forward path the bank resolved to (enum kq_fwd_mode, never AUTO) */

@@ -17,7 +17,7 @@ _lib = None
 KQ_LINEAR_DEMOD, KQ_AM_DEMOD, KQ_FM_DEMOD = 0, 1, 2
 KQ_IQ_CF32, KQ_IQ_S16, KQ_IQ_S8 = 0, 1, 2
 KQ_FWD_AUTO, KQ_FWD_FULL, KQ_FWD_PRUNED = 0, 1, 2
-KQ_ABI_VERSION = 5        # include/ka9q_hip.h
+KQ_ABI_VERSION = 6        # include/ka9q_hip.h
 
 
 class KqError(RuntimeError):
@@ -70,7 +70,8 @@ class RtpCounters(C.Structure):
 
 class HostTiming(C.Structure):
     """kq_host_timing: the host's own time inside the process calls"""
-    _fields_ = [("call_ms", C.c_double), ("stage_ms", C.c_double), ("slot_wait_ms", C.c_double), ("calls", C.c_uint64)]
+    _fields_ = [("call_ms", C.c_double), ("stage_ms", C.c_double), ("slot_wait_ms", C.c_double), ("calls", C.c_uint64),
+                ("lock_wait_ms", C.c_double), ("lock_wait_max_ms", C.c_double), ("ctl_hold_max_ms", C.c_double)]
 
 
 class Timing(C.Structure):

@@ -362,24 +362,48 @@ int ilog2(unsigned v) {
 
 int sync_all(kq_bank *b);
 
-// every entry point taking a handle: the handle's device made current, the handle's lock held
+// every entry point taking a handle: the handle's device made current, the handle's lock held.
+// kq_host_timing's lock figures are kept here: a `receiver` scope (the process calls) records how long it WAITED for the
+// lock, every other scope how long it HELD it (device waits taken with the lock let go -- Unlocked -- not counted): the
+// worst of the second is the longest the receiver thread can have been kept out by the control plane.
 struct BankScope {
+  using clock = std::chrono::steady_clock;
   kq::DeviceScope dev;
   std::unique_lock<std::recursive_mutex> lk;
-  explicit BankScope(kq_bank *b) : dev(b ? b->cfg.device : -1) {
-    if (b) lk = std::unique_lock<std::recursive_mutex>(b->mu);
+  kq_bank *bank = nullptr;
+  bool receiver = false;
+  clock::time_point t_acq;
+  double unlocked_ms = 0;
+  explicit BankScope(kq_bank *b, bool receiver_ = false) : dev(b ? b->cfg.device : -1), bank(b), receiver(receiver_) {
+    if (!b) return;
+    auto const t0 = clock::now();
+    lk = std::unique_lock<std::recursive_mutex>(b->mu);
+    t_acq = clock::now();
+    if (receiver) {
+      double const w = std::chrono::duration<double, std::milli>(t_acq - t0).count();
+      b->host_acc.lock_wait_ms += w;
+      if (w > b->host_acc.lock_wait_max_ms) b->host_acc.lock_wait_max_ms = w;
+    }
   }
   explicit BankScope(const kq_bank *b) : BankScope(const_cast<kq_bank *>(b)) {}
+  ~BankScope() {
+    if (!bank || receiver || !lk.owns_lock()) return;
+    double const h = std::chrono::duration<double, std::milli>(clock::now() - t_acq).count() - unlocked_ms;
+    if (h > bank->host_acc.ctl_hold_max_ms) bank->host_acc.ctl_hold_max_ms = h;
+  }
 };
 // a wait for the device inside an entry point: the lock is let go for its duration (one level: an entry point called from
 // another keeps the outer one's)
 struct Unlocked {
+  BankScope &scope;
   std::unique_lock<std::recursive_mutex> &lk;
-  explicit Unlocked(BankScope &s) : lk(s.lk) {
+  BankScope::clock::time_point t0;
+  explicit Unlocked(BankScope &s) : scope(s), lk(s.lk), t0(BankScope::clock::now()) {
     if (lk.owns_lock()) lk.unlock();
   }
   ~Unlocked() {
     if (lk.mutex() && !lk.owns_lock()) lk.lock();
+    scope.unlocked_ms += std::chrono::duration<double, std::milli>(BankScope::clock::now() - t0).count();
   }
 };
 
@@ -491,6 +515,19 @@ void ctl_cancel(kq_bank *b, int side, void *dst) {
   (reinterpret_cast<CtlRecHost *>(q.buf[q.cur]) + it->second)->nbytes = 0;
   q.at.erase(it);
 }
+// withdraw every queued write that starts inside [dst, dst + bytes): a bulk rewrite of that range follows, and the records
+// of one launch are applied concurrently (a 4-byte list entry queued earlier must not land beside the chunk covering it)
+void ctl_cancel_range(kq_bank *b, int side, const void *dst, size_t bytes) {
+  kq_bank::CtlQueue &q = b->ctl[side];
+  unsigned long long const lo = (unsigned long long)(uintptr_t)dst, hi = lo + bytes;
+  for (auto it = q.at.begin(); it != q.at.end();) {
+    if (it->first >= lo && it->first < hi) {
+      (reinterpret_cast<CtlRecHost *>(q.buf[q.cur]) + it->second)->nbytes = 0;
+      it = q.at.erase(it);
+    } else
+      ++it;
+  }
+}
 
 // the design jobs gathered since the last call: one launch on the main stream
 // `ctl_queue` != null: that many write records of the filter side's queue ride in the same launch (*took_records set)
@@ -586,7 +623,10 @@ void build_n0mask(const kq_bank *b, float low, float high, std::vector<unsigned 
     }
 }
 
-// the mask set for these edges: an existing one, or a free slot filled now (*fresh).  Takes a reference.
+// the mask set for these edges: an existing one, or a free slot filled now (*fresh).  Takes a reference.  -1: no slot
+// left (cannot happen while every reference belongs to a channel and a channel gives its old slot back BEFORE it asks
+// for a new one -- upload_n0mask; the planes hold exactly max_channels sets, so a slot past them is refused, never
+// written)
 int acquire_n0slot(kq_bank *b, float low, float high, bool *fresh) {
   auto const key = std::make_pair(low, high);
   auto it = b->n0slot_of.find(key);
@@ -601,7 +641,11 @@ int acquire_n0slot(kq_bank *b, float low, float high, bool *fresh) {
         slot = (int)k;
         break;
       }
-    if (slot < 0) {  // (never more slots than channels: every reference belongs to a channel)
+    if (slot < 0) {
+      if (b->n0slot_refs.size() >= (size_t)b->cfg.max_channels) {
+        set_err("compute_n0 mask slots exhausted (%zu sets for %u channels)", b->n0slot_refs.size(), b->cfg.max_channels);
+        return -1;
+      }
       slot = (int)b->n0slot_refs.size();
       b->n0slot_refs.push_back(0);
       b->n0slot_key.push_back(key);
@@ -622,10 +666,19 @@ int upload_n0mask(kq_bank *b, int c) {
   int const nsub = b->use64k ? 4 : 1;
   bool fresh = false;
   int const old = b->chans[c].n0slot;
-  int const slot = acquire_n0slot(b, b->chans[c].cfg.low, b->chans[c].cfg.high, &fresh);
-  release_n0slot(b, old);  // (after the acquire: unchanged edges keep their slot)
+  auto const key = std::make_pair(b->chans[c].cfg.low, b->chans[c].cfg.high);
+  if (old >= 0 && (size_t)old < b->n0slot_refs.size() && b->n0slot_refs[old] > 0 && b->n0slot_key[old] == key) {
+    // unchanged edges keep their slot (and its reference)
+    return ctl_put(b, CTL_FILTER, b->chd.n0slot + c, &old, sizeof(int)) ? -1 : 0;
+  }
+  // the old set goes back FIRST: in a full bank of distinct edges it is the only free one (asking first ran
+  // one set past the planes).  Reusing it in place is safe: the mask write below is queued behind the filter passes in
+  // flight, and no other channel refers to a slot whose count reached zero
+  release_n0slot(b, old);
+  b->chans[c].n0slot = -1;
+  int const slot = acquire_n0slot(b, key.first, key.second, &fresh);
+  if (slot < 0) return -1;
   b->chans[c].n0slot = slot;
-  // filter side: applied behind whatever filter pass in flight still reads a slot its last user has just given back
   std::vector<unsigned long long> m;
   std::vector<unsigned> meta;
   if (fresh) {
@@ -975,6 +1028,13 @@ int upload_lists(kq_bank *b) {
   // the filter launch's list on the filter side; the demodulators' lists, and the PCM stage's copy of the active list,
   // on the demodulator side (the last call's demodulators may still be walking the old ones)
   size_t const n = b->list_active_host.size() * sizeof(int);
+  {  // single entries queued while the lists were current (lists_add / lists_remove) give way to the rebuild
+    size_t const whole = (size_t)b->cfg.max_channels * sizeof(int);
+    ctl_cancel_range(b, CTL_FILTER, b->list_active_dev, whole);
+    ctl_cancel_range(b, CTL_DEMOD, b->list_active_ds_dev, whole);
+    if (b->list_pll_dev) ctl_cancel_range(b, CTL_DEMOD, b->list_pll_dev, kq_bank::kMaxPll * sizeof(int));
+    for (int k = 0; k < 3; k++) ctl_cancel_range(b, CTL_DEMOD, b->list_dev[k], whole);
+  }
   if (ctl_put(b, CTL_FILTER, b->list_active_dev, b->list_active_host.data(), n)) return -1;
   if (ctl_put(b, CTL_DEMOD, b->list_active_ds_dev, b->list_active_host.data(), n)) return -1;
   if (!b->list_pll_host.empty())
@@ -1062,6 +1122,10 @@ int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigne
                const float2 *spectrum = nullptr) {
   auto const t0 = std::chrono::steady_clock::now();
   int const rc = run_blocks_timed(b, window, nblocks, update_host, spectrum);
+  // A call that failed may have left the lists' bulk records queued and unapplied; a 4-byte record of lists_add /
+  // lists_remove beside them in one launch would race with the chunk that covers it.  With the lists marked
+  // stale those entry points queue nothing, and the next call's rebuild rewrites the queued chunks in place.
+  if (rc < 0) b->lists_dirty = true;
   b->host_acc.call_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   b->host_acc.calls++;
   return rc;
@@ -1503,6 +1567,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
 
   kq_bank *b = new kq_bank();
   b->cfg = *cfg;
+  b->chans.reserve(cfg->max_channels);  // the elements never move (kq_bank_rtp_from_planes keeps an address past the lock)
   kq::Geom &g = b->g;
   g.N = (int)N;
   g.L = (int)cfg->L;
@@ -1957,10 +2022,13 @@ int kq_bank_add_channels(kq_bank *b, const kq_channel_config *cfgs, unsigned n, 
     return -1;
   }
   if (n == 0) return 0;
-  bool holes = false, any_pll = false;
+  bool holes = false, any_pll = false, any_nan = false;
   for (HostChan const &h : b->chans) holes = holes || !h.active;
   for (unsigned i = 0; i < n; i++) any_pll = any_pll || is_pll(cfgs[i]);
-  if (holes || any_pll || n < 4) {  // slot reuse and carrier-loop slots: one by one; all or nothing
+  // a NaN beta is not a key the ordered maps below can hold (it breaks their strict weak ordering): such a batch takes
+  // the one-by-one path, whose design takes the value as the reference's does (queue_design)
+  for (unsigned i = 0; i < n; i++) any_nan = any_nan || std::isnan(cfgs[i].kaiser_beta);
+  if (holes || any_pll || any_nan || n < 4) {  // slot reuse and carrier-loop slots: one by one; all or nothing
     std::vector<int> got;
     for (unsigned i = 0; i < n; i++) {
       int const c = kq_bank_add_channel(b, &cfgs[i]);
@@ -2134,6 +2202,7 @@ int kq_bank_add_channels(kq_bank *b, const kq_channel_config *cfgs, unsigned n, 
         bool fresh = false;
         int const slot = acquire_n0slot(b, cfgs[i].low, cfgs[i].high, &fresh);
         hs[i].n0slot = slots[i] = slot;
+        if (slot < 0) return -1;
         taken = i + 1;
         if (fresh) {
           std::vector<unsigned long long> m;
@@ -2649,10 +2718,11 @@ int kq_bank_pull_wait(kq_bank *b, unsigned lag) {
 int kq_bank_host_io_wait(kq_bank *b) {
   BankScope dev_scope_(b);
   if (!b) return -1;
+  hipStream_t const cin = b->copy_in, cout = b->copy_out;  // (read under the lock: host_io_setup may be creating them)
   {
     Unlocked u(dev_scope_);
-    if (b->copy_in) HIP_TRY(hipStreamSynchronize(b->copy_in));
-    if (b->copy_out) HIP_TRY(hipStreamSynchronize(b->copy_out));
+    if (cin) HIP_TRY(hipStreamSynchronize(cin));
+    if (cout) HIP_TRY(hipStreamSynchronize(cout));
   }
   return report_lost_sibling(b);  // the planes just landed come from kernels that have finished
 }
@@ -2821,12 +2891,30 @@ unsigned kq_bank_blocks_ready(const kq_bank *b) {
   return (unsigned)(b->pending / b->g.L);
 }
 
+// The back-pressure wait of a process call (the staging slot it is about to fill was last read four calls ago), taken
+// BEFORE the call looks at any state and with the handle's lock let go: the operator's thread is not kept out for the
+// length of a device wait (tools/soak_realtime.py showed 10 ms set_filter calls that were this wait).  Only the
+// receiver thread advances stage_next, so the slot is still the next one when the lock is back.
+int slot_prewait(BankScope &scope, kq_bank *b) {
+  hipEvent_t const ev = b->stage_ev[b->stage_next];
+  auto const t0 = std::chrono::steady_clock::now();
+  {
+    Unlocked u(scope);
+    HIP_TRY(hipEventSynchronize(ev));
+  }
+  double const w = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  b->host_acc.slot_wait_ms += w;
+  b->host_acc.call_ms += w;
+  return 0;
+}
+
 int kq_bank_process(kq_bank *b) {
-  BankScope dev_scope_(b);
+  BankScope dev_scope_(b, true);
   if (!b) {
     set_err("NULL bank");
     return -1;
   }
+  if (slot_prewait(dev_scope_, b)) return -1;
   kq::Geom const &g = b->g;
   if (acc_flush(b)) return -1;  // what kq_bank_push_rtp has gathered goes into the ring now
   unsigned nb = (unsigned)(b->pending / g.L);
@@ -2848,7 +2936,7 @@ int kq_bank_process(kq_bank *b) {
 }
 
 int kq_bank_process_resident(kq_bank *b, const void *iq_dev, unsigned nblocks) {
-  BankScope dev_scope_(b);
+  BankScope dev_scope_(b, true);
   if (!b || !iq_dev) {
     set_err("NULL argument");
     return -1;
@@ -2857,12 +2945,13 @@ int kq_bank_process_resident(kq_bank *b, const void *iq_dev, unsigned nblocks) {
     set_err("nblocks %u out of range 1..%u", nblocks, b->cfg.max_blocks);
     return -1;
   }
+  if (slot_prewait(dev_scope_, b)) return -1;
   std::vector<unsigned char> upd(nblocks, 1);
   return run_blocks(b, (const float2 *)iq_dev, nblocks, upd.data());
 }
 
 int kq_bank_process_spectrum(kq_bank *b, const void *spectrum_dev, unsigned nblocks) {
-  BankScope dev_scope_(b);
+  BankScope dev_scope_(b, true);
   if (!b || !spectrum_dev) {
     set_err("NULL argument");
     return -1;
@@ -2900,9 +2989,11 @@ int kq_bank_sync(kq_bank *b) {
   if (!b) return -1;
   // "everything issued so far" includes what the control plane has queued for the next call: applied now
   if (ctl_flush_now(b)) return -1;
+  hipStream_t const st[4] = {b->stream, b->stream2, b->copy_in, b->copy_out};  // (read under the lock)
   {
     Unlocked u(dev_scope_);
-    if (sync_all(b)) return -1;
+    for (hipStream_t x : st)
+      if (x) HIP_TRY(hipStreamSynchronize(x));
   }
   return report_lost_sibling(b);
 }
@@ -3065,19 +3156,30 @@ int kq_bank_rtp_from_planes(kq_bank *b, int ch, unsigned blk, const int16_t *pcm
     set_err("NULL bank");
     return -1;
   }
-  std::lock_guard<std::recursive_mutex> lk(b->mu);  // (the channel's RTP state; no device scope: nothing here touches the device)
-  if (!valid_ch(b, ch) || !dst || !pcm_plane || !status_plane || blk >= (unsigned)b->g.max_blocks) {
-    set_err("bad channel / block or NULL plane");
-    return -1;
+  // Host work only, and meant to be spread over the host's threads by channel range: the bank's lock is held just long
+  // enough to check the channel and take the address of its RTP state (b->chans is reserved for max_channels at create:
+  // its elements never move).  One thread per channel at a time -- the caller's partition -- owns that state; a channel
+  // removed or restarted while its packetiser runs is the caller's race, as two threads in audio.c:82 would be.
+  kq_out_rtp_state *o = nullptr;
+  int olen = 0, max_blocks = 0;
+  {
+    std::lock_guard<std::recursive_mutex> lk(b->mu);
+    if (!valid_ch(b, ch) || !dst || !pcm_plane || !status_plane || blk >= (unsigned)b->g.max_blocks) {
+      set_err("bad channel / block or NULL plane");
+      return -1;
+    }
+    o = &b->chans[ch].out_rtp;
+    olen = b->g.olen;
+    max_blocks = b->g.max_blocks;
   }
-  size_t const cb = (size_t)ch * b->g.max_blocks + blk;
+  size_t const cb = (size_t)ch * max_blocks + blk;
   int const nout = status_plane[cb].nout;
-  if (nout < 0 || nout > 2 * b->g.olen) {
+  if (nout < 0 || nout > 2 * olen) {
     set_err("status plane: nout %d out of range", nout);
     return -1;
   }
-  return packetize_block(b->chans[ch].out_rtp, reinterpret_cast<const unsigned char *>(pcm_plane + cb * 2 * (size_t)b->g.olen),
-                         (size_t)nout, nout == 2 * b->g.olen, dst, cap, used);
+  return packetize_block(*o, reinterpret_cast<const unsigned char *>(pcm_plane + cb * 2 * (size_t)olen), (size_t)nout,
+                         nout == 2 * olen, dst, cap, used);
 }
 
 int kq_bank_pull_filter_output(kq_bank *b, int ch, unsigned blk, float *dst, size_t cap) {

@@ -203,10 +203,17 @@ kq_fanout *kq_fanout_create(int device, int rank, int world, int root, const voi
         // a flag that could not be allocated or set counts as "my set-up failed", but the collective is still entered
         // whenever there is memory to run it on
         bool set = flag && hipMemsetD32Async((hipDeviceptr_t)flag, ok ? 1 : 0, 1, f->side) == hipSuccess;
-        if (flag && !set) set = hipMemsetD32Async((hipDeviceptr_t)flag, 0, 1, f->side) == hipSuccess;
+        if (flag && !set) {  // the word must hold a KNOWN value before the reduction reads it: second try from the host
+          static const int zero = 0;
+          set = hipMemcpyAsync(flag, &zero, sizeof(int), hipMemcpyHostToDevice, f->side) == hipSuccess;
+          if (ok) kq_internal_set_error("kq_fanout_create: the agreement word could not be set on rank %d", rank);
+          ok = false;  // (either way this rank's vote is "failed")
+        }
+        // with the word still undefined the collective is entered all the same (the peers are blocked in it) and its
+        // result is not believed: min() over garbage could read as a yes
         bool const agreed = flag && r.AllReduce(flag, flag, 1, ncclInt32, ncclMin, f->comm, f->side) == ncclSuccess &&
                             hipMemcpyAsync(&all, flag, sizeof(int), hipMemcpyDeviceToHost, f->side) == hipSuccess &&
-                            hipStreamSynchronize(f->side) == hipSuccess;
+                            hipStreamSynchronize(f->side) == hipSuccess && set;
         if (!agreed) {
           if (ok) kq_internal_set_error("kq_fanout_create: the ranks' agreement (ncclAllReduce) failed on rank %d", rank);
           ok = false;

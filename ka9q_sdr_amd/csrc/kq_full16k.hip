@@ -1067,7 +1067,11 @@ void launch_filter_full64k(hipStream_t s, const Geom &g, const ChanDev &ch, cons
                            const int *chan_list, bool plain, bool swept, const float2 *window_paired, const Big64 &big) {
   size_t const lds_bytes = (size_t)kXchElems * sizeof(float2);
   const float2 *tab = twiddle_tables();
-  if (!tab) return;  // allocation failure: the caller's launch check reports it
+  if (!tab) {  // allocation failure: the caller's launch check reports it; the side job this launch was to carry still runs
+    if (big.iir.sums)
+      launch_block_energy_iir(s, big.iir.sums, big.iir.L, big.iir.nblocks, big.iir.update, big.iir.state, big.iir.if_power);
+    return;
+  }
   bool const n0 = compute_n0 && ch.n0lane && ch.n0meta;
   bool const dump = spec_dump != nullptr;
   bool const paired = plain && window_paired != nullptr;

@@ -465,3 +465,60 @@ def test_if_power_recurrence_in_the_filter_launch_is_the_stand_alone_one(gpu, co
     assert np.all(np.isfinite(a)) and np.all(a > 0)
     assert a.tobytes() == b.tobytes()
     assert np.all(a[:, 0, :] == a[:, 1, :])          # one front end: every channel reports the same IF power
+
+
+@pytest.mark.parametrize("L,D,C", [(8192, 256, 1), (8192, 256, 2), (8192, 256, 9), (32768, 512, 3)])
+def test_full_bank_of_distinct_edges_changes_every_filter(gpu, L, D, C):
+    """compute_n0's passband masks live in max_channels slot sets, one per distinct pair of edges (kq_bank.cpp
+    acquire_n0slot).  A FULL bank in which every channel has its own edges has no free set: a filter change must give the
+    channel's old set back before it asks for a new one (asking first wrote one set past the planes -- 2 KiB,
+    8 KiB at N = 65536, beyond n0lane and 4 bytes beyond n0meta).  Every channel's filter changes twice between calls, on
+    a bank of exactly C channels and on a twin with room to spare: status (n0 among the words) and audio bit for bit,
+    and n0 against the oracle's compute_n0 (radio.c:383-425) after each change."""
+    from common import oracle_cfg
+    fs = 10_000_000 if L == 8192 else 20_000_000
+    g = dict(samprate=fs, L=L, M=L + 1, D=D)
+    nb, ncalls = 2, 3
+    base = wl.channel_plan("cfg3" if L == 8192 else "cfg5", max(C, 4))[:C]
+    plan = [dict(p) for p in base]
+    for c, p in enumerate(plan):                    # all edges distinct from the start
+        p["low"], p["high"] = p["low"] - 10.0 * c, p["high"] + 7.0 * c
+    iq = wl.make_iq(fs, ncalls * nb * L, seed=21)
+
+    def edges(c, k):
+        p = plan[c]
+        return p["low"] * (0.9 - 0.05 * k) - c, p["high"] * (0.8 + 0.07 * k) + 3 * c, 3.0
+
+    got = []
+    for room in (C, C + 55):
+        bank = kq.Bank(fs, L, g["M"], D, room, nb, compute_n0=True, fwd_mode=kq.KQ_FWD_FULL, pl_tone=False)
+        for p in plan:
+            bank.add_channel(bank_cfg(p))
+        rec = []
+        for k in range(ncalls):
+            if k:
+                for c in range(C):
+                    bank.set_filter(c, *edges(c, k))
+                for c in range(0, C, 2):            # and once more for some: same edges again keep their set
+                    bank.set_filter(c, *edges(c, k))
+            bank.push_iq(iq[k * nb * L:(k + 1) * nb * L])
+            assert bank.process() == nb
+            rec.append(([[bank.status(c, b) for b in range(nb)] for c in range(C)],
+                        [[bank.audio(c, b).copy() for b in range(nb)] for c in range(C)]))
+        bank.close()
+        got.append(rec)
+    for k in range(ncalls):
+        for c in range(C):
+            for b in range(nb):
+                assert got[0][k][0][c][b] == got[1][k][0][c][b], (k, c, b)
+                assert np.array_equal(got[0][k][1][c][b], got[1][k][1][c][b]), (k, c, b)
+    for c in range(C):
+        ch = ko.Channel(oracle_cfg(plan[c], fs, L, g["M"], D, compute_n0=1))
+        for k in range(ncalls):
+            if k:
+                ch.set_filter(*edges(c, k))
+            for b in range(nb):
+                _, st, _, _ = ch.block(iq[(k * nb + b) * L:(k * nb + b + 1) * L])
+                have = got[0][k][0][c][b]["n0"]
+                assert abs(have - st["n0"]) <= 2e-5 * abs(st["n0"]), (c, k, b, have, st["n0"])
+        ch.close()

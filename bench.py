@@ -70,7 +70,8 @@ def parse():
     ap.add_argument("--no-realtime", action="store_true",
                     help="skip the `realtime` object: the largest channel count one GPU carries at 1.0 x real time, measured "
                          "(cfg 4 geometry, 2 blocks per call, host I/O every call; about 25 s)")
-    ap.add_argument("--realtime-seconds", type=float, default=10.0, help="length of the run that has to hold real time")
+    ap.add_argument("--realtime-seconds", type=float, default=60.0,
+                    help="length of the paced run that has to go without a late delivery")
     ap.add_argument("--gpu-state", action="store_true",
                     help="sample shader clock and power at 50 Hz over the spin-up steps (disturbs the timed steps by about 1 %%)")
     return ap.parse_args()
@@ -311,57 +312,94 @@ def measure_row(torch, kq, wl, config, blocks, dev_index, stream, pci_bus, spin_
 
 
 def measure_channels_at_realtime(torch, kq, wl, dev_index, stream, seconds):
-    """BASELINE.json's "channels @ real-time", measured instead of extrapolated: the reference's operating
-    point is every channel at 1.0 x the front end's rate (one `radio` per channel, main.c:105, README.md:470-477).  cfg 4's
-    geometry (N = 16384, D = 256, 10 MS/s, FM, compute_n0 on), ONE bank of C channels on this GPU, two blocks per call
-    (1.64 ms of signal), the batch from pinned host memory and every channel's audio + status to pinned host memory after
-    every call (kq_bank_push_iq_async / kq_bank_pull_planes_async / kq_bank_pull_wait: the host never runs more than two
-    deliveries ahead).  A first short run at 32768 channels places the candidate; the candidate then has to hold
-    realtime_factor >= 1.0 over `seconds` of wall time (else it is lowered by 2 % and tried again).  Then the same C with
-    the int16 PCM plane (the reference's real output format, audio.c:22-28) instead of float audio, and with four blocks
-    per call."""
-    from ka9q_sdr_amd.realtime import measure_realtime
+    """BASELINE.json's "channels @ real-time" as a DEADLINE figure: the reference's operating point is every
+    channel at 1.0 x the front end's rate (one `radio` per channel, main.c:105, README.md:470-477; the receiver loop of
+    main.c:288-365 takes packets as they arrive).  cfg 4's geometry (N = 16384, D = 256, 10 MS/s, FM, compute_n0 on), ONE bank
+    of C channels on this GPU, two blocks per call (1.64 ms of signal), PACED: a batch becomes available every 1.64 ms of wall
+    time and not sooner, is pushed from pinned host memory, processed, and every channel's audio + status is back in pinned
+    host memory two calls later (realtime_harness.py).  `channels` = the largest count tried whose run of `seconds` (>= 60 by
+    default) had ZERO deliveries more than one call period behind schedule; beside it the mean-factor figure of the rounds
+    before (throughput mode: batch after batch as fast as they go) and the count that leaves 5 % of every period idle."""
+    from realtime_harness import measure_realtime
+
+    def keep(t):
+        d = t.get("deadline") or {}
+        return {"channels": t["channels"], "blocks_per_call": t["blocks_per_call"], "paced": t["paced"], "wall_s": t["wall_s"],
+                "realtime_factor": t["realtime_factor"], "late_deliveries": d.get("late_deliveries"),
+                "backlog_max": (d.get("backlog_calls") or {}).get("max"), "interval_max_ms": t["delivery_interval_ms"]["max"]}
+
     trials = []
     probe = measure_realtime(torch, kq, wl, "cfg4", 32768, 2, dev_index, stream, seconds=1.5)
-    trials.append(probe)
-    C = int(32768 * probe["realtime_factor"] * 0.985) // 256 * 256     # 1.5 % under the short run's rate: the long run has to HOLD it
-    best = None
-    for _ in range(4):
-        r = measure_realtime(torch, kq, wl, "cfg4", C, 2, dev_index, stream, seconds=1.05 * seconds)
-        trials.append(r)
-        if r["realtime_factor"] >= 1.0:
-            best = r
+    trials.append(keep(probe))
+    c_mean = 32768 * probe["realtime_factor"]           # where the MEAN factor crosses 1.0 (ms per call is affine in C)
+    # ---- paced search, short runs: down from 2 % under the mean-factor count in steps of 1.5 %
+    C = int(c_mean * 0.98) // 256 * 256
+    cand = None
+    for _ in range(6):
+        r = measure_realtime(torch, kq, wl, "cfg4", C, 2, dev_index, stream, seconds=5.0, paced=True)
+        trials.append(keep(r))
+        if r["deadline"]["late_deliveries"] == 0 and r["deadline"]["backlog_calls"]["max"] == 0:
+            cand = C
             break
-        C = int(C * min(0.98, r["realtime_factor"] * 0.995)) // 256 * 256
-    out = {"definition": "largest channel count of ONE bank on one GPU whose measured realtime_factor (signal time / wall time) "
-                         "stayed >= 1.0 over the run: cfg4 geometry (N=16384, decimate 256, 10 MS/s, FM, compute_n0=1), 2 blocks "
-                         "(1.64 ms of signal) per call, input from pinned host memory, audio + status of every channel to pinned "
-                         "host memory every call",
-           "channels": best["channels"] if best else 0, "held_seconds": best["wall_s"] if best else 0.0,
-           "float_audio": best, "trials": [{k: t[k] for k in ("channels", "blocks_per_call", "realtime_factor", "wall_s")} for t in trials]}
-    if best:
-        out["pcm_int16"] = measure_realtime(torch, kq, wl, "cfg4", best["channels"], 2, dev_index, stream, seconds=min(4.0, seconds), pcm=True)
-        out["four_blocks_per_call"] = measure_realtime(torch, kq, wl, "cfg4", best["channels"], 4, dev_index, stream,
-                                                       seconds=min(4.0, seconds))
-        # both ends in the reference's own formats: RTP datagrams of int16 I/Q in (radio.c:110-122, main.c:318-341; one
-        # kq_bank_push_rtp per datagram), int16 PCM planes out
-        out["rtp_in_pcm_out"] = measure_realtime(torch, kq, wl, "cfg4", best["channels"], 2, dev_index, stream,
-                                                 seconds=min(4.0, seconds), pcm=True, rtp_samples=1024)
-        # a busy control plane beside the stream: a filter change before every call, mode restarts, a channel leaving and
-        # returning (~1100 operations per second); none of them waits for the device or holds up the calls in flight
-        out["with_control_plane"] = measure_realtime(torch, kq, wl, "cfg4", best["channels"], 2, dev_index, stream,
-                                                     seconds=min(4.0, seconds), pcm=True, control_plane=True)
-        # for a host that does not read the noise estimate (status.n0 = NaN): without compute_n0 the bank runs its pruned forward
-        # path (the `without_compute_n0` row of this line at 1024 x 64) -- how many channels THAT holds at real time, PCM planes out
-        p2 = measure_realtime(torch, kq, wl, "cfg4", 49152, 2, dev_index, stream, seconds=1.5, pcm=True, compute_n0=False)
-        C2 = int(49152 * p2["realtime_factor"] * 0.985) // 256 * 256
+        C = int(C * 0.985) // 256 * 256
+    # ---- the hold: `seconds` of paced running without a late delivery (else 1.5 % fewer channels, once more)
+    best = None
+    if cand:
+        C = cand
         for _ in range(2):
-            r2 = measure_realtime(torch, kq, wl, "cfg4", C2, 2, dev_index, stream, seconds=min(4.0, seconds), pcm=True, compute_n0=False)
-            if r2["realtime_factor"] >= 1.0:
+            r = measure_realtime(torch, kq, wl, "cfg4", C, 2, dev_index, stream, seconds=seconds, paced=True)
+            trials.append(keep(r))
+            if r["deadline"]["late_deliveries"] == 0:
+                best = r
                 break
-            C2 = int(C2 * min(0.98, r2["realtime_factor"] * 0.995)) // 256 * 256
+            C = int(C * 0.985) // 256 * 256
+    out = {"definition": "largest channel count tried of ONE bank on one GPU that ran PACED for held_seconds with zero late "
+                         "deliveries: cfg4 geometry (N=16384, decimate 256, 10 MS/s, FM, compute_n0=1), 2 blocks (1.64 ms of "
+                         "signal) per call, a batch available every 1.64 ms of wall time, pushed from pinned host memory, audio + "
+                         "status of every channel in pinned host memory two calls later; late = in hand more than one call "
+                         "period behind that schedule (realtime_harness.py)",
+           "channels": best["channels"] if best else 0, "held_seconds": best["wall_s"] if best else 0.0,
+           "late_deliveries": best["deadline"]["late_deliveries"] if best else None,
+           "mean_factor_channels": int(c_mean) // 256 * 256,
+           "mean_factor_note": "the figure of rounds 4-5: the count at which throughput-mode realtime_factor (a mean) crosses 1.0",
+           "float_audio": best, "trials": trials}
+    if best:
+        Cb, short = best["channels"], min(5.0, seconds)
+        # the count that leaves 5 % of every call period idle: throughput-mode factor >= 1 / 0.95 (one placement, one check)
+        C5 = int(c_mean * 0.95 * 0.995) // 256 * 256
+        r5 = measure_realtime(torch, kq, wl, "cfg4", C5, 2, dev_index, stream, seconds=2.0)
+        if r5["realtime_factor"] < 1.0 / 0.95:
+            C5 = int(C5 * r5["realtime_factor"] * 0.95 * 0.997) // 256 * 256
+            r5 = measure_realtime(torch, kq, wl, "cfg4", C5, 2, dev_index, stream, seconds=2.0)
+        out["five_percent_headroom"] = {"channels": C5, "realtime_factor": r5["realtime_factor"], "ms_per_call": r5["ms_per_call"],
+                                        "note": "throughput mode: factor >= 1.0526 means every 1.64 ms period has >= 5 % to spare"}
+        # the reference's real output format (int16 PCM, audio.c:22-28) instead of float audio; then with the 24-byte status
+        # records (kq_bank_pull_pcm_planes_compact_async); each paced, and its mean factor from a short throughput run
+        for name, kw in (("pcm_int16", dict(pcm=True)), ("pcm_compact_status", dict(pcm=True, compact_status=True)),
+                         ("four_blocks_per_call", dict()),
+                         # both ends in the reference's own formats: RTP datagrams of int16 I/Q in (radio.c:110-122,
+                         # main.c:318-341; one kq_bank_push_rtp per datagram), int16 PCM planes out
+                         ("rtp_in_pcm_out", dict(pcm=True, rtp_samples=1024)),
+                         # a busy control plane beside the stream: a filter change before every call, mode restarts, a channel
+                         # leaving and returning; none of them waits for the device or holds up the calls in flight
+                         ("with_control_plane", dict(pcm=True, control_plane=True))):
+            nb = 4 if name == "four_blocks_per_call" else 2
+            out[name] = measure_realtime(torch, kq, wl, "cfg4", Cb, nb, dev_index, stream, seconds=short, paced=True, **kw)
+        for name, kw in (("pcm_int16", dict(pcm=True)), ("pcm_compact_status", dict(pcm=True, compact_status=True))):
+            t = measure_realtime(torch, kq, wl, "cfg4", Cb, 2, dev_index, stream, seconds=2.0, **kw)
+            out[name]["throughput_realtime_factor"] = t["realtime_factor"]
+            out[name]["throughput_copy_GBps"] = t["d2h_GBps"]
+        # for a host that does not read the noise estimate (status.n0 = NaN): without compute_n0 the bank runs its pruned forward
+        # path (the `without_compute_n0` row of this line at 1024 x 64) -- how many channels THAT holds, PCM planes out, paced
+        p2 = measure_realtime(torch, kq, wl, "cfg4", 49152, 2, dev_index, stream, seconds=1.5, pcm=True, compute_n0=False)
+        C2 = int(49152 * p2["realtime_factor"] * 0.97) // 256 * 256
+        for _ in range(3):
+            r2 = measure_realtime(torch, kq, wl, "cfg4", C2, 2, dev_index, stream, seconds=short, pcm=True, compute_n0=False, paced=True)
+            if r2["deadline"]["late_deliveries"] == 0:
+                break
+            C2 = int(C2 * 0.98) // 256 * 256
         out["without_compute_n0"] = dict(r2, note="secondary: the reference's demodulators run compute_n0 on every block; `channels` is "
-                                                  "the count tried last, it held real time iff realtime_factor >= 1")
+                                                  "the count tried last, it held iff deadline.late_deliveries == 0")
     return out
 
 
@@ -764,9 +802,10 @@ def main():
                 "channels_total": total_ch,
                 "front_end_Msamples_per_s": round(front_end_msps, 2),
                 "realtime_factor": round(front_end_msps * 1e6 / fs, 2),
-                "channels_at_realtime": int(total_ch * front_end_msps * 1e6 / fs),
-                "channels_at_realtime_note": "extrapolated: channels_total x realtime_factor of this 64-blocks-per-step, HBM-resident "
-                                             "run; the MEASURED figure (one bank, 2 blocks per call, host I/O) is realtime.channels",
+                "channels_at_realtime": (realtime["channels"] if realtime else None),
+                "channels_at_realtime_note": "MEASURED, = realtime.channels: one bank, 2 blocks per call, host I/O, paced, zero late "
+                                             "deliveries (null when the realtime legs were not run: N > 1, --no-realtime, profiler)",
+                "channels_x_factor_extrapolated": int(total_ch * front_end_msps * 1e6 / fs),
                 "parallelism": "channels sharded x%d, front-end I/Q broadcast over RCCL" % world if world > 1 else "1 GPU",
             },
             "roofline": roofline(k_ms, bool(a.n0), fwd_used, tm2["demod_ms"] / max(1, tm2["filter_launches"])),

@@ -2,7 +2,7 @@
  * reference's operating point (one `radio` process per channel behind one multicast group, main.c:105, README.md:470-477) as
  * one channel bank fed in small batches.  INTEGRATION.md section B2.
  *
- *   radio_realtime [channels [blocks_per_call [seconds [pcm [operator]]]]]      defaults 32768 2 3 1 0
+ *   radio_realtime [channels [blocks_per_call [seconds [pcm [operator [paced]]]]]]      defaults 32768 2 3 1 0 0
  *
  * A 10 MS/s front end with FM carriers 140 kHz apart (rank 0 of radio_fanout.c's stream), N = 16384, decimate 256: a
  * batch of 2 blocks is 1.64 ms of signal.  The host's loop is the one a live receiver runs --
@@ -12,19 +12,27 @@
  * -- with the input in pinned host memory (what a socket reader fills) and every channel's audio handed back to pinned host
  * memory after every call, as clipped big-endian int16 PCM words (audio.c:22-28: what send_mono_output puts on the wire) with
  * the silent-packet masks, or as floats (pcm = 0), plus the status plane.  Set-up is one kq_bank_add_channels call.
- * operator = 1: somebody works the receiver meanwhile -- before every call one channel's filter is changed
- * (kq_bank_set_filter: display.c:161-177), before every other call a channel is dropped or the dropped one comes back
- * (kq_bank_remove_channel / kq_bank_add_channel), before every fourth a channel is retuned (kq_bank_set_second_lo).  None of
- * these waits for the device; the calls in flight keep the parameters they were queued with.
+ * operator = 1: somebody works the receiver meanwhile, ON A THREAD OF THEIR OWN as in the reference (display.c / radio_status.c
+ * beside the demodulator threads): about once per call period one channel's filter is changed (kq_bank_set_filter:
+ * display.c:161-177), every other time a channel is dropped or the dropped one comes back (kq_bank_remove_channel /
+ * kq_bank_add_channel), every fourth a channel is retuned (kq_bank_set_second_lo).  None of these waits for the device; the
+ * calls in flight keep the parameters they were queued with.  Both threads take the handle's lock: the receiver's worst wait
+ * for it and the operator's longest hold are printed (kq_host_timing.lock_wait_max_ms / ctl_hold_max_ms).
+ * paced = 1: the front end is a clock -- batch n is complete at A_n = start + (n + 1) x 1.64 ms and the loop takes it then
+ * (process the batch before it, push this one, queue the delivery, take the delivery queued two calls ago), as a socket
+ * reader takes main.c:288-365's packets.  Printed:
+ * deliveries in hand more than one call period behind that schedule (late), the deepest backlog in whole periods, and the
+ * intervals between deliveries.  paced = 0: batch after batch as fast as they go; the factor printed is then a mean.
  * Prints the real-time factor (signal time / wall time; >= 1 means the bank keeps up), the host's own time per call and
  * the delivery rate, and checks a delivered channel: squelch open, the 1 kHz tone's deviation seen.
  *
  *   gcc -std=gnu11 -O2 -Iinclude examples/radio_realtime.c -Lka9q_sdr_amd/lib -lka9q_hip \
- *       -Wl,-rpath,$PWD/ka9q_sdr_amd/lib -lm -o radio_realtime
+ *       -Wl,-rpath,$PWD/ka9q_sdr_amd/lib -lm -lpthread -o radio_realtime
  * (nothing of HIP in the host program: the pinned buffers come from kq_host_alloc.)
  */
 #include <complex.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -44,12 +52,78 @@ static double now_s(void){
 }
 static double emitter_freq(int e){ return (e - (NEMIT - 1) / 2.0) * 140000.0; }
 
+/* the operator's thread: a change about once per call period, until told to stop */
+struct operator_args {
+  kq_bank *bank;
+  kq_channel_config *cc;
+  unsigned C;
+  double period_s;
+  volatile int stop, failed;
+  long ops;
+  double worst_s, total_s;
+};
+static void *operator_thread(void *arg){
+  struct operator_args *o = arg;
+  kq_bank *bank = o->bank;
+  unsigned const C = o->C;
+  int away = -1;                        /* the channel that has been dropped and not yet come back */
+  for(long k = 0; !o->stop; k++){
+    double const t0 = now_s();
+    int rc = 0;
+    unsigned const c = 64u + (unsigned)((k * 7919) % (C - 64));  /* (channels 0..63 are left alone: the check reads channel 5) */
+    float const w = 6000.f + 125.f * (float)(k % 17);
+    if((int)c != away){
+      rc |= kq_bank_set_filter(bank, (int)c, -w, w, 3.0f) != 0;
+      o->ops++;
+    }
+    if(k % 2 == 0){
+      if(away < 0){
+        away = 64 + (int)((k * 104729 + 3) % (C - 64));
+        rc |= kq_bank_remove_channel(bank, away) != 0;
+      } else {
+        rc |= kq_bank_add_channel(bank, &o->cc[away]) != away;   /* the bank hands out the lowest hole: the only one */
+        away = -1;
+      }
+      o->ops++;
+    }
+    if(k % 4 == 1){
+      unsigned const r = 64u + (unsigned)((k * 15485863) % (C - 64));
+      if((int)r != away){
+        rc |= kq_bank_set_second_lo(bank, (int)r, o->cc[r].second_lo + (k & 4 ? 1.0 : 0.0)) != 0;
+        o->ops++;
+      }
+    }
+    if(rc){
+      fprintf(stderr, "operator: %s\n", kq_last_error());
+      o->failed = 1;
+      break;
+    }
+    double const dt = now_s() - t0;       /* this round's two or three operations together */
+    o->total_s += dt;
+    if(dt > o->worst_s)
+      o->worst_s = dt;
+    double const next = t0 + o->period_s;
+    while(now_s() < next && !o->stop){
+      struct timespec ts = {0, 100000};
+      nanosleep(&ts, NULL);
+    }
+  }
+  if(away >= 0 && !o->failed)             /* everybody is back when the receiver checks its last delivery */
+    o->failed |= kq_bank_add_channel(bank, &o->cc[away]) != away;
+  return NULL;
+}
+static int cmp_double(const void *a, const void *b){
+  double const x = *(const double *)a, y = *(const double *)b;
+  return (x > y) - (x < y);
+}
+
 int main(int argc, char **argv){
   unsigned const C = argc > 1 ? (unsigned)atoi(argv[1]) : 32768u;
   unsigned const B = argc > 2 ? (unsigned)atoi(argv[2]) : 2u;
   double const seconds = argc > 3 ? atof(argv[3]) : 3.0;
   int const pcm = argc > 4 ? atoi(argv[4]) : 1;
   int const operator_on = argc > 5 ? atoi(argv[5]) : 0;
+  int const paced = argc > 6 ? atoi(argv[6]) : 0;
   if(C == 0 || B == 0 || B > 64)
     return 2;
   if(kq_abi_version() != KQ_ABI_VERSION || kq_device_count() <= 0){
@@ -107,84 +181,126 @@ int main(int argc, char **argv){
 
   /* ---- the receiver's loop (the same batch over and over: the stream is synthetic, the work is not) */
   double const signal_s = (double)B * L / SAMPRATE;
-  long calls = 0, warm = 50, ops = 0;
-  double op_worst = 0, op_total = 0;    /* host time inside the operator's calls */
-  int away = -1;                        /* the channel that has been dropped and not yet come back */
+  long calls = 0, warm = 50;
   kq_host_timing ht;
   int rc = 0;
+  size_t const cap = (size_t)(seconds / signal_s * 1.5) + 1024;   /* per-call records of the timed part */
+  double *stamp = malloc(cap * sizeof *stamp), *lag = malloc(cap * sizeof *lag);
+  struct operator_args op = { .bank = bank, .cc = cc, .C = C, .period_s = signal_s };
+  pthread_t op_tid;
+  int op_started = 0;
+  double origin = 0;                      /* paced: batch n of the timed part is complete at origin + (n + 1) signal_s */
   if(kq_bank_push_iq_async(bank, in, nin, KQ_IQ_CF32) != 0)
     rc = 1;
   for(long k = 0; rc == 0; k++){
     if(k == warm){                      /* clocks up, every buffer touched once */
       kq_bank_host_io_wait(bank);
       kq_bank_get_host_timing(bank, &ht, 1);
+      if(operator_on && C > 64){
+        op_started = pthread_create(&op_tid, NULL, operator_thread, &op) == 0;
+        if(!op_started)
+          rc = 1;
+      }
       t0 = now_s();
+      origin = t0 + 2e-4 - signal_s;
     }
     int const j = (int)(k % 3);
-    if(operator_on && C > 64){
-      double const op_t0 = now_s();
-      unsigned const c = 64u + (unsigned)((k * 7919) % (C - 64));  /* (channels 0..63 are left alone: the check below reads channel 5) */
-      float const w = 6000.f + 125.f * (float)(k % 17);
-      if((int)c != away){
-        rc |= kq_bank_set_filter(bank, (int)c, -w, w, 3.0f) != 0;
-        ops++;
-      }
-      if(k % 2 == 0){
-        if(away < 0){
-          away = 64 + (int)((k * 104729 + 3) % (C - 64));
-          rc |= kq_bank_remove_channel(bank, away) != 0;
-        } else {
-          rc |= kq_bank_add_channel(bank, &cc[away]) != away;   /* the bank hands out the lowest hole: the only one */
-          away = -1;
-        }
-        ops++;
-      }
-      if(k % 4 == 1){
-        unsigned const r = 64u + (unsigned)((k * 15485863) % (C - 64));
-        if((int)r != away){
-          rc |= kq_bank_set_second_lo(bank, (int)r, cc[r].second_lo + (k & 4 ? 1.0 : 0.0)) != 0;
-          ops++;
-        }
-      }
-      if(rc){
-        fprintf(stderr, "operator: %s\n", kq_last_error());
-        break;
-      }
-      double const op_dt = now_s() - op_t0;   /* this call's two or three operations together */
-      op_total += op_dt;
-      if(k >= warm && op_dt > op_worst)
-        op_worst = op_dt;
+    if(paced && k >= warm){             /* the batch that is pushed below has just arrived: not before */
+      double const due = origin + (double)(calls + 1) * signal_s;
+      double now = now_s();
+      while(now < due)
+        now = now_s();
+      if((size_t)calls < cap)
+        lag[calls] = now - due;
     }
+    /* (process first, then push: an input copy queued behind the previous call's output copy would wait with it for that
+     * call's demodulators -- ka9q_hip.h "Call order for full overlap") */
     if(kq_bank_process(bank) != (int)B || kq_bank_push_iq_async(bank, in, nin, KQ_IQ_CF32) != 0)
       rc = 1;
-    else if(pcm ? kq_bank_pull_pcm_planes_async(bank, out[j], mask[j], st[j]) : kq_bank_pull_planes_async(bank, out[j], st[j]))
+    if(rc == 0 && (pcm ? kq_bank_pull_pcm_planes_async(bank, out[j], mask[j], st[j]) : kq_bank_pull_planes_async(bank, out[j], st[j])))
       rc = 1;
-    else if(kq_bank_pull_wait(bank, 2) != 0)      /* delivery k - 2 has landed: out[(k - 2) % 3] is the host's to read */
+    else if(rc == 0 && kq_bank_pull_wait(bank, 2) != 0)      /* delivery k - 2 has landed: out[(k - 2) % 3] is the host's to read */
+      rc = 1;
+    if(op.failed)
       rc = 1;
     if(k >= warm){
+      double const now = now_s();
+      if((size_t)calls < cap)
+        stamp[calls] = now;
       calls++;
-      if(now_s() - t0 >= seconds)
+      if(now - t0 >= seconds)
         break;
     }
+  }
+  double const wall = now_s() - t0;
+  if(op_started){
+    op.stop = 1;
+    pthread_join(op_tid, NULL);
+    if(op.failed)
+      rc = 1;
   }
   if(rc != 0 || kq_bank_host_io_wait(bank) != 0){
     fprintf(stderr, "receiver loop: %s\n", kq_last_error());
     return 1;
   }
-  double const wall = now_s() - t0;
+  if(op_started){                       /* the channel that came back last takes part in one more call before the check */
+    int const j = (int)((warm + calls) % 3);
+    if(rc || kq_bank_process(bank) != (int)B ||
+       (pcm ? kq_bank_pull_pcm_planes_async(bank, out[j], mask[j], st[j]) : kq_bank_pull_planes_async(bank, out[j], st[j])) ||
+       kq_bank_host_io_wait(bank) != 0){
+      fprintf(stderr, "last call: %s\n", kq_last_error());
+      return 1;
+    }
+  }
   kq_bank_get_host_timing(bank, &ht, 0);
   double const per_call = wall / calls;
   double const d2h = (double)rows * (OLEN * (pcm ? 2 : 4) + sizeof(kq_chan_status) + (pcm ? 4 : 0));
-  printf("%u channels x %u blocks per call (%.3f ms of signal): %.4f ms per call over %ld calls = %.3f x real time\n", C, B,
-         signal_s * 1e3, per_call * 1e3, calls, signal_s / per_call);
-  if(operator_on)
-    printf("operator: %ld changes (filter, channel dropped / back, retune) = %.0f per second beside the stream; host time inside them "
-           "%.4f ms per call, worst %.3f ms\n", ops, ops / wall, 1e3 * op_total / (double)(calls + warm), 1e3 * op_worst);
-  printf("host inside kq_bank_process: %.4f ms per call (per-channel staging %.4f); delivered %s + status: %.2f GB/s\n",
-         ht.call_ms / (double)ht.calls, ht.stage_ms / (double)ht.calls, pcm ? "int16 PCM" : "float audio", d2h / per_call / 1e9);
+  printf("%u channels x %u blocks per call (%.3f ms of signal): %.4f ms per call over %ld calls = %.3f x real time%s\n", C, B,
+         signal_s * 1e3, per_call * 1e3, calls, signal_s / per_call, paced ? " (paced by the clock)" : " (a mean: batches as fast as they go)");
+  {                                     /* deliveries as the host sees them */
+    size_t const n = (size_t)calls < cap ? (size_t)calls : cap;
+    size_t const skip = paced ? (size_t)(0.5 / signal_s) < n / 4 ? (size_t)(0.5 / signal_s) : n / 4 : 0;
+    double *iv = malloc(n * sizeof *iv);
+    size_t niv = 0;
+    for(size_t i = skip + 1; i < n; i++)
+      iv[niv++] = stamp[i] - stamp[i - 1];
+    qsort(iv, niv, sizeof *iv, cmp_double);
+    if(niv > 0)
+      printf("delivery intervals: p50 %.3f  p99 %.3f  p99.9 %.3f  max %.3f ms\n", 1e3 * iv[niv / 2], 1e3 * iv[(size_t)(0.99 * (niv - 1))],
+             1e3 * iv[(size_t)(0.999 * (niv - 1))], 1e3 * iv[niv - 1]);
+    if(paced){
+      long late = 0, backlog_max = 0;
+      double worst = 0;
+      for(size_t i = skip; i < n; i++){
+        double const due = origin + (double)(i + 1) * signal_s;
+        double const late_by = stamp[i] - due - signal_s;      /* delivery i - 2 is due with the start of iteration i */
+        if(late_by > 0){
+          late++;
+          if(late_by > worst)
+            worst = late_by;
+        }
+        long const bl = (long)floor(lag[i] / signal_s);
+        if(bl > backlog_max)
+          backlog_max = bl;
+      }
+      printf("deadline: %ld of %zu deliveries more than one call period behind schedule (worst %.3f ms late), deepest backlog %ld periods\n",
+             late, n - skip, 1e3 * worst, backlog_max);
+    }
+    free(iv);
+  }
+  if(op_started)
+    printf("operator thread: %ld changes (filter, channel dropped / back, retune) = %.0f per second beside the stream; host time inside "
+           "them worst %.3f ms per round; the receiver waited for the handle's lock %.4f ms per call, worst %.3f ms; longest hold by "
+           "another entry point %.3f ms\n", op.ops, op.ops / wall, 1e3 * op.worst_s, ht.lock_wait_ms / (double)ht.calls,
+           ht.lock_wait_max_ms, ht.ctl_hold_max_ms);
+  printf("host inside kq_bank_process: %.4f ms per call (per-channel staging %.4f, waiting for the device %.4f); delivered %s + status: %.2f GB/s\n",
+         ht.call_ms / (double)ht.calls, ht.stage_ms / (double)ht.calls, ht.slot_wait_ms / (double)ht.calls,
+         pcm ? "int16 PCM" : "float audio", d2h / per_call / 1e9);
+  free(stamp);
+  free(lag);
 
   /* ---- a delivered plane: every channel reports olen samples per block; channel 5 sits on a carrier */
-  int const jl = (int)((warm + calls - 1 + 0) % 3);
+  int const jl = (int)((warm + calls - 1 + (op_started ? 1 : 0)) % 3);
   const kq_chan_status *s = st[jl];
   unsigned open = 0;
   size_t counted = 0;

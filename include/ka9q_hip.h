@@ -120,6 +120,19 @@ typedef struct kq_chan_status {
   int32_t nout;            /* floats of audio this block: olen (mono) or 2*olen (stereo) */
 } kq_chan_status;
 
+/* The part of kq_chan_status a receiver reads with every block (kq_bank_pull_pcm_planes_compact_async): at real time the
+ * 64-byte record is half of what a PCM delivery moves over the link, and most of it changes at the rate of the status
+ * packets (radio_status.c), not of the blocks.  The whole record stays available through kq_bank_pull_status and the
+ * full-plane pulls. */
+typedef struct kq_chan_status_compact {
+  float bb_power;          /* as kq_chan_status */
+  float n0;
+  float snr;
+  float aux;               /* FM: foffset (fm.c:148); AM and linear: agc_gain (agc.gain after the block) */
+  int32_t state;           /* FM: squelch_count (fm.c:70); AM and linear: hangcount */
+  int32_t nout;            /* words of audio this block */
+} kq_chan_status_compact;
+
 /* Per-kernel device time accumulated since the last reset (HIP events on the bank's stream) */
 typedef struct kq_timing {
   double filter_ms;        /* pre-detection filter kernel (mix + forward FFT + response + IFFT) */
@@ -278,6 +291,8 @@ void *kq_bank_stream(kq_bank *bank);
  *                             480-word chunk is all zero, the packet send_mono_output would not send) and the status
  *                             plane -- half the bytes of the float plane; the conversion rides in the copy kernel and
  *                             does not need kq_bank_enable_pcm.  olen a multiple of 8.
+ *  kq_bank_pull_pcm_planes_compact_async: the same with kq_chan_status_compact records (24 bytes per channel-block
+ *                             instead of 64; the plane 16-byte aligned) -- a third fewer bytes per delivery at N/D = 64.
  *  kq_bank_pull_wait:         blocks until the delivery queued `lag` deliveries before the newest one has landed (0: the
  *                             newest; at most 7) -- a streaming host takes the planes of call k-2 in hand while calls
  *                             k-1 and k are in flight.
@@ -288,6 +303,8 @@ void *kq_bank_stream(kq_bank *bank);
 int kq_bank_push_iq_async(kq_bank *bank, const void *iq_pinned, size_t nsamples, int format);
 int kq_bank_pull_planes_async(kq_bank *bank, float *audio_pinned, kq_chan_status *status_pinned);
 int kq_bank_pull_pcm_planes_async(kq_bank *bank, int16_t *pcm_pinned, uint32_t *silent_mask_pinned, kq_chan_status *status_pinned);
+int kq_bank_pull_pcm_planes_compact_async(kq_bank *bank, int16_t *pcm_pinned, uint32_t *silent_mask_pinned,
+                                          kq_chan_status_compact *status_pinned);
 int kq_bank_pull_wait(kq_bank *bank, unsigned lag);
 int kq_bank_host_io_wait(kq_bank *bank);
 
@@ -366,6 +383,9 @@ typedef struct kq_host_timing {
   double ctl_hold_max_ms;  /* the longest any OTHER entry point held the lock (device waits with the lock let go excluded) */
 } kq_host_timing;
 int kq_bank_get_host_timing(kq_bank *bank, kq_host_timing *t, int reset);
+/* The entry point behind ctl_hold_max_ms (its name, e.g. "kq_bank_set_filter"; "" when nothing has held the lock since the
+ * last reset).  Read it before the kq_bank_get_host_timing call that resets. */
+const char *kq_bank_worst_lock_holder(kq_bank *bank);
 /* Which forward path the bank resolved to (enum kq_fwd_mode, never AUTO) */
 int kq_bank_fwd_mode(const kq_bank *bank);
 

@@ -79,6 +79,9 @@ class Timing(C.Structure):
                 ("filter_launches", C.c_uint64), ("channel_blocks", C.c_uint64)]
 
 
+# kq_chan_status_compact: aux = FM foffset / AM, linear agc_gain; state = FM squelch_count / AM, linear hangcount
+COMPACT_STATUS_DTYPE = np.dtype([("bb_power", "f4"), ("n0", "f4"), ("snr", "f4"), ("aux", "f4"), ("state", "i4"), ("nout", "i4")])
+
 STATUS_DTYPE = np.dtype([
     ("if_power", "f4"), ("bb_power", "f4"), ("n0", "f4"), ("snr", "f4"), ("foffset", "f4"),
     ("pdeviation", "f4"), ("agc_gain", "f4"), ("noise_gain", "f4"), ("plfreq", "f4"), ("cphase", "f4"), ("pll_lock", "i4"), ("lock_count", "i4"),
@@ -167,8 +170,11 @@ def load_library():
     L.kq_bank_pull_planes_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.kq_bank_host_io_wait.argtypes = [C.c_void_p]
     L.kq_bank_pull_pcm_planes_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kq_bank_pull_pcm_planes_compact_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.kq_bank_pull_wait.argtypes = [C.c_void_p, C.c_uint]
     L.kq_bank_get_host_timing.argtypes = [C.c_void_p, C.POINTER(HostTiming), C.c_int]
+    L.kq_bank_worst_lock_holder.argtypes = [C.c_void_p]
+    L.kq_bank_worst_lock_holder.restype = C.c_char_p
     L.kq_shard_range.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     L.kq_fanout_unique_id.argtypes = [C.c_void_p]
     L.kq_fanout_create.restype = C.c_void_p
@@ -341,14 +347,23 @@ class Bank:
         """queues the copy of the last call's audio [C][max_blocks][2 olen] / status [C][max_blocks] planes to pinned host memory"""
         self._chk(self.lib.kq_bank_pull_planes_async(self.h, audio_ptr, status_ptr), "kq_bank_pull_planes_async")
 
-    def pull_pcm_planes_async(self, pcm_ptr, mask_ptr, status_ptr):
+    def pull_pcm_planes_async(self, pcm_ptr, mask_ptr, status_ptr, compact=False):
         """the last call's audio as clipped big-endian int16 words [C][max_blocks][2 olen], the silent-chunk masks
-        [C][max_blocks] and the status plane to pinned host memory (kq_bank_pull_pcm_planes_async)"""
-        self._chk(self.lib.kq_bank_pull_pcm_planes_async(self.h, pcm_ptr, mask_ptr, status_ptr), "kq_bank_pull_pcm_planes_async")
+        [C][max_blocks] and the status plane to pinned host memory (kq_bank_pull_pcm_planes_async); compact: the status
+        plane as 24-byte kq_chan_status_compact records (COMPACT_STATUS_DTYPE)"""
+        if compact:
+            self._chk(self.lib.kq_bank_pull_pcm_planes_compact_async(self.h, pcm_ptr, mask_ptr, status_ptr),
+                      "kq_bank_pull_pcm_planes_compact_async")
+        else:
+            self._chk(self.lib.kq_bank_pull_pcm_planes_async(self.h, pcm_ptr, mask_ptr, status_ptr), "kq_bank_pull_pcm_planes_async")
 
     def pull_wait(self, lag=0):
         """block until the plane delivery queued `lag` deliveries before the newest has landed"""
         self._chk(self.lib.kq_bank_pull_wait(self.h, lag), "kq_bank_pull_wait")
+
+    def worst_lock_holder(self):
+        """the entry point that held the handle's lock longest since the last host_timing reset (ctl_hold_max_ms)"""
+        return (self.lib.kq_bank_worst_lock_holder(self.h) or b"").decode()
 
     def host_timing(self, reset=True):
         t = HostTiming()

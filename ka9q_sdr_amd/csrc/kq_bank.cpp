@@ -340,6 +340,7 @@ struct kq_bank {
 
   int timing = 0;  // 0 off, 1 filter kernel only, >= 2 every scope
   kq_host_timing host_acc = {};  // the host's own time inside the process calls (always on: three clock reads per call)
+  const char *worst_holder = "";  // the entry point behind host_acc.ctl_hold_max_ms
   std::vector<EventPair> ev_filter, ev_demod, ev_ingest;
   size_t ev_used[3] = {0, 0, 0};
   kq_timing acc = {};
@@ -372,9 +373,11 @@ struct BankScope {
   std::unique_lock<std::recursive_mutex> lk;
   kq_bank *bank = nullptr;
   bool receiver = false;
+  const char *who;  // the entry point (its function name, taken where the scope is declared)
   clock::time_point t_acq;
   double unlocked_ms = 0;
-  explicit BankScope(kq_bank *b, bool receiver_ = false) : dev(b ? b->cfg.device : -1), bank(b), receiver(receiver_) {
+  explicit BankScope(kq_bank *b, bool receiver_ = false, const char *fn = __builtin_FUNCTION())
+      : dev(b ? b->cfg.device : -1), bank(b), receiver(receiver_), who(fn) {
     if (!b) return;
     auto const t0 = clock::now();
     lk = std::unique_lock<std::recursive_mutex>(b->mu);
@@ -385,11 +388,14 @@ struct BankScope {
       if (w > b->host_acc.lock_wait_max_ms) b->host_acc.lock_wait_max_ms = w;
     }
   }
-  explicit BankScope(const kq_bank *b) : BankScope(const_cast<kq_bank *>(b)) {}
+  explicit BankScope(const kq_bank *b, const char *fn = __builtin_FUNCTION()) : BankScope(const_cast<kq_bank *>(b), false, fn) {}
   ~BankScope() {
     if (!bank || receiver || !lk.owns_lock()) return;
     double const h = std::chrono::duration<double, std::milli>(clock::now() - t_acq).count() - unlocked_ms;
-    if (h > bank->host_acc.ctl_hold_max_ms) bank->host_acc.ctl_hold_max_ms = h;
+    if (h > bank->host_acc.ctl_hold_max_ms) {
+      bank->host_acc.ctl_hold_max_ms = h;
+      bank->worst_holder = who;
+    }
   }
 };
 // a wait for the device inside an entry point: the lock is let go for its duration (one level: an entry point called from
@@ -2677,7 +2683,7 @@ int kq_bank_pull_planes_async(kq_bank *b, float *audio, kq_chan_status *status) 
 // The reference's real output format (audio.c:22-28, 45-50, 95-100): clipped int16 in network byte order, half the bytes
 // of the float plane.  The conversion runs inside the copy kernel (the same arithmetic as k_pcm, the stage behind
 // kq_bank_enable_pcm, which this call does not need).
-int kq_bank_pull_pcm_planes_async(kq_bank *b, int16_t *pcm, uint32_t *silent_mask, kq_chan_status *status) {
+static int pull_pcm_planes(kq_bank *b, int16_t *pcm, uint32_t *silent_mask, void *status, bool compact) {
   BankScope dev_scope_(b);
   if (!pcm) {
     set_err("NULL pcm plane");
@@ -2692,11 +2698,19 @@ int kq_bank_pull_pcm_planes_async(kq_bank *b, int16_t *pcm, uint32_t *silent_mas
   if (pull_prologue(b)) return -1;
   size_t const n = b->chans.size() * (size_t)b->g.max_blocks;
   size_t const sbytes = n * sizeof(kq_chan_status), s16 = sbytes & ~(size_t)15;
-  kq::launch_copy_pcm_to_host(b->copy_out, b->pl.audio, pcm, silent_mask, 2 * b->g.olen, b->pl.status, status, n);
+  kq::launch_copy_pcm_to_host(b->copy_out, b->pl.audio, pcm, silent_mask, 2 * b->g.olen, b->pl.status, status, n,
+                              compact && status ? b->chd.mode : nullptr, b->g.max_blocks);
   LAUNCH_CHECK("PCM plane copy");
-  if (status && sbytes > s16)
+  if (status && !compact && sbytes > s16)
     HIP_TRY(hipMemcpyAsync((char *)status + s16, (const char *)b->pl.status + s16, sbytes - s16, hipMemcpyDeviceToHost, b->copy_out));
   return pull_epilogue(b);
+}
+int kq_bank_pull_pcm_planes_async(kq_bank *b, int16_t *pcm, uint32_t *silent_mask, kq_chan_status *status) {
+  return pull_pcm_planes(b, pcm, silent_mask, status, false);
+}
+// ... with the 24 bytes of every status record a receiver reads per block (include/ka9q_hip.h kq_chan_status_compact)
+int kq_bank_pull_pcm_planes_compact_async(kq_bank *b, int16_t *pcm, uint32_t *silent_mask, kq_chan_status_compact *status) {
+  return pull_pcm_planes(b, pcm, silent_mask, status, true);
 }
 
 int kq_bank_pull_wait(kq_bank *b, unsigned lag) {
@@ -3271,8 +3285,17 @@ int kq_bank_get_host_timing(kq_bank *b, kq_host_timing *t, int reset) {
   if (!b || !t) return -1;
   std::lock_guard<std::recursive_mutex> lk(b->mu);
   *t = b->host_acc;
-  if (reset) b->host_acc = kq_host_timing{};
+  if (reset) {
+    b->host_acc = kq_host_timing{};
+    b->worst_holder = "";
+  }
   return 0;
+}
+
+const char *kq_bank_worst_lock_holder(kq_bank *b) {
+  if (!b) return "";
+  std::lock_guard<std::recursive_mutex> lk(b->mu);
+  return b->worst_holder;  // (a function name: static storage)
 }
 
 int kq_bank_fwd_mode(const kq_bank *b) { return b ? b->fwd_mode : -1; }

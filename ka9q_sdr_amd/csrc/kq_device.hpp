@@ -119,7 +119,8 @@ void ensure_dynamic_lds(const void *kernel, size_t bytes);
 void launch_copy_to_host(hipStream_t s, const float *audio, float *haudio, int row, const kq_chan_status *status, void *hstatus,
                          size_t rows);
 void launch_copy_pcm_to_host(hipStream_t s, const float *audio, short *hpcm, unsigned *hmask, int row,
-                             const kq_chan_status *status, void *hstatus, size_t rows);
+                             const kq_chan_status *status, void *hstatus, size_t rows, const int *mode_compact = nullptr,
+                             int max_blocks = 1);
 void launch_ingest(hipStream_t s, const void *src, int format, float2 *dst, size_t nsamples, float scale);
 // IF power in two launches.  _sum (in front of the filter, whose row-paired samples it also writes): per-block partial
 // sums of |s|^2 into sums[nblocks * block_energy_split(L)], and the call's parameter block from `params_host` (pinned,

@@ -275,10 +275,16 @@ __device__ __forceinline__ unsigned pcm_word_be(float x) {
   unsigned const h = (unsigned)v & 0xffffu;
   return ((h << 8) | (h >> 8)) & 0xffffu;
 }
+// COMPACT: instead of the whole 64-byte status records, the 24 bytes a receiver reads per block (kq_chan_status_compact:
+// bb_power, n0, snr, FM foffset / AM + linear agc.gain, FM squelch counter / AM + linear hang counter, nout) -- at real
+// time the status plane is half of the PCM delivery's bytes.  A workgroup packs 256 records into LDS and stores them as
+// whole 16-byte pieces (6144 bytes per trip, 16-byte aligned whatever the trip).
+template <bool COMPACT>
 __global__ void __launch_bounds__(256) k_copy_pcm_to_host(const float *__restrict__ audio, short *__restrict__ hpcm,
                                                           unsigned *__restrict__ hmask, int row,
                                                           const kq_chan_status *__restrict__ status, u32x4 *__restrict__ hstatus,
-                                                          size_t rows, size_t status16) {
+                                                          size_t rows, size_t status16, const int *__restrict__ mode,
+                                                          int max_blocks) {
   size_t const stride = (size_t)gridDim.x * blockDim.x;
   size_t const tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int const sub = (int)(tid & 15);
@@ -304,18 +310,51 @@ __global__ void __launch_bounds__(256) k_copy_pcm_to_host(const float *__restric
       hmask[r] = ~nonzero & (chunks >= 32 ? 0xffffffffu : ((1u << chunks) - 1u));
     }
   }
-  const u32x4 *sp = reinterpret_cast<const u32x4 *>(status);
-  if (hstatus)
+  if (!hstatus) return;
+  if constexpr (COMPACT) {
+    __shared__ __attribute__((aligned(16))) unsigned rec[256 * 6];
+    size_t const trips = (rows + 255) / 256;
+    for (size_t trip = blockIdx.x; trip < trips; trip += gridDim.x) {  // (uniform per workgroup: the barriers are safe)
+      size_t const r0 = trip * 256, r = r0 + threadIdx.x;
+      if (r < rows) {
+        kq_chan_status const st = status[r];
+        bool const fm = mode[r / (size_t)max_blocks] == KQ_FM_DEMOD;
+        unsigned *o = rec + 6 * threadIdx.x;
+        o[0] = __float_as_uint(st.bb_power);
+        o[1] = __float_as_uint(st.n0);
+        o[2] = __float_as_uint(st.snr);
+        o[3] = __float_as_uint(fm ? st.foffset : st.agc_gain);
+        o[4] = (unsigned)(fm ? st.squelch_count : st.hangcount);
+        o[5] = (unsigned)st.nout;
+      }
+      __syncthreads();
+      size_t const nrec = min((size_t)256, rows - r0);
+      unsigned const words = (unsigned)nrec * 6, full = words / 4;
+      u32x4 *dst = reinterpret_cast<u32x4 *>(reinterpret_cast<unsigned *>(hstatus) + r0 * 6);  // r0 * 24 bytes: a multiple of 16
+      for (unsigned i = threadIdx.x; i < full; i += 256)
+        __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(rec)[i], dst + i);
+      if (threadIdx.x < words - 4 * full)  // the last trip's odd record: its trailing 8 bytes
+        reinterpret_cast<unsigned *>(dst)[4 * full + threadIdx.x] = rec[4 * full + threadIdx.x];
+      __syncthreads();
+    }
+  } else {
+    const u32x4 *sp = reinterpret_cast<const u32x4 *>(status);
     for (size_t i = tid; i < status16; i += stride) __builtin_nontemporal_store(sp[i], hstatus + i);
+  }
 }
 void launch_copy_pcm_to_host(hipStream_t s, const float *audio, short *hpcm, unsigned *hmask, int row,
-                             const kq_chan_status *status, void *hstatus, size_t rows) {
-  size_t const bytes = rows * ((size_t)row * sizeof(short) + 4 + (hstatus ? sizeof(kq_chan_status) : 0));
+                             const kq_chan_status *status, void *hstatus, size_t rows, const int *mode_compact, int max_blocks) {
+  size_t const sbytes = hstatus ? (mode_compact ? sizeof(kq_chan_status_compact) : sizeof(kq_chan_status)) : 0;
+  size_t const bytes = rows * ((size_t)row * sizeof(short) + 4 + sbytes);
   unsigned wgs = (unsigned)std::min<size_t>(64, std::max<size_t>(4, (bytes + (2u << 20) - 1) >> 21));
   static int const forced = getenv("KQ_COPY_WGS") ? atoi(getenv("KQ_COPY_WGS")) : 0;
   if (forced > 0) wgs = (unsigned)forced;
-  hipLaunchKernelGGL(k_copy_pcm_to_host, dim3(wgs), dim3(256), 0, s, audio, hpcm, hmask, row, status, (u32x4 *)hstatus, rows,
-                     rows * sizeof(kq_chan_status) / 16);
+  if (mode_compact)
+    hipLaunchKernelGGL(k_copy_pcm_to_host<true>, dim3(wgs), dim3(256), 0, s, audio, hpcm, hmask, row, status, (u32x4 *)hstatus, rows,
+                       rows * sizeof(kq_chan_status) / 16, mode_compact, max_blocks);
+  else
+    hipLaunchKernelGGL(k_copy_pcm_to_host<false>, dim3(wgs), dim3(256), 0, s, audio, hpcm, hmask, row, status, (u32x4 *)hstatus, rows,
+                       rows * sizeof(kq_chan_status) / 16, mode_compact, max_blocks);
 }
 
 // ---------------------------------------------------------------- full-FFT pre-detection filter

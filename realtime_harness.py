@@ -1,4 +1,5 @@
-"""Channels at 1.0 x real time on one GPU, MEASURED (BASELINE.json's "channels @ real-time").
+"""Channels at 1.0 x real time on one GPU, MEASURED (BASELINE.json's "channels @ real-time").  A measurement harness, not
+part of the product package: it lives beside bench.py.
 
 The reference's operating point is one `radio` process per channel, each at the front end's rate (main.c:105,
 README.md:470-477).  Here: C channels of one bank, a small batch of B blocks per call (B = 2 at cfg 4's geometry: 1.64 ms
@@ -6,9 +7,28 @@ of signal), every batch fed from pinned host memory and every channel's audio + 
 after every call.  What scales with C rather than with C x B is exercised here and nowhere else: the per-call oscillator
 parameters of every channel, the demodulator grid, the status plane, several GB/s of audio leaving the GPU.
 
+Two ways of running the receiver's loop:
+
+* throughput (paced=False): batch after batch as fast as the bank takes them; realtime_factor = signal time / wall time.
+  A MEAN: it says the bank keeps up on average, not that every delivery is on time.
+* paced (paced=True): the front end delivers a batch every `period` = B L / samprate seconds and not sooner (the loop waits
+  for the wall clock, as a socket reader waits for main.c:288-365's packets).  Iteration n starts when batch n is complete
+  (A_n = origin + (n + 1) period): it processes the batch pushed one iteration earlier, pushes batch n, queues the call's
+  delivery and takes the delivery queued two iterations earlier.  Deadline accounting per iteration:
+      start lag   = (moment the iteration starts) - A_n            0 while the loop keeps up
+      backlog     = floor(start lag / period)                      whole batches waiting behind the one being taken
+      late        = delivery n - 2 in hand later than A_n + period (more than one call period behind its schedule)
+  plus the intervals between consecutive deliveries.  A count "holds real time" here only with ZERO late deliveries.
+
+Python's cyclic garbage collector is frozen and switched off inside the timed loops (gc.freeze / gc.disable): with torch
+imported a full collection stops the interpreter for 20-30 ms -- the unexplained maximum delivery intervals of round 5's
+float-audio legs (`gc` in the result says how the run was made, `KQ_RT_GC=1` leaves it on for an A/B).
+
 Used by bench.py (the `realtime` object of the N = 1 line), tools/realtime_probe.py and tests/test_gpu_realtime.py.
 """
 import ctypes
+import gc
+import os
 import time
 
 import numpy as np
@@ -27,8 +47,13 @@ def build_bank(kq, wl, config, C, B, dev_index, stream, compute_n0=True):
     return bank, plan, time.perf_counter() - t0
 
 
+def _pct(a, q):
+    return round(float(np.percentile(a, q)), 4)
+
+
 def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.0, host_io=True, pcm=False, warm_calls=50,
-                     retunes_per_call=0, swept_channels=0, rtp_samples=0, control_plane=False, compute_n0=True):
+                     retunes_per_call=0, swept_channels=0, rtp_samples=0, control_plane=False, compute_n0=True, paced=False,
+                     compact_status=False):
     """C channels, B blocks per call, for `seconds` of wall time.  host_io: input from pinned host memory, audio (float, or
     the int16 PCM words when pcm) + status planes to pinned host memory after every call into one of three buffer sets; the
     host waits for the planes of call k-2 once it has queued call k (it never runs more than two deliveries ahead of what it
@@ -59,7 +84,8 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
             outs = [torch.zeros(C * B * 2 * olen, dtype=torch.float32).pin_memory() for _ in range(nbuf)]
         stats = [torch.zeros(C * B * ctypes.sizeof(kq.ChanStatus), dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
         nout_words = sum((2 if p.get("channels", 1) == 2 else 1) * olen for p in plan) * B
-        out_bytes = nout_words * (2 if pcm else 4) + stats[0].numel() + (4 * C * B if pcm else 0)
+        status_bytes = C * B * (kq.bank.COMPACT_STATUS_DTYPE.itemsize if (compact_status and pcm) else ctypes.sizeof(kq.ChanStatus))
+        out_bytes = nout_words * (2 if pcm else 4) + status_bytes + (4 * C * B if pcm else 0)
 
         pkts = []
         if rtp_samples:      # the batch as datagrams: header patched per call (sequence number, timestamp), payload fixed
@@ -106,34 +132,52 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
                 gone.append(c)
                 nops[0] += 1
 
-        def call(k):
+        def control(k):
             for i in range(retunes_per_call):
                 c = (k * 7919 + i * 104729) % C
                 bank.set_second_lo(c, plan[c]["second_lo"] + (1.0 if k & 1 else 0.0))
             if control_plane:
                 operate(k)
-            assert bank.process() == B
-            push_batch()
+
+        def deliver(k):
             j = k % nbuf
             if pcm:
-                bank.pull_pcm_planes_async(outs[j].data_ptr(), masks[j].data_ptr(), stats[j].data_ptr())
+                bank.pull_pcm_planes_async(outs[j].data_ptr(), masks[j].data_ptr(), stats[j].data_ptr(), compact=compact_status)
             else:
                 bank.pull_planes_async(outs[j].data_ptr(), stats[j].data_ptr())
             bank.pull_wait(2)     # the planes of call k-2 are in host memory now; calls k-1 and k are in flight
 
+        # One order of the three steps for both modes: process what was pushed before, push the batch that has just come in,
+        # queue the delivery.  (Pushing FIRST looks more natural for a paced loop and is 25-60 % slower: the input copy then
+        # sits behind the previous call's output copy kernel on a hardware queue they share and waits with it for that
+        # call's demodulators -- 1.85 / 2.45 ms per call against 1.49 at 33 792 channels, gpurun r6b; include/ka9q_hip.h
+        # "Call order for full overlap".)  Paced, the batch pushed in iteration n is the one complete at A_n and is
+        # processed in iteration n + 1: one period of pipeline delay, no effect on the schedule.
+        def call(k):
+            control(k)
+            assert bank.process() == B
+            push_batch()
+            deliver(k)
+
+        call_paced = call
+
         push_batch()
     else:
         iq_dev = torch.from_numpy(iq_host).to(dev)
+        nops = [0]
+        gone = []
 
         def call(k):
             bank.process_resident(iq_dev.data_ptr(), B)
 
-    stamps = []
+        call_paced = call
+
+    signal_s = B * L / fs
+    gc_on = os.environ.get("KQ_RT_GC", "0") == "1"
 
     def run(ncalls, k0):
         for k in range(k0, k0 + ncalls):
             call(k)
-            stamps.append(time.perf_counter())     # (with host I/O: the moment delivery k - 2 was in hand)
 
     run(warm_calls, 0)
     if host_io:
@@ -145,54 +189,122 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
         bank.host_io_wait()
     torch.cuda.synchronize()
     est = (time.perf_counter() - t0) / 8
-    ncalls = int(max(16, min(400000, seconds / max(est, 1e-6))))
     bank.host_timing(reset=True)
     bank.enable_timing(1)
     bank.timing(reset=True)
-    if host_io:
-        nops[0] = 0
-    del stamps[:]
-    t0 = time.perf_counter()
-    k = warm_calls + 8                 # by the clock, not by the estimate: the run lasts at least `seconds`
-    while True:
-        call(k)
-        stamps.append(time.perf_counter())
-        k += 1
-        n = k - (warm_calls + 8)
-        if n >= 16 and (n & 15) == 0 and (stamps[-1] - t0 >= seconds or n >= 400000):
-            break
-    ncalls = k - (warm_calls + 8)
+    nops[0] = 0
+    period = signal_s
+    cap = int(min(400000, max(64, 1.5 * seconds / (period if paced else max(est, 1e-5)) + 64)))
+    stamps = np.zeros(cap)          # when the iteration's delivery (k - 2) was in hand
+    lag = np.zeros(cap)             # paced: how long after its batch was complete the iteration started
+    gc_pauses = []
+    if not gc_on:
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+    else:                           # the A/B leg: every collection's generation and length
+        t_gc = [0.0]
+
+        def on_gc(phase, info):
+            if phase == "start":
+                t_gc[0] = time.perf_counter()
+            else:
+                gc_pauses.append((info.get("generation", -1), (time.perf_counter() - t_gc[0]) * 1e3))
+        gc.callbacks.append(on_gc)
+    k = warm_calls + 8 + 1
+    n = 0
+    try:
+        t0 = time.perf_counter()
+        if paced:
+            origin = t0 + 2e-4 - period          # A_0 = origin + period: the first batch completes 0.2 ms from now
+            while True:
+                due = origin + (n + 1) * period
+                now = time.perf_counter()
+                while now < due:                 # (a spin: sleep() comes back up to 60 us late, 4 % of a call)
+                    now = time.perf_counter()
+                lag[n] = now - due
+                call_paced(k)
+                stamps[n] = time.perf_counter()
+                k += 1
+                n += 1
+                if n >= 16 and (n & 15) == 0 and (stamps[n - 1] - t0 >= seconds or n + 16 > cap):
+                    break
+        else:
+            while True:                          # by the clock, not by the estimate: the run lasts at least `seconds`
+                call(k)
+                stamps[n] = time.perf_counter()
+                k += 1
+                n += 1
+                if n >= 16 and (n & 15) == 0 and (stamps[n - 1] - t0 >= seconds or n + 16 > cap):
+                    break
+    finally:
+        if not gc_on:
+            gc.enable()
+            gc.unfreeze()
+        else:
+            gc.callbacks.remove(on_gc)
+    ncalls = n
+    t_loop = stamps[n - 1] - t0
     if host_io:
         bank.host_io_wait()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / ncalls
+    stamps, lag = stamps[:n], lag[:n]
     # pacing as the host sees it: the intervals between consecutive deliveries (a receiver's output buffer has to ride out the
     # longest of them)
-    iv = np.diff(np.array(stamps)) * 1e3 if len(stamps) > 2 else np.zeros(1)
-    pacing = {"p50": round(float(np.percentile(iv, 50)), 4), "p99": round(float(np.percentile(iv, 99)), 4),
-              "max": round(float(iv.max()), 4)}
+    iv = np.diff(stamps) * 1e3 if n > 2 else np.zeros(1)
+    pacing = {"p50": _pct(iv, 50), "p99": _pct(iv, 99), "p99.9": _pct(iv, 99.9), "max": round(float(iv.max()), 4),
+              "longer_than_two_periods": int((iv > 2e3 * period).sum())}
+    deadline = None
+    if paced:
+        due = origin + (np.arange(n) + 1) * period
+        late_by = stamps - due - period            # delivery n - 2, due with the start of iteration n; > 0: a period behind
+        backlog = np.floor(lag / period)
+        skip = min(n // 4, int(0.5 / period))      # the first half second is warm-up of the pacing itself
+        deadline = {"period_ms": round(period * 1e3, 4), "deliveries": int(n - skip),
+                    "late_deliveries": int((late_by[skip:] > 0).sum()),
+                    "worst_lateness_ms": round(float(max(0.0, late_by[skip:].max())) * 1e3, 4),
+                    "backlog_calls": {"p99.9": _pct(backlog[skip:], 99.9), "max": int(backlog[skip:].max())},
+                    "start_lag_ms": {"p50": _pct(lag[skip:] * 1e3, 50), "p99.9": _pct(lag[skip:] * 1e3, 99.9),
+                                     "max": round(float(lag[skip:].max()) * 1e3, 4)},
+                    "host_busy_fraction": round(float(1.0 - np.clip(due[skip + 1:] - stamps[skip:-1], 0, None).sum() /
+                                                      max(1e-9, stamps[-1] - due[skip])), 4),
+                    "definition": "batch n is complete at A_n = origin + (n + 1) period; iteration n starts then (or as soon as "
+                                  "the loop is free), pushes / processes / queues batch n and takes delivery n - 2; late = that "
+                                  "delivery in hand after A_n + period; backlog = whole periods the iteration started behind A_n"}
+    bank_worst_holder = bank.worst_lock_holder()
     ht = bank.host_timing(reset=True)
     tm = bank.timing(reset=True)
     bank.enable_timing(0)
     checksum = None
     if host_io:
-        j = (warm_calls + 8 + ncalls - 1) % nbuf
-        st = np.frombuffer(stats[j].numpy().tobytes(), dtype=kq.bank.STATUS_DTYPE).reshape(C, B)
+        j = (k - 1) % nbuf
+        if compact_status and pcm:
+            st = np.frombuffer(stats[j].numpy().tobytes()[:C * B * kq.bank.COMPACT_STATUS_DTYPE.itemsize],
+                               dtype=kq.bank.COMPACT_STATUS_DTYPE).reshape(C, B)
+        else:
+            st = np.frombuffer(stats[j].numpy().tobytes(), dtype=kq.bank.STATUS_DTYPE).reshape(C, B)
         a = outs[j].numpy().reshape(C, B, 2 * olen)
         if gone:           # (the channel that is away right now still shows its last delivery: not counted)
             st = np.delete(st, gone[0], axis=0)
-        checksum = {"nout_sum": int(st["nout"].sum()), "squelch_open": int((st["squelch_count"] < 2).sum()),
+        sq = st["state"] if (compact_status and pcm) else st["squelch_count"]
+        checksum = {"nout_sum": int(st["nout"].sum()), "squelch_open": int((sq < 2).sum()),
                     "audio_abs_sum": float(np.abs(a[::max(1, C // 997), :, :olen].astype(np.float64)).sum())}
     bank.close()
-    signal_s = B * L / fs
     return {"config": config, "channels": C, "blocks_per_call": B, "compute_n0": int(bool(compute_n0)), "signal_ms_per_call": round(signal_s * 1e3, 4),
             "ms_per_call": round(dt * 1e3, 4), "realtime_factor": round(signal_s / dt, 4), "calls": ncalls,
-            "wall_s": round(dt * ncalls, 2), "delivery_interval_ms": pacing,
+            "wall_s": round(dt * ncalls, 2), "paced": bool(paced), "deadline": deadline, "delivery_interval_ms": pacing,
+            "gc": ({"collections": len(gc_pauses), "longest_ms": round(max([p[1] for p in gc_pauses] or [0.0]), 3),
+                    "longest_generation": max(gc_pauses or [(-1, 0.0)], key=lambda p: p[1])[0]} if gc_on else
+                   "frozen and off inside the timed loop"),
+            "worst_lock_holder": bank_worst_holder,
             "filter_kernel_ms": round(tm["filter_ms"] / max(1, tm["filter_launches"]), 4),
             "host_ms_per_call": round(ht["call_ms"] / max(1, ht["calls"]), 4),
             "host_stage_ms_per_call": round(ht["stage_ms"] / max(1, ht["calls"]), 4),
             "host_slot_wait_ms_per_call": round(ht["slot_wait_ms"] / max(1, ht["calls"]), 4),
-            "host_io": ("pcm int16 + status" if pcm else "float audio + status") if host_io else None,
+            "lock_wait_max_ms": round(ht["lock_wait_max_ms"], 4), "ctl_hold_max_ms": round(ht["ctl_hold_max_ms"], 4),
+            "host_io": (("pcm int16 + compact status (24 B)" if compact_status else "pcm int16 + status") if pcm else
+                        "float audio + status") if host_io else None,
             "d2h_bytes_per_call": out_bytes, "d2h_GBps": round(out_bytes / dt / 1e9, 3),
             "h2d_bytes_per_call": B * L * 8 if host_io else 0,
             "input": ("RTP datagrams of %d int16 I/Q samples (kq_bank_push_rtp)" % rtp_samples) if rtp_samples else

@@ -52,28 +52,37 @@ def test_radio_fanout_c_example_runs_with_a_world_of_one(gpu):
     assert row[0] == "0" and float(row[1]) > 0 and float(row[2]) > 0 and float(row[1]) >= float(row[2]), row
 
 
-@pytest.mark.parametrize("pcm,operator", [(1, 0), (0, 0), (1, 1)])
-def test_radio_realtime_c_example(gpu, pcm, operator):
+@pytest.mark.parametrize("pcm,operator,paced", [(1, 0, 0), (0, 0, 0), (1, 1, 0), (1, 1, 1), (0, 0, 1)])
+def test_radio_realtime_c_example(gpu, pcm, operator, paced):
     """examples/radio_realtime.c: 8192 channels from plain C in the receiver's loop -- process, push the next batch, queue the
     delivery (int16 PCM words + silent masks, or floats), wait for the delivery two back -- set up with one
     kq_bank_add_channels call; every delivered channel-block carries olen samples with the squelch open, and the bank keeps
-    up with real time (8192 channels are a quarter of what one GPU carries).  operator = 1: filter changes, a channel dropped and
-    brought back, retunes between the calls in flight (~1000 a second) -- none of which may cost the loop its pace."""
+    up with real time (8192 channels are a quarter of what one GPU carries).  operator = 1: a second thread changes filters,
+    drops a channel and brings it back, retunes (~1000 operations a second) beside the calls in flight -- none of which may
+    cost the loop its pace: the receiver's worst wait for the handle's lock stays far below a call period.  paced = 1: the
+    batches arrive by the clock (one per 1.64 ms) and every delivery has to be on time: zero late, no backlog."""
     lib = os.path.join(ROOT, "ka9q_sdr_amd", "lib")
-    out = os.path.join(tempfile.gettempdir(), "kq_radio_realtime_example_%d_%d_%d" % (os.getpid(), pcm, operator))
+    out = os.path.join(tempfile.gettempdir(), "kq_radio_realtime_example_%d_%d_%d_%d" % (os.getpid(), pcm, operator, paced))
     r = subprocess.run(["gcc", "-std=gnu11", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "examples", "radio_realtime.c"), "-L", lib, "-lka9q_hip", "-Wl,-rpath," + lib,
-                        "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", out], capture_output=True, text=True)   # (no HIP library on the line)
+                        "-Wl,-rpath,/opt/rocm/lib", "-lm", "-lpthread", "-o", out], capture_output=True, text=True)   # (no HIP library on the line)
     assert r.returncode == 0, r.stderr
     try:
-        run = subprocess.run([out, "8192", "2", "1.5", str(pcm), str(operator)], capture_output=True, text=True, timeout=300)
+        run = subprocess.run([out, "8192", "2", "2.5" if paced else "1.5", str(pcm), str(operator), str(paced)],
+                             capture_output=True, text=True, timeout=300)
     finally:
         os.unlink(out)
     assert run.returncode == 0, run.stdout + run.stderr
     lines = run.stdout.strip().splitlines()
     assert lines[-1] == "ok", run.stdout
     rt = [ln for ln in lines if "x real time" in ln]
-    assert len(rt) == 1 and float(rt[0].split("=")[-1].split("x")[0]) > 2.0, rt
+    factor = float(rt[0].split("=")[-1].split("x")[0])
+    assert len(rt) == 1 and (0.995 < factor < 1.005 if paced else factor > 2.0), rt
     if operator:
-        op = [ln for ln in lines if ln.startswith("operator:")]
+        op = [ln for ln in lines if ln.startswith("operator thread:")]
         assert len(op) == 1 and float(op[0].split("=")[1].split()[0]) > 500, op
+        worst_wait = float(op[0].split("worst")[2].split("ms")[0])
+        assert worst_wait < 0.8, op             # half a call period
+    if paced:
+        dl = [ln for ln in lines if ln.startswith("deadline:")]
+        assert len(dl) == 1 and dl[0].startswith("deadline: 0 of ") and "deepest backlog 0 periods" in dl[0], dl

@@ -510,7 +510,8 @@ def test_full_bank_of_distinct_edges_changes_every_filter(gpu, L, D, C):
     for k in range(ncalls):
         for c in range(C):
             for b in range(nb):
-                assert got[0][k][0][c][b] == got[1][k][0][c][b], (k, c, b)
+                sa, sb = got[0][k][0][c][b], got[1][k][0][c][b]
+                assert all(np.array_equal(sa[f], sb[f], equal_nan=True) for f in sa), (k, c, b, sa, sb)
                 assert np.array_equal(got[0][k][1][c][b], got[1][k][1][c][b]), (k, c, b)
     for c in range(C):
         ch = ko.Channel(oracle_cfg(plan[c], fs, L, g["M"], D, compute_n0=1))

@@ -282,6 +282,28 @@ def test_pcm_planes_straight_to_the_host(gpu):
             clipped += int(np.sum(np.abs(a) >= 1.0))
             silent += bin(wmask).count("1")
     assert clipped > 0 and silent > 0
+    # the same delivery with the 24-byte records a receiver reads per block (kq_bank_pull_pcm_planes_compact_async): words and
+    # masks unchanged, every field equal to the full record's -- FM: foffset / squelch counter, linear: agc.gain / hang counter;
+    # C * nb = 24 records, so the plane ends in an odd record behind the last whole 16-byte piece
+    pcm2 = _pinned(C * nb * 2 * olen, torch.int16)
+    mask2 = _pinned(C * nb, torch.int32)
+    comp = _pinned(C * nb * kq.bank.COMPACT_STATUS_DTYPE.itemsize + 64, torch.uint8)
+    comp.fill_(0xA5)
+    bank.pull_pcm_planes_async(pcm2.data_ptr(), mask2.data_ptr(), comp.data_ptr(), compact=True)
+    bank.pull_wait(0)
+    nbytes = C * nb * kq.bank.COMPACT_STATUS_DTYPE.itemsize
+    assert kq.bank.COMPACT_STATUS_DTYPE.itemsize == 24
+    assert bytes(comp.numpy()[nbytes:]) == b"\xa5" * 64              # nothing written past the plane
+    cs = np.frombuffer(comp.numpy()[:nbytes].tobytes(), dtype=kq.bank.COMPACT_STATUS_DTYPE).reshape(C, nb)
+    assert np.array_equal(pcm2.numpy(), pcm.numpy()) and np.array_equal(mask2.numpy(), mask.numpy())
+    for c, p in enumerate(plan):
+        fm = p["demod"] == "fm"
+        for b in range(nb):
+            full = st[c, b]
+            for f in ("bb_power", "n0", "snr", "nout"):
+                assert np.array_equal(cs[c, b][f], full[f], equal_nan=True), (c, b, f)
+            assert np.array_equal(cs[c, b]["aux"], full["foffset" if fm else "agc_gain"], equal_nan=True), (c, b)
+            assert cs[c, b]["state"] == full["squelch_count" if fm else "hangcount"], (c, b)
     with pytest.raises(kq.KqError):
         bank.pull_wait(8)               # only the last eight deliveries are remembered
     bank.close()

@@ -36,18 +36,22 @@ def main():
     ap.add_argument("--swept", type=int, default=0, help="channels with a swept Doppler oscillator (rate != 0)")
     ap.add_argument("--rtp", type=int, default=0, help="input as RTP datagrams of this many int16 I/Q samples (kq_bank_push_rtp)")
     ap.add_argument("--control-plane", action="store_true", help="filter / mode changes and a channel leaving and returning around every call")
+    ap.add_argument("--paced", action="store_true", help="batches arrive by the wall clock at the front end's rate: deadline accounting "
+                    "(late deliveries, backlog) instead of a mean factor")
+    ap.add_argument("--compact", action="store_true", help="with --pcm: 24-byte status records (kq_bank_pull_pcm_planes_compact_async)")
     a = ap.parse_args()
     import torch
     import ka9q_sdr_amd as kq
     from ka9q_sdr_amd import workload as wl
-    from ka9q_sdr_amd.realtime import measure_realtime
+    from realtime_harness import measure_realtime
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     for C in [int(x) for x in a.channels.split(",")]:
         for B in [int(x) for x in a.blocks.split(",")]:
             r = measure_realtime(torch, kq, wl, a.config, C, B, 0, stream, seconds=a.seconds, host_io=not a.no_io, pcm=a.pcm,
-                                 retunes_per_call=a.retunes, swept_channels=a.swept, rtp_samples=a.rtp, control_plane=a.control_plane)
+                                 retunes_per_call=a.retunes, swept_channels=a.swept, rtp_samples=a.rtp, control_plane=a.control_plane,
+                                 paced=a.paced, compact_status=a.compact)
             print(json.dumps(r), flush=True)
 
 

@@ -186,6 +186,8 @@ int main(int argc, char **argv){
   int rc = 0;
   size_t const cap = (size_t)(seconds / signal_s * 1.5) + 1024;   /* per-call records of the timed part */
   double *stamp = malloc(cap * sizeof *stamp), *lag = malloc(cap * sizeof *lag);
+  float (*step)[4] = malloc(cap * sizeof *step);       /* ms inside process / push / queueing the delivery / waiting for delivery k - 2 */
+  kq_bank_enable_timing(bank, 1);
   struct operator_args op = { .bank = bank, .cc = cc, .C = C, .period_s = signal_s };
   pthread_t op_tid;
   int op_started = 0;
@@ -215,12 +217,25 @@ int main(int argc, char **argv){
     }
     /* (process first, then push: an input copy queued behind the previous call's output copy would wait with it for that
      * call's demodulators -- ka9q_hip.h "Call order for full overlap") */
-    if(kq_bank_process(bank) != (int)B || kq_bank_push_iq_async(bank, in, nin, KQ_IQ_CF32) != 0)
+    double const p0 = now_s();
+    if(kq_bank_process(bank) != (int)B)
       rc = 1;
+    double const p1 = now_s();
+    if(rc == 0 && kq_bank_push_iq_async(bank, in, nin, KQ_IQ_CF32) != 0)
+      rc = 1;
+    double const p2 = now_s();
     if(rc == 0 && (pcm ? kq_bank_pull_pcm_planes_async(bank, out[j], mask[j], st[j]) : kq_bank_pull_planes_async(bank, out[j], st[j])))
       rc = 1;
-    else if(rc == 0 && kq_bank_pull_wait(bank, 2) != 0)      /* delivery k - 2 has landed: out[(k - 2) % 3] is the host's to read */
+    double const p3 = now_s();
+    if(rc == 0 && kq_bank_pull_wait(bank, 2) != 0)           /* delivery k - 2 has landed: out[(k - 2) % 3] is the host's to read */
       rc = 1;
+    if(k >= warm && (size_t)calls < cap){
+      double const p4 = now_s();
+      step[calls][0] = (float)(1e3 * (p1 - p0));
+      step[calls][1] = (float)(1e3 * (p2 - p1));
+      step[calls][2] = (float)(1e3 * (p3 - p2));
+      step[calls][3] = (float)(1e3 * (p4 - p3));
+    }
     if(op.failed)
       rc = 1;
     if(k >= warm){
@@ -268,6 +283,43 @@ int main(int argc, char **argv){
     if(niv > 0)
       printf("delivery intervals: p50 %.3f  p99 %.3f  p99.9 %.3f  max %.3f ms\n", 1e3 * iv[niv / 2], 1e3 * iv[(size_t)(0.99 * (niv - 1))],
              1e3 * iv[(size_t)(0.999 * (niv - 1))], 1e3 * iv[niv - 1]);
+    {                                   /* where the longest interval went: the host's four steps of that iteration */
+      size_t worst = skip + 1;
+      for(size_t i = skip + 1; i < n; i++)
+        if(stamp[i] - stamp[i - 1] > stamp[worst] - stamp[worst - 1])
+          worst = i;
+      {                                 /* when the eight longest intervals happened: a period would point at a timer */
+        size_t top[8];
+        size_t ntop = 0;
+        for(size_t i = skip + 1; i < n; i++){
+          double const d = stamp[i] - stamp[i - 1];
+          if(d < 1.5 * signal_s)
+            continue;
+          if(i > skip + 1 && stamp[i - 1] - stamp[i - 2] >= 1.5 * signal_s)
+            continue;                   /* (the iterations that catch up behind a stall are part of it) */
+          if(ntop < 8)
+            top[ntop++] = i;
+          else {
+            size_t m = 0;
+            for(size_t q = 1; q < 8; q++)
+              if(stamp[top[q]] - stamp[top[q] - 1] < stamp[top[m]] - stamp[top[m] - 1])
+                m = q;
+            if(d > stamp[top[m]] - stamp[top[m] - 1])
+              top[m] = i;
+          }
+        }
+        printf("stalls (intervals beyond 1.5 periods, the longest %zu): at", ntop);
+        for(size_t q = 0; q < ntop; q++)
+          printf(" %.2f s (%.2f ms)", stamp[top[q]] - t0, 1e3 * (stamp[top[q]] - stamp[top[q] - 1]));
+        printf("\n");
+      }
+      kq_timing tm;
+      kq_bank_get_timing(bank, &tm, 0);
+      if(worst < n)
+        printf("longest interval (%.3f ms, call %zu): process %.3f, push %.3f, queueing the delivery %.3f, waiting for delivery k-2 %.3f ms; "
+               "longest filter pass on the device %.3f ms (mean %.3f)\n", 1e3 * (stamp[worst] - stamp[worst - 1]), worst, step[worst][0],
+               step[worst][1], step[worst][2], step[worst][3], tm.filter_max_ms, tm.filter_ms / (double)(tm.filter_launches ? tm.filter_launches : 1));
+    }
     if(paced){
       long late = 0, backlog_max = 0;
       double worst = 0;
@@ -298,6 +350,7 @@ int main(int argc, char **argv){
          pcm ? "int16 PCM" : "float audio", d2h / per_call / 1e9);
   free(stamp);
   free(lag);
+  free(step);
 
   /* ---- a delivered plane: every channel reports olen samples per block; channel 5 sits on a carrier */
   int const jl = (int)((warm + calls - 1 + (op_started ? 1 : 0)) % 3);

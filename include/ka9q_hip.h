@@ -140,6 +140,8 @@ typedef struct kq_timing {
   double ingest_ms;        /* format conversion + IF power */
   uint64_t filter_launches;
   uint64_t channel_blocks; /* channel-blocks processed by the filter kernel */
+  double filter_max_ms;    /* the longest single filter pass of a call since the last reset (timing level 1: the marker pair
+                              around the call's filter kernels) -- a stall of the device shows here, one of the host does not */
 } kq_timing;
 
 const char *kq_last_error(void);

@@ -877,8 +877,11 @@ int harvest_slot(kq_bank *b, int slot) {
   b->stage_timed[slot] = false;
   float ms = 0;
   // (a call that failed between the two records leaves an interval that does not exist: dropped, not an error of this call)
-  if (hipEventElapsedTime(&ms, b->stage_t0[slot], b->stage_ev[slot]) == hipSuccess && ms > 0) b->acc.filter_ms += ms;
-  else (void)hipGetLastError();
+  if (hipEventElapsedTime(&ms, b->stage_t0[slot], b->stage_ev[slot]) == hipSuccess && ms > 0) {
+    b->acc.filter_ms += ms;
+    if (ms > b->acc.filter_max_ms) b->acc.filter_max_ms = ms;
+  } else
+    (void)hipGetLastError();
   return 0;
 }
 
@@ -1534,8 +1537,11 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     return nullptr;
   }
   unsigned const N = cfg->L + cfg->M - 1;
-  if (cfg->L == 0 || cfg->M < 2 || (N & (N - 1)) != 0 || N < 16) {
-    set_err("L+M-1 = %u must be a power of two >= 16", N);
+  // FFTW plans any N (filter.c:78); here a power of two, or -- on the generic kernels, one LDS block -- an even 2^a 3^b 5^c
+  // up to 16384 (a front end whose rate is not 48 kHz x 2^k: 240 kHz gives decimate 5, radio_status.c:266)
+  bool const n_pow2 = (N & (N - 1)) == 0;
+  if (cfg->L == 0 || cfg->M < 2 || N < 16 || (!n_pow2 && (!kq::fft_size_ok((int)N) || N > 16384))) {
+    set_err("L+M-1 = %u must be a power of two >= 16, or an even 2^a 3^b 5^c in 16..16384", N);
     return nullptr;
   }
   if (cfg->decimate < 2 || N % cfg->decimate != 0 || cfg->L % cfg->decimate != 0 || (cfg->M - 1) % cfg->decimate != 0) {
@@ -1543,8 +1549,8 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     return nullptr;
   }
   unsigned const Ndec = N / cfg->decimate;
-  if ((Ndec & (Ndec - 1)) != 0 || Ndec < 4) {
-    set_err("N/decimate = %u must be a power of two >= 4", Ndec);
+  if (Ndec < 4 || ((Ndec & (Ndec - 1)) != 0 && (!kq::fft_size_ok((int)Ndec) || Ndec > 16384))) {
+    set_err("N/decimate = %u must be a power of two >= 4, or an even 2^a 3^b 5^c in 4..16384", Ndec);
     return nullptr;
   }
   if (cfg->max_channels == 0 || cfg->max_blocks == 0 || cfg->samprate <= 0) {
@@ -1589,9 +1595,22 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   {
     // pltask geometry (fm.c:201-205): decimate 32 from the audio master; needs a usable transform size
     int const pn = g.Ndec / 32, plen = g.olen / 32;
-    bool const ok = pn >= 4 && plen >= 1 && (pn & (pn - 1)) == 0 && !cfg->pl_tone_off;
+    // (a size that 32 does not divide has no PL slave: create_filter_output would warn and truncate, filter.c:106-107)
+    bool const ok = pn >= 4 && plen >= 1 && !cfg->pl_tone_off &&
+                    ((pn & (pn - 1)) == 0 || (g.Ndec % 32 == 0 && g.olen % 32 == 0 && kq::fft_size_ok(pn)));
     g.pl_n = ok ? pn : 0;
     g.pl_l = ok ? plen : 0;
+  }
+  {  // the generic path's transform plans (powers of two: no tables)
+    bool ok_n = false, ok_d = false, ok_p = true;
+    g.dN = kq::fft_dim(g.N, &ok_n);
+    g.dNdec = kq::fft_dim(g.Ndec, &ok_d);
+    g.dPl = g.pl_n > 0 ? kq::fft_dim(g.pl_n, &ok_p) : kq::FftDim{};
+    if (!ok_n || !ok_d || !ok_p) {
+      set_err("transform plan for N = %d / N/decimate = %d failed", g.N, g.Ndec);
+      delete b;
+      return nullptr;
+    }
   }
   g.max_blocks = (int)cfg->max_blocks;
   g.dsamprate = (float)cfg->samprate / cfg->decimate;

@@ -73,6 +73,7 @@ int ilog2(unsigned v) {
 
 struct MasterDev {
   int N, log2N;
+  kq::FftDim dim;
   float2 *d_in = nullptr, *d_fdomain = nullptr;
   float2 *d_tmp = nullptr;  // N > 16384: scratch of the two-pass transform
   std::vector<float2> stage;
@@ -151,8 +152,10 @@ float kq_compat_compute_n0(struct filter_in *m, int samprate, float low, float h
 
 struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filtertype in_type) {
   unsigned const N = L + M - 1;
-  if (L == 0 || M == 0 || (N & (N - 1)) != 0 || N > (1u << 22) || N < 4) {
-    fprintf(stderr, "ka9q_hip: create_filter_input: N=%u must be a power of two in 4..4194304\n", N);
+  // FFTW plans any N (filter.c:78); here: a power of two up to 2^22, or 2^a 3^b 5^c (even) up to 65536
+  bool const pow2 = (N & (N - 1)) == 0;
+  if (L == 0 || M == 0 || N < 4 || (pow2 ? N > (1u << 22) : !kq::fft_size_ok((int)N))) {
+    fprintf(stderr, "ka9q_hip: create_filter_input: N=%u must be a power of two in 4..4194304 or an even 2^a 3^b 5^c up to 65536\n", N);
     return NULL;
   }
   if (!ctx_init()) return NULL;
@@ -171,7 +174,10 @@ struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filte
   MasterDev *d = new MasterDev();
   d->N = (int)N;
   d->log2N = ilog2(N);
-  d->tw = twiddles(d->log2N);
+  d->tw = twiddles(d->log2N);  // (half-circle table of the next power of two: lds_fft's; also what the slaves are handed)
+  bool dim_ok = false;
+  d->dim = kq::fft_dim((int)N, &dim_ok);
+  if (!dim_ok) d->tw = nullptr;
   d->stage.resize(N);
   if (!d->tw || hipMalloc((void **)&d->d_in, N * sizeof(float2)) != hipSuccess ||
       hipMalloc((void **)&d->d_fdomain, N * sizeof(float2)) != hipSuccess ||
@@ -214,10 +220,10 @@ int execute_filter_input(struct filter_in *m) {
     std::lock_guard<std::mutex> lk(d->in_mu);
     if (hipMemcpyAsync(d->d_in, src, N * sizeof(float2), hipMemcpyHostToDevice, s) != hipSuccess) return -1;
     d->in_block = m->blocknum + 1;  // only this thread moves blocknum (below, once the transform is done)
-    if (N > 16384)
-      kq::launch_fft_large(s, d->d_in, d->d_fdomain, d->d_tmp, d->log2N, -1, d->tw, d->log2N);
-    else
-      kq::launch_fft_single(s, d->d_in, d->d_fdomain, d->log2N, -1, d->tw, d->log2N);
+    if (N > 16384) {
+      if (kq::launch_fft_large(s, d->d_in, d->d_fdomain, d->d_tmp, N, -1, d->tw, d->log2N)) return -1;
+    } else
+      kq::launch_fft_single(s, d->d_in, d->d_fdomain, d->dim, -1, d->tw, d->log2N);
   }
   size_t const bins = (m->in_type == REAL) ? N / 2 + 1 : N;
   if (hipMemcpyAsync(m->fdomain, d->d_fdomain, bins * sizeof(float2), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
@@ -270,9 +276,13 @@ struct filter_out *create_filter_output(struct filter_in *master, kq_cfloat *res
   int const N = (int)(master->ilen + master->impulse_length - 1);
   int const nd = N / (int)decimate;
   if ((N % decimate) != 0) fprintf(stderr, "Warning: FFT size %d is not divisible by decimation ratio %u\n", N, decimate);
-  if ((nd & (nd - 1)) != 0 || nd < 4 || nd > 16384) {
-    fprintf(stderr, "ka9q_hip: create_filter_output: N/decimate=%d must be a power of two in 4..16384\n", nd);
-    return NULL;
+  {
+    bool dim_ok = false;
+    if (nd >= 4 && nd <= 16384) (void)kq::fft_dim(nd, &dim_ok);  // (makes and caches the plan the slave's kernel will ask for)
+    if (!dim_ok) {
+      fprintf(stderr, "ka9q_hip: create_filter_output: N/decimate=%d must be an even 2^a 3^b 5^c in 4..16384\n", nd);
+      return NULL;
+    }
   }
   struct filter_out *s = (struct filter_out *)calloc(1, sizeof(*s));
   if (!s) return NULL;

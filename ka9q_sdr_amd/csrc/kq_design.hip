@@ -60,7 +60,7 @@ __global__ void k_kaiser(float *__restrict__ w, int M, float beta) {
 // grid: one workgroup per response.  REAL: the taps are real (window_rfilter): the spectrum is N/2+1 bins in and out.
 // dynamic LDS: N float2
 template <bool REAL>
-__global__ void k_design(int log2n, int M, int spec, const DesignJob *__restrict__ jobs, const float2 *__restrict__ given,
+__global__ void k_design(FftDim dim, int M, int spec, const DesignJob *__restrict__ jobs, const float2 *__restrict__ given,
                          float2 *__restrict__ out, float2 *__restrict__ scratch, float *__restrict__ sumsq, int nsum,
                          const float2 *__restrict__ tw, int tw_log2, const DesignTarget *__restrict__ targets,
                          const unsigned char *__restrict__ ctlq, unsigned njobs) {
@@ -72,7 +72,7 @@ __global__ void k_design(int log2n, int M, int spec, const DesignJob *__restrict
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   __shared__ float red_f[16];
   __shared__ int red_i[16];
-  int const N = 1 << log2n, nbins = REAL ? N / 2 + 1 : N;
+  int const N = dim.n, nbins = REAL ? N / 2 + 1 : N;
   DesignJob const job = jobs[blockIdx.x];
   const float2 *in = given ? given + (size_t)blockIdx.x * nbins : nullptr;
   float2 *res = targets ? static_cast<float2 *>(targets[blockIdx.x].resp) : out + (size_t)blockIdx.x * nbins;
@@ -95,16 +95,16 @@ __global__ void k_design(int log2n, int M, int spec, const DesignJob *__restrict
     } else {
       s = in[i];
     }
-    lds[bitrev((unsigned)i, log2n)] = s;
+    lds[fft_pos((unsigned)i, dim)] = s;
   }
-  lds_fft<+1>(lds, log2n, tw, tw_log2);
+  fft_any<+1>(lds, dim, tw, tw_log2);
 
   // ---- taps: rotate by M/2 so the response is causal, window, scale by 1/N (filter.c:377-386); zero beyond M
   float const inv_n = 1.0f / (float)N;
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
     float2 t = make_float2(0.f, 0.f);
     if (n < M) {
-      float2 const x = lds[(n - M / 2 + N) & (N - 1)];
+      float2 const x = lds[(n - M / 2 + N) % N];
       float const w = kaiser_tap(n, M, job.beta);
       t = REAL ? make_float2(x.x * w * inv_n, 0.f) : make_float2(x.x * w * inv_n, x.y * w * inv_n);
     }
@@ -114,9 +114,9 @@ __global__ void k_design(int log2n, int M, int spec, const DesignJob *__restrict
   __syncthreads();
   for (int n = threadIdx.x; n < N; n += blockDim.x) {  // read back what other threads of the workgroup just wrote
     const volatile float *q = reinterpret_cast<const volatile float *>(taps + n);
-    lds[bitrev((unsigned)n, log2n)] = make_float2(q[0], q[1]);
+    lds[fft_pos((unsigned)n, dim)] = make_float2(q[0], q[1]);
   }
-  lds_fft<-1>(lds, log2n, tw, tw_log2);
+  fft_any<-1>(lds, dim, tw, tw_log2);
 
   // ---- response, and the sum of |H|^2 noise_gain is built from (filter.c:472-497: nsum bins)
   float acc = 0;
@@ -155,6 +155,77 @@ const float2 *design_twiddles(int log2T) {
   tabs[{dev, log2T}] = d;
   return d;
 }
+
+}  // namespace
+
+bool fft_size_ok(int n) {
+  if (n < 2 || n > 65536 || (n & 1)) return false;
+  for (int p : {2, 3, 5})
+    while (n % p == 0) n /= p;
+  return n == 1;
+}
+
+// The plan of an n-point transform on the generic path, tables on the current device (cached per device and size)
+FftDim fft_dim(int n, bool *ok) {
+  FftDim d{};
+  d.n = n;
+  d.log2n = -1;
+  if (ok) *ok = false;
+  if (n >= 1 && (n & (n - 1)) == 0) {
+    d.log2n = 0;
+    while ((1 << d.log2n) < n) d.log2n++;
+    if (ok) *ok = true;
+    return d;
+  }
+  if (!fft_size_ok(n)) return d;
+  {  // radices: 4s first (fewest passes), then 2, 3s, 5s
+    int m = n;
+    while (m % 4 == 0) d.f[d.nf++] = 4, m /= 4;
+    while (m % 2 == 0) d.f[d.nf++] = 2, m /= 2;
+    while (m % 3 == 0) d.f[d.nf++] = 3, m /= 3;
+    while (m % 5 == 0) d.f[d.nf++] = 5, m /= 5;
+  }
+  static std::mutex mu;
+  static std::map<std::pair<int, int>, std::pair<const unsigned short *, const float2 *>> tabs;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return d;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = tabs.find({dev, n});
+  if (it == tabs.end()) {
+    std::vector<unsigned short> rev(n);
+    for (int p = 0; p < n; p++) {  // position p = sum_k d_k prod_{j<k} f_j holds index i = sum_k d_k n / prod_{j<=k} f_j
+      int rest = p, weight = n, i = 0;
+      for (int k = 0; k < d.nf; k++) {
+        weight /= d.f[k];
+        i += (rest % d.f[k]) * weight;
+        rest /= d.f[k];
+      }
+      rev[i] = (unsigned short)p;
+    }
+    std::vector<float2> tw(n);
+    for (int k = 0; k < n; k++) {
+      double const a = -2.0 * M_PI * (double)k / (double)n;
+      tw[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    unsigned short *drev = nullptr;
+    float2 *dtw = nullptr;
+    if (hipMalloc((void **)&drev, n * sizeof(unsigned short)) != hipSuccess || hipMalloc((void **)&dtw, n * sizeof(float2)) != hipSuccess ||
+        hipMemcpy(drev, rev.data(), n * sizeof(unsigned short), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dtw, tw.data(), n * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) {
+      if (drev) (void)hipFree(drev);
+      if (dtw) (void)hipFree(dtw);
+      return d;
+    }
+    it = tabs.emplace(std::make_pair(dev, n), std::make_pair((const unsigned short *)drev, (const float2 *)dtw)).first;
+  }
+  d.rev = it->second.first;
+  d.twc = it->second.second;
+  d.tw_n = n;
+  if (ok) *ok = true;
+  return d;
+}
+
+namespace {
 
 // Workspace of the design kernels: per device, grown on demand, never freed.  (hipMalloc / hipFree around every design --
 // round 1's form -- made each retune a device-wide synchronisation: hipFree waits for everything in flight, so
@@ -208,10 +279,11 @@ Workspace *workspace() {
 int design_batch(int L, int M, bool real_taps, int spec, const std::vector<DesignJob> &jobs, const cfloat *given,
                  std::vector<cfloat> &out, std::vector<float> *sumsq, int nsum) {
   int const N = L + M - 1;
-  int log2n = 0;
-  while ((1 << log2n) < N) log2n++;
-  if (N < 2 || (1 << log2n) != N || N > 16384 || M < 1 || jobs.empty()) {
-    kq_internal_set_error("response design: N = %d must be a power of two in 2..16384", N);
+  bool dim_ok = false;
+  FftDim const dim = (N >= 2 && N <= 16384) ? fft_dim(N, &dim_ok) : FftDim{};
+  int const log2n = dim.log2n >= 0 ? dim.log2n : 1;  // (the half-circle table is only read for powers of two)
+  if (!dim_ok || M < 1 || jobs.empty()) {
+    kq_internal_set_error("response design: N = %d must be 2^a 3^b 5^c in 2..16384", N);
     return -1;
   }
   int ndev = 0;
@@ -244,7 +316,7 @@ int design_batch(int L, int M, bool real_taps, int spec, const std::vector<Desig
     int const threads = N >= 1024 ? 256 : 64;
     auto go = [&](auto kernel) {
       ensure_dynamic_lds((const void *)kernel, lds_bytes);
-      hipLaunchKernelGGL(kernel, dim3((unsigned)count), dim3(threads), lds_bytes, st, log2n, M, spec, (const DesignJob *)w->buf[0],
+      hipLaunchKernelGGL(kernel, dim3((unsigned)count), dim3(threads), lds_bytes, st, dim, M, spec, (const DesignJob *)w->buf[0],
                          (const float2 *)(given ? w->buf[1] : nullptr), (float2 *)w->buf[2], (float2 *)w->buf[3], (float *)w->buf[4],
                          nsum, tw, log2n, (const DesignTarget *)nullptr, (const unsigned char *)nullptr, (unsigned)count);
     };
@@ -319,23 +391,25 @@ int design_responses(int N, int L_dec, int M_dec, int out_type, const std::vecto
 // M_dec - 1) float2 of device memory.  The twiddle table of this size must exist (design_prepare, which may block).
 int design_prepare(int L_dec, int M_dec) {
   int const N = L_dec + M_dec - 1;
-  int log2n = 0;
-  while ((1 << log2n) < N) log2n++;
-  if (N < 2 || (1 << log2n) != N || N > 16384) return -1;
-  return design_twiddles(log2n) ? 0 : -1;
+  if (N < 2 || N > 16384) return -1;
+  bool ok = false;
+  FftDim const dim = fft_dim(N, &ok);
+  if (!ok) return -1;
+  return design_twiddles(dim.log2n >= 0 ? dim.log2n : 1) ? 0 : -1;
 }
 int design_launch(void *stream, int L_dec, int M_dec, const DesignJob *jobs, const DesignTarget *targets, unsigned count,
                   void *scratch, const void *ctl_queue, unsigned ctl_records) {
   int const N = L_dec + M_dec - 1;
-  int log2n = 0;
-  while ((1 << log2n) < N) log2n++;
+  bool dim_ok = false;
+  FftDim const dim = fft_dim(N, &dim_ok);  // (cached since design_prepare: no allocation here)
+  int const log2n = dim.log2n >= 0 ? dim.log2n : 1;
   hipStream_t const st = static_cast<hipStream_t>(stream);
   const float2 *tw = design_twiddles(log2n);
-  if (!tw || count == 0) return tw ? 0 : -1;
+  if (!tw || !dim_ok || count == 0) return (tw && dim_ok) ? 0 : -1;
   size_t const lds_bytes = (size_t)N * sizeof(float2);
   ensure_dynamic_lds((const void *)k_design<false>, lds_bytes);
   if (!ctl_queue) ctl_records = 0;
-  hipLaunchKernelGGL(k_design<false>, dim3(count + ctl_records), dim3(N >= 1024 ? 256 : 64), lds_bytes, st, log2n, M_dec, (int)SPEC_BAND,
+  hipLaunchKernelGGL(k_design<false>, dim3(count + ctl_records), dim3(N >= 1024 ? 256 : 64), lds_bytes, st, dim, M_dec, (int)SPEC_BAND,
                      jobs, (const float2 *)nullptr, (float2 *)nullptr, (float2 *)scratch, (float *)nullptr, N, tw, log2n, targets,
                      static_cast<const unsigned char *>(ctl_queue), count);
   return hipGetLastError() == hipSuccess ? 0 : -1;

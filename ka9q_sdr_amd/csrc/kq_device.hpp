@@ -29,8 +29,25 @@ struct PllState {
   int lock_count, pll_lock, fft_samples, fft_ptr;
 };
 
+// A transform size on the generic path (kq_ldsfft.hpp lds_fft_mixed): n = f[0] f[1] ... f[nf-1] with radices 2..5, or a
+// power of two (log2n >= 0: then rev / twc are not used and the kernels run lds_fft as ever).  fft_dim() builds one on the
+// current device: the tables are cached per (device, n) and never freed.  ok = false: n has a prime factor beyond 5, or
+// is beyond 65536 (rev is 16 bits wide), or the allocation failed.
+struct FftDim {
+  int n;
+  int log2n;                  // -1: not a power of two
+  int nf;
+  unsigned char f[12];
+  const unsigned short *rev;  // [n] digit reversal: natural index i goes to position rev[i]; null for powers of two
+  const float2 *twc;          // [tw_n] exp(-2 pi i k / tw_n)
+  int tw_n;
+};
+FftDim fft_dim(int n, bool *ok);
+bool fft_size_ok(int n);      // n = 2^a 3^b 5^c, 2 <= n <= 65536, even
+
 struct Geom {
   int N, L, M, D;
+  FftDim dN, dNdec, dPl;  // the transforms of the generic path: master, slave / audio master, PL slave
   int Ndec, olen, Mdec;
   int log2N, log2Ndec;
   int samprate;
@@ -196,10 +213,9 @@ void launch_pcm(hipStream_t s, const Geom &g, const Planes &pl, short *pcm, unsi
 void launch_pl_track(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_fm,
                      int n_fm, int nblocks);
 // single transforms for the compat surface
-void launch_fft_single(hipStream_t s, const float2 *in, float2 *out, int log2n, int sign, const float2 *tw, int tw_log2);
+void launch_fft_single(hipStream_t s, const float2 *in, float2 *out, const FftDim &d, int sign, const float2 *tw, int tw_log2);
 // the same for 2^15 .. 2^22 points, through global memory (`tmp`: N elements of scratch)
-void launch_fft_large(hipStream_t s, const float2 *in, float2 *out, float2 *tmp, int log2n, int sign, const float2 *tw,
-                      int tw_log2);
+int launch_fft_large(hipStream_t s, const float2 *in, float2 *out, float2 *tmp, int N, int sign, const float2 *tw, int tw_log2);
 void launch_n0_single(hipStream_t s, const float2 *fdomain, int N, int samprate, float low, float high, float *out);
 void launch_slave_single(hipStream_t s, const float2 *fdomain, const float2 *resp, float2 *out, int N, int Ndec,
                          int in_real, int out_type, const float2 *tw, int tw_log2);

@@ -380,9 +380,9 @@ __global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__res
     double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
     if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
     float2 const lo = phasor_turns(turns);
-    lds[bitrev((unsigned)i, g.log2N)] = cmul(x[i], lo);
+    lds[fft_pos((unsigned)i, g.dN)] = cmul(x[i], lo);
   }
-  lds_fft<-1>(lds, g.log2N, tw, g.tw_log2);  // filter.c:151
+  fft_any<-1>(lds, g.dN, tw, g.tw_log2);  // filter.c:151
 
   if (spec_dump != nullptr && c == spec_ch) {
     float2 *o = spec_dump + (size_t)b * N;
@@ -429,11 +429,11 @@ __global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__res
         gp = cadd(pos, cconj(neg));
         gn = csub(neg, cconj(pos));
       }
-      G[bitrev((unsigned)k, g.log2Ndec)] = gn;
+      G[fft_pos((unsigned)k, g.dNdec)] = gn;
     }
-    G[bitrev((unsigned)p, g.log2Ndec)] = gp;
+    G[fft_pos((unsigned)p, g.dNdec)] = gp;
   }
-  lds_fft<+1>(G, g.log2Ndec, tw, g.tw_log2);  // filter.c:250
+  fft_any<+1>(G, g.dNdec, tw, g.tw_log2);  // filter.c:250
 
   float2 *o = pl.filt + ((size_t)c * g.max_blocks + b) * g.olen;
   for (int i = threadIdx.x; i < g.olen; i += blockDim.x) o[i] = G[Ndec - g.olen + i];  // filter.c:131
@@ -833,6 +833,10 @@ __global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, 
   float *AIN = reinterpret_cast<float *>(F + AN);
   float2 *PLB = reinterpret_cast<float2 *>(AIN + AN);
   float2 *TWL = PLB + g.pl_n;  // exp(-2 pi i k / AN), k < AN/2
+  // AN with a factor 3 or 5 (kq_ldsfft.hpp lds_fft_mixed): twiddles from the plan's own table; where TWL would sit, a second
+  // buffer of AN bins takes the products in digit-reversed order (that permutation is no involution: no swapping in place)
+  bool const mixed = g.dNdec.log2n < 0;
+  float2 *F2 = TWL;
   bool const pl_on = g.pl_n > 0 && pl.plout != nullptr;
   bool const flat = (ch.flags[c] & FLAG_FLAT) != 0;
   const float *stream = fmout + (size_t)c * g.max_blocks * AL;  // detected samples of this call, block after block
@@ -848,13 +852,18 @@ __global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, 
     for (int n = lane; n < AL; n += 64) aud[n] = stream[(size_t)b * AL + n];
     return;
   }
-  for (int k = lane; k < AN / 2; k += 64) TWL[k] = tw[(size_t)k << (g.tw_log2 - g.log2Ndec)];
+  if (!mixed)
+    for (int k = lane; k < AN / 2; k += 64) TWL[k] = tw[(size_t)k << (g.tw_log2 - g.log2Ndec)];
   for (int i = lane; i < AN; i += 64) {
     float const v = sample((long long)b * AL - (AM - 1) + i);
     AIN[i] = v;
-    F[bitrev((unsigned)i, g.log2Ndec)] = make_float2(v, 0.f);
+    F[fft_pos((unsigned)i, g.dNdec)] = make_float2(v, 0.f);
   }
-  lds_fft<-1>(F, g.log2Ndec, TWL, g.log2Ndec);  // forward transform of the audio master (fm.c:162, filter.c:151)
+  // forward transform of the audio master (fm.c:162, filter.c:151)
+  if (mixed)
+    lds_fft_mixed<-1>(F, g.dNdec);
+  else
+    lds_fft<-1>(F, g.log2Ndec, TWL, g.log2Ndec);
   if (pl_on) {
     // PL slave: REAL -> REAL, decimate 32 (fm.c:219,234; filter.c:206-208 then c2r of pl_n points)
     int const PN = g.pl_n;
@@ -865,11 +874,14 @@ __global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, 
       if (k == 0 || k == PN / 2) {
         gk.y = 0.f;
       } else {
-        PLB[bitrev((unsigned)(PN - k), log2pl)] = cconj(gk);
+        PLB[fft_pos((unsigned)(PN - k), g.dPl)] = cconj(gk);
       }
-      PLB[bitrev((unsigned)k, log2pl)] = gk;
+      PLB[fft_pos((unsigned)k, g.dPl)] = gk;
     }
-    lds_fft<+1>(PLB, log2pl, TWL, g.log2Ndec);
+    if (mixed)
+      lds_fft_mixed<+1>(PLB, g.dPl);
+    else
+      lds_fft<+1>(PLB, log2pl, TWL, g.log2Ndec);
     float *po = pl.plout + ((size_t)c * g.max_blocks + b) * g.pl_l;
     for (int n = lane; n < g.pl_l; n += 64) po[n] = PLB[PN - g.pl_l + n].x;  // filter.c:140
     __syncthreads();
@@ -881,6 +893,21 @@ __global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, 
   // multiply DC..Nyquist (filter.c:206-208) and Hermitian-extend for the c2r transform, which ignores the
   // imaginary parts of DC and Nyquist.  Lane k touches only F[k] and F[AN-k].
   const float2 *HA = ch.aresp + (size_t)c * (AN / 2 + 1);
+  if (mixed) {
+    for (int k = lane; k <= AN / 2; k += 64) {
+      float2 const gk = cmul(HA[k], F[k]);
+      if (k == 0 || k == AN / 2) {
+        F2[fft_pos((unsigned)k, g.dNdec)] = make_float2(gk.x, 0.f);
+      } else {
+        F2[fft_pos((unsigned)k, g.dNdec)] = gk;
+        F2[fft_pos((unsigned)(AN - k), g.dNdec)] = cconj(gk);
+      }
+    }
+    lds_fft_mixed<+1>(F2, g.dNdec);
+    float const gain = ch.fm_gain[c];
+    for (int n = lane; n < AL; n += 64) aud[n] = F2[AN - AL + n].x * gain;  // fm.c:169-170
+    return;
+  }
   for (int k = lane; k <= AN / 2; k += 64) {
     float2 const gk = cmul(HA[k], F[k]);
     if (k == 0 || k == AN / 2) {
@@ -1638,7 +1665,7 @@ static int fm_disc_waves(const Geom &g, int nblocks) {
 }
 static size_t fm_disc_lds_bytes(const Geom &g, int waves = 1) { return (size_t)g.olen * 12 * waves; }
 static size_t fm_audio_lds_bytes(const Geom &g) {
-  return (size_t)g.Ndec * (8 + 4) + (size_t)g.pl_n * 8 + (size_t)(g.Ndec / 2) * 8;
+  return (size_t)g.Ndec * (8 + 4) + (size_t)g.pl_n * 8 + (size_t)(g.dNdec.log2n < 0 ? g.Ndec : g.Ndec / 2) * 8;
 }
 size_t demod_fm_lds_bytes(const Geom &g) { return std::max(fm_disc_lds_bytes(g), fm_audio_lds_bytes(g)); }
 
@@ -1711,23 +1738,24 @@ void launch_pcm(hipStream_t s, const Geom &g, const Planes &pl, short *pcm, unsi
 }
 
 // ---------------------------------------------------------------- single transforms (compat surface)
-__global__ void k_fft_single(const float2 *__restrict__ in, float2 *__restrict__ out, int log2n, int sign,
+__global__ void k_fft_single(const float2 *__restrict__ in, float2 *__restrict__ out, FftDim d, int sign,
                              const float2 *__restrict__ tw, int tw_log2) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  int const n = 1 << log2n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) lds[bitrev((unsigned)i, log2n)] = in[i];
+  int const n = d.n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) lds[fft_pos((unsigned)i, d)] = in[i];
   if (sign < 0)
-    lds_fft<-1>(lds, log2n, tw, tw_log2);
+    fft_any<-1>(lds, d, tw, tw_log2);
   else
-    lds_fft<+1>(lds, log2n, tw, tw_log2);
+    fft_any<+1>(lds, d, tw, tw_log2);
   for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = lds[i];
 }
 
-void launch_fft_single(hipStream_t s, const float2 *in, float2 *out, int log2n, int sign, const float2 *tw, int tw_log2) {
-  size_t const lds_bytes = sizeof(float2) << log2n;
+// n: a power of two (tw / tw_log2: the half-circle table lds_fft reads) or any 2^a 3^b 5^c the caller has a plan for
+void launch_fft_single(hipStream_t s, const float2 *in, float2 *out, const FftDim &d, int sign, const float2 *tw, int tw_log2) {
+  size_t const lds_bytes = sizeof(float2) * (size_t)d.n;
   ensure_dynamic_lds((const void *)k_fft_single, lds_bytes);
-  int const threads = (1 << log2n) >= 4096 ? 1024 : 256;
-  hipLaunchKernelGGL(k_fft_single, dim3(1), dim3(threads), lds_bytes, s, in, out, log2n, sign, tw, tw_log2);
+  int const threads = d.n >= 4096 ? 1024 : 256;
+  hipLaunchKernelGGL(k_fft_single, dim3(1), dim3(threads), lds_bytes, s, in, out, d, sign, tw, tw_log2);
 }
 
 // Transforms beyond the 16384 points one workgroup holds in LDS (compat masters up to 2^22 points): N = Na * Nb through
@@ -1735,16 +1763,26 @@ void launch_fft_single(hipStream_t s, const float2 *in, float2 *out, int log2n, 
 //   X[k1 + Na k2] = sum_n2 W_Nb^{n2 k2} W_N^{n2 k1} sum_n1 x[Nb n1 + n2] W_Na^{n1 k1}
 // k_fft_cols: one workgroup per n2 runs the Na-point transform over n1, applies W_N^{n2 k1}, stores tmp[k1][n2];
 // k_fft_rows: one workgroup per k1 runs the Nb-point transform over n2 and scatters to out[k1 + Na k2].
-__global__ void k_fft_cols(const float2 *__restrict__ in, float2 *__restrict__ tmp, int log2na, int log2nb, int sign,
-                           const float2 *__restrict__ tw, int tw_log2) {
+// (powers of two: da / db carry log2 and the W_N^{n2 k1} factors come from the half-circle table; otherwise twN is the
+// full-circle table of N points and n2 k1 < N indexes it directly)
+__global__ void k_fft_cols(const float2 *__restrict__ in, float2 *__restrict__ tmp, FftDim da, FftDim db, int sign,
+                           const float2 *__restrict__ tw, int tw_log2, const float2 *__restrict__ twN) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  int const na = 1 << log2na, nb = 1 << log2nb, n2 = blockIdx.x;
-  for (int i = threadIdx.x; i < na; i += blockDim.x) lds[bitrev((unsigned)i, log2na)] = in[(size_t)nb * i + n2];
+  int const na = da.n, nb = db.n, n2 = blockIdx.x;
+  for (int i = threadIdx.x; i < na; i += blockDim.x) lds[fft_pos((unsigned)i, da)] = in[(size_t)nb * i + n2];
   if (sign < 0)
-    lds_fft<-1>(lds, log2na, tw, tw_log2);
+    fft_any<-1>(lds, da, tw, tw_log2);
   else
-    lds_fft<+1>(lds, log2na, tw, tw_log2);
-  unsigned const half = 1u << (tw_log2 - 1), shift = (unsigned)(tw_log2 - log2na - log2nb);
+    fft_any<+1>(lds, da, tw, tw_log2);
+  if (twN) {
+    for (int k1 = threadIdx.x; k1 < na; k1 += blockDim.x) {
+      float2 w = twN[(size_t)n2 * k1];
+      if (sign > 0) w.y = -w.y;
+      tmp[(size_t)k1 * nb + n2] = cmul(lds[k1], w);
+    }
+    return;
+  }
+  unsigned const half = 1u << (tw_log2 - 1), shift = (unsigned)(tw_log2 - da.log2n - db.log2n);
   for (int k1 = threadIdx.x; k1 < na; k1 += blockDim.x) {
     unsigned e = ((unsigned)n2 * (unsigned)k1) << shift;  // exponent on the table's period, < 2^tw_log2
     float2 w = tw[e & (half - 1)];
@@ -1753,27 +1791,46 @@ __global__ void k_fft_cols(const float2 *__restrict__ in, float2 *__restrict__ t
     tmp[(size_t)k1 * nb + n2] = cmul(lds[k1], w);
   }
 }
-__global__ void k_fft_rows(const float2 *__restrict__ tmp, float2 *__restrict__ out, int log2na, int log2nb, int sign,
+__global__ void k_fft_rows(const float2 *__restrict__ tmp, float2 *__restrict__ out, FftDim da, FftDim db, int sign,
                            const float2 *__restrict__ tw, int tw_log2) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
-  int const na = 1 << log2na, nb = 1 << log2nb, k1 = blockIdx.x;
-  for (int i = threadIdx.x; i < nb; i += blockDim.x) lds[bitrev((unsigned)i, log2nb)] = tmp[(size_t)k1 * nb + i];
+  int const na = da.n, nb = db.n, k1 = blockIdx.x;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) lds[fft_pos((unsigned)i, db)] = tmp[(size_t)k1 * nb + i];
   if (sign < 0)
-    lds_fft<-1>(lds, log2nb, tw, tw_log2);
+    fft_any<-1>(lds, db, tw, tw_log2);
   else
-    lds_fft<+1>(lds, log2nb, tw, tw_log2);
+    fft_any<+1>(lds, db, tw, tw_log2);
   for (int k2 = threadIdx.x; k2 < nb; k2 += blockDim.x) out[(size_t)k1 + (size_t)na * k2] = lds[k2];
 }
 
-void launch_fft_large(hipStream_t s, const float2 *in, float2 *out, float2 *tmp, int log2n, int sign, const float2 *tw,
-                      int tw_log2) {
-  int const log2na = (log2n + 1) / 2, log2nb = log2n - log2na;
-  size_t const lds_a = sizeof(float2) << log2na, lds_b = sizeof(float2) << log2nb;
+// N beyond one LDS block: a power of two up to 2^22, or 2^a 3^b 5^c up to 65536 (the full-circle table's reach)
+int launch_fft_large(hipStream_t s, const float2 *in, float2 *out, float2 *tmp, int N, int sign, const float2 *tw, int tw_log2) {
+  bool ok = false;
+  FftDim const dn = fft_dim(N, &ok);
+  if (!ok) return -1;
+  int na, nb;
+  if (dn.log2n >= 0) {
+    int const log2na = (dn.log2n + 1) / 2;
+    na = 1 << log2na;
+    nb = N >> log2na;
+  } else {  // split the radices so that both sides fit one LDS block and stay even where they can
+    na = 1;
+    for (int k = 0; k < dn.nf; k++)
+      if ((long long)na * na < N) na *= dn.f[k];
+    nb = N / na;
+    if (na > 16384 || nb > 16384) return -1;
+  }
+  bool oka = false, okb = false;
+  FftDim const da = fft_dim(na, &oka), db = fft_dim(nb, &okb);
+  if (!oka || !okb) return -1;
+  size_t const lds_a = sizeof(float2) * (size_t)na, lds_b = sizeof(float2) * (size_t)nb;
   ensure_dynamic_lds((const void *)k_fft_cols, lds_a);
   ensure_dynamic_lds((const void *)k_fft_rows, lds_b);
-  int const ta = (1 << log2na) >= 1024 ? 256 : 64, tb = (1 << log2nb) >= 1024 ? 256 : 64;
-  hipLaunchKernelGGL(k_fft_cols, dim3(1u << log2nb), dim3(ta), lds_a, s, in, tmp, log2na, log2nb, sign, tw, tw_log2);
-  hipLaunchKernelGGL(k_fft_rows, dim3(1u << log2na), dim3(tb), lds_b, s, tmp, out, log2na, log2nb, sign, tw, tw_log2);
+  int const ta = na >= 1024 ? 256 : 64, tb = nb >= 1024 ? 256 : 64;
+  hipLaunchKernelGGL(k_fft_cols, dim3((unsigned)nb), dim3(ta), lds_a, s, in, tmp, da, db, sign, tw, tw_log2,
+                     dn.log2n >= 0 ? (const float2 *)nullptr : dn.twc);
+  hipLaunchKernelGGL(k_fft_rows, dim3((unsigned)na), dim3(tb), lds_b, s, tmp, out, da, db, sign, tw, tw_log2);
+  return 0;
 }
 
 // compute_n0 (radio.c:383-425) on one resident master spectrum (the compat surface and the demodulator entry points)
@@ -1808,8 +1865,9 @@ void launch_n0_single(hipStream_t s, const float2 *fdomain, int N, int samprate,
 // One slave execution on a resident master spectrum: all four in/out type combinations of
 // filter.c:206-250.  out: N_dec float2 (complex out) or N_dec floats packed in float2[N_dec/2] (real out).
 __global__ void k_slave_single(const float2 *__restrict__ X, const float2 *__restrict__ H, float2 *__restrict__ out, int N,
-                               int Ndec, int log2Ndec, int in_real, int out_type, const float2 *__restrict__ tw, int tw_log2) {
+                               FftDim dd, int in_real, int out_type, const float2 *__restrict__ tw, int tw_log2) {
   extern __shared__ __attribute__((aligned(16))) float2 G[];
+  int const Ndec = dd.n;
   bool const out_real = out_type == 3;
   for (int p = threadIdx.x; p <= Ndec / 2; p += blockDim.x) {
     float2 gp = cmul(H[p], X[p]);
@@ -1830,13 +1888,13 @@ __global__ void k_slave_single(const float2 *__restrict__ X, const float2 *__res
         gn = csub(neg, cconj(pos));
       }
       if (out_real) gn = cconj(gp);  // c2r Hermitian extension
-      G[bitrev((unsigned)k, log2Ndec)] = gn;
+      G[fft_pos((unsigned)k, dd)] = gn;
     } else if (out_real) {
       gp.y = 0;  // c2r ignores the imaginary parts of DC and Nyquist
     }
-    G[bitrev((unsigned)p, log2Ndec)] = gp;
+    G[fft_pos((unsigned)p, dd)] = gp;
   }
-  lds_fft<+1>(G, log2Ndec, tw, tw_log2);
+  fft_any<+1>(G, dd, tw, tw_log2);
   if (out_real) {
     float *o = reinterpret_cast<float *>(out);
     for (int i = threadIdx.x; i < Ndec; i += blockDim.x) o[i] = G[i].x;
@@ -1847,9 +1905,10 @@ __global__ void k_slave_single(const float2 *__restrict__ X, const float2 *__res
 
 // The bank's slave on a spectrum handed in from outside (kq_bank_process_spectrum): COMPLEX in, COMPLEX or CROSS_CONJ out,
 // the last `olen` of the N_dec outputs (filter.c:131) to `out`.
-__global__ void k_slave_bank(const float2 *__restrict__ X, const float2 *__restrict__ H, float2 *__restrict__ out, int N, int Ndec,
-                             int log2Ndec, int olen, int out_type, const float2 *__restrict__ tw, int tw_log2) {
+__global__ void k_slave_bank(const float2 *__restrict__ X, const float2 *__restrict__ H, float2 *__restrict__ out, int N, FftDim dd,
+                             int olen, int out_type, const float2 *__restrict__ tw, int tw_log2) {
   extern __shared__ __attribute__((aligned(16))) float2 G[];
+  int const Ndec = dd.n;
   for (int p = threadIdx.x; p <= Ndec / 2; p += blockDim.x) {
     float2 gp = cmul(H[p], X[p]);
     if (p > 0 && p < Ndec / 2) {
@@ -1860,34 +1919,34 @@ __global__ void k_slave_bank(const float2 *__restrict__ X, const float2 *__restr
         gp = cadd(pos, cconj(neg));
         gn = csub(neg, cconj(pos));
       }
-      G[bitrev((unsigned)k, log2Ndec)] = gn;
+      G[fft_pos((unsigned)k, dd)] = gn;
     }
-    G[bitrev((unsigned)p, log2Ndec)] = gp;
+    G[fft_pos((unsigned)p, dd)] = gp;
   }
-  lds_fft<+1>(G, log2Ndec, tw, tw_log2);
+  fft_any<+1>(G, dd, tw, tw_log2);
   for (int i = threadIdx.x; i < olen; i += blockDim.x) out[i] = G[Ndec - olen + i];
 }
 
 void launch_slave_bank(hipStream_t s, const float2 *fdomain, const float2 *resp, float2 *out, int N, int Ndec, int olen,
                        int out_type, const float2 *tw, int tw_log2) {
-  int log2Ndec = 0;
-  while ((1 << log2Ndec) < Ndec) log2Ndec++;
+  bool ok = false;
+  FftDim const dd = fft_dim(Ndec, &ok);  // (cached: the bank / the compat slave made the plan when it was created)
+  if (!ok) return;
   size_t const lds_bytes = sizeof(float2) * (size_t)Ndec;
   ensure_dynamic_lds((const void *)k_slave_bank, lds_bytes);
   int const threads = Ndec >= 4096 ? 1024 : 256;
-  hipLaunchKernelGGL(k_slave_bank, dim3(1), dim3(threads), lds_bytes, s, fdomain, resp, out, N, Ndec, log2Ndec, olen, out_type, tw,
-                     tw_log2);
+  hipLaunchKernelGGL(k_slave_bank, dim3(1), dim3(threads), lds_bytes, s, fdomain, resp, out, N, dd, olen, out_type, tw, tw_log2);
 }
 
 void launch_slave_single(hipStream_t s, const float2 *fdomain, const float2 *resp, float2 *out, int N, int Ndec, int in_real,
                          int out_type, const float2 *tw, int tw_log2) {
-  int log2Ndec = 0;
-  while ((1 << log2Ndec) < Ndec) log2Ndec++;
+  bool ok = false;
+  FftDim const dd = fft_dim(Ndec, &ok);
+  if (!ok) return;
   size_t const lds_bytes = sizeof(float2) * (size_t)Ndec;
   ensure_dynamic_lds((const void *)k_slave_single, lds_bytes);
   int const threads = Ndec >= 4096 ? 1024 : 256;
-  hipLaunchKernelGGL(k_slave_single, dim3(1), dim3(threads), lds_bytes, s, fdomain, resp, out, N, Ndec, log2Ndec, in_real,
-                     out_type, tw, tw_log2);
+  hipLaunchKernelGGL(k_slave_single, dim3(1), dim3(threads), lds_bytes, s, fdomain, resp, out, N, dd, in_real, out_type, tw, tw_log2);
 }
 
 }  // namespace kq

@@ -147,4 +147,88 @@ __device__ inline void lds_fft(float2 *s, int log2n, const float2 *__restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Sizes with a factor 3 or 5 (round 6: FFTW plans whatever N = L + M - 1 and N / decimate come out, filter.c:78,132, and
+// decimate = samprate / 48000 is 5 at 240 kHz, radio_status.c:266).  n = f[0] f[1] ... f[nf-1], radices 2, 3, 4, 5, applied
+// in that order as in-place decimation-in-time stages: the stage of radix r over span m (the product of the radices before
+// it) takes s[base + j + q m], q < r, times W_{m r}^{j q}, through an r-point transform back into the same places.  The
+// input goes in DIGIT-REVERSED: natural index i sits at rev[i] (table built by the host with the plan: position
+// p = sum_k d_k prod_{j<k} f[j] holds index i = sum_k d_k n / prod_{j<=k} f[j]); the result comes out in natural order,
+// as from lds_fft.  Twiddles from the bank's full-circle table twc[k] = exp(-2 pi i k / tw_n), n | tw_n.
+// The fast kernels stay with powers of two; this is the generic path's transform (k_filter_full, k_fm_audio, k_design,
+// the compat kernels).  log2n >= 0 says the size IS a power of two: fft_pos / fft_any then are bitrev / lds_fft.
+__device__ __forceinline__ unsigned fft_pos(unsigned i, const FftDim &d) { return d.log2n >= 0 ? bitrev(i, d.log2n) : d.rev[i]; }
+
+template <int SIGN>
+__device__ inline void lds_fft_mixed(float2 *s, const FftDim &d) {
+  int const n = d.n;
+  int m = 1;
+  __syncthreads();
+  for (int st = 0; st < d.nf; st++) {
+    int const r = d.f[st];
+    int const tstep = d.tw_n / (m * r);  // W_{m r}^{1} = twc[tstep]
+    for (int i = threadIdx.x; i < n / r; i += blockDim.x) {
+      int const j = i % m, base = (i / m) * m * r + j;
+      float2 a[5];
+#pragma unroll
+      for (int q = 0; q < 5; q++) {
+        if (q < r) {
+          float2 v = s[base + q * m];
+          if (q && j) {
+            float2 w = d.twc[(size_t)j * q * tstep];
+            if (SIGN > 0) w.y = -w.y;
+            v = cmul(v, w);
+          }
+          a[q] = v;
+        }
+      }
+      // r-point transforms, forward kernel exp(-2 pi i q t / r); SIGN > 0 conjugates the constants
+      float const sg = SIGN < 0 ? 1.f : -1.f;
+      if (r == 2) {
+        s[base] = cadd(a[0], a[1]);
+        s[base + m] = csub(a[0], a[1]);
+      } else if (r == 4) {
+        float2 const b0 = cadd(a[0], a[2]), b1 = csub(a[0], a[2]), b2 = cadd(a[1], a[3]), b3 = csub(a[1], a[3]);
+        float2 const b3r = make_float2(sg * b3.y, -sg * b3.x);  // b3 times -i (forward) / +i (backward)
+        s[base] = cadd(b0, b2);
+        s[base + m] = cadd(b1, b3r);
+        s[base + 2 * m] = csub(b0, b2);
+        s[base + 3 * m] = csub(b1, b3r);
+      } else if (r == 3) {
+        float const c1 = -0.5f, s1 = sg * -0.86602540378443864676f;  // exp(-+2 pi i / 3)
+        float2 const t1 = cadd(a[1], a[2]), t2 = csub(a[1], a[2]);
+        float2 const u = make_float2(a[0].x + c1 * t1.x, a[0].y + c1 * t1.y);
+        float2 const v = make_float2(-s1 * t2.y, s1 * t2.x);  // i s1 t2
+        s[base] = cadd(a[0], t1);
+        s[base + m] = cadd(u, v);
+        s[base + 2 * m] = csub(u, v);
+      } else {  // r == 5
+        float const c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+        float const s1 = sg * -0.95105651629515357212f, s2 = sg * -0.58778525229247312917f;  // sin(-+2 pi / 5), sin(-+4 pi / 5)
+        float2 const t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]), t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
+        float2 const u1 = make_float2(a[0].x + c1 * t1.x + c2 * t2.x, a[0].y + c1 * t1.y + c2 * t2.y);
+        float2 const u2 = make_float2(a[0].x + c2 * t1.x + c1 * t2.x, a[0].y + c2 * t1.y + c1 * t2.y);
+        float2 const w1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+        float2 const w2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+        float2 const v1 = make_float2(-w1.y, w1.x), v2 = make_float2(-w2.y, w2.x);  // i w
+        s[base] = cadd(a[0], cadd(t1, t2));
+        s[base + m] = cadd(u1, v1);
+        s[base + 4 * m] = csub(u1, v1);
+        s[base + 2 * m] = cadd(u2, v2);
+        s[base + 3 * m] = csub(u2, v2);
+      }
+    }
+    m *= r;
+    __syncthreads();
+  }
+}
+// either kind: `tw` / `tw_log2` are lds_fft's half-circle table (used for powers of two only)
+template <int SIGN>
+__device__ __forceinline__ void fft_any(float2 *s, const FftDim &d, const float2 *__restrict__ tw, int tw_log2) {
+  if (d.log2n >= 0)
+    lds_fft<SIGN>(s, d.log2n, tw, tw_log2);
+  else
+    lds_fft_mixed<SIGN>(s, d);
+}
+
 }  // namespace kq

@@ -169,7 +169,7 @@ static int demod_start(kqo_chan *c){
       int const PL_N = AN / PL_decimate, PL_L = AL / PL_decimate, PL_M = PL_N - PL_L + 1;
       c->plfreq = NAN;
       c->pl_fft_ptr = c->pl_last_fft = 0;
-      if(PL_N >= 4 && PL_L >= 1 && (PL_N & (PL_N - 1)) == 0){
+      if(PL_N >= 4 && PL_L >= 1 && ((PL_N & (PL_N - 1)) == 0 || (AN % PL_decimate == 0 && AL % PL_decimate == 0))){
         c->pl_samprate = c->dsamprate / PL_decimate;
         float complex *plr = calloc(PL_N / 2 + 1, sizeof(float complex));
         for(int j = 0; j <= PL_N / 2; j++){

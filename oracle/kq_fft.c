@@ -1,11 +1,15 @@
-/* kq_fft.c -- power-of-two single-precision FFT for the oracle (test infrastructure only).
+/* kq_fft.c -- single-precision FFT for the oracle (test infrastructure only): powers of two, and since round 6 every
+ * n = 2^a 3^b 5^c (the sizes a front end whose rate is not 48 kHz x 2^k needs: filter.c:78,102-107,132 plan whatever
+ * N and N / decimate come out, radio_status.c:266 gives decimate = samprate / 48000 -- 240 kHz: 5).
  *
  * Stands in for the FFTW3f calls of the reference (filter.c:78,87,132,141,373-374,430-432;
  * fm.c:228; linear.c:92).  Same conventions as FFTW: unnormalised, forward kernel
  * exp(-2*pi*i*jk/n), backward exp(+2*pi*i*jk/n); r2c returns n/2+1 bins; c2r consumes
  * n/2+1 bins and ignores the imaginary parts of DC and Nyquist.
  * Arithmetic is float (twiddles computed in double, rounded once), iterative radix-2
- * decimation in time after a bit-reversal permutation.
+ * decimation in time after a bit-reversal permutation.  Sizes with a factor 3 or 5 take a recursive mixed-radix
+ * decimation in time (radices 4, 2, 3, 5; the power-of-two path is left exactly as it was: its rounding is what the
+ * committed vectors were generated with).  Checked against numpy's float64 transforms in tests/test_oracle_filter.py.
  */
 #define _GNU_SOURCE 1
 #include <stdlib.h>
@@ -20,11 +24,40 @@ struct kqo_fft {
   float complex *scratch; /* n, for r2c/c2r and in-place safety */
   float *work;            /* 4 n floats: split re / im ping-pong buffers of the fast variant */
   float *twr, *twi;       /* n floats each: exp(-2*pi*i*k/n) split, k < n (the radix-4 pass reads up to 3 j m < n) */
+  unsigned nf, fac[32];   /* mixed sizes (log2n == 0 and n > 1): the radices, outermost first */
+  float complex *twf;     /* mixed sizes: exp(-2*pi*i*k/n), k < n */
 };
 
+/* n = 2^a 3^b 5^c ?  fills the radix list (4s first, then 2, 3s, 5s) */
+static int factorise(unsigned n, unsigned *fac, unsigned *nf){
+  *nf = 0;
+  while(n % 4 == 0){ fac[(*nf)++] = 4; n /= 4; }
+  while(n % 2 == 0){ fac[(*nf)++] = 2; n /= 2; }
+  while(n % 3 == 0){ fac[(*nf)++] = 3; n /= 3; }
+  while(n % 5 == 0){ fac[(*nf)++] = 5; n /= 5; }
+  return n == 1;
+}
+
 kqo_fft *kqo_fft_create(unsigned n){
-  if(n == 0 || (n & (n - 1)) != 0)
+  if(n == 0)
     return NULL;
+  if((n & (n - 1)) != 0){       /* a factor 3 or 5: the mixed-radix plan */
+    unsigned fac[32], nf;
+    if(!factorise(n, fac, &nf))
+      return NULL;
+    kqo_fft *p = calloc(1, sizeof(*p));
+    p->n = n;
+    p->nf = nf;
+    memcpy(p->fac, fac, sizeof fac);
+    p->twf = malloc(sizeof(float complex) * n);
+    p->scratch = malloc(sizeof(float complex) * 2 * n);
+    for(unsigned k = 0; k < n; k++){
+      double sn, cs;
+      sincos(-2.0 * M_PI * (double)k / (double)n, &sn, &cs);
+      p->twf[k] = (float)cs + (float)sn * _Complex_I;
+    }
+    return p;
+  }
   kqo_fft *p = calloc(1, sizeof(*p));
   p->n = n;
   while((1u << p->log2n) < n)
@@ -65,6 +98,7 @@ void kqo_fft_destroy(kqo_fft *p){
   free(p->work);
   free(p->twr);
   free(p->twi);
+  free(p->twf);
   free(p);
 }
 
@@ -162,8 +196,49 @@ static void fft_fast(const kqo_fft *p, const float complex *in, float complex *o
     out[i] = ar[i] + ai[i] * _Complex_I;
 }
 
+/* ---- mixed radix, decimation in time: n = r m; the r sub-sequences in[q + r j] are transformed (recursively) into
+ * out[q m .. q m + m - 1], then for every k < m the r values out[k + q m] W_n^{q k} go through an r-point transform.
+ * `stride` = distance of consecutive elements of `in`; tw = exp(-+2 pi i k / ntot) (ntot / n = tstride). */
+static void mixed_rec(const kqo_fft *p, unsigned level, unsigned n, const float complex *in, unsigned stride, float complex *out,
+                      int sign){
+  if(n == 1){
+    out[0] = in[0];
+    return;
+  }
+  unsigned const r = p->fac[level], m = n / r, tstride = p->n / n;
+  for(unsigned q = 0; q < r; q++)
+    mixed_rec(p, level + 1, m, in + (size_t)q * stride, stride * r, out + (size_t)q * m, sign);
+  for(unsigned k = 0; k < m; k++){
+    float complex a[5], b[5];
+    for(unsigned q = 0; q < r; q++){
+      float complex w = p->twf[(size_t)q * k * tstride];
+      if(sign > 0)
+        w = conjf(w);
+      a[q] = q ? cmulf_(out[k + q * m], w) : out[k];
+    }
+    for(unsigned t = 0; t < r; t++){            /* the r-point transform, W_r^{q t} from the same table */
+      float complex acc = a[0];
+      for(unsigned q = 1; q < r; q++){
+        float complex w = p->twf[(size_t)((q * t) % r) * (p->n / r)];
+        if(sign > 0)
+          w = conjf(w);
+        acc += cmulf_(a[q], w);
+      }
+      b[t] = acc;
+    }
+    for(unsigned t = 0; t < r; t++)
+      out[k + t * m] = b[t];
+  }
+}
+
 void kqo_fft_c2c(const kqo_fft *p, const float complex *in, float complex *out, int sign){
   unsigned const n = p->n;
+  if(p->twf){                                   /* a size with a factor 3 or 5 */
+    float complex *src = p->scratch + n;         /* (r2c / c2r hand in p->scratch itself) */
+    memcpy(src, in, sizeof(float complex) * n);
+    mixed_rec(p, 0, n, src, 1, out, sign);
+    return;
+  }
   if(Fast && n >= 4){
     fft_fast(p, in, out, sign);
     return;

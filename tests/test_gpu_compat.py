@@ -43,8 +43,12 @@ def lib(gpu):
 # preceding case of the same size would otherwise have left behind in the allocator's recycled block.
 # The last two are the master sizes past one LDS block: cfg 5's N = 65536 (create_filter_input has no size limit,
 # filter.c:54-91) and 2^17.
+# Lb = 4800 ... : sizes with factors 3 and 5 (N = 9600, 15360, 3840; 48000 = 2^7 3 5^3 past one LDS block), which FFTW plans
+# like any other (filter.c:78,132): the mixed-radix transforms of kq_ldsfft.hpp.
 @pytest.mark.parametrize("in_type,out_type,D,Lb", [(1, 3, 4, 512), (1, 1, 4, 512), (1, 2, 4, 512), (1, 1, 16, 512),
-                                                    (3, 3, 1, 512), (3, 1, 1, 512), (1, 1, 512, 32768), (1, 2, 64, 65536)])
+                                                    (3, 3, 1, 512), (3, 1, 1, 512), (1, 1, 512, 32768), (1, 2, 64, 65536),
+                                                    (1, 3, 5, 4800), (1, 1, 5, 4800), (1, 2, 8, 7680), (3, 3, 1, 1920),
+                                                    (3, 1, 2, 1920), (1, 1, 25, 24000)])
 def test_compat_filter_matches_oracle(lib, in_type, out_type, D, Lb):
     M = Lb + 1
     N = Lb + M - 1

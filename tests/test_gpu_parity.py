@@ -286,6 +286,15 @@ GEOMETRIES = [
     (65536, 49152, 16385, 32,  8000000, "full", True),       # N = 65536 full-spectrum kernel, N/D = 2048, L != M - 1
     (65536, 33280, 32257, 256, 4000000, "full", True),       # L not a multiple of 1024: 8-byte window loads
     (65536, 32768, 32769, 8,   2000000, "full", True),       # N/D = 8192: the slave reads bins of every sub-transform row
+    # sizes with factors 3 and 5 (round 6; FFTW plans them all, filter.c:78,132): front ends that are not 48 kHz x 2^k
+    (9600,  4800,  4801,  5,   240000, "auto", True),        # 240 kHz: decimate = samprate / 48000 = 5 (radio_status.c:266); N/D = 1920
+    (15360, 7680,  7681,  8,   384000, "full", True),        # N = 2^10 3 5, N/D = 1920, PL slave of 60 points
+    (12000, 6000,  6001,  10,  480000, "auto", True),        # N = 2^5 3 5^3, N/D = 1200
+    (7680,  3840,  3841,  4,   192000, "auto", False),       # the reference's default L with M = L + 1: N/D = 1920
+    (3840,  2880,  961,   2,   96000,  "auto", True),        # L != M - 1, decimate 2
+    (9600,  4800,  4801,  150, 7200000, "auto", True),       # N/D = 64 behind a master with factors 3 and 5: the N/D = 64 demodulators
+    (6000,  3000,  3001,  5,   240000, "auto", True),        # N/D = 1200, olen = 600
+    (3000,  1500,  1501,  2,   96000,  "auto", True),        # N = 2^3 3 5^3 (one radix-2 pass), N/D = 1500
 ]
 
 

@@ -252,3 +252,71 @@ def test_fast_transform_equals_the_plain_one(log2n):
         for fast in (0, 1):
             assert np.sqrt(np.mean(np.abs(res[fast, key] - w) ** 2)) / scale < tol, (key, fast)
         assert np.sqrt(np.mean(np.abs(res[1, key] - res[0, key]) ** 2)) / scale < tol, key
+
+
+@pytest.mark.parametrize("n", [6, 60, 1200, 1920, 3000, 9600, 12000, 15360, 48000])
+def test_mixed_radix_transform_against_float64(n):
+    """Sizes 2^a 3^b 5^c (round 6: FFTW plans whatever N and N / decimate come out, filter.c:78,132; decimate =
+    samprate / 48000 is 5 at 240 kHz, radio_status.c:266): the oracle's mixed-radix transform against numpy's float64
+    one, both directions, and the r2c / c2r pair the FM audio filter uses; a size with a factor 7 is refused."""
+    L = ko.lib()
+    L.kqo_fft_create.restype = C.c_void_p
+    L.kqo_fft_create.argtypes = [C.c_uint]
+    L.kqo_fft_destroy.argtypes = [C.c_void_p]
+    L.kqo_fft_c2c.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.kqo_fft_r2c.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.kqo_fft_c2r.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    assert not L.kqo_fft_create(7 * n)
+    p = L.kqo_fft_create(n)
+    assert p
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    y = np.zeros(n, np.complex64)
+    for sign, ref in ((-1, np.fft.fft(x.astype(np.complex128))), (+1, np.fft.ifft(x.astype(np.complex128)) * n)):
+        L.kqo_fft_c2c(p, x.ctypes.data, y.ctypes.data, sign)
+        assert np.sqrt(np.mean(np.abs(y - ref) ** 2) / np.mean(np.abs(ref) ** 2)) < 4e-7
+    xr = rng.standard_normal(n).astype(np.float32)
+    yc = np.zeros(n // 2 + 1, np.complex64)
+    L.kqo_fft_r2c(p, xr.ctypes.data, yc.ctypes.data)
+    ref = np.fft.rfft(xr.astype(np.float64))
+    assert np.sqrt(np.mean(np.abs(yc - ref) ** 2) / np.mean(np.abs(ref) ** 2)) < 4e-7
+    back = np.zeros(n, np.float32)
+    L.kqo_fft_c2r(p, yc.ctypes.data, back.ctypes.data)
+    assert np.abs(back / n - xr).max() < 3e-6
+    L.kqo_fft_destroy(p)
+
+
+def test_overlap_save_at_a_size_with_factors_3_and_5_is_direct_convolution():
+    """N = 9600, decimate 5 (a 240 kHz front end): the oracle's master + slave against the direct convolution of the
+    input with the designed impulse response, decimated -- the overlap-save identity, independent of any FFT."""
+    Lb, D = 4800, 5
+    M = Lb + 1
+    N = Lb + M - 1
+    O = ko.lib()
+    om = O.kqo_create_filter_input(Lb, M, 1)
+    os_ = O.kqo_create_filter_output(om, None, D, 1)
+    assert om and os_
+    assert O.kqo_set_filter(os_, -0.11, 0.17, 3.0) == 0
+    oso = C.cast(os_, C.POINTER(_FilterOut)).contents
+    omi = C.cast(om, C.POINTER(_FilterIn)).contents
+    nd = N // D
+    H = _as(oso.response, nd, np.complex64).astype(np.complex128)
+    # the decimated response H[k] serves signed master bins k: the equivalent N-point response is zero elsewhere
+    Hfull = np.zeros(N, np.complex128)
+    Hfull[:nd // 2 + 1] = H[:nd // 2 + 1]
+    Hfull[N - (nd - nd // 2 - 1):] = H[nd // 2 + 1:]
+    h = np.fft.ifft(Hfull) * N                  # impulse response at the input rate (both transforms are unnormalised)
+    rng = np.random.default_rng(3)
+    nb = 4
+    x = (rng.standard_normal(nb * Lb) + 1j * rng.standard_normal(nb * Lb)).astype(np.complex64)
+    full = np.convolve(np.concatenate([np.zeros(M - 1), x.astype(np.complex128)]), h[:N])[M - 1:M - 1 + nb * Lb]
+    for b in range(nb):
+        _as(omi.input_c, Lb, np.complex64)[:] = x[b * Lb:(b + 1) * Lb]
+        O.kqo_execute_filter_input(om)
+        O.kqo_execute_filter_output(os_)
+        got = _as(oso.output_c, Lb // D, np.complex64)
+        want = full[b * Lb:(b + 1) * Lb][::D]
+        if b > 0:                                       # (block 0 starts from a zero history on both sides)
+            assert np.sqrt(np.mean(np.abs(got - want) ** 2) / np.mean(np.abs(want) ** 2)) < 2e-5
+    O.kqo_delete_filter_output(os_)
+    O.kqo_delete_filter_input(om)

@@ -26,15 +26,26 @@
 
 // ---- mock device work: each launcher is one operation of the in-order stream
 namespace kq {
-void launch_fft_single(hipStream_t, const float2 *in, float2 *out, int log2n, int, const float2 *, int) {
+void launch_fft_single(hipStream_t, const float2 *in, float2 *out, const FftDim &d, int, const float2 *, int) {
   std::lock_guard<std::mutex> lk(mock_stream_mutex());
-  for (int i = 0; i < (1 << log2n); i++) out[i] = in[i];
+  for (int i = 0; i < d.n; i++) out[i] = in[i];
 }
-void launch_fft_large(hipStream_t, const float2 *in, float2 *out, float2 *tmp, int log2n, int, const float2 *, int) {
+int launch_fft_large(hipStream_t, const float2 *in, float2 *out, float2 *tmp, int N, int, const float2 *, int) {
   std::lock_guard<std::mutex> lk(mock_stream_mutex());
-  for (int i = 0; i < (1 << log2n); i++) tmp[i] = in[i];
-  for (int i = 0; i < (1 << log2n); i++) out[i] = tmp[i];
+  for (int i = 0; i < N; i++) tmp[i] = in[i];
+  for (int i = 0; i < N; i++) out[i] = tmp[i];
+  return 0;
 }
+FftDim fft_dim(int n, bool *ok) {  // (the mock transforms copy: a plan is its size)
+  FftDim d{};
+  d.n = n;
+  d.log2n = -1;
+  if (n >= 1 && (n & (n - 1)) == 0)
+    for (d.log2n = 0; (1 << d.log2n) < n;) d.log2n++;
+  if (ok) *ok = true;
+  return d;
+}
+bool fft_size_ok(int n) { return n >= 2 && (n & 1) == 0; }
 void launch_n0_single(hipStream_t, const float2 *X, int N, int, float, float, float *out) {
   std::lock_guard<std::mutex> lk(mock_stream_mutex());
   float acc = 0;

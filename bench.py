@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--fanout", default="c", choices=["c", "torch"],
                     help="front-end fan-out: c = the library's kq_fanout_* (ncclBroadcast, the product path); torch = "
                          "ka9q_sdr_amd/shard.py's torch.distributed twin (always used with --backend gloo)")
+    ap.add_argument("--ingest", default="both", choices=["resident", "host", "both"],
+                    help="N > 1 with the C fan-out: where the root takes each batch from -- its own device memory (`value`), pinned "
+                         "host memory (H2D + ncclBroadcast + compute in one pipeline: the `host_ingest` object), or both")
     ap.add_argument("--rccl-max-channels", type=int, default=0,
                     help="N > 0: export NCCL_MAX_NCHANNELS=N before RCCL initialises (default 0: RCCL's own choice; the "
                          "broadcast's footprint costs the step <= 2.5 %% at any count, profiles/r04/bcast_side_kernel_probe.txt)")
@@ -662,6 +665,45 @@ def main():
         a_steps_done = a.steps + nd
     else:
         a_steps_done = a.steps
+    # N > 1: the root's batch from PINNED HOST memory (what a socket reader fills): kq_fanout_post copies it into the slot on
+    # the side stream and broadcasts it from there -- H2D, ncclBroadcast and the ranks' compute in one pipeline, which the
+    # resident steps above (the root re-broadcasts a slot in place) do not exercise (VERDICT r5 #6a).  Beside `value`, never it.
+    host_ingest = None
+    if use_c and ((world > 1 and a.ingest in ("host", "both")) or (world == 1 and a.ingest == "host")):
+        iq_pin_all = torch.from_numpy(np.ascontiguousarray(iq_host)).pin_memory() if rank == 0 else None
+        src = iq_pin_all.data_ptr() if rank == 0 else None
+
+        def step_host(k):
+            i = k & 1
+            p = fan.acquire(i, cs)
+            bank.process_resident(p, B)
+            fan.release(i, cs)
+            fan._chk(lib.kq_fanout_post(fan.h, i, src, nwin, 0), "kq_fanout_post (host batch)")
+
+        k0 = spin + a.warmup + a_steps_done
+        k0 += k0 & 1
+        for k in range(8):
+            step_host(k0 + k)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        th0 = time.perf_counter()
+        for k in range(a.steps):
+            step_host(k0 + 8 + k)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        th_s = time.perf_counter() - th0
+        if dist:
+            th = torch.tensor([th_s], device=tdev, dtype=torch.float64)
+            dist.all_reduce(th, op=dist.ReduceOp.MAX)
+            th_s = float(th.item())
+        a_steps_done += (k0 - (spin + a.warmup + a_steps_done)) + 8 + a.steps     # (the slots keep alternating)
+        host_ingest = {"ms_per_step": round(th_s / a.steps * 1e3, 4), "steps": a.steps,
+                       "value": round(C * world * B * L * a.steps / th_s / 1e6, 1),
+                       "h2d_bytes_per_step": nwin * 8,
+                       "note": "every step's batch leaves pinned host memory on the root: kq_fanout_post(src_is_device = 0) = H2D into "
+                               "the slot + ncclBroadcast on the side stream, two slots deep, beside the ranks' compute"}
     # the demodulator kernels' time comes from a few extra, untimed steps with the full set of events
     bank.enable_timing(2)
     for k in range(4):       # (an even count: the slots keep their parity)
@@ -824,6 +866,12 @@ def main():
                            "libraries_mapped": sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln}),
                            "note": "ranks = ncclCommCount of the fan-out's communicator (0: one rank, no communicator); "
                                    "bcast_ms = HIP events around ncclBroadcast on the side stream, rank 0"}
+        # the scaling curve is a statement about RCCL over xGMI: it is measured only when RCCL itself carried the batches
+        # between `world` ranks (kq_fanout_stats.rccl_ranks = ncclCommCount)
+        out["scaling_measured"] = bool(world == 1 or (fan_stats is not None and fan_stats["rccl_ranks"] == world))
+        if host_ingest:
+            host_ingest["fraction_of_value"] = round(host_ingest["value"] / max(value, 1e-9), 4)
+            out["host_ingest"] = host_ingest
         out["step_frac"] = round(out["roofline"]["algorithmic_bytes_per_launch"] / (elapsed / a.steps) / 8e12, 4)
         if per_rank is not None:
             out["per_rank"] = per_rank

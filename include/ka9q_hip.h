@@ -53,11 +53,15 @@ typedef struct kq_bank kq_bank;   /* opaque */
  * called from main.c:232) plus demod->filter.decimate and demod->input.samprate
  * (radio_status.c:264-267), which the reference keeps per process.
  * Limits (deviations from the reference, which hands any L / M to FFTW -- main.c:160-170, filter.c:78,132):
- *   - N = L + M - 1 and N / decimate must be powers of two (the reference's default, N = 8192, is one); decimate must
- *     divide N, L and M - 1 (the reference only warns when it does not, filter.c:106-107);
+ *   - N = L + M - 1 and N / decimate: powers of two (the reference's default, N = 8192, is one), or -- since round 6, on
+ *     the generic kernels -- any even 2^a 3^b 5^c up to 16384: the sizes of a front end whose rate is not 48 kHz x 2^k
+ *     (decimate = samprate / 48000, radio_status.c:266: 5 at 240 kHz with L = 4800, M = 4801).  A prime factor beyond 5 is
+ *     refused.  decimate must divide N, L and M - 1 (the reference only warns when it does not, filter.c:106-107).  The fast
+ *     kernels (N = 16384 / 65536 full-spectrum, the pruned ones, N/D = 64 and 256 demodulators) are power-of-two only;
  *   - the full-spectrum forward path (compute_n0 = 1) serves N <= 16384 and N = 65536; N = 32768 only without compute_n0;
- *   - at most 64 carrier-tracking channels (kq_channel_config.pll, linear.c:129-246) per bank -- each keeps a 65536-sample
- *     search ring; kq_bank_add_channel / kq_bank_set_mode return -1 beyond that;
+ *   - carrier-tracking channels (kq_channel_config.pll, linear.c:129-246): as many as the bank has channels, up to 65536;
+ *     each keeps a 65536-sample search ring (544 KiB with its state), allocated 64 channels at a time as the count grows;
+ *   - the PL-tone measurement needs 32 to divide N / decimate and L / decimate (fm.c:201-205 decimates by 32);
  *   - FM channels need N / decimate <= 8192 (the post-detection filter lives in one CU's LDS).
  * Nothing limits max_channels but memory (~3 KiB per channel + the planes): banks of 34560 channels run in the bench. */
 typedef struct kq_bank_config {
@@ -66,7 +70,7 @@ typedef struct kq_bank_config {
                             * banks on several GPUs (kq_bank_create included). */
   int samprate;            /* front-end complex sample rate, Hz */
   unsigned L;              /* new samples per block            (demod->filter.L) */
-  unsigned M;              /* impulse response length          (demod->filter.M); N = L+M-1 power of two */
+  unsigned M;              /* impulse response length          (demod->filter.M); N = L+M-1: see Limits */
   unsigned decimate;       /* D: output rate = samprate / D    (demod->filter.decimate), >= 2 */
   unsigned max_channels;
   unsigned max_blocks;     /* largest number of blocks one kq_bank_process call may take */
@@ -198,8 +202,9 @@ int kq_bank_set_mode(kq_bank *bank, int ch, const kq_channel_config *mode);
  * calls already queued (which keep the values they were queued with) and in front of its own kernels -- a new filter
  * response included, which is designed on the bank's stream where it is used (kq_bank_get_response then fetches it).  A
  * bank running at real time with several calls in flight is not stalled by its control plane (0.001-0.05 ms of host time
- * per operation at 32768 channels; only carrier-tracking channels, whose loop state moves between slots, still drain
- * the device -- and kq_bank_get_response of a channel whose filter has just been set). */
+ * per operation at 32768 channels; carrier-tracking channels included since round 6: a loop's slot is its own and is
+ * started afresh by the queue.  Only kq_bank_get_response of a channel whose filter has just been set waits, and a
+ * carrier-tracking channel that needs a new chunk of 64 slots allocated). */
 /* demod->filter.isb and demod->output.channels of a running linear channel (linear.c:117-120, 291-300): the slave's
  * out_type and the mono / stereo hand-off change from the next block on; AGC state and response are left alone. */
 int kq_bank_set_linear_options(kq_bank *bank, int ch, int isb, int channels);

@@ -11,8 +11,10 @@
  *   - `fwd_plan` / `rev_plan` are opaque device contexts (void *), not fftwf_plan.
  *   - response arrays handed to create_filter_output() must come from malloc()/calloc()
  *     (the reference frees them with fftwf_free, filter.c:271; here it is free()).
- *   - N = L+M-1 and N/decimate must be powers of two, 4 <= N <= 2^22 (past 16384 points the master's transform runs
- *     in two passes through device memory), 4 <= N/decimate <= 16384.
+ *   - N = L+M-1: a power of two, 4 <= N <= 2^22, or an even 2^a 3^b 5^c up to 65536 (240 kHz front ends: L = 4800,
+ *     M = 4801, decimate 5); past 16384 points the master's transform runs in two passes through device memory.
+ *     N/decimate: the same kinds of size, 4 <= N/decimate <= 16384.  A prime factor beyond 5 returns NULL (FFTW would
+ *     plan it, filter.c:78,132).
  *   - This surface moves one block over PCIe per call; it exists for drop-in correctness.  The
  *     throughput path is the channel bank in ka9q_hip.h.
  */

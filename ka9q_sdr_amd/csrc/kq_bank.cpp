@@ -119,6 +119,7 @@ struct HostChan {
   int out_type;
   std::vector<kq::cfloat> resp, aresp;
   float noise_gain;
+  int pll_slot = -1;  // carrier-tracking channels: the slot of the loop's state and ring (pll_acquire)
   int n0slot = -1;  // which of the bank's compute_n0 mask sets this channel uses (shared by all channels with its edges)
   // where the channel stands in the bank's lists (kq_bank: list_host[lk][lpos], list_active_host[apos]); lk = 3: on the
   // carrier-loop list, -1: on none
@@ -181,8 +182,15 @@ struct kq_bank {
   kq::Planes pl;
   int *list_dev[3] = {nullptr, nullptr, nullptr};  // fm, am, linear (without PLL)
   // carrier-tracking linear channels (linear.c:129-246): own list, 65536-sample search ring per channel
-  static constexpr int kMaxPll = 64;
-  int *list_pll_dev = nullptr;
+  // carrier-tracking channels: a slot each (state + 65536-sample ring + search scratch), handed out from chunks of
+  // kq::kPllChunk that are allocated as the count grows; a slot stays with its channel until the channel leaves the set, so
+  // adding or removing one moves nothing and waits for nothing (rounds 1-5: slot = rank, 64 at most, synchronous moves)
+  static constexpr int kMaxPllChunks = 1024;
+  int *list_pll_dev = nullptr;         // [max_channels]
+  int *pll_slot_dev = nullptr;         // [max_channels] channel -> slot
+  kq::PllChunk *pll_chunks_dev = nullptr;  // [kMaxPllChunks]
+  std::vector<kq::PllChunk> pll_chunks;
+  std::vector<int> pll_free;           // slots not in use, lowest last
   int *list_active_dev = nullptr;      // the active channels, for the filter launch, when remove_channel has left holes
   int *list_active_ds_dev = nullptr;   // the same list as the PCM stage reads it, on the demodulators' stream
   // Every active channel, in no particular order (the lists follow the channels' coming and going incrementally: a channel
@@ -191,8 +199,6 @@ struct kq_bank {
   // only while there are holes (fewer entries than slots); a bank whose channels have ALL been removed never launches.
   std::vector<int> list_active_host;
   std::vector<int> list_pll_host;
-  kq::PllState *pll_state = nullptr;
-  float2 *pll_rings = nullptr, *pll_side = nullptr;
   std::vector<int> list_host[3];
   bool lists_dirty = true;
   float *energy_state = nullptr;
@@ -312,6 +318,7 @@ struct kq_bank {
   // no channel has `retuned` set, and the cached launch decisions below still hold.
   bool osc_dirty = true;
   int64_t planes_n_w = 0, planes_out_abs = 0, rebased_at = 0;
+  size_t refresh_next = 0;  // the channel whose closed forms the next steady call re-references first
   bool cache_any = false;
   // Retunes (kq_bank_set_second_lo / _doppler / _shift) leave the steady state intact: the channels touched since the last
   // call are on patch_list, and the next call advances everybody on the device as usual and then overwrites just those
@@ -1041,7 +1048,7 @@ int upload_lists(kq_bank *b) {
     size_t const whole = (size_t)b->cfg.max_channels * sizeof(int);
     ctl_cancel_range(b, CTL_FILTER, b->list_active_dev, whole);
     ctl_cancel_range(b, CTL_DEMOD, b->list_active_ds_dev, whole);
-    if (b->list_pll_dev) ctl_cancel_range(b, CTL_DEMOD, b->list_pll_dev, kq_bank::kMaxPll * sizeof(int));
+    if (b->list_pll_dev) ctl_cancel_range(b, CTL_DEMOD, b->list_pll_dev, whole);
     for (int k = 0; k < 3; k++) ctl_cancel_range(b, CTL_DEMOD, b->list_dev[k], whole);
   }
   if (ctl_put(b, CTL_FILTER, b->list_active_dev, b->list_active_host.data(), n)) return -1;
@@ -1125,6 +1132,7 @@ int lists_remove(kq_bank *b, int c, bool from_active = true) {
 // `spectrum` holds its N bins per block -- slave, compute_n0 and demodulators only (kq_bank_process_spectrum)
 int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const unsigned char *update_host,
                      const float2 *spectrum);
+void note_patch(kq_bank *b, int ch);
 
 // kq_bank_get_host_timing: the host's wall time inside one call, kernels only queued (call_ms includes slot_wait_ms)
 int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigned char *update_host,
@@ -1194,6 +1202,29 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     b->n_active = n_active;
     b->sweep_lists_dirty = true;
   } else {
+    // Rolling re-reference.  The device advances the oscillator planes from call to call; the host's closed forms, which a
+    // retune is patched from, are referred to the sample they were last staged at and lose digits as that recedes (f k at
+    // k = 2^24: 1e-9 turns).  Until round 5 the whole bank was therefore staged afresh every 2^24 samples -- at 32768
+    // channels a call with 0.4-3 ms more host time and 2 MB over the link every 1.68 s: the periodic stall of a paced
+    // receiver (tools/rt_stall_diag.sh: long delivery intervals at multiples of 1.68 s).  Now every call moves a few
+    // channels' reference up and re-stages just those through the patch records (33 of 32768 per 2-block call), so that
+    // each channel comes round at least once per 2^24 samples and no call is different from the others.
+    {
+      size_t const Cn = b->chans.size();
+      double const span = (double)nblocks * (double)g.L;
+      size_t want = (size_t)((double)Cn * span / (double)(1 << 24)) + 1;
+      want = std::min({want, Cn, (size_t)kq_bank::kMaxPatch / 2});
+      for (size_t i = 0; i < want && (int)b->patch_list.size() < kq_bank::kMaxPatch / 2; i++) {
+        size_t const c = b->refresh_next < Cn ? b->refresh_next : 0;
+        b->refresh_next = c + 1;
+        HostChan &h = b->chans[c];
+        if (!h.active || h.patched) continue;  // (a channel the operator has just set is staged from fresh forms anyway)
+        h.lo2.rebase(b->n_abs);
+        h.dop.rebase(b->n_abs);
+        h.shift.rebase(b->out_abs);
+        note_patch(b, (int)c);
+      }
+    }
     for (int c : b->patch_list) {
       if ((size_t)c >= b->chans.size()) continue;
       HostChan &h = b->chans[c];
@@ -1437,8 +1468,8 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   }
   LAUNCH_CHECK("demodulators");
   if (!b->list_pll_host.empty())
-    kq::launch_demod_pll(ds, g, chd, pl, b->tw, b->list_pll_dev, (int)b->list_pll_host.size(), b->pll_state,
-                         b->pll_rings, b->pll_side, (int)nblocks, b->cfg.compute_n0);
+    kq::launch_demod_pll(ds, g, chd, pl, b->tw, b->list_pll_dev, (int)b->list_pll_host.size(), b->pll_chunks_dev, b->pll_slot_dev,
+                         (int)nblocks, b->cfg.compute_n0);
   if (g.pl_n > 0 && !b->list_host[0].empty())
     kq::launch_pl_track(ds, g, chd, pl, b->tw, b->list_dev[0], (int)b->list_host[0].size(), (int)nblocks);
   if (b->pcm_on) {
@@ -1470,11 +1501,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     }
     b->rebased_at = b->n_abs;
     b->osc_dirty = spectrum != nullptr;  // (a spectrum call stages no oscillators the next call could advance)
-  } else if (b->n_abs - b->rebased_at > ((int64_t)1 << 24)) {
-    // the host's closed forms are referred to the sample of the last full staging: move them up before f k loses digits
-    // (2^24 samples: 1e-9 turns) -- the next call stages afresh from the host's own oscillators
-    b->osc_dirty = true;
-  }
+  }  // (steady calls keep the host's closed forms fresh a few channels at a time: the rolling re-reference above)
   b->last_blocks = nblocks;
   return (int)nblocks;
 }
@@ -1852,8 +1879,14 @@ int kq_bank_destroy(kq_bank *b) {
                   b->pl2[0].plout, b->pl2[1].plout, b->pl.audio, b->pl.status, b->pl2[0].filt, b->pl2[0].n0raw, b->pl2[0].if_power,
                   b->pl2[1].filt, b->pl2[1].n0raw, b->pl2[1].if_power, b->energy_state, b->win_paired,
                   b->big.sync, b->big.n0part, b->big.xs,
-                  b->list_dev[0], b->list_dev[1], b->list_dev[2], b->list_active_dev, b->list_active_ds_dev, b->chd.fflags, b->list_unswept_dev, b->list_swept_dev, b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->list_pll_dev, b->pll_state, b->pll_rings,
-                  b->pll_side, b->dq.scratch, b->dq.ng_next};
+                  b->list_dev[0], b->list_dev[1], b->list_dev[2], b->list_active_dev, b->list_active_ds_dev, b->chd.fflags, b->list_unswept_dev, b->list_swept_dev, b->spec_dump, b->stage_dev, b->pcm, b->pcm_mask, b->list_pll_dev, b->pll_slot_dev, b->pll_chunks_dev,
+                  b->dq.scratch, b->dq.ng_next};
+  for (kq::PllChunk const &ck : b->pll_chunks) {
+    if (ck.state) (void)hipFree(ck.state);
+    if (ck.rings) (void)hipFree(ck.rings);
+    if (ck.side) (void)hipFree(ck.side);
+  }
+  b->pll_chunks.clear();
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (auto *v : {&b->ev_filter, &b->ev_demod, &b->ev_ingest})
@@ -1906,32 +1939,9 @@ int kq_bank_destroy(kq_bank *b) {
 namespace {
 static bool is_pll(const kq_channel_config &c) { return c.demod_type == KQ_LINEAR_DEMOD && c.pll; }
 
-// PLL channels own the slot equal to their rank among the PLL channels (upload_lists): when a channel enters or
-// leaves that set the carried state of the channels behind it moves by one slot
-static int move_pll_slot(kq_bank *b, int from, int to) {
-  HIP_TRY(hipMemcpy(b->pll_state + to, b->pll_state + from, sizeof(kq::PllState), hipMemcpyDeviceToDevice));
-  HIP_TRY(hipMemcpy(b->pll_rings + (size_t)to * 65536, b->pll_rings + (size_t)from * 65536, sizeof(float2) * 65536,
-                    hipMemcpyDeviceToDevice));
-  return 0;
-}
-
-// slot channel `ch` has or would have among the PLL channels, and how many others there are
-static void pll_rank(const kq_bank *b, int ch, int &rank, int &npll) {
-  rank = npll = 0;
-  for (int c = 0; c < (int)b->chans.size(); c++)
-    if (c != ch && b->chans[c].active && is_pll(b->chans[c].cfg)) {
-      npll++;
-      if (c < ch) rank++;
-    }
-}
-
-// checks and lazy allocations before a channel becomes a PLL channel (linear.c:51-56: the carrier search window is
-// +-300 Hz, x2 when squaring, in bins of the 65536-point transform)
-static int pll_admit(kq_bank *b, const kq_channel_config &m, int npll) {
-  if (npll >= kq_bank::kMaxPll) {
-    set_err("at most %d carrier-tracking (pll) channels per bank", kq_bank::kMaxPll);
-    return -1;
-  }
+// checks before a channel becomes a PLL channel (linear.c:51-56: the carrier search window is +-300 Hz, x2 when squaring,
+// in bins of the 65536-point transform)
+static int pll_admit(kq_bank *b, const kq_channel_config &m) {
   float const samptime = (float)b->g.D / (float)b->g.samprate;
   float const binsize = (float)(1. / (65536 * samptime));
   int const nbins = 2 * (int)round((m.square ? 2 : 1) * 300.f / binsize) + 1;
@@ -1939,27 +1949,55 @@ static int pll_admit(kq_bank *b, const kq_channel_config &m, int npll) {
     set_err("output rate too low for the PLL search window (%d bins > 4096)", nbins);
     return -1;
   }
-  if (!b->pll_state) {
-    if (ctl_flush_now(b) || sync_all(b)) return -1;
-    if (dev_alloc(&b->pll_state, kq_bank::kMaxPll) || dev_alloc(&b->pll_rings, (size_t)kq_bank::kMaxPll * 65536) ||
-        dev_alloc(&b->pll_side, (size_t)kq_bank::kMaxPll * 4096) || dev_alloc(&b->list_pll_dev, kq_bank::kMaxPll))
-      return -1;
-  }
   return 0;
 }
 
-// open slot `rank` for a fresh loop (linear.c:97-112) / close it; both streams are idle
-static int pll_enter(kq_bank *b, int rank, int npll) {
-  for (int s = npll; s > rank; s--)
-    if (move_pll_slot(b, s - 1, s)) return -1;
-  HIP_TRY(hipMemset(b->pll_state + rank, 0, sizeof(kq::PllState)));
-  HIP_TRY(hipMemset(b->pll_rings + (size_t)rank * 65536, 0, sizeof(float2) * 65536));
+// A slot for channel c's carrier loop, started afresh (linear.c:97-112): state and ring are zeroed by fill records of the
+// demodulator side's queue -- applied in front of the next call's demodulators, behind the ones in flight, which may
+// still be running the slot's previous owner.  Nothing here waits for the device; a chunk of slots is allocated when the
+// free list runs out (33 MiB per 64 channels).
+static int pll_acquire(kq_bank *b, int c) {
+  size_t const Cmax = b->cfg.max_channels;
+  if (!b->list_pll_dev) {
+    if (dev_alloc(&b->list_pll_dev, Cmax) || dev_alloc(&b->pll_slot_dev, Cmax) ||
+        dev_alloc(&b->pll_chunks_dev, (size_t)kq_bank::kMaxPllChunks))
+      return -1;
+  }
+  if (b->pll_free.empty()) {
+    if ((int)b->pll_chunks.size() >= kq_bank::kMaxPllChunks) {
+      set_err("at most %d carrier-tracking (pll) channels per bank", kq_bank::kMaxPllChunks * kq::kPllChunk);
+      return -1;
+    }
+    kq::PllChunk ck{};
+    if (dev_alloc(&ck.state, (size_t)kq::kPllChunk) || dev_alloc(&ck.rings, (size_t)kq::kPllChunk * 65536) ||
+        dev_alloc(&ck.side, (size_t)kq::kPllChunk * 4096)) {
+      if (ck.state) (void)hipFree(ck.state);
+      if (ck.rings) (void)hipFree(ck.rings);
+      if (ck.side) (void)hipFree(ck.side);
+      return -1;
+    }
+    int const k = (int)b->pll_chunks.size();
+    b->pll_chunks.push_back(ck);
+    if (ctl_put(b, CTL_DEMOD, b->pll_chunks_dev + k, &ck, sizeof ck)) return -1;
+    for (int s = kq::kPllChunk - 1; s >= 0; s--) b->pll_free.push_back(k * kq::kPllChunk + s);
+  }
+  int const slot = b->pll_free.back();
+  b->pll_free.pop_back();
+  kq::PllChunk const &ck = b->pll_chunks[slot / kq::kPllChunk];
+  int const sl = slot % kq::kPllChunk;
+  if (ctl_fill(b, CTL_DEMOD, ck.state + sl, 0u, sizeof(kq::PllState)) ||
+      ctl_fill(b, CTL_DEMOD, ck.rings + (size_t)sl * 65536, 0u, sizeof(float2) * 65536) ||
+      ctl_put(b, CTL_DEMOD, b->pll_slot_dev + c, &slot, sizeof(int))) {
+    b->pll_free.push_back(slot);
+    return -1;
+  }
+  b->chans[c].pll_slot = slot;
   return 0;
 }
-static int pll_leave(kq_bank *b, int rank, int npll) {
-  for (int s = rank; s < npll; s++)
-    if (move_pll_slot(b, s + 1, s)) return -1;
-  return 0;
+static void pll_release(kq_bank *b, int c) {
+  int &slot = b->chans[c].pll_slot;
+  if (slot >= 0) b->pll_free.push_back(slot);
+  slot = -1;
 }
 }  // namespace
 
@@ -1993,12 +2031,7 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
     set_err("FM working set of %zu bytes exceeds the 160 KiB of LDS at this geometry", kq::demod_fm_lds_bytes(b->g));
     return -1;
   }
-  if (is_pll(*cfg)) {
-    int rank, npll;
-    pll_rank(b, c, rank, npll);
-    if (pll_admit(b, *cfg, npll)) return -1;
-    if (ctl_flush_now(b) || sync_all(b) || pll_enter(b, rank, npll)) return -1;
-  }
+  if (is_pll(*cfg) && pll_admit(b, *cfg)) return -1;
   HostChan h;
   h.cfg = *cfg;
   h.out_type = (cfg->demod_type == KQ_LINEAR_DEMOD && cfg->isb) ? kq::FT_CROSS_CONJ : kq::FT_COMPLEX;
@@ -2012,12 +2045,8 @@ int kq_bank_add_channel(kq_bank *b, const kq_channel_config *cfg) {
     b->chans.push_back(h);
   else
     b->chans[c] = h;
-  if (upload_channel(b, c) || queue_design(b, c)) {
-    if (is_pll(*cfg)) {  // give the slot back
-      int rank, npll;
-      pll_rank(b, c, rank, npll);
-      (void)pll_leave(b, rank, npll);
-    }
+  if ((is_pll(*cfg) && pll_acquire(b, c)) || upload_channel(b, c) || queue_design(b, c)) {
+    pll_release(b, c);  // (the slot it may have been given)
     release_n0slot(b, b->chans[c].n0slot);  // (the mask set it may have been given)
     b->chans[c].n0slot = -1;
     if (appended)
@@ -2264,13 +2293,8 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
     return -1;
   }
   HostChan &h = b->chans[ch];
-  if (is_pll(h.cfg)) {  // carrier-loop slots move by synchronous copies: both streams idle first (at most 64 such channels)
-    if (ctl_flush_now(b) || sync_all(b)) return -1;
-    int rank, npll;
-    pll_rank(b, ch, rank, npll);
-    if (pll_leave(b, rank, npll)) return -1;
-  }
-  // (nothing on the device changes otherwise: the calls in flight still carry the channel, the next call's lists do not)
+  pll_release(b, ch);  // (a carrier loop's slot goes back on the free list: its next owner starts it afresh)
+  // (nothing on the device changes: the calls in flight still carry the channel, the next call's lists do not)
   if (lists_remove(b, ch)) return -1;
   h.active = false;
   h.retuned = false;
@@ -2324,12 +2348,9 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
   // last call's demodulators (upload_channel); only carrier-loop slots, moved by synchronous copies, need the device idle
   HostChan &h = b->chans[ch];
   bool const was = is_pll(h.cfg), now = is_pll(*m);
-  if ((was || now) && (ctl_flush_now(b) || sync_all(b))) return -1;
-  int rank, npll;
-  pll_rank(b, ch, rank, npll);
-  if (now && pll_admit(b, *m, npll)) return -1;
-  if (was && pll_leave(b, rank, npll)) return -1;  // a fresh loop either way (linear.c:97-112)
-  if (now && pll_enter(b, rank, npll)) return -1;
+  if (now && pll_admit(b, *m)) return -1;
+  if (was) pll_release(b, ch);  // a fresh loop either way (linear.c:97-112): the slot comes back zeroed, or another one
+  if (now && pll_acquire(b, ch)) return -1;
   // the mode table entry (radio.c:341-363); the input oscillators are not touched
   h.cfg.demod_type = m->demod_type;
   h.cfg.low = m->low > m->high ? m->high : m->low;  // radio.c:343-349

@@ -177,7 +177,12 @@ FftDim fft_dim(int n, bool *ok) {
     if (ok) *ok = true;
     return d;
   }
-  if (!fft_size_ok(n)) return d;
+  {  // (odd sizes are fine here -- a factor of a two-pass transform may be one; fft_size_ok's evenness is the filters' rule)
+    int m = n;
+    for (int p : {2, 3, 5})
+      while (m % p == 0) m /= p;
+    if (n < 2 || n > 65536 || m != 1) return d;
+  }
   {  // radices: 4s first (fewest passes), then 2, 3s, 5s
     int m = n;
     while (m % 4 == 0) d.f[d.nf++] = 4, m /= 4;

@@ -45,6 +45,15 @@ struct FftDim {
 FftDim fft_dim(int n, bool *ok);
 bool fft_size_ok(int n);      // n = 2^a 3^b 5^c, 2 <= n <= 65536, even
 
+// Carrier-tracking channels keep their loop state, 65536-sample ring and search scratch in a SLOT of their own for as long
+// as they exist (kq_bank.cpp pll_acquire): storage grows by chunks of kPllChunk slots, nothing ever moves.
+constexpr int kPllChunk = 64;
+struct PllChunk {
+  PllState *state;  // [kPllChunk]
+  float2 *rings;    // [kPllChunk][65536]
+  float2 *side;     // [kPllChunk][4096]
+};
+
 struct Geom {
   int N, L, M, D;
   FftDim dN, dNdec, dPl;  // the transforms of the generic path: master, slave / audio master, PL slave
@@ -206,7 +215,7 @@ bool demod_agc_wave_supported(const Geom &g);
 void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const int *list_fm, int n_fm,
                     const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0);
 void launch_demod_pll(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_pll,
-                      int n_pll, PllState *state, float2 *rings, float2 *side, int nblocks, int compute_n0);
+                      int n_pll, const PllChunk *chunks, const int *slot_of, int nblocks, int compute_n0);
 // chan_list (both): the active channels when kq_bank_remove_channel has left holes (nchan = its length), else null
 void launch_pcm(hipStream_t s, const Geom &g, const Planes &pl, short *pcm, unsigned *mask, int nchan, int nblocks,
                 const int *chan_list);

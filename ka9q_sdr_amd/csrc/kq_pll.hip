@@ -67,20 +67,22 @@ __device__ void fft16k(float2 *s, const float2 *__restrict__ tw, int tw_log2) {
 
 // dynamic LDS: 16384 float2 (search transform) + olen float2 (the block)
 __global__ void __launch_bounds__(1024) k_demod_linear_pll(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ tw,
-                                                           const int *__restrict__ list, PllState *__restrict__ states,
-                                                           float2 *__restrict__ rings, float2 *__restrict__ sides,
-                                                           int nblocks, int compute_n0) {
+                                                           const int *__restrict__ list, const PllChunk *__restrict__ chunks,
+                                                           const int *__restrict__ slot_of, int nblocks, int compute_n0) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   __shared__ float red_a[16], red_b[16];
   __shared__ int red_i[16];
   constexpr int FS = 1 << 16;  // linear.c:43
-  int const slot = blockIdx.x, c = list[slot];
+  int const c = list[blockIdx.x], slot = slot_of[c];  // the channel's slot: its for as long as it tracks a carrier
+  PllChunk const ck = chunks[slot / kPllChunk];
+  PllState *const states = ck.state;
+  int const sl = slot % kPllChunk;
   int const tid = threadIdx.x, nthr = blockDim.x, nw = nthr >> 6;
   int const olen = g.olen;
   float2 *S = lds + 16384;
-  float2 *ring = rings + (size_t)slot * FS;
-  float2 *side = sides + (size_t)slot * 4096;
-  PllState st = states[slot];
+  float2 *ring = ck.rings + (size_t)sl * FS;
+  float2 *side = ck.side + (size_t)sl * 4096;
+  PllState st = states[sl];
 
   bool const square = (ch.flags[c] & FLAG_SQUARE) != 0;
   bool const stereo = (ch.flags[c] & FLAG_STEREO) != 0;
@@ -307,7 +309,7 @@ __global__ void __launch_bounds__(1024) k_demod_linear_pll(Geom g, ChanDev ch, P
     __syncthreads();
   }
   if (tid == 0) {
-    states[slot] = st;
+    states[sl] = st;
     ch.gain[c] = gain;
     ch.hang[c] = hang;
     ch.n0[c] = n0;
@@ -315,11 +317,11 @@ __global__ void __launch_bounds__(1024) k_demod_linear_pll(Geom g, ChanDev ch, P
 }
 
 void launch_demod_pll(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *tw, const int *list_pll,
-                      int n_pll, PllState *state, float2 *rings, float2 *side, int nblocks, int compute_n0) {
+                      int n_pll, const PllChunk *chunks, const int *slot_of, int nblocks, int compute_n0) {
   if (n_pll <= 0) return;
   size_t const lds_bytes = ((size_t)16384 + g.olen) * sizeof(float2);
   ensure_dynamic_lds((const void *)k_demod_linear_pll, lds_bytes);
-  hipLaunchKernelGGL(k_demod_linear_pll, dim3(n_pll), dim3(1024), lds_bytes, s, g, ch, pl, tw, list_pll, state, rings, side,
+  hipLaunchKernelGGL(k_demod_linear_pll, dim3(n_pll), dim3(1024), lds_bytes, s, g, ch, pl, tw, list_pll, chunks, slot_of,
                      nblocks, compute_n0);
 }
 

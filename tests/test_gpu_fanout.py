@@ -336,7 +336,8 @@ def test_rccl_library_bound_is_the_one_torch_mapped(gpu):
     assert len({os.path.realpath(m) for m in mapped}) == 1, mapped
 
 
-def test_bench_launches_itself_as_two_ranks(gpu):
+@pytest.mark.parametrize("config,blocks,total", [("cfg4", 64, 2048), ("cfg5", 16, 1024)])
+def test_bench_launches_itself_as_two_ranks(gpu, config, blocks, total):
     """`bench.py --gpus 2` as a FRESH child process (never an exec of this one): self_launch starts the two ranks through
     torch.distributed.run, rank 0's identifier travels over the process group, both ranks enter kq_fanout_create -- where
     RCCL itself refuses two ranks on one GPU, on every rank, so the all-or-nothing return and the ranks' fall-back
@@ -349,6 +350,7 @@ def test_bench_launches_itself_as_two_ranks(gpu):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6", "--spinup", "20",
+           "--config", config, "--blocks", str(blocks),
            "--no-cpu-baseline", "--no-rows", "--no-realtime", "--no-host-io", "--no-second-row"]
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
@@ -362,7 +364,9 @@ def test_bench_launches_itself_as_two_ranks(gpu):
     assert len(lines) == 1, out
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak"
-    assert d["config"]["channels_total"] == 2048
+    assert d["config"]["channels_total"] == total and d["config"]["workload"].startswith(config)
+    # RCCL carried nothing between the two ranks (one GPU): the line says that no scaling figure may be read off it
+    assert d["scaling_measured"] is False and "host_ingest" not in d
     pr = d["per_rank"]
     assert [r["rank"] for r in pr] == [0, 1]
     for r in pr:
@@ -374,3 +378,23 @@ def test_bench_launches_itself_as_two_ranks(gpu):
     assert d["fanout"].startswith("torch.distributed.broadcast (gloo)"), d["fanout"]
     assert "kq_fanout unavailable" in d["fanout"] and "ncclCommInitRank" in d["fanout"], d["fanout"]
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
+
+
+def test_bench_host_ingest_leg_on_one_gpu(gpu):
+    """bench.py's `host_ingest` leg (at N > 1: the root takes every batch from pinned host memory and kq_fanout_post copies it
+    into the slot and broadcasts it on the side stream -- H2D + ncclBroadcast + compute in one pipeline) run at N = 1 with
+    `--ingest host`: the same code path with a world of one, so that the driver's 8-GPU run does not execute it for the
+    first time."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--spinup", "40", "--ingest", "host",
+           "--no-cpu-baseline", "--no-rows", "--no-realtime", "--no-host-io", "--no-second-row"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    hi = d["host_ingest"]
+    assert hi["steps"] == 10 and hi["value"] > 0.5 * d["value"] and hi["h2d_bytes_per_step"] == 8 * (8192 + 64 * 8192)
+    assert d["scaling_measured"] is True and d["n_gpus"] == 1

@@ -15,7 +15,9 @@ pytestmark = pytest.mark.gpu
 
 AUDIO_TOL = 1e-5      # relative RMS, north_star
 FILT_TOL = 1e-5
-FIRST_LINEAR_TOL = 2e-3   # audio of a linear channel's first block (AGC start-up on numerically-zero samples, linear.c:271-272)
+FIRST_LINEAR_TOL = 4e-3   # audio of a linear channel's first block (AGC start-up on numerically-zero samples, linear.c:271-272);
+                          # observed <= 7e-4 at powers of two, 2.5e-3 at N = 15360 (the mixed-radix transforms round differently from
+                          # the oracle's recursion: the start-up samples themselves are rounding noise)
 EXACT_TOL = 2e-6          # status sums against float64 arithmetic on the kernel's own samples
 
 
@@ -978,6 +980,132 @@ def test_retune_mid_stream_is_sample_exact(gpu, name, mode):
                 got = bank.filter_output(c, b)
                 assert rel_rms(got, filt) < FILT_TOL, (call, c, b, rel_rms(got, filt))
     bank.close()
+
+
+def _pll_case(fs, nsamp, seed):
+    """two emitters for carrier-tracking channels: a full-carrier AM signal at +20 037 Hz and a suppressed-carrier DSB one at
+    -30 061 Hz"""
+    t = np.arange(nsamp) / fs
+    rng = np.random.default_rng(seed)
+    msg = np.cos(2 * np.pi * 1000.0 * t)
+    sig = 0.1 * (1 + 0.5 * msg) * np.exp(2j * np.pi * 20037.0 * t)
+    sig = sig + 0.1 * np.cos(2 * np.pi * 700.0 * t) * np.exp(-2j * np.pi * 30061.0 * t + 0.7j)
+    return (sig + 1e-3 * (rng.standard_normal(nsamp) + 1j * rng.standard_normal(nsamp))).astype(np.complex64)
+
+
+def _pll_plan(n):
+    """n carrier-tracking channels: CAM (pll), DSB (pll + square) and stereo CAM in turn, each with its own offset from the
+    carrier inside the +-300 Hz search window (linear.c:51-56)"""
+    plan = []
+    for c in range(n):
+        off = -200.0 + 400.0 * ((c * 37) % 101) / 100.0
+        if c % 3 == 1:
+            plan.append(dict(demod="linear", low=-5000.0, high=5000.0, second_lo=30061.0 - 61.0 + 0.5 * off, hangtime=1.1,
+                             recovery_rate=6.0, pll=1, square=1))
+        else:
+            plan.append(dict(demod="linear", low=-5000.0, high=5000.0, second_lo=-20037.0 + off, hangtime=0.0, recovery_rate=50.0,
+                             pll=1, channels=2 if c % 3 == 2 else 1))
+    return plan
+
+
+def test_a_thousand_carrier_tracking_channels_in_one_bank(gpu):
+    """linear.c:129-246 on 1 024 channels of ONE bank (rounds 1-5 stopped at 64: slot = rank among the PLL channels, fixed
+    allocations; now a slot per channel out of chunks of 64 that are allocated as the count grows, kq_bank.cpp pll_acquire).
+    Every 93rd channel against the oracle: lock state, lock counter, hang counter block for block, carrier phase and offset,
+    audio; all channels: locked at the end, the right number of samples."""
+    g = wl.GEOMETRY["cfg1"]
+    fs, L = g["samprate"], g["L"]
+    C, nblocks, per_call = 1024, 48, 8
+    iq = _pll_case(fs, nblocks * L, 43)
+    plan = _pll_plan(C)
+    sampled = list(range(0, C, 93)) + [C - 1]
+    want = run_oracle([plan[c] for c in sampled], g, iq, nblocks)
+    bank = kq.Bank(fs, L, g["M"], g["D"], C, per_call, fwd_mode=kq.KQ_FWD_FULL)
+    for p in plan:
+        bank.add_channel(bank_cfg(p))
+    got = {c: dict(audio=[], status=[]) for c in sampled}
+    last = None
+    for first in range(0, nblocks, per_call):
+        bank.push_iq(iq[first * L:(first + per_call) * L])
+        assert bank.process() == per_call
+        for c in sampled:
+            for b in range(per_call):
+                got[c]["audio"].append(bank.audio(c, b))
+                got[c]["status"].append(bank.status(c, b))
+        if first + per_call == nblocks:
+            last = [bank.status(c, per_call - 1) for c in range(C)]
+    bank.close()
+    olen = L // g["D"]
+    for c in range(C):
+        assert last[c]["pll_lock"] == 1 and last[c]["nout"] == (2 * olen if plan[c].get("channels", 1) == 2 else olen), (c, last[c])
+    for i, c in enumerate(sampled):
+        auds, sts, _ = want[i]
+        for b in range(nblocks):
+            sg, sw = got[c]["status"][b], sts[b]
+            assert (sg["pll_lock"], sg["lock_count"], sg["nout"], sg["hangcount"]) == \
+                   (sw["pll_lock"], sw["lock_count"], sw["nout"], sw["hangcount"]), (c, b)
+            np.testing.assert_allclose(sg["foffset"], sw["foffset"], rtol=1e-3, atol=1e-3)
+            np.testing.assert_allclose(sg["cphase"], sw["cphase"], atol=2e-4)
+        a_g, a_w = np.concatenate(got[c]["audio"][24:]), np.concatenate(auds[24:])
+        assert rel_rms(a_g, a_w) < 2e-5, (c, rel_rms(a_g, a_w))
+
+
+def test_carrier_tracking_channels_come_and_go_while_the_bank_runs(gpu):
+    """Channels enter and leave the carrier-tracking set between calls in flight -- removed, added back into the holes, set_mode
+    out of a PLL mode and into one -- with nothing drained: slots are handed out from a free list and started afresh by fill
+    records in front of the next call's demodulators (rounds 1-5 moved the loops' state by synchronous copies).  Against a twin
+    that is drained around every change: every status word and every audio sample of every channel bit for bit; 150 channels
+    = three chunks of slots."""
+    g = dict(samprate=192000, L=2048, M=2049, D=4)
+    fs, L = g["samprate"], g["L"]
+    C, nb, ncalls = 150, 4, 9
+    iq = _pll_case(fs, ncalls * nb * L, 44)
+    plan = _pll_plan(C)
+    plain = dict(demod="linear", low=100.0, high=3000.0, second_lo=-20037.0, hangtime=1.1, recovery_rate=6.0)
+    out = []
+    for drained in (False, True):
+        bank = kq.Bank(fs, L, g["M"], g["D"], C, nb, fwd_mode=kq.KQ_FWD_FULL)
+        for p in plan[:100]:                              # the rest arrive while the bank runs
+            bank.add_channel(bank_cfg(p))
+        rec = []
+
+        def change(fn, *a):
+            if drained:
+                bank.sync()
+            return fn(*a)
+
+        for k in range(ncalls):
+            if k == 2:
+                for c in range(100, 130):
+                    assert change(bank.add_channel, bank_cfg(plan[c])) == c
+                for c in (3, 64, 65, 99):                 # out of the set: their slots go back
+                    change(bank.remove_channel, c)
+            if k == 4:
+                for c in (64, 3):                         # back into the holes (lowest first), fresh loops in recycled slots
+                    assert change(bank.add_channel, bank_cfg(plan[c])) in (3, 64)
+                for c in (10, 70):                        # a PLL mode -> plain SSB -> (two calls later) a PLL mode again
+                    change(bank.set_mode, c, bank_cfg(plain))
+                change(bank.set_mode, 11, bank_cfg(plan[12]))      # PLL -> PLL: a fresh loop in the same slot
+            if k == 6:
+                for c in (10, 70):
+                    change(bank.set_mode, c, bank_cfg(plan[c]))
+                for c in range(130, C):                   # the first two land in the holes 65 and 99, the rest behind
+                    change(bank.add_channel, bank_cfg(plan[c]))
+            bank.push_iq(iq[k * nb * L:(k + 1) * nb * L])
+            assert bank.process() == nb
+            live = sorted(c for c in range(bank.num_channels) if bank.channel_active(c))
+            rec.append({c: ([bank.status(c, b) for b in range(nb)], [bank.audio(c, b).copy() for b in range(nb)]) for c in live})
+        bank.close()
+        out.append(rec)
+    a, b = out
+    for k in range(ncalls):
+        assert a[k].keys() == b[k].keys(), k
+        for c in a[k]:
+            for blk in range(nb):
+                sa, sb = a[k][c][0][blk], b[k][c][0][blk]
+                assert all(np.array_equal(sa[f], sb[f], equal_nan=True) for f in sa), (k, c, blk, sa, sb)
+                assert np.array_equal(a[k][c][1][blk], b[k][c][1][blk]), (k, c, blk)
+    assert len(a[-1]) >= 148
 
 
 @pytest.mark.parametrize("mode", ["cam", "dsb"])

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 T=${1:-suite}
 mkdir -p $R/gpurun_out/$T
-cd $R && timeout 1200 python -m pytest tests -m gpu -x -q < /dev/null > gpurun_out/$T/gpu.txt 2>&1
+cd $R && timeout 1500 python -m pytest tests -m gpu -x -q --timeout 420 < /dev/null > gpurun_out/$T/gpu.txt 2>&1
 echo "pytest rc=$?"
 grep -E "passed|failed|^FAILED|^ERROR" gpurun_out/$T/gpu.txt
 grep -E "^E  " gpurun_out/$T/gpu.txt | head -20

@@ -210,6 +210,14 @@ int main(int argc, char **argv){
     if(paced && k >= warm){             /* the batch that is pushed below has just arrived: not before */
       double const due = origin + (double)(calls + 1) * signal_s;
       double now = now_s();
+      /* sleep most of the way, spin the last 0.2 ms: a loop that only spins is a CPU hog to the scheduler, and on a host shared
+       * with other jobs it was taken off its core for 5-11 ms once or twice a minute (the whole stall outside the library's calls) */
+      if(due - now > 3e-4){
+        double const nap = due - now - 2e-4;
+        struct timespec ts = { (time_t)nap, (long)((nap - (double)(time_t)nap) * 1e9) };
+        nanosleep(&ts, NULL);
+        now = now_s();
+      }
       while(now < due)
         now = now_s();
       if((size_t)calls < cap)

@@ -1087,7 +1087,12 @@ __global__ void __launch_bounds__(64) k_fm_audio256(Geom g, ChanDev ch, Planes p
 // Static LDS: S[64][128] float2 (64 KiB) | FO[65][128] float (row 0 = the block before the chunk) | Y[16][128] float.
 namespace {
 struct Audio256 {  // k_fm_audio256's transform pair, set up once per wave
+  // wf / wi: the lane-exchange stages' twiddles as the lane applies them -- the stage's twiddle in the upper lane of a
+  // butterfly pair, 1 in the lower one -- and sg: -1 / +1 likewise.  A stage is then the same six instructions in every
+  // lane (round 6; until then both arms of `bit ? (o - z) w : z + o` were computed and one selected: twelve).  The values
+  // are the old form's bit for bit: o - z and z + o round once either way, and a product with (1, 0) is exact.
   float2 hf[4], wf[6], wi[6], w4[3];
+  float sg[6];
   int lane;
   __device__ __forceinline__ void init(int lane_, const float2 *HA) {
     lane = lane_;
@@ -1104,8 +1109,10 @@ struct Audio256 {  // k_fm_audio256's transform pair, set up once per wave
       int const half = 1 << s;
       float sn, cs;
       sincospif((float)(lane & (half - 1)) / (float)half, &sn, &cs);
-      wf[s] = make_float2(cs, -sn);
-      wi[s] = make_float2(cs, sn);
+      bool const up = (lane >> s) & 1;
+      wf[s] = up ? make_float2(cs, -sn) : make_float2(1.f, 0.f);
+      wi[s] = up ? make_float2(cs, sn) : make_float2(1.f, 0.f);
+      sg[s] = up ? -1.f : 1.f;
     }
 #pragma unroll
     for (int r = 1; r < 4; r++) {
@@ -1139,17 +1146,16 @@ struct Audio256 {  // k_fm_audio256's transform pair, set up once per wave
     for (int r = 0; r < 4; r++) {
       float2 z = u[r];
 #pragma unroll
-      for (int s = 5; s >= 0; s--) {
+      for (int s = 5; s >= 0; s--) {  // forward, decimation in frequency: upper lane (o - z) w, lower lane z + o
         float2 const o = xor_pow(z, s);
-        z = ((lane >> s) & 1) ? cmul(csub(o, z), wf[s]) : cadd(z, o);
+        z = cmul(make_float2(fmaf(z.x, sg[s], o.x), fmaf(z.y, sg[s], o.y)), wf[s]);
       }
       z = cmul(hf[r], z);
 #pragma unroll
-      for (int s = 0; s < 6; s++) {
-        int const bit = (lane >> s) & 1;
-        float2 const v = bit ? cmul(z, wi[s]) : z;
+      for (int s = 0; s < 6; s++) {  // backward, decimation in time: v = z w (upper) / z (lower); upper o - v, lower v + o
+        float2 const v = cmul(z, wi[s]);
         float2 const o = xor_pow(v, s);
-        z = bit ? csub(o, v) : cadd(v, o);
+        z = make_float2(fmaf(v.x, sg[s], o.x), fmaf(v.y, sg[s], o.y));
       }
       u[r] = r ? cmul(z, cconj(w4[r - 1])) : z;
     }

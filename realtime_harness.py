@@ -139,25 +139,34 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
             if control_plane:
                 operate(k)
 
-        def deliver(k):
-            j = k % nbuf
-            if pcm:
-                bank.pull_pcm_planes_async(outs[j].data_ptr(), masks[j].data_ptr(), stats[j].data_ptr(), compact=compact_status)
-            else:
-                bank.pull_planes_async(outs[j].data_ptr(), stats[j].data_ptr())
-            bank.pull_wait(2)     # the planes of call k-2 are in host memory now; calls k-1 and k are in flight
-
         # One order of the three steps for both modes: process what was pushed before, push the batch that has just come in,
         # queue the delivery.  (Pushing FIRST looks more natural for a paced loop and is 25-60 % slower: the input copy then
         # sits behind the previous call's output copy kernel on a hardware queue they share and waits with it for that
         # call's demodulators -- 1.85 / 2.45 ms per call against 1.49 at 33 792 channels, gpurun r6b; include/ka9q_hip.h
         # "Call order for full overlap".)  Paced, the batch pushed in iteration n is the one complete at A_n and is
         # processed in iteration n + 1: one period of pipeline delay, no effect on the schedule.
+        steps = np.zeros((4, 400064), np.float32)     # ms inside control + process / push / queueing the delivery / waiting for k - 2
+        step_n = [0]
+
         def call(k):
+            t_a = time.perf_counter()
             control(k)
             assert bank.process() == B
+            t_b = time.perf_counter()
             push_batch()
-            deliver(k)
+            t_c = time.perf_counter()
+            j = k % nbuf
+            if pcm:
+                bank.pull_pcm_planes_async(outs[j].data_ptr(), masks[j].data_ptr(), stats[j].data_ptr(), compact=compact_status)
+            else:
+                bank.pull_planes_async(outs[j].data_ptr(), stats[j].data_ptr())
+            t_d = time.perf_counter()
+            bank.pull_wait(2)     # the planes of call k-2 are in host memory now; calls k-1 and k are in flight
+            i = step_n[0]
+            if i < steps.shape[1]:
+                steps[0, i], steps[1, i], steps[2, i], steps[3, i] = (t_b - t_a) * 1e3, (t_c - t_b) * 1e3, (t_d - t_c) * 1e3, \
+                    (time.perf_counter() - t_d) * 1e3
+                step_n[0] = i + 1
 
         call_paced = call
 
@@ -166,6 +175,9 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
         iq_dev = torch.from_numpy(iq_host).to(dev)
         nops = [0]
         gone = []
+
+        steps = np.zeros((4, 1), np.float32)
+        step_n = [0]
 
         def call(k):
             bank.process_resident(iq_dev.data_ptr(), B)
@@ -193,6 +205,7 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
     bank.enable_timing(1)
     bank.timing(reset=True)
     nops[0] = 0
+    step_n[0] = 0
     period = signal_s
     cap = int(min(400000, max(64, 1.5 * seconds / (period if paced else max(est, 1e-5)) + 64)))
     stamps = np.zeros(cap)          # when the iteration's delivery (k - 2) was in hand
@@ -220,7 +233,13 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
             while True:
                 due = origin + (n + 1) * period
                 now = time.perf_counter()
-                while now < due:                 # (a spin: sleep() comes back up to 60 us late, 4 % of a call)
+                # sleep most of the way, spin the last 0.25 ms.  (A loop that only spins is a CPU hog to the scheduler: on a host
+                # shared with other jobs it was taken off its core for 5-11 ms once or twice a minute -- gpurun r6i, the whole
+                # stall OUTSIDE the library's calls; a thread that sleeps is woken ahead of the hogs.)
+                if due - now > 4e-4:
+                    time.sleep(due - now - 2.5e-4)
+                    now = time.perf_counter()
+                while now < due:
                     now = time.perf_counter()
                 lag[n] = now - due
                 call_paced(k)
@@ -255,6 +274,15 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
     iv = np.diff(stamps) * 1e3 if n > 2 else np.zeros(1)
     pacing = {"p50": _pct(iv, 50), "p99": _pct(iv, 99), "p99.9": _pct(iv, 99.9), "max": round(float(iv.max()), 4),
               "longer_than_two_periods": int((iv > 2e3 * period).sum())}
+    worst = None
+    if host_io and n > 2 and step_n[0] >= n:
+        w = int(np.argmax(iv)) + 1           # the iteration that ended the longest interval: where its host time went
+        worst = {"interval_ms": round(float(iv[w - 1]), 4), "at_s": round(float(stamps[w] - t0), 2),
+                 "process_ms": round(float(steps[0, w]), 4), "push_ms": round(float(steps[1, w]), 4),
+                 "queue_delivery_ms": round(float(steps[2, w]), 4), "wait_delivery_ms": round(float(steps[3, w]), 4),
+                 "spin_before_ms": round(float(iv[w - 1] - steps[:, w].sum()), 4),
+                 "note": "the host's four steps inside the iteration that closed the longest delivery interval; spin_before = what "
+                         "is left: waiting for the clock (paced) or time outside the loop's calls (the host itself held up)"}
     deadline = None
     if paced:
         due = origin + (np.arange(n) + 1) * period
@@ -294,6 +322,7 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
     return {"config": config, "channels": C, "blocks_per_call": B, "compute_n0": int(bool(compute_n0)), "signal_ms_per_call": round(signal_s * 1e3, 4),
             "ms_per_call": round(dt * 1e3, 4), "realtime_factor": round(signal_s / dt, 4), "calls": ncalls,
             "wall_s": round(dt * ncalls, 2), "paced": bool(paced), "deadline": deadline, "delivery_interval_ms": pacing,
+            "longest_interval": worst,
             "gc": ({"collections": len(gc_pauses), "longest_ms": round(max([p[1] for p in gc_pauses] or [0.0]), 3),
                     "longest_generation": max(gc_pauses or [(-1, 0.0)], key=lambda p: p[1])[0]} if gc_on else
                    "frozen and off inside the timed loop"),

@@ -336,8 +336,11 @@ def test_rccl_library_bound_is_the_one_torch_mapped(gpu):
     assert len({os.path.realpath(m) for m in mapped}) == 1, mapped
 
 
-@pytest.mark.parametrize("config,blocks,total", [("cfg4", 64, 2048), ("cfg5", 16, 1024)])
-def test_bench_launches_itself_as_two_ranks(gpu, config, blocks, total):
+# cfg 5 with 16 channels x 4 blocks per rank: two PROCESSES share the one GPU here, and N = 65536's sibling workgroups wait for each
+# other (kq_full16k.hip sibling_exchange) -- with both ranks' launches in flight at once every sibling has to fit on the device, or
+# the two tenants starve each other's siblings until the bounded waits run out (minutes; the full 512 x 16 did exactly that).
+@pytest.mark.parametrize("config,blocks,channels,total", [("cfg4", 64, 1024, 2048), ("cfg5", 4, 16, 32)])
+def test_bench_launches_itself_as_two_ranks(gpu, config, blocks, channels, total):
     """`bench.py --gpus 2` as a FRESH child process (never an exec of this one): self_launch starts the two ranks through
     torch.distributed.run, rank 0's identifier travels over the process group, both ranks enter kq_fanout_create -- where
     RCCL itself refuses two ranks on one GPU, on every rank, so the all-or-nothing return and the ranks' fall-back
@@ -350,7 +353,7 @@ def test_bench_launches_itself_as_two_ranks(gpu, config, blocks, total):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6", "--spinup", "20",
-           "--config", config, "--blocks", str(blocks),
+           "--config", config, "--blocks", str(blocks), "--channels", str(channels),
            "--no-cpu-baseline", "--no-rows", "--no-realtime", "--no-host-io", "--no-second-row"]
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:

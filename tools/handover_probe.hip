@@ -12,9 +12,15 @@
 // workgroups of 68 KiB LDS per CU as the filter kernel has:
 //   mode 0  body only
 //   mode 1  body + today's front: 64 sixteen-byte loads per thread of the shared window
-//   mode 2  body + the pipelined hand-over: 16 window loads, 12 stores into the channel's pool, flag, 12 loads of what the
-//           siblings stored one block earlier
-// and prints the time per launch of each.  (mode 2) - (mode 0) against (mode 1) - (mode 0) is what the hand-over costs
+//   mode 2  body + the pipelined hand-over: 16 window loads, 12 stores into the channel's pool, a counter, 12 loads of what the
+//           siblings stored one block earlier -- in the form MI355X_MICROARCH.md measures as valid between workgroups on any
+//           XCDs: `sc1` stores, every storing wave's vmcnt(0), a workgroup barrier, ONE agent-scope atomic add; the consumer
+//           polls with a relaxed `sc1` load, a workgroup barrier, `sc1` loads of the rows
+//   mode 3  the same through the XCD's own L2 (the siblings ARE on one XCD): plain stores (the vector L1 writes through), loads
+//           that bypass the consumer's L1 (`sc0`); nothing the memory model promises, the best case of "the hand-over lives in L2"
+// (The first version of this probe released with __threadfence() and polled with ACQUIRE loads: every poll invalidates the
+// poller's L2, and 6 000 pollers took the launch from 1 ms to 14 -- the guide's "255 pollers cut chip bandwidth 37-71 %".)
+// Prints the time per launch of each.  (mode 2) - (mode 0) against (mode 1) - (mode 0) is what the hand-over costs
 // against what it saves on the memory side; the vector instructions a shared stage saves (15 -> 6.5 packed per output)
 // are not in here and are credited separately.
 #include <hip/hip_runtime.h>
@@ -51,7 +57,7 @@ __device__ __forceinline__ v4f body(v4f acc, int n) {
 
 template <int MODE>
 __global__ __launch_bounds__(kT, 4) void k_probe(const char *__restrict__ win, char *__restrict__ pool, unsigned *__restrict__ flags,
-                                                 float *__restrict__ out, int nchan, int body_n, unsigned epoch, unsigned *__restrict__ lost) {
+                                                 float *__restrict__ out, int nchan, int body_n, unsigned base, unsigned *__restrict__ lost) {
   extern __shared__ float lds[];  // 68 KiB: two workgroups per CU
   int const t = threadIdx.x;
   // siblings of a channel: workgroup ids congruent mod 8 (one XCD).  id = 8 * (4 * (chan / 8) + sibling) + chan % 8
@@ -59,7 +65,21 @@ __global__ __launch_bounds__(kT, 4) void k_probe(const char *__restrict__ win, c
   if (chan >= nchan) return;
   v4f acc = (v4f){1.f, 2.f, 3.f, 4.f};
   char *const mypool = pool + (size_t)chan * 2 * 4 * kClassBytes;   // [slot][class][16 row pairs][512][16 B]
-  unsigned *const myflags = flags + (size_t)chan * 2 * 4;           // [slot][sibling]
+  unsigned *const mycount = flags + (size_t)chan * 2;               // [slot]: adds of the four siblings, never reset
+  // (compiler builtins, not inline assembly: the compiler then counts the loads in flight itself.  aux bit 4 = sc1, bit 0 = sc0)
+  using rsrc_t = __amdgpu_buffer_rsrc_t;
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  rsrc_t const pr = __builtin_amdgcn_make_buffer_rsrc(mypool, 0, (int)(2 * 4 * kClassBytes), 0x00020000);
+  rsrc_t const cr = __builtin_amdgcn_make_buffer_rsrc(mycount, 0, 8, 0x00020000);
+  auto st16 = [&](unsigned off, v4f v) {
+    if (MODE == 2)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), pr, (int)off, 0, 16);
+    else
+      *reinterpret_cast<v4f *>(mypool + off) = v;
+  };
+  auto ld16 = [&](unsigned off) {
+    return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(pr, (int)off, 0, MODE == 2 ? 16 : 1));
+  };
   auto produce = [&](int b) {  // rows 4 S .. 4 S + 3 (row pairs) of all four quarters of block b's window; three classes out
     const char *w = win + (size_t)(b & (kBlocks - 1)) * kWinBytes;
     v4f x[16];
@@ -76,43 +96,41 @@ __global__ __launch_bounds__(kT, 4) void k_probe(const char *__restrict__ win, c
       y[4 + i] = r + s;
       y[8 + i] = r - s;
     }
-    char *slot = mypool + (size_t)(b & 1) * 4 * kClassBytes;
-    int n = 0;
+    unsigned const slot = (unsigned)(b & 1) * 4u * (unsigned)kClassBytes;
 #pragma unroll
-    for (int cls = 0; cls < 4; cls++) {
-      if (cls == S) continue;
+    for (int n = 0; n < 3; n++) {
+      int const cls = n + (n >= S ? 1 : 0);  // the three classes that are not this sibling's
 #pragma unroll
-      for (int i = 0; i < 4; i++)
-        *reinterpret_cast<v4f *>(slot + (size_t)cls * kClassBytes + (size_t)(4 * S + i) * kRowBytes + t * 16) = y[4 * n + i];
-      n++;
+      for (int i = 0; i < 4; i++) st16(slot + (unsigned)cls * (unsigned)kClassBytes + (unsigned)(4 * S + i) * kRowBytes + t * 16, y[4 * n + i]);
     }
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, before the barrier its signalling lane joins
     __syncthreads();
-    if (t == 0) __hip_atomic_store(myflags + (b & 1) * 4 + S, epoch + (unsigned)b + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) __hip_atomic_fetch_add(mycount + (b & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto consume = [&](int b) {  // this class's rows from the three siblings
-    if (t < 4 && t != S) {
-      unsigned const want = epoch + (unsigned)b + 1u;
+    if (t == 0) {
+      unsigned const want = base + 4u * (unsigned)(b / 2 + 1);   // all four siblings have stored block b (and the ones before)
       int it = 0;
-      while (__hip_atomic_load(myflags + (b & 1) * 4 + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want && ++it < (1 << 17))
-        __builtin_amdgcn_s_sleep(4);
+      for (;;) {
+        unsigned const v = __builtin_amdgcn_raw_buffer_load_b32(cr, (b & 1) * 4, 0, 16);   // relaxed, sc1: no invalidate, no fence
+        if ((int)(v - want) >= 0 || ++it >= (1 << 17)) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
       if (it >= (1 << 17)) atomicAdd(lost, 1u);  // (a sibling that never came: counted, never waited for without end)
     }
     __syncthreads();
-    const char *slot = mypool + (size_t)(b & 1) * 4 * kClassBytes + (size_t)S * kClassBytes;
+    unsigned const slot = (unsigned)(b & 1) * 4u * (unsigned)kClassBytes + (unsigned)S * (unsigned)kClassBytes;
     v4f x[12];
-    int n = 0;
 #pragma unroll
-    for (int sib = 0; sib < 4; sib++) {
-      if (sib == S) continue;
+    for (int n = 0; n < 3; n++) {
+      int const sib = n + (n >= S ? 1 : 0);
 #pragma unroll
-      for (int i = 0; i < 4; i++) x[4 * n + i] = *reinterpret_cast<const v4f *>(slot + (size_t)(4 * sib + i) * kRowBytes + t * 16);
-      n++;
+      for (int i = 0; i < 4; i++) x[4 * n + i] = ld16(slot + (unsigned)(4 * sib + i) * kRowBytes + t * 16);
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) acc += x[i];
   };
-  if (MODE == 2) produce(0);
+  if (MODE >= 2) produce(0);
   for (int b = 0; b < kBlocks; b++) {
     if (MODE == 1) {  // today: the whole window, 64 loads
       const char *w = win + (size_t)b * kWinBytes;
@@ -125,7 +143,7 @@ __global__ __launch_bounds__(kT, 4) void k_probe(const char *__restrict__ win, c
         for (int i = 0; i < 16; i++) acc += x[i];
       }
     }
-    if (MODE == 2) {
+    if (MODE >= 2) {
       // consume first: a sibling can then never store block b + 2 into the slot block b still sits in (its produce(b + 2)
       // follows its consume(b + 1), which needs everybody's produce(b + 1), which follows everybody's consume(b)) -- two
       // slots are enough, and what is consumed here was stored a whole body ago
@@ -161,19 +179,21 @@ int main(int argc, char **argv) {
   CHECK(hipFuncSetAttribute((const void *)k_probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   CHECK(hipFuncSetAttribute((const void *)k_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   CHECK(hipFuncSetAttribute((const void *)k_probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CHECK(hipFuncSetAttribute((const void *)k_probe<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  unsigned epoch = 0;
+  unsigned base = 0;  // what a slot's counter holds when a launch of mode 2 / 3 starts: 32 adds per such launch
   int const grid = ((nchan + 7) / 8) * 8 * 4;
   auto run = [&](int mode, int reps) {
     float best = 1e9f, sum = 0;
     for (int r = 0; r < reps + 3; r++) {
       CHECK(hipEventRecord(e0, 0));
-      epoch += 64;
-      if (mode == 0) hipLaunchKernelGGL(k_probe<0>, dim3(grid), dim3(kT), lds, 0, win, pool, flags, out, nchan, body_n, epoch, lost);
-      if (mode == 1) hipLaunchKernelGGL(k_probe<1>, dim3(grid), dim3(kT), lds, 0, win, pool, flags, out, nchan, body_n, epoch, lost);
-      if (mode == 2) hipLaunchKernelGGL(k_probe<2>, dim3(grid), dim3(kT), lds, 0, win, pool, flags, out, nchan, body_n, epoch, lost);
+      if (mode == 0) hipLaunchKernelGGL(k_probe<0>, dim3(grid), dim3(kT), lds, 0, win, pool, flags, out, nchan, body_n, base, lost);
+      if (mode == 1) hipLaunchKernelGGL(k_probe<1>, dim3(grid), dim3(kT), lds, 0, win, pool, flags, out, nchan, body_n, base, lost);
+      if (mode == 2) hipLaunchKernelGGL(k_probe<2>, dim3(grid), dim3(kT), lds, 0, win, pool, flags, out, nchan, body_n, base, lost);
+      if (mode == 3) hipLaunchKernelGGL(k_probe<3>, dim3(grid), dim3(kT), lds, 0, win, pool, flags, out, nchan, body_n, base, lost);
+      if (mode >= 2) base += 4u * (kBlocks / 2);
       CHECK(hipEventRecord(e1, 0));
       CHECK(hipEventSynchronize(e1));
       float ms;
@@ -188,12 +208,13 @@ int main(int argc, char **argv) {
     return sum / reps;
   };
   for (int r = 0; r < 20; r++) run(1, 1);  // clocks up
-  float const t0 = run(0, 20), t1 = run(1, 20), t2 = run(2, 20);
+  float const t0 = run(0, 20), t1 = run(1, 20), t2 = run(2, 20), t3 = run(3, 20);
   unsigned nlost = 0;
   CHECK(hipMemcpy(&nlost, lost, sizeof nlost, hipMemcpyDeviceToHost));
   printf("waits that ran out (must be 0): %u\n", nlost);
   printf("front of today (64 window loads per thread):   +%.4f ms over the body alone\n", t1 - t0);
-  printf("pipelined hand-over (16 + 12 loads, 12 stores): +%.4f ms over the body alone\n", t2 - t0);
+  printf("pipelined hand-over, sc1 stores and loads:      +%.4f ms over the body alone\n", t2 - t0);
+  printf("pipelined hand-over through the XCD's L2:       +%.4f ms over the body alone\n", t3 - t0);
   printf("hand-over bytes through the pool per launch: %.2f GB written, as much read; pool footprint %.0f MiB, live per XCD at a time "
          "(16 channel-blocks in flight): %.1f MiB against 4 MiB of L2\n",
          (double)nchan * kBlocks * 3 * kClassBytes / 1e9, (double)nchan * 2 * 4 * kClassBytes / 1048576.0, 16.0 * 2 * 3 * kClassBytes / 1048576.0);

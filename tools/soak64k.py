@@ -95,4 +95,18 @@ print("host I/O: %d steps queued without a host wait; last step's audio vs the b
 assert worst == 0.0
 bank.close()
 ref.close()
+# ---- N = 65536 at real time (round 6): the sibling workgroups' exchange beside other tenants' kernels -- the plane copy kernel of the
+# call before and the demodulators on their own stream fill CUs while the siblings wait for each other.  cfg 5's geometry, one
+# block (1.64 ms of signal) per call, paced by the clock, PCM planes + compact status out; kq_bank_host_io_wait raises if a
+# sibling's word never arrived.
+from realtime_harness import measure_realtime  # noqa: E402
+rt_seconds = max(4.0, min(30.0, steps / 300.0))
+stream = torch.cuda.Stream(device=dev)
+torch.cuda.set_stream(stream)
+r = measure_realtime(torch, kq, wl, "cfg5", 8192, 1, 0, stream, seconds=rt_seconds, pcm=True, compact_status=True, paced=True)
+print("N = 65536 at real time: %d swept SSB channels x 1 block per call, paced for %.0f s: %d of %d deliveries late (worst %.3f ms), "
+      "delivery intervals %s, filter pass %.3f ms mean / %.3f max of a %.3f ms period" %
+      (r["channels"], r["wall_s"], r["deadline"]["late_deliveries"], r["deadline"]["deliveries"], r["deadline"]["worst_lateness_ms"],
+       r["delivery_interval_ms"], r["filter_kernel_ms"], r["filter_kernel_max_ms"], r["deadline"]["period_ms"]))
+assert r["check"]["nout_sum"] == 8192 * 64, r["check"]
 print("soak ok")

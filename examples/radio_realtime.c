@@ -329,11 +329,13 @@ int main(int argc, char **argv){
                step[worst][1], step[worst][2], step[worst][3], tm.filter_max_ms, tm.filter_ms / (double)(tm.filter_launches ? tm.filter_launches : 1));
     }
     if(paced){
-      long late = 0, backlog_max = 0;
+      long late = 0, late_playout = 0, backlog_max = 0;
       double worst = 0;
       for(size_t i = skip; i < n; i++){
         double const due = origin + (double)(i + 1) * signal_s;
         double const late_by = stamp[i] - due - signal_s;      /* delivery i - 2 is due with the start of iteration i */
+        if(late_by > 0.100)                                     /* beyond the reference player's playout buffer (monitor.c:83) */
+          late_playout++;
         if(late_by > 0){
           late++;
           if(late_by > worst)
@@ -343,8 +345,8 @@ int main(int argc, char **argv){
         if(bl > backlog_max)
           backlog_max = bl;
       }
-      printf("deadline: %ld of %zu deliveries more than one call period behind schedule (worst %.3f ms late), deepest backlog %ld periods\n",
-             late, n - skip, 1e3 * worst, backlog_max);
+      printf("deadline: %ld of %zu deliveries more than one call period behind schedule (worst %.3f ms late), deepest backlog %ld periods; "
+             "beyond the reference player's 100 ms playout buffer (monitor.c:83): %ld\n", late, n - skip, 1e3 * worst, backlog_max, late_playout);
     }
     free(iv);
   }

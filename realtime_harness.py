@@ -191,6 +191,22 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
         for k in range(k0, k0 + ncalls):
             call(k)
 
+    # (before the warm-up, not between it and the timed loop: a full collection with torch loaded takes 50-100 ms, the device
+    #  falls idle and the first filter passes of the timed loop then ran 20 ms instead of 1.4 -- gpurun r6k)
+    gc_pauses = []
+    if not gc_on:
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+    else:                           # the A/B leg: every collection's generation and length
+        t_gc = [0.0]
+
+        def on_gc(phase, info):
+            if phase == "start":
+                t_gc[0] = time.perf_counter()
+            else:
+                gc_pauses.append((info.get("generation", -1), (time.perf_counter() - t_gc[0]) * 1e3))
+        gc.callbacks.append(on_gc)
     run(warm_calls, 0)
     if host_io:
         bank.host_io_wait()
@@ -210,20 +226,6 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
     cap = int(min(400000, max(64, 1.5 * seconds / (period if paced else max(est, 1e-5)) + 64)))
     stamps = np.zeros(cap)          # when the iteration's delivery (k - 2) was in hand
     lag = np.zeros(cap)             # paced: how long after its batch was complete the iteration started
-    gc_pauses = []
-    if not gc_on:
-        gc.collect()
-        gc.freeze()
-        gc.disable()
-    else:                           # the A/B leg: every collection's generation and length
-        t_gc = [0.0]
-
-        def on_gc(phase, info):
-            if phase == "start":
-                t_gc[0] = time.perf_counter()
-            else:
-                gc_pauses.append((info.get("generation", -1), (time.perf_counter() - t_gc[0]) * 1e3))
-        gc.callbacks.append(on_gc)
     k = warm_calls + 8 + 1
     n = 0
     try:
@@ -271,16 +273,17 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
     stamps, lag = stamps[:n], lag[:n]
     # pacing as the host sees it: the intervals between consecutive deliveries (a receiver's output buffer has to ride out the
     # longest of them)
-    iv = np.diff(stamps) * 1e3 if n > 2 else np.zeros(1)
+    skip_iv = min(n // 4, int(0.5 / period)) if paced else 0     # paced: the first half second is warm-up of the pacing itself
+    iv = np.diff(stamps[skip_iv:]) * 1e3 if n - skip_iv > 2 else np.zeros(1)
     pacing = {"p50": _pct(iv, 50), "p99": _pct(iv, 99), "p99.9": _pct(iv, 99.9), "max": round(float(iv.max()), 4),
               "longer_than_two_periods": int((iv > 2e3 * period).sum())}
     worst = None
     if host_io and n > 2 and step_n[0] >= n:
-        w = int(np.argmax(iv)) + 1           # the iteration that ended the longest interval: where its host time went
-        worst = {"interval_ms": round(float(iv[w - 1]), 4), "at_s": round(float(stamps[w] - t0), 2),
+        w = int(np.argmax(iv)) + 1 + skip_iv           # the iteration that ended the longest interval: where its host time went
+        worst = {"interval_ms": round(float(iv[w - 1 - skip_iv]), 4), "at_s": round(float(stamps[w] - t0), 2),
                  "process_ms": round(float(steps[0, w]), 4), "push_ms": round(float(steps[1, w]), 4),
                  "queue_delivery_ms": round(float(steps[2, w]), 4), "wait_delivery_ms": round(float(steps[3, w]), 4),
-                 "spin_before_ms": round(float(iv[w - 1] - steps[:, w].sum()), 4),
+                 "spin_before_ms": round(float(iv[w - 1 - skip_iv] - steps[:, w].sum()), 4),
                  "note": "the host's four steps inside the iteration that closed the longest delivery interval; spin_before = what "
                          "is left: waiting for the clock (paced) or time outside the loop's calls (the host itself held up)"}
     deadline = None
@@ -291,6 +294,9 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
         skip = min(n // 4, int(0.5 / period))      # the first half second is warm-up of the pacing itself
         deadline = {"period_ms": round(period * 1e3, 4), "deliveries": int(n - skip),
                     "late_deliveries": int((late_by[skip:] > 0).sum()),
+                    # the reference's player rides out 100 ms (monitor.c:83 PLAYOUT = SAMPRATE / 10): deliveries beyond THAT
+                    # are the ones a listener hears
+                    "playout_ms": 100.0, "late_beyond_playout": int((late_by[skip:] > 0.100).sum()),
                     "worst_lateness_ms": round(float(max(0.0, late_by[skip:].max())) * 1e3, 4),
                     "backlog_calls": {"p99.9": _pct(backlog[skip:], 99.9), "max": int(backlog[skip:].max())},
                     "start_lag_ms": {"p50": _pct(lag[skip:] * 1e3, 50), "p99.9": _pct(lag[skip:] * 1e3, 99.9),

@@ -14,8 +14,9 @@
 //   mode 1  body + today's front: 64 sixteen-byte loads per thread of the shared window
 //   mode 2  body + the pipelined hand-over: 16 window loads, 12 stores into the channel's pool, a counter, 12 loads of what the
 //           siblings stored one block earlier -- in the form MI355X_MICROARCH.md measures as valid between workgroups on any
-//           XCDs: `sc1` stores, every storing wave's vmcnt(0), a workgroup barrier, ONE agent-scope atomic add; the consumer
-//           polls with a relaxed `sc1` load, a workgroup barrier, `sc1` loads of the rows
+//           XCDs: `sc1` stores, every storing wave's vmcnt(0), a workgroup barrier, ONE relaxed agent-scope flag store; the
+//           consumer polls with relaxed agent-scope loads (as kq_full16k.hip's sibling_exchange does), a workgroup barrier,
+//           `sc1` loads of the rows
 //   mode 3  the same through the XCD's own L2 (the siblings ARE on one XCD): plain stores (the vector L1 writes through), loads
 //           that bypass the consumer's L1 (`sc0`); nothing the memory model promises, the best case of "the hand-over lives in L2"
 // (The first version of this probe released with __threadfence() and polled with ACQUIRE loads: every poll invalidates the
@@ -65,12 +66,11 @@ __global__ __launch_bounds__(kT, 4) void k_probe(const char *__restrict__ win, c
   if (chan >= nchan) return;
   v4f acc = (v4f){1.f, 2.f, 3.f, 4.f};
   char *const mypool = pool + (size_t)chan * 2 * 4 * kClassBytes;   // [slot][class][16 row pairs][512][16 B]
-  unsigned *const mycount = flags + (size_t)chan * 2;               // [slot]: adds of the four siblings, never reset
+  unsigned *const myflags = flags + (size_t)chan * 2 * 4;           // [slot][sibling]: launch tag + block, relaxed agent-scope words
   // (compiler builtins, not inline assembly: the compiler then counts the loads in flight itself.  aux bit 4 = sc1, bit 0 = sc0)
   using rsrc_t = __amdgpu_buffer_rsrc_t;
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   rsrc_t const pr = __builtin_amdgcn_make_buffer_rsrc(mypool, 0, (int)(2 * 4 * kClassBytes), 0x00020000);
-  rsrc_t const cr = __builtin_amdgcn_make_buffer_rsrc(mycount, 0, 8, 0x00020000);
   auto st16 = [&](unsigned off, v4f v) {
     if (MODE == 2)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), pr, (int)off, 0, 16);
@@ -105,17 +105,14 @@ __global__ __launch_bounds__(kT, 4) void k_probe(const char *__restrict__ win, c
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, before the barrier its signalling lane joins
     __syncthreads();
-    if (t == 0) __hip_atomic_fetch_add(mycount + (b & 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) __hip_atomic_store(myflags + (b & 1) * 4 + S, base + (unsigned)b + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto consume = [&](int b) {  // this class's rows from the three siblings
-    if (t == 0) {
-      unsigned const want = base + 4u * (unsigned)(b / 2 + 1);   // all four siblings have stored block b (and the ones before)
+    if (t < 4 && t != S) {  // relaxed polls (the product's sibling_exchange): no acquire, nothing invalidated
+      unsigned const want = base + (unsigned)b + 1u;
       int it = 0;
-      for (;;) {
-        unsigned const v = __builtin_amdgcn_raw_buffer_load_b32(cr, (b & 1) * 4, 0, 16);   // relaxed, sc1: no invalidate, no fence
-        if ((int)(v - want) >= 0 || ++it >= (1 << 17)) break;
+      while (__hip_atomic_load(myflags + (b & 1) * 4 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want && ++it < (1 << 17))
         __builtin_amdgcn_s_sleep(8);
-      }
       if (it >= (1 << 17)) atomicAdd(lost, 1u);  // (a sibling that never came: counted, never waited for without end)
     }
     __syncthreads();
@@ -183,7 +180,7 @@ int main(int argc, char **argv) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  unsigned base = 0;  // what a slot's counter holds when a launch of mode 2 / 3 starts: 32 adds per such launch
+  unsigned base = 0;  // launch tag of the flag words
   int const grid = ((nchan + 7) / 8) * 8 * 4;
   auto run = [&](int mode, int reps) {
     float best = 1e9f, sum = 0;
@@ -193,7 +190,7 @@ int main(int argc, char **argv) {
       if (mode == 1) hipLaunchKernelGGL(k_probe<1>, dim3(grid), dim3(kT), lds, 0, win, pool, flags, out, nchan, body_n, base, lost);
       if (mode == 2) hipLaunchKernelGGL(k_probe<2>, dim3(grid), dim3(kT), lds, 0, win, pool, flags, out, nchan, body_n, base, lost);
       if (mode == 3) hipLaunchKernelGGL(k_probe<3>, dim3(grid), dim3(kT), lds, 0, win, pool, flags, out, nchan, body_n, base, lost);
-      if (mode >= 2) base += 4u * (kBlocks / 2);
+      if (mode >= 2) base += 64u;
       CHECK(hipEventRecord(e1, 0));
       CHECK(hipEventSynchronize(e1));
       float ms;

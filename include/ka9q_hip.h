@@ -58,7 +58,10 @@ typedef struct kq_bank kq_bank;   /* opaque */
  *     (decimate = samprate / 48000, radio_status.c:266: 5 at 240 kHz with L = 4800, M = 4801).  A prime factor beyond 5 is
  *     refused.  decimate must divide N, L and M - 1 (the reference only warns when it does not, filter.c:106-107).  The fast
  *     kernels (N = 16384 / 65536 full-spectrum, the pruned ones, N/D = 64 and 256 demodulators) are power-of-two only;
- *   - the full-spectrum forward path (compute_n0 = 1) serves N <= 16384 and N = 65536; N = 32768 only without compute_n0;
+ *   - the full-spectrum forward path (compute_n0 = 1) serves N <= 16384 and N = 65536; N = 32768 only without compute_n0.
+ *     At N = 65536 the four workgroups of a channel-block wait for each other (bounded: a lost one gives NaN and an error
+ *     from kq_bank_sync, never a hung device): run such banks from ONE process per GPU -- two processes' launches in flight on
+ *     one device can starve each other's workgroups until the waits run out;
  *   - carrier-tracking channels (kq_channel_config.pll, linear.c:129-246): as many as the bank has channels, up to 65536;
  *     each keeps a 65536-sample search ring (544 KiB with its state), allocated 64 channels at a time as the count grows;
  *   - the PL-tone measurement needs 32 to divide N / decimate and L / decimate (fm.c:201-205 decimates by 32);

@@ -1165,10 +1165,13 @@ struct Audio256 {  // k_fm_audio256's transform pair, set up once per wave
 };
 }  // namespace
 
-__global__ void __launch_bounds__(512) k_demod_fm256(Geom g, ChanDev ch, Planes pl, const float *__restrict__ hist_in,
-                                                      float *__restrict__ hist_out, const int *__restrict__ list, int nblocks,
-                                                      int compute_n0) {
-  constexpr int olen = 128, W = 8;  // (16 waves leave 128 registers per lane: the audio transform then spills 112 of them)
+// W waves per channel: 8 (two per SIMD, 173 registers) or 16 (four per SIMD: the 128 registers that leaves spill 19 since the
+// exchange stages of round 6 -- 112 before, when 16 was first tried and dropped); KQ_FM256_WAVES picks, see launch_demods
+template <int W>
+__global__ void __launch_bounds__(64 * W) k_demod_fm256(Geom g, ChanDev ch, Planes pl, const float *__restrict__ hist_in,
+                                                         float *__restrict__ hist_out, const int *__restrict__ list, int nblocks,
+                                                         int compute_n0) {
+  constexpr int olen = 128;
   __shared__ __attribute__((aligned(16))) float2 S[64 * olen];
   __shared__ __attribute__((aligned(16))) float FO[65 * olen];
   __shared__ float Yall[W * olen];
@@ -1682,8 +1685,15 @@ void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes
   static bool const fused_off = getenv("KQ_FM_FUSED") && atoi(getenv("KQ_FM_FUSED")) == 0;
   bool const fused = g.Ndec == 256 && g.olen == 128 && g.Mdec == 129 && g.pl_n == 0 && !fused_off;
   if (n_fm > 0 && fused) {
-    hipLaunchKernelGGL(k_demod_fm256, dim3(n_fm), dim3(512), 0, s, g, ch, pl, fm_hist_in, fm_hist_out, list_fm, nblocks,
-                       compute_n0);
+    // (8 against 16 waves per channel, tools/ab_fm256.sh, three alternating rounds on one box: 35.3 / 35.2 / 35.7 us against
+    //  35.3 / 35.6 / 35.4 -- the launch is bound by its vector instruction count, 55 000 issue cycles per SIMD either way)
+    static int const waves = getenv("KQ_FM256_WAVES") ? atoi(getenv("KQ_FM256_WAVES")) : 8;
+    if (waves != 16)
+      hipLaunchKernelGGL(k_demod_fm256<8>, dim3(n_fm), dim3(512), 0, s, g, ch, pl, fm_hist_in, fm_hist_out, list_fm, nblocks,
+                         compute_n0);
+    else
+      hipLaunchKernelGGL(k_demod_fm256<16>, dim3(n_fm), dim3(1024), 0, s, g, ch, pl, fm_hist_in, fm_hist_out, list_fm, nblocks,
+                         compute_n0);
   } else if (n_fm > 0) {
     int const waves = fm_disc_waves(g, nblocks);
     size_t const lds_a = fm_disc_lds_bytes(g, waves), lds_b = fm_audio_lds_bytes(g);

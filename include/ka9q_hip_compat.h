@@ -9,8 +9,9 @@
  *
  * Differences a maintainer must know:
  *   - `fwd_plan` / `rev_plan` are opaque device contexts (void *), not fftwf_plan.
- *   - response arrays handed to create_filter_output() must come from malloc()/calloc()
- *     (the reference frees them with fftwf_free, filter.c:271; here it is free()).
+ *   - response arrays handed to create_filter_output() must come from malloc()/calloc() or from this library's
+ *     fftwf_alloc_complex (ka9q_hip_fftw.h: what fm.c:56 calls, once -lfftw3f has left the link line); the reference frees
+ *     them with fftwf_free (filter.c:271), here it is free() -- which releases either.
  *   - N = L+M-1: a power of two, 4 <= N <= 2^22, or an even 2^a 3^b 5^c up to 65536 (240 kHz front ends: L = 4800,
  *     M = 4801, decimate 5); past 16384 points the master's transform runs in two passes through device memory.
  *     N/decimate: the same kinds of size, 4 <= N/decimate <= 16384.  A prime factor beyond 5 returns NULL (FFTW would

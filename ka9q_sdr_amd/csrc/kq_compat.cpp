@@ -540,3 +540,120 @@ float cnrmf(kq_cfloat x) { return __real__ x * __real__ x + __imag__ x * __imag_
 double cnrm(kq_cdouble x) { return __real__ x * __real__ x + __imag__ x * __imag__ x; }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The FFTW entry points the reference calls OUTSIDE filter.c (include/ka9q_hip_fftw.h): fm.c:226-228,255,281-283 (the PL
+// tone's 16384-point r2c transform), linear.c:90-92,178,313-317 (the carrier search's 65536-point transform), the
+// allocators of fm.c:56,208 / modulate.c:115 (responses handed to create_filter_output, which frees them with free():
+// these allocate with aligned_alloc), and main.c:102-103,183-184 (wisdom / threads: nothing to do).  With them
+// `fm.o` / `linear.o` / `main.o` link against this library alone -- no libfftw3f on the link line.
+// A plan is (size, kind, the caller's two buffers); fftwf_execute moves one transform over the link and back.
+struct kq_fftwf_plan_s {
+  int n, kind;  // kind 0: c2c (sign), 1: r2c, 2: c2r
+  int sign;
+  void *in, *out;
+  int log2T;  // the half-circle table handed to the kernels (powers of two read it)
+  kq::FftDim dim;
+  float2 *d_in = nullptr, *d_out = nullptr, *d_tmp = nullptr;
+  std::vector<float2> stage;
+};
+
+static kq_fftwf_plan_s *fftw_plan_make(int n, int kind, int sign, void *in, void *out) {
+  bool const pow2 = n > 0 && (n & (n - 1)) == 0;
+  if (n < 2 || !in || !out || (pow2 ? n > (1 << 22) : !kq::fft_size_ok(n))) {
+    fprintf(stderr, "ka9q_hip: fftwf_plan: size %d must be a power of two up to 4194304 or an even 2^a 3^b 5^c up to 65536\n", n);
+    return nullptr;
+  }
+  if (!ctx_init()) return nullptr;
+  kq::DeviceScope dev_scope_(ctx().device);
+  auto *p = new kq_fftwf_plan_s();
+  p->n = n;
+  p->kind = kind;
+  p->sign = sign;
+  p->in = in;
+  p->out = out;
+  p->log2T = ilog2((unsigned)n);
+  bool ok = false;
+  p->dim = kq::fft_dim(n, &ok);
+  if (!ok || !twiddles(p->log2T) || hipMalloc((void **)&p->d_in, (size_t)n * sizeof(float2)) != hipSuccess ||
+      hipMalloc((void **)&p->d_out, (size_t)n * sizeof(float2)) != hipSuccess ||
+      (n > 16384 && hipMalloc((void **)&p->d_tmp, (size_t)n * sizeof(float2)) != hipSuccess)) {
+    (void)hipFree(p->d_in);
+    (void)hipFree(p->d_out);
+    delete p;
+    return nullptr;
+  }
+  if (kind != 0) p->stage.resize(n);
+  return p;
+}
+
+extern "C" {
+
+void *fftwf_malloc(size_t n) { return aligned_alloc(64, (n + 63) & ~(size_t)63); }
+float *fftwf_alloc_real(size_t n) { return static_cast<float *>(fftwf_malloc(n * sizeof(float))); }
+kq_cfloat *fftwf_alloc_complex(size_t n) { return static_cast<kq_cfloat *>(fftwf_malloc(n * sizeof(kq_cfloat))); }
+void fftwf_free(void *p) { free(p); }
+
+kq_fftwf_plan_s *fftwf_plan_dft_1d(int n, kq_cfloat *in, kq_cfloat *out, int sign, unsigned) {
+  return fftw_plan_make(n, 0, sign < 0 ? -1 : +1, in, out);
+}
+kq_fftwf_plan_s *fftwf_plan_dft_r2c_1d(int n, float *in, kq_cfloat *out, unsigned) { return fftw_plan_make(n, 1, -1, in, out); }
+kq_fftwf_plan_s *fftwf_plan_dft_c2r_1d(int n, kq_cfloat *in, float *out, unsigned) { return fftw_plan_make(n, 2, +1, in, out); }
+
+void fftwf_execute(const kq_fftwf_plan_s *cp) {
+  auto *p = const_cast<kq_fftwf_plan_s *>(cp);
+  if (!p) return;
+  kq::DeviceScope dev_scope_(ctx().device);
+  DevCtx &c = ctx();
+  int const n = p->n;
+  const void *src = p->in;
+  if (p->kind == 1) {  // real samples in
+    const float *x = static_cast<const float *>(p->in);
+    for (int i = 0; i < n; i++) p->stage[i] = make_float2(x[i], 0.f);
+    src = p->stage.data();
+  } else if (p->kind == 2) {  // n/2 + 1 bins in: Hermitian extension, DC and Nyquist taken as real (FFTW's c2r)
+    const float2 *X = static_cast<const float2 *>(p->in);
+    p->stage[0] = make_float2(X[0].x, 0.f);
+    p->stage[n / 2] = make_float2(X[n / 2].x, 0.f);
+    for (int k = 1; k < n / 2; k++) {
+      p->stage[k] = X[k];
+      p->stage[n - k] = make_float2(X[k].x, -X[k].y);
+    }
+    src = p->stage.data();
+  }
+  float2 *tw = twiddles(p->log2T);
+  std::lock_guard<std::mutex> lk(c.mu);  // one transform at a time on the context's stream
+  if (hipMemcpyAsync(p->d_in, src, (size_t)n * sizeof(float2), hipMemcpyHostToDevice, c.stream) != hipSuccess) return;
+  if (n > 16384) {
+    if (kq::launch_fft_large(c.stream, p->d_in, p->d_out, p->d_tmp, n, p->sign, tw, p->log2T)) return;
+  } else {
+    kq::launch_fft_single(c.stream, p->d_in, p->d_out, p->dim, p->sign, tw, p->log2T);
+  }
+  if (p->kind == 2) {
+    if (hipMemcpyAsync(p->stage.data(), p->d_out, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost, c.stream) != hipSuccess) return;
+    if (hipStreamSynchronize(c.stream) != hipSuccess) return;
+    float *y = static_cast<float *>(p->out);
+    for (int i = 0; i < n; i++) y[i] = p->stage[i].x;
+    return;
+  }
+  size_t const bins = p->kind == 1 ? (size_t)n / 2 + 1 : (size_t)n;
+  if (hipMemcpyAsync(p->out, p->d_out, bins * sizeof(float2), hipMemcpyDeviceToHost, c.stream) != hipSuccess) return;
+  (void)hipStreamSynchronize(c.stream);
+}
+
+void fftwf_destroy_plan(kq_fftwf_plan_s *p) {
+  if (!p) return;
+  kq::DeviceScope dev_scope_(ctx().device);
+  (void)hipFree(p->d_in);
+  (void)hipFree(p->d_out);
+  (void)hipFree(p->d_tmp);
+  delete p;
+}
+
+// main.c:102-103,183-184: FFTW's wisdom and threading have no counterpart here
+int fftwf_import_system_wisdom(void) { return 1; }
+void fftwf_make_planner_thread_safe(void) {}
+int fftwf_init_threads(void) { return 1; }
+void fftwf_plan_with_nthreads(int) {}
+
+}  // extern "C"

@@ -73,7 +73,7 @@ def test_library_exports_exactly_its_headers(lib):
                          check=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
     declared = set()
-    for h in ("ka9q_hip.h", "ka9q_hip_compat.h", "ka9q_hip_radio.h"):
+    for h in ("ka9q_hip.h", "ka9q_hip_compat.h", "ka9q_hip_radio.h", "ka9q_hip_fftw.h"):
         declared |= _declared(h)
     declared |= {"Kaiser_beta"}
     declared -= {"send_mono_output", "send_stereo_output"}       # the host program's (weak references here)

@@ -139,3 +139,73 @@ def test_design_entry_points_run_on_the_device(lib):
     assert lib.window_rfilter(128, 129, h.ctypes.data, 2.0) == 0
     ko.lib().kqo_window_rfilter(128, 129, h2.ctypes.data, 2.0)
     assert np.abs(h - h2).max() / np.abs(h2).max() < 1e-6
+
+
+def test_fftw_entry_points_outside_the_filter_api(lib):
+    """include/ka9q_hip_fftw.h: the FFTW names fm.c:226-283 (PL tone: 16384-point r2c), linear.c:90-317 (carrier search:
+    65536-point c2c) and main.c:102-103,183-184 call outside filter.c, served by the library so that their objects link
+    without libfftw3f.  Transforms against numpy's float64 ones; a response from fftwf_alloc_complex handed to
+    create_filter_output and released by delete_filter_output (fm.c:56 / filter.c:271)."""
+    for n in ("fftwf_alloc_real", "fftwf_alloc_complex", "fftwf_malloc"):
+        getattr(lib, n).restype = C.c_void_p
+        getattr(lib, n).argtypes = [C.c_size_t]
+    lib.fftwf_free.argtypes = [C.c_void_p]
+    lib.fftwf_plan_dft_1d.restype = C.c_void_p
+    lib.fftwf_plan_dft_1d.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_uint]
+    lib.fftwf_plan_dft_r2c_1d.restype = C.c_void_p
+    lib.fftwf_plan_dft_r2c_1d.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint]
+    lib.fftwf_plan_dft_c2r_1d.restype = C.c_void_p
+    lib.fftwf_plan_dft_c2r_1d.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint]
+    lib.fftwf_execute.argtypes = [C.c_void_p]
+    lib.fftwf_destroy_plan.argtypes = [C.c_void_p]
+    assert lib.fftwf_import_system_wisdom() == 1 and lib.fftwf_init_threads() == 1
+    lib.fftwf_make_planner_thread_safe()
+    lib.fftwf_plan_with_nthreads(4)
+    rng = np.random.default_rng(12)
+
+    def err(a, b):
+        return np.sqrt(np.mean(np.abs(a - b) ** 2) / np.mean(np.abs(b) ** 2))
+
+    # fm.c:226-228,255: r2c of (1 << 19) / 32 points, executed again and again on the same buffers
+    n = 16384
+    pin, pout = lib.fftwf_alloc_real(n), lib.fftwf_alloc_complex(n // 2 + 1)
+    assert pin and pout and pin % 64 == 0
+    plan = lib.fftwf_plan_dft_r2c_1d(n, pin, pout, 1 << 6)
+    assert plan
+    for _ in range(2):
+        x = rng.standard_normal(n).astype(np.float32)
+        _as(pin, n, np.float32)[:] = x
+        lib.fftwf_execute(plan)
+        assert err(_as(pout, n // 2 + 1, np.complex64), np.fft.rfft(x.astype(np.float64))) < 4e-7
+    lib.fftwf_destroy_plan(plan)
+    # back again: c2r (unnormalised, DC and Nyquist taken as real)
+    X = np.fft.rfft(x.astype(np.float64)).astype(np.complex64)
+    _as(pout, n // 2 + 1, np.complex64)[:] = X
+    plan = lib.fftwf_plan_dft_c2r_1d(n, pout, pin, 1 << 6)
+    lib.fftwf_execute(plan)
+    assert np.abs(_as(pin, n, np.float32) / n - x).max() < 2e-6
+    lib.fftwf_destroy_plan(plan)
+    lib.fftwf_free(pin)
+    lib.fftwf_free(pout)
+    # linear.c:90-92,178: c2c forward of 65536 points (two passes through device memory); and a size with factors 3 and 5
+    for n, sign in ((65536, -1), (65536, +1), (9600, -1), (48000, -1)):
+        a, b = lib.fftwf_alloc_complex(n), lib.fftwf_alloc_complex(n)
+        plan = lib.fftwf_plan_dft_1d(n, a, b, sign, 1 << 6)
+        assert plan
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        _as(a, n, np.complex64)[:] = x
+        lib.fftwf_execute(plan)
+        ref = np.fft.fft(x.astype(np.complex128)) if sign < 0 else np.fft.ifft(x.astype(np.complex128)) * n
+        assert err(_as(b, n, np.complex64), ref) < 5e-7, (n, sign)
+        lib.fftwf_destroy_plan(plan)
+        lib.fftwf_free(a)
+        lib.fftwf_free(b)
+    assert not lib.fftwf_plan_dft_1d(7 * 64, lib.fftwf_alloc_complex(448), lib.fftwf_alloc_complex(448), -1, 0)   # a factor 7: refused
+    # fm.c:56-66: a response allocated by fftwf_alloc_complex, owned and released by the filter (filter.c:271)
+    Lb, M = 512, 513
+    m = lib.create_filter_input(Lb, M, 3)
+    resp = lib.fftwf_alloc_complex((Lb + M - 1) // 2 + 1)
+    _as(resp, (Lb + M - 1) // 2 + 1, np.complex64)[:] = 1e-3
+    s = lib.create_filter_output(m, resp, 1, 3)
+    assert s and s.contents.response == resp
+    assert lib.delete_filter_output(s) == 0 and lib.delete_filter_input(m) == 0

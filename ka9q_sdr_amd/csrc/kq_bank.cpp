@@ -1567,8 +1567,8 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   // FFTW plans any N (filter.c:78); here a power of two, or -- on the generic kernels, one LDS block -- an even 2^a 3^b 5^c
   // up to 16384 (a front end whose rate is not 48 kHz x 2^k: 240 kHz gives decimate 5, radio_status.c:266)
   bool const n_pow2 = (N & (N - 1)) == 0;
-  if (cfg->L == 0 || cfg->M < 2 || N < 16 || (!n_pow2 && (!kq::fft_size_ok((int)N) || N > 16384))) {
-    set_err("L+M-1 = %u must be a power of two >= 16, or an even 2^a 3^b 5^c in 16..16384", N);
+  if (cfg->L == 0 || cfg->M < 2 || N < 16 || (!n_pow2 && (!kq::fft_size_ok((int)N) || N > 65536))) {
+    set_err("L+M-1 = %u must be a power of two >= 16, or an even 2^a 3^b 5^c in 16..65536", N);
     return nullptr;
   }
   if (cfg->decimate < 2 || N % cfg->decimate != 0 || cfg->L % cfg->decimate != 0 || (cfg->M - 1) % cfg->decimate != 0) {
@@ -1663,7 +1663,8 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   }
   b->use64k = b->fwd_mode == KQ_FWD_FULL && can64k;
   if (b->fwd_mode == KQ_FWD_FULL && N > 16384 && !b->use64k && (!kq::split_supported(g) || cfg->compute_n0)) {
-    set_err("N = %u: the full path beyond 16384 points needs N = 65536, or N = 32768 with N/D <= 2048 and compute_n0 off", N);
+    set_err("N = %u: the full path beyond 16384 points needs N = 65536, or compute_n0 off and a split N = S x N1 with N1 <= 16384 a "
+            "size of its own (N = 32768; 19200, 24000, 38400, 48000 ...) and N/D small enough to sit beside it in LDS", N);
     delete b;
     return nullptr;
   }

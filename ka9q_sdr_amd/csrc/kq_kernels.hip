@@ -454,12 +454,15 @@ void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const P
 // X[k] = sum_s W_N^{s k} F_s[k mod N1]; only the N/D bins the slave reads (filter.c:206-227) are combined,
 // into a small side buffer.  Same mix, response multiply, CROSS_CONJ and inverse transform as k_filter_full.
 // compute_n0 needs every bin of the N-point spectrum and is not available on this path.
+// Round 6: N1 and N/D may carry factors 3 and 5 (d1 / g.dNdec; twN = the full-circle table of N points then), so that a
+// bank takes N = 19200, 24000, 38400, 48000 ... as well as 32768.
 // grid (channel, block); dynamic LDS = (N1 + N_dec) float2.
 __global__ void k_filter_split(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ window,
-                               const float2 *__restrict__ tw, int S, int log2N1, const int *__restrict__ chan_list) {
+                               const float2 *__restrict__ tw, int S, FftDim d1, const float2 *__restrict__ twN,
+                               const int *__restrict__ chan_list) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   int const c = chan_list ? chan_list[blockIdx.x] : (int)blockIdx.x, b = blockIdx.y;
-  int const N = g.N, Ndec = g.Ndec, N1 = 1 << log2N1;
+  int const N = g.N, Ndec = g.Ndec, N1 = d1.n;
   float2 *side = lds + N1;  // X at signed bin k, stored at index k mod N_dec
   for (int i = threadIdx.x; i < Ndec; i += blockDim.x) side[i] = make_float2(0.f, 0.f);
 
@@ -476,16 +479,21 @@ __global__ void k_filter_split(Geom g, ChanDev ch, Planes pl, const float2 *__re
       double const rr = old ? hr : r;
       double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
       if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
-      lds[bitrev((unsigned)i, log2N1)] = cmul(x[n], phasor_turns(turns));
+      lds[fft_pos((unsigned)i, d1)] = cmul(x[n], phasor_turns(turns));
     }
-    lds_fft<-1>(lds, log2N1, tw, g.tw_log2);
+    fft_any<-1>(lds, d1, tw, g.tw_log2);
     for (int q = threadIdx.x; q < Ndec; q += blockDim.x) {
       int const k = (q <= Ndec / 2) ? q : q - Ndec;            // signed bin
       int const src = (k >= 0) ? k : N1 + k;                   // k mod N1
       int idx = (int)(((long long)s * k) % N);                 // W_N^{s k}
       if (idx < 0) idx += N;
-      float2 w = tw[(size_t)(idx & (N / 2 - 1)) << (g.tw_log2 - g.log2N)];
-      if (idx >= N / 2) w = make_float2(-w.x, -w.y);
+      float2 w;
+      if (twN) {
+        w = twN[idx];
+      } else {
+        w = tw[(size_t)(idx & (N / 2 - 1)) << (g.tw_log2 - g.log2N)];
+        if (idx >= N / 2) w = make_float2(-w.x, -w.y);
+      }
       side[q] = cadd(side[q], cmul(w, lds[src]));
     }
   }
@@ -503,27 +511,38 @@ __global__ void k_filter_split(Geom g, ChanDev ch, Planes pl, const float2 *__re
         gp = cadd(pos, cconj(neg));
         gn = csub(neg, cconj(pos));
       }
-      G[bitrev((unsigned)k, g.log2Ndec)] = gn;
+      G[fft_pos((unsigned)k, g.dNdec)] = gn;
     }
-    G[bitrev((unsigned)p, g.log2Ndec)] = gp;
+    G[fft_pos((unsigned)p, g.dNdec)] = gp;
   }
-  lds_fft<+1>(G, g.log2Ndec, tw, g.tw_log2);
+  fft_any<+1>(G, g.dNdec, tw, g.tw_log2);
   float2 *o = pl.filt + ((size_t)c * g.max_blocks + b) * g.olen;
   for (int i = threadIdx.x; i < g.olen; i += blockDim.x) o[i] = G[Ndec - g.olen + i];
 }
 
+// the split N = S * N1: the smallest S whose N1 is a size the LDS transform takes (a power of two: S = N / 16384)
+static int split_factor(const Geom &g) {
+  if (g.dN.log2n >= 0) return g.N > 16384 ? g.N >> 14 : 0;
+  for (int S = 2; S <= 64; S++)
+    if (g.N % S == 0 && g.N / S <= 16384 && fft_size_ok(g.N / S)) return S;
+  return 0;
+}
 bool split_supported(const Geom &g) {
-  return g.N > 16384 && g.N <= 65536 && (size_t)g.Ndec * 8 + 16384 * 8 <= 160 * 1024 - 256;
+  int const S = g.N > 16384 && g.N <= 65536 ? split_factor(g) : 0;
+  return S > 0 && (size_t)g.Ndec * 8 + (size_t)(g.N / S) * 8 <= 160 * 1024 - 256 && g.Ndec <= g.N / S;
 }
 
 void launch_filter_split(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                          const float2 *tw, int nchan, int nblocks, const int *chan_list) {
-  int const log2N1 = 14;
-  int const S = g.N >> log2N1;
-  size_t const lds_bytes = ((size_t)(1 << log2N1) + g.Ndec) * sizeof(float2);
+  int const S = split_factor(g);
+  if (S <= 0) return;
+  bool ok = false;
+  FftDim const d1 = fft_dim(g.N / S, &ok);  // (cached since the bank was created)
+  if (!ok) return;
+  size_t const lds_bytes = ((size_t)d1.n + g.Ndec) * sizeof(float2);
   ensure_dynamic_lds((const void *)k_filter_split, lds_bytes);
-  hipLaunchKernelGGL(k_filter_split, dim3(nchan, nblocks), dim3(1024), lds_bytes, s, g, ch, pl, window, tw, S, log2N1,
-                     chan_list);
+  hipLaunchKernelGGL(k_filter_split, dim3(nchan, nblocks), dim3(1024), lds_bytes, s, g, ch, pl, window, tw, S, d1,
+                     g.dN.log2n >= 0 ? (const float2 *)nullptr : g.dN.twc, chan_list);
 }
 
 // ---------------------------------------------------------------- demodulators

@@ -297,6 +297,8 @@ GEOMETRIES = [
     (9600,  4800,  4801,  150, 7200000, "auto", True),       # N/D = 64 behind a master with factors 3 and 5: the N/D = 64 demodulators
     (6000,  3000,  3001,  5,   240000, "auto", True),        # N/D = 1200, olen = 600
     (3000,  1500,  1501,  2,   96000,  "auto", True),        # N = 2^3 3 5^3 (one radix-2 pass), N/D = 1500
+    (24000, 12000, 12001, 25,  1200000, "full", False),      # beyond one LDS block with factors 3 and 5: split kernel, 2 x 12000
+    (38400, 19200, 19201, 40,  1920000, "full", False),      # split kernel, 3 x 12800, N/D = 960
 ]
 
 

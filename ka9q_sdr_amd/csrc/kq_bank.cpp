@@ -2350,8 +2350,22 @@ int kq_bank_set_mode(kq_bank *b, int ch, const kq_channel_config *m) {
   HostChan &h = b->chans[ch];
   bool const was = is_pll(h.cfg), now = is_pll(*m);
   if (now && pll_admit(b, *m)) return -1;
-  if (was) pll_release(b, ch);  // a fresh loop either way (linear.c:97-112): the slot comes back zeroed, or another one
-  if (now && pll_acquire(b, ch)) return -1;
+  {  // a fresh loop either way (linear.c:97-112).  The new slot is taken BEFORE the old one goes back: a failure (the
+     // allocation of another chunk) then leaves the channel as it was, loop and all
+    int const old_slot = h.pll_slot;
+    if (now) {
+      h.pll_slot = -1;
+      if (pll_acquire(b, ch)) {
+        h.pll_slot = old_slot;
+        if (old_slot >= 0 && ctl_put(b, CTL_DEMOD, b->pll_slot_dev + ch, &old_slot, sizeof(int))) return -1;
+        return -1;
+      }
+    }
+    if (was && old_slot >= 0) {
+      b->pll_free.push_back(old_slot);
+      if (!now) h.pll_slot = -1;
+    }
+  }
   // the mode table entry (radio.c:341-363); the input oscillators are not touched
   h.cfg.demod_type = m->demod_type;
   h.cfg.low = m->low > m->high ? m->high : m->low;  // radio.c:343-349

@@ -33,6 +33,7 @@
 #include <complex.h>
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -180,6 +181,11 @@ int main(int argc, char **argv){
   }
 
   /* ---- the receiver's loop (the same batch over and over: the stream is synthetic, the work is not) */
+  if(paced){      /* a receiver thread belongs in a real-time class; an ordinary user is normally refused (said below) */
+    struct sched_param sp = { .sched_priority = 1 };
+    printf("scheduler: %s\n", sched_setscheduler(0, SCHED_FIFO, &sp) == 0 ? "SCHED_FIFO" : "SCHED_OTHER (SCHED_FIFO refused: the long intervals "
+           "of a paced run on a shared host are this thread kept off its core)");
+  }
   double const signal_s = (double)B * L / SAMPRATE;
   long calls = 0, warm = 50;
   kq_host_timing ht;

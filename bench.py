@@ -406,6 +406,9 @@ def measure_channels_at_realtime(torch, kq, wl, dev_index, stream, seconds):
                          ("with_control_plane", dict(pcm=True, control_plane=True))):
             nb = 4 if name == "four_blocks_per_call" else 2
             out[name] = measure_realtime(torch, kq, wl, "cfg4", Cb, nb, dev_index, stream, seconds=short, paced=True, **kw)
+        # BASELINE's cfg 3 mix (FM + AM + USB / LSB in equal shares of the 64 emitters) at the same count: the AM / SSB
+        # demodulators' AGC scans instead of the FM discriminator on half of the channels
+        out["mixed_fm_am_ssb"] = measure_realtime(torch, kq, wl, "cfg3", Cb, 2, dev_index, stream, seconds=short, paced=True, pcm=True)
         for name, kw in (("pcm_int16", dict(pcm=True)), ("pcm_compact_status", dict(pcm=True, compact_status=True))):
             t = measure_realtime(torch, kq, wl, "cfg4", Cb, 2, dev_index, stream, seconds=2.0, **kw)
             out[name]["throughput_realtime_factor"] = t["realtime_factor"]

@@ -109,6 +109,23 @@ def test_no_silent_cpu_fallback(lib):
     assert lib.create_filter_input(512, 513, 1) is None
 
 
+def test_sizes_are_checked_before_any_device_is_asked_for(lib):
+    """N = L + M - 1 and N / decimate: powers of two, or even 2^a 3^b 5^c (round 6: the sizes FFTW takes and a front end at 240 kHz
+    needs, filter.c:78,132, radio_status.c:266).  A prime factor beyond 5 is refused with a message that says so -- with or
+    without a GPU in the box; a size that is served fails here only for want of a device."""
+    for L_, M_, D_, ok in ((4800, 4801, 5, True), (7680, 7681, 8, True), (12000, 12001, 25, True), (448 * 8, 448 * 8 + 1, 4, False),
+                           (4800, 4801, 7, False), (33 * 512, 33 * 512 + 1, 2, False)):
+        try:
+            b = kq.Bank(240000, L_, M_, D_, 1, 1, compute_n0=False)
+            b.close()
+            assert ok and lib.kq_device_count() > 0
+        except kq.KqError as e:
+            if ok:
+                assert "no HIP device" in str(e) and lib.kq_device_count() <= 0, str(e)
+            else:
+                assert "2^a 3^b 5^c" in str(e) or "divide" in str(e), str(e)
+
+
 def test_host_nco_entry_points(lib):
     """set_osc/step_osc of the compat surface are host scalar code: check them against the oracle."""
     import kq_oracle as ko
@@ -132,7 +149,11 @@ def test_headers_are_valid_c():
     inc = os.path.join(ROOT, "include")
     for body in ('#include "ka9q_hip.h"\nint f(void){ kq_bank_config c = {0}; return c.device; }\n',
                  '#include "ka9q_hip_compat.h"\nint f(void){ struct osc o; struct notchfilter n; (void)o; (void)n; return 0; }\n',
-                 '#include "ka9q_hip.h"\n#include "ka9q_hip_compat.h"\nint f(void){ return 0; }\n'):
+                 '#include "ka9q_hip.h"\n#include "ka9q_hip_compat.h"\nint f(void){ return 0; }\n',
+                 # the FFTW names of fm.c:226-228 / linear.c:90-92 / main.c:102-103, as a C host without <fftw3.h> sees them
+                 '#include "ka9q_hip_fftw.h"\nint f(void){ fftwf_complex *a = fftwf_alloc_complex(8); float *r = fftwf_alloc_real(8);\n'
+                 '  fftwf_plan p = fftwf_plan_dft_r2c_1d(8, r, a, FFTW_ESTIMATE); fftwf_execute(p); fftwf_destroy_plan(p);\n'
+                 '  fftwf_free(a); fftwf_free(r); fftwf_make_planner_thread_safe(); return fftwf_import_system_wisdom(); }\n'):
         with tempfile.NamedTemporaryFile("w", suffix=".c", delete=False) as t:
             t.write(body)
         r = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", t.name],

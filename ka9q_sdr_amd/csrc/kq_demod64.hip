@@ -787,7 +787,179 @@ __device__ void agc_channel(const Geom &g, const ChanDev &ch, const Planes &pl, 
   }
 }
 
+// The same for any block length (the generic geometries: N/D = 128 ... 16384, mixed radix included): one wave per
+// channel, a block in groups of 64 samples (the last one may be short), gain / hang counter / carrier estimate carried
+// from group to group in wave-uniform registers.  Where the 64-sample form keeps a block's end state per half, a block
+// here ends with a group, so the state after the group is the block's.  k_demod_am / k_demod_linear (one LANE per
+// channel, kq_kernels.hip) did this work before round 6: 1024 channels were 16 waves on a device with 1024 SIMDs.
+// FULL: the group has 64 samples and the serial loops unroll; the short last group of a block runs them as loops.
+
+// carrier tracking (am.c:62), serial; lane i keeps the value after sample i
+template <bool FULL>
+__device__ __forceinline__ float carrier_group(float env, int nsamp, int lane, float &dc) {
+  float dc_mine = dc;
+  int const ns = FULL ? 64 : nsamp;
+  constexpr int UNR = FULL ? 32 : 1;  // a runtime trip count and v_readlane (convergent) do not unroll
+#pragma unroll UNR
+  for (int i = 0; i < ns; i++) {
+    float const e = rdlane(env, i);
+    dc += 0.0001f * (e - dc);
+    dc_mine = (lane == i) ? dc : dc_mine;
+  }
+  return dc_mine;
+}
+
+// the AGC recurrence over one group in agc_channel's four forms (held / coasting / plain / general); returns the gain
+// each lane's sample is scaled by
+template <bool LINEAR, bool FULL>
+__device__ __forceinline__ float agc_group(float level, float inv, int nsamp, int lane, float headroom, float recovery,
+                                           int hangmax, float &gain, int &hang) {
+  int const ns = FULL ? 64 : nsamp;
+  constexpr int UNR = FULL ? 32 : 1;
+  bool const mine = lane < ns;
+  float g_mine = gain;
+  bool const held = !isnan(gain) && hang >= ns &&
+                    __ballot(mine && (LINEAR ? level * gain > headroom : gain * level > headroom)) == 0ull;
+  if (held) {
+    hang -= ns;
+    return g_mine;
+  }
+  if (hangmax != 0 && hang < ns && !isnan(gain)) {
+    float gg = gain, after = gain;
+#pragma unroll UNR
+    for (int i = 0; i < ns; i++) {
+      gg = (i >= hang) ? gg * recovery : gg;
+      after = (lane == i) ? gg : after;
+    }
+    float before = __shfl_up(after, 1, 64);
+    before = (lane == 0) ? gain : before;
+    if (__ballot(mine && (LINEAR ? level * before > headroom : before * level > headroom)) == 0ull) {
+      gain = gg;
+      hang = 0;
+      return after;
+    }
+  }
+  if (hangmax == 0 && hang == 0 && !isnan(gain) && __ballot(mine && isnan(inv)) == 0ull) {
+#pragma unroll UNR
+    for (int i = 0; i < ns; i++) {
+      float const lv = rdlane(level, i), iv = rdlane(inv, i);
+      bool const attack = LINEAR ? lv * gain > headroom : gain * lv > headroom;
+      gain = attack ? iv : gain * recovery;
+      g_mine = (lane == i) ? gain : g_mine;
+    }
+    return g_mine;
+  }
+#pragma unroll UNR
+  for (int i = 0; i < ns; i++) {
+    float const lv = rdlane(level, i), iv = rdlane(inv, i);
+    bool const nan_gain = isnan(gain);
+    bool const attack = nan_gain || (LINEAR ? lv * gain > headroom : gain * lv > headroom);
+    float const rec = (hang != 0) ? gain : gain * recovery;
+    int const hdec = (hang != 0) ? hang - 1 : 0;
+    hang = (attack && !nan_gain) ? hangmax : (attack ? hang : hdec);
+    gain = attack ? iv : rec;
+    g_mine = (lane == i) ? gain : g_mine;
+  }
+  return g_mine;
+}
+
+template <bool LINEAR>
+__device__ void agc_channel_any(const Geom &g, const ChanDev &ch, const Planes &pl, int c, int nblocks, int compute_n0) {
+  int const lane = threadIdx.x & 63;
+  int const olen = g.olen;
+  float const headroom = ch.headroom[c], recovery = ch.recovery[c];
+  int const hangmax = ch.hangmax[c];
+  bool const stereo = LINEAR && (ch.flags[c] & FLAG_STEREO) != 0;
+  double const sh_ph = LINEAR ? ch.sh_phase[c] : 0.0, sh_f = LINEAR ? ch.sh_freq[c] : 0.0;
+  float gain = ch.gain[c], dc = LINEAR ? 0.f : ch.dc[c];
+  int hang = ch.hang[c];
+  float n0 = ch.n0[c];
+  int const ngroups = (olen + 63) / 64;
+  const float2 *in = pl.filt + (size_t)c * g.max_blocks * olen;  // the call's blocks are contiguous
+  float2 s_next = (lane < olen && nblocks > 0) ? in[lane] : make_float2(0.f, 0.f);
+  for (int b = 0; b < nblocks; b++) {
+    float *aud = pl.audio + ((size_t)c * g.max_blocks + b) * (2 * (size_t)olen);
+    float sig = 0.f, noi = 0.f;
+    for (int gr = 0; gr < ngroups; gr++) {
+      int const off = gr * 64;
+      int const nsamp = olen - off < 64 ? olen - off : 64;  // wave-uniform
+      float2 const S = s_next;
+      {  // the next group's samples travel while this one's recurrence runs
+        int nb = b, noff = off + 64;
+        if (noff >= olen) {
+          nb++;
+          noff = 0;
+        }
+        s_next = (nb < nblocks && noff + lane < olen) ? in[(size_t)nb * olen + noff + lane] : make_float2(0.f, 0.f);
+      }
+      float const rp = S.x * S.x, ip = S.y * S.y;
+      float const env = sqrtf(LINEAR ? rp + ip : S.x * S.x + S.y * S.y);  // amplitude (linear.c:260) / envelope (am.c:58)
+      float level = env;
+      sig += LINEAR ? rp : S.x * S.x + S.y * S.y;  // lanes past the block's end hold zeros
+      noi += LINEAR ? ip : 0.f;
+      if (!LINEAR) level = nsamp == 64 ? carrier_group<true>(env, 64, lane, dc) : carrier_group<false>(env, nsamp, lane, dc);
+      float const inv = headroom / level;
+      float const g_mine = nsamp == 64 ? agc_group<LINEAR, true>(level, inv, 64, lane, headroom, recovery, hangmax, gain, hang)
+                                       : agc_group<LINEAR, false>(level, inv, nsamp, lane, headroom, recovery, hangmax, gain, hang);
+      if (lane < nsamp) {
+        int const n = off + lane;
+        if (LINEAR) {
+          float2 sv = make_float2(S.x * g_mine, S.y * g_mine);
+          if (sh_f != 0.0) {  // linear.c:283-289
+            double turns = sh_ph + sh_f * ((double)b * olen + n);
+            turns -= rint(turns);
+            float sn, cs;
+            sincospif(2.f * (float)turns, &sn, &cs);
+            sv = cmul(sv, make_float2(cs, sn));
+          }
+          if (stereo)
+            reinterpret_cast<float2 *>(aud)[n] = sv;
+          else
+            aud[n] = sv.x;
+        } else {
+          aud[n] = (env - level) * g_mine;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      sig += __shfl_xor(sig, o, 64);
+      noi += __shfl_xor(noi, o, 64);
+    }
+    if (lane == 0) {
+      kq_chan_status st;
+      put_status(st, g, ch, pl, c, b, compute_n0, .001, n0);
+      st.bb_power = (sig + noi) / (2.f * olen);  // am.c:78, linear.c:302
+      st.snr = LINEAR ? NAN : 0.f;               // linear.c:309
+      st.foffset = 0;
+      st.pdeviation = 0;
+      st.agc_gain = gain;
+      st.squelch_count = 0;
+      st.hangcount = hang;
+      st.blanked = 0;
+      st.nout = stereo ? 2 * olen : olen;
+      pl.status[(size_t)c * g.max_blocks + b] = st;
+    }
+  }
+  if (lane == 0) {
+    ch.gain[c] = gain;
+    ch.hang[c] = hang;
+    ch.n0[c] = n0;
+    if (!LINEAR) ch.dc[c] = dc;
+  }
+}
+
 }  // namespace
+
+// grid = n_am + n_lin workgroups of one wave, one channel each, any block length
+__global__ void __launch_bounds__(64) k_demod_agc_any(Geom g, ChanDev ch, Planes pl, const int *__restrict__ list_am, int n_am,
+                                                      const int *__restrict__ list_lin, int n_lin, int nblocks, int compute_n0) {
+  int const wg = blockIdx.x;
+  if (wg < n_am)
+    agc_channel_any<false>(g, ch, pl, list_am[wg], nblocks, compute_n0);
+  else if (wg - n_am < n_lin)
+    agc_channel_any<true>(g, ch, pl, list_lin[wg - n_am], nblocks, compute_n0);
+}
 
 // grid = n_fm + n_am + n_lin workgroups, one channel each: one wave, or four (THREADS = 256) of which the other three
 // join in on de-emphasised FM channels and leave at once everywhere else
@@ -825,7 +997,12 @@ __global__ void __launch_bounds__(THREADS) k_demod64(Geom g, ChanDev ch, Planes 
 
 // Register-resident demodulators exist for olen = 32 (all three types) and olen = 64 (AM / linear)
 bool demod64_supported(const Geom &g) { return g.Ndec == 64 && g.olen == 32 && g.Mdec == 33; }
-bool demod_agc_wave_supported(const Geom &g) { return g.olen == 64 || g.olen == 32; }
+// wave-per-channel AM / linear: every block length (KQ_AGC_WAVE=0: the one-lane-per-channel kernels for the lengths other
+// than 32 and 64, A/B switch)
+bool demod_agc_wave_supported(const Geom &g) {
+  static bool const off = getenv("KQ_AGC_WAVE") && atoi(getenv("KQ_AGC_WAVE")) == 0;
+  return g.olen == 64 || g.olen == 32 || !off;
+}
 
 void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const int *list_fm, int n_fm,
                     const int *list_am, int n_am, const int *list_lin, int n_lin, int nblocks, int compute_n0) {
@@ -845,6 +1022,10 @@ void launch_demod64(hipStream_t s, const Geom &g, const ChanDev &ch, const Plane
     else
       hipLaunchKernelGGL((k_demod64<32, 64>), dim3(wgs), dim3(64), 0, s, g, ch, pl, list_fm, n_fm, list_am, n_am, list_lin, n_lin,
                          nblocks, compute_n0);
+  } else if (g.olen != 64) {  // any other length: AM / linear by the group (FM stays on the generic kernels)
+    int const wgs = n_am + n_lin;
+    if (wgs == 0) return;
+    hipLaunchKernelGGL(k_demod_agc_any, dim3(wgs), dim3(64), 0, s, g, ch, pl, list_am, n_am, list_lin, n_lin, nblocks, compute_n0);
   } else {  // olen = 64: AM / linear only; FM stays on the generic kernel (launch_demods)
     int const wgs = n_am + n_lin;
     if (wgs == 0) return;

@@ -998,7 +998,8 @@ __global__ void __launch_bounds__(THREADS) k_demod64(Geom g, ChanDev ch, Planes 
 // Register-resident demodulators exist for olen = 32 (all three types) and olen = 64 (AM / linear)
 bool demod64_supported(const Geom &g) { return g.Ndec == 64 && g.olen == 32 && g.Mdec == 33; }
 // wave-per-channel AM / linear: every block length (KQ_AGC_WAVE=0: the one-lane-per-channel kernels for the lengths other
-// than 32 and 64, A/B switch)
+// than 32 and 64 -- an A/B switch for tools/bench_mixed.py only: their in-sequence power sums miss the 2e-6 float64 bar of
+// tests/test_gpu_parity.py's keyed-signal case at 600 samples per block, which the per-lane partial sums here meet)
 bool demod_agc_wave_supported(const Geom &g) {
   static bool const off = getenv("KQ_AGC_WAVE") && atoi(getenv("KQ_AGC_WAVE")) == 0;
   return g.olen == 64 || g.olen == 32 || !off;

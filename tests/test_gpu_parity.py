@@ -612,6 +612,39 @@ def test_random_channel_plans_generic_demodulators(gpu, seed):
     _compare(plan, got, want, check_n0=True)
 
 
+@pytest.mark.parametrize("N,L,M,D,fs", [(6000, 3000, 3001, 5, 240000),       # 600 samples per block: nine groups of 64 and one of 24
+                                          (2048, 1024, 1025, 8, 384000),      # 128: two whole groups
+                                          (3840, 2880, 961, 2, 96000)])       # 1440: 22 groups and one of 32
+def test_every_form_of_the_agc_recurrence_on_a_keyed_signal(gpu, N, L, M, D, fs):
+    """The wave-per-channel AM / SSB demodulator for any block length (k_demod_agc_any) walks the AGC recurrence of
+    am.c:64-74 / linear.c:269-279 in four forms -- gain held while the hang counter outlasts a group, coasting where it
+    runs out inside one, the counter-free form of a channel without a hang time, and the general one -- and picks per
+    group of 64 samples.  A keyed carrier (on 9 ms, off 14 ms, two levels) in noise with hang times of 0, 2.5 ms, 30 ms
+    and 1.1 s makes every form and every hand-over between them occur; the hang counter after each block is compared
+    exactly, gains and audio at the usual bar."""
+    g = dict(samprate=fs, L=L, M=M, D=D)
+    ds = fs / D
+    f0 = 0.13 * fs
+    nblocks = 12
+    t = np.arange(nblocks * L) / fs
+    rng = np.random.default_rng(N)
+    key = ((t % 0.023) < 0.009) * np.where((t % 0.046) < 0.023, 1.0, 0.35)
+    sig = 0.2 * key * np.exp(2j * np.pi * (f0 + 700.0) * t)
+    iq = (sig + 2e-3 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    plan = []
+    for hang in (0.0, 0.0025, 0.03, 1.1):
+        plan.append(dict(demod="linear", low=100.0, high=3000.0, second_lo=-f0, hangtime=hang, recovery_rate=20.0))
+        plan.append(dict(demod="am", low=-4000.0, high=4000.0, second_lo=-f0 - 700.0, hangtime=hang, recovery_rate=50.0))
+    plan.append(dict(demod="linear", low=-3000.0, high=3000.0, second_lo=-f0, hangtime=0.0025, recovery_rate=6.0, channels=2,
+                     shift=0.004 * ds))
+    want = run_oracle(plan, g, iq, nblocks, compute_n0=1)
+    got, used = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_AUTO, compute_n0=True, per_call=5)
+    _compare(plan, got, want, check_n0=True, geom=g)
+    hangs = {c: [st["hangcount"] for st in got[c]["status"]] for c in range(len(plan))}
+    assert any(h != 0 for h in hangs[2]) and any(h == 0 for h in hangs[2]), hangs[2]     # 2.5 ms: runs out and is set again
+    assert all(h == 0 for h in hangs[0]) and all(h > 0 for h in hangs[6][1:]), (hangs[0], hangs[6])
+
+
 @pytest.mark.parametrize("seed,per_call", [(5, 4), (6, 5), (7, 11), (8, 1)])
 def test_cfg2_geometry_without_the_pl_measurement(gpu, seed, per_call):
     """cfg 2 as SURVEY 8d measures it (pltask off): the de-emphasis overlap-save then runs in k_fm_audio256 -- one wave per

@@ -356,7 +356,7 @@ def test_swept_and_fixed_channels_side_by_side_against_the_oracle(gpu, config, e
     bank.close()
 
 
-@pytest.mark.parametrize("geom", ["n1024", "cfg4"])
+@pytest.mark.parametrize("geom", ["n1024", "cfg4", "n9600"])
 def test_control_plane_between_calls_in_flight(gpu, geom):
     """The control plane no longer waits for the device: kq_bank_set_filter / set_mode / add_channel / remove_channel /
     set_n0 / set_linear_options write their parameters on the bank's stream, behind the calls in flight (which keep the
@@ -366,6 +366,10 @@ def test_control_plane_between_calls_in_flight(gpu, geom):
     drains the device before every change and after every call."""
     if geom == "n1024":
         g = dict(samprate=192000, L=512, M=513, D=4)
+        plan = _mixed_plan(g["samprate"], 14)
+        emit = range(24, 40)
+    elif geom == "n9600":                             # a size with factors 3 and 5: design jobs, mask sets and the
+        g = dict(samprate=240000, L=4800, M=4801, D=5)    # group-wise AGC demodulator (960 samples per block) behind the queue
         plan = _mixed_plan(g["samprate"], 14)
         emit = range(24, 40)
     else:

@@ -383,7 +383,10 @@ def measure_channels_at_realtime(torch, kq, wl, dev_index, stream, seconds):
            "float_audio": best, "trials": trials,
            "holds": [{"channels": h["channels"], "deadline": h["deadline"], "delivery_interval_ms": h["delivery_interval_ms"],
                       "longest_interval": h.get("longest_interval"), "filter_kernel_ms": h["filter_kernel_ms"],
-                      "filter_kernel_max_ms": h["filter_kernel_max_ms"]} for h in holds]}
+                      "filter_kernel_max_ms": h["filter_kernel_max_ms"],
+                      # whose time the longest filter interval was: the host's between queueing its two markers, the rest the device's
+                      "filter_max_host_submit_ms": h.get("filter_max_host_submit_ms"), "filter_max_pass": h.get("filter_max_pass")}
+                     for h in holds]}
     if best:
         Cb, short = best["channels"], min(5.0, seconds)
         # the count that leaves 5 % of every call period idle: throughput-mode factor >= 1 / 0.95 (one placement, one check)

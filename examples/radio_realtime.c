@@ -204,6 +204,7 @@ int main(int argc, char **argv){
     if(k == warm){                      /* clocks up, every buffer touched once */
       kq_bank_host_io_wait(bank);
       kq_bank_get_host_timing(bank, &ht, 1);
+      { kq_timing discard; kq_bank_get_timing(bank, &discard, 1); }   /* the device's side from here on too */
       if(operator_on && C > 64){
         op_started = pthread_create(&op_tid, NULL, operator_thread, &op) == 0;
         if(!op_started)
@@ -331,8 +332,10 @@ int main(int argc, char **argv){
       kq_bank_get_timing(bank, &tm, 0);
       if(worst < n)
         printf("longest interval (%.3f ms, call %zu): process %.3f, push %.3f, queueing the delivery %.3f, waiting for delivery k-2 %.3f ms; "
-               "longest filter pass on the device %.3f ms (mean %.3f)\n", 1e3 * (stamp[worst] - stamp[worst - 1]), worst, step[worst][0],
-               step[worst][1], step[worst][2], step[worst][3], tm.filter_max_ms, tm.filter_ms / (double)(tm.filter_launches ? tm.filter_launches : 1));
+               "longest filter interval in the device's queue %.3f ms (mean %.3f; pass %llu of the timed part, %.3f ms of it the host "
+               "between queueing its two markers)\n", 1e3 * (stamp[worst] - stamp[worst - 1]), worst, step[worst][0],
+               step[worst][1], step[worst][2], step[worst][3], tm.filter_max_ms, tm.filter_ms / (double)(tm.filter_launches ? tm.filter_launches : 1),
+               (unsigned long long)tm.filter_max_launch, tm.filter_max_submit_ms);
     }
     if(paced){
       long late = 0, late_playout = 0, backlog_max = 0;

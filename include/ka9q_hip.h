@@ -148,8 +148,14 @@ typedef struct kq_timing {
   double ingest_ms;        /* format conversion + IF power */
   uint64_t filter_launches;
   uint64_t channel_blocks; /* channel-blocks processed by the filter kernel */
-  double filter_max_ms;    /* the longest single filter pass of a call since the last reset (timing level 1: the marker pair
-                              around the call's filter kernels) -- a stall of the device shows here, one of the host does not */
+  double filter_max_ms;    /* the longest single filter INTERVAL of a call since the last reset (timing level 1: from the marker
+                              queued in front of the call's filter kernels to the one behind them, as the device's queue
+                              processed them).  It holds the kernels' run time, anything that kept the queue from starting them,
+                              and the host's own delay between queueing the two markers: */
+  double filter_max_submit_ms; /* ... the host's part of that longest interval: wall time between queueing its two markers.
+                              Small (tens of microseconds) = the time went by on the device's side; about the interval = the
+                              calling thread was off its core in the middle of the call */
+  uint64_t filter_max_launch;  /* ... and which filter pass since the last reset it was (0-based; to find it in a kernel trace) */
 } kq_timing;
 
 const char *kq_last_error(void);

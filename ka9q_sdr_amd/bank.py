@@ -76,7 +76,8 @@ class HostTiming(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("filter_ms", C.c_double), ("demod_ms", C.c_double), ("ingest_ms", C.c_double),
-                ("filter_launches", C.c_uint64), ("channel_blocks", C.c_uint64), ("filter_max_ms", C.c_double)]
+                ("filter_launches", C.c_uint64), ("channel_blocks", C.c_uint64), ("filter_max_ms", C.c_double),
+                ("filter_max_submit_ms", C.c_double), ("filter_max_launch", C.c_uint64)]
 
 
 # kq_chan_status_compact: aux = FM foffset / AM, linear agc_gain; state = FM squelch_count / AM, linear hangcount

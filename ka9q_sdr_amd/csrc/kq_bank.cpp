@@ -218,6 +218,10 @@ struct kq_bank {
   hipEvent_t stage_ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t stage_t0[kSlots] = {nullptr, nullptr, nullptr, nullptr};
   bool stage_timed[kSlots] = {false, false, false, false};
+  // the host's side of that interval: when the opening marker was queued, how long until the closing one was, which call
+  std::chrono::steady_clock::time_point stage_h0[kSlots];
+  double stage_submit_ms[kSlots] = {0, 0, 0, 0};
+  uint64_t stage_launch[kSlots] = {0, 0, 0, 0};
   int stage_next = 0;
   size_t stage_bytes = 0;
   float2 *spec_dump = nullptr;
@@ -886,7 +890,11 @@ int harvest_slot(kq_bank *b, int slot) {
   // (a call that failed between the two records leaves an interval that does not exist: dropped, not an error of this call)
   if (hipEventElapsedTime(&ms, b->stage_t0[slot], b->stage_ev[slot]) == hipSuccess && ms > 0) {
     b->acc.filter_ms += ms;
-    if (ms > b->acc.filter_max_ms) b->acc.filter_max_ms = ms;
+    if (ms > b->acc.filter_max_ms) {
+      b->acc.filter_max_ms = ms;
+      b->acc.filter_max_submit_ms = b->stage_submit_ms[slot];
+      b->acc.filter_max_launch = b->stage_launch[slot];
+    }
   } else
     (void)hipGetLastError();
   return 0;
@@ -1308,6 +1316,8 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   if (b->timing) {
     HIP_TRY(hipEventRecord(b->stage_t0[slot], b->stream));
     b->stage_timed[slot] = true;
+    b->stage_h0[slot] = std::chrono::steady_clock::now();
+    b->stage_launch[slot] = b->acc.filter_launches;
   }
   // The IF-power recurrence rides in the first full-spectrum launch of the call (one wave of its first workgroup,
   // kq_full16k.hip) where there is one; KQ_IIR_IN_FILTER=0: as a launch of its own in front of the demodulators, as before
@@ -1410,6 +1420,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     b->acc.channel_blocks += (uint64_t)C * nblocks;
   }
   HIP_TRY(hipEventRecord(b->stage_ev[slot], b->stream));
+  if (b->timing) b->stage_submit_ms[slot] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b->stage_h0[slot]).count();
   // Where the demodulators of this call run.  On a second stream they overlap the next call's filter pass -- but that
   // kernel leaves no room beside it (500 of a SIMD's 512 registers), so what they take it loses, and at N = 65536 a
   // displaced sibling workgroup stalls the three that wait for it.  Measured on one box (tools/ab_env_rows.sh,

@@ -349,6 +349,8 @@ def measure_realtime(torch, kq, wl, config, C, B, dev_index, stream, seconds=10.
             "worst_lock_holder": bank_worst_holder,
             "filter_kernel_ms": round(tm["filter_ms"] / max(1, tm["filter_launches"]), 4),
             "filter_kernel_max_ms": round(tm["filter_max_ms"], 4),
+            # the longest interval's host part (wall time between queueing its two markers) and which pass it was
+            "filter_max_host_submit_ms": round(tm["filter_max_submit_ms"], 4), "filter_max_pass": int(tm["filter_max_launch"]),
             "host_ms_per_call": round(ht["call_ms"] / max(1, ht["calls"]), 4),
             "host_stage_ms_per_call": round(ht["stage_ms"] / max(1, ht["calls"]), 4),
             "host_slot_wait_ms_per_call": round(ht["slot_wait_ms"] / max(1, ht["calls"]), 4),

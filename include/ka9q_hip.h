@@ -54,9 +54,9 @@ typedef struct kq_bank kq_bank;   /* opaque */
  * (radio_status.c:264-267), which the reference keeps per process.
  * Limits (deviations from the reference, which hands any L / M to FFTW -- main.c:160-170, filter.c:78,132):
  *   - N = L + M - 1 and N / decimate: powers of two (the reference's default, N = 8192, is one), or -- since round 6, on
- *     the generic kernels -- any even 2^a 3^b 5^c up to 16384 (up to 65536 without compute_n0, where N splits into a few
+ *     the generic kernels -- any even 2^a 3^b 5^c 7^d up to 16384 (up to 65536 without compute_n0, where N splits into a few
  *     transforms of at most 16384 points: 24000, 38400, 48000 ...): the sizes of a front end whose rate is not 48 kHz x 2^k
- *     (decimate = samprate / 48000, radio_status.c:266: 5 at 240 kHz with L = 4800, M = 4801).  A prime factor beyond 5 is
+ *     (decimate = samprate / 48000, radio_status.c:266: 5 at 240 kHz with L = 4800, M = 4801).  A prime factor beyond 7 is
  *     refused.  decimate must divide N, L and M - 1 (the reference only warns when it does not, filter.c:106-107).  The fast
  *     kernels (N = 16384 / 65536 full-spectrum, the pruned ones, N/D = 64 and 256 demodulators) are power-of-two only;
  *   - the full-spectrum forward path (compute_n0 = 1) serves N <= 16384 and N = 65536; N = 32768 only without compute_n0.

@@ -12,9 +12,9 @@
  *   - response arrays handed to create_filter_output() must come from malloc()/calloc() or from this library's
  *     fftwf_alloc_complex (ka9q_hip_fftw.h: what fm.c:56 calls, once -lfftw3f has left the link line); the reference frees
  *     them with fftwf_free (filter.c:271), here it is free() -- which releases either.
- *   - N = L+M-1: a power of two, 4 <= N <= 2^22, or an even 2^a 3^b 5^c up to 65536 (240 kHz front ends: L = 4800,
+ *   - N = L+M-1: a power of two, 4 <= N <= 2^22, or an even 2^a 3^b 5^c 7^d up to 65536 (240 kHz front ends: L = 4800,
  *     M = 4801, decimate 5); past 16384 points the master's transform runs in two passes through device memory.
- *     N/decimate: the same kinds of size, 4 <= N/decimate <= 16384.  A prime factor beyond 5 returns NULL (FFTW would
+ *     N/decimate: the same kinds of size, 4 <= N/decimate <= 16384.  A prime factor beyond 7 returns NULL (FFTW would
  *     plan it, filter.c:78,132).
  *   - This surface moves one block over PCIe per call; it exists for drop-in correctness.  The
  *     throughput path is the channel bank in ka9q_hip.h.

@@ -12,7 +12,7 @@
  * and serves hosts without FFTW's headers.  Every transform runs on the GPU: fftwf_execute moves one transform over the link
  * and back (16384 points: ~0.1 ms), like the rest of the compat surface.
  *
- * Differences: sizes are powers of two up to 2^22 or even 2^a 3^b 5^c up to 65536 (NULL plan otherwise: FFTW plans any n);
+ * Differences: sizes are powers of two up to 2^22 or even 2^a 3^b 5^c 7^d up to 65536 (NULL plan otherwise: FFTW plans any n);
  * `flags` are ignored; plans are not thread-safe against each other's execution beyond one transform at a time (a mutex);
  * fftwf_alloc_* memory is released by fftwf_free OR free() -- delete_filter_output's free() of a response from
  * fftwf_alloc_complex (fm.c:56, filter.c:271) is therefore fine, which ka9q_hip_compat.h used to list as a difference.

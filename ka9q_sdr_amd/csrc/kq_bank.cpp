@@ -1575,11 +1575,11 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     return nullptr;
   }
   unsigned const N = cfg->L + cfg->M - 1;
-  // FFTW plans any N (filter.c:78); here a power of two, or -- on the generic kernels, one LDS block -- an even 2^a 3^b 5^c
+  // FFTW plans any N (filter.c:78); here a power of two, or -- on the generic kernels, one LDS block -- an even 2^a 3^b 5^c 7^d
   // up to 16384 (a front end whose rate is not 48 kHz x 2^k: 240 kHz gives decimate 5, radio_status.c:266)
   bool const n_pow2 = (N & (N - 1)) == 0;
   if (cfg->L == 0 || cfg->M < 2 || N < 16 || (!n_pow2 && (!kq::fft_size_ok((int)N) || N > 65536))) {
-    set_err("L+M-1 = %u must be a power of two >= 16, or an even 2^a 3^b 5^c in 16..65536", N);
+    set_err("L+M-1 = %u must be a power of two >= 16, or an even 2^a 3^b 5^c 7^d in 16..65536", N);
     return nullptr;
   }
   if (cfg->decimate < 2 || N % cfg->decimate != 0 || cfg->L % cfg->decimate != 0 || (cfg->M - 1) % cfg->decimate != 0) {
@@ -1588,7 +1588,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   }
   unsigned const Ndec = N / cfg->decimate;
   if (Ndec < 4 || ((Ndec & (Ndec - 1)) != 0 && (!kq::fft_size_ok((int)Ndec) || Ndec > 16384))) {
-    set_err("N/decimate = %u must be a power of two >= 4, or an even 2^a 3^b 5^c in 4..16384", Ndec);
+    set_err("N/decimate = %u must be a power of two >= 4, or an even 2^a 3^b 5^c 7^d in 4..16384", Ndec);
     return nullptr;
   }
   if (cfg->max_channels == 0 || cfg->max_blocks == 0 || cfg->samprate <= 0) {

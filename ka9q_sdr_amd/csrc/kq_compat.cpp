@@ -152,10 +152,10 @@ float kq_compat_compute_n0(struct filter_in *m, int samprate, float low, float h
 
 struct filter_in *create_filter_input(unsigned int L, unsigned int M, enum filtertype in_type) {
   unsigned const N = L + M - 1;
-  // FFTW plans any N (filter.c:78); here: a power of two up to 2^22, or 2^a 3^b 5^c (even) up to 65536
+  // FFTW plans any N (filter.c:78); here: a power of two up to 2^22, or 2^a 3^b 5^c 7^d (even) up to 65536
   bool const pow2 = (N & (N - 1)) == 0;
   if (L == 0 || M == 0 || N < 4 || (pow2 ? N > (1u << 22) : !kq::fft_size_ok((int)N))) {
-    fprintf(stderr, "ka9q_hip: create_filter_input: N=%u must be a power of two in 4..4194304 or an even 2^a 3^b 5^c up to 65536\n", N);
+    fprintf(stderr, "ka9q_hip: create_filter_input: N=%u must be a power of two in 4..4194304 or an even 2^a 3^b 5^c 7^d up to 65536\n", N);
     return NULL;
   }
   if (!ctx_init()) return NULL;
@@ -280,7 +280,7 @@ struct filter_out *create_filter_output(struct filter_in *master, kq_cfloat *res
     bool dim_ok = false;
     if (nd >= 4 && nd <= 16384) (void)kq::fft_dim(nd, &dim_ok);  // (makes and caches the plan the slave's kernel will ask for)
     if (!dim_ok) {
-      fprintf(stderr, "ka9q_hip: create_filter_output: N/decimate=%d must be an even 2^a 3^b 5^c in 4..16384\n", nd);
+      fprintf(stderr, "ka9q_hip: create_filter_output: N/decimate=%d must be an even 2^a 3^b 5^c 7^d in 4..16384\n", nd);
       return NULL;
     }
   }
@@ -561,7 +561,7 @@ struct kq_fftwf_plan_s {
 static kq_fftwf_plan_s *fftw_plan_make(int n, int kind, int sign, void *in, void *out) {
   bool const pow2 = n > 0 && (n & (n - 1)) == 0;
   if (n < 2 || !in || !out || (pow2 ? n > (1 << 22) : !kq::fft_size_ok(n))) {
-    fprintf(stderr, "ka9q_hip: fftwf_plan: size %d must be a power of two up to 4194304 or an even 2^a 3^b 5^c up to 65536\n", n);
+    fprintf(stderr, "ka9q_hip: fftwf_plan: size %d must be a power of two up to 4194304 or an even 2^a 3^b 5^c 7^d up to 65536\n", n);
     return nullptr;
   }
   if (!ctx_init()) return nullptr;

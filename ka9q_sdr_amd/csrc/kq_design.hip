@@ -160,7 +160,7 @@ const float2 *design_twiddles(int log2T) {
 
 bool fft_size_ok(int n) {
   if (n < 2 || n > 65536 || (n & 1)) return false;
-  for (int p : {2, 3, 5})
+  for (int p : {2, 3, 5, 7})
     while (n % p == 0) n /= p;
   return n == 1;
 }
@@ -179,16 +179,17 @@ FftDim fft_dim(int n, bool *ok) {
   }
   {  // (odd sizes are fine here -- a factor of a two-pass transform may be one; fft_size_ok's evenness is the filters' rule)
     int m = n;
-    for (int p : {2, 3, 5})
+    for (int p : {2, 3, 5, 7})
       while (m % p == 0) m /= p;
     if (n < 2 || n > 65536 || m != 1) return d;
   }
-  {  // radices: 4s first (fewest passes), then 2, 3s, 5s
+  {  // radices: 4s first (fewest passes), then 2, 3s, 5s, 7s
     int m = n;
     while (m % 4 == 0) d.f[d.nf++] = 4, m /= 4;
     while (m % 2 == 0) d.f[d.nf++] = 2, m /= 2;
     while (m % 3 == 0) d.f[d.nf++] = 3, m /= 3;
     while (m % 5 == 0) d.f[d.nf++] = 5, m /= 5;
+    while (m % 7 == 0) d.f[d.nf++] = 7, m /= 7;
   }
   static std::mutex mu;
   static std::map<std::pair<int, int>, std::pair<const unsigned short *, const float2 *>> tabs;
@@ -288,7 +289,7 @@ int design_batch(int L, int M, bool real_taps, int spec, const std::vector<Desig
   FftDim const dim = (N >= 2 && N <= 16384) ? fft_dim(N, &dim_ok) : FftDim{};
   int const log2n = dim.log2n >= 0 ? dim.log2n : 1;  // (the half-circle table is only read for powers of two)
   if (!dim_ok || M < 1 || jobs.empty()) {
-    kq_internal_set_error("response design: N = %d must be 2^a 3^b 5^c in 2..16384", N);
+    kq_internal_set_error("response design: N = %d must be 2^a 3^b 5^c 7^d in 2..16384", N);
     return -1;
   }
   int ndev = 0;

@@ -31,7 +31,7 @@ struct PllState {
 
 // A transform size on the generic path (kq_ldsfft.hpp lds_fft_mixed): n = f[0] f[1] ... f[nf-1] with radices 2..5, or a
 // power of two (log2n >= 0: then rev / twc are not used and the kernels run lds_fft as ever).  fft_dim() builds one on the
-// current device: the tables are cached per (device, n) and never freed.  ok = false: n has a prime factor beyond 5, or
+// current device: the tables are cached per (device, n) and never freed.  ok = false: n has a prime factor beyond 7, or
 // is beyond 65536 (rev is 16 bits wide), or the allocation failed.
 struct FftDim {
   int n;
@@ -43,7 +43,7 @@ struct FftDim {
   int tw_n;
 };
 FftDim fft_dim(int n, bool *ok);
-bool fft_size_ok(int n);      // n = 2^a 3^b 5^c, 2 <= n <= 65536, even
+bool fft_size_ok(int n);      // n = 2^a 3^b 5^c 7^d, 2 <= n <= 65536, even
 
 // Carrier-tracking channels keep their loop state, 65536-sample ring and search scratch in a SLOT of their own for as long
 // as they exist (kq_bank.cpp pll_acquire): storage grows by chunks of kPllChunk slots, nothing ever moves.

@@ -852,7 +852,7 @@ __global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, 
   float *AIN = reinterpret_cast<float *>(F + AN);
   float2 *PLB = reinterpret_cast<float2 *>(AIN + AN);
   float2 *TWL = PLB + g.pl_n;  // exp(-2 pi i k / AN), k < AN/2
-  // AN with a factor 3 or 5 (kq_ldsfft.hpp lds_fft_mixed): twiddles from the plan's own table; where TWL would sit, a second
+  // AN with a factor 3, 5 or 7 (kq_ldsfft.hpp lds_fft_mixed): twiddles from the plan's own table; where TWL would sit, a second
   // buffer of AN bins takes the products in digit-reversed order (that permutation is no involution: no swapping in place)
   bool const mixed = g.dNdec.log2n < 0;
   float2 *F2 = TWL;
@@ -1785,7 +1785,7 @@ __global__ void k_fft_single(const float2 *__restrict__ in, float2 *__restrict__
   for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = lds[i];
 }
 
-// n: a power of two (tw / tw_log2: the half-circle table lds_fft reads) or any 2^a 3^b 5^c the caller has a plan for
+// n: a power of two (tw / tw_log2: the half-circle table lds_fft reads) or any 2^a 3^b 5^c 7^d the caller has a plan for
 void launch_fft_single(hipStream_t s, const float2 *in, float2 *out, const FftDim &d, int sign, const float2 *tw, int tw_log2) {
   size_t const lds_bytes = sizeof(float2) * (size_t)d.n;
   ensure_dynamic_lds((const void *)k_fft_single, lds_bytes);
@@ -1838,7 +1838,7 @@ __global__ void k_fft_rows(const float2 *__restrict__ tmp, float2 *__restrict__ 
   for (int k2 = threadIdx.x; k2 < nb; k2 += blockDim.x) out[(size_t)k1 + (size_t)na * k2] = lds[k2];
 }
 
-// N beyond one LDS block: a power of two up to 2^22, or 2^a 3^b 5^c up to 65536 (the full-circle table's reach)
+// N beyond one LDS block: a power of two up to 2^22, or 2^a 3^b 5^c 7^d up to 65536 (the full-circle table's reach)
 int launch_fft_large(hipStream_t s, const float2 *in, float2 *out, float2 *tmp, int N, int sign, const float2 *tw, int tw_log2) {
   bool ok = false;
   FftDim const dn = fft_dim(N, &ok);

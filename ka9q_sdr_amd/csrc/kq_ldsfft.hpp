@@ -148,8 +148,8 @@ __device__ inline void lds_fft(float2 *s, int log2n, const float2 *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Sizes with a factor 3 or 5 (round 6: FFTW plans whatever N = L + M - 1 and N / decimate come out, filter.c:78,132, and
-// decimate = samprate / 48000 is 5 at 240 kHz, radio_status.c:266).  n = f[0] f[1] ... f[nf-1], radices 2, 3, 4, 5, applied
+// Sizes with a factor 3, 5 or 7 (round 6: FFTW plans whatever N = L + M - 1 and N / decimate come out, filter.c:78,132, and
+// decimate = samprate / 48000 is 5 at 240 kHz, radio_status.c:266).  n = f[0] f[1] ... f[nf-1], radices 2, 3, 4, 5, 7, applied
 // in that order as in-place decimation-in-time stages: the stage of radix r over span m (the product of the radices before
 // it) takes s[base + j + q m], q < r, times W_{m r}^{j q}, through an r-point transform back into the same places.  The
 // input goes in DIGIT-REVERSED: natural index i sits at rev[i] (table built by the host with the plan: position
@@ -169,9 +169,9 @@ __device__ inline void lds_fft_mixed(float2 *s, const FftDim &d) {
     int const tstep = d.tw_n / (m * r);  // W_{m r}^{1} = twc[tstep]
     for (int i = threadIdx.x; i < n / r; i += blockDim.x) {
       int const j = i % m, base = (i / m) * m * r + j;
-      float2 a[5];
+      float2 a[7];
 #pragma unroll
-      for (int q = 0; q < 5; q++) {
+      for (int q = 0; q < 7; q++) {
         if (q < r) {
           float2 v = s[base + q * m];
           if (q && j) {
@@ -202,7 +202,7 @@ __device__ inline void lds_fft_mixed(float2 *s, const FftDim &d) {
         s[base] = cadd(a[0], t1);
         s[base + m] = cadd(u, v);
         s[base + 2 * m] = csub(u, v);
-      } else {  // r == 5
+      } else if (r == 5) {
         float const c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
         float const s1 = sg * -0.95105651629515357212f, s2 = sg * -0.58778525229247312917f;  // sin(-+2 pi / 5), sin(-+4 pi / 5)
         float2 const t1 = cadd(a[1], a[4]), t2 = cadd(a[2], a[3]), t3 = csub(a[1], a[4]), t4 = csub(a[2], a[3]);
@@ -216,6 +216,26 @@ __device__ inline void lds_fft_mixed(float2 *s, const FftDim &d) {
         s[base + 4 * m] = csub(u1, v1);
         s[base + 2 * m] = cadd(u2, v2);
         s[base + 3 * m] = csub(u2, v2);
+      } else {  // r == 7: X_k = a0 + sum_j [t_j cos(2 pi j k / 7) -+ i d_j sin(2 pi j k / 7)], t_j = a_j + a_{7-j}, d_j = a_j - a_{7-j}
+        float const c1 = 0.62348980185873353053f, c2 = -0.22252093395631440429f, c3 = -0.90096886790241912624f;
+        float const s1 = sg * -0.78183148246802980871f, s2 = sg * -0.97492791218182360702f, s3 = sg * -0.43388373911755812048f;
+        float2 const t1 = cadd(a[1], a[6]), t2 = cadd(a[2], a[5]), t3 = cadd(a[3], a[4]);
+        float2 const d1 = csub(a[1], a[6]), d2 = csub(a[2], a[5]), d3 = csub(a[3], a[4]);
+        // j k mod 7 for k = 1: 1 2 3; k = 2: 2 4 6 = 2 -3 -1; k = 3: 3 6 2 = 3 -1 2 (cosine even, sine odd)
+        float2 const u1 = make_float2(a[0].x + c1 * t1.x + c2 * t2.x + c3 * t3.x, a[0].y + c1 * t1.y + c2 * t2.y + c3 * t3.y);
+        float2 const u2 = make_float2(a[0].x + c2 * t1.x + c3 * t2.x + c1 * t3.x, a[0].y + c2 * t1.y + c3 * t2.y + c1 * t3.y);
+        float2 const u3 = make_float2(a[0].x + c3 * t1.x + c1 * t2.x + c2 * t3.x, a[0].y + c3 * t1.y + c1 * t2.y + c2 * t3.y);
+        float2 const w1 = make_float2(s1 * d1.x + s2 * d2.x + s3 * d3.x, s1 * d1.y + s2 * d2.y + s3 * d3.y);
+        float2 const w2 = make_float2(s2 * d1.x - s3 * d2.x - s1 * d3.x, s2 * d1.y - s3 * d2.y - s1 * d3.y);
+        float2 const w3 = make_float2(s3 * d1.x - s1 * d2.x + s2 * d3.x, s3 * d1.y - s1 * d2.y + s2 * d3.y);
+        float2 const v1 = make_float2(-w1.y, w1.x), v2 = make_float2(-w2.y, w2.x), v3 = make_float2(-w3.y, w3.x);  // i w
+        s[base] = cadd(cadd(a[0], t1), cadd(t2, t3));
+        s[base + m] = cadd(u1, v1);
+        s[base + 6 * m] = csub(u1, v1);
+        s[base + 2 * m] = cadd(u2, v2);
+        s[base + 5 * m] = csub(u2, v2);
+        s[base + 3 * m] = cadd(u3, v3);
+        s[base + 4 * m] = csub(u3, v3);
       }
     }
     m *= r;

@@ -1,5 +1,5 @@
 /* kq_fft.c -- single-precision FFT for the oracle (test infrastructure only): powers of two, and since round 6 every
- * n = 2^a 3^b 5^c (the sizes a front end whose rate is not 48 kHz x 2^k needs: filter.c:78,102-107,132 plan whatever
+ * n = 2^a 3^b 5^c 7^d (the sizes a front end whose rate is not 48 kHz x 2^k needs: filter.c:78,102-107,132 plan whatever
  * N and N / decimate come out, radio_status.c:266 gives decimate = samprate / 48000 -- 240 kHz: 5).
  *
  * Stands in for the FFTW3f calls of the reference (filter.c:78,87,132,141,373-374,430-432;
@@ -7,8 +7,8 @@
  * exp(-2*pi*i*jk/n), backward exp(+2*pi*i*jk/n); r2c returns n/2+1 bins; c2r consumes
  * n/2+1 bins and ignores the imaginary parts of DC and Nyquist.
  * Arithmetic is float (twiddles computed in double, rounded once), iterative radix-2
- * decimation in time after a bit-reversal permutation.  Sizes with a factor 3 or 5 take a recursive mixed-radix
- * decimation in time (radices 4, 2, 3, 5; the power-of-two path is left exactly as it was: its rounding is what the
+ * decimation in time after a bit-reversal permutation.  Sizes with a factor 3, 5 or 7 take a recursive mixed-radix
+ * decimation in time (radices 4, 2, 3, 5, 7; the power-of-two path is left exactly as it was: its rounding is what the
  * committed vectors were generated with).  Checked against numpy's float64 transforms in tests/test_oracle_filter.py.
  */
 #define _GNU_SOURCE 1
@@ -28,20 +28,21 @@ struct kqo_fft {
   float complex *twf;     /* mixed sizes: exp(-2*pi*i*k/n), k < n */
 };
 
-/* n = 2^a 3^b 5^c ?  fills the radix list (4s first, then 2, 3s, 5s) */
+/* n = 2^a 3^b 5^c 7^d ?  fills the radix list (4s first, then 2, 3s, 5s, 7s) */
 static int factorise(unsigned n, unsigned *fac, unsigned *nf){
   *nf = 0;
   while(n % 4 == 0){ fac[(*nf)++] = 4; n /= 4; }
   while(n % 2 == 0){ fac[(*nf)++] = 2; n /= 2; }
   while(n % 3 == 0){ fac[(*nf)++] = 3; n /= 3; }
   while(n % 5 == 0){ fac[(*nf)++] = 5; n /= 5; }
+  while(n % 7 == 0){ fac[(*nf)++] = 7; n /= 7; }
   return n == 1;
 }
 
 kqo_fft *kqo_fft_create(unsigned n){
   if(n == 0)
     return NULL;
-  if((n & (n - 1)) != 0){       /* a factor 3 or 5: the mixed-radix plan */
+  if((n & (n - 1)) != 0){       /* a factor 3, 5 or 7: the mixed-radix plan */
     unsigned fac[32], nf;
     if(!factorise(n, fac, &nf))
       return NULL;
@@ -209,7 +210,7 @@ static void mixed_rec(const kqo_fft *p, unsigned level, unsigned n, const float 
   for(unsigned q = 0; q < r; q++)
     mixed_rec(p, level + 1, m, in + (size_t)q * stride, stride * r, out + (size_t)q * m, sign);
   for(unsigned k = 0; k < m; k++){
-    float complex a[5], b[5];
+    float complex a[7], b[7];
     for(unsigned q = 0; q < r; q++){
       float complex w = p->twf[(size_t)q * k * tstride];
       if(sign > 0)
@@ -233,7 +234,7 @@ static void mixed_rec(const kqo_fft *p, unsigned level, unsigned n, const float 
 
 void kqo_fft_c2c(const kqo_fft *p, const float complex *in, float complex *out, int sign){
   unsigned const n = p->n;
-  if(p->twf){                                   /* a size with a factor 3 or 5 */
+  if(p->twf){                                   /* a size with a factor 3, 5 or 7 */
     float complex *src = p->scratch + n;         /* (r2c / c2r hand in p->scratch itself) */
     memcpy(src, in, sizeof(float complex) * n);
     mixed_rec(p, 0, n, src, 1, out, sign);

@@ -31,7 +31,7 @@ kqo_filter_in *kqo_create_filter_input(unsigned L, unsigned M, int in_type){
   m->blocknum = 0;
   m->plan = kqo_fft_create(m->n);
   if(!m->plan){
-    fprintf(stderr, "kq oracle: FFT size %u has a prime factor beyond 5\n", m->n);
+    fprintf(stderr, "kq oracle: FFT size %u has a prime factor beyond 7\n", m->n);
     free(m);
     return NULL;
   }
@@ -96,7 +96,7 @@ kqo_filter_out *kqo_create_filter_output(kqo_filter_in *m, float complex *respon
   s->noise_gain = response ? kqo_noise_gain(s) : NAN;
   s->plan = kqo_fft_create(n_dec);
   if(!s->plan){
-    fprintf(stderr, "kq oracle: decimated FFT size %u has a prime factor beyond 5\n", n_dec);
+    fprintf(stderr, "kq oracle: decimated FFT size %u has a prime factor beyond 7\n", n_dec);
     free(s);
     return NULL;
   }

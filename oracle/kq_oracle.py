@@ -203,7 +203,7 @@ class Channel:
         self.cfg = cfg
         self.h = self.L.kqo_chan_create(C.byref(cfg))
         if not self.h:
-            raise ValueError("oracle: unsupported geometry (FFT sizes must be of the form 2^a 3^b 5^c)")
+            raise ValueError("oracle: unsupported geometry (FFT sizes must be of the form 2^a 3^b 5^c 7^d)")
         self.olen = self.L.kqo_chan_olen(self.h)
         self.N = cfg.L + cfg.M - 1
 

@@ -110,10 +110,11 @@ def test_no_silent_cpu_fallback(lib):
 
 
 def test_sizes_are_checked_before_any_device_is_asked_for(lib):
-    """N = L + M - 1 and N / decimate: powers of two, or even 2^a 3^b 5^c (round 6: the sizes FFTW takes and a front end at 240 kHz
-    needs, filter.c:78,132, radio_status.c:266).  A prime factor beyond 5 is refused with a message that says so -- with or
+    """N = L + M - 1 and N / decimate: powers of two, or even 2^a 3^b 5^c 7^d (round 6: the sizes FFTW takes and a front end at 240 kHz
+    needs, filter.c:78,132, radio_status.c:266).  A prime factor beyond 7 is refused with a message that says so -- with or
     without a GPU in the box; a size that is served fails here only for want of a device."""
-    for L_, M_, D_, ok in ((4800, 4801, 5, True), (7680, 7681, 8, True), (12000, 12001, 25, True), (448 * 8, 448 * 8 + 1, 4, False),
+    for L_, M_, D_, ok in ((4800, 4801, 5, True), (7680, 7681, 8, True), (12000, 12001, 25, True), (448 * 8, 448 * 8 + 1, 4, True),
+                           (11 * 256, 11 * 256 + 1, 4, False),
                            (4800, 4801, 7, False), (33 * 512, 33 * 512 + 1, 2, False)):
         try:
             b = kq.Bank(240000, L_, M_, D_, 1, 1, compute_n0=False)
@@ -123,7 +124,7 @@ def test_sizes_are_checked_before_any_device_is_asked_for(lib):
             if ok:
                 assert "no HIP device" in str(e) and lib.kq_device_count() <= 0, str(e)
             else:
-                assert "2^a 3^b 5^c" in str(e) or "divide" in str(e), str(e)
+                assert "2^a 3^b 5^c 7^d" in str(e) or "divide" in str(e), str(e)
 
 
 def test_host_nco_entry_points(lib):

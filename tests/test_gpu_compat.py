@@ -44,11 +44,13 @@ def lib(gpu):
 # The last two are the master sizes past one LDS block: cfg 5's N = 65536 (create_filter_input has no size limit,
 # filter.c:54-91) and 2^17.
 # Lb = 4800 ... : sizes with factors 3 and 5 (N = 9600, 15360, 3840; 48000 = 2^7 3 5^3 past one LDS block), which FFTW plans
-# like any other (filter.c:78,132): the mixed-radix transforms of kq_ldsfft.hpp.
+# like any other (filter.c:78,132): the mixed-radix transforms of kq_ldsfft.hpp.  Lb = 6720, 3584, 896, 23520: a factor 7 (336 kHz =
+# 7 x 48 kHz: N = 13440; N = 7168 = 2^10 7; 1792; 47040 = 2^6 3 5 7^2 past one LDS block).
 @pytest.mark.parametrize("in_type,out_type,D,Lb", [(1, 3, 4, 512), (1, 1, 4, 512), (1, 2, 4, 512), (1, 1, 16, 512),
                                                     (3, 3, 1, 512), (3, 1, 1, 512), (1, 1, 512, 32768), (1, 2, 64, 65536),
                                                     (1, 3, 5, 4800), (1, 1, 5, 4800), (1, 2, 8, 7680), (3, 3, 1, 1920),
-                                                    (3, 1, 2, 1920), (1, 1, 25, 24000)])
+                                                    (3, 1, 2, 1920), (1, 1, 25, 24000),
+                                                    (1, 1, 7, 6720), (1, 3, 4, 3584), (3, 3, 1, 896), (1, 2, 14, 23520)])
 def test_compat_filter_matches_oracle(lib, in_type, out_type, D, Lb):
     M = Lb + 1
     N = Lb + M - 1
@@ -187,8 +189,8 @@ def test_fftw_entry_points_outside_the_filter_api(lib):
     lib.fftwf_destroy_plan(plan)
     lib.fftwf_free(pin)
     lib.fftwf_free(pout)
-    # linear.c:90-92,178: c2c forward of 65536 points (two passes through device memory); and a size with factors 3 and 5
-    for n, sign in ((65536, -1), (65536, +1), (9600, -1), (48000, -1)):
+    # linear.c:90-92,178: c2c forward of 65536 points (two passes through device memory); and sizes with factors 3, 5 and 7
+    for n, sign in ((65536, -1), (65536, +1), (9600, -1), (48000, -1), (7 * 64, -1), (47040, +1)):
         a, b = lib.fftwf_alloc_complex(n), lib.fftwf_alloc_complex(n)
         plan = lib.fftwf_plan_dft_1d(n, a, b, sign, 1 << 6)
         assert plan
@@ -200,7 +202,7 @@ def test_fftw_entry_points_outside_the_filter_api(lib):
         lib.fftwf_destroy_plan(plan)
         lib.fftwf_free(a)
         lib.fftwf_free(b)
-    assert not lib.fftwf_plan_dft_1d(7 * 64, lib.fftwf_alloc_complex(448), lib.fftwf_alloc_complex(448), -1, 0)   # a factor 7: refused
+    assert not lib.fftwf_plan_dft_1d(11 * 64, lib.fftwf_alloc_complex(704), lib.fftwf_alloc_complex(704), -1, 0)   # a factor 11: refused
     # fm.c:56-66: a response allocated by fftwf_alloc_complex, owned and released by the filter (filter.c:271)
     Lb, M = 512, 513
     m = lib.create_filter_input(Lb, M, 3)

@@ -299,6 +299,10 @@ GEOMETRIES = [
     (3000,  1500,  1501,  2,   96000,  "auto", True),        # N = 2^3 3 5^3 (one radix-2 pass), N/D = 1500
     (24000, 12000, 12001, 25,  1200000, "full", False),      # beyond one LDS block with factors 3 and 5: split kernel, 2 x 12000
     (38400, 19200, 19201, 40,  1920000, "full", False),      # split kernel, 3 x 12800, N/D = 960
+    # ... and 7 (a rate of 7 x 48 kHz; 2 x 7^4 = four radix-7 passes)
+    (13440, 6720,  6721,  7,   336000, "auto", True),        # N = 2^7 3 5 7, N/D = 1920
+    (7168,  3584,  3585,  4,   192000, "auto", True),        # N = 2^10 7, N/D = 1792 = 2^8 7, 896 samples per block
+    (4802,  2401,  2402,  7,   336000, "auto", True),        # N = 2 7^4, N/D = 686 = 2 7^3, 343 samples per block
 ]
 
 

@@ -254,11 +254,11 @@ def test_fast_transform_equals_the_plain_one(log2n):
         assert np.sqrt(np.mean(np.abs(res[1, key] - res[0, key]) ** 2)) / scale < tol, key
 
 
-@pytest.mark.parametrize("n", [6, 60, 1200, 1920, 3000, 9600, 12000, 15360, 48000])
+@pytest.mark.parametrize("n", [6, 60, 1200, 1920, 3000, 9600, 12000, 15360, 48000, 14, 1792, 7168, 13440, 2 * 7 ** 4])
 def test_mixed_radix_transform_against_float64(n):
-    """Sizes 2^a 3^b 5^c (round 6: FFTW plans whatever N and N / decimate come out, filter.c:78,132; decimate =
+    """Sizes 2^a 3^b 5^c 7^d (round 6: FFTW plans whatever N and N / decimate come out, filter.c:78,132; decimate =
     samprate / 48000 is 5 at 240 kHz, radio_status.c:266): the oracle's mixed-radix transform against numpy's float64
-    one, both directions, and the r2c / c2r pair the FM audio filter uses; a size with a factor 7 is refused."""
+    one, both directions, and the r2c / c2r pair the FM audio filter uses; a size with a factor 11 is refused."""
     L = ko.lib()
     L.kqo_fft_create.restype = C.c_void_p
     L.kqo_fft_create.argtypes = [C.c_uint]
@@ -266,7 +266,7 @@ def test_mixed_radix_transform_against_float64(n):
     L.kqo_fft_c2c.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.kqo_fft_r2c.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.kqo_fft_c2r.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-    assert not L.kqo_fft_create(7 * n)
+    assert not L.kqo_fft_create(11 * n)
     p = L.kqo_fft_create(n)
     assert p
     rng = np.random.default_rng(n)

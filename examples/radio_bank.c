@@ -41,12 +41,14 @@ int main(void){
     double const f = 20000. + 3000. * cos(2 * M_PI * 1000. * t);            /* instantaneous frequency */
     phase += 2 * M_PI * f / 192000.;
     /* a little noise, as every real signal has: the FM SNR estimate (fm.c:100-102) divides by the envelope's variance,
-     * which for a synthetic constant envelope is float rounding of either sign -- and a negative one reads as SNR 0 */
+     * which for a synthetic constant envelope is float rounding of either sign -- and a negative one reads as SNR 0, which
+     * closes the squelch (at 2e-3 of noise the in-channel SNR was 63 dB, the variance three units of float rounding: any
+     * change in the order of the kernel's sums could flip it; 1e-2 leaves a factor 30) */
     lcg = lcg * 1664525u + 1013904223u;
     float const nr = ((lcg >> 8) & 0xffff) / 65536.f - 0.5f;
     lcg = lcg * 1664525u + 1013904223u;
     float const ni = ((lcg >> 8) & 0xffff) / 65536.f - 0.5f;
-    iq[i] = (0.5f * (float)cos(phase) + 2e-3f * nr) + (0.5f * (float)sin(phase) + 2e-3f * ni) * I;
+    iq[i] = (0.5f * (float)cos(phase) + 1e-2f * nr) + (0.5f * (float)sin(phase) + 1e-2f * ni) * I;
   }
   if(kq_bank_push_iq(bank, iq, n, KQ_IQ_CF32, 0) != 0 || kq_bank_process(bank) != (int)nblocks || kq_bank_sync(bank) != 0){
     fprintf(stderr, "processing failed: %s\n", kq_last_error());

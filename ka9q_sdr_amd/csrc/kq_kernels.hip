@@ -373,14 +373,29 @@ __global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__res
   double const hp0 = ch.hist_phase[c], hf0 = ch.hist_freq[c], hr = ch.hist_rate[c];
   const float2 *x = window + (size_t)b * g.L;
   double const mbase = (double)b * g.L;
-  for (int i = threadIdx.x; i < N; i += blockDim.x) {
-    double const m = mbase + i;
-    bool const old = (b == 0) && i < g.M - 1;  // history of the call's first block: pre-retune oscillator
-    double const rr = old ? hr : r;
-    double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
-    if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
-    float2 const lo = phasor_turns(turns);
-    lds[fft_pos((unsigned)i, g.dN)] = cmul(x[i], lo);
+  // One oscillator over the whole window and no sweep (every block but the first one after a retune, every channel that is
+  // not Doppler-tracked): a thread's samples are blockDim apart, so its phasor advances by one constant step; evaluated afresh
+  // in double every fourth sample, three float products in between (3 x 6e-8 of rounding against the 1e-5 of the parity bar).
+  // The per-sample evaluation in double was 800 of this kernel's 1 770 vector instructions per wave (tools/pmc_sq.sh).
+  bool const one_osc = r == 0.0 && (b != 0 || (hr == 0.0 && hp0 == ph0 && hf0 == f0));
+  if (one_osc) {
+    float2 const step = phasor_turns(f0 * (double)blockDim.x);
+    float2 lo = make_float2(1.f, 0.f);
+    int k = 0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x, k++) {
+      lo = (k & 3) ? cmul(lo, step) : phasor_turns(ph0 + f0 * (mbase + i));
+      lds[fft_pos((unsigned)i, g.dN)] = cmul(x[i], lo);
+    }
+  } else {
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      double const m = mbase + i;
+      bool const old = (b == 0) && i < g.M - 1;  // history of the call's first block: pre-retune oscillator
+      double const rr = old ? hr : r;
+      double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
+      if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
+      float2 const lo = phasor_turns(turns);
+      lds[fft_pos((unsigned)i, g.dN)] = cmul(x[i], lo);
+    }
   }
   fft_any<-1>(lds, g.dN, tw, g.tw_log2);  // filter.c:151
 

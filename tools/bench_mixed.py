@@ -4,7 +4,8 @@ decimate 5 (radio_status.c:266) -- C channels (FM / AM / USB in turn), B blocks 
 real-time factor of the front end (a block is 20 ms of signal) and, for scale, the same channel count at N = 8192 / decimate 4 /
 192 kHz (the reference's default size, a power of two, same generic kernels).
 
-    python tools/bench_mixed.py [channels [blocks]]
+    python tools/bench_mixed.py [channels [blocks [which [calls]]]]      which: 0 / 1 / 2 = one of the three sizes only (-1: all);
+                                                                         calls: timed calls per line (100; a counter pass wants few)
 """
 import os
 import sys
@@ -20,10 +21,14 @@ from ka9q_sdr_amd import workload as wl  # noqa: E402
 
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+WHICH = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+CALLS = int(sys.argv[4]) if len(sys.argv) > 4 else 100
 dev = torch.device("cuda", 0)
-for name, fs, L, M, D in (("240 kHz, N = 9600 (2^7 3 5^2), N/D = 1920", 240000, 4800, 4801, 5),
+for idx, (name, fs, L, M, D) in enumerate((("240 kHz, N = 9600 (2^7 3 5^2), N/D = 1920", 240000, 4800, 4801, 5),
                           ("384 kHz, N = 15360 (2^10 3 5), N/D = 1920", 384000, 7680, 7681, 8),
-                          ("192 kHz, N = 8192, N/D = 2048 (powers of two, same kernels)", 192000, 3840, 4353, 4)):
+                          ("192 kHz, N = 8192, N/D = 2048 (powers of two, same kernels)", 192000, 3840, 4353, 4))):
+    if WHICH >= 0 and idx != WHICH:
+        continue
     for n0 in (True, False):
         plan = []
         for c in range(C):
@@ -38,10 +43,10 @@ for name, fs, L, M, D in (("240 kHz, N = 9600 (2^7 3 5^2), N/D = 1920", 240000, 
         bank.add_channels([wl.bank_channel_config(p) for p in plan])
         iq = wl.make_iq(fs, (M - 1) + B * L, seed=3)
         buf = torch.from_numpy(iq).to(dev)
-        for _ in range(20):
+        for _ in range(min(20, CALLS)):
             bank.process_resident(buf.data_ptr(), B)
         torch.cuda.synchronize()
-        n = 100
+        n = CALLS
         t0 = time.perf_counter()
         for _ in range(n):
             bank.process_resident(buf.data_ptr(), B)

@@ -114,6 +114,10 @@ struct HostChan {
   // the next block were mixed with these (radio.c:132-139)
   Osc lo2_old, dop_old;
   bool retuned = false;
+  // ... and how many samples from the start of the NEXT call's first window still carry the old oscillators (ChanDev::hist_len):
+  // M - 1 when the retune happens; a call of n blocks takes n L off it; the channel stays `retuned` while any are left
+  int64_t hist_old = 0;
+  int hist_dev = -1;  // what hist_len[c] on the device was last told
   bool active = true;  // false: a hole left by kq_bank_remove_channel, reused by the next kq_bank_add_channel
   kq_out_rtp_state out_rtp{};  // demod->output.rtp + output.silent (audio.c:32-132)
   int out_type;
@@ -323,6 +327,7 @@ struct kq_bank {
   bool osc_dirty = true;
   int64_t planes_n_w = 0, planes_out_abs = 0, rebased_at = 0;
   size_t refresh_next = 0;  // the channel whose closed forms the next steady call re-references first
+  std::vector<int> ret_host;  // the channels whose windows of the call being staged hold samples of an old oscillator
   bool cache_any = false;
   // Retunes (kq_bank_set_second_lo / _doppler / _shift) leave the steady state intact: the channels touched since the last
   // call are on patch_list, and the next call advances everybody on the device as usual and then overwrites just those
@@ -989,6 +994,7 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
   // them the channels retuned since the last call (their first block is redone on the per-sample path)
   int *ret = reinterpret_cast<int *>(flags + ((b->cfg.max_blocks + 7) & ~7u));
   int nret = 0, npatch = 0;
+  b->ret_host.clear();
   {  // the bitmap of the slot's last use goes back to zero
     unsigned long long *bits = reinterpret_cast<unsigned long long *>(b->stage_host[slot] + b->bits_off);
     for (unsigned w : b->slot_bit_words[slot]) bits[w] = 0;
@@ -1010,7 +1016,10 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
       npatch++;
       bits[c >> 6] |= 1ull << (c & 63);
       b->slot_bit_words[slot].push_back((unsigned)(c >> 6));
-      if (h.retuned) ret[nret++] = c;
+      if (h.retuned) {
+        ret[nret++] = c;
+        b->ret_host.push_back(c);
+      }
     }
   } else {
     for (size_t c = 0; c < C; c++) {
@@ -1019,7 +1028,10 @@ int stage_call_params(kq_bank *b, int64_t n_w, const unsigned char *update, unsi
       for (int k = 0; k < 8; k++) pl[(size_t)k * Cmax + c] = v[k];
     }
     for (size_t c = 0; c < C; c++)
-      if (b->chans[c].active && b->chans[c].retuned) ret[nret++] = (int)c;
+      if (b->chans[c].active && b->chans[c].retuned) {
+        ret[nret++] = (int)c;
+        b->ret_host.push_back((int)c);
+      }
   }
   *nret_out = nret;
   *npatch_out = npatch;
@@ -1141,6 +1153,7 @@ int lists_remove(kq_bank *b, int c, bool from_active = true) {
 int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const unsigned char *update_host,
                      const float2 *spectrum);
 void note_patch(kq_bank *b, int ch);
+void note_retune(kq_bank *b, int ch);
 
 // kq_bank_get_host_timing: the host's wall time inside one call, kernels only queued (call_ms includes slot_wait_ms)
 int run_blocks(kq_bank *b, const float2 *window, unsigned nblocks, const unsigned char *update_host,
@@ -1267,6 +1280,22 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   int slot = 0, nret = 0, npatch = 0;
   int64_t const n_w = b->n_abs - (g.M - 1);
   if (stage_call_params(b, n_w, update_host, nblocks, &slot, &nret, steady, &npatch)) return -1;
+  // how far into the call's windows those channels' old samples reach (ChanDev::hist_len; M - 1 right after the retune), and
+  // how many leading blocks the kernels that mix a whole window with one oscillator therefore leave to the per-sample variant
+  unsigned nredo = 1;
+  {
+    int64_t deepest = 0;
+    for (int c : b->ret_host) {
+      HostChan &h = b->chans[c];
+      deepest = std::max(deepest, h.hist_old);
+      int const len = (int)std::min<int64_t>(h.hist_old, INT32_MAX);
+      if (h.hist_dev != len) {
+        if (ctl_put(b, CTL_FILTER, b->chd.hist_len + c, &len, sizeof len)) return -1;
+        h.hist_dev = len;
+      }
+    }
+    nredo = (unsigned)std::min<int64_t>(nblocks, std::max<int64_t>(1, (deepest + g.L - 1) / g.L));
+  }
   size_t const ret_off = 8 * Cmax * sizeof(double) + ((b->cfg.max_blocks + 7) & ~7u);
   const int *retune_list = reinterpret_cast<const int *>(reinterpret_cast<const unsigned char *>(b->osc_dev2[pp]) + ret_off);
   // full-spectrum path: the register-resident N = 16384 kernel where it applies (KQ_FULL_LDS=1 forces the LDS one)
@@ -1380,9 +1409,9 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
       // history half still carries the old one: redo just those channel-blocks on the per-sample path.
       if (nret > 0) {
         if (g.N > 16384)
-          kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, nret, 1, retune_list);
+          kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, nret, (int)nredo, retune_list);
         else
-          full_launch(b->stream, g, chd, pl, window, b->tw, nret, 1, 0, nullptr, -1, retune_list);
+          full_launch(b->stream, g, chd, pl, window, b->tw, nret, (int)nredo, 0, nullptr, -1, retune_list);
       }
     } else if (b->use64k) {
       bool const holes = b->list_active_host.size() != b->chans.size();
@@ -1397,7 +1426,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
       launch64k(holes ? (int)b->list_active_host.size() : C, (int)nblocks, holes ? b->list_active_dev : nullptr, plain);
       // the steady-state variant mixes a whole window with one oscillator: the first block of a channel retuned since
       // the last call (history still on the old one) is redone with the per-sample variant
-      if (plain && nret > 0) launch64k(nret, 1, retune_list, false);
+      if (plain && nret > 0) launch64k(nret, (int)nredo, retune_list, false);
     } else if (g.N > 16384) {
       kq::launch_filter_split(b->stream, g, chd, pl, window, b->tw, C, (int)nblocks, nullptr);
     } else {
@@ -1413,7 +1442,7 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
                     b->cfg.compute_n0, b->spec_dump, b->spec_ch, holes ? b->list_active_dev : nullptr, false, false, swept_steady);
       }
       if (use16k && (plain || mixed || swept_steady) && nret > 0)
-        full_launch(b->stream, g, chd, pl, window, b->tw, nret, 1, b->cfg.compute_n0, b->spec_dump, b->spec_ch, retune_list);
+        full_launch(b->stream, g, chd, pl, window, b->tw, nret, (int)nredo, b->cfg.compute_n0, b->spec_dump, b->spec_ch, retune_list);
     }
     LAUNCH_CHECK("pre-detection filter");
     b->acc.filter_launches++;
@@ -1498,14 +1527,25 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
   b->n_abs += (int64_t)nblocks * g.L;
   b->out_abs += (int64_t)nblocks * g.olen;
   for (int c : b->patch_list)
-    if ((size_t)c < b->chans.size()) {
-      b->chans[c].patched = false;
-      b->chans[c].retuned = false;
-    }
+    if ((size_t)c < b->chans.size()) b->chans[c].patched = false;
   b->patch_list.clear();
+  // the channels that went through this call with samples of an old oscillator in their windows: the call has moved the
+  // windows on by nblocks L; whoever has old samples left (M - 1 > L and a short call) goes through the next call the same way
+  for (int c : b->ret_host) {
+    if ((size_t)c >= b->chans.size()) continue;
+    HostChan &h = b->chans[c];
+    if (!h.retuned) continue;
+    h.hist_old -= (int64_t)nblocks * g.L;
+    if (h.hist_old > 0 && h.active) {
+      note_patch(b, c);
+    } else {
+      h.retuned = false;
+      h.hist_old = 0;
+    }
+  }
+  b->ret_host.clear();
   if (!steady) {
     for (HostChan &h : b->chans) {
-      h.retuned = false;
       h.lo2.rebase(b->n_abs);
       h.dop.rebase(b->n_abs);
       h.shift.rebase(b->out_abs);
@@ -1518,6 +1558,23 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
 }
 
 bool valid_ch(const kq_bank *b, int ch) { return b && ch >= 0 && (size_t)ch < b->chans.size() && b->chans[ch].active; }
+
+// The second LO or the Doppler oscillator of channel `ch` is about to be set: the samples mixed so far keep what they were
+// mixed with (radio.c:132-139 mixes sample by sample, osc.c:22-36 changes only what follows), and the next M - 1 of them are
+// the history of the windows to come.  Several settings between two calls are one transition (nothing was mixed with the
+// ones in between).  A setting while an EARLIER transition is still inside the history -- possible only where M - 1 > L,
+// within M - 1 - L samples of it -- takes the oscillator in force now as the old one: the kernels know one transition per
+// window, and the older one concerns the fewer, oldest samples.
+void note_retune(kq_bank *b, int ch) {
+  HostChan &h = b->chans[ch];
+  int64_t const hist = (int64_t)b->g.M - 1;
+  if (!h.retuned || h.hist_old < hist) {
+    h.lo2_old = h.lo2;
+    h.dop_old = h.dop;
+    h.retuned = true;
+  }
+  h.hist_old = hist;
+}
 
 // an oscillator of channel `ch` has been set (or the channel is new): the next call patches its planes -- or, with too
 // many of them, stages the whole bank
@@ -1710,6 +1767,7 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.recovery, C);
   rc |= dev_alloc(&b->chd.hangmax, C);
   rc |= dev_alloc(&b->chd.noise_gain, C);
+  rc |= dev_alloc(&b->chd.hist_len, C);
   b->chd.n0lane = nullptr;
   b->chd.n0meta = nullptr;
   b->chd.n0slot = nullptr;
@@ -1884,7 +1942,7 @@ int kq_bank_destroy(kq_bank *b) {
   for (hipStream_t st : {b->copy_in, b->copy_out})  // before any plane they read or write is freed
     if (st) (void)hipStreamSynchronize(st);
   void *ptrs[] = {b->ring[0], b->ring[1], b->tw, b->chan_tw, b->chd.mode, b->chd.flags, b->chd.low, b->chd.high, b->chd.resp,
-                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.n0lane, b->chd.n0meta, b->chd.n0slot, b->fmout, b->fm_hist[0], b->fm_hist[1],
+                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.hist_len, b->chd.n0lane, b->chd.n0meta, b->chd.n0slot, b->fmout, b->fm_hist[0], b->fm_hist[1],
                   b->osc_dev2[0], b->osc_dev2[1], b->chd.fm_state,
                   b->chd.lastaudio, b->chd.sq_count, b->chd.ahist, b->chd.foffset, b->chd.pdev, b->chd.gain, b->chd.hang,
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
@@ -2310,6 +2368,7 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
   if (lists_remove(b, ch)) return -1;
   h.active = false;
   h.retuned = false;
+  h.hist_old = 0;
   h.patched = false;  // (its entry on the patch list, if any, is skipped: the next call stages the whole bank)
   release_n0slot(b, h.n0slot);
   h.n0slot = -1;
@@ -2434,11 +2493,7 @@ int kq_bank_set_second_lo(kq_bank *b, int ch, double hz) {
     set_err("bad channel or NaN");
     return -1;
   }
-  if (!b->chans[ch].retuned) {
-    b->chans[ch].lo2_old = b->chans[ch].lo2;
-    b->chans[ch].dop_old = b->chans[ch].dop;
-    b->chans[ch].retuned = true;
-  }
+  note_retune(b, ch);
   b->chans[ch].cfg.second_lo = hz;
   b->chans[ch].lo2.set(hz == 0 ? 0.0 : hz / b->g.samprate, 0.0, b->n_abs);
   b->chan_tw_dirty = true;
@@ -2453,11 +2508,7 @@ int kq_bank_set_doppler(kq_bank *b, int ch, double hz, double hz_per_s) {
     return -1;
   }
   double const fs = b->g.samprate;
-  if (!b->chans[ch].retuned) {
-    b->chans[ch].lo2_old = b->chans[ch].lo2;
-    b->chans[ch].dop_old = b->chans[ch].dop;
-    b->chans[ch].retuned = true;
-  }
+  note_retune(b, ch);
   b->chans[ch].cfg.doppler = hz;
   b->chans[ch].cfg.doppler_rate = hz_per_s;
   b->chans[ch].dop.set(-hz / fs, -hz_per_s / (fs * fs), b->n_abs);

@@ -104,7 +104,17 @@ __global__ void k_design(FftDim dim, int M, int spec, const DesignJob *__restric
   for (int n = threadIdx.x; n < N; n += blockDim.x) {
     float2 t = make_float2(0.f, 0.f);
     if (n < M) {
-      float2 const x = lds[(n - M / 2 + N) % N];
+      int const src = (n - M / 2 + N) % N;
+      float2 x = lds[src];
+      // The reference rotates IN PLACE, n descending (filter.c:389-390, 445-446): for n < M/2 the source slot N - M/2 + n
+      // lies above every slot still to be written only while L > M/2; with a longer impulse response (M >= 2 L) the slots
+      // up to M - 1 among them have been written already -- from their own source, which at that time was untouched -- and
+      // the reference's taps carry that.  Same here (one level deep: the source of a source is below it).
+      if (n < M / 2 && src < M) {
+        float2 const y = lds[src - M / 2];
+        float const ws = kaiser_tap(src, M, job.beta);
+        x = REAL ? make_float2(y.x * ws * inv_n, 0.f) : make_float2(y.x * ws * inv_n, y.y * ws * inv_n);
+      }
       float const w = kaiser_tap(n, M, job.beta);
       t = REAL ? make_float2(x.x * w * inv_n, 0.f) : make_float2(x.x * w * inv_n, x.y * w * inv_n);
     }

@@ -91,6 +91,11 @@ struct ChanDev {
   // the same for the M-1 history samples of the call's first block: they were mixed before a retune took effect
   // and keep the old oscillator (radio.c:132-139 mixes sample by sample; osc.c:22-36 only changes what follows)
   double *hist_phase, *hist_freq, *hist_rate;
+  // ... and how many samples from the start of the call's first window still carry it: sample i of block b's window is an old
+  // one while b L + i < hist_len[c].  M - 1 at the first call after a retune; where M - 1 > L (the reference's default
+  // -L 3840 -M 4353) the second block's window still reaches back that far, and with short calls so does the next call's.
+  // Only read where the history planes differ from the current ones: the word of a channel that was not retuned is stale.
+  int *hist_len;
   // post-detection shift oscillator at output sample 0 of the call
   double *sh_phase, *sh_freq;
   // carried demodulator state

@@ -250,7 +250,9 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c], rs = ch.lo_rate[c];
     double const hp0 = ch.hist_phase[c], hf0 = ch.hist_freq[c], hr = ch.hist_rate[c];
     double const mbase = (double)b * g.L;
-    bool const retuned = b == 0 && (hp0 != ph0 || hf0 != f0 || hr != rs);
+    // samples of an old oscillator in this window: those of the call's first hist_len[c] that lie beyond its start (ChanDev)
+    int const n_old = (hp0 != ph0 || hf0 != f0 || hr != rs) ? ch.hist_len[c] - b * g.L : 0;
+    bool const retuned = n_old > 0;
     if (PLAIN || (!retuned && fabs(rs) <= kSweepLimit64k)) {
       constexpr bool kSwept = !PLAIN || BIG == 2;
       // staging for two steps of loads (a step = the row pair 2 i, 2 i + 1 of all four quarters): sa = even row, sb = odd
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
         for (int j = 0; j < 4; j++) {
           int const i = 16384 * j + 512 * n1 + t;
           double const m = mbase + i;
-          bool const old = (b == 0) && i < g.M - 1;
+          bool const old = i < n_old;
           double const rr = old ? hr : rs;
           double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
           if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
@@ -399,7 +401,8 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     double const ph0 = ch.lo_phase[c], f0 = ch.lo_freq[c], r = ch.lo_rate[c];
     double const hp0 = ch.hist_phase[c], hf0 = ch.hist_freq[c], hr = ch.hist_rate[c];
     double const mbase = (double)b * g.L;
-    bool const retuned = b == 0 && (hp0 != ph0 || hf0 != f0 || hr != r);
+    int const n_old = (hp0 != ph0 || hf0 != f0 || hr != r) ? ch.hist_len[c] - b * g.L : 0;  // (as above)
+    bool const retuned = n_old > 0;
     if (PLAIN || (r == 0.0 && !retuned)) {
       float2 *const sw = stab + (t >> 6) * 32;
       if constexpr (!PLAIN) {
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
       for (int n1 = 0; n1 < 32; n1++) {
         int const i = 512 * n1 + t;
         double const m = mbase + i;
-        bool const old = (b == 0) && i < g.M - 1;  // history of the call's first block: pre-retune oscillator
+        bool const old = i < n_old;  // mixed before the retune took effect: pre-retune oscillator
         double const rr = old ? hr : r;
         double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
         if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));

@@ -377,7 +377,11 @@ __global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__res
   // not Doppler-tracked): a thread's samples are blockDim apart, so its phasor advances by one constant step; evaluated afresh
   // in double every fourth sample, three float products in between (3 x 6e-8 of rounding against the 1e-5 of the parity bar).
   // The per-sample evaluation in double was 800 of this kernel's 1 770 vector instructions per wave (tools/pmc_sq.sh).
-  bool const one_osc = r == 0.0 && (b != 0 || (hr == 0.0 && hp0 == ph0 && hf0 == f0));
+  // (samples of an old oscillator: the first hist_len[c] of the call's first window, ChanDev -- block b's window has those
+  //  that lie beyond its start, if the history planes differ from the current ones at all)
+  bool const same_osc = hr == r && hp0 == ph0 && hf0 == f0;
+  int const n_old = same_osc ? 0 : ch.hist_len[c] - b * g.L;
+  bool const one_osc = r == 0.0 && n_old <= 0;
   if (one_osc) {
     float2 const step = phasor_turns(f0 * (double)blockDim.x);
     float2 lo = make_float2(1.f, 0.f);
@@ -389,7 +393,7 @@ __global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__res
   } else {
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
       double const m = mbase + i;
-      bool const old = (b == 0) && i < g.M - 1;  // history of the call's first block: pre-retune oscillator
+      bool const old = i < n_old;  // mixed before the retune took effect: pre-retune oscillator
       double const rr = old ? hr : r;
       double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
       if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
@@ -485,12 +489,13 @@ __global__ void k_filter_split(Geom g, ChanDev ch, Planes pl, const float2 *__re
   double const hp0 = ch.hist_phase[c], hf0 = ch.hist_freq[c], hr = ch.hist_rate[c];
   const float2 *x = window + (size_t)b * g.L;
   double const mbase = (double)b * g.L;
+  int const n_old = (hr == r && hp0 == ph0 && hf0 == f0) ? 0 : ch.hist_len[c] - b * g.L;  // as in k_filter_full
   for (int s = 0; s < S; s++) {
     __syncthreads();
     for (int i = threadIdx.x; i < N1; i += blockDim.x) {
       int const n = S * i + s;
       double const m = mbase + n;
-      bool const old = (b == 0) && n < g.M - 1;
+      bool const old = n < n_old;
       double const rr = old ? hr : r;
       double turns = old ? hp0 + hf0 * m : ph0 + f0 * m;
       if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));

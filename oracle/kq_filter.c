@@ -214,7 +214,8 @@ int kqo_window_filter(int L, int M, float complex *response, float beta){
   kqo_fft_c2c(plan, response, buf, +1);                        /* to time domain: filter.c:377-378 */
   kqo_make_kaiser(win, (unsigned)M, beta);
   float const gain = 1. / N;                                   /* filter.c:387 */
-  /* descending n so the rotation by M/2 never reads an already overwritten slot (filter.c:389-390) */
+  /* in place, n descending, as filter.c:389-390 does it: no slot is read after it was written as long as L > M/2; with a
+   * longer impulse response the first taps are formed from slots the loop has already written, here as there */
   for(int n = M - 1; n >= 0; n--)
     buf[n] = buf[(n - M / 2 + N) % N] * win[n] * gain;
   for(int n = M; n < N; n++)

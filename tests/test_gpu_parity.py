@@ -303,6 +303,11 @@ GEOMETRIES = [
     (13440, 6720,  6721,  7,   336000, "auto", True),        # N = 2^7 3 5 7, N/D = 1920
     (7168,  3584,  3585,  4,   192000, "auto", True),        # N = 2^10 7, N/D = 1792 = 2^8 7, 896 samples per block
     (4802,  2401,  2402,  7,   336000, "auto", True),        # N = 2 7^4, N/D = 686 = 2 7^3, 343 samples per block
+    # an impulse response of two and three blocks (M >= 2 L): window_filter's in-place rotation (filter.c:389-390) then forms
+    # its first taps from slots it has already written -- the response design follows the reference in that (both the complex
+    # design and the REAL one of the FM audio filter, fm.c:64: 16 samples per block against 49 taps)
+    (4096,  1024,  3073,  64,  2000000, "auto", False),
+    (4096,  1024,  3073,  16,  2000000, "full", True),
 ]
 
 
@@ -981,41 +986,75 @@ def test_pcm_rtp_datagrams(gpu):
     bank.close()
 
 
-@pytest.mark.parametrize("name,mode", [("cfg4", "pruned"), ("cfg4", "full"), ("cfg5", "pruned"), ("cfg5", "full")])
-def test_retune_mid_stream_is_sample_exact(gpu, name, mode):
+# the generic kernels (k_filter_full steps a float oscillator through a window that has ONE unswept oscillator and evaluates per
+# sample in double otherwise: both in this test; k_filter_split beyond one LDS block) at sizes of their own
+RETUNE_GEOMETRIES = {"n8192": dict(samprate=192000, L=3840, M=4353, D=4),        # the reference's default -L / -M (main.c:160-170)
+                     "n9600": dict(samprate=240000, L=4800, M=4801, D=5),
+                     "n32768": dict(samprate=4000000, L=16384, M=16385, D=128)}
+
+
+# ... and where M - 1 > L (the reference's default -L 3840 -M 4353, main.c:160-170; N = 16384 and 65536 likewise): the SECOND
+# block after a retune still has M - 1 - L samples of the old oscillator in its window -- and with one block per call that
+# block belongs to the next call
+RETUNE_GEOMETRIES.update({"n16384_long_m": dict(samprate=192000, L=7680, M=8705, D=4),
+                          "n16384_long_m_d256": dict(samprate=10000000, L=6144, M=10241, D=256),  # two blocks of old history
+                          "n65536_long_m": dict(samprate=20000000, L=24576, M=40961, D=512),
+                          "n4096_long_m": dict(samprate=2000000, L=1024, M=3073, D=64)})         # pruned-capable, three blocks
+
+
+@pytest.mark.parametrize("name,mode,per", [("cfg4", "pruned", 2), ("cfg4", "full", 2), ("cfg5", "pruned", 2), ("cfg5", "full", 2),
+                                           ("n8192", "full", 2), ("n9600", "full", 2), ("n32768", "full", 2),
+                                           ("n8192", "full", 1), ("n16384_long_m", "full", 2), ("n16384_long_m", "full", 1),
+                                           ("n16384_long_m_d256", "full", 1), ("n16384_long_m_d256", "pruned", 1),
+                                           ("n65536_long_m", "full", 1), ("n65536_long_m", "pruned", 2),
+                                           ("n4096_long_m", "pruned", 1), ("n4096_long_m", "full", 3)])
+def test_retune_mid_stream_is_sample_exact(gpu, name, mode, per):
     """osc.c:22-36 + radio.c:132-139: a retune changes only the samples mixed after it; the M-1 history samples of
-    the next block keep the old oscillator (phase continuous).  Second LO and Doppler retuned between calls."""
+    the blocks that follow keep the old oscillator (phase continuous).  Second LO and Doppler retuned between calls of
+    `per` blocks."""
     import kq_oracle as ko
     from common import oracle_cfg
-    g = wl.GEOMETRY[name]
+    if name in RETUNE_GEOMETRIES:
+        g = RETUNE_GEOMETRIES[name]
+        ds = g["samprate"] / g["D"]
+        # (each channel on an emitter of the synthetic band: the 1e-5 bar is relative to the channel's own output)
+        lo = [-wl.emitter_freq(e, g["samprate"]) for e in (24, 27, 26)]           # an FM, an SSB and an AM emitter
+        plan = [dict(demod="fm", low=-0.16 * ds, high=0.16 * ds, second_lo=lo[0], doppler=0.0, doppler_rate=0.0),
+                dict(demod="linear", low=0.002 * ds, high=0.06 * ds, second_lo=lo[1], hangtime=1.1, recovery_rate=6.0, doppler=0.0,
+                     doppler_rate=0.0),
+                dict(demod="am", low=-0.1 * ds, high=0.1 * ds, second_lo=lo[2], recovery_rate=50.0, doppler=0.0, doppler_rate=0.0)]
+    else:
+        g = wl.GEOMETRY[name]
+        plan = wl.channel_plan(name, 3)
     fs, L = g["samprate"], g["L"]
-    plan = wl.channel_plan(name, 3)
     for p in plan:
         p["second_lo"] -= p["doppler"]
         p["doppler"] = p["doppler_rate"] = 0.0
-    nblocks = 6
+    ncalls = 3 if per == 2 else 12 // per
+    nblocks = ncalls * per
     iq = wl.make_iq(fs, nblocks * L, seed=29)
     chans = [ko.Channel(oracle_cfg(p, fs, L, g["M"], g["D"])) for p in plan]
-    bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), 2, fwd_mode=kq.KQ_FWD_PRUNED if mode == "pruned" else kq.KQ_FWD_FULL)
+    bank = kq.Bank(fs, L, g["M"], g["D"], len(plan), per, fwd_mode=kq.KQ_FWD_PRUNED if mode == "pruned" else kq.KQ_FWD_FULL)
     for p in plan:
         bank.add_channel(bank_cfg(p))
-    for call in range(3):
-        if call == 1:      # retune channel 0's second LO by a non-bin-aligned amount, start a Doppler sweep on channel 1
+    first, second = (1, 2) if per == 2 else (ncalls // 3, 2 * ncalls // 3)
+    for call in range(ncalls):
+        if call == first:  # retune channel 0's second LO by a non-bin-aligned amount, start a Doppler sweep on channel 1
             new_lo = plan[0]["second_lo"] + 777.7
             bank.set_second_lo(0, new_lo)
             chans[0].set_lo2(new_lo)
             bank.set_doppler(1, 1500.0, 80.0)
             chans[1].set_doppler(1500.0, 80.0)
-        if call == 2:      # and back again
+        if call == second:  # and back again
             bank.set_second_lo(0, plan[0]["second_lo"])
             chans[0].set_lo2(plan[0]["second_lo"])
             bank.set_doppler(1, 0.0, 0.0)
             chans[1].set_doppler(0.0, 0.0)
-        bank.push_iq(iq[2 * call * L:2 * (call + 1) * L])
-        assert bank.process() == 2
+        bank.push_iq(iq[per * call * L:per * (call + 1) * L])
+        assert bank.process() == per
         for c, ch in enumerate(chans):
-            for b in range(2):
-                _, _, filt, _ = ch.block(iq[(2 * call + b) * L:(2 * call + b + 1) * L], want_filt=True)
+            for b in range(per):
+                _, _, filt, _ = ch.block(iq[(per * call + b) * L:(per * call + b + 1) * L], want_filt=True)
                 got = bank.filter_output(c, b)
                 assert rel_rms(got, filt) < FILT_TOL, (call, c, b, rel_rms(got, filt))
     bank.close()

@@ -57,7 +57,8 @@ typedef struct kq_bank kq_bank;   /* opaque */
  *     the generic kernels -- any even 2^a 3^b 5^c 7^d up to 16384 (up to 65536 without compute_n0, where N splits into a few
  *     transforms of at most 16384 points: 24000, 38400, 48000 ...): the sizes of a front end whose rate is not 48 kHz x 2^k
  *     (decimate = samprate / 48000, radio_status.c:266: 5 at 240 kHz with L = 4800, M = 4801).  A prime factor beyond 7 is
- *     refused.  decimate must divide N, L and M - 1 (the reference only warns when it does not, filter.c:106-107).  The fast
+ *     refused.  decimate must divide N, L and M - 1 (the reference only warns when it does not, filter.c:106-107); decimate 1
+ *     (a 48 kHz front end) needs N <= 8192.  The fast
  *     kernels (N = 16384 / 65536 full-spectrum, the pruned ones, N/D = 64 and 256 demodulators) are power-of-two only;
  *   - the full-spectrum forward path (compute_n0 = 1) serves N <= 16384 and N = 65536; N = 32768 only without compute_n0.
  *     At N = 65536 the four workgroups of a channel-block wait for each other (bounded: a lost one gives NaN and an error
@@ -75,7 +76,8 @@ typedef struct kq_bank_config {
   int samprate;            /* front-end complex sample rate, Hz */
   unsigned L;              /* new samples per block            (demod->filter.L) */
   unsigned M;              /* impulse response length          (demod->filter.M); N = L+M-1: see Limits */
-  unsigned decimate;       /* D: output rate = samprate / D    (demod->filter.decimate), >= 2 */
+  unsigned decimate;       /* D: output rate = samprate / D    (demod->filter.decimate), >= 1 (1 -- a 48 kHz front end -- with
+                              L + M - 1 <= 8192) */
   unsigned max_channels;
   unsigned max_blocks;     /* largest number of blocks one kq_bank_process call may take */
   float gain_factor;       /* demod->sdr.gain_factor (radio.c:122); 1.0 for synthetic float input */

@@ -1639,8 +1639,14 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
     set_err("L+M-1 = %u must be a power of two >= 16, or an even 2^a 3^b 5^c 7^d in 16..65536", N);
     return nullptr;
   }
-  if (cfg->decimate < 2 || N % cfg->decimate != 0 || cfg->L % cfg->decimate != 0 || (cfg->M - 1) % cfg->decimate != 0) {
-    set_err("decimate %u must be >= 2 and divide N, L and M-1", cfg->decimate);
+  if (cfg->decimate < 1 || N % cfg->decimate != 0 || cfg->L % cfg->decimate != 0 || (cfg->M - 1) % cfg->decimate != 0) {
+    set_err("decimate %u must be >= 1 and divide N, L and M-1", cfg->decimate);
+    return nullptr;
+  }
+  // decimate = samprate / 48000 = 1 (radio_status.c:266: a 48 kHz front end, a sound-card receiver): the slave's transform is
+  // as long as the master's and needs a buffer of its own beside it in LDS (k_filter_full)
+  if (cfg->decimate == 1 && N > 8192) {
+    set_err("decimate 1 needs L+M-1 = %u <= 8192 (master and slave transform side by side in LDS)", N);
     return nullptr;
   }
   unsigned const Ndec = N / cfg->decimate;

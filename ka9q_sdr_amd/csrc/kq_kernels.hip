@@ -435,7 +435,8 @@ __global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__res
 
   // --- slave: response multiply (filter.c:206-227), CROSS_CONJ (filter.c:239-249)
   // G goes to the unused middle of the spectrum buffer: bins N_dec/2+1 .. N-N_dec/2 are never read
-  float2 *G = lds + (Ndec / 2 + 1);
+  // (decimate 1: there is no such middle -- every bin is read -- and the launch has asked for a second buffer behind the first)
+  float2 *G = Ndec == N ? lds + N : lds + (Ndec / 2 + 1);
   const float2 *H = ch.resp + (size_t)c * Ndec;
   bool const isb = (ch.fflags[c] & FLAG_ISB) != 0;
   for (int p = threadIdx.x; p <= Ndec / 2; p += blockDim.x) {
@@ -461,7 +462,7 @@ __global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__res
 void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes &pl, const float2 *window,
                         const float2 *tw, int nchan, int nblocks, int compute_n0, float2 *spec_dump, int spec_ch,
                         const int *chan_list) {
-  size_t const lds_bytes = (size_t)g.N * sizeof(float2);
+  size_t const lds_bytes = (size_t)g.N * sizeof(float2) * (g.Ndec == g.N ? 2 : 1);
   ensure_dynamic_lds((const void *)k_filter_full, lds_bytes);
   int const threads = g.N >= 4096 ? 1024 : 256;
   hipLaunchKernelGGL(k_filter_full, dim3(nchan, nblocks), dim3(threads), lds_bytes, s, g, ch, pl, window, tw, compute_n0,

@@ -303,6 +303,10 @@ GEOMETRIES = [
     (13440, 6720,  6721,  7,   336000, "auto", True),        # N = 2^7 3 5 7, N/D = 1920
     (7168,  3584,  3585,  4,   192000, "auto", True),        # N = 2^10 7, N/D = 1792 = 2^8 7, 896 samples per block
     (4802,  2401,  2402,  7,   336000, "auto", True),        # N = 2 7^4, N/D = 686 = 2 7^3, 343 samples per block
+    # decimate 1 (samprate / 48000 at a 48 kHz front end, radio_status.c:266): the slave's transform is the master's size
+    (2048,  1024,  1025,  1,   48000,  "auto", True),
+    (1920,  960,   961,   1,   48000,  "auto", True),        # 20 ms blocks at 48 kHz: N = 2^7 3 5
+    (8192,  3840,  4353,  1,   48000,  "full", False),       # the largest: two 64 KiB buffers side by side
     # an impulse response of two and three blocks (M >= 2 L): window_filter's in-place rotation (filter.c:389-390) then forms
     # its first taps from slots it has already written -- the response design follows the reference in that (both the complex
     # design and the REAL one of the FM audio filter, fm.c:64: 16 samples per block against 49 taps)

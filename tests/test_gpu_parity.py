@@ -681,6 +681,39 @@ def test_cfg2_geometry_without_the_pl_measurement(gpu, seed, per_call):
             assert all(np.isnan(st["plfreq"]) for st in got[c]["status"])
 
 
+@pytest.mark.parametrize("name,pl_tone", [("cfg2", False), ("cfg2", True), ("cfg3", True), ("cfg1", True)])
+def test_more_than_64_blocks_in_one_call(gpu, name, pl_tone):
+    """A call of 150 blocks (max_blocks is the host's choice; a file replayed faster than real time uses long calls): the FM
+    kernels walk a call in chunks of 64 blocks (k_demod_fm256's LDS, k_demod_fm's phases), the wave-per-channel ones block
+    by block, the squelch / hang / n0 chains run through all of them.  FM, AM and SSB against the oracle, then 23 more
+    blocks in a second call."""
+    g = wl.GEOMETRY[name]
+    fs = g["samprate"]
+    plan = [dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-(wl.emitter_freq(0, fs) + 3.0)),
+            dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-(wl.emitter_freq(1, fs) - 7.0), flat=1),
+            dict(demod="am", low=-5000.0, high=5000.0, second_lo=-wl.emitter_freq(2, fs), recovery_rate=50.0),
+            dict(demod="linear", low=100.0, high=3000.0, second_lo=-wl.emitter_freq(3, fs), hangtime=1.1, recovery_rate=6.0),
+            dict(demod="fm", low=-8000.0, high=8000.0, second_lo=0.9 * 21.0 / 64 * fs)]    # half way between two emitters: squelch shut
+    nblocks, last = (150 + 23, 23) if name != "cfg1" else (70 + 9, 9)
+    iq = wl.make_iq(fs, nblocks * g["L"], seed=77)
+    want = run_oracle(plan, g, iq, nblocks, compute_n0=1)
+    got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_AUTO, compute_n0=True, per_call=nblocks - last, pl_tone=pl_tone)
+    if name == "cfg1":          # (at 192 kHz the emitters stand 2.7 kHz apart: no empty channel there)
+        _compare(plan, got, want, check_n0=True, geom=g)
+        return
+    _compare(plan[:4], got[:4], want[:4], check_n0=True, geom=g)
+    # the empty channel: 60 dB below the band's power, its output is compared at 5e-5 of its own RMS (float rounding of a
+    # 16384-point transform of the whole band); what matters here is its squelch counter, which runs through the chunk borders
+    _, sts, filts = want[4]
+    assert rel_rms(np.concatenate(got[4]["filt"]), np.concatenate(filts)) < 5e-5
+    assert [st["squelch_count"] for st in got[4]["status"]] == [st["squelch_count"] for st in sts]
+    assert [st["blanked"] for st in got[4]["status"]] == [st["blanked"] for st in sts]
+    if name == "cfg2":      # (32 samples per block at cfg 3: the SNR estimate of noise alone reopens the squelch now and then)
+        assert any(st["squelch_count"] > 64 for st in sts)
+    for a, w in zip(got[4]["audio"], want[4][0]):
+        assert len(a) == len(w) and (not np.any(w) or rel_rms(a, w) < 1e-3)
+
+
 def test_long_run_phase_continuity(gpu):
     """2.5 million input samples (300 blocks over five process calls, more than 150 renormalisation periods of the
     reference's NCO recurrence): the closed-form oscillators of the bank must not drift away from the oracle's

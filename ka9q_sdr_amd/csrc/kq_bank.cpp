@@ -112,12 +112,15 @@ struct HostChan {
   Osc lo2, dop, shift;
   // oscillators as they were before a retune that has not reached the kernels yet: the M-1 history samples of
   // the next block were mixed with these (radio.c:132-139)
-  Osc lo2_old, dop_old;
+  Osc lo2_old, dop_old;    // the oscillators before the last retune (the history planes) ...
+  Osc lo2_old2, dop_old2;  // ... and the ones before the retune before that, while samples of theirs are still in the history
   bool retuned = false;
   // ... and how many samples from the start of the NEXT call's first window still carry the old oscillators (ChanDev::hist_len):
   // M - 1 when the retune happens; a call of n blocks takes n L off it; the channel stays `retuned` while any are left
   int64_t hist_old = 0;
-  int hist_dev = -1;  // what hist_len[c] on the device was last told
+  int64_t hist_old2 = 0;  // the same for lo2_old2 / dop_old2 (the older transition: fewer samples; 0 = there is none)
+  int hist_dev = -1;   // what hist_len[c] on the device was last told
+  int hist2_dev = 0;   // ... and hist2_len[c]
   bool active = true;  // false: a hole left by kq_bank_remove_channel, reused by the next kq_bank_add_channel
   kq_out_rtp_state out_rtp{};  // demod->output.rtp + output.silent (audio.c:32-132)
   int out_type;
@@ -972,6 +975,19 @@ void eval_planes(const kq_bank *b, const HostChan &h, int64_t n_w, double out[8]
   }
 }
 
+// the older of two transitions inside the history (note_retune): its oscillators at the window start, as the history planes
+void eval_old2(const HostChan &h, int64_t n_w, double out[3]) {
+  double q = h.lo2_old2.phase_at(n_w), f = h.lo2_old2.step_at(n_w), r = h.lo2_old2.sweep();
+  if (h.dop_old2.set_f != 0) {
+    q += h.dop_old2.phase_at(n_w);
+    f += h.dop_old2.step_at(n_w);
+    r += h.dop_old2.sweep();
+  }
+  out[0] = q - std::floor(q);
+  out[1] = f;
+  out[2] = r;
+}
+
 // Per-call parameters: oscillator phase/step/sweep for a call whose first window starts at absolute
 // sample n_w, the shift oscillator at the first output sample, and the IF-power update flags.
 // Filled into the next pinned staging slot (returned in *slot_out); the first kernel of the call copies it to the device.
@@ -1293,6 +1309,16 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
         if (ctl_put(b, CTL_FILTER, b->chd.hist_len + c, &len, sizeof len)) return -1;
         h.hist_dev = len;
       }
+      int const len2 = (int)std::min<int64_t>(h.hist_old2, INT32_MAX);
+      if (len2 > 0) {  // (its phase is the window start's: written for every call it lasts)
+        double v[3];
+        eval_old2(h, n_w, v);
+        if (ctl_put(b, CTL_FILTER, b->chd.hist2_osc + 3 * (size_t)c, v, sizeof v)) return -1;
+      }
+      if (h.hist2_dev != len2) {
+        if (ctl_put(b, CTL_FILTER, b->chd.hist2_len + c, &len2, sizeof len2)) return -1;
+        h.hist2_dev = len2;
+      }
     }
     nredo = (unsigned)std::min<int64_t>(nblocks, std::max<int64_t>(1, (deepest + g.L - 1) / g.L));
   }
@@ -1536,11 +1562,12 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     HostChan &h = b->chans[c];
     if (!h.retuned) continue;
     h.hist_old -= (int64_t)nblocks * g.L;
+    h.hist_old2 = std::max<int64_t>(0, h.hist_old2 - (int64_t)nblocks * g.L);
     if (h.hist_old > 0 && h.active) {
       note_patch(b, c);
     } else {
       h.retuned = false;
-      h.hist_old = 0;
+      h.hist_old = h.hist_old2 = 0;
     }
   }
   b->ret_host.clear();
@@ -1562,17 +1589,21 @@ bool valid_ch(const kq_bank *b, int ch) { return b && ch >= 0 && (size_t)ch < b-
 // The second LO or the Doppler oscillator of channel `ch` is about to be set: the samples mixed so far keep what they were
 // mixed with (radio.c:132-139 mixes sample by sample, osc.c:22-36 changes only what follows), and the next M - 1 of them are
 // the history of the windows to come.  Several settings between two calls are one transition (nothing was mixed with the
-// ones in between).  A setting while an EARLIER transition is still inside the history -- possible only where M - 1 > L,
-// within M - 1 - L samples of it -- takes the oscillator in force now as the old one: the kernels know one transition per
-// window, and the older one concerns the fewer, oldest samples.
+// ones in between).  A setting while an EARLIER transition is still inside the history -- possible only where M - 1 > L: a
+// channel retuned before every block at the reference's default -L 3840 -M 4353 -- makes that one the older of TWO the
+// kernels know per window (hist2_*); a third inside the same M - 1 samples (M - 1 > 2 L) drops the oldest.
 void note_retune(kq_bank *b, int ch) {
   HostChan &h = b->chans[ch];
   int64_t const hist = (int64_t)b->g.M - 1;
-  if (!h.retuned || h.hist_old < hist) {
-    h.lo2_old = h.lo2;
-    h.dop_old = h.dop;
-    h.retuned = true;
+  if (h.retuned && h.hist_old == hist) return;  // set again before anything was mixed with the setting in between
+  if (h.retuned) {  // the transition before this one still has samples in the history: it becomes the older of two
+    h.lo2_old2 = h.lo2_old;
+    h.dop_old2 = h.dop_old;
+    h.hist_old2 = h.hist_old;
   }
+  h.lo2_old = h.lo2;
+  h.dop_old = h.dop;
+  h.retuned = true;
   h.hist_old = hist;
 }
 
@@ -1774,6 +1805,8 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.hangmax, C);
   rc |= dev_alloc(&b->chd.noise_gain, C);
   rc |= dev_alloc(&b->chd.hist_len, C);
+  rc |= dev_alloc(&b->chd.hist2_len, C);
+  rc |= dev_alloc(&b->chd.hist2_osc, 3 * C);
   b->chd.n0lane = nullptr;
   b->chd.n0meta = nullptr;
   b->chd.n0slot = nullptr;
@@ -1948,7 +1981,7 @@ int kq_bank_destroy(kq_bank *b) {
   for (hipStream_t st : {b->copy_in, b->copy_out})  // before any plane they read or write is freed
     if (st) (void)hipStreamSynchronize(st);
   void *ptrs[] = {b->ring[0], b->ring[1], b->tw, b->chan_tw, b->chd.mode, b->chd.flags, b->chd.low, b->chd.high, b->chd.resp,
-                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.hist_len, b->chd.n0lane, b->chd.n0meta, b->chd.n0slot, b->fmout, b->fm_hist[0], b->fm_hist[1],
+                  b->chd.aresp, b->chd.fm_gain, b->chd.headroom, b->chd.recovery, b->chd.hangmax, b->chd.noise_gain, b->chd.hist_len, b->chd.hist2_len, b->chd.hist2_osc, b->chd.n0lane, b->chd.n0meta, b->chd.n0slot, b->fmout, b->fm_hist[0], b->fm_hist[1],
                   b->osc_dev2[0], b->osc_dev2[1], b->chd.fm_state,
                   b->chd.lastaudio, b->chd.sq_count, b->chd.ahist, b->chd.foffset, b->chd.pdev, b->chd.gain, b->chd.hang,
                   b->chd.dc, b->chd.n0, b->chd.plresp, b->chd.plring, b->chd.pl_ptr, b->chd.pl_last, b->chd.plfreq,
@@ -2374,7 +2407,7 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
   if (lists_remove(b, ch)) return -1;
   h.active = false;
   h.retuned = false;
-  h.hist_old = 0;
+  h.hist_old = h.hist_old2 = 0;
   h.patched = false;  // (its entry on the patch list, if any, is skipped: the next call stages the whole bank)
   release_n0slot(b, h.n0slot);
   h.n0slot = -1;
@@ -2385,7 +2418,7 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
   b->cache_any = b->n_active > 0;
   b->sweep_lists_dirty = true;
   h.r_eff = 0;
-  h.lo2 = h.dop = h.shift = h.lo2_old = h.dop_old = Osc{};
+  h.lo2 = h.dop = h.shift = h.lo2_old = h.dop_old = h.lo2_old2 = h.dop_old2 = Osc{};
   h.out_rtp = kq_out_rtp_state{};
   while (!b->chans.empty() && !b->chans.back().active) b->chans.pop_back();  // holes at the end just go
   return 0;

@@ -96,6 +96,12 @@ struct ChanDev {
   // -L 3840 -M 4353) the second block's window still reaches back that far, and with short calls so does the next call's.
   // Only read where the history planes differ from the current ones: the word of a channel that was not retuned is stale.
   int *hist_len;
+  // A channel retuned again while samples of the oscillator BEFORE the last one are still in the history (M - 1 > L and a
+  // retune before every block): those oldest samples -- the first hist2_len[c] of the call's first window, fewer than
+  // hist_len[c] -- carry hist2_osc[3 c .. 3 c + 2] (phase, step, sweep at the window start).  Read only where hist_len says
+  // there are old samples at all; 0 = none of the older kind.
+  int *hist2_len;
+  double *hist2_osc;
   // post-detection shift oscillator at output sample 0 of the call
   double *sh_phase, *sh_freq;
   // carried demodulator state

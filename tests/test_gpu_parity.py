@@ -353,6 +353,45 @@ def test_geometry_sweep(gpu, N, L, M, D, fs, mode, n0):
     _compare(plan, got, want, check_n0=n0, geom=g)
 
 
+def _smooth_sizes(lo, hi):
+    out = []
+    for n in range(lo, hi + 1, 2):
+        m = n
+        for p in (2, 3, 5, 7):
+            while m % p == 0:
+                m //= p
+        if m == 1:
+            out.append(n)
+    return out
+
+
+@pytest.mark.parametrize("seed", list(range(48)))
+def test_geometries_drawn_at_random(gpu, seed):
+    """The sweep above is a list somebody chose.  Here the geometry is drawn: N/decimate any even 2^a 3^b 5^c 7^d in 64..2048,
+    decimate from 1 to 64 (the front end at decimate x 48 kHz, radio_status.c:266), the impulse response between a quarter and
+    0.55 of N/decimate (so M - 1 < L, = L and > L all occur), 2 to 4 blocks per call, compute_n0 on; FM / AM / USB / ISB
+    against the oracle as in the sweep."""
+    rng = np.random.default_rng(9000 + seed)
+    while True:
+        nd = int(rng.choice(_smooth_sizes(64, 2048)))
+        D = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 25, 32, 64]))
+        N = nd * D
+        if N <= (8192 if D == 1 else 16384) and N >= 256:
+            break
+    k = int(rng.integers(nd // 4, int(nd * 0.55) + 1))
+    M, L, fs = k * D + 1, (nd - k) * D, 48000 * D
+    g = dict(samprate=fs, L=L, M=M, D=D)
+    plan, iq, nblocks = _sweep_case(N, L, M, D, fs)
+    if D == 1:                                  # (the sweep's AM channel would straddle the band edge at decimate 1)
+        plan[1]["second_lo"] = -0.11 * fs + 0.2 * fs
+    want = run_oracle(plan, g, iq, nblocks, compute_n0=1)
+    got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_AUTO, compute_n0=True, per_call=int(rng.integers(2, 5)))
+    try:
+        _compare(plan, got, want, check_n0=True, geom=g)
+    except AssertionError as e:
+        raise AssertionError("geometry N = %d (L = %d, M = %d), decimate %d, %d Hz: %s" % (N, L, M, D, fs, e)) from e
+
+
 def test_filter_and_shift_changed_while_running(gpu):
     """What the UI does between blocks (display.c:161-177, radio.c:304-311): new filter edges / Kaiser beta and a new
     post-detection shift; the response is swapped at the next block (filter.c:538-543), the shift oscillator keeps
@@ -1094,6 +1133,60 @@ def test_retune_mid_stream_is_sample_exact(gpu, name, mode, per):
                 _, _, filt, _ = ch.block(iq[(per * call + b) * L:(per * call + b + 1) * L], want_filt=True)
                 got = bank.filter_output(c, b)
                 assert rel_rms(got, filt) < FILT_TOL, (call, c, b, rel_rms(got, filt))
+    bank.close()
+
+
+@pytest.mark.parametrize("seed", list(range(48)))
+def test_retunes_at_geometries_drawn_at_random(gpu, seed):
+    """The retune rule at geometries nobody chose: N/decimate, decimate and the impulse response drawn as in
+    test_geometries_drawn_at_random but up to 0.7 of N/decimate (M - 1 up to 2.3 L: old samples in up to three blocks), one
+    to three blocks per call, a second-LO retune and a Doppler sweep switched on and off again at drawn calls.  Filter output
+    of every block from the third on (the first two are the leading edge of a long impulse response) against the oracle."""
+    import kq_oracle as ko
+    from common import oracle_cfg
+    rng = np.random.default_rng(9500 + seed)
+    while True:
+        nd = int(rng.choice(_smooth_sizes(64, 2048)))
+        D = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 16, 32, 64]))
+        N = nd * D
+        if N <= (8192 if D == 1 else 16384) and N >= 512:
+            break
+    k = int(rng.integers(nd // 4, int(nd * 0.7) + 1))
+    M, L, fs = k * D + 1, (nd - k) * D, 48000 * D
+    ds = 48000.0
+    lo = [-wl.emitter_freq(e, fs) for e in (24, 27, 26)]
+    plan = [dict(demod="fm", low=-0.16 * ds, high=0.16 * ds, second_lo=lo[0]),
+            dict(demod="linear", low=0.002 * ds, high=0.06 * ds, second_lo=lo[1], hangtime=1.1, recovery_rate=6.0),
+            dict(demod="am", low=-0.1 * ds, high=0.1 * ds, second_lo=lo[2], recovery_rate=50.0)]
+    per = int(rng.integers(1, 4))
+    ncalls = 15 // per
+    iq = wl.make_iq(fs, ncalls * per * L, seed=31 + seed, emitters=range(20, 32))
+    chans = [ko.Channel(oracle_cfg(p, fs, L, M, D)) for p in plan]
+    bank = kq.Bank(fs, L, M, D, len(plan), per, fwd_mode=kq.KQ_FWD_AUTO)
+    for p in plan:
+        bank.add_channel(bank_cfg(p))
+    first = int(rng.integers(ncalls // 3, ncalls // 2 + 1))
+    second = int(rng.integers(first + 1, ncalls))
+    for call in range(ncalls):
+        if call == first:
+            bank.set_second_lo(0, lo[0] + 777.7)
+            chans[0].set_lo2(lo[0] + 777.7)
+            bank.set_doppler(1, 1500.0, 80.0)
+            chans[1].set_doppler(1500.0, 80.0)
+        if call == second:
+            bank.set_second_lo(0, lo[0])
+            chans[0].set_lo2(lo[0])
+            bank.set_doppler(1, 0.0, 0.0)
+            chans[1].set_doppler(0.0, 0.0)
+        bank.push_iq(iq[per * call * L:per * (call + 1) * L])
+        assert bank.process() == per
+        for c, ch in enumerate(chans):
+            for b in range(per):
+                _, _, filt, _ = ch.block(iq[(per * call + b) * L:(per * call + b + 1) * L], want_filt=True)
+                if per * call + b >= 2:
+                    e = rel_rms(bank.filter_output(c, b), filt)
+                    assert e < FILT_TOL, ("N = %d (L = %d, M = %d), decimate %d, %d blocks per call, retunes at calls %d and %d: "
+                                          "call %d channel %d block %d: %.2e" % (N, L, M, D, per, first, second, call, c, b, e))
     bank.close()
 
 

@@ -12,10 +12,14 @@ from test_rtp_ingest import rtp_packet
 pytestmark = pytest.mark.gpu
 
 
-def test_packet_stream_matches_oracle(gpu):
-    g = dict(samprate=192000, L=512, M=513, D=4)
-    plan = wl.channel_plan("cfg1", 1)
-    iq = wl.make_iq(g["samprate"], 16 * g["L"], seed=31)
+@pytest.mark.parametrize("fs,L,M,D", [(192000, 512, 513, 4),
+                                       (192000, 3840, 4353, 4),      # the reference's default -L / -M: M - 1 > L
+                                       (240000, 4800, 4801, 5),      # N = 9600
+                                       (48000, 960, 961, 1)])        # decimate 1
+def test_packet_stream_matches_oracle(gpu, fs, L, M, D):
+    g = dict(samprate=fs, L=L, M=M, D=D)
+    plan = [dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-(wl.emitter_freq(24, fs) + 3.0))]
+    iq = wl.make_iq(g["samprate"], 16 * g["L"] + 2000, seed=31, emitters=range(20, 30))
     i16 = np.stack([np.round(iq.real * 20000), np.round(iq.imag * 20000)], axis=1).astype("<i2")
     i8 = np.stack([np.round(iq.real * 100), np.round(iq.imag * 100)], axis=1).astype("i1")
     p = dict(plan[0])
@@ -26,7 +30,8 @@ def test_packet_stream_matches_oracle(gpu):
     want, got = [], []
     n, pos, seq, ts = 240, 0, 65500, 4000000000                  # sequence and timestamp both wrap on the way
     packets = []
-    for k in range(30):
+    npk = 16 * g["L"] // n
+    for k in range(npk):
         kind = 98 if 10 <= k < 14 else 97                        # a few int8 packets in between
         body = (i8 if kind == 98 else i16)[pos:pos + n].tobytes()
         extra = dict(csrc=(5,)) if k == 3 else dict(pad=4) if k == 4 else {}
@@ -54,9 +59,9 @@ def test_packet_stream_matches_oracle(gpu):
         got += [(bank.audio(0, b), bank.status(0, b)) for b in range(nb)]
     c = bank.rtp_counters()
     assert (c["samples"], c["packets"], c["dupes"], c["drops"]) == (ing.samples, ing.rtp.packets, ing.rtp.dupes, ing.rtp.drops)
-    assert c["samples"] == 30 * n + 1000 and c["dupes"] == 1
+    assert c["samples"] == npk * n + 1000 and c["dupes"] == 1
     assert (c["next_seq"], c["next_timestamp"], c["ssrc"]) == (ing.rtp.seq, ing.rtp.timestamp, 0x1234)
-    assert len(got) == len(want) == (30 * n + 1000) // g["L"]
+    assert len(got) == len(want) == (npk * n + 1000) // g["L"]
     for (ga, gs), (wa, ws) in zip(got, want):
         assert gs["nout"] == ws["nout"] and gs["squelch_count"] == ws["squelch_count"]
         np.testing.assert_allclose(gs["if_power"], ws["if_power"], rtol=2e-4, atol=1e-12)

@@ -1190,6 +1190,95 @@ def test_retunes_at_geometries_drawn_at_random(gpu, seed):
     bank.close()
 
 
+@pytest.mark.parametrize("seed", list(range(32)))
+def test_an_operator_at_geometries_drawn_at_random(gpu, seed):
+    """What the UI and the Doppler thread do to a running receiver (display.c:161-177, doppler.c, radio.c:290-374) -- second LO,
+    Doppler with and without a rate and off again, shift, filter edges and Kaiser beta, mode -- drawn at random between the
+    calls of a bank whose geometry is drawn as in test_geometries_drawn_at_random (impulse responses up to 0.6 of
+    N/decimate), one to three blocks per call.  Every block's filter output from the third on, the sample counts and the FM
+    channels' squelch counters against the oracle given the same operations."""
+    import kq_oracle as ko
+    from common import oracle_cfg
+    rng = np.random.default_rng(9900 + seed)
+    while True:
+        nd = int(rng.choice(_smooth_sizes(64, 2048)))
+        D = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 16, 32, 64]))
+        N = nd * D
+        if N <= (8192 if D == 1 else 16384) and N >= 512:
+            break
+    k = int(rng.integers(nd // 4, int(nd * 0.6) + 1))
+    M, L, fs = k * D + 1, (nd - k) * D, 48000 * D
+    modes = dict(fm=dict(demod="fm", low=-7000.0, high=7000.0),
+                 am=dict(demod="am", low=-4500.0, high=4500.0, recovery_rate=50.0),
+                 usb=dict(demod="linear", low=100.0, high=3000.0, hangtime=1.1, recovery_rate=6.0),
+                 isb=dict(demod="linear", low=-3000.0, high=3000.0, hangtime=1.1, recovery_rate=6.0, isb=1, channels=2))
+    names = list(modes)
+    C = 5
+    cur = []
+    for c in range(C):
+        p = dict(modes[names[int(rng.integers(0, 4))]])
+        # (an FM or AM emitter each: whatever mode the channel is in or is switched to, its passband holds a signal -- the
+        #  1e-5 bar is relative to the channel's own output, and float rounding of the whole band is 2e-5 of an empty one)
+        p["second_lo"] = -(wl.emitter_freq((20, 21, 22, 24, 25)[c], fs) + float(rng.uniform(-50, 50)))
+        cur.append(p)
+    per = int(rng.integers(1, 4))
+    ncalls = 14 // per + 1
+    iq = wl.make_iq(fs, ncalls * per * L, seed=41 + seed, emitters=range(20, 32))
+    chans = [ko.Channel(oracle_cfg(p, fs, L, M, D)) for p in cur]
+    bank = kq.Bank(fs, L, M, D, C, per, fwd_mode=kq.KQ_FWD_AUTO)
+    for p in cur:
+        bank.add_channel(bank_cfg(p))
+    log = []
+    for call in range(ncalls):
+        for _ in range(int(rng.integers(0, 3)) if call >= 1 else 0):
+            c = int(rng.integers(0, C))
+            op = ("lo", "doppler", "doppler_off", "shift", "filter", "mode")[int(rng.integers(0, 6))]
+            if op == "lo":
+                hz = cur[c]["second_lo"] + float(rng.uniform(-400, 400))
+                bank.set_second_lo(c, hz)
+                chans[c].set_lo2(hz)
+                cur[c]["second_lo"] = hz
+            elif op == "doppler":
+                hz, rate = float(rng.uniform(-2000, 2000)), float(rng.choice([0.0, rng.uniform(-120, 120)]))
+                bank.set_doppler(c, hz, rate)
+                chans[c].set_doppler(hz, rate)
+            elif op == "doppler_off":
+                bank.set_doppler(c, 0.0, 0.0)
+                chans[c].set_doppler(0.0, 0.0)
+            elif op == "shift":
+                if cur[c]["demod"] != "linear":
+                    continue
+                hz = float(rng.uniform(-300, 300))
+                bank.set_shift(c, hz)
+                chans[c].set_shift(hz)
+            elif op == "filter":
+                lo_, hi_ = cur[c]["low"] * float(rng.uniform(0.6, 1.0)), cur[c]["high"] * float(rng.uniform(0.6, 1.0))
+                beta = float(rng.choice([2.0, 3.0, 5.0]))
+                bank.set_filter(c, lo_, hi_, beta)
+                chans[c].set_filter(lo_, hi_, beta)
+            else:
+                p = dict(modes[names[int(rng.integers(0, 4))]], second_lo=cur[c]["second_lo"])
+                bank.set_mode(c, bank_cfg(p))
+                chans[c].set_mode(oracle_cfg(p, fs, L, M, D))
+                cur[c] = p
+            log.append((call, c, op))
+        bank.push_iq(iq[per * call * L:per * (call + 1) * L])
+        assert bank.process() == per
+        for c, ch in enumerate(chans):
+            for b in range(per):
+                _, st, filt, _ = ch.block(iq[(per * call + b) * L:(per * call + b + 1) * L], want_filt=True)
+                where = "N = %d (L = %d, M = %d), decimate %d, %d per call; operations %s; call %d channel %d block %d" % (
+                    N, L, M, D, per, log, call, c, b)
+                gs = bank.status(c, b)
+                assert gs["nout"] == st["nout"], where
+                if per * call + b >= 2:
+                    e = rel_rms(bank.filter_output(c, b), filt)
+                    assert e < FILT_TOL, "%s: %.2e" % (where, e)
+                    if cur[c]["demod"] == "fm":
+                        assert gs["squelch_count"] == st["squelch_count"], where
+    bank.close()
+
+
 def _pll_case(fs, nsamp, seed):
     """two emitters for carrier-tracking channels: a full-carrier AM signal at +20 037 Hz and a suppressed-carrier DSB one at
     -30 061 Hz"""

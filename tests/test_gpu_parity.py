@@ -1279,6 +1279,43 @@ def test_an_operator_at_geometries_drawn_at_random(gpu, seed):
     bank.close()
 
 
+@pytest.mark.parametrize("name", ["n8192", "n16384_long_m"])
+def test_every_channel_of_a_large_bank_retuned_at_once(gpu, name):
+    """1 300 channels at a geometry with M - 1 > L, all retuned between two calls of one block (more than the patch records of
+    a call hold: the bank stages every channel afresh), half of them again before the next call (two transitions in the
+    window), calls of one block: a sample of the channels against the oracle."""
+    import kq_oracle as ko
+    from common import oracle_cfg
+    g = RETUNE_GEOMETRIES[name]
+    fs, L, M, D = g["samprate"], g["L"], g["M"], g["D"]
+    C = 1300
+    plan = [dict(demod="fm", low=-6000.0, high=6000.0, second_lo=-(wl.emitter_freq(20 + c % 10, fs) + 0.37 * (c // 10)))
+            for c in range(C)]
+    sample = [0, 1, 7, 511, 512, 1023, 1024, 1299]
+    ncalls = 8
+    iq = wl.make_iq(fs, ncalls * L, seed=5, emitters=range(20, 30))
+    chans = {c: ko.Channel(oracle_cfg(plan[c], fs, L, M, D)) for c in sample}
+    bank = kq.Bank(fs, L, M, D, C, 1, fwd_mode=kq.KQ_FWD_FULL, pl_tone=False)
+    bank.add_channels([bank_cfg(p) for p in plan])
+    for call in range(ncalls):
+        if call in (3, 4):
+            for c in range(C):
+                if call == 3 or c % 2 == 0:
+                    hz = plan[c]["second_lo"] + (55.5 if call == 3 else -31.25)
+                    bank.set_second_lo(c, hz)
+                    plan[c]["second_lo"] = hz
+                    if c in chans:
+                        chans[c].set_lo2(hz)
+        bank.push_iq(iq[call * L:(call + 1) * L])
+        assert bank.process() == 1
+        for c, ch in chans.items():
+            _, _, filt, _ = ch.block(iq[call * L:(call + 1) * L], want_filt=True)
+            if call >= 2:
+                e = rel_rms(bank.filter_output(c, 0), filt)
+                assert e < FILT_TOL, (call, c, e)
+    bank.close()
+
+
 def _pll_case(fs, nsamp, seed):
     """two emitters for carrier-tracking channels: a full-carrier AM signal at +20 037 Hz and a suppressed-carrier DSB one at
     -30 061 Hz"""

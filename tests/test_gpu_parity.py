@@ -1190,10 +1190,11 @@ def test_retunes_at_geometries_drawn_at_random(gpu, seed):
     bank.close()
 
 
-@pytest.mark.parametrize("seed", list(range(32)))
+@pytest.mark.parametrize("seed", list(range(48)))
 def test_an_operator_at_geometries_drawn_at_random(gpu, seed):
     """What the UI and the Doppler thread do to a running receiver (display.c:161-177, doppler.c, radio.c:290-374) -- second LO,
-    Doppler with and without a rate and off again, shift, filter edges and Kaiser beta, mode -- drawn at random between the
+    Doppler with and without a rate and off again, shift, filter edges and Kaiser beta, mode, channels leaving and joining --
+    drawn at random between the
     calls of a bank whose geometry is drawn as in test_geometries_drawn_at_random (impulse responses up to 0.6 of
     N/decimate), one to three blocks per call.  Every block's filter output from the third on, the sample counts and the FM
     channels' squelch counters against the oracle given the same operations."""
@@ -1232,7 +1233,29 @@ def test_an_operator_at_geometries_drawn_at_random(gpu, seed):
     for call in range(ncalls):
         for _ in range(int(rng.integers(0, 3)) if call >= 1 else 0):
             c = int(rng.integers(0, C))
-            op = ("lo", "doppler", "doppler_off", "shift", "filter", "mode")[int(rng.integers(0, 6))]
+            op = ("lo", "doppler", "doppler_off", "shift", "filter", "mode", "leave", "join")[int(rng.integers(0, 8))]
+            if op == "join":        # a channel joins on the master's live history (its oracle is primed with the M - 1 samples before)
+                holes = [h for h in range(C) if chans[h] is None]
+                if not holes or per * call * L < M - 1:
+                    continue
+                c = holes[0]
+                p = dict(modes[names[int(rng.integers(0, 4))]], second_lo=cur[c]["second_lo"] + float(rng.uniform(-20, 20)))
+                assert bank.add_channel(bank_cfg(p)) == c
+                chans[c] = ko.Channel(oracle_cfg(p, fs, L, M, D))
+                chans[c].prime_history(iq[per * call * L - (M - 1):per * call * L])
+                cur[c] = p
+                log.append((call, c, op))
+                continue
+            if chans[c] is None:
+                continue
+            if op == "leave":
+                if sum(ch is not None for ch in chans) <= 2:
+                    continue
+                bank.remove_channel(c)
+                chans[c].close()
+                chans[c] = None
+                log.append((call, c, op))
+                continue
             if op == "lo":
                 hz = cur[c]["second_lo"] + float(rng.uniform(-400, 400))
                 bank.set_second_lo(c, hz)
@@ -1265,6 +1288,9 @@ def test_an_operator_at_geometries_drawn_at_random(gpu, seed):
         bank.push_iq(iq[per * call * L:per * (call + 1) * L])
         assert bank.process() == per
         for c, ch in enumerate(chans):
+            if ch is None:
+                assert not bank.channel_active(c)
+                continue
             for b in range(per):
                 _, st, filt, _ = ch.block(iq[(per * call + b) * L:(per * call + b + 1) * L], want_filt=True)
                 where = "N = %d (L = %d, M = %d), decimate %d, %d per call; operations %s; call %d channel %d block %d" % (

@@ -814,6 +814,81 @@ def test_int16_ingest_and_zero_fill(gpu):
     bank.close()
 
 
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_lost_packets_at_geometries_drawn_at_random(gpu, seed):
+    """The zero fill of radio.c:81-100 (lost packets: the filter input gets zeros, the oscillators step on, IF power is not
+    updated for blocks that complete inside the fill) at drawn geometries and drawn gap lengths, from a fraction of a block to
+    two and a half, between pieces of int16 data of drawn lengths -- with an impulse response longer than a block the zeros
+    stay in the history for several blocks.  An AM and an FM channel: sample counts, IF power, audio."""
+    import kq_oracle as ko
+    from common import oracle_cfg
+    rng = np.random.default_rng(9700 + seed)
+    while True:
+        nd = int(rng.choice(_smooth_sizes(64, 1024)))
+        D = int(rng.choice([1, 2, 4, 5, 8, 16, 32]))
+        N = nd * D
+        if N <= (8192 if D == 1 else 16384) and N >= 512:
+            break
+    k = int(rng.integers(nd // 4, int(nd * 0.6) + 1))
+    M, L, fs = k * D + 1, (nd - k) * D, 48000 * D
+    plan = [dict(demod="am", low=-4500.0, high=4500.0, recovery_rate=50.0, second_lo=-(wl.emitter_freq(22, fs) + 0.5)),
+            dict(demod="fm", low=-7000.0, high=7000.0, second_lo=-(wl.emitter_freq(24, fs) - 2.0))]
+    total = 14 * L
+    x = wl.make_iq(fs, total, seed=3 + seed, emitters=range(20, 28))
+    xi = np.stack([np.round(x.real * 20000), np.round(x.imag * 20000)], axis=1).astype("<i2")
+    chans = [ko.Channel(oracle_cfg(p, fs, L, M, D, gain_factor=0.5)) for p in plan]
+    bank = kq.Bank(fs, L, M, D, len(plan), 24, gain_factor=0.5, fwd_mode=kq.KQ_FWD_AUTO)
+    for p in plan:
+        bank.add_channel(bank_cfg(p))
+    want = [[] for _ in plan]
+    got = [[] for _ in plan]
+    pos = 0
+    steps = []
+
+    def drain():
+        nb = bank.blocks_ready()
+        if nb:
+            assert bank.process() == nb
+            for c in range(len(plan)):
+                got[c] += [(bank.audio(c, b), bank.status(c, b)) for b in range(nb)]
+
+    while pos < total - 2 * L:
+        n = int(rng.integers(L // 5, 2 * L))
+        n = min(n, total - pos)
+        bank.push_iq(xi[pos:pos + n])
+        for c, ch in enumerate(chans):
+            want[c] += ch.push_raw(xi[pos:pos + n].tobytes(), n, 1)
+        pos += n
+        drain()
+        z = int(rng.integers(1, int(2.5 * L)))
+        bank.push_zeros(z)
+        for c, ch in enumerate(chans):
+            want[c] += ch.zero_fill(z)
+        drain()
+        steps.append((n, z))
+    where = "N = %d (L = %d, M = %d), decimate %d, (data, zeros) %s" % (N, L, M, D, steps)
+    for c in range(len(plan)):
+        assert len(got[c]) == len(want[c]), where
+        for b in range(len(want[c])):
+            wa, ws = want[c][b]
+            ga, st = got[c][b]
+            assert st["nout"] == ws["nout"], where
+            np.testing.assert_allclose(st["if_power"], ws["if_power"], rtol=2e-4, atol=1e-12, err_msg=where)
+            if b >= 2 and np.abs(wa).max() > 0 and np.all(np.isfinite(wa)):
+                if plan[c]["demod"] == "am":
+                    # (a block that is mostly fill has an output 1e-3 of the others': its own RMS is no yardstick for 1e-5 --
+                    #  block by block a loose bound that a wrong sample count or a misplaced zero would break by orders,
+                    #  the 1e-5 bar on the whole run below)
+                    assert rel_rms(ga, wa) < 1e-3, "%s: channel %d block %d: %.2e" % (where, c, b, rel_rms(ga, wa))
+                else:
+                    assert st["squelch_count"] == ws["squelch_count"], where
+        if plan[c]["demod"] == "am":
+            fin = [b for b in range(2, len(want[c])) if np.all(np.isfinite(want[c][b][0]))]
+            e = rel_rms(np.concatenate([got[c][b][0] for b in fin]), np.concatenate([want[c][b][0] for b in fin]))
+            assert e < AUDIO_TOL, "%s: channel %d: %.2e" % (where, c, e)
+    bank.close()
+
+
 @pytest.mark.parametrize("name,nchan,nblocks", [("cfg3", 40, 5), ("cfg4", 33, 4), ("cfg2", 37, 3)])
 def test_config_geometry_pruned(gpu, name, nchan, nblocks):
     """Pruned forward path (only the N/D bins the slave reads) against the oracle's full N-point FFT."""

@@ -1137,6 +1137,58 @@ def test_pcm_rtp_datagrams(gpu):
     bank.close()
 
 
+@pytest.mark.parametrize("seed", list(range(20)))
+def test_pcm_and_rtp_output_at_geometries_drawn_at_random(gpu, seed):
+    """The output stage (audio.c:22-132) where a block is not 512 samples: drawn N/decimate (16 ... 3000 samples per block,
+    odd counts among them -- 343, 675 ...), so that a block is a fraction of a 480-word packet, or several and a rest, mono and
+    stereo; PCM words and silence masks bit for bit against the oracle on the same device audio, the datagrams byte for byte
+    (sequence numbers, timestamps advancing over skipped packets, the marker on resume), over calls of three blocks."""
+    import kq_oracle as ko
+    rng = np.random.default_rng(9800 + seed)
+    while True:
+        nd = int(rng.choice(_smooth_sizes(32, 4096)))
+        D = int(rng.choice([1, 2, 4, 5, 8, 16]))
+        N = nd * D
+        if N <= (8192 if D == 1 else 16384) and N >= 256:
+            break
+    k = int(rng.integers(nd // 4, nd // 2 + 1))
+    M, L, fs = k * D + 1, (nd - k) * D, 48000 * D
+    per, ncalls = 3, 4
+    nb = per * ncalls
+    t = np.arange(nb * L) / fs
+    f0 = 0.21 * fs
+    sig = 0.2 * np.exp(1j * (2 * np.pi * f0 * t + 3.0 * np.sin(2 * np.pi * 1000.0 * t)))
+    sig[4 * L:7 * L] = 0                                    # the carrier drops for three blocks, then comes back
+    iq = (sig + 1e-4 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    plan = [dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-f0, headroom=float(rng.choice([0.1778, 30.0]))),
+            dict(demod="linear", low=-5000.0, high=5000.0, second_lo=-f0, hangtime=1.1, recovery_rate=6.0, channels=2)]
+    bank = kq.Bank(fs, L, M, D, len(plan), per, fwd_mode=kq.KQ_FWD_AUTO)
+    bank.enable_pcm(True)
+    ssrc = [0xCAFE0001, 0x7FFFFFF2]
+    ora = []
+    for c, p in enumerate(plan):
+        bank.add_channel(bank_cfg(p))
+        bank.set_output_ssrc(c, ssrc[c])
+        ora.append(ko.OutRtp(ssrc=ssrc[c]))
+    where = "N = %d (L = %d, M = %d), decimate %d: %d samples per block" % (N, L, M, D, L // D)
+    for call in range(ncalls):
+        bank.push_iq(iq[call * per * L:(call + 1) * per * L])
+        assert bank.process() == per
+        for c in range(len(plan)):
+            for b in range(per):
+                a = bank.audio(c, b)
+                got, gmask = bank.pcm(c, b)
+                want, wmask, nch = ko.pcm_block(a)
+                assert np.array_equal(got, want) and gmask == wmask and nch == (len(a) + 479) // 480, (where, call, c, b)
+                assert bank.rtp_audio(c, b) == ora[c].packetize(a, stereo=(c == 1)), (where, call, c, b)
+    for c in range(len(plan)):
+        st = bank.output_rtp_state(c)
+        assert (st["seq"], st["timestamp"], st["silent"], st["packets"], st["bytes"]) == \
+               (ora[c].seq, ora[c].timestamp, ora[c].silent, ora[c].packets, ora[c].bytes), where
+        assert st["timestamp"] == nb * (L // D), where
+    bank.close()
+
+
 # the generic kernels (k_filter_full steps a float oscillator through a window that has ONE unswept oscillator and evaluates per
 # sample in double otherwise: both in this test; k_filter_split beyond one LDS block) at sizes of their own
 RETUNE_GEOMETRIES = {"n8192": dict(samprate=192000, L=3840, M=4353, D=4),        # the reference's default -L / -M (main.c:160-170)

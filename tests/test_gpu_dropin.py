@@ -92,11 +92,18 @@ FM = dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-20000.0)
 USB = dict(demod="linear", low=100.0, high=3000.0, second_lo=-20000.0, hangtime=1.1, recovery_rate=6.0)
 
 
-def test_library_demod_am_thread(harness):
-    iq = _signal("am", 1)
-    recs, _ = _run(harness, "am", iq, AM["low"], AM["high"], ["--recovery", "50"])
-    auds, sts, _ = _oracle(AM, iq)
-    assert all(len(a) == L // D for a, _ in recs)
+# the thread entry points at the reference's own default -L 3840 -M 4353 (main.c:160-170: a history longer than a block) and at a
+# 240 kHz front end (N = 9600, decimate 5) beside the power-of-two geometry of the rest of this file
+GEOMS = [None, (192000, 3840, 4353, 4), (240000, 4800, 4801, 5)]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_library_demod_am_thread(harness, geom):
+    iq = _signal("am", 1, geom)
+    recs, _ = _run(harness, "am", iq, AM["low"], AM["high"], ["--recovery", "50"], geom=geom)
+    auds, sts, _ = _oracle(AM, iq, geom)
+    l_, d_ = (geom or (FS, L, M, D))[1], (geom or (FS, L, M, D))[3]
+    assert all(len(a) == l_ // d_ for a, _ in recs)
     assert rel_rms(np.concatenate([a for a, _ in recs]), np.concatenate(auds)) < 1e-5
     for b in range(NB):
         assert abs(recs[b][1]["n0"] / sts[b]["n0"] - 1) < 2e-4               # am.c:46-49 runs before the hand-off
@@ -121,10 +128,11 @@ def test_reference_am_c_runs_on_the_library(harness):
         assert abs(ref[b][1]["noise_gain"] / mine[b][1]["noise_gain"] - 1) < 1e-6   # set_filter under both threads
 
 
-def test_library_demod_fm_thread(harness):
-    iq = _signal("fm", 3)
-    recs, _ = _run(harness, "fm", iq, FM["low"], FM["high"])
-    auds, sts, _ = _oracle(FM, iq)
+@pytest.mark.parametrize("geom", GEOMS)
+def test_library_demod_fm_thread(harness, geom):
+    iq = _signal("fm", 3, geom)
+    recs, _ = _run(harness, "fm", iq, FM["low"], FM["high"], geom=geom)
+    auds, sts, _ = _oracle(FM, iq, geom)
     assert rel_rms(np.concatenate([a for a, _ in recs]), np.concatenate(auds)) < 1e-5
     for b in range(1, NB):
         assert abs(recs[b][1]["pdeviation"] - sts[b]["pdeviation"]) < 1e-4 * 3000
@@ -133,13 +141,15 @@ def test_library_demod_fm_thread(harness):
     assert abs(recs[-1][1]["pdeviation"] - 3000) < 150
 
 
-@pytest.mark.parametrize("stereo", [False, True])
-def test_library_demod_linear_thread(harness, stereo):
-    iq = _signal("usb", 4)
+@pytest.mark.parametrize("stereo,geom", [(False, None), (True, None), (False, GEOMS[1]), (True, GEOMS[2])])
+def test_library_demod_linear_thread(harness, stereo, geom):
+    iq = _signal("usb", 4, geom)
     p = dict(USB, channels=2 if stereo else 1)
-    recs, _ = _run(harness, "linear", iq, p["low"], p["high"], ["--hang", "1.1", "--recovery", "6"] + (["--stereo"] if stereo else []))
-    auds, sts, _ = _oracle(p, iq)
-    assert all(len(a) == (2 if stereo else 1) * L // D for a, _ in recs)
+    recs, _ = _run(harness, "linear", iq, p["low"], p["high"], ["--hang", "1.1", "--recovery", "6"] + (["--stereo"] if stereo else []),
+                   geom=geom)
+    auds, sts, _ = _oracle(p, iq, geom)
+    l_, d_ = (geom or (FS, L, M, D))[1], (geom or (FS, L, M, D))[3]
+    assert all(len(a) == (2 if stereo else 1) * l_ // d_ for a, _ in recs)
     # the first block is the AGC start-up on numerically-zero samples (linear.c:271-272): compared from block 1 on
     assert rel_rms(np.concatenate([a for a, _ in recs[1:]]), np.concatenate(auds[1:])) < 1e-5
     for b in range(1, NB):

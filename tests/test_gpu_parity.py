@@ -1317,7 +1317,7 @@ def test_retunes_at_geometries_drawn_at_random(gpu, seed):
     bank.close()
 
 
-@pytest.mark.parametrize("seed", list(range(48)))
+@pytest.mark.parametrize("seed", list(range(48)) + [1000 + k for k in range(16)] + [2000 + k for k in range(8)])
 def test_an_operator_at_geometries_drawn_at_random(gpu, seed):
     """What the UI and the Doppler thread do to a running receiver (display.c:161-177, doppler.c, radio.c:290-374) -- second LO,
     Doppler with and without a rate and off again, shift, filter edges and Kaiser beta, mode, channels leaving and joining --
@@ -1329,10 +1329,17 @@ def test_an_operator_at_geometries_drawn_at_random(gpu, seed):
     from common import oracle_cfg
     rng = np.random.default_rng(9900 + seed)
     while True:
-        nd = int(rng.choice(_smooth_sizes(64, 2048)))
-        D = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 16, 32, 64]))
+        if seed >= 2000:        # ... the 65536-point kernels (four sibling workgroups per channel-block; pruned-stream at N/D = 128)
+            D = int(rng.choice([32, 64, 128, 256, 512]))
+            nd = 65536 // D
+        elif seed >= 1000:      # ... the 16384-point register kernel at splits of L and M nobody chose (and the pruned ones)
+            D = int(rng.choice([4, 8, 16, 32, 64, 128, 256]))
+            nd = 16384 // D
+        else:
+            nd = int(rng.choice(_smooth_sizes(64, 2048)))
+            D = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 16, 32, 64]))
         N = nd * D
-        if N <= (8192 if D == 1 else 16384) and N >= 512:
+        if N <= (8192 if D == 1 else 16384 if seed < 1000 else 65536) and N >= 512:
             break
     k = int(rng.integers(nd // 4, int(nd * 0.6) + 1))
     M, L, fs = k * D + 1, (nd - k) * D, 48000 * D
@@ -1353,7 +1360,7 @@ def test_an_operator_at_geometries_drawn_at_random(gpu, seed):
     ncalls = 14 // per + 1
     iq = wl.make_iq(fs, ncalls * per * L, seed=41 + seed, emitters=range(20, 32))
     chans = [ko.Channel(oracle_cfg(p, fs, L, M, D)) for p in cur]
-    bank = kq.Bank(fs, L, M, D, C, per, fwd_mode=kq.KQ_FWD_AUTO)
+    bank = kq.Bank(fs, L, M, D, C, per, compute_n0=bool(seed % 2), fwd_mode=kq.KQ_FWD_AUTO)
     for p in cur:
         bank.add_channel(bank_cfg(p))
     log = []

@@ -1608,6 +1608,53 @@ def test_carrier_tracking_channels_come_and_go_while_the_bank_runs(gpu):
     assert len(a[-1]) >= 148
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_carrier_tracking_at_geometries_drawn_at_random(gpu, seed):
+    """The carrier loop (linear.c:129-246) where a block is not 2048 samples: N/decimate drawn from 512 ... 4096 (7-smooth
+    sizes among them), decimate 1 ... 32, four and a half seconds of signal in as many blocks as that takes, calls of a drawn length.
+    CAM and DSB (squaring loop) in turn: lock state, lock counter and hang counter block for block, offset and phase, audio
+    once locked."""
+    rng = np.random.default_rng(9600 + seed)
+    while True:
+        nd = int(rng.choice(_smooth_sizes(512, 4096)))
+        D = int(rng.choice([1, 2, 4, 5, 8, 16, 32]))
+        N = nd * D
+        if N <= (8192 if D == 1 else 16384) and N >= 2048:
+            break
+    k = int(rng.integers(nd // 4, nd // 2 + 1))
+    M, L, fs = k * D + 1, (nd - k) * D, 48000 * D
+    g = dict(samprate=fs, L=L, M=M, D=D)
+    nblocks = int(np.ceil(4.5 * fs / L))
+    t = np.arange(nblocks * L) / fs
+    msg = np.cos(2 * np.pi * 1000.0 * t)
+    fc = 0.1 * fs
+    if seed % 2 == 0:
+        sig = 0.1 * (1 + 0.5 * msg) * np.exp(2j * np.pi * (fc + 37.0) * t)
+        p = dict(demod="linear", low=-5000.0, high=5000.0, second_lo=-fc, hangtime=0.0, recovery_rate=50.0, pll=1)
+    else:
+        sig = 0.1 * msg * np.exp(2j * np.pi * (fc - 61.0) * t + 0.7j)
+        p = dict(demod="linear", low=-5000.0, high=5000.0, second_lo=-fc, hangtime=1.1, recovery_rate=6.0, pll=1, square=1)
+    iq = (sig + 1e-3 * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    plan = [p, dict(p, channels=2)]
+    want = run_oracle(plan, g, iq, nblocks)
+    got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_AUTO, per_call=int(rng.integers(3, 40)))
+    where = "N = %d (L = %d, M = %d), decimate %d, %d blocks" % (N, L, M, D, nblocks)
+    for c in range(len(plan)):
+        auds, sts, _ = want[c]
+        for b in range(nblocks):
+            sg, sw = got[c]["status"][b], sts[b]
+            assert (sg["pll_lock"], sg["lock_count"], sg["nout"], sg["hangcount"]) == \
+                   (sw["pll_lock"], sw["lock_count"], sw["nout"], sw["hangcount"]), (where, c, b)
+            np.testing.assert_allclose(sg["foffset"], sw["foffset"], rtol=1e-3, atol=1e-3, err_msg=where)
+            np.testing.assert_allclose(sg["cphase"], sw["cphase"], atol=2e-4, err_msg=where)
+        locked = [b for b in range(nblocks) if sts[b]["pll_lock"]]
+        assert locked, where                     # (the lock detector's count runs in blocks: short blocks take longer)
+        first = min(max(locked[0] + 2, nblocks // 3), nblocks - 1)
+        a_g = np.concatenate(got[c]["audio"][first:])
+        a_w = np.concatenate(auds[first:])
+        assert rel_rms(a_g, a_w) < 2e-5, (where, c, rel_rms(a_g, a_w))
+
+
 @pytest.mark.parametrize("mode", ["cam", "dsb"])
 def test_linear_carrier_pll(gpu, mode):
     """linear.c:129-246: carrier search (65536-point transform, +-300 Hz window), coarse + fine NCO, 2nd-order loop,

@@ -1056,6 +1056,38 @@ def test_pl_tone_measurement_cfg2_geometry(gpu):
         assert sum(1 for a, b in zip(tones[:-1], tones[1:]) if not (a == b or (np.isnan(a) and np.isnan(b)))) >= 1
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_pl_tone_at_geometries_drawn_at_random(gpu, seed):
+    """pltask (fm.c:189-285) where 32 divides N/decimate and the block length but nothing else is chosen: PL slaves of 8 ... 64
+    points (60, 42 and 28 among them), 1 ... 30 PL samples per block, 0.8 s of a 100 Hz tone under the voice -- two ring transforms;
+    the tone, and with it the peak bin, equal to the oracle's in every block; everything else as in the sweep."""
+    rng = np.random.default_rng(9650 + seed)
+    while True:
+        nd = int(rng.choice([n for n in _smooth_sizes(256, 2048) if n % 64 == 0]))      # (an even PL slave: N/decimate / 32)
+        D = int(rng.choice([2, 4, 5, 8, 16, 32]))
+        if nd * D <= 16384:
+            break
+    k = 32 * int(rng.integers(max(1, nd // 128), nd // 64 + 1))
+    N, M, L, fs = nd * D, k * D + 1, (nd - k) * D, 48000 * D
+    g = dict(samprate=fs, L=L, M=M, D=D)
+    nblocks = int(np.ceil(0.8 * fs / L))
+    t = np.arange(nblocks * L) / fs
+    fc = 0.1 * fs
+    ph = 2 * np.pi * fc * t + 3.0 * np.sin(2 * np.pi * 1000.0 * t) + 6.0 * np.sin(2 * np.pi * 100.0 * t)
+    sigma = 0.1 * 10 ** (-30 / 20) / np.sqrt(2 * 16000.0 / fs)
+    iq = (0.1 * np.exp(1j * ph) + sigma / np.sqrt(2) * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    plan = [dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-fc),
+            dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-fc, flat=1)]
+    want = run_oracle(plan, g, iq, nblocks)
+    got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_AUTO, per_call=int(rng.integers(3, 30)))
+    try:
+        _compare(plan, got, want)
+    except AssertionError as e:
+        raise AssertionError("N = %d (L = %d, M = %d), decimate %d, %d blocks: %s" % (N, L, M, D, nblocks, e)) from e
+    tones = [s_["plfreq"] for s_ in got[0]["status"]]
+    assert np.isnan(tones[0]) and abs(tones[-1] - 100.0) < 0.5, (N, L, M, D, tones[0], tones[-1])
+
+
 def test_pcm_output_stage(gpu):
     """scaleclip + network byte order + per-480-word silence flags (audio.c:22-28, 45-50, 95-100),
     bit exact against the oracle applied to the same device audio; includes clipping and an all-zero (squelched) block."""

@@ -392,6 +392,35 @@ def test_geometries_drawn_at_random(gpu, seed):
         raise AssertionError("geometry N = %d (L = %d, M = %d), decimate %d, %d Hz: %s" % (N, L, M, D, fs, e)) from e
 
 
+@pytest.mark.parametrize("nd,D,k", [(4, 4, 2), (4, 8, 1), (6, 4, 3), (8, 2, 4), (8, 16, 3), (10, 5, 4), (12, 4, 6), (14, 8, 6), (16, 1, 8),
+                                    (16, 4, 9), (20, 3, 8), (24, 2, 11), (32, 1, 16), (32, 64, 16), (36, 7, 17), (48, 5, 20)])
+def test_the_smallest_geometries(gpu, nd, D, k):
+    """The small end of what kq_bank_create takes (N >= 16, N/decimate >= 4): slaves of 4 ... 48 points, two to 28 samples per
+    block, workgroups with more threads than points -- FM / AM / USB / ISB against the oracle as in the sweep."""
+    N, M, L, fs = nd * D, k * D + 1, (nd - k) * D, 48000 * D
+    if N < 16:
+        pytest.skip("N < 16")
+    g = dict(samprate=fs, L=L, M=M, D=D)
+    plan, iq, nblocks = _sweep_case(N, L, M, D, fs)
+    nblocks = 40
+    plan, iq, _ = _sweep_case(N, L, M, D, fs)
+    rng = np.random.default_rng(nd * 100 + D)
+    t = np.arange(nblocks * L) / fs
+    ds, f0 = fs / D, 0.11 * fs
+    bw = min(8000.0, 0.2 * ds)
+    sig = 0.3 * np.exp(1j * (2 * np.pi * f0 * t + 4.0 * np.sin(2 * np.pi * 500.0 * t)))
+    sig += 0.1 * np.exp(2j * np.pi * (f0 + 0.37 * ds) * t) * (1 + 0.5 * np.sin(2 * np.pi * 300.0 * t))
+    sig += 0.05 * np.exp(2j * np.pi * (f0 - 0.21 * ds + 0.2 * bw) * t)
+    sigma = 0.3 * 10 ** (-30 / 20) / np.sqrt(4 * bw / fs)          # 30 dB in the FM channel, as in the sweep
+    iq = (sig + sigma * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    want = run_oracle(plan, g, iq, nblocks, compute_n0=1)
+    got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_AUTO, compute_n0=True, per_call=7)
+    try:
+        _compare(plan, got, want, check_n0=True, geom=g)
+    except AssertionError as e:
+        raise AssertionError("geometry N = %d (L = %d, M = %d), decimate %d: %s" % (N, L, M, D, e)) from e
+
+
 def test_filter_and_shift_changed_while_running(gpu):
     """What the UI does between blocks (display.c:161-177, radio.c:304-311): new filter edges / Kaiser beta and a new
     post-detection shift; the response is swapped at the next block (filter.c:538-543), the shift oscillator keeps

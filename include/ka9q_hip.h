@@ -66,7 +66,9 @@ typedef struct kq_bank kq_bank;   /* opaque */
  *     one device can starve each other's workgroups until the waits run out;
  *   - carrier-tracking channels (kq_channel_config.pll, linear.c:129-246): as many as the bank has channels, up to 65536;
  *     each keeps a 65536-sample search ring (544 KiB with its state), allocated 64 channels at a time as the count grows;
- *   - the PL-tone measurement needs 32 to divide N / decimate and L / decimate (fm.c:201-205 decimates by 32);
+ *   - the PL-tone measurement (fm.c:201-205 decimates by 32) runs where N / decimate / 32 is at least 4 and a size this
+ *     library has a transform for -- even, no prime factor beyond 7; where 32 does not divide the sizes they are truncated as
+ *     create_filter_output truncates them (filter.c:103-107,116), the tone reading that much off, as in the reference;
  *   - FM channels need N / decimate <= 8192 (the post-detection filter lives in one CU's LDS).
  * Nothing limits max_channels but memory (~3 KiB per channel + the planes): banks of 34560 channels run in the bench. */
 typedef struct kq_bank_config {

@@ -1727,9 +1727,10 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   {
     // pltask geometry (fm.c:201-205): decimate 32 from the audio master; needs a usable transform size
     int const pn = g.Ndec / 32, plen = g.olen / 32;
-    // (a size that 32 does not divide has no PL slave: create_filter_output would warn and truncate, filter.c:106-107)
-    bool const ok = pn >= 4 && plen >= 1 && !cfg->pl_tone_off &&
-                    ((pn & (pn - 1)) == 0 || (g.Ndec % 32 == 0 && g.olen % 32 == 0 && kq::fft_size_ok(pn)));
+    // (where 32 does not divide N/decimate or the block, create_filter_output warns and truncates both, filter.c:103-107,116:
+    //  the slave then resamples by N_dec / PL_N instead of 32 and the tone reads that much off -- what the reference does, and
+    //  what happens here; only a PL_N this library has no transform for -- odd, or with a prime factor beyond 7 -- has no PL slave)
+    bool const ok = pn >= 4 && plen >= 1 && !cfg->pl_tone_off && ((pn & (pn - 1)) == 0 || kq::fft_size_ok(pn));
     g.pl_n = ok ? pn : 0;
     g.pl_l = ok ? plen : 0;
   }

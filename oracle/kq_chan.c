@@ -164,12 +164,14 @@ static int demod_start(kqo_chan *c){
     }
     {
       /* pltask set-up, fm.c:196-229.  PL_N = AN/32 must leave a usable transform (the reference runs it
-       * regardless; below 4 points it is meaningless and the oracle leaves plfreq NaN). */
+       * regardless; below 4 points it is meaningless and the oracle leaves plfreq NaN).  Where 32 does not divide AN or AL,
+       * create_filter_output warns and truncates (filter.c:103-107,116) and so does kqo_create_filter_output; a PL_N this
+       * oracle's FFT has no plan for (odd, or a prime factor beyond 7) leaves plfreq NaN. */
       int const PL_decimate = 32;
       int const PL_N = AN / PL_decimate, PL_L = AL / PL_decimate, PL_M = PL_N - PL_L + 1;
       c->plfreq = NAN;
       c->pl_fft_ptr = c->pl_last_fft = 0;
-      if(PL_N >= 4 && PL_L >= 1 && ((PL_N & (PL_N - 1)) == 0 || (AN % PL_decimate == 0 && AL % PL_decimate == 0))){
+      if(PL_N >= 4 && PL_L >= 1 && ((PL_N & (PL_N - 1)) == 0 || kqo_fft_size_ok((unsigned)PL_N))){
         c->pl_samprate = c->dsamprate / PL_decimate;
         float complex *plr = calloc(PL_N / 2 + 1, sizeof(float complex));
         for(int j = 0; j <= PL_N / 2; j++){

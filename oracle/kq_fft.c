@@ -39,6 +39,12 @@ static int factorise(unsigned n, unsigned *fac, unsigned *nf){
   return n == 1;
 }
 
+/* an even n = 2^a 3^b 5^c 7^d: the sizes the real transforms below are used at */
+int kqo_fft_size_ok(unsigned n){
+  unsigned fac[32], nf;
+  return n >= 2 && (n & 1) == 0 && factorise(n, fac, &nf);
+}
+
 kqo_fft *kqo_fft_create(unsigned n){
   if(n == 0)
     return NULL;

@@ -35,6 +35,7 @@
 /* ---------- FFT (stands in for FFTW3f; kq_fft.c) ---------- */
 typedef struct kqo_fft kqo_fft;
 kqo_fft *kqo_fft_create(unsigned n);           /* n = 2^a 3^b 5^c 7^d >= 1 (NULL otherwise) */
+int kqo_fft_size_ok(unsigned n);               /* even and of that form */
 void kqo_fft_destroy(kqo_fft *p);
 /* 1: kqo_fft_c2c (and r2c / c2r through it) use the radix-4 autosort variant -- CPU-baseline timing only
  * (tests/test_oracle_filter.py::test_fast_transform_equals_the_plain_one).  A plan carries its own scratch buffers, which

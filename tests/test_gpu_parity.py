@@ -1117,6 +1117,35 @@ def test_pl_tone_at_geometries_drawn_at_random(gpu, seed):
     assert np.isnan(tones[0]) and abs(tones[-1] - 100.0) < 0.5, (N, L, M, D, tones[0], tones[-1])
 
 
+@pytest.mark.parametrize("nd,D,k", [(400, 4, 160), (900, 2, 400), (270, 8, 110), (1350, 4, 600), (2000, 2, 900)])
+def test_pl_tone_where_32_does_not_divide_the_sizes(gpu, nd, D, k):
+    """fm.c:201-205 with N/decimate or the block length no multiple of 32: create_filter_output warns and truncates
+    (filter.c:103-107,116), the PL slave then resamples by N_dec / PL_N instead of 32 and the reference reads the tone that much
+    off (100 Hz as 104.2 at N/decimate = 400).  The library does what the reference does: tone and peak bin equal to the
+    oracle's -- whose create_filter_output truncates the same way -- in every block."""
+    N, M, L, fs = nd * D, k * D + 1, (nd - k) * D, 48000 * D
+    g = dict(samprate=fs, L=L, M=M, D=D)
+    pn = nd // 32
+    assert nd % 32 != 0
+    nblocks = int(np.ceil(0.9 * fs / L))
+    t = np.arange(nblocks * L) / fs
+    fc = 0.1 * fs
+    rng = np.random.default_rng(nd)
+    ph = 2 * np.pi * fc * t + 3.0 * np.sin(2 * np.pi * 1000.0 * t) + 6.0 * np.sin(2 * np.pi * 100.0 * t)
+    sigma = 0.1 * 10 ** (-30 / 20) / np.sqrt(2 * 16000.0 / fs)
+    iq = (0.1 * np.exp(1j * ph) + sigma / np.sqrt(2) * (rng.standard_normal(len(t)) + 1j * rng.standard_normal(len(t)))).astype(np.complex64)
+    plan = [dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-fc),
+            dict(demod="fm", low=-8000.0, high=8000.0, second_lo=-fc, flat=1)]
+    want = run_oracle(plan, g, iq, nblocks)
+    got, _ = _run_bank(plan, g, iq, nblocks, kq.KQ_FWD_AUTO, per_call=11)
+    _compare(plan, got, want)
+    tone = got[0]["status"][-1]["plfreq"]
+    if pn == 62:            # (2 x 31: no transform of that size here or in the oracle -- FFTW would plan it -- and no PL slave)
+        assert np.isnan(tone)
+    else:                   # (off by the resampling error and by the samples dropped at every block border: a few per cent)
+        assert abs(tone - 100.0) < 8.0, tone
+
+
 def test_pcm_output_stage(gpu):
     """scaleclip + network byte order + per-480-word silence flags (audio.c:22-28, 45-50, 95-100),
     bit exact against the oracle applied to the same device audio; includes clipping and an all-zero (squelched) block."""

@@ -3,6 +3,8 @@
 Bars (north_star): float outputs within 1e-5 RMS relative to the oracle's signal RMS; sample counts,
 block sequence and decision state (squelch counter, hang counter, blanked-sample count) bit exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -353,6 +355,11 @@ def test_geometry_sweep(gpu, N, L, M, D, fs, mode, n0):
     _compare(plan, got, want, check_n0=n0, geom=g)
 
 
+# KQ_FUZZ_EXTRA=n in the environment: n more seeds for each of the drawn families below (a longer hunt by hand:
+#   KQ_FUZZ_EXTRA=200 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "drawn_at_random")
+_EXTRA = [100000 + k for k in range(int(os.environ.get("KQ_FUZZ_EXTRA", "0")))]
+
+
 def _smooth_sizes(lo, hi):
     out = []
     for n in range(lo, hi + 1, 2):
@@ -365,7 +372,7 @@ def _smooth_sizes(lo, hi):
     return out
 
 
-@pytest.mark.parametrize("seed", list(range(48)))
+@pytest.mark.parametrize("seed", list(range(48)) + _EXTRA)
 def test_geometries_drawn_at_random(gpu, seed):
     """The sweep above is a list somebody chose.  Here the geometry is drawn: N/decimate any even 2^a 3^b 5^c 7^d in 64..2048,
     decimate from 1 to 64 (the front end at decimate x 48 kHz, radio_status.c:266), the impulse response between a quarter and
@@ -843,7 +850,7 @@ def test_int16_ingest_and_zero_fill(gpu):
     bank.close()
 
 
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(24)) + _EXTRA)
 def test_lost_packets_at_geometries_drawn_at_random(gpu, seed):
     """The zero fill of radio.c:81-100 (lost packets: the filter input gets zeros, the oscillators step on, IF power is not
     updated for blocks that complete inside the fill) at drawn geometries and drawn gap lengths, from a fraction of a block to
@@ -1227,7 +1234,7 @@ def test_pcm_rtp_datagrams(gpu):
     bank.close()
 
 
-@pytest.mark.parametrize("seed", list(range(20)))
+@pytest.mark.parametrize("seed", list(range(20)) + _EXTRA)
 def test_pcm_and_rtp_output_at_geometries_drawn_at_random(gpu, seed):
     """The output stage (audio.c:22-132) where a block is not 512 samples: drawn N/decimate (16 ... 3000 samples per block,
     odd counts among them -- 343, 675 ...), so that a block is a fraction of a 480-word packet, or several and a rest, mono and
@@ -1353,7 +1360,7 @@ def test_retune_mid_stream_is_sample_exact(gpu, name, mode, per):
     bank.close()
 
 
-@pytest.mark.parametrize("seed", list(range(48)))
+@pytest.mark.parametrize("seed", list(range(48)) + _EXTRA)
 def test_retunes_at_geometries_drawn_at_random(gpu, seed):
     """The retune rule at geometries nobody chose: N/decimate, decimate and the impulse response drawn as in
     test_geometries_drawn_at_random but up to 0.7 of N/decimate (M - 1 up to 2.3 L: old samples in up to three blocks), one
@@ -1407,7 +1414,7 @@ def test_retunes_at_geometries_drawn_at_random(gpu, seed):
     bank.close()
 
 
-@pytest.mark.parametrize("seed", list(range(48)) + [1000 + k for k in range(16)] + [2000 + k for k in range(8)])
+@pytest.mark.parametrize("seed", list(range(48)) + [1000 + k for k in range(16)] + [2000 + k for k in range(8)] + _EXTRA)
 def test_an_operator_at_geometries_drawn_at_random(gpu, seed):
     """What the UI and the Doppler thread do to a running receiver (display.c:161-177, doppler.c, radio.c:290-374) -- second LO,
     Doppler with and without a rate and off again, shift, filter edges and Kaiser beta, mode, channels leaving and joining --
@@ -1419,17 +1426,17 @@ def test_an_operator_at_geometries_drawn_at_random(gpu, seed):
     from common import oracle_cfg
     rng = np.random.default_rng(9900 + seed)
     while True:
-        if seed >= 2000:        # ... the 65536-point kernels (four sibling workgroups per channel-block; pruned-stream at N/D = 128)
+        if 2000 <= seed < 3000:  # ... the 65536-point kernels (four sibling workgroups per channel-block; pruned-stream at N/D = 128)
             D = int(rng.choice([32, 64, 128, 256, 512]))
             nd = 65536 // D
-        elif seed >= 1000:      # ... the 16384-point register kernel at splits of L and M nobody chose (and the pruned ones)
+        elif 1000 <= seed < 2000:  # ... the 16384-point register kernel at splits of L and M nobody chose (and the pruned ones)
             D = int(rng.choice([4, 8, 16, 32, 64, 128, 256]))
             nd = 16384 // D
         else:
             nd = int(rng.choice(_smooth_sizes(64, 2048)))
             D = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 10, 16, 32, 64]))
         N = nd * D
-        if N <= (8192 if D == 1 else 16384 if seed < 1000 else 65536) and N >= 512:
+        if N <= (8192 if D == 1 else 65536 if 1000 <= seed < 3000 else 16384) and N >= 512:
             break
     k = int(rng.integers(nd // 4, int(nd * 0.6) + 1))
     M, L, fs = k * D + 1, (nd - k) * D, 48000 * D

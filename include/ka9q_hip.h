@@ -225,9 +225,9 @@ int kq_bank_set_linear_options(kq_bank *bank, int ch, int isb, int channels);
 /* Second LO and Doppler: the new setting mixes the samples pushed from now on; the M - 1 samples before them, the history of
  * the windows to come, keep what they were mixed with (radio.c:132-139 mixes sample by sample).  That holds for every block
  * the old samples reach into -- one where M - 1 <= L, two with the reference's default -L 3840 -M 4353, across calls if the
- * calls are short.  Two transitions per window: a channel may be set again while old samples of its previous setting are
- * still inside its history (M - 1 > L and a retune before every block); a THIRD setting inside the same M - 1 samples
- * (only possible where M - 1 > 2 L) treats the oldest samples as mixed with the middle oscillator. */
+ * calls are short.  A channel may be set again while old samples of its previous settings are still inside its history
+ * (M - 1 > L and a retune before every block): up to five transitions per window are kept apart; a sixth inside the same
+ * M - 1 samples (only possible where M - 1 > 5 L) treats the oldest samples as mixed with the oscillator after theirs. */
 int kq_bank_set_second_lo(kq_bank *bank, int ch, double hz);                 /* radio.c:290 set_second_LO */
 int kq_bank_set_doppler(kq_bank *bank, int ch, double hz, double hz_per_s);  /* radio.c:180 set_doppler */
 int kq_bank_set_shift(kq_bank *bank, int ch, double hz);                     /* radio.c:304 set_shift */

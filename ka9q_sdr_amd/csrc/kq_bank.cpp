@@ -113,14 +113,19 @@ struct HostChan {
   // oscillators as they were before a retune that has not reached the kernels yet: the M-1 history samples of
   // the next block were mixed with these (radio.c:132-139)
   Osc lo2_old, dop_old;    // the oscillators before the last retune (the history planes) ...
-  Osc lo2_old2, dop_old2;  // ... and the ones before the retune before that, while samples of theirs are still in the history
+  // ... and the ones before the retunes before that, while samples of theirs are still in the history: [0] the transition
+  // before the last, [l + 1] the one before [l]
+  Osc lo2_oldx[kq::kOldLevels], dop_oldx[kq::kOldLevels];
   bool retuned = false;
   // ... and how many samples from the start of the NEXT call's first window still carry the old oscillators (ChanDev::hist_len):
   // M - 1 when the retune happens; a call of n blocks takes n L off it; the channel stays `retuned` while any are left
   int64_t hist_old = 0;
-  int64_t hist_old2 = 0;  // the same for lo2_old2 / dop_old2 (the older transition: fewer samples; 0 = there is none)
+  int64_t hist_oldx[kq::kOldLevels] = {};  // the same for lo2_oldx / dop_oldx (older: fewer samples; 0 ends the list)
   int hist_dev = -1;   // what hist_len[c] on the device was last told
-  int hist2_dev = 0;   // ... and hist2_len[c]
+  // ... and hist2_len[kOldLevels c + l]; -1 = never (the words of a slot taken over from a removed channel are whatever that
+  // one left: the first retune writes every level)
+  int histx_dev[kq::kOldLevels] = {-1, -1, -1, -1};
+  static_assert(kq::kOldLevels == 4, "histx_dev's initialiser");
   bool active = true;  // false: a hole left by kq_bank_remove_channel, reused by the next kq_bank_add_channel
   kq_out_rtp_state out_rtp{};  // demod->output.rtp + output.silent (audio.c:32-132)
   int out_type;
@@ -975,13 +980,13 @@ void eval_planes(const kq_bank *b, const HostChan &h, int64_t n_w, double out[8]
   }
 }
 
-// the older of two transitions inside the history (note_retune): its oscillators at the window start, as the history planes
-void eval_old2(const HostChan &h, int64_t n_w, double out[3]) {
-  double q = h.lo2_old2.phase_at(n_w), f = h.lo2_old2.step_at(n_w), r = h.lo2_old2.sweep();
-  if (h.dop_old2.set_f != 0) {
-    q += h.dop_old2.phase_at(n_w);
-    f += h.dop_old2.step_at(n_w);
-    r += h.dop_old2.sweep();
+// an older transition inside the history (note_retune): its oscillators at the window start, as the history planes
+void eval_older(const HostChan &h, int l, int64_t n_w, double out[3]) {
+  double q = h.lo2_oldx[l].phase_at(n_w), f = h.lo2_oldx[l].step_at(n_w), r = h.lo2_oldx[l].sweep();
+  if (h.dop_oldx[l].set_f != 0) {
+    q += h.dop_oldx[l].phase_at(n_w);
+    f += h.dop_oldx[l].step_at(n_w);
+    r += h.dop_oldx[l].sweep();
   }
   out[0] = q - std::floor(q);
   out[1] = f;
@@ -1309,15 +1314,18 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
         if (ctl_put(b, CTL_FILTER, b->chd.hist_len + c, &len, sizeof len)) return -1;
         h.hist_dev = len;
       }
-      int const len2 = (int)std::min<int64_t>(h.hist_old2, INT32_MAX);
-      if (len2 > 0) {  // (its phase is the window start's: written for every call it lasts)
-        double v[3];
-        eval_old2(h, n_w, v);
-        if (ctl_put(b, CTL_FILTER, b->chd.hist2_osc + 3 * (size_t)c, v, sizeof v)) return -1;
-      }
-      if (h.hist2_dev != len2) {
-        if (ctl_put(b, CTL_FILTER, b->chd.hist2_len + c, &len2, sizeof len2)) return -1;
-        h.hist2_dev = len2;
+      for (int l = 0; l < kq::kOldLevels; l++) {
+        size_t const k = (size_t)c * kq::kOldLevels + l;
+        int const lenx = (int)std::min<int64_t>(h.hist_oldx[l], INT32_MAX);
+        if (lenx > 0) {  // (its phase is the window start's: written for every call it lasts)
+          double v[3];
+          eval_older(h, l, n_w, v);
+          if (ctl_put(b, CTL_FILTER, b->chd.hist2_osc + 3 * k, v, sizeof v)) return -1;
+        }
+        if (h.histx_dev[l] != lenx) {
+          if (ctl_put(b, CTL_FILTER, b->chd.hist2_len + k, &lenx, sizeof lenx)) return -1;
+          h.histx_dev[l] = lenx;
+        }
       }
     }
     nredo = (unsigned)std::min<int64_t>(nblocks, std::max<int64_t>(1, (deepest + g.L - 1) / g.L));
@@ -1562,12 +1570,13 @@ int run_blocks_timed(kq_bank *b, const float2 *window, unsigned nblocks, const u
     HostChan &h = b->chans[c];
     if (!h.retuned) continue;
     h.hist_old -= (int64_t)nblocks * g.L;
-    h.hist_old2 = std::max<int64_t>(0, h.hist_old2 - (int64_t)nblocks * g.L);
+    for (int64_t &n : h.hist_oldx) n = std::max<int64_t>(0, n - (int64_t)nblocks * g.L);
     if (h.hist_old > 0 && h.active) {
       note_patch(b, c);
     } else {
       h.retuned = false;
-      h.hist_old = h.hist_old2 = 0;
+      h.hist_old = 0;
+      for (int64_t &n : h.hist_oldx) n = 0;
     }
   }
   b->ret_host.clear();
@@ -1590,16 +1599,22 @@ bool valid_ch(const kq_bank *b, int ch) { return b && ch >= 0 && (size_t)ch < b-
 // mixed with (radio.c:132-139 mixes sample by sample, osc.c:22-36 changes only what follows), and the next M - 1 of them are
 // the history of the windows to come.  Several settings between two calls are one transition (nothing was mixed with the
 // ones in between).  A setting while an EARLIER transition is still inside the history -- possible only where M - 1 > L: a
-// channel retuned before every block at the reference's default -L 3840 -M 4353 -- makes that one the older of TWO the
-// kernels know per window (hist2_*); a third inside the same M - 1 samples (M - 1 > 2 L) drops the oldest.
+// channel retuned before every block at the reference's default -L 3840 -M 4353 -- moves that one, and any before it, one
+// level down the list the kernels know per window (hist2_*: kOldLevels of them beyond the last); one more than that inside
+// the same M - 1 samples (M - 1 > 5 L and a retune before every block) drops the oldest.
 void note_retune(kq_bank *b, int ch) {
   HostChan &h = b->chans[ch];
   int64_t const hist = (int64_t)b->g.M - 1;
   if (h.retuned && h.hist_old == hist) return;  // set again before anything was mixed with the setting in between
-  if (h.retuned) {  // the transition before this one still has samples in the history: it becomes the older of two
-    h.lo2_old2 = h.lo2_old;
-    h.dop_old2 = h.dop_old;
-    h.hist_old2 = h.hist_old;
+  if (h.retuned) {  // the transition before this one still has samples in the history: it and its elders move one level down
+    for (int l = kq::kOldLevels - 1; l > 0; l--) {
+      h.lo2_oldx[l] = h.lo2_oldx[l - 1];
+      h.dop_oldx[l] = h.dop_oldx[l - 1];
+      h.hist_oldx[l] = h.hist_oldx[l - 1];
+    }
+    h.lo2_oldx[0] = h.lo2_old;
+    h.dop_oldx[0] = h.dop_old;
+    h.hist_oldx[0] = h.hist_old;
   }
   h.lo2_old = h.lo2;
   h.dop_old = h.dop;
@@ -1806,8 +1821,8 @@ kq_bank *kq_bank_create(const kq_bank_config *cfg) {
   rc |= dev_alloc(&b->chd.hangmax, C);
   rc |= dev_alloc(&b->chd.noise_gain, C);
   rc |= dev_alloc(&b->chd.hist_len, C);
-  rc |= dev_alloc(&b->chd.hist2_len, C);
-  rc |= dev_alloc(&b->chd.hist2_osc, 3 * C);
+  rc |= dev_alloc(&b->chd.hist2_len, C * kq::kOldLevels);
+  rc |= dev_alloc(&b->chd.hist2_osc, 3 * C * kq::kOldLevels);
   b->chd.n0lane = nullptr;
   b->chd.n0meta = nullptr;
   b->chd.n0slot = nullptr;
@@ -2408,7 +2423,8 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
   if (lists_remove(b, ch)) return -1;
   h.active = false;
   h.retuned = false;
-  h.hist_old = h.hist_old2 = 0;
+  h.hist_old = 0;
+  for (int64_t &n : h.hist_oldx) n = 0;
   h.patched = false;  // (its entry on the patch list, if any, is skipped: the next call stages the whole bank)
   release_n0slot(b, h.n0slot);
   h.n0slot = -1;
@@ -2419,7 +2435,8 @@ int kq_bank_remove_channel(kq_bank *b, int ch) {
   b->cache_any = b->n_active > 0;
   b->sweep_lists_dirty = true;
   h.r_eff = 0;
-  h.lo2 = h.dop = h.shift = h.lo2_old = h.dop_old = h.lo2_old2 = h.dop_old2 = Osc{};
+  h.lo2 = h.dop = h.shift = h.lo2_old = h.dop_old = Osc{};
+  for (int l = 0; l < kq::kOldLevels; l++) h.lo2_oldx[l] = h.dop_oldx[l] = Osc{};
   h.out_rtp = kq_out_rtp_state{};
   while (!b->chans.empty() && !b->chans.back().active) b->chans.pop_back();  // holes at the end just go
   return 0;

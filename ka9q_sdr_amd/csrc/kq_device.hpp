@@ -66,6 +66,8 @@ struct Geom {
   int pl_n, pl_l;   // PL slave geometry N_dec/32, olen/32 (0: PL measurement off)
 };
 
+constexpr int kOldLevels = 4;  // retune transitions a window may hold beyond the last one (ChanDev::hist2_*)
+
 struct ChanDev {
   // configuration
   int *mode;            // enum kq_demod_type
@@ -96,10 +98,11 @@ struct ChanDev {
   // -L 3840 -M 4353) the second block's window still reaches back that far, and with short calls so does the next call's.
   // Only read where the history planes differ from the current ones: the word of a channel that was not retuned is stale.
   int *hist_len;
-  // A channel retuned again while samples of the oscillator BEFORE the last one are still in the history (M - 1 > L and a
-  // retune before every block): those oldest samples -- the first hist2_len[c] of the call's first window, fewer than
-  // hist_len[c] -- carry hist2_osc[3 c .. 3 c + 2] (phase, step, sweep at the window start).  Read only where hist_len says
-  // there are old samples at all; 0 = none of the older kind.
+  // A channel retuned again while samples of oscillators BEFORE the last one are still in the history (M - 1 > L and a retune
+  // before every block): level l = 0 is the transition before the last, l + 1 the one before that.  The first
+  // hist2_len[kOldLevels c + l] samples of the call's first window -- fewer with every level -- carry
+  // hist2_osc[3 (kOldLevels c + l) ...] (phase, step, sweep at the window start).  Read only where hist_len says there are old
+  // samples at all; a level of 0 samples ends the list.  (kq_ldsfft.hpp: load_older / pick_older)
   int *hist2_len;
   double *hist2_osc;
   // post-detection shift oscillator at output sample 0 of the call

@@ -339,19 +339,19 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     } else {
       // first block after a retune (history still on the old oscillator), or a sweep beyond the table path's reach:
       // closed-form phase per sample
-      // (and of the oscillator before that one, where the channel was retuned twice inside M - 1 samples: ChanDev::hist2_*)
-      int const n_old2 = n_old > 0 ? ch.hist2_len[c] - b * g.L : 0;
-      double const h2p = n_old2 > 0 ? ch.hist2_osc[3 * (size_t)c] : 0.0, h2f = n_old2 > 0 ? ch.hist2_osc[3 * (size_t)c + 1] : 0.0,
-                   h2r = n_old2 > 0 ? ch.hist2_osc[3 * (size_t)c + 2] : 0.0;
+      // (and of the oscillators before that one, where the channel was retuned again inside M - 1 samples: ChanDev::hist2_*)
+      OlderOsc older;
+      load_older(ch, c, b * g.L, n_old > 0, older);
 #pragma unroll
       for (int n1 = 0; n1 < 32; n1++) {
         v2f acc = (v2f){0.f, 0.f};
         for (int j = 0; j < 4; j++) {
           int const i = 16384 * j + 512 * n1 + t;
           double const m = mbase + i;
-          bool const old = i < n_old, old2 = i < n_old2;
-          double const rr = old2 ? h2r : old ? hr : rs;
-          double turns = old2 ? h2p + h2f * m : old ? hp0 + hf0 * m : ph0 + f0 * m;
+          bool const old = i < n_old;
+          double pp = old ? hp0 : ph0, ff = old ? hf0 : f0, rr = old ? hr : rs;
+          pick_older(older, i, pp, ff, rr);
+          double turns = pp + ff * m;
           if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
           turns -= (double)(r4 * (512 * n1 + t)) * (1.0 / 65536.0) + 0.25 * (double)(r4 * j);
           acc = rfft::pk_cmadd(buf_ld2(xr, toff, (unsigned)(32 * j + n1) * (unsigned)(512 * sizeof(float2))), phasor2(turns), acc);
@@ -441,17 +441,17 @@ __global__ __launch_bounds__(kT, 4) void k_filter_full16k(Geom g, ChanDev ch, Pl
     } else if constexpr (!PLAIN) {
       // swept channels, and the first block after a retune (history still on the old oscillator): closed-form phase
       // per sample
-      // (and of the oscillator before that one, where the channel was retuned twice inside M - 1 samples: ChanDev::hist2_*)
-      int const n_old2 = n_old > 0 ? ch.hist2_len[c] - b * g.L : 0;
-      double const h2p = n_old2 > 0 ? ch.hist2_osc[3 * (size_t)c] : 0.0, h2f = n_old2 > 0 ? ch.hist2_osc[3 * (size_t)c + 1] : 0.0,
-                   h2r = n_old2 > 0 ? ch.hist2_osc[3 * (size_t)c + 2] : 0.0;
+      // (and of the oscillators before that one, where the channel was retuned again inside M - 1 samples: ChanDev::hist2_*)
+      OlderOsc older;
+      load_older(ch, c, b * g.L, n_old > 0, older);
 #pragma unroll
       for (int n1 = 0; n1 < 32; n1++) {
         int const i = 512 * n1 + t;
         double const m = mbase + i;
-        bool const old = i < n_old, old2 = i < n_old2;  // mixed before the retune took effect: pre-retune oscillator(s)
-        double const rr = old2 ? h2r : old ? hr : r;
-        double turns = old2 ? h2p + h2f * m : old ? hp0 + hf0 * m : ph0 + f0 * m;
+        bool const old = i < n_old;  // mixed before the retune took effect: pre-retune oscillator(s)
+        double pp = old ? hp0 : ph0, ff = old ? hf0 : f0, rr = old ? hr : r;
+        pick_older(older, i, pp, ff, rr);
+        double turns = pp + ff * m;
         if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
         v[rfft::bitrev5(n1)] = pk_cmul(buf_ld2(xr, toff, (unsigned)n1 * (unsigned)(512 * sizeof(float2))), phasor2(turns));
       }

@@ -381,10 +381,9 @@ __global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__res
   //  that lie beyond its start, if the history planes differ from the current ones at all)
   bool const same_osc = hr == r && hp0 == ph0 && hf0 == f0;
   int const n_old = same_osc ? 0 : ch.hist_len[c] - b * g.L;
-  // (... and of the oscillator before that one, where a channel was retuned twice inside M - 1 samples: hist2_*)
-  int const n_old2 = n_old > 0 ? ch.hist2_len[c] - b * g.L : 0;
-  double const h2p = n_old2 > 0 ? ch.hist2_osc[3 * (size_t)c] : 0.0, h2f = n_old2 > 0 ? ch.hist2_osc[3 * (size_t)c + 1] : 0.0,
-               h2r = n_old2 > 0 ? ch.hist2_osc[3 * (size_t)c + 2] : 0.0;
+  // (... and of the oscillators before that one, where a channel was retuned again inside M - 1 samples: hist2_*)
+  OlderOsc older;
+  load_older(ch, c, b * g.L, n_old > 0, older);
   bool const one_osc = r == 0.0 && n_old <= 0;
   if (one_osc) {
     float2 const step = phasor_turns(f0 * (double)blockDim.x);
@@ -397,9 +396,10 @@ __global__ void k_filter_full(Geom g, ChanDev ch, Planes pl, const float2 *__res
   } else {
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
       double const m = mbase + i;
-      bool const old = i < n_old, old2 = i < n_old2;  // mixed before the retune took effect: pre-retune oscillator(s)
-      double const rr = old2 ? h2r : old ? hr : r;
-      double turns = old2 ? h2p + h2f * m : old ? hp0 + hf0 * m : ph0 + f0 * m;
+      bool const old = i < n_old;  // mixed before the retune took effect: pre-retune oscillator(s)
+      double pp = old ? hp0 : ph0, ff = old ? hf0 : f0, rr = old ? hr : r;
+      pick_older(older, i, pp, ff, rr);
+      double turns = pp + ff * m;
       if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
       float2 const lo = phasor_turns(turns);
       lds[fft_pos((unsigned)i, g.dN)] = cmul(x[i], lo);
@@ -495,17 +495,17 @@ __global__ void k_filter_split(Geom g, ChanDev ch, Planes pl, const float2 *__re
   const float2 *x = window + (size_t)b * g.L;
   double const mbase = (double)b * g.L;
   int const n_old = (hr == r && hp0 == ph0 && hf0 == f0) ? 0 : ch.hist_len[c] - b * g.L;  // as in k_filter_full
-  int const n_old2 = n_old > 0 ? ch.hist2_len[c] - b * g.L : 0;
-  double const h2p = n_old2 > 0 ? ch.hist2_osc[3 * (size_t)c] : 0.0, h2f = n_old2 > 0 ? ch.hist2_osc[3 * (size_t)c + 1] : 0.0,
-               h2r = n_old2 > 0 ? ch.hist2_osc[3 * (size_t)c + 2] : 0.0;
+  OlderOsc older;
+  load_older(ch, c, b * g.L, n_old > 0, older);
   for (int s = 0; s < S; s++) {
     __syncthreads();
     for (int i = threadIdx.x; i < N1; i += blockDim.x) {
       int const n = S * i + s;
       double const m = mbase + n;
-      bool const old = n < n_old, old2 = n < n_old2;
-      double const rr = old2 ? h2r : old ? hr : r;
-      double turns = old2 ? h2p + h2f * m : old ? hp0 + hf0 * m : ph0 + f0 * m;
+      bool const old = n < n_old;
+      double pp = old ? hp0 : ph0, ff = old ? hf0 : f0, rr = old ? hr : r;
+      pick_older(older, n, pp, ff, rr);
+      double turns = pp + ff * m;
       if (rr != 0.0) turns += rr * (0.5 * m * (m - 1.0));
       lds[fft_pos((unsigned)i, d1)] = cmul(x[n], phasor_turns(turns));
     }

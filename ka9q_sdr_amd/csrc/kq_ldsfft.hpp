@@ -147,6 +147,34 @@ __device__ inline void lds_fft(float2 *s, int log2n, const float2 *__restrict__ 
   }
 }
 
+// The oscillators of retune transitions before the last one that still have samples in a window (ChanDev::hist2_*): `shift`
+// = b L takes the counts from the call's first window to block b's; `any` = the window has old samples at all.
+struct OlderOsc {
+  int n[kOldLevels];
+  double p[kOldLevels], f[kOldLevels], r[kOldLevels];
+};
+__device__ __forceinline__ void load_older(const ChanDev &ch, int c, int shift, bool any, OlderOsc &o) {
+#pragma unroll
+  for (int l = 0; l < kOldLevels; l++) {
+    size_t const k = (size_t)c * kOldLevels + l;
+    o.n[l] = any ? ch.hist2_len[k] - shift : 0;
+    bool const on = o.n[l] > 0;
+    o.p[l] = on ? ch.hist2_osc[3 * k] : 0.0;
+    o.f[l] = on ? ch.hist2_osc[3 * k + 1] : 0.0;
+    o.r[l] = on ? ch.hist2_osc[3 * k + 2] : 0.0;
+  }
+}
+// sample i of the window: the oldest transition it lies before decides (the counts fall with the level)
+__device__ __forceinline__ void pick_older(const OlderOsc &o, int i, double &ph, double &ff, double &rr) {
+#pragma unroll
+  for (int l = 0; l < kOldLevels; l++)
+    if (i < o.n[l]) {
+      ph = o.p[l];
+      ff = o.f[l];
+      rr = o.r[l];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Sizes with a factor 3, 5 or 7 (round 6: FFTW plans whatever N = L + M - 1 and N / decimate come out, filter.c:78,132, and
 // decimate = samprate / 48000 is 5 at 240 kHz, radio_status.c:266).  n = f[0] f[1] ... f[nf-1], radices 2, 3, 4, 5, 7, applied

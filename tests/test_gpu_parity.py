@@ -1363,8 +1363,9 @@ def test_retune_mid_stream_is_sample_exact(gpu, name, mode, per):
 @pytest.mark.parametrize("seed", list(range(48)) + _EXTRA)
 def test_retunes_at_geometries_drawn_at_random(gpu, seed):
     """The retune rule at geometries nobody chose: N/decimate, decimate and the impulse response drawn as in
-    test_geometries_drawn_at_random but up to 0.7 of N/decimate (M - 1 up to 2.3 L: old samples in up to three blocks), one
-    to three blocks per call, a second-LO retune and a Doppler sweep switched on and off again at drawn calls.  Filter output
+    test_geometries_drawn_at_random but up to 0.7 of N/decimate (M - 1 up to 2.3 L: old samples in up to three blocks; every
+    third seed up to 0.82: 4.5 L), one to three blocks per call, a second-LO retune and a Doppler sweep switched on and off again
+    at drawn calls, and on every third seed a tuning knob turned on a third channel: a step before each of up to five calls in a row.  Filter output
     of every block from the third on (the first two are the leading edge of a long impulse response) against the oracle."""
     import kq_oracle as ko
     from common import oracle_cfg
@@ -1375,7 +1376,7 @@ def test_retunes_at_geometries_drawn_at_random(gpu, seed):
         N = nd * D
         if N <= (8192 if D == 1 else 16384) and N >= 512:
             break
-    k = int(rng.integers(nd // 4, int(nd * 0.7) + 1))
+    k = int(rng.integers(nd // 4, int(nd * (0.7 if seed % 3 else 0.82)) + 1))      # (every third seed: M - 1 up to 4.5 L)
     M, L, fs = k * D + 1, (nd - k) * D, 48000 * D
     ds = 48000.0
     lo = [-wl.emitter_freq(e, fs) for e in (24, 27, 26)]
@@ -1391,7 +1392,12 @@ def test_retunes_at_geometries_drawn_at_random(gpu, seed):
         bank.add_channel(bank_cfg(p))
     first = int(rng.integers(ncalls // 3, ncalls // 2 + 1))
     second = int(rng.integers(first + 1, ncalls))
+    knob = set(range(first + 1, min(second, first + 6))) if seed % 3 == 0 else set()    # a tuning knob turned: a step before every call
     for call in range(ncalls):
+        if call in knob:
+            hz = lo[2] + 12.5 * (call - first)
+            bank.set_second_lo(2, hz)
+            chans[2].set_lo2(hz)
         if call == first:
             bank.set_second_lo(0, lo[0] + 777.7)
             chans[0].set_lo2(lo[0] + 777.7)

@@ -148,31 +148,31 @@ __device__ inline void lds_fft(float2 *s, int log2n, const float2 *__restrict__ 
 }
 
 // The oscillators of retune transitions before the last one that still have samples in a window (ChanDev::hist2_*): `shift`
-// = b L takes the counts from the call's first window to block b's; `any` = the window has old samples at all.
+// = b L takes the counts from the call's first window to block b's; `any` = the window has old samples at all.  Only the first
+// level's count is held in a register: the few samples that lie before it fetch their oscillator where they need it (a list
+// held in registers -- 28 of them -- put the per-sample variants of k_filter_full16k into scratch).
 struct OlderOsc {
-  int n[kOldLevels];
-  double p[kOldLevels], f[kOldLevels], r[kOldLevels];
+  const int *len;      // the channel's kOldLevels counts
+  const double *osc;   // ... and (phase, step, sweep) triples
+  int shift, n0;       // n0: samples of this window that lie before the transition before the last (0: none of any level)
 };
 __device__ __forceinline__ void load_older(const ChanDev &ch, int c, int shift, bool any, OlderOsc &o) {
-#pragma unroll
-  for (int l = 0; l < kOldLevels; l++) {
-    size_t const k = (size_t)c * kOldLevels + l;
-    o.n[l] = any ? ch.hist2_len[k] - shift : 0;
-    bool const on = o.n[l] > 0;
-    o.p[l] = on ? ch.hist2_osc[3 * k] : 0.0;
-    o.f[l] = on ? ch.hist2_osc[3 * k + 1] : 0.0;
-    o.r[l] = on ? ch.hist2_osc[3 * k + 2] : 0.0;
-  }
+  size_t const k = (size_t)c * kOldLevels;
+  o.len = ch.hist2_len + k;
+  o.osc = ch.hist2_osc + 3 * k;
+  o.shift = shift;
+  o.n0 = any ? o.len[0] - shift : 0;
 }
 // sample i of the window: the oldest transition it lies before decides (the counts fall with the level)
 __device__ __forceinline__ void pick_older(const OlderOsc &o, int i, double &ph, double &ff, double &rr) {
-#pragma unroll
-  for (int l = 0; l < kOldLevels; l++)
-    if (i < o.n[l]) {
-      ph = o.p[l];
-      ff = o.f[l];
-      rr = o.r[l];
+  if (i < o.n0) {
+    for (int l = 0; l < kOldLevels; l++) {
+      if (i >= o.len[l] - o.shift) break;
+      ph = o.osc[3 * l];
+      ff = o.osc[3 * l + 1];
+      rr = o.osc[3 * l + 2];
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

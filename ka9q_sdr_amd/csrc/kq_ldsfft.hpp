@@ -148,13 +148,16 @@ __device__ inline void lds_fft(float2 *s, int log2n, const float2 *__restrict__ 
 }
 
 // The oscillators of retune transitions before the last one that still have samples in a window (ChanDev::hist2_*): `shift`
-// = b L takes the counts from the call's first window to block b's; `any` = the window has old samples at all.  Only the first
-// level's count is held in a register: the few samples that lie before it fetch their oscillator where they need it (a list
-// held in registers -- 28 of them -- put the per-sample variants of k_filter_full16k into scratch).
+// = b L takes the counts from the call's first window to block b's; `any` = the window has old samples at all.  The first
+// level -- a second transition in a window, the usual case -- is held in registers; the few samples that lie before a third
+// one fetch their oscillator where they need it (the whole list in registers, 28 of them, put the per-sample variants of
+// k_filter_full16k 52 bytes into scratch; this form leaves them without, as they were).
 struct OlderOsc {
   const int *len;      // the channel's kOldLevels counts
   const double *osc;   // ... and (phase, step, sweep) triples
-  int shift, n0;       // n0: samples of this window that lie before the transition before the last (0: none of any level)
+  int shift;
+  int n0, n1;          // samples of this window before the transition before the last / before the one before that
+  double p0, f0, r0;   // level 0's oscillator (the usual case of a second transition: in registers)
 };
 __device__ __forceinline__ void load_older(const ChanDev &ch, int c, int shift, bool any, OlderOsc &o) {
   size_t const k = (size_t)c * kOldLevels;
@@ -162,11 +165,19 @@ __device__ __forceinline__ void load_older(const ChanDev &ch, int c, int shift, 
   o.osc = ch.hist2_osc + 3 * k;
   o.shift = shift;
   o.n0 = any ? o.len[0] - shift : 0;
+  o.n1 = o.n0 > 0 ? o.len[1] - shift : 0;
+  o.p0 = o.n0 > 0 ? o.osc[0] : 0.0;
+  o.f0 = o.n0 > 0 ? o.osc[1] : 0.0;
+  o.r0 = o.n0 > 0 ? o.osc[2] : 0.0;
 }
 // sample i of the window: the oldest transition it lies before decides (the counts fall with the level)
 __device__ __forceinline__ void pick_older(const OlderOsc &o, int i, double &ph, double &ff, double &rr) {
-  if (i < o.n0) {
-    for (int l = 0; l < kOldLevels; l++) {
+  bool const l0 = i < o.n0;
+  ph = l0 ? o.p0 : ph;
+  ff = l0 ? o.f0 : ff;
+  rr = l0 ? o.r0 : rr;
+  if (i < o.n1) {
+    for (int l = 1; l < kOldLevels; l++) {
       if (i >= o.len[l] - o.shift) break;
       ph = o.osc[3 * l];
       ff = o.osc[3 * l + 1];

@@ -468,7 +468,13 @@ void launch_filter_full(hipStream_t s, const Geom &g, const ChanDev &ch, const P
                         const int *chan_list) {
   size_t const lds_bytes = (size_t)g.N * sizeof(float2) * (g.Ndec == g.N ? 2 : 1);
   ensure_dynamic_lds((const void *)k_filter_full, lds_bytes);
-  int const threads = g.N >= 4096 ? 1024 : 256;
+  static int const forced = getenv("KQ_FULL_THREADS") ? atoi(getenv("KQ_FULL_THREADS")) : 0;  // A/B switch (tools/bench_mixed.py)
+  // By how many workgroups a CU's 160 KiB of LDS hold: 256 threads where there are four or more of them, 512 where two or
+  // three, 1024 where one workgroup has the CU to itself (tools/bench_mixed.py and a sweep over N with KQ_FULL_THREADS, filter
+  // kernel ms for 1024 channels x 8 blocks at 1024 / 512 / 256 threads: N = 2048 0.33 / 0.16 / 0.13, 4096 0.53 / 0.29 / 0.28,
+  // 6144 0.94 / 0.51 / 0.66, 8192 0.90 / 0.64 / 0.74, 9600 1.20 / 0.87 / 1.32, 10240 1.37 / 1.64 / 2.61, 15360 1.74 / 2.10 / 3.44;
+  // until round 6 it was 1024 from N = 4096 on)
+  int const threads = forced > 0 ? forced : lds_bytes <= 40 * 1024 ? 256 : 2 * lds_bytes + 512 <= 160 * 1024 ? 512 : 1024;
   hipLaunchKernelGGL(k_filter_full, dim3(nchan, nblocks), dim3(threads), lds_bytes, s, g, ch, pl, window, tw, compute_n0,
                      spec_dump, spec_ch, chan_list);
 }

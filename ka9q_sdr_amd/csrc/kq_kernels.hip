@@ -875,12 +875,12 @@ __global__ void __launch_bounds__(1024) k_demod_fm(Geom g, ChanDev ch, Planes pl
 // writes the AM-1 samples that will precede the next call into `hist_out` (a different buffer: every block-0
 // workgroup of this launch is still reading hist_in).
 // Dynamic LDS carve:  F float2[AN] | AIN float[AN] | PLB float2[pl_n] | TWL float2[AN/2]
-__global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ tw,
+__global__ void __launch_bounds__(256) k_fm_audio(Geom g, ChanDev ch, Planes pl, const float2 *__restrict__ tw,
                                                  const float *__restrict__ fmout, const float *__restrict__ hist_in,
                                                  float *__restrict__ hist_out, const int *__restrict__ list, int nblocks) {
   extern __shared__ __attribute__((aligned(16))) float2 lds[];
   int const c = list[blockIdx.x], b = blockIdx.y;
-  int const lane = threadIdx.x;
+  int const lane = threadIdx.x, nthr = blockDim.x;  // 64 ... 256 threads (launch_demods): every loop strides by the workgroup
   int const AN = g.Ndec, AM = g.Mdec, AL = g.olen;
   float2 *F = lds;
   float *AIN = reinterpret_cast<float *>(F + AN);
@@ -898,16 +898,16 @@ __global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, 
   auto sample = [&](long long j) { return j >= 0 ? stream[j] : hin[(AM - 1) + j]; };
   if (b == nblocks - 1) {
     float *ho = hist_out + (size_t)c * (AM - 1);
-    for (int i = lane; i < AM - 1; i += 64) ho[i] = sample((long long)nblocks * AL - (AM - 1) + i);
+    for (int i = lane; i < AM - 1; i += nthr) ho[i] = sample((long long)nblocks * AL - (AM - 1) + i);
   }
   float *aud = pl.audio + ((size_t)c * g.max_blocks + b) * (2 * (size_t)AL);
   if (flat && !pl_on) {
-    for (int n = lane; n < AL; n += 64) aud[n] = stream[(size_t)b * AL + n];
+    for (int n = lane; n < AL; n += nthr) aud[n] = stream[(size_t)b * AL + n];
     return;
   }
   if (!mixed)
-    for (int k = lane; k < AN / 2; k += 64) TWL[k] = tw[(size_t)k << (g.tw_log2 - g.log2Ndec)];
-  for (int i = lane; i < AN; i += 64) {
+    for (int k = lane; k < AN / 2; k += nthr) TWL[k] = tw[(size_t)k << (g.tw_log2 - g.log2Ndec)];
+  for (int i = lane; i < AN; i += nthr) {
     float const v = sample((long long)b * AL - (AM - 1) + i);
     AIN[i] = v;
     F[fft_pos((unsigned)i, g.dNdec)] = make_float2(v, 0.f);
@@ -922,7 +922,7 @@ __global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, 
     int const PN = g.pl_n;
     int log2pl = 0;
     while ((1 << log2pl) < PN) log2pl++;
-    for (int k = lane; k <= PN / 2; k += 64) {
+    for (int k = lane; k <= PN / 2; k += nthr) {
       float2 gk = cmul(ch.plresp[k], F[k]);
       if (k == 0 || k == PN / 2) {
         gk.y = 0.f;
@@ -936,18 +936,18 @@ __global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, 
     else
       lds_fft<+1>(PLB, log2pl, TWL, g.log2Ndec);
     float *po = pl.plout + ((size_t)c * g.max_blocks + b) * g.pl_l;
-    for (int n = lane; n < g.pl_l; n += 64) po[n] = PLB[PN - g.pl_l + n].x;  // filter.c:140
+    for (int n = lane; n < g.pl_l; n += nthr) po[n] = PLB[PN - g.pl_l + n].x;  // filter.c:140
     __syncthreads();
   }
   if (flat) {
-    for (int n = lane; n < AL; n += 64) aud[n] = AIN[AM - 1 + n];
+    for (int n = lane; n < AL; n += nthr) aud[n] = AIN[AM - 1 + n];
     return;
   }
   // multiply DC..Nyquist (filter.c:206-208) and Hermitian-extend for the c2r transform, which ignores the
   // imaginary parts of DC and Nyquist.  Lane k touches only F[k] and F[AN-k].
   const float2 *HA = ch.aresp + (size_t)c * (AN / 2 + 1);
   if (mixed) {
-    for (int k = lane; k <= AN / 2; k += 64) {
+    for (int k = lane; k <= AN / 2; k += nthr) {
       float2 const gk = cmul(HA[k], F[k]);
       if (k == 0 || k == AN / 2) {
         F2[fft_pos((unsigned)k, g.dNdec)] = make_float2(gk.x, 0.f);
@@ -958,10 +958,10 @@ __global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, 
     }
     lds_fft_mixed<+1>(F2, g.dNdec);
     float const gain = ch.fm_gain[c];
-    for (int n = lane; n < AL; n += 64) aud[n] = F2[AN - AL + n].x * gain;  // fm.c:169-170
+    for (int n = lane; n < AL; n += nthr) aud[n] = F2[AN - AL + n].x * gain;  // fm.c:169-170
     return;
   }
-  for (int k = lane; k <= AN / 2; k += 64) {
+  for (int k = lane; k <= AN / 2; k += nthr) {
     float2 const gk = cmul(HA[k], F[k]);
     if (k == 0 || k == AN / 2) {
       F[k] = make_float2(gk.x, 0.f);
@@ -971,7 +971,7 @@ __global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, 
     }
   }
   __syncthreads();
-  for (int i = lane; i < AN; i += 64) {  // bit-reverse in place, then backward transform
+  for (int i = lane; i < AN; i += nthr) {  // bit-reverse in place, then backward transform
     unsigned const r = bitrev((unsigned)i, g.log2Ndec);
     if (r > (unsigned)i) {
       float2 const t = F[i];
@@ -981,7 +981,7 @@ __global__ void __launch_bounds__(64) k_fm_audio(Geom g, ChanDev ch, Planes pl, 
   }
   lds_fft<+1>(F, g.log2Ndec, TWL, g.log2Ndec);
   float const gain = ch.fm_gain[c];
-  for (int n = lane; n < AL; n += 64) aud[n] = F[AN - AL + n].x * gain;  // fm.c:169-170
+  for (int n = lane; n < AL; n += nthr) aud[n] = F[AN - AL + n].x * gain;  // fm.c:169-170
 }
 
 // The same de-emphasis overlap-save for AN = 256 (AL = 128, AM = 129: BASELINE cfg 2's geometry) with the PL measurement off:
@@ -1757,8 +1757,14 @@ void launch_demods(hipStream_t s, const Geom &g, const ChanDev &ch, const Planes
       hipLaunchKernelGGL(k_fm_audio256, dim3(n_fm, (nblocks + 1) / 2), dim3(64), 0, s, g, ch, pl, fmout, fm_hist_in, fm_hist_out,
                          list_fm, nblocks);
     else
-      hipLaunchKernelGGL(k_fm_audio, dim3(n_fm, nblocks), dim3(64), lds_b, s, g, ch, pl, tw, fmout, fm_hist_in, fm_hist_out,
+    {
+      // one wave per block up to a 512-point audio master; four from there on (the transform's passes are loops over the
+      // workgroup with a barrier each: tools/bench_mixed.py, KQ_FM_AUDIO_THREADS)
+      static int const forced = getenv("KQ_FM_AUDIO_THREADS") ? atoi(getenv("KQ_FM_AUDIO_THREADS")) : 0;
+      int const thr = forced > 0 ? forced : g.Ndec >= 1024 ? 256 : 64;
+      hipLaunchKernelGGL(k_fm_audio, dim3(n_fm, nblocks), dim3(thr), lds_b, s, g, ch, pl, tw, fmout, fm_hist_in, fm_hist_out,
                          list_fm, nblocks);
+    }
   }
   if (n_am > 0)
     hipLaunchKernelGGL(k_demod_am, dim3((n_am + 63) / 64), dim3(64), 0, s, g, ch, pl, list_am, n_am, nblocks, compute_n0);
